@@ -1,0 +1,409 @@
+"""fake_bullet.py -- TEST INFRASTRUCTURE ONLY (used by tests/golden/gen_goldens.py, run only in the
+build container where /root/reference exists).
+
+A numpy/float64 stand-in for the slice of the PyBullet API that PyFlyt's hot path calls
+("lower boundary"): enough to let the *reference's own* `Aviary`, `QuadX`,
+`Fixedwing` and gym env classes run unmodified, so that golden trajectories can be captured with
+the reference's real PyFlyt-side arithmetic.
+
+It is an independent second restatement of Bullet's free-multibody tick [BULLET-FROM-MEMORY]:
+where oracle/uav_oracle.c integrates the composite body about its centre of mass, this file
+follows Bullet's own structure -- per-link spatial bias forces and inertias accumulated at the
+base origin and a 6x6 solve (btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof
+with zero-DoF children). Agreement of the two to ~1e-12 is checked in tests/test_oracle_golden.py.
+
+This is NOT PyBullet and pins nothing about real Bullet; "parity unpinned" at that boundary.
+"""
+from __future__ import annotations
+
+import math
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+
+def _vec(s, n=3):
+    v = [float(x) for x in s.split()]
+    assert len(v) == n
+    return np.array(v)
+
+
+def quat_from_euler(rpy):
+    phi, the, psi = rpy[0] / 2.0, rpy[1] / 2.0, rpy[2] / 2.0
+    q = np.array(
+        [
+            math.sin(phi) * math.cos(the) * math.cos(psi) - math.cos(phi) * math.sin(the) * math.sin(psi),
+            math.cos(phi) * math.sin(the) * math.cos(psi) + math.sin(phi) * math.cos(the) * math.sin(psi),
+            math.cos(phi) * math.cos(the) * math.sin(psi) - math.sin(phi) * math.sin(the) * math.cos(psi),
+            math.cos(phi) * math.cos(the) * math.cos(psi) + math.sin(phi) * math.sin(the) * math.sin(psi),
+        ]
+    )
+    return q / math.sqrt(float(q @ q))
+
+
+def euler_from_quat(q):
+    sqx, sqy, sqz, squ = q[0] * q[0], q[1] * q[1], q[2] * q[2], q[3] * q[3]
+    sarg = -2.0 * (q[0] * q[2] - q[3] * q[1]) / (sqx + sqy + sqz + squ)
+    if sarg <= -0.99999:
+        return (0.0, -0.5 * math.pi, 2.0 * math.atan2(q[0], -q[1]))
+    if sarg >= 0.99999:
+        return (0.0, 0.5 * math.pi, 2.0 * math.atan2(-q[0], q[1]))
+    return (
+        math.atan2(2.0 * (q[1] * q[2] + q[3] * q[0]), squ - sqx - sqy + sqz),
+        math.asin(sarg),
+        math.atan2(2.0 * (q[0] * q[1] + q[3] * q[2]), squ + sqx - sqy - sqz),
+    )
+
+
+def matrix_from_quat(q):
+    d = float(np.dot(q, q))
+    s = 2.0 / d
+    xs, ys, zs = q[0] * s, q[1] * s, q[2] * s
+    wx, wy, wz = q[3] * xs, q[3] * ys, q[3] * zs
+    xx, xy, xz = q[0] * xs, q[0] * ys, q[0] * zs
+    yy, yz, zz = q[1] * ys, q[1] * zs, q[2] * zs
+    return np.array(
+        [
+            [1.0 - (yy + zz), xy - wz, xz + wy],
+            [xy + wz, 1.0 - (xx + zz), yz - wx],
+            [xz - wy, yz + wx, 1.0 - (xx + yy)],
+        ]
+    )
+
+
+def _skew(r):
+    return np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]], dtype=np.float64)
+
+
+class _Link:
+    def __init__(self, name):
+        self.name = name
+        self.mass = 0.0
+        self.inertia = np.zeros((3, 3))
+        self.inertial_origin = np.zeros(3)
+        self.joint_origin = np.zeros(3)
+        self.boxes = []  # (centre in link frame, half extents)
+
+
+class _Body:
+    """A free (or fixed) base with rigidly attached child links; all frames axis-aligned."""
+
+    def __init__(self, links, fixed, pos, quat, scale=1.0):
+        self.fixed = fixed
+        self.links = links  # links[0] = base, children in joint order (link index = i-1)
+        self.p = np.array(pos, dtype=np.float64)
+        self.q = np.array(quat, dtype=np.float64)
+        self.v = np.zeros(3)
+        self.w = np.zeros(3)
+        self.scale = scale
+        # COM offset of each link in the base frame
+        self.r = [l.joint_origin + l.inertial_origin for l in links]
+        self.force = [np.zeros(3) for _ in links]  # world-frame, at the link COM
+        self.torque = [np.zeros(3) for _ in links]
+        self.use_gyro_term = True
+        self.max_coord_vel = 100.0
+
+    def clear_forces(self):
+        for f in self.force:
+            f[:] = 0.0
+        for t in self.torque:
+            t[:] = 0.0
+
+    def world_boxes(self):
+        R = matrix_from_quat(self.q)
+        out = []
+        for l in self.links:
+            for c, h in l.boxes:
+                centre = self.p + R @ ((l.joint_origin + c) * self.scale)
+                out.append((centre, R, h * self.scale))
+        return out
+
+
+def _box_box_overlap(ca, Ra, ha, cb, hb):
+    """btBoxBoxDetector / dBoxBox2 separating-axis verdict; box b is world-axis-aligned."""
+    t = ca - cb
+    Q = np.abs(Ra)
+    for i in range(3):
+        if abs(t[i]) - (hb[i] + Q[i] @ ha) > 0.0:
+            return False
+    for j in range(3):
+        if abs(t @ Ra[:, j]) - (ha[j] + Q[:, j] @ hb) > 0.0:
+            return False
+    Q = Q + 1e-5
+    for i in range(3):
+        i1, i2 = (i + 1) % 3, (i + 2) % 3
+        for j in range(3):
+            j1, j2 = (j + 1) % 3, (j + 2) % 3
+            expr1 = t[i2] * Ra[i1, j] - t[i1] * Ra[i2, j]
+            rad = hb[i1] * Q[i2, j] + hb[i2] * Q[i1, j] + ha[j1] * Q[i, j2] + ha[j2] * Q[i, j1]
+            if abs(expr1) - rad > 2.220446049250313e-16:
+                return False
+    return True
+
+
+def parse_urdf(path):
+    root = ET.parse(path).getroot()
+    links = {}
+    order = []
+    for le in root.findall("link"):
+        l = _Link(le.get("name"))
+        ine = le.find("inertial")
+        if ine is not None:
+            o = ine.find("origin")
+            if o is not None:
+                assert np.allclose(_vec(o.get("rpy", "0 0 0")), 0.0)
+                l.inertial_origin = _vec(o.get("xyz", "0 0 0"))
+            l.mass = float(ine.find("mass").get("value"))
+            it = ine.find("inertia")
+            ixx, iyy, izz = (float(it.get(k)) for k in ("ixx", "iyy", "izz"))
+            ixy, ixz, iyz = (float(it.get(k)) for k in ("ixy", "ixz", "iyz"))
+            l.inertia = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+        for ce in le.findall("collision"):
+            o = ce.find("origin")
+            c = np.zeros(3)
+            if o is not None:
+                assert np.allclose(_vec(o.get("rpy", "0 0 0")), 0.0)
+                c = _vec(o.get("xyz", "0 0 0"))
+            box = ce.find("geometry").find("box")
+            if box is not None:
+                l.boxes.append((c, 0.5 * _vec(box.get("size"))))
+        links[l.name] = l
+        order.append(l.name)
+    children = set()
+    joint_children = []
+    for je in root.findall("joint"):
+        assert je.get("type") == "fixed", "only fixed joints are on the hot path"
+        parent = je.find("parent").get("link")
+        child = je.find("child").get("link")
+        o = je.find("origin")
+        if o is not None:
+            assert np.allclose(_vec(o.get("rpy", "0 0 0")), 0.0)
+            links[child].joint_origin = _vec(o.get("xyz", "0 0 0"))
+        children.add(child)
+        joint_children.append((parent, child))
+    base = [n for n in order if n not in children]
+    assert len(base) == 1
+    for parent, _ in joint_children:
+        assert parent == base[0], "only one level of fixed children is supported"
+    return [links[base[0]]] + [links[c] for _, c in joint_children]
+
+
+class BulletClient:
+    """Duck-type of pybullet_utils.bullet_client.BulletClient for the hot-path method set."""
+
+    DIRECT = 2
+    GUI = 1
+    LINK_FRAME = 1
+    WORLD_FRAME = 2
+    URDF_USE_INERTIA_FROM_FILE = 2
+
+    def __init__(self, connection_mode=None):
+        self._bodies = {}
+        self._next_id = 0
+        self._gravity = np.zeros(3)
+        self._dt = 1.0 / 240.0
+        self._contacts = []
+        self._search = ""
+        self.use_gyro_term = True
+
+    # ------------------------------------------------------------ no-ops
+    def setAdditionalSearchPath(self, path):
+        self._search = path
+
+    def addUserDebugText(self, **kwargs):
+        return 0
+
+    def resetDebugVisualizerCamera(self, **kwargs):
+        pass
+
+    def disconnect(self):
+        pass
+
+    def changeDynamics(self, body, link, **kwargs):
+        # PyFlyt only zeroes the artificial damping (base_drone.py:301-304); the tick below has none
+        assert set(kwargs) <= {"linearDamping", "angularDamping"}
+        assert all(v == 0.0 for v in kwargs.values())
+
+    # ------------------------------------------------------------ world
+    def resetSimulation(self):
+        self._bodies = {}
+        self._next_id = 0
+        self._contacts = []
+
+    def setGravity(self, x, y, z):
+        self._gravity = np.array([x, y, z], dtype=np.float64)
+
+    def loadURDF(self, fileName, basePosition=None, baseOrientation=None, useFixedBase=False,
+                 globalScaling=1.0, flags=0):
+        pos = np.zeros(3) if basePosition is None else np.array(basePosition, dtype=np.float64)
+        quat = np.array([0, 0, 0, 1.0]) if baseOrientation is None else np.array(baseOrientation, dtype=np.float64)
+        if os.path.basename(fileName) == "plane.urdf" and not os.path.isabs(fileName):
+            # pybullet_data/plane.urdf [BULLET-FROM-MEMORY]: collision box 30x30x10 at z=-5
+            l = _Link("planeLink")
+            l.boxes.append((np.array([0.0, 0.0, -5.0]), np.array([15.0, 15.0, 5.0])))
+            body = _Body([l], True, pos, quat, globalScaling)
+        else:
+            body = _Body(parse_urdf(fileName), bool(useFixedBase), pos, quat, globalScaling)
+            assert flags & self.URDF_USE_INERTIA_FROM_FILE
+        body.use_gyro_term = self.use_gyro_term
+        bid = self._next_id
+        self._next_id += 1
+        self._bodies[bid] = body
+        return bid
+
+    def getNumBodies(self):
+        return len(self._bodies)
+
+    def getBodyUniqueId(self, i):
+        return sorted(self._bodies)[i]
+
+    def getNumJoints(self, body):
+        return len(self._bodies[body].links) - 1
+
+    # ------------------------------------------------------------ state access
+    def resetBasePositionAndOrientation(self, body, pos, orn):
+        b = self._bodies[body]
+        b.p = np.array(pos, dtype=np.float64)
+        b.q = np.array(orn, dtype=np.float64)
+        b.v = np.zeros(3)
+        b.w = np.zeros(3)
+
+    def resetBaseVelocity(self, body, linearVelocity=None, angularVelocity=None):
+        b = self._bodies[body]
+        if linearVelocity is not None:
+            b.v = np.array(linearVelocity, dtype=np.float64)
+        if angularVelocity is not None:
+            b.w = np.array(angularVelocity, dtype=np.float64)
+
+    def getBasePositionAndOrientation(self, body):
+        b = self._bodies[body]
+        return tuple(b.p), tuple(b.q)
+
+    def getBaseVelocity(self, body):
+        b = self._bodies[body]
+        return tuple(b.v), tuple(b.w)
+
+    @staticmethod
+    def getMatrixFromQuaternion(q):
+        return tuple(matrix_from_quat(np.asarray(q, dtype=np.float64)).reshape(-1))
+
+    @staticmethod
+    def getEulerFromQuaternion(q):
+        return euler_from_quat(np.asarray(q, dtype=np.float64))
+
+    @staticmethod
+    def getQuaternionFromEuler(rpy):
+        return tuple(quat_from_euler(np.asarray(rpy, dtype=np.float64)))
+
+    def getLinkStates(self, body, ids, computeLinkVelocity=False):
+        b = self._bodies[body]
+        R = matrix_from_quat(b.q)
+        out = []
+        for i in ids:
+            r = R @ b.r[int(i) + 1]
+            pos = b.p + r
+            vel = b.v + np.cross(b.w, r)
+            out.append((tuple(pos), tuple(b.q), (0, 0, 0), (0, 0, 0, 1), tuple(pos), tuple(b.q), tuple(vel), tuple(b.w)))
+        return tuple(out)
+
+    # ------------------------------------------------------------ forces
+    def applyExternalForce(self, body, link, force, pos, frame):
+        b = self._bodies[body]
+        assert frame == self.LINK_FRAME and np.allclose(pos, 0.0)
+        R = matrix_from_quat(b.q)
+        b.force[int(link) + 1] += R @ np.asarray(force, dtype=np.float64)
+
+    def applyExternalTorque(self, body, link, torque, frame):
+        b = self._bodies[body]
+        assert frame == self.LINK_FRAME
+        R = matrix_from_quat(b.q)
+        b.torque[int(link) + 1] += R @ np.asarray(torque, dtype=np.float64)
+
+    def getContactPoints(self, *args, **kwargs):
+        return list(self._contacts)
+
+    # ------------------------------------------------------------ the tick
+    def stepSimulation(self):
+        dt = self._dt
+        # 1) collision detection at the pre-integration pose
+        self._contacts = []
+        ids = sorted(self._bodies)
+        for ia in ids:
+            for ib in ids:
+                if ib <= ia:
+                    continue
+                A, B = self._bodies[ia], self._bodies[ib]
+                if A.fixed == B.fixed:
+                    assert A.fixed or True  # drone-drone contact is out of scope
+                    if not A.fixed:
+                        continue
+                fixed, free = (A, B) if A.fixed else (B, A)
+                idf, idr = (ia, ib) if A.fixed else (ib, ia)
+                hit = False
+                for cb, Rb, hb in fixed.world_boxes():
+                    assert np.allclose(Rb, np.eye(3))
+                    for ca, Ra, ha in free.world_boxes():
+                        if _box_box_overlap(ca, Ra, ha, cb, hb):
+                            hit = True
+                if hit:
+                    self._contacts.append((0, idf, idr, -1, -1))
+        # 2) dynamics per free body
+        for bid in ids:
+            b = self._bodies[bid]
+            if b.fixed:
+                b.clear_forces()
+                continue
+            R = matrix_from_quat(b.q)
+            w_l = R.T @ b.w
+            v_l = R.T @ b.v
+            I6 = np.zeros((6, 6))   # spatial inertia at the base origin, [angular; linear]
+            bias = np.zeros(6)      # zero-acceleration force
+            for l, r, f, t in zip(b.links, b.r, b.force, b.torque):
+                m = l.mass
+                rx = _skew(r)
+                # link COM velocity in (axis-aligned) link frame
+                v_i = v_l + np.cross(w_l, r)
+                # spatial bias force at the link COM: (w x I w [gyro flag], m w x v)
+                p_ang = np.cross(w_l, l.inertia @ w_l) if b.use_gyro_term else np.zeros(3)
+                p_lin = m * np.cross(w_l, v_i)
+                # external + gravity, into link frame
+                f_l = R.T @ (f + m * self._gravity)
+                t_l = R.T @ t
+                z_ang = p_ang - t_l
+                z_lin = p_lin - f_l
+                # shift to the base origin: torque += r x force
+                bias[:3] += z_ang + np.cross(r, z_lin)
+                bias[3:] += z_lin
+                I6[:3, :3] += l.inertia + m * (rx.T @ rx)
+                I6[:3, 3:] += m * rx
+                I6[3:, :3] += m * rx.T
+                I6[3:, 3:] += m * np.eye(3)
+            acc = -np.linalg.solve(I6, bias)
+            wdot = R @ acc[:3]
+            vdot = R @ (acc[3:] + np.cross(w_l, v_l))
+            vm = b.max_coord_vel
+            b.w = np.clip(b.w + wdot * dt, -vm, vm)
+            b.v = np.clip(b.v + vdot * dt, -vm, vm)
+            b.p = b.p + dt * b.v
+            # exponential-map quaternion update with world-frame omega
+            fAngle = math.sqrt(float(b.w @ b.w))
+            if fAngle * dt > 0.25 * math.pi:
+                fAngle = 0.25 * math.pi / dt
+            if fAngle < 0.001:
+                axis = b.w * (0.5 * dt - (dt * dt * dt) * 0.020833333333 * fAngle * fAngle)
+            else:
+                axis = b.w * (math.sin(0.5 * fAngle * dt) / fAngle)
+            cw = math.cos(fAngle * dt * 0.5)
+            x, y, z, w = b.q
+            ax, ay, az = axis
+            nq = np.array(
+                [
+                    cw * x + ax * w + ay * z - az * y,
+                    cw * y + ay * w + az * x - ax * z,
+                    cw * z + az * w + ax * y - ay * x,
+                    cw * w - ax * x - ay * y - az * z,
+                ]
+            )
+            b.q = nq * (1.0 / math.sqrt(float(nq @ nq)))
+            b.clear_forces()

@@ -1,0 +1,273 @@
+"""gen_goldens.py -- generates the committed golden vectors under tests/golden/*.npz.
+
+RUN ONLY IN THE BUILD CONTAINER (needs /root/reference):  python tests/golden/gen_goldens.py
+
+It imports the reference's own Python (PyFlyt @ /root/reference) under the module stubs of
+ref_stubs.py and drives the *real* reference classes -- PID, Motors, BoringBodies, LiftingSurface,
+QuadX, Fixedwing, Aviary, QuadXHoverEnv, QuadXWaypointsEnv, FixedwingWaypointsEnv -- recording
+inputs (actions, every RNG draw) and outputs (states, observations, rewards, flags).
+
+What these vectors pin: all PyFlyt-side arithmetic and env semantics. What they do NOT pin:
+PyBullet itself -- `pybullet` is replaced by oracle/fake_bullet.py (our restatement), so the
+Bullet boundary stays "parity unpinned" (SURVEY.md section 8(c)).
+
+The .npz files hold data only (inputs + expected outputs); no reference source travels.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402
+
+gym = ref_stubs.install()
+
+from PyFlyt.core import Aviary  # noqa: E402
+from PyFlyt.core.abstractions.pid import PID  # noqa: E402
+from PyFlyt.gym_envs.fixedwing_envs.fixedwing_waypoints_env import FixedwingWaypointsEnv  # noqa: E402
+from PyFlyt.gym_envs.quadx_envs.quadx_hover_env import QuadXHoverEnv  # noqa: E402
+from PyFlyt.gym_envs.quadx_envs.quadx_waypoints_env import QuadXWaypointsEnv  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path}: " + ", ".join(f"{k}{np.asarray(v).shape}" for k, v in arrays.items()))
+
+
+# --------------------------------------------------------------------------- components
+def gen_pid():
+    rng = np.random.default_rng(11)
+    out = {}
+    gains = {
+        "ang_vel": ([4.0e-2, 4.0e-2, 8.0e-2], [5.0e-7, 5.0e-7, 2.7e-4], [1.0e-4, 1.0e-4, 0.0], [1.0, 1.0, 1.0]),
+        "lin_vel": ([0.8, 0.8], [0.3, 0.3], [0.5, 0.5], [0.4, 0.4]),
+        "z_vel": ([2.0], [0.5], [0.05], [1.0]),
+    }
+    for name, (kp, ki, kd, lim) in gains.items():
+        n = len(kp)
+        pid = PID(np.array(kp), np.array(ki), np.array(kd), np.array(lim), 1.0 / 120.0)
+        states = rng.normal(0, 1.5, size=(60, n))
+        sps = rng.normal(0, 1.5, size=(60, n))
+        outs = np.stack([pid.step(s, sp) for s, sp in zip(states, sps)])
+        out[f"{name}_gains"] = np.array([kp, ki, kd, lim])
+        out[f"{name}_state"] = states
+        out[f"{name}_setpoint"] = sps
+        out[f"{name}_out"] = outs
+    save("pid", **out)
+
+
+def gen_aero_and_motors():
+    """Real LiftingSurface / Motors / QuadX objects (constructed by the reference from its YAML)."""
+    env = Aviary(start_pos=np.array([[0.0, 0.0, 10.0]]), start_orn=np.zeros((1, 3)), drone_type="fixedwing",
+                 np_random=ref_stubs.RecordingRNG(np.random.default_rng(0)))
+    fw = env.drones[0]
+    alphas = np.concatenate([np.linspace(-np.pi, np.pi, 73), np.deg2rad([-9.0, -8.99, 13.99, 14.0, 14.01, 9.0, 89.9, -89.9])])
+    acts = np.array([-1.0, -0.35, 0.0, 0.5, 1.0])
+    coeffs = np.zeros((5, len(acts), len(alphas), 3))
+    rng = np.random.default_rng(5)
+    vels = np.concatenate([rng.normal(0, 12.0, size=(40, 3)), np.array([[20.0, 0, -1.0], [20.0, 0.5, 3.0], [-5.0, 1.0, 2.0]])])
+    forces = np.zeros((5, len(vels), 3))
+    torques = np.zeros((5, len(vels), 3))
+    consts = np.zeros((5, 6))
+    for s, surf in enumerate(fw.lifting_surfaces.surfaces):
+        consts[s] = [surf.area, surf.aspect, surf.Cl_alpha_3D, surf.theta_f, surf.aero_tau, surf.half_rho]
+        for a, act in enumerate(acts):
+            for k, al in enumerate(alphas):
+                coeffs[s, a, k] = surf._jitted_compute_aero_data(
+                    al, surf.aspect, surf.flap_to_chord, surf.aero_tau, act, surf.deflection_limit, surf.eta,
+                    surf.Cl_alpha_3D, surf.alpha_stall_P_base, surf.alpha_0_base, surf.alpha_stall_N_base, surf.Cd_0)
+        for k, v in enumerate(vels):
+            act = 0.3
+            alpha, V = surf._compute_aoa_freestream(v, surf.lift_unit, surf.drag_unit)
+            Cl, Cd, CM = surf._jitted_compute_aero_data(
+                alpha, surf.aspect, surf.flap_to_chord, surf.aero_tau, act, surf.deflection_limit, surf.eta,
+                surf.Cl_alpha_3D, surf.alpha_stall_P_base, surf.alpha_0_base, surf.alpha_stall_N_base, surf.Cd_0)
+            forces[s, k], torques[s, k] = surf._jitted_compute_force_torque(
+                alpha, V, Cl, Cd, CM, surf.half_rho, surf.area, surf.chord, surf.lift_unit, surf.drag_unit, surf.torque_unit)
+    save("aero", alphas=alphas, actuations=acts, coeffs=coeffs, vels=vels, forces=forces, torques=torques,
+         force_actuation=0.3, consts=consts)
+
+    # motors + mixer + drag on a real QuadX
+    env = Aviary(start_pos=np.array([[0.0, 0.0, 1.0]]), start_orn=np.zeros((1, 3)), drone_type="quadx",
+                 np_random=ref_stubs.RecordingRNG(np.random.default_rng(0)))
+    q = env.drones[0]
+    thr = np.linspace(-1.0, 1.0, 21)[:, None] * np.array([1.0, 0.9, 0.8, 0.7])
+    thrust = np.zeros((len(thr), 4, 3))
+    torque = np.zeros((len(thr), 4, 3))
+    for i, t in enumerate(thr):
+        thrust[i], torque[i] = q.motors._jitted_compute_thrust_torque(
+            None, t, q.motors.max_rpm, q.motors.thrust_unit, q.motors.thrust_coef, q.motors.torque_coef)
+    # mixer/saturation through update_control in mode 0 with zero rate error -> cmd = [PID(...), T]
+    rng = np.random.default_rng(9)
+    cmds = np.concatenate([rng.uniform(-1.2, 1.2, size=(80, 4)), np.zeros((1, 4)), np.ones((1, 4)) * 0.3])
+    cmds[:, 3] = np.abs(cmds[:, 3])
+    pwms = np.zeros_like(cmds)
+    for i, c in enumerate(cmds):
+        # drive the reference's own mixing/saturation branch (quadx.py:482-493): with zero state,
+        # unit kp, zero ki/kd and wide limits the rate PID passes the setpoint through unchanged
+        q.set_mode(0)
+        q.state = np.zeros((4, 3))
+        q.PIDs[0].kp = np.ones(3)
+        q.PIDs[0].ki = np.zeros(3)
+        q.PIDs[0].kd = np.zeros(3)
+        q.PIDs[0].limits = np.ones(3) * 10.0
+        q.setpoint = np.array([c[0], c[1], c[2], c[3]])
+        q.update_control(0)
+        pwms[i] = q.pwm
+    drag_v = rng.normal(0, 3.0, size=(20, 3))
+    drag_f = -np.sign(drag_v) * q.body.drag_consts[0] * drag_v**2
+    save("quadx_components", throttle=thr, thrust=thrust, torque=torque, max_rpm=q.motors.max_rpm,
+         mix_cmd=np.concatenate([cmds[:, :3], np.clip(cmds[:, 3:], 0, 1)], axis=1), mix_pwm=pwms,
+         drag_v=drag_v, drag_f=drag_f, drag_consts=q.body.drag_consts)
+
+
+# --------------------------------------------------------------------------- Aviary level
+def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True, drone_options=None):
+    rng_env = ref_stubs.RecordingRNG(np.random.default_rng(seed))
+    if not noise:
+        rng_env.normal = lambda *a, **k: 0.0
+    env = Aviary(start_pos=np.array([start_pos]), start_orn=np.array([start_orn]), drone_type=drone_type,
+                 np_random=rng_env, drone_options=drone_options or {})
+    env.set_mode(mode)
+    rng = np.random.default_rng(seed + 1000)
+    sp_dim = 4 if not (drone_type == "fixedwing" and mode == -1) else 6
+    states, auxs, sps, xis, contacts = [], [], [], [], []
+    init_state, init_aux, init_sp = env.state(0).copy(), env.aux_state(0).copy(), env.drones[0].setpoint.copy()
+    sp = np.array(env.drones[0].setpoint, dtype=np.float64).copy()
+    for k in range(n_steps):
+        if k % 25 == 10:
+            if drone_type == "quadx":
+                if mode == -1:
+                    sp = rng.uniform(0.1, 0.6, size=4)
+                elif mode == 0:
+                    sp = np.array([*rng.uniform(-1.0, 1.0, size=3), rng.uniform(0.2, 0.6)])
+                elif mode == 1:
+                    sp = np.array([*rng.uniform(-0.4, 0.4, size=3), rng.uniform(-0.5, 0.5)])
+                elif mode == 2:
+                    sp = np.array([*rng.uniform(-0.5, 0.5, size=3), rng.uniform(0.5, 2.0)])
+                elif mode == 3:
+                    sp = np.array([*rng.uniform(-0.3, 0.3, size=3), rng.uniform(0.5, 2.0)])
+                elif mode == 4:
+                    sp = np.array([*rng.uniform(-1.0, 1.0, size=2), rng.uniform(-0.5, 0.5), rng.uniform(0.5, 2.0)])
+                elif mode in (5, 6):
+                    sp = np.array([*rng.uniform(-1.0, 1.0, size=2), rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5)])
+                elif mode == 7:
+                    sp = np.array([*rng.uniform(-2.0, 2.0, size=2), rng.uniform(-1.0, 1.0), rng.uniform(0.5, 2.5)])
+            else:
+                sp = rng.uniform(-1.0, 1.0, size=sp_dim)
+                sp[-1] = rng.uniform(0.0, 1.0)
+            env.set_setpoint(0, sp.copy())
+        env.step()
+        states.append(env.state(0).copy())
+        auxs.append(env.aux_state(0).copy())
+        sps.append(np.array(env.drones[0].setpoint, dtype=np.float64).copy())
+        x = rng_env.drain("normal") if noise else np.zeros(0)
+        xis.append(np.concatenate([x, np.full(2 - len(x), np.nan)]))
+        contacts.append(bool(np.any(env.contact_array)))
+    return dict(states=np.array(states), aux=np.array(auxs), setpoints=np.array(sps), xi=np.array(xis),
+                contact=np.array(contacts), init_state=init_state, init_aux=init_aux, init_setpoint=init_sp,
+                mode=mode, start_pos=np.array(start_pos), start_orn=np.array(start_orn), noise=noise)
+
+
+def gen_aviary():
+    for mode in range(-1, 8):
+        d = run_aviary("quadx", mode, 200, seed=100 + mode, start_pos=[0.3, -0.2, 1.5],
+                       start_orn=[0.05, -0.08, 0.6], noise=True)
+        save(f"aviary_quadx_mode{mode}".replace("-1", "m1"), **d)
+    d = run_aviary("quadx", 7, 120, seed=7, start_pos=[0.0, 0.0, 1.0], start_orn=[0, 0, 0], noise=False)
+    save("aviary_quadx_mode7_nonoise", **d)
+    # a drop onto the floor: contact reporting (no contact response is restated -> keep only up to contact)
+    d = run_aviary("quadx", 0, 150, seed=3, start_pos=[0.0, 0.0, 0.15], start_orn=[0.3, 0.2, 0.0], noise=False)
+    save("aviary_quadx_drop", **d)
+    for mode in (0, -1):
+        d = run_aviary("fixedwing", mode, 200, seed=200 + mode, start_pos=[0.0, 0.0, 10.0], start_orn=[0.02, 0.05, -0.3], noise=True)
+        save(f"aviary_fixedwing_mode{mode}".replace("-1", "m1"), **d)
+
+
+# --------------------------------------------------------------------------- env level
+def flat_obs(env, obs, num_targets):
+    if isinstance(obs, dict):
+        t = np.zeros((num_targets, 3))
+        n = obs["target_deltas"].shape[0]
+        t[:n] = obs["target_deltas"]
+        return np.concatenate([obs["attitude"], t.reshape(-1)])
+    return np.array(obs, dtype=np.float64)
+
+
+def run_env(make, n_steps, seed, action_fn, num_targets=0, ticks=6):
+    env = make()
+    obs, info = env.reset(seed=seed)
+    rng_env = env.np_random
+    rec = dict(action=[], obs=[], reward=[], term=[], trunc=[], xi=[], reset_before=[], reset_obs=[], reset_xi=[],
+               reset_u=[], info_oob=[], info_col=[], info_complete=[], info_ntr=[])
+
+    def log_reset(o):
+        rec["reset_obs"].append(flat_obs(env, o, num_targets))
+        u = rng_env.drain("uniform")
+        x = rng_env.drain("normal")
+        rec["reset_u"].append(u if len(u) else np.zeros(3 * max(num_targets, 1)))
+        rec["reset_xi"].append(x)
+
+    log_reset(obs)
+    rng = np.random.default_rng(seed + 77)
+    need_reset = False
+    ep_seed = seed
+    for k in range(n_steps):
+        if need_reset:
+            ep_seed += 1
+            obs, info = env.reset(seed=ep_seed)
+            rng_env = env.np_random
+            log_reset(obs)
+            need_reset = False
+            rec["reset_before"].append(k)
+        a = action_fn(env, rng, k)
+        obs, r, te, tr, info = env.step(a)
+        x = rng_env.drain("normal")
+        rec["action"].append(a)
+        rec["obs"].append(flat_obs(env, obs, num_targets))
+        rec["reward"].append(r)
+        rec["term"].append(te)
+        rec["trunc"].append(tr)
+        rec["xi"].append(np.concatenate([x, np.full(ticks - len(x), np.nan)]))
+        rec["info_oob"].append(info["out_of_bounds"])
+        rec["info_col"].append(info["collision"])
+        rec["info_complete"].append(info["env_complete"])
+        rec["info_ntr"].append(info.get("num_targets_reached", 0))
+        need_reset = bool(te or tr)
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["seed"] = seed
+    return out
+
+
+def uniform_action(env, rng, k):
+    return rng.uniform(env.action_space.low, env.action_space.high)
+
+
+def gentle_quad_action(env, rng, k):
+    return np.array([*rng.uniform(-0.3, 0.3, size=3), rng.uniform(0.33, 0.40)])
+
+
+def gentle_fw_action(env, rng, k):
+    return np.array([*rng.uniform(-0.3, 0.3, size=3), rng.uniform(-0.2, 0.8)])
+
+
+def gen_envs():
+    save("env_hover_random", **run_env(lambda: QuadXHoverEnv(), 500, 0, uniform_action, ticks=6))
+    save("env_hover_gentle_trunc", **run_env(lambda: QuadXHoverEnv(max_duration_seconds=0.5), 120, 1, gentle_quad_action, ticks=6))
+    save("env_hover_euler_sparse", **run_env(lambda: QuadXHoverEnv(angle_representation="euler", sparse_reward=True), 150, 2, uniform_action, ticks=6))
+    save("env_quadx_waypoints_random", **run_env(lambda: QuadXWaypointsEnv(), 400, 3, uniform_action, num_targets=4, ticks=8))
+    save("env_quadx_waypoints_reach", **run_env(lambda: QuadXWaypointsEnv(goal_reach_distance=2.5), 300, 4, gentle_quad_action, num_targets=4, ticks=8))
+    save("env_fixedwing_waypoints_random", **run_env(lambda: FixedwingWaypointsEnv(), 500, 5, uniform_action, num_targets=4, ticks=8))
+    save("env_fixedwing_waypoints_gentle", **run_env(lambda: FixedwingWaypointsEnv(goal_reach_distance=40.0), 400, 6, gentle_fw_action, num_targets=4, ticks=8))
+
+
+if __name__ == "__main__":
+    gen_pid()
+    gen_aero_and_motors()
+    gen_aviary()
+    gen_envs()

@@ -1,0 +1,195 @@
+"""The fp64 oracle (oracle/uav_oracle.c) against the golden vectors captured from the reference's
+own Python (tests/golden/gen_goldens.py). CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+TOL = 1e-10
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ------------------------------------------------------------------ components
+@pytest.mark.parametrize("name,n", [("ang_vel", 3), ("lin_vel", 2), ("z_vel", 1)])
+def test_pid(golden_dir, name, n):
+    g = load(golden_dir, "pid")
+    kp, ki, kd, lim = (np.ascontiguousarray(x) for x in g[f"{name}_gains"])
+    I, E = np.zeros(3), np.zeros(3)
+    for s, sp, ref in zip(g[f"{name}_state"], g[f"{name}_setpoint"], g[f"{name}_out"]):
+        out = np.zeros(3)
+        s, sp = np.ascontiguousarray(s), np.ascontiguousarray(sp)
+        O.lib().orc_pid_step(dp(kp), dp(ki), dp(kd), dp(lim), 1.0 / 120.0, n, dp(I), dp(E), dp(s), dp(sp), dp(out))
+        np.testing.assert_allclose(out[:n], ref, rtol=0, atol=1e-15)
+
+
+def test_aero_coefficients_and_forces(golden_dir):
+    g = load(golden_dir, "aero")
+    P = O.make_params("fixedwing")
+    for s in range(5):
+        S = P.surf[s]
+        np.testing.assert_allclose(
+            [S.area, S.aspect, S.Cl_alpha_3D, S.theta_f, S.aero_tau, S.half_rho], g["consts"][s], rtol=1e-15)
+        for a, act in enumerate(g["actuations"]):
+            for k, al in enumerate(g["alphas"]):
+                out = np.zeros(3)
+                O.lib().orc_surface_aero(C.byref(S), float(al), float(act), dp(out))
+                np.testing.assert_allclose(out, g["coeffs"][s, a, k], rtol=1e-13, atol=1e-15)
+        for k, v in enumerate(g["vels"]):
+            F, T = np.zeros(3), np.zeros(3)
+            v = np.ascontiguousarray(v)
+            O.lib().orc_surface_force(C.byref(S), dp(v), float(g["force_actuation"]), dp(F), dp(T))
+            np.testing.assert_allclose(F, g["forces"][s, k], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(T, g["torques"][s, k], rtol=1e-12, atol=1e-13)
+
+
+def test_quadx_mixer_motors_drag(golden_dir):
+    g = load(golden_dir, "quadx_components")
+    P = O.make_params("quadx")
+    np.testing.assert_allclose(np.array(P.max_rpm[:]), g["max_rpm"], rtol=1e-15)
+    np.testing.assert_allclose(np.array(P.drag_const[:]), g["drag_consts"][0], rtol=1e-15)
+    for cmd, ref in zip(g["mix_cmd"], g["mix_pwm"]):
+        pwm = np.zeros(4)
+        cmd = np.ascontiguousarray(cmd)
+        O.lib().orc_quadx_mix(C.byref(P), dp(cmd), dp(pwm))
+        np.testing.assert_allclose(pwm, ref, rtol=0, atol=1e-15)
+    for v, f in zip(g["drag_v"], g["drag_f"]):
+        out = np.zeros(3)
+        v = np.ascontiguousarray(v)
+        O.lib().orc_body_drag(C.byref(P), dp(v), dp(out))
+        np.testing.assert_allclose(out, f, rtol=1e-15)
+    # thrust/torque: orc_motors_update with dt/tau bypassed -> use pwm == throttle, xi == 0
+    thrust_t = ((C.c_double * 3) * 4)
+    for thr, th_ref, tq_ref in zip(g["throttle"], g["thrust"], g["torque"]):
+        t = np.ascontiguousarray(thr.copy())
+        th, tq = thrust_t(), thrust_t()
+        O.lib().orc_motors_update.argtypes = [C.POINTER(O.Params), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                              C.c_double, thrust_t, thrust_t]
+        O.lib().orc_motors_update(C.byref(P), dp(t), dp(t.copy()), 0.0, th, tq)
+        np.testing.assert_allclose(t, thr, rtol=1e-15)  # pwm == throttle leaves throttle unchanged
+        np.testing.assert_allclose(np.array([list(r) for r in th]), th_ref, rtol=1e-14, atol=1e-18)
+        np.testing.assert_allclose(np.array([list(r) for r in tq]), tq_ref, rtol=1e-14, atol=1e-20)
+
+
+# ------------------------------------------------------------------ Aviary level
+def lane_state(L, fixedwing):
+    st = np.array([list(L.w_b), list(L.rpy), list(L.v_b), list(L.p)])
+    aux = np.array(list(L.actuation) + [L.throttle[0]]) if fixedwing else np.array(list(L.throttle))
+    return st, aux
+
+
+AVIARY = [f"aviary_quadx_mode{m}" for m in ["m1", 0, 1, 2, 3, 4, 5, 6, 7, "7_nonoise"]] + \
+         ["aviary_fixedwing_mode0", "aviary_fixedwing_modem1"]
+
+
+@pytest.mark.parametrize("name", AVIARY)
+def test_aviary_trajectory(golden_dir, name):
+    g = load(golden_dir, name)
+    fw = "fixedwing" in name
+    noise = bool(g["noise"])
+    P = O.make_params("fixedwing" if fw else "quadx", noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF,
+                      start_pos=g["start_pos"], start_rpy=g["start_orn"])
+    L = O.Lane()
+    lib = O.lib()
+    lib.orc_aviary_reset(C.byref(P), C.byref(L), 0)
+    lib.orc_set_mode(C.byref(P), C.byref(L), int(g["mode"]))
+    st, aux = lane_state(L, fw)
+    np.testing.assert_allclose(st, g["init_state"], atol=1e-14)
+    np.testing.assert_allclose(np.array(list(L.setpoint))[: len(g["init_setpoint"])], g["init_setpoint"], atol=1e-14)
+    worst = 0.0
+    for k in range(len(g["states"])):
+        sp = g["setpoints"][k]
+        for i, x in enumerate(sp):
+            L.setpoint[i] = x
+        xi = np.ascontiguousarray(np.nan_to_num(g["xi"][k]))
+        lib.orc_aviary_step(C.byref(P), C.byref(L), dp(xi), 0, 0)
+        st, aux = lane_state(L, fw)
+        err = max(np.abs(st - g["states"][k]).max(), np.abs(aux - g["aux"][k]).max())
+        worst = max(worst, err)
+        assert bool(L.contact_step) == bool(g["contact"][k])
+    assert worst < TOL, worst
+
+
+def test_aviary_drop_contact(golden_dir):
+    """Free fall onto the floor: the contact flag must rise on the same Aviary step as in the
+    reference-on-fake-Bullet run; states are compared up to that step (no contact response)."""
+    g = load(golden_dir, "aviary_quadx_drop")
+    P = O.make_params("quadx", start_pos=g["start_pos"], start_rpy=g["start_orn"])
+    L = O.Lane()
+    lib = O.lib()
+    lib.orc_aviary_reset(C.byref(P), C.byref(L), 0)
+    lib.orc_set_mode(C.byref(P), C.byref(L), 0)
+    first = int(np.argmax(g["contact"]))
+    assert g["contact"][first]
+    for k in range(first + 1):
+        for i, x in enumerate(g["setpoints"][k]):
+            L.setpoint[i] = x
+        lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+        assert bool(L.contact_step) == bool(g["contact"][k]), k
+        st, aux = lane_state(L, False)
+        np.testing.assert_allclose(st, g["states"][k], atol=TOL)
+
+
+# ------------------------------------------------------------------ env level
+ENVS = [
+    ("env_hover_random", "hover", {}),
+    ("env_hover_gentle_trunc", "hover", {"max_steps": 20}),
+    ("env_hover_euler_sparse", "hover", {"angle_repr": 0, "sparse_reward": 1}),
+    ("env_quadx_waypoints_random", "quadx_waypoints", {}),
+    ("env_quadx_waypoints_reach", "quadx_waypoints", {"goal_reach_distance": 2.5}),
+    ("env_fixedwing_waypoints_random", "fixedwing_waypoints", {}),
+    ("env_fixedwing_waypoints_gentle", "fixedwing_waypoints", {"goal_reach_distance": 40.0}),
+]
+
+
+@pytest.mark.parametrize("name,env,over", ENVS)
+def test_env_trajectory(golden_dir, name, env, over):
+    g = load(golden_dir, name)
+    P = O.make_params(env, noise_mode=O.NOISE_INJECT, **over)
+    lib = O.lib()
+    D = lib.orc_obs_dim(C.byref(P))
+    assert D == g["obs"].shape[1]
+    L = O.Lane()
+    resets = set(int(k) for k in g["reset_before"])
+    ri = 0
+
+    def do_reset():
+        nonlocal ri
+        xr = np.ascontiguousarray(g["reset_xi"][ri])
+        u = np.ascontiguousarray(g["reset_u"][ri])
+        lib.orc_env_reset(C.byref(P), C.byref(L), 0, dp(xr), dp(u))
+        obs = np.frombuffer(L.obs, dtype=np.float64, count=D)
+        np.testing.assert_allclose(obs, g["reset_obs"][ri], atol=TOL)
+        ri += 1
+
+    do_reset()
+    seen = dict(term=0, trunc=0, col=0, oob=0, complete=0, reached=0)
+    for k in range(len(g["action"])):
+        if k in resets:
+            do_reset()
+        a = np.ascontiguousarray(g["action"][k])
+        xi = np.ascontiguousarray(np.nan_to_num(g["xi"][k]))
+        lib.orc_env_step(C.byref(P), C.byref(L), dp(a), dp(xi))
+        obs = np.frombuffer(L.obs, dtype=np.float64, count=D)
+        np.testing.assert_allclose(obs, g["obs"][k], atol=TOL, err_msg=f"step {k}")
+        assert abs(L.reward - g["reward"][k]) < 1e-9, (k, L.reward, g["reward"][k])
+        assert bool(L.terminated) == bool(g["term"][k]), k
+        assert bool(L.truncated) == bool(g["trunc"][k]), k
+        assert bool(L.info_oob) == bool(g["info_oob"][k])
+        assert bool(L.info_collision) == bool(g["info_col"][k])
+        assert bool(L.info_complete) == bool(g["info_complete"][k])
+        assert int(L.num_targets_reached) == int(g["info_ntr"][k])
+        seen["term"] += int(g["term"][k]); seen["trunc"] += int(g["trunc"][k])
+        seen["col"] += int(g["info_col"][k]); seen["oob"] += int(g["info_oob"][k])
+        seen["complete"] += int(g["info_complete"][k]); seen["reached"] = max(seen["reached"], int(g["info_ntr"][k]))
+    assert ri == len(g["reset_obs"])
+    print(name, seen)

@@ -256,6 +256,18 @@ def gentle_fw_action(env, rng, k):
     return np.array([*rng.uniform(-0.3, 0.3, size=3), rng.uniform(-0.2, 0.8)])
 
 
+def lowthrust_quad_action(env, rng, k):
+    return np.array([*rng.uniform(-0.5, 0.5, size=3), rng.uniform(0.0, 0.25)])
+
+
+def gen_envs_crash():
+    save("env_hover_crash", **run_env(lambda: QuadXHoverEnv(), 150, 8, lowthrust_quad_action, ticks=6))
+    # the fixedwing cannot reach the 30 m x 30 m floor box from its default start (z=10, 20 m/s), so
+    # floor contact for it is pinned at Aviary level, from a low start
+    d = run_aviary("fixedwing", 0, 60, seed=12, start_pos=[0.0, 0.0, 0.8], start_orn=[0.2, 0.25, 0.0], noise=True)
+    save("aviary_fixedwing_drop", **d)
+
+
 def gen_envs():
     save("env_hover_random", **run_env(lambda: QuadXHoverEnv(), 500, 0, uniform_action, ticks=6))
     save("env_hover_gentle_trunc", **run_env(lambda: QuadXHoverEnv(max_duration_seconds=0.5), 120, 1, gentle_quad_action, ticks=6))
@@ -271,3 +283,4 @@ if __name__ == "__main__":
     gen_aero_and_motors()
     gen_aviary()
     gen_envs()
+    gen_envs_crash()

@@ -119,23 +119,27 @@ def test_aviary_trajectory(golden_dir, name):
     assert worst < TOL, worst
 
 
-def test_aviary_drop_contact(golden_dir):
-    """Free fall onto the floor: the contact flag must rise on the same Aviary step as in the
-    reference-on-fake-Bullet run; states are compared up to that step (no contact response)."""
-    g = load(golden_dir, "aviary_quadx_drop")
-    P = O.make_params("quadx", start_pos=g["start_pos"], start_rpy=g["start_orn"])
+@pytest.mark.parametrize("name", ["aviary_quadx_drop", "aviary_fixedwing_drop"])
+def test_aviary_drop_contact(golden_dir, name):
+    """Fall onto the floor: the contact flag must rise on the same Aviary step as in the
+    reference-on-fake-Bullet run (neither side restates a contact response)."""
+    g = load(golden_dir, name)
+    fw = "fixedwing" in name
+    noise = bool(g["noise"])
+    P = O.make_params("fixedwing" if fw else "quadx", noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF,
+                      start_pos=g["start_pos"], start_rpy=g["start_orn"])
     L = O.Lane()
     lib = O.lib()
     lib.orc_aviary_reset(C.byref(P), C.byref(L), 0)
     lib.orc_set_mode(C.byref(P), C.byref(L), 0)
-    first = int(np.argmax(g["contact"]))
-    assert g["contact"][first]
-    for k in range(first + 1):
+    assert g["contact"].any() and not g["contact"][0]
+    for k in range(len(g["states"])):
         for i, x in enumerate(g["setpoints"][k]):
             L.setpoint[i] = x
-        lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+        xi = np.ascontiguousarray(np.nan_to_num(g["xi"][k]))
+        lib.orc_aviary_step(C.byref(P), C.byref(L), dp(xi), 0, 0)
         assert bool(L.contact_step) == bool(g["contact"][k]), k
-        st, aux = lane_state(L, False)
+        st, aux = lane_state(L, fw)
         np.testing.assert_allclose(st, g["states"][k], atol=TOL)
 
 
@@ -144,6 +148,7 @@ ENVS = [
     ("env_hover_random", "hover", {}),
     ("env_hover_gentle_trunc", "hover", {"max_steps": 20}),
     ("env_hover_euler_sparse", "hover", {"angle_repr": 0, "sparse_reward": 1}),
+    ("env_hover_crash", "hover", {}),
     ("env_quadx_waypoints_random", "quadx_waypoints", {}),
     ("env_quadx_waypoints_reach", "quadx_waypoints", {"goal_reach_distance": 2.5}),
     ("env_fixedwing_waypoints_random", "fixedwing_waypoints", {}),

@@ -1,0 +1,183 @@
+/*
+ * pyflyt_amd.h -- C ABI of the MI355X-native batched UAV-physics step.
+ *
+ * Drop-in boundary for ONE hot path of jjshoots/PyFlyt (reference @ v0.30.0): `Aviary.step()` and
+ * the per-drone `update_control / update_physics / update_state` loop plus the 6-DoF integrator
+ * PyBullet supplies underneath it, for N independent drones at one wavefront lane per drone.
+ * The reference is pure Python and has no FFI of its own; each entry point below names the
+ * reference interface it replaces (file:line relative to /root/reference/PyFlyt/), and
+ * INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer in pf_buffers is a DEVICE pointer into memory the
+ *     caller owns (PyTorch-ROCm tensors: tensor.data_ptr()); the library only borrows them for the
+ *     duration of a call and owns nothing but its context.
+ *   - every call is asynchronous on the caller's HIP stream (`stream` = hipStream_t, e.g.
+ *     torch.cuda.current_stream().cuda_stream); no internal threads, no hidden synchronisation.
+ *   - every function returns 0 on success, a negative pf_status or a positive hipError_t
+ *     otherwise; pf_last_error() gives the message. No exceptions cross the boundary.
+ *   - one context per GPU; a context is not re-entrant.
+ *   - there is NO CPU fallback: without a gfx950 device pf_ctx_create fails.
+ */
+#ifndef PYFLYT_AMD_H
+#define PYFLYT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ABI_VERSION 1
+#define PF_MAX_TARGETS 8
+#define PF_MAX_BOXES 8
+#define PF_MAX_SURF 5
+
+enum pf_status { PF_OK = 0, PF_ERR_ARG = -1, PF_ERR_UNSUPPORTED = -2, PF_ERR_NO_DEVICE = -3 };
+enum pf_vehicle { PF_QUADX = 0, PF_FIXEDWING = 1 };
+enum pf_task { PF_TASK_NONE = 0, PF_TASK_HOVER = 1, PF_TASK_WAYPOINTS = 2 };
+enum pf_noise { PF_NOISE_OFF = 0, PF_NOISE_INJECT = 1, PF_NOISE_PHILOX = 2 };
+enum pf_autoreset { PF_AUTORESET_OFF = 0, PF_AUTORESET_NEXT_STEP = 1, PF_AUTORESET_SAME_STEP = 2 };
+
+/* bits of the per-lane `flags` word (state group PF_G_INT, .y) */
+enum pf_flag {
+  PF_F_TERMINATED = 1, PF_F_TRUNCATED = 2, PF_F_CONTACT = 4, /* contact after the last tick */
+  PF_F_INFO_COLLISION = 8, PF_F_INFO_OOB = 16, PF_F_INFO_COMPLETE = 32
+};
+
+typedef struct pf_pid {
+  float kp[3], ki[3], kd[3], lim[3];
+} pf_pid;
+
+typedef struct pf_box {
+  float c[3], h[3]; /* centre in the base frame, half extents */
+} pf_box;
+
+/* one lifting surface: abstractions/lifting_surfaces.py:141-239 (constants precomputed on host) */
+typedef struct pf_surface {
+  float r[3];                       /* link COM offset in the base frame */
+  float lift[3], drag[3], torque[3]; /* unit vectors */
+  float Cl_alpha_3D, inv_Cl_alpha_3D, aero_tau_eta; /* Cl3D, 1/Cl3D, aero_tau*eta */
+  float flap_to_chord, inv_pi_aspect, exp_term;     /* 1/(pi*AR), 0.41*(1-exp(-17/AR)) */
+  float alpha_0_base, alpha_stall_P_base, alpha_stall_N_base; /* radians */
+  float Cd_0, deflection_limit_rad, dt_over_tau;
+  float half_rho_area, chord;
+} pf_surface;
+
+/* All constants of one batched simulation. Filled by the host from its own parameter tables
+ * (pyflyt_amd/params.py; numbers from cf2x.yaml/.urdf and fixedwing.yaml/.urdf, cited there). */
+typedef struct pf_params {
+  int32_t vehicle;  /* pf_vehicle */
+  int32_t task;     /* pf_task */
+  int32_t flight_mode;        /* quadx: -1..7 (quadx.py:233-259); fixedwing: -1, 0 */
+  int32_t noise_mode;         /* pf_noise */
+  int32_t autoreset;          /* pf_autoreset */
+  int32_t angle_repr;         /* 0 euler, 1 quaternion (quadx_base_env.py:62-69) */
+  int32_t sparse_reward;
+  int32_t num_targets;
+  int32_t max_steps;          /* agent_hz * max_duration_seconds (quadx_base_env.py:121) */
+  int32_t env_step_ratio;     /* 120 / agent_hz (quadx_base_env.py:122) */
+  int32_t settle_steps;       /* 10 (quadx_base_env.py:209) */
+  int32_t ticks_per_control;  /* physics_hz / control_hz (base_drone.py:102) */
+  int32_t use_gyro_term;      /* [BULLET-FROM-MEMORY] btMultiBody::m_useGyroTerm */
+  int32_t throttle_remap;     /* fixedwing_base_env.py:260 */
+  int32_t n_motors, n_surf, n_boxes;
+  int32_t has_com_offset;
+  uint64_t seed;
+
+  /* world / integrator: aviary.py:79,226 + Bullet defaults */
+  float dt, gravity_z, max_coord_vel;
+  float plane_half_xy, plane_half_z;
+  /* composite body */
+  float inv_mass;
+  float com[3];
+  float I_own[6], I_pa[6], I_inv[6]; /* symmetric: xx xy xz yy yz zz */
+  float bound_radius;
+  pf_box boxes[PF_MAX_BOXES];
+  /* motors: motors.py:110-195 */
+  float motor_r[4][3];
+  float thrust_unit[4][3];
+  float motor_dt_over_tau[4], motor_fmax[4] /* Ct*max_rpm^2 */, motor_tmax[4] /* Cq*max_rpm^2, signed */;
+  float motor_noise[4];
+  /* quadx */
+  float motor_map[4][4];      /* quadx.py:130-137 */
+  float drag_const[3];        /* boring_bodies.py:63 */
+  float drag_coef_pqr;        /* cf2x.yaml:11 */
+  pf_pid pid[4];              /* ang_vel, ang_pos, lin_vel, lin_pos (cf2x.yaml:13-41) */
+  pf_pid zpid[2];             /* z_vel, z_pos (cf2x.yaml:43-54) */
+  float control_period, inv_control_period;
+  /* fixedwing */
+  pf_surface surf[PF_MAX_SURF];
+  int32_t assist_ids[6];      /* fixedwing.py:143 */
+  float assist_signs[6];      /* fixedwing.py:144 */
+  /* env */
+  float start_pos[3], start_quat[4], start_vel[3];
+  float dome, goal_reach_distance, min_height;
+  float wp_dist_reward, wp_yaw_penalty;
+  float action_low[4], action_high[4]; /* action space box (quadx_base_env.py:80-102) */
+} pf_params;
+
+/* Device buffers of one call. state layout: float4 groups, [n_groups][n_lanes][4]. */
+typedef struct pf_buffers {
+  float* state;            /* [pf_state_groups()][n][4] fp32/int32, persistent */
+  const float* actions;    /* [n][4]   gym action (quadx_base_env.py:269) */
+  float* obs;              /* [n][pf_obs_dim()] row-major */
+  float* final_obs;        /* [n][pf_obs_dim()] or NULL; written for finished lanes under SAME_STEP */
+  float* reward;           /* [n] */
+  uint8_t* terminated;     /* [n] */
+  uint8_t* truncated;      /* [n] */
+  const float* xi;         /* PF_NOISE_INJECT: [env_step_ratio*ticks_per_control][n] raw motor-noise draws */
+  const float* xi_reset;   /* PF_NOISE_INJECT: [settle_steps*ticks_per_control][n] */
+  const float* u_targets;  /* PF_NOISE_INJECT, waypoint tasks: [3*num_targets][n] theta|phi|dist draws */
+  /* Aviary-level calls only */
+  const float* setpoints;  /* [n][4] (quadx, fixedwing mode 0) or [n][6] (fixedwing mode -1) */
+  float* out_state;        /* [n][12]: ang_vel, ang_pos, lin_vel, lin_pos rows of Aviary.state(i) */
+  float* out_aux;          /* [n][4] quadx throttle | [n][6] fixedwing surfaces + throttle */
+  uint8_t* out_contact;    /* [n] contact_array[planeId] after the step, or NULL */
+  const float* start_pose; /* pf_aviary_reset: [n][7] per-lane spawn (pos xyz, quat xyzw) or NULL = pf_params */
+} pf_buffers;
+
+typedef struct pf_ctx pf_ctx;
+
+int pf_abi_version(void);
+/* struct sizes as compiled, so that a foreign-language binding can verify its mirror of the structs */
+size_t pf_sizeof_params(void);
+size_t pf_sizeof_buffers(void);
+/* message of the last failing call (per context, or global when ctx is NULL) */
+const char* pf_last_error(const pf_ctx* ctx);
+
+/* Replaces constructing `Aviary(...)` + the drone objects (core/aviary.py:69-216,
+ * core/drones/quadx.py:22-220, fixedwing.py:18-192): binds the parameter block to a device.
+ * lane_offset = global index of lane 0 (multi-GPU sharding; keys the counter-based RNG). */
+int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lane_offset, pf_ctx** out);
+void pf_ctx_destroy(pf_ctx* ctx);
+int pf_state_groups(const pf_ctx* ctx); /* float4 groups per lane in pf_buffers.state */
+int pf_obs_dim(const pf_ctx* ctx);
+int pf_n_lanes(const pf_ctx* ctx);
+
+/* env.reset(): gym_envs/quadx_envs/quadx_base_env.py:149-212 (begin_reset + end_reset incl. the
+ * 10 settle Aviary steps), quadx_hover_env.py:70-83, quadx_waypoints_env.py:112-125,
+ * fixedwing_waypoints_env.py:101-114. mask (device, [n] bytes) selects lanes; NULL = all. */
+int pf_env_reset(pf_ctx* ctx, const pf_buffers* b, const uint8_t* mask, void* stream);
+/* env.step(action): quadx_base_env.py:269-301 / fixedwing_base_env.py:244-278 with the task's
+ * compute_state + compute_term_trunc_reward, env_step_ratio x Aviary.step() (core/aviary.py:480-531)
+ * fused in one launch; auto-reset per pf_params.autoreset. */
+int pf_env_step(pf_ctx* ctx, const pf_buffers* b, void* stream);
+
+/* Aviary-level surface (core/aviary.py): reset :218-312, set_mode :440-458, step :480-531 with
+ * set_all_setpoints :470-478 folded in (b->setpoints), state/aux_state :335-369 -> out_state/out_aux.
+ * n_steps Aviary steps are fused in one launch (setpoints held, as the reference holds them). */
+int pf_aviary_reset(pf_ctx* ctx, const pf_buffers* b, void* stream);
+int pf_aviary_set_mode(pf_ctx* ctx, const pf_buffers* b, int mode, float* setpoints_out, void* stream);
+int pf_aviary_step(pf_ctx* ctx, const pf_buffers* b, int n_steps, void* stream);
+
+/* Synthetic uniform actions inside [action_low, action_high] for benchmark rollouts
+ * (the role of env.action_space.sample(), tests/test_gym_envs.py:104), keyed by
+ * (seed, global lane, step_index). */
+int pf_sample_actions(pf_ctx* ctx, float* actions, uint32_t step_index, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYFLYT_AMD_H */

@@ -72,8 +72,8 @@ void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-/* 24-bit uniform in (0,1): (k + 0.5) * 2^-24, exactly representable in fp32 and fp64 */
-static inline double u24(uint32_t x) { return ((double)(x >> 8) + 0.5) * (1.0 / 16777216.0); }
+/* 23-bit uniform in (0,1): (k + 0.5) * 2^-23, k < 2^23 -- exactly representable in fp32 and fp64 */
+static inline double u24(uint32_t x) { return ((double)(x >> 9) + 0.5) * (1.0 / 8388608.0); }
 void orc_uniform4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double u[4]) {
   uint32_t r[4];
   orc_philox4x32(key, c0, c1, c2, c3, r);

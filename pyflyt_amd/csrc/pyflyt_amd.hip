@@ -1,0 +1,579 @@
+// pyflyt_amd.hip -- kernels + C ABI (include/pyflyt_amd.h) of the MI355X-native batched UAV step.
+//
+// Execution model: one wavefront lane per drone, one 64-lane wavefront per workgroup (no
+// inter-wave synchronisation anywhere), persistent state as float4 groups [group][lane][4] so that
+// every state access is a 16 B/lane, 1 KiB/wave coalesced global_load/store_dwordx4. The whole env
+// step (env_step_ratio x ticks_per_control physics ticks, controller, reward, termination,
+// auto-reset with its settle ticks) stays in registers; the row-major observation tile is
+// transposed through LDS so that the [n][obs_dim] output is written with full-width stores.
+// No MFMA: there is no dense contraction on this path (3x3 work only).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/pyflyt_amd.h"
+#include "uav_vehicles.hpp"
+
+namespace pf {
+
+constexpr int kWave = 64;
+constexpr int kMaxObs = 36;  // 13 + 4 + 6 + 3*4 = 35
+
+enum { OP_STEP = 0, OP_RESET = 1 };
+
+// ------------------------------------------------------------------ waypoint task state
+template <int TASK>
+struct Targets {
+  float t[4][3];
+  int n_left;
+  PF_DEV void load(const float4* S, size_t n, size_t i, int g) {
+    if (TASK != PF_TASK_WAYPOINTS) return;
+    float4 a = S[(size_t)(g + 0) * n + i], b = S[(size_t)(g + 1) * n + i], c = S[(size_t)(g + 2) * n + i];
+    t[0][0] = a.x; t[0][1] = a.y; t[0][2] = a.z; t[1][0] = a.w;
+    t[1][1] = b.x; t[1][2] = b.y; t[2][0] = b.z; t[2][1] = b.w;
+    t[2][2] = c.x; t[3][0] = c.y; t[3][1] = c.z; t[3][2] = c.w;
+  }
+  PF_DEV void store(float4* S, size_t n, size_t i, int g) const {
+    if (TASK != PF_TASK_WAYPOINTS) return;
+    S[(size_t)(g + 0) * n + i] = float4{t[0][0], t[0][1], t[0][2], t[1][0]};
+    S[(size_t)(g + 1) * n + i] = float4{t[1][1], t[1][2], t[2][0], t[2][1]};
+    S[(size_t)(g + 2) * n + i] = float4{t[2][2], t[3][0], t[3][1], t[3][2]};
+  }
+  PF_DEV void pop() {  // waypoint_handler.py:181-188
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) t[k][c] = t[k + 1][c];
+    n_left -= 1;
+  }
+};
+
+// ------------------------------------------------------------------ the fused env kernel
+// Per lane this is a small state machine over "Aviary steps":
+//   step phase   : env_step_ratio Aviary steps, each followed by compute_state +
+//                  compute_term_trunc_reward (quadx_base_env.py:287-296), early exit on term/trunc;
+//   settle phase : after a (auto-)reset, settle_steps Aviary steps with the mode's default
+//                  setpoint (quadx_base_env.py:209-210).
+// Both phases run through the single inlined aviary_step() below; the loop trip count is the
+// wave-wide maximum of what the lanes still have to do.
+template <class VEH, int TASK, int MODE_T>
+__global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_buffers B, const int n,
+                                                    const uint64_t lane0, const int op, const uint8_t* mask) {
+  __shared__ float tile[kWave * kMaxObs];
+  const int tid = threadIdx.x;
+  const int wave_base = blockIdx.x * kWave;
+  const int lane = wave_base + tid;
+  const bool valid = lane < n;
+  const size_t li = valid ? lane : n - 1;
+  const size_t N = (size_t)n;
+  const float4* Sin = reinterpret_cast<const float4*>(B.state);
+  float4* Sout = reinterpret_cast<float4*>(B.state);
+  const int mode = (MODE_T == kRuntimeMode) ? P.flight_mode : MODE_T;
+
+  VEH V;
+  Targets<TASK> tg;
+  float new_dist;
+  int4 ints;
+  V.load(Sin, N, li, mode, new_dist, ints);
+  tg.load(Sin, N, li, VEH::G_TGT);
+  int step_count = ints.x, flags = ints.y;
+  uint32_t rng_ctr = (uint32_t)ints.z;
+  tg.n_left = ints.w;
+  bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
+  float old_dist = new_dist;
+
+  Noise nz;
+  nz.mode = P.noise_mode; nz.n = n; nz.lane = (int)li;
+  nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
+  nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
+
+  // what does this lane do in this launch?
+  bool active, do_reset;
+  if (op == OP_RESET) {
+    do_reset = (mask == nullptr) || (mask[li] != 0);
+    active = do_reset;
+  } else {
+    do_reset = (P.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc);
+    active = true;
+  }
+  active = active && valid;
+
+  float sp[6] = {0, 0, 0, 0, 0, 0};
+  float act4[4] = {0, 0, 0, 0};
+  float reward = 0.0f;
+  bool settling = false;
+  int remaining = 0, done_its = 0;
+  bool pop_pending = false;
+  bool rpy_valid = false;
+  const int D = ((P.angle_repr ? 13 : 12) + 4 + VEH::AUX) + (TASK == PF_TASK_WAYPOINTS ? 3 * P.num_targets : 0);
+
+  // begin_reset + waypoint sampling + set_mode (quadx_base_env.py:149-206)
+  auto begin_reset = [&]() {
+    V.reset(P, nullptr, sp);
+    rpy_valid = true;
+    step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
+    act4[0] = act4[1] = act4[2] = act4[3] = 0.0f;
+    nz.begin_event(rng_ctr, 1u, B.xi_reset);
+    if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
+      const int nt = P.num_targets;
+      tg.n_left = nt;
+      new_dist = INFINITY; old_dist = INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < nt) {
+          float theta, phi, dist;
+          if (P.noise_mode == PF_NOISE_INJECT && B.u_targets != nullptr) {
+            theta = B.u_targets[(size_t)i * N + li];
+            phi = B.u_targets[(size_t)(nt + i) * N + li];
+            dist = B.u_targets[(size_t)(2 * nt + i) * N + li];
+          } else {
+            theta = (2.0f * kPi) * nz.uniform(i, 2u);
+            phi = (2.0f * kPi) * nz.uniform(nt + i, 2u);
+            dist = fmaf(P.dome * 0.9f - 1.0f, nz.uniform(2 * nt + i, 2u), 1.0f);
+          }
+          float st, ct, sph, cph;
+          sincosf(theta, &st, &ct);
+          sincosf(phi, &sph, &cph);
+          float zz = __builtin_fabsf(dist * cph);
+          tg.t[i][0] = dist * sph * ct; tg.t[i][1] = dist * sph * st; tg.t[i][2] = zz > P.min_height ? zz : P.min_height;
+        }
+      }
+    }
+    V.set_mode(mode, sp);
+    settling = true; remaining = P.settle_steps; done_its = 0;
+  };
+  // compute_state (quadx_hover_env.py:85-115 / quadx_waypoints_env.py:127-175): only the
+  // waypoint bookkeeping has side effects; the observation vector itself is assembled at the end
+  auto wp_distance = [&]() {
+    if (TASK != PF_TASK_WAYPOINTS) return;
+    if (pop_pending) { tg.pop(); pop_pending = false; }
+    m3 Re = rot_from_quat(quat_from_euler(V.b.rpy));  // quadx_base_env.py:243, waypoint_handler.py:135
+    v3 d = mulT(Re, v3{tg.t[0][0] - V.b.p.x, tg.t[0][1] - V.b.p.y, tg.t[0][2] - V.b.p.z});
+    old_dist = new_dist;
+    new_dist = sqrtf(dot(d, d));
+  };
+  // compute_term_trunc_reward (quadx_base_env.py:251-267, quadx_hover_env.py:117-138,
+  // quadx_waypoints_env.py:177-204, fixedwing_waypoints_env.py:169-190)
+  auto term_trunc_reward = [&]() {
+    if (step_count > P.max_steps) trunc = true;
+    if (V.b.contact_step) { reward = -100.0f; flags |= PF_F_INFO_COLLISION; term = true; }
+    if (sqrtf(dot(V.b.p, V.b.p)) > P.dome) { reward = -100.0f; flags |= PF_F_INFO_OOB; term = true; }
+    if (TASK == PF_TASK_HOVER) {
+      if (!P.sparse_reward) {
+        v3 d{V.b.p.x, V.b.p.y, V.b.p.z - 1.0f};
+        float lin = sqrtf(dot(d, d));
+        float yaw_rate = __builtin_fabsf(V.b.wb.z);
+        reward -= 0.01f * (yaw_rate * yaw_rate);
+        float ang = sqrtf(fmaf(V.b.rpy.x, V.b.rpy.x, V.b.rpy.y * V.b.rpy.y));
+        reward -= lin + ang;
+        reward += 1.0f;
+      }
+    } else if (TASK == PF_TASK_WAYPOINTS) {
+      if (!P.sparse_reward) {
+        float progress = (isinf(old_dist + new_dist)) ? 0.0f : old_dist - new_dist;
+        reward += __builtin_fmaxf(3.0f * progress, 0.0f);
+        reward += P.wp_dist_reward / new_dist;
+        if (P.wp_yaw_penalty != 0.0f) {
+          float yaw_rate = __builtin_fabsf(V.b.wb.z);
+          reward -= P.wp_yaw_penalty * (yaw_rate * yaw_rate);
+        }
+      }
+      if (new_dist < P.goal_reach_distance) {
+        reward = 100.0f;
+        pop_pending = true;  // the observation of this step still shows the reached target
+        bool all = (tg.n_left - 1) == 0;
+        if (all) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
+      }
+    }
+  };
+  // flattened observation row of this lane -> LDS tile (Appendix A of SURVEY.md)
+  auto write_obs_row = [&]() {
+    float* row = tile + tid * D;
+    int k = 0;
+    row[k++] = V.b.wb.x; row[k++] = V.b.wb.y; row[k++] = V.b.wb.z;
+    quat qe = quat_from_euler(V.b.rpy);
+    if (P.angle_repr) { row[k++] = qe.x; row[k++] = qe.y; row[k++] = qe.z; row[k++] = qe.w; }
+    else { row[k++] = V.b.rpy.x; row[k++] = V.b.rpy.y; row[k++] = V.b.rpy.z; }
+    row[k++] = V.b.vb.x; row[k++] = V.b.vb.y; row[k++] = V.b.vb.z;
+    row[k++] = V.b.p.x; row[k++] = V.b.p.y; row[k++] = V.b.p.z;
+    row[k++] = act4[0]; row[k++] = act4[1]; row[k++] = act4[2]; row[k++] = act4[3];
+    float aux[VEH::AUX];
+    V.aux(aux);
+#pragma unroll
+    for (int a = 0; a < VEH::AUX; ++a) row[k++] = aux[a];
+    if (TASK == PF_TASK_WAYPOINTS) {
+      m3 Re = rot_from_quat(qe);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < P.num_targets) {
+          v3 d = mulT(Re, v3{tg.t[i][0] - V.b.p.x, tg.t[i][1] - V.b.p.y, tg.t[i][2] - V.b.p.z});
+          bool live = i < tg.n_left;
+          row[k++] = live ? d.x : 0.0f; row[k++] = live ? d.y : 0.0f; row[k++] = live ? d.z : 0.0f;
+        }
+      }
+    }
+  };
+  // tile -> global, full-width. Rows [wave_base, wave_base+rows) are contiguous in the output.
+  auto flush_tile = [&](float* out, bool all_rows) {
+    __syncthreads();
+    if (all_rows) {
+      const int rows = min(kWave, n - wave_base);
+      const int total = rows * D;
+      float* g = out + (size_t)wave_base * D;
+      const int n4 = total >> 2;
+      const float4* t4 = reinterpret_cast<const float4*>(tile);
+      float4* g4 = reinterpret_cast<float4*>(g);
+      for (int i = tid; i < n4; i += kWave) g4[i] = t4[i];
+      for (int i = (n4 << 2) + tid; i < total; i += kWave) g[i] = tile[i];
+    } else if (active) {  // partial (masked reset): this lane writes its own row
+      float* g = out + (size_t)lane * D;
+      const float* row = tile + tid * D;
+      for (int k = 0; k < D; ++k) g[k] = row[k];
+    }
+    __syncthreads();
+  };
+
+  if (active) {
+    if (do_reset) {
+      begin_reset();
+    } else {
+      const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+      act4[0] = a.x; act4[1] = a.y; act4[2] = a.z; act4[3] = a.w;
+      sp[0] = a.x; sp[1] = a.y; sp[2] = a.z;
+      sp[3] = P.throttle_remap ? fmaf(a.w, 0.5f, 0.5f) : a.w;  // fixedwing_base_env.py:260
+      reward = -0.1f;
+      remaining = (term || trunc) ? 0 : P.env_step_ratio;
+      nz.begin_event(rng_ctr, 0u, B.xi);
+    }
+  }
+
+  // lanes past the end of the batch never write; a wave whose in-range lanes are all active can
+  // flush its observation tile with full-width stores
+  const bool wave_all = __all(active || !valid);
+  float out_reward = 0.0f;
+  bool out_term = false, out_trunc = false;
+  for (int phase = 0; phase < 2; ++phase) {
+    while (__any(remaining > 0)) {
+      if (remaining > 0) {
+        V.template aviary_step<MODE_T>(P, sp, nz, done_its * P.ticks_per_control);
+        rpy_valid = true;
+        remaining -= 1;
+        done_its += 1;
+        if (!settling) {
+          wp_distance();
+          term_trunc_reward();
+          if (term || trunc) remaining = 0;
+        }
+      }
+    }
+    if (phase == 1) break;
+    // ---- end of the step phase
+    const bool stepped = active && !settling && op == OP_STEP;
+    if (stepped) {
+      step_count += 1;  // quadx_base_env.py:299
+      rng_ctr += 1;
+      out_reward = reward; out_term = term; out_trunc = trunc;
+    }
+    const bool same = stepped && P.autoreset == PF_AUTORESET_SAME_STEP && (term || trunc);
+    if (!__any(same)) break;
+    if (B.final_obs != nullptr) {  // terminal observation, before the state is re-initialised
+      if (!rpy_valid) { V.b.rpy = euler_from_quat(V.b.q); rpy_valid = true; }
+      if (active) write_obs_row();
+      flush_tile(B.final_obs, wave_all);
+    }
+    if (same) begin_reset();  // the lane restarts inside the same call (quadx_base_env.py:149-212)
+  }
+
+  if (active && settling) {  // end_reset: compute_state after the settle steps (quadx_base_env.py:212)
+    wp_distance();
+    rng_ctr += 1;
+  }
+  if (active && !rpy_valid) { V.b.rpy = euler_from_quat(V.b.q); rpy_valid = true; }
+
+  // ---- outputs
+  if (active) {
+    write_obs_row();
+    if (pop_pending) { tg.pop(); pop_pending = false; }
+    flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
+            (trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0);
+    V.store(Sout, N, li, mode, new_dist, int4{step_count, flags, (int)rng_ctr, tg.n_left});
+    tg.store(Sout, N, li, VEH::G_TGT);
+    if (op == OP_STEP) {  // a NEXT_STEP reset call reports (r=0, not done), gymnasium's convention
+      B.reward[li] = out_reward;
+      B.terminated[li] = out_term ? 1 : 0;
+      B.truncated[li] = out_trunc ? 1 : 0;
+    }
+  }
+  flush_tile(B.obs, wave_all);
+}
+
+// ------------------------------------------------------------------ Aviary-level kernels
+template <class VEH>
+__global__ void __launch_bounds__(kWave) aviary_reset_kernel(const pf_params P, const pf_buffers B, const int n,
+                                                             const float* pose) {
+  const int lane = blockIdx.x * kWave + threadIdx.x;
+  if (lane >= n) return;
+  VEH V;
+  float sp[6];
+  V.reset(P, pose ? pose + (size_t)lane * 7 : nullptr, sp);
+  float4* S = reinterpret_cast<float4*>(B.state);
+  V.store(S, (size_t)n, (size_t)lane, /*mode=*/7, INFINITY, int4{0, 0, 0, 0});
+  if (B.out_state) {
+    float* o = B.out_state + (size_t)lane * 12;
+    o[0] = V.b.wb.x; o[1] = V.b.wb.y; o[2] = V.b.wb.z; o[3] = V.b.rpy.x; o[4] = V.b.rpy.y; o[5] = V.b.rpy.z;
+    o[6] = V.b.vb.x; o[7] = V.b.vb.y; o[8] = V.b.vb.z; o[9] = V.b.p.x; o[10] = V.b.p.y; o[11] = V.b.p.z;
+  }
+  if (B.out_aux) {
+    float aux[VEH::AUX];
+    V.aux(aux);
+    for (int k = 0; k < VEH::AUX; ++k) B.out_aux[(size_t)lane * VEH::AUX + k] = aux[k];
+  }
+}
+
+template <class VEH>
+__global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params P, const pf_buffers B, const int n,
+                                                                const int old_mode, const int new_mode, float* sp_out) {
+  const int lane = blockIdx.x * kWave + threadIdx.x;
+  if (lane >= n) return;
+  VEH V;
+  float nd;
+  int4 ints;
+  // load everything (old mode 7 == all groups), re-initialise the controllers, store everything
+  V.load(reinterpret_cast<const float4*>(B.state), (size_t)n, (size_t)lane, 7, nd, ints);
+  V.b.rpy = euler_from_quat(V.b.q);
+  float sp[6] = {0, 0, 0, 0, 0, 0};
+  if (sp_out)
+    for (int k = 0; k < VEH::SP; ++k) sp[k] = sp_out[(size_t)lane * VEH::SP + k];
+  V.set_mode(new_mode, sp);
+  V.store(reinterpret_cast<float4*>(B.state), (size_t)n, (size_t)lane, 7, nd, ints);
+  if (sp_out)
+    for (int k = 0; k < VEH::SP; ++k) sp_out[(size_t)lane * VEH::SP + k] = sp[k];
+  (void)old_mode;
+  (void)P;
+}
+
+template <class VEH>
+__global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, const pf_buffers B, const int n,
+                                                            const uint64_t lane0, const int n_steps) {
+  const int lane = blockIdx.x * kWave + threadIdx.x;
+  if (lane >= n) return;
+  const size_t li = lane, N = n;
+  VEH V;
+  float nd;
+  int4 ints;
+  const int mode = P.flight_mode;
+  V.load(reinterpret_cast<const float4*>(B.state), N, li, mode, nd, ints);
+  V.b.rpy = euler_from_quat(V.b.q);
+  uint32_t rng_ctr = (uint32_t)ints.z;
+  Noise nz;
+  nz.mode = P.noise_mode; nz.n = n; nz.lane = lane;
+  nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
+  nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
+  float sp[6] = {0, 0, 0, 0, 0, 0};
+  const int spn = (P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (k < spn) sp[k] = B.setpoints[li * spn + k];
+  bool contact = false;
+  for (int s = 0; s < n_steps; ++s) {
+    nz.begin_event(rng_ctr, 0u, B.xi ? B.xi + (size_t)s * P.ticks_per_control * N : nullptr);
+    V.template aviary_step<kRuntimeMode>(P, sp, nz, 0);
+    rng_ctr += 1;
+    contact = V.b.contact_step;
+  }
+  int flags = (ints.y & ~PF_F_CONTACT) | (V.b.contact_now ? PF_F_CONTACT : 0);
+  V.store(reinterpret_cast<float4*>(B.state), N, li, mode, nd, int4{ints.x, flags, (int)rng_ctr, ints.w});
+  if (B.out_state) {
+    float4* o = reinterpret_cast<float4*>(B.out_state + li * 12);
+    o[0] = float4{V.b.wb.x, V.b.wb.y, V.b.wb.z, V.b.rpy.x};
+    o[1] = float4{V.b.rpy.y, V.b.rpy.z, V.b.vb.x, V.b.vb.y};
+    o[2] = float4{V.b.vb.z, V.b.p.x, V.b.p.y, V.b.p.z};
+  }
+  if (B.out_aux) {
+    float aux[VEH::AUX];
+    V.aux(aux);
+    for (int k = 0; k < VEH::AUX; ++k) B.out_aux[li * VEH::AUX + k] = aux[k];
+  }
+  if (B.out_contact) B.out_contact[li] = contact ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) sample_actions_kernel(const pf_params P, float* actions, const int n,
+                                                             const uint64_t lane0, const uint32_t step_index) {
+  const int lane = blockIdx.x * 256 + threadIdx.x;
+  if (lane >= n) return;
+  f4 u = uniform4(philox4x32((uint32_t)P.seed, (uint32_t)(P.seed >> 32), (uint32_t)(lane0 + lane), step_index, 0u, 3u));
+  float4 a{fmaf(P.action_high[0] - P.action_low[0], u.a, P.action_low[0]),
+           fmaf(P.action_high[1] - P.action_low[1], u.b, P.action_low[1]),
+           fmaf(P.action_high[2] - P.action_low[2], u.c, P.action_low[2]),
+           fmaf(P.action_high[3] - P.action_low[3], u.d, P.action_low[3])};
+  reinterpret_cast<float4*>(actions)[lane] = a;
+}
+
+}  // namespace pf
+
+// ====================================================================== C ABI
+struct pf_ctx {
+  pf_params P;
+  int n;
+  int device;
+  uint64_t lane0;
+  char err[256];
+};
+static thread_local char g_err[256] = "";
+
+static int fail(pf_ctx* ctx, int code, const char* msg) {
+  snprintf(ctx ? ctx->err : g_err, 256, "%s", msg);
+  if (ctx) snprintf(g_err, 256, "%s", msg);
+  return code;
+}
+static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
+  char buf[256];
+  snprintf(buf, sizeof(buf), "%s: %s", where, hipGetErrorString(e));
+  return fail(ctx, (int)e, buf);
+}
+#define PF_HIP(ctx, call)                                   \
+  do {                                                      \
+    hipError_t e__ = (call);                                \
+    if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
+  } while (0)
+
+template <class VEH, int TASK>
+static void launch_env_t(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
+  const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
+  if (ctx->P.vehicle == PF_QUADX && ctx->P.flight_mode == 0)
+    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, 0>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask);
+  else
+    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, pf::kRuntimeMode>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask);
+}
+extern "C" {
+
+int pf_abi_version(void) { return PF_ABI_VERSION; }
+size_t pf_sizeof_params(void) { return sizeof(pf_params); }
+size_t pf_sizeof_buffers(void) { return sizeof(pf_buffers); }
+const char* pf_last_error(const pf_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lane_offset, pf_ctx** out) {
+  if (!params || !out || n_lanes <= 0) return fail(nullptr, PF_ERR_ARG, "pf_ctx_create: bad argument");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    return fail(nullptr, PF_ERR_NO_DEVICE, "pf_ctx_create: no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(nullptr, PF_ERR_ARG, "pf_ctx_create: bad device index");
+  const pf_params& P = *params;
+  if (P.vehicle != PF_QUADX && P.vehicle != PF_FIXEDWING) return fail(nullptr, PF_ERR_ARG, "unknown vehicle");
+  if (P.task == PF_TASK_WAYPOINTS && (P.num_targets < 1 || P.num_targets > 4))
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "num_targets must be in 1..4");
+  if (P.vehicle == PF_QUADX && (P.flight_mode < -1 || P.flight_mode > 7)) return fail(nullptr, PF_ERR_ARG, "quadx flight_mode must be in -1..7");
+  if (P.vehicle == PF_FIXEDWING && (P.flight_mode < -1 || P.flight_mode > 0)) return fail(nullptr, PF_ERR_ARG, "fixedwing flight_mode must be -1 or 0");
+  if (P.vehicle == PF_FIXEDWING && P.task == PF_TASK_HOVER) return fail(nullptr, PF_ERR_UNSUPPORTED, "no fixedwing hover task in the reference");
+  if (P.task != PF_TASK_NONE && P.vehicle == PF_FIXEDWING && P.flight_mode != 0) return fail(nullptr, PF_ERR_UNSUPPORTED, "fixedwing env uses flight_mode 0");
+  // quat_integrate()'s polynomial range: |w| dt / 2 <= pi/8 given the per-coordinate clamp
+  if (1.7320508f * P.max_coord_vel * P.dt * 0.5f > 0.3926991f + 1e-6f)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "max_coord_vel * dt too large for the exponential-map polynomial");
+  if (P.ticks_per_control < 1 || P.env_step_ratio < 0 || P.n_boxes > PF_MAX_BOXES) return fail(nullptr, PF_ERR_ARG, "bad loop constants");
+  pf_ctx* c = new (std::nothrow) pf_ctx;
+  if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
+  c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
+  *out = c;
+  return PF_OK;
+}
+void pf_ctx_destroy(pf_ctx* ctx) { delete ctx; }
+int pf_state_groups(const pf_ctx* ctx) { return ctx->P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : pf::Fixedwing::GROUPS; }
+int pf_obs_dim(const pf_ctx* ctx) {
+  const pf_params& P = ctx->P;
+  int aux = P.vehicle == PF_QUADX ? 4 : 6;
+  return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? 3 * P.num_targets : 0);
+}
+int pf_n_lanes(const pf_ctx* ctx) { return ctx->n; }
+
+static int ensure_device(pf_ctx* ctx) {
+  int cur = -1;
+  PF_HIP(ctx, hipGetDevice(&cur));
+  if (cur != ctx->device) PF_HIP(ctx, hipSetDevice(ctx->device));
+  return PF_OK;
+}
+
+static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, void* stream) {
+  if (!ctx || !b || !b->state || !b->obs) return fail(ctx, PF_ERR_ARG, "pf_env_*: state and obs buffers are required");
+  const pf_params& P = ctx->P;
+  if (P.task == PF_TASK_NONE) return fail(ctx, PF_ERR_ARG, "pf_env_*: context has no env task (use the pf_aviary_* calls)");
+  if (op == pf::OP_STEP && (!b->actions || !b->reward || !b->terminated || !b->truncated))
+    return fail(ctx, PF_ERR_ARG, "pf_env_step: actions/reward/terminated/truncated buffers are required");
+  if (P.noise_mode == PF_NOISE_INJECT && ((op == pf::OP_STEP && !b->xi) || !b->xi_reset))
+    if (!(op == pf::OP_STEP && P.autoreset == PF_AUTORESET_OFF && b->xi))
+      return fail(ctx, PF_ERR_ARG, "PF_NOISE_INJECT needs xi (step) and xi_reset (reset/auto-reset)");
+  int rc = ensure_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (P.vehicle == PF_QUADX) {
+    if (P.task == PF_TASK_HOVER) launch_env_t<pf::QuadX, PF_TASK_HOVER>(ctx, b, op, mask, s);
+    else launch_env_t<pf::QuadX, PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
+  } else {
+    launch_env_t<pf::Fixedwing, PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
+  }
+  PF_HIP(ctx, hipGetLastError());
+  return PF_OK;
+}
+int pf_env_reset(pf_ctx* ctx, const pf_buffers* b, const uint8_t* mask, void* stream) {
+  return launch_env(ctx, b, pf::OP_RESET, mask, stream);
+}
+int pf_env_step(pf_ctx* ctx, const pf_buffers* b, void* stream) { return launch_env(ctx, b, pf::OP_STEP, nullptr, stream); }
+
+int pf_aviary_reset(pf_ctx* ctx, const pf_buffers* b, void* stream) {
+  if (!ctx || !b || !b->state) return fail(ctx, PF_ERR_ARG, "pf_aviary_reset: state buffer required");
+  int rc = ensure_device(ctx);
+  if (rc) return rc;
+  const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
+  hipStream_t s = (hipStream_t)stream;
+  const float* pose = b->start_pose;
+  if (ctx->P.vehicle == PF_QUADX)
+    hipLaunchKernelGGL(pf::aviary_reset_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, pose);
+  else
+    hipLaunchKernelGGL(pf::aviary_reset_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, pose);
+  ctx->P.flight_mode = 0;  // drone.reset() -> set_mode(0) (quadx.py:224, fixedwing.py:196)
+  PF_HIP(ctx, hipGetLastError());
+  return PF_OK;
+}
+int pf_aviary_set_mode(pf_ctx* ctx, const pf_buffers* b, int mode, float* setpoints_out, void* stream) {
+  if (!ctx || !b || !b->state) return fail(ctx, PF_ERR_ARG, "pf_aviary_set_mode: state buffer required");
+  if (ctx->P.vehicle == PF_QUADX && (mode < -1 || mode > 7)) return fail(ctx, PF_ERR_ARG, "`mode` must be between -1 and 7");
+  if (ctx->P.vehicle == PF_FIXEDWING && (mode < -1 || mode > 0)) return fail(ctx, PF_ERR_ARG, "`mode` must be between -1 and 0");
+  int rc = ensure_device(ctx);
+  if (rc) return rc;
+  const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->P.vehicle == PF_QUADX)
+    hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->P.flight_mode, mode, setpoints_out);
+  else
+    hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->P.flight_mode, mode, setpoints_out);
+  ctx->P.flight_mode = mode;
+  PF_HIP(ctx, hipGetLastError());
+  return PF_OK;
+}
+int pf_aviary_step(pf_ctx* ctx, const pf_buffers* b, int n_steps, void* stream) {
+  if (!ctx || !b || !b->state || !b->setpoints) return fail(ctx, PF_ERR_ARG, "pf_aviary_step: state and setpoints required");
+  if (n_steps < 1) return fail(ctx, PF_ERR_ARG, "pf_aviary_step: n_steps must be >= 1");
+  if (ctx->P.noise_mode == PF_NOISE_INJECT && !b->xi) return fail(ctx, PF_ERR_ARG, "PF_NOISE_INJECT needs xi");
+  int rc = ensure_device(ctx);
+  if (rc) return rc;
+  const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->P.vehicle == PF_QUADX)
+    hipLaunchKernelGGL(pf::aviary_step_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps);
+  else
+    hipLaunchKernelGGL(pf::aviary_step_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps);
+  PF_HIP(ctx, hipGetLastError());
+  return PF_OK;
+}
+int pf_sample_actions(pf_ctx* ctx, float* actions, uint32_t step_index, void* stream) {
+  if (!ctx || !actions) return fail(ctx, PF_ERR_ARG, "pf_sample_actions: bad argument");
+  int rc = ensure_device(ctx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pf::sample_actions_kernel, dim3((ctx->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->P, actions, ctx->n, ctx->lane0, step_index);
+  PF_HIP(ctx, hipGetLastError());
+  return PF_OK;
+}
+
+}  // extern "C"

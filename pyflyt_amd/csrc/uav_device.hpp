@@ -1,0 +1,172 @@
+// uav_device.hpp -- device-side math for the batched UAV step (gfx950 / CDNA4, fp32).
+// One wavefront lane owns one drone; everything here is per-lane register arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PF_DEV __device__ __forceinline__
+
+namespace pf {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+struct v3 {
+  float x, y, z;
+};
+PF_DEV v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+PF_DEV v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+PF_DEV v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+PF_DEV v3 operator*(float s, v3 a) { return v3{s * a.x, s * a.y, s * a.z}; }
+PF_DEV float dot(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+PF_DEV v3 cross(v3 a, v3 b) {
+  return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+PF_DEV float clampf(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
+// x*|x| == sign(x)*x^2 (np.sign(x) * x**2 in the reference)
+PF_DEV float sq_signed(float x) { return x * __builtin_fabsf(x); }
+
+struct quat {
+  float x, y, z, w;
+};
+// body->world rotation, row major (btMatrix3x3::setRotation; quadx.py:521 uses its transpose)
+struct m3 {
+  float m00, m01, m02, m10, m11, m12, m20, m21, m22;
+};
+PF_DEV m3 rot_from_quat(quat q) {
+  float d = fmaf(q.x, q.x, fmaf(q.y, q.y, fmaf(q.z, q.z, q.w * q.w)));
+  float s = 2.0f / d;
+  float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+  float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+  float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+  return m3{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+}
+PF_DEV v3 mul(const m3& R, v3 a) {  // R a : body -> world
+  return v3{fmaf(R.m00, a.x, fmaf(R.m01, a.y, R.m02 * a.z)), fmaf(R.m10, a.x, fmaf(R.m11, a.y, R.m12 * a.z)),
+            fmaf(R.m20, a.x, fmaf(R.m21, a.y, R.m22 * a.z))};
+}
+PF_DEV v3 mulT(const m3& R, v3 a) {  // R^T a : world -> body
+  return v3{fmaf(R.m00, a.x, fmaf(R.m10, a.y, R.m20 * a.z)), fmaf(R.m01, a.x, fmaf(R.m11, a.y, R.m21 * a.z)),
+            fmaf(R.m02, a.x, fmaf(R.m12, a.y, R.m22 * a.z))};
+}
+// symmetric 3x3 stored xx xy xz yy yz zz
+PF_DEV v3 symmul(const float S[6], v3 a) {
+  return v3{fmaf(S[0], a.x, fmaf(S[1], a.y, S[2] * a.z)), fmaf(S[1], a.x, fmaf(S[3], a.y, S[4] * a.z)),
+            fmaf(S[2], a.x, fmaf(S[4], a.y, S[5] * a.z))};
+}
+
+// pybullet getEulerFromQuaternion (ZYX, gimbal-lock branch at |sarg| >= 0.99999) -- quadx.py:526
+PF_DEV v3 euler_from_quat(quat q) {
+  float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+  float sarg = -2.0f * (q.x * q.z - q.w * q.y) / (sqx + sqy + sqz + squ);
+  v3 e;
+  if (sarg <= -0.99999f) {
+    e = v3{0.0f, -0.5f * kPi, 2.0f * atan2f(q.x, -q.y)};
+  } else if (sarg >= 0.99999f) {
+    e = v3{0.0f, 0.5f * kPi, 2.0f * atan2f(-q.x, q.y)};
+  } else {
+    e.x = atan2f(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+    e.y = asinf(sarg);
+    e.z = atan2f(2.0f * (q.x * q.y + q.w * q.z), squ + sqx - sqy - sqz);
+  }
+  return e;
+}
+// pybullet getQuaternionFromEuler -- quadx_base_env.py:243
+PF_DEV quat quat_from_euler(v3 e) {
+  float sr, cr, sp, cp, sy, cy;
+  sincosf(0.5f * e.x, &sr, &cr);
+  sincosf(0.5f * e.y, &sp, &cp);
+  sincosf(0.5f * e.z, &sy, &cy);
+  quat q{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+  float inv = rsqrtf(fmaf(q.x, q.x, fmaf(q.y, q.y, fmaf(q.z, q.z, q.w * q.w))));
+  return quat{q.x * inv, q.y * inv, q.z * inv, q.w * inv};
+}
+
+// q <- exp(w dt/2) (x) q, normalised: btMultiBody::stepPositionsMultiDof. The half-angle
+// theta = |w| dt/2 is bounded by sqrt(3)*max_coord_vel*dt/2 <= pi/8 (enforced at context creation),
+// so sin(theta)/theta and cos(theta) are short even polynomials in theta^2: no sqrt, no trig.
+PF_DEV quat quat_integrate(quat q, v3 w, float half_dt) {
+  float t2 = dot(w, w) * (half_dt * half_dt);
+  float sinc = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, 2.7557319e-6f, -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+  float c = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, -2.7557319e-7f, 2.4801587e-5f), -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
+  float k = sinc * half_dt;
+  float ax = w.x * k, ay = w.y * k, az = w.z * k;
+  quat n{c * q.x + ax * q.w + ay * q.z - az * q.y, c * q.y + ay * q.w + az * q.x - ax * q.z,
+         c * q.z + az * q.w + ax * q.y - ay * q.x, c * q.w - ax * q.x - ay * q.y - az * q.z};
+  float inv = rsqrtf(fmaf(n.x, n.x, fmaf(n.y, n.y, fmaf(n.z, n.z, n.w * n.w))));
+  return quat{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
+}
+
+// ---------------------------------------------------------------- contact reporting
+// btBoxBoxDetector verdict (15 separating axes) for an oriented box against the world-aligned
+// ground box; see oracle/uav_oracle.c:orc_box_box_overlap for the restated rule.
+PF_DEV bool box_overlaps_aabb(v3 ca, const m3& R, const float ha[3], v3 cb, const float hb[3]) {
+  float t[3] = {ca.x - cb.x, ca.y - cb.y, ca.z - cb.z};
+  float Rm[3][3] = {{R.m00, R.m01, R.m02}, {R.m10, R.m11, R.m12}, {R.m20, R.m21, R.m22}};
+  float Q[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Q[i][j] = __builtin_fabsf(Rm[i][j]);
+  bool sep = false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float rad = hb[i] + Q[i][0] * ha[0] + Q[i][1] * ha[1] + Q[i][2] * ha[2];
+    sep |= (__builtin_fabsf(t[i]) - rad > 0.0f);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float proj = t[0] * Rm[0][j] + t[1] * Rm[1][j] + t[2] * Rm[2][j];
+    float rad = ha[j] + Q[0][j] * hb[0] + Q[1][j] * hb[1] + Q[2][j] * hb[2];
+    sep |= (__builtin_fabsf(proj) - rad > 0.0f);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      float expr1 = t[i2] * Rm[i1][j] - t[i1] * Rm[i2][j];
+      float rad = hb[i1] * (Q[i2][j] + 1e-5f) + hb[i2] * (Q[i1][j] + 1e-5f) + ha[j1] * (Q[i][j2] + 1e-5f) +
+                  ha[j2] * (Q[i][j1] + 1e-5f);
+      sep |= (__builtin_fabsf(expr1) - rad > 2.220446e-16f);
+    }
+  }
+  return !sep;
+}
+
+// ---------------------------------------------------------------- counter-based RNG
+// Philox4x32-10; integer stream bit-identical to oracle/uav_oracle.c:orc_philox4x32.
+struct u32x4 {
+  uint32_t a, b, c, d;
+};
+PF_DEV u32x4 philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return u32x4{c0, c1, c2, c3};
+}
+// 23-bit uniform in (0,1), exact in fp32
+PF_DEV float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
+struct f4 {
+  float a, b, c, d;
+};
+PF_DEV f4 uniform4(u32x4 r) { return f4{u01(r.a), u01(r.b), u01(r.c), u01(r.d)}; }
+// Box-Muller on (a,b) and (c,d). v_sin/v_cos take revolutions: sin(2 pi u) = __builtin_amdgcn_sinf(u).
+PF_DEV f4 normal4(u32x4 r) {
+  f4 u = uniform4(r);
+  float ra = sqrtf(-2.0f * __logf(u.a)), rb = sqrtf(-2.0f * __logf(u.c));
+  return f4{ra * __builtin_amdgcn_cosf(u.b), ra * __builtin_amdgcn_sinf(u.b), rb * __builtin_amdgcn_cosf(u.d),
+            rb * __builtin_amdgcn_sinf(u.d)};
+}
+PF_DEV float pick4(f4 v, uint32_t i) {
+  float lo = (i & 1u) ? v.b : v.a, hi = (i & 1u) ? v.d : v.c;
+  return (i & 2u) ? hi : lo;
+}
+
+}  // namespace pf

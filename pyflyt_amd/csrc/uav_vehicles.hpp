@@ -1,0 +1,468 @@
+// uav_vehicles.hpp -- per-lane "vehicle programs": the batched equivalent of the reference's
+// DroneClass contract (core/abstractions/base_drone.py:139-241: reset / update_control /
+// update_physics / update_state) fused with the Bullet free-body tick, one drone per lane, fp32.
+#pragma once
+#include "../../include/pyflyt_amd.h"
+#include "uav_device.hpp"
+
+namespace pf {
+
+// ------------------------------------------------------------------------------------------
+// Motor-noise source. INJECT reads raw draws xi ~ N(num_motors, 1) laid out [tick][n] (coalesced);
+// PHILOX derives them from (seed, global lane, event counter, call, stream) -- same integer stream
+// as the oracle. motors.py:134-138.
+struct Noise {
+  int mode;
+  const float* xi;  // current phase's injected draws
+  int n, lane;
+  uint32_t k0, k1, c0, c1, stream;
+  float nmot;
+  int cached;
+  f4 z;
+  PF_DEV void begin_event(uint32_t ctr, uint32_t strm, const float* inj) {
+    c1 = ctr; stream = strm; xi = inj; cached = -1;
+  }
+  PF_DEV float get(int flat) {
+    if (mode == PF_NOISE_OFF) return 0.0f;
+    if (mode == PF_NOISE_INJECT) return xi[(size_t)flat * n + lane];
+    int call = flat >> 2;
+    if (call != cached) {
+      z = normal4(philox4x32(k0, k1, c0, c1, (uint32_t)call, stream));
+      cached = call;
+    }
+    return nmot + pick4(z, (uint32_t)flat & 3u);
+  }
+  PF_DEV float uniform(int flat, uint32_t strm) const {  // uncached, for reset-time sampling
+    f4 u = uniform4(philox4x32(k0, k1, c0, c1, (uint32_t)(flat >> 2), strm));
+    return pick4(u, (uint32_t)flat & 3u);
+  }
+};
+
+// abstractions/pid.py:70-94 for one component
+PF_DEV float pid1(float kp, float ki, float kd, float lim, float T, float invT, float& I, float& E, float st, float sp) {
+  float e = sp - st;
+  I = clampf(fmaf(ki * e, T, I), -lim, lim);
+  float d = kd * (e - E) * invT;
+  E = e;
+  return clampf(kp * e + I + d, -lim, lim);
+}
+
+// Rigid body shared by both vehicles: the Bullet base state + what update_state derives from it.
+struct Body {
+  v3 p;
+  quat q;
+  v3 v, w;      // world frame, at the base origin
+  m3 R;         // body -> world
+  v3 wb, vb;    // quadx.py:522-523
+  v3 rpy;       // quadx.py:526 (refreshed once per Aviary step)
+  bool contact_now, contact_step;
+
+  PF_DEV void derive() {
+    R = rot_from_quat(q);
+    wb = mulT(R, w);
+    vb = mulT(R, v);
+  }
+  // collision detection at the current pose against the ground box (aviary.py:240-242,523-525)
+  PF_DEV bool detect_contact(const pf_params& P) const {
+    if (p.z - P.bound_radius > 0.0f) return false;
+    const float hb[3] = {P.plane_half_xy, P.plane_half_xy, P.plane_half_z};
+    v3 cb{0.0f, 0.0f, -P.plane_half_z};
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < PF_MAX_BOXES; ++k) {
+      if (k < P.n_boxes) {
+        v3 c = p + mul(R, v3{P.boxes[k].c[0], P.boxes[k].c[1], P.boxes[k].c[2]});
+        hit |= box_overlaps_aabb(c, R, P.boxes[k].h, cb, hb);
+      }
+    }
+    return hit;
+  }
+  // stepSimulation (aviary.py:516): collision detection at the pre-integration pose, then the
+  // semi-implicit Euler free-body tick. F, tau: body frame; tau about the base origin.
+  PF_DEV void tick(const pf_params& P, v3 F, v3 tau) {
+    contact_now = detect_contact(P);
+    v3 com{P.com[0], P.com[1], P.com[2]};
+    if (P.has_com_offset) tau = tau - cross(com, F);
+    v3 h = symmul(P.I_pa, wb);
+    if (P.use_gyro_term) h = h + symmul(P.I_own, wb);
+    v3 wdot_b = symmul(P.I_inv, tau - cross(wb, h));
+    v3 wdot = mul(R, wdot_b);
+    v3 a = P.inv_mass * mul(R, F);
+    a.z += P.gravity_z;
+    if (P.has_com_offset) {
+      v3 cw = mul(R, com);
+      a = a - cross(wdot, cw) - cross(w, cross(w, cw));
+    }
+    const float dt = P.dt, vm = P.max_coord_vel;
+    w = v3{clampf(fmaf(wdot.x, dt, w.x), -vm, vm), clampf(fmaf(wdot.y, dt, w.y), -vm, vm), clampf(fmaf(wdot.z, dt, w.z), -vm, vm)};
+    v = v3{clampf(fmaf(a.x, dt, v.x), -vm, vm), clampf(fmaf(a.y, dt, v.y), -vm, vm), clampf(fmaf(a.z, dt, v.z), -vm, vm)};
+    p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z)};
+    q = quat_integrate(q, w, 0.5f * dt);
+    derive();
+    contact_step |= contact_now;
+  }
+  PF_DEV void spawn(const pf_params& P, const float* pose /* [7] or null */) {
+    if (pose) {
+      p = v3{pose[0], pose[1], pose[2]};
+      q = quat{pose[3], pose[4], pose[5], pose[6]};
+    } else {
+      p = v3{P.start_pos[0], P.start_pos[1], P.start_pos[2]};
+      q = quat{P.start_quat[0], P.start_quat[1], P.start_quat[2], P.start_quat[3]};
+    }
+    v = v3{P.start_vel[0], P.start_vel[1], P.start_vel[2]};
+    w = v3{0.0f, 0.0f, 0.0f};
+    contact_now = false;
+    contact_step = false;
+    derive();
+    rpy = euler_from_quat(q);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// QuadX: drones/quadx.py. MODE_T == kRuntimeMode selects the flight mode from pf_params at run
+// time; any other value folds the cascade at compile time (mode 0 is the env hot path).
+constexpr int kRuntimeMode = 100;
+
+struct QuadX {
+  static constexpr int GROUPS = 15, G_INT = 6, G_TGT = 12, AUX = 4, SP = 4;
+  Body b;
+  float thr[4];
+  float pwm[4];
+  float I0[3], E0[3];                    // ang_vel PID
+  float I1[3], E1[3];                    // ang_pos PID
+  float I2[2], E2[2], I3[2], E3[2];      // lin_vel, lin_pos PIDs
+  float zI[2], zE[2];                    // z_vel, z_pos PIDs
+
+  static PF_DEV bool needs_cascade(int mode) { return mode > 0; }
+
+  PF_DEV void load(const float4* S, size_t n, size_t i, int mode, float& new_dist, int4& ints) {
+    float4 g0 = S[0 * n + i], g1 = S[1 * n + i], g2 = S[2 * n + i], g3 = S[3 * n + i], g4 = S[4 * n + i],
+           g5 = S[5 * n + i];
+    float4 gi = S[6 * n + i];
+    b.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
+    b.q = quat{g1.x, g1.y, g1.z, g1.w};
+    b.v = v3{g2.x, g2.y, g2.z};
+    b.w = v3{g2.w, g3.x, g3.y};
+    thr[0] = g3.z; thr[1] = g3.w; thr[2] = g4.x; thr[3] = g4.y;
+    I0[0] = g4.z; I0[1] = g4.w; I0[2] = g5.x;
+    E0[0] = g5.y; E0[1] = g5.z; E0[2] = g5.w;
+    ints = int4{__float_as_int(gi.x), __float_as_int(gi.y), __float_as_int(gi.z), __float_as_int(gi.w)};
+    if (needs_cascade(mode)) {
+      float4 g7 = S[7 * n + i], g8 = S[8 * n + i], g9 = S[9 * n + i], g10 = S[10 * n + i], g11 = S[11 * n + i];
+      I1[0] = g7.x; I1[1] = g7.y; I1[2] = g7.z; E1[0] = g7.w;
+      E1[1] = g8.x; E1[2] = g8.y; I2[0] = g8.z; I2[1] = g8.w;
+      E2[0] = g9.x; E2[1] = g9.y; I3[0] = g9.z; I3[1] = g9.w;
+      E3[0] = g10.x; E3[1] = g10.y; zI[0] = g10.z; zI[1] = g10.w;
+      zE[0] = g11.x; zE[1] = g11.y;
+    } else {
+      zero_cascade();
+      zI[0] = zI[1] = zE[0] = zE[1] = 0.0f;
+    }
+    b.contact_now = (ints.y & PF_F_CONTACT) != 0;
+    b.contact_step = false;
+    b.derive();
+    if (needs_cascade(mode)) b.rpy = euler_from_quat(b.q);
+    else b.rpy = v3{0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pwm[k] = 0.0f;
+  }
+  PF_DEV void store(float4* S, size_t n, size_t i, int mode, float new_dist, int4 ints) const {
+    S[0 * n + i] = float4{b.p.x, b.p.y, b.p.z, new_dist};
+    S[1 * n + i] = float4{b.q.x, b.q.y, b.q.z, b.q.w};
+    S[2 * n + i] = float4{b.v.x, b.v.y, b.v.z, b.w.x};
+    S[3 * n + i] = float4{b.w.y, b.w.z, thr[0], thr[1]};
+    S[4 * n + i] = float4{thr[2], thr[3], I0[0], I0[1]};
+    S[5 * n + i] = float4{I0[2], E0[0], E0[1], E0[2]};
+    S[6 * n + i] = float4{__int_as_float(ints.x), __int_as_float(ints.y), __int_as_float(ints.z), __int_as_float(ints.w)};
+    if (needs_cascade(mode)) {
+      S[7 * n + i] = float4{I1[0], I1[1], I1[2], E1[0]};
+      S[8 * n + i] = float4{E1[1], E1[2], I2[0], I2[1]};
+      S[9 * n + i] = float4{E2[0], E2[1], I3[0], I3[1]};
+      S[10 * n + i] = float4{E3[0], E3[1], zI[0], zI[1]};
+      S[11 * n + i] = float4{zE[0], zE[1], 0.0f, 0.0f};
+    }
+  }
+  PF_DEV void zero_cascade() {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) I1[k] = E1[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) I2[k] = E2[k] = I3[k] = E3[k] = 0.0f;
+  }
+  // set_mode (quadx.py:233-373): fresh PID objects (NOT the z PIDs, quadx.py:206) + default setpoint
+  PF_DEV void set_mode(int mode, float sp[6]) {
+    if (mode == -1) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) I0[k] = E0[k] = 0.0f;
+    zero_cascade();
+    sp[0] = sp[1] = sp[2] = sp[3] = 0.0f;
+    if (mode == 0) sp[3] = -1.0f;
+    else if (mode == 1 || mode == 5 || mode == 6) {}
+    else if (mode == 7) { sp[0] = b.p.x; sp[1] = b.p.y; sp[2] = b.rpy.z; sp[3] = b.p.z; }
+    else sp[3] = b.p.z;
+  }
+  // drone.reset() + update_state (quadx.py:222-231, aviary.py:310-311); setpoint -> zeros(4)
+  PF_DEV void reset(const pf_params& P, const float* pose, float sp[6]) {
+    b.spawn(P, pose);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) thr[k] = pwm[k] = 0.0f;
+    set_mode(0, sp);
+    sp[0] = sp[1] = sp[2] = sp[3] = 0.0f;
+    zI[0] = zI[1] = zE[0] = zE[1] = 0.0f;
+  }
+  PF_DEV void pid3(const pf_pid& g, const pf_params& P, float* I, float* E, v3 st, float a[3], int n) {
+    const float s[3] = {st.x, st.y, st.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < n) a[k] = pid1(g.kp[k], g.ki[k], g.kd[k], g.lim[k], P.control_period, P.inv_control_period, I[k], E[k], s[k], a[k]);
+  }
+  // update_control (quadx.py:401-493)
+  template <int MODE_T>
+  PF_DEV void control(const pf_params& P, const float sp[6]) {
+    const int mode = (MODE_T == kRuntimeMode) ? P.flight_mode : MODE_T;
+    float a[3] = {sp[0], sp[1], sp[2]};
+    float z = sp[3];
+    if (mode == -1) {
+      pwm[0] = a[0]; pwm[1] = a[1]; pwm[2] = a[2]; pwm[3] = z;
+      return;
+    }
+    if (mode == 0 || mode == 2) {
+      pid3(P.pid[0], P, I0, E0, b.wb, a, 3);
+    } else if (mode == 1 || mode == 3) {
+      pid3(P.pid[1], P, I1, E1, b.rpy, a, 3);
+      pid3(P.pid[0], P, I0, E0, b.wb, a, 3);
+    } else {
+      if (mode == 7) pid3(P.pid[3], P, I3, E3, b.p, a, 2);
+      if (mode == 6 || mode == 7) {  // quadx.py:448-451,460-463
+        float s, c;
+        sincosf(b.rpy.z, &s, &c);
+        float a0 = c * a[0] + s * a[1], a1 = -s * a[0] + c * a[1];
+        a[0] = a0; a[1] = a1;
+      }
+      pid3(P.pid[2], P, I2, E2, b.vb, a, 2);
+      { float t0 = -a[1], t1 = a[0]; a[0] = t0; a[1] = t1; }
+      pid3(P.pid[1], P, I1, E1, b.rpy, a, mode == 7 ? 3 : 2);
+      pid3(P.pid[0], P, I0, E0, b.wb, a, 3);
+    }
+    if (mode == 0) {
+      z = clampf(z, 0.0f, 1.0f);
+    } else {
+      if (!(mode == 1 || mode == 5 || mode == 6))
+        z = pid1(P.zpid[1].kp[0], P.zpid[1].ki[0], P.zpid[1].kd[0], P.zpid[1].lim[0], P.control_period,
+                 P.inv_control_period, zI[1], zE[1], b.p.z, z);
+      z = pid1(P.zpid[0].kp[0], P.zpid[0].ki[0], P.zpid[0].kd[0], P.zpid[0].lim[0], P.control_period,
+               P.inv_control_period, zI[0], zE[0], b.vb.z, z);
+      z = clampf(z, 0.0f, 1.0f);
+    }
+    // mixing + saturation handling (quadx.py:482-493)
+    const float cmd[4] = {a[0], a[1], a[2], z};
+    float hi = -INFINITY, lo = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = P.motor_map[i][0] * cmd[0] + P.motor_map[i][1] * cmd[1] + P.motor_map[i][2] * cmd[2] + P.motor_map[i][3] * cmd[3];
+      pwm[i] = s;
+      hi = __builtin_fmaxf(hi, s);
+      lo = __builtin_fminf(lo, s);
+    }
+    if (hi != lo) {
+      float pmax = __builtin_fminf(hi, 1.0f), pmin = __builtin_fmaxf(lo, 0.05f);
+      float ka = (pmin - lo) / (pmax - lo), ks = (hi - pmax) / (hi - pmin);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pwm[i] += ka * (pmax - pwm[i]) - ks * (pwm[i] - pmin);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pwm[i] = clampf(pwm[i], 0.05f, 1.0f);
+  }
+  // update_physics + stepSimulation + update_state for one tick (quadx.py:495-535)
+  PF_DEV void tick(const pf_params& P, float xi) {
+    v3 F{-P.drag_const[0] * sq_signed(b.vb.x), -P.drag_const[1] * sq_signed(b.vb.y), -P.drag_const[2] * sq_signed(b.vb.z)};
+    v3 tau{0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // motors.py:131-138,182-193
+      float t = fmaf(P.motor_dt_over_tau[i], pwm[i] - thr[i], thr[i]);
+      t = fmaf(xi * t, P.motor_noise[i], t);
+      thr[i] = t;
+      float k = sq_signed(t);
+      float f = k * P.motor_fmax[i];
+      F.z += f;
+      tau.x = fmaf(P.motor_r[i][1], f, tau.x);
+      tau.y = fmaf(-P.motor_r[i][0], f, tau.y);
+      tau.z = fmaf(k, P.motor_tmax[i], tau.z);
+    }
+    if (!b.contact_now) {  // quadx.py:502-510
+      tau.x = fmaf(-P.drag_coef_pqr, sq_signed(b.wb.x), tau.x);
+      tau.y = fmaf(-P.drag_coef_pqr, sq_signed(b.wb.y), tau.y);
+      tau.z = fmaf(-P.drag_coef_pqr, sq_signed(b.wb.z), tau.z);
+    }
+    b.tick(P, F, tau);
+  }
+  // one Aviary.step (aviary.py:480-531): control on the first tick, pwm held afterwards
+  template <int MODE_T>
+  PF_DEV void aviary_step(const pf_params& P, const float sp[6], Noise& nz, int flat_base) {
+    b.contact_step = false;
+    control<MODE_T>(P, sp);
+    for (int t = 0; t < P.ticks_per_control; ++t) tick(P, nz.get(flat_base + t));
+    b.rpy = euler_from_quat(b.q);
+  }
+  PF_DEV void aux(float* o) const {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = thr[k];
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// Fixedwing: drones/fixedwing.py + abstractions/lifting_surfaces.py
+struct Fixedwing {
+  static constexpr int GROUPS = 9, G_INT = 5, G_TGT = 6, AUX = 6, SP = 6;
+  Body b;
+  float act[5];
+  float thr;
+
+  PF_DEV void load(const float4* S, size_t n, size_t i, int mode, float& new_dist, int4& ints) {
+    (void)mode;
+    float4 g0 = S[0 * n + i], g1 = S[1 * n + i], g2 = S[2 * n + i], g3 = S[3 * n + i], g4 = S[4 * n + i];
+    float4 gi = S[5 * n + i];
+    b.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
+    b.q = quat{g1.x, g1.y, g1.z, g1.w};
+    b.v = v3{g2.x, g2.y, g2.z};
+    b.w = v3{g2.w, g3.x, g3.y};
+    act[0] = g3.z; act[1] = g3.w; act[2] = g4.x; act[3] = g4.y; act[4] = g4.z; thr = g4.w;
+    ints = int4{__float_as_int(gi.x), __float_as_int(gi.y), __float_as_int(gi.z), __float_as_int(gi.w)};
+    b.contact_now = (ints.y & PF_F_CONTACT) != 0;
+    b.contact_step = false;
+    b.derive();
+    b.rpy = v3{0.0f, 0.0f, 0.0f};
+  }
+  PF_DEV void store(float4* S, size_t n, size_t i, int mode, float new_dist, int4 ints) const {
+    (void)mode;
+    S[0 * n + i] = float4{b.p.x, b.p.y, b.p.z, new_dist};
+    S[1 * n + i] = float4{b.q.x, b.q.y, b.q.z, b.q.w};
+    S[2 * n + i] = float4{b.v.x, b.v.y, b.v.z, b.w.x};
+    S[3 * n + i] = float4{b.w.y, b.w.z, act[0], act[1]};
+    S[4 * n + i] = float4{act[2], act[3], act[4], thr};
+    S[5 * n + i] = float4{__int_as_float(ints.x), __int_as_float(ints.y), __int_as_float(ints.z), __int_as_float(ints.w)};
+  }
+  PF_DEV void set_mode(int mode, float sp[6]) {  // fixedwing.py:206-227
+    (void)mode;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sp[k] = 0.0f;
+  }
+  PF_DEV void reset(const pf_params& P, const float* pose, float sp[6]) {  // fixedwing.py:194-204
+    b.spawn(P, pose);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) act[k] = 0.0f;
+    thr = 0.0f;
+    set_mode(0, sp);
+  }
+  // lifting_surfaces.py:266-498 for one surface; returns force & torque in the (axis-aligned) link frame
+  PF_DEV void surface(const pf_surface& S, v3 vloc, float a, v3& F, v3& T) const {
+    v3 lift{S.lift[0], S.lift[1], S.lift[2]}, drag{S.drag[0], S.drag[1], S.drag[2]};
+    float V2 = dot(vloc, vloc);
+    float la = dot(vloc, lift), fa = dot(vloc, drag);
+    float alpha = atan2f(-la, fa);  // :342-345
+    // :386-394
+    float defl = a * S.deflection_limit_rad;
+    float dCl = S.Cl_alpha_3D * S.aero_tau_eta * defl;
+    float dClmax = S.flap_to_chord * dCl;
+    float ClmaxP = fmaf(S.Cl_alpha_3D, S.alpha_stall_P_base - S.alpha_0_base, dClmax);
+    float ClmaxN = fmaf(S.Cl_alpha_3D, S.alpha_stall_N_base - S.alpha_0_base, dClmax);
+    float a0 = S.alpha_0_base - dCl * S.inv_Cl_alpha_3D;
+    float aP = fmaf(ClmaxP, S.inv_Cl_alpha_3D, a0), aN = fmaf(ClmaxN, S.inv_Cl_alpha_3D, a0);
+    float Cl, Cd, CM;
+    if (aN < alpha && alpha < aP) {  // :397-406
+      Cl = S.Cl_alpha_3D * (alpha - a0);
+      float ai = Cl * S.inv_pi_aspect;
+      float ae = alpha - a0 - ai;
+      float se, ce;
+      sincosf(ae, &se, &ce);
+      float CT = S.Cd_0 * ce;
+      float CN = (Cl + CT * se) / ce;
+      Cd = CN * se + CT * ce;
+      CM = -CN * (0.25f - 0.175f * (1.0f - 2.0f * ae * (1.0f / kPi)));
+    } else {  // :409-448
+      float ai;
+      if (alpha > 0.0f) {
+        float ai_stall = S.Cl_alpha_3D * (aP - a0) * S.inv_pi_aspect;
+        float x0 = aP, x1 = 0.5f * kPi;
+        ai = (alpha <= x0) ? ai_stall : (alpha >= x1 ? 0.0f : ai_stall - ai_stall / (x1 - x0) * (alpha - x0));
+      } else {
+        float ai_stall = S.Cl_alpha_3D * (aN - a0) * S.inv_pi_aspect;
+        float x0 = -0.5f * kPi, x1 = aN;
+        ai = (alpha <= x0) ? 0.0f : (alpha >= x1 ? ai_stall : ai_stall / (x1 - x0) * (alpha - x0));
+      }
+      float ae = alpha - a0 - ai;
+      float se, ce;
+      sincosf(ae, &se, &ce);
+      float Cd90 = fmaf(-4.26e-2f, defl * defl, fmaf(2.1e-1f, defl, 1.98f));
+      float CN = Cd90 * se * (1.0f / (0.56f + 0.44f * __builtin_fabsf(se)) - S.exp_term);
+      float CT = 0.5f * S.Cd_0 * ce;
+      Cl = CN * ce - CT * se;
+      Cd = CN * se + CT * ce;
+      CM = -CN * (0.25f - 0.175f * (1.0f - 2.0f * __builtin_fabsf(ae) * (1.0f / kPi)));
+    }
+    // :485-498
+    float QA = S.half_rho_area * V2;
+    float L = Cl * QA, D = Cd * QA;
+    float sa, ca;
+    sincosf(alpha, &sa, &ca);
+    float fn = L * ca + D * sa, fp = L * sa - D * ca;
+    F = v3{lift.x * fn + drag.x * fp, lift.y * fn + drag.y * fp, lift.z * fn + drag.z * fp};
+    float tm = QA * CM * S.chord;
+    T = v3{tm * S.torque[0], tm * S.torque[1], tm * S.torque[2]};
+  }
+  float cmd[6];
+  template <int MODE_T>
+  PF_DEV void control(const pf_params& P, const float sp[6]) {  // fixedwing.py:229-259
+    if (P.flight_mode == -1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cmd[k] = sp[k];
+    } else {
+      const float s4[4] = {sp[0], sp[1], sp[2], sp[3]};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        int id = P.assist_ids[k];
+        float val = id == 0 ? s4[0] : (id == 1 ? s4[1] : (id == 2 ? s4[2] : s4[3]));
+        cmd[k] = val * P.assist_signs[k];
+      }
+    }
+  }
+  PF_DEV void tick(const pf_params& P, float xi) {
+    v3 F{0.0f, 0.0f, 0.0f}, tau{0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < PF_MAX_SURF; ++i) {
+      const pf_surface& S = P.surf[i];
+      act[i] = fmaf(S.dt_over_tau, cmd[i] - act[i], act[i]);  // lifting_surfaces.py:277
+      v3 r{S.r[0], S.r[1], S.r[2]};
+      v3 vloc = b.vb + cross(b.wb, r);  // lifting_surfaces.py:73-110
+      v3 f, t;
+      surface(S, vloc, act[i], f, t);
+      F = F + f;
+      tau = tau + cross(r, f) + t;
+    }
+    {  // motor (fixedwing.py:147-168,264), thrust along +x at the base origin
+      float t = fmaf(P.motor_dt_over_tau[0], cmd[5] - thr, thr);
+      t = fmaf(xi * t, P.motor_noise[0], t);
+      thr = t;
+      float k = sq_signed(t);
+      v3 u{P.thrust_unit[0][0], P.thrust_unit[0][1], P.thrust_unit[0][2]};
+      v3 f = (k * P.motor_fmax[0]) * u;
+      v3 r{P.motor_r[0][0], P.motor_r[0][1], P.motor_r[0][2]};
+      F = F + f;
+      tau = tau + cross(r, f) + (k * P.motor_tmax[0]) * u;
+    }
+    b.tick(P, F, tau);
+  }
+  template <int MODE_T>
+  PF_DEV void aviary_step(const pf_params& P, const float sp[6], Noise& nz, int flat_base) {
+    b.contact_step = false;
+    control<MODE_T>(P, sp);
+    for (int t = 0; t < P.ticks_per_control; ++t) tick(P, nz.get(flat_base + t));
+    b.rpy = euler_from_quat(b.q);
+  }
+  PF_DEV void aux(float* o) const {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = act[k];
+    o[5] = thr;
+  }
+};
+
+}  // namespace pf

@@ -1,0 +1,170 @@
+"""BatchEngine: owns the PyTorch-ROCm tensors of one batched simulation and drives the HIP kernels
+through the C ABI (include/pyflyt_amd.h). PyTorch is plumbing here -- device memory and streams;
+all arithmetic happens in libpyflyt_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchEngine:
+    """N independent drones ("lanes") on one GPU.
+
+    Tensors (all on `device`):
+      state      [groups, n, 4] float32  persistent SoA state (float4 groups)
+      obs        [n, obs_dim]   float32
+      final_obs  [n, obs_dim]   float32  (SAME_STEP auto-reset only)
+      reward     [n]            float32
+      terminated [n], truncated [n]  bool
+    """
+
+    def __init__(self, params: L.PfParams, num_lanes: int, device="cuda:0", lane_offset: int = 0):
+        if not torch.cuda.is_available():
+            raise L.PyFlytAmdError("pyflyt_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.PyFlytAmdError(f"device must be a ROCm 'cuda' device, got {device}")
+        self.params = params
+        self.n = int(num_lanes)
+        self.lane_offset = int(lane_offset)
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._ctx = C.c_void_p()
+        L.check(self.lib.pf_ctx_create(C.byref(params), self.n, index, self.lane_offset, C.byref(self._ctx)))
+        self.groups = self.lib.pf_state_groups(self._ctx)
+        self.obs_dim = self.lib.pf_obs_dim(self._ctx)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.state = torch.zeros(self.groups, self.n, 4, **f32)
+        self.obs = torch.zeros(self.n, self.obs_dim, **f32)
+        self.final_obs = torch.zeros(self.n, self.obs_dim, **f32) if params.autoreset == L.AUTORESET_SAME_STEP else None
+        self.reward = torch.zeros(self.n, **f32)
+        self.terminated = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+        self.truncated = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+        self.out_state = None
+        self.out_aux = None
+        self.out_contact = None
+        self._buf = L.PfBuffers()
+
+    def close(self):
+        if self._ctx:
+            self.lib.pf_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _buffers(self, actions=None, xi=None, xi_reset=None, u_targets=None, setpoints=None, start_pose=None):
+        b = self._buf
+        b.state = _ptr(self.state)
+        b.actions = _ptr(actions)
+        b.obs = _ptr(self.obs)
+        b.final_obs = _ptr(self.final_obs)
+        b.reward = _ptr(self.reward)
+        b.terminated = _ptr(self.terminated)
+        b.truncated = _ptr(self.truncated)
+        b.xi = _ptr(xi)
+        b.xi_reset = _ptr(xi_reset)
+        b.u_targets = _ptr(u_targets)
+        b.setpoints = _ptr(setpoints)
+        b.out_state = _ptr(self.out_state)
+        b.out_aux = _ptr(self.out_aux)
+        b.out_contact = _ptr(self.out_contact)
+        b.start_pose = _ptr(start_pose)
+        return b
+
+    def _check_f32(self, t, shape, name):
+        if t is None:
+            return None
+        if t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} must be a contiguous float32 tensor of shape {tuple(shape)} on {self.device}, "
+                             f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+        return t
+
+    @property
+    def ticks_per_step(self):
+        return self.params.env_step_ratio * self.params.ticks_per_control
+
+    @property
+    def settle_ticks(self):
+        return self.params.settle_steps * self.params.ticks_per_control
+
+    # ------------------------------------------------------------------ env level
+    def env_reset(self, mask=None, xi_reset=None, u_targets=None):
+        if mask is not None:
+            if mask.dtype != torch.bool and mask.dtype != torch.uint8:
+                raise ValueError("mask must be a bool/uint8 tensor")
+            mask = mask.to(device=self.device).contiguous()
+        self._check_f32(xi_reset, (self.settle_ticks, self.n), "xi_reset")
+        b = self._buffers(xi_reset=xi_reset, u_targets=u_targets)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_env_reset(self._ctx, C.byref(b), _ptr(mask), self._stream()), self._ctx)
+        return self.obs
+
+    def env_step(self, actions, xi=None, xi_reset=None, u_targets=None):
+        self._check_f32(actions, (self.n, 4), "actions")
+        self._check_f32(xi, (self.ticks_per_step, self.n), "xi")
+        self._check_f32(xi_reset, (self.settle_ticks, self.n), "xi_reset")
+        b = self._buffers(actions=actions, xi=xi, xi_reset=xi_reset, u_targets=u_targets)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_env_step(self._ctx, C.byref(b), self._stream()), self._ctx)
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def sample_actions(self, out, step_index: int):
+        self._check_f32(out, (self.n, 4), "out")
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_sample_actions(self._ctx, _ptr(out), int(step_index) & 0xFFFFFFFF, self._stream()), self._ctx)
+        return out
+
+    # ------------------------------------------------------------------ Aviary level
+    def _aviary_outputs(self):
+        if self.out_state is None:
+            aux = 4 if self.params.vehicle == L.QUADX else 6
+            self.out_state = torch.zeros(self.n, 12, dtype=torch.float32, device=self.device)
+            self.out_aux = torch.zeros(self.n, aux, dtype=torch.float32, device=self.device)
+            self.out_contact = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+
+    def aviary_reset(self, start_pose=None):
+        self._aviary_outputs()
+        self._check_f32(start_pose, (self.n, 7), "start_pose")
+        b = self._buffers(start_pose=start_pose)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_aviary_reset(self._ctx, C.byref(b), self._stream()), self._ctx)
+        self.params.flight_mode = 0
+
+    def aviary_set_mode(self, mode: int, setpoints):
+        self._aviary_outputs()
+        b = self._buffers()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_aviary_set_mode(self._ctx, C.byref(b), int(mode), _ptr(setpoints), self._stream()), self._ctx)
+        self.params.flight_mode = int(mode)
+
+    def aviary_step(self, setpoints, n_steps: int = 1, xi=None):
+        self._aviary_outputs()
+        b = self._buffers(setpoints=setpoints, xi=xi)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_aviary_step(self._ctx, C.byref(b), int(n_steps), self._stream()), self._ctx)
+        return self.out_state, self.out_aux
+
+    # ------------------------------------------------------------------ state views
+    def ints(self):
+        """[n, 4] int32 view: step_count, flags, rng_ctr, n_targets_left."""
+        g = 6 if self.params.vehicle == L.QUADX else 5
+        return self.state[g].view(torch.int32)
+
+    def flags(self):
+        return self.ints()[:, 1]

@@ -1,0 +1,306 @@
+"""Vehicle / env constants -> pf_params.
+
+The numbers below are copied (as numbers, with citations) from the reference's model files --
+file:line relative to /root/reference/PyFlyt/ -- and turned, in float64 on the host, into the
+derived constants the kernels consume (rounded to fp32 exactly once). Users can override any
+entry through the `vehicle_options` / env kwargs, mirroring the reference's `drone_options`.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Any
+
+import numpy as np
+
+from . import _lib as L
+
+# --------------------------------------------------------------------------- model tables
+CF2X: dict[str, Any] = {
+    # models/vehicles/cf2x/cf2x.urdf:13-14 (base link), :30-36 (collision box), :42,54,66,78 (prop COMs)
+    "mass": 0.027,
+    "inertia_diag": (1.4e-5, 1.4e-5, 2.17e-5),
+    "collision_boxes": [((0.0, 0.0, 0.0), (0.09, 0.09, 0.02))],
+    "motor_r": [(0.028, -0.028, 0.0), (-0.028, 0.028, 0.0), (0.028, 0.028, 0.0), (-0.028, -0.028, 0.0)],
+    # models/vehicles/cf2x/cf2x.yaml:1-6
+    "total_thrust": 2.0, "thrust_coef": 3.16e-10, "torque_coef": 7.94e-12, "noise_ratio": 0.02, "motor_tau": 0.01,
+    # drones/quadx.py:94-101 (torque signs), :130-137 (motor map)
+    "torque_signs": (-1.0, -1.0, 1.0, 1.0),
+    "motor_map": [(-1.0, -1.0, -1.0, 1.0), (1.0, 1.0, -1.0, 1.0), (1.0, -1.0, 1.0, 1.0), (-1.0, 1.0, 1.0, 1.0)],
+    # cf2x.yaml:8-11
+    "drag_coef_xyz": 3.0, "drag_area_xyz": 4.0e-4, "drag_coef_pqr": 1.0e-4,
+    # cf2x.yaml:13-54 (kp, ki, kd, lim)
+    "pid": {
+        "ang_vel": ([4.0e-2, 4.0e-2, 8.0e-2], [5.0e-7, 5.0e-7, 2.7e-4], [1.0e-4, 1.0e-4, 0.0], [1.0, 1.0, 1.0]),
+        "ang_pos": ([2.0, 2.0, 2.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [3.0, 3.0, 3.0]),
+        "lin_vel": ([0.8, 0.8], [0.3, 0.3], [0.5, 0.5], [0.4, 0.4]),
+        "lin_pos": ([1.0, 1.0], [0.0, 0.0], [0.0, 0.0], [2.0, 2.0]),
+        "z_pos": ([1.0], [0.0], [0.0], [1.0]),
+        "z_vel": ([2.0], [0.5], [0.05], [1.0]),
+    },
+    "control_hz": 120,  # drones/quadx.py:27
+}
+
+_SURF_COMMON = dict(Cl_alpha_2D=6.283, flap_to_chord=0.3, eta=0.65, Cd_0=0.01, tau=0.05)
+FIXEDWING: dict[str, Any] = {
+    # models/vehicles/fixedwing/fixedwing.urdf: (mass, link origin) -- all link inertias are zero
+    "links": [
+        (0.3, (0.0, 0.0, 0.0)),      # base_link :16-20
+        (0.1, (-1.1, 0.0, 0.0)),     # horizontal_tail :39-43,58
+        (0.05, (-1.1, 0.0, 0.15)),   # vertical_tail :65-69,84
+        (0.2, (-0.5, 0.95, 0.0)),    # ail_left :91-95,110
+        (0.2, (-0.5, -0.95, 0.0)),   # ail_right :117-121,136
+        (0.5, (-0.5, 0.0, 0.0)),     # main_wing :143-147,162
+        (1.0, (-0.45, 0.0, 0.0)),    # fuselage :169-173,188
+    ],
+    # collision boxes :44-49,70-75,96-101,122-127,148-153,174-179 (centre, size)
+    "collision_boxes": [
+        ((-1.1, 0.0, 0.0), (0.3, 0.6, 0.05)), ((-1.1, 0.0, 0.15), (0.3, 0.05, 0.3)),
+        ((-0.5, 0.95, 0.0), (0.31, 0.3, 0.06)), ((-0.5, -0.95, 0.0), (0.31, 0.3, 0.06)),
+        ((-0.5, 0.0, 0.0), (0.3, 1.8, 0.05)), ((-0.45, 0.0, 0.0), (1.4, 0.2, 0.2)),
+    ],
+    # models/vehicles/fixedwing/fixedwing.yaml:1-6 ; drones/fixedwing.py:147-168
+    "total_thrust": 18.0, "thrust_coef": 3.16e-10, "torque_coef": 7.94e-12, "noise_ratio": 0.02, "motor_tau": 0.01,
+    "motor_r": (0.0, 0.0, 0.0), "thrust_unit": (1.0, 0.0, 0.0),
+    # surfaces in the order of drones/fixedwing.py:80-138; params fixedwing.yaml:8-71
+    "surfaces": [
+        dict(name="left_aileron", r=(-0.5, 0.95, 0.0), lift=(0, 0, 1), chord=0.3, span=0.3, alpha_0_base=-2.0,
+             alpha_stall_P_base=14.0, alpha_stall_N_base=-9.0, deflection_limit=30.0, **_SURF_COMMON),
+        dict(name="right_aileron", r=(-0.5, -0.95, 0.0), lift=(0, 0, 1), chord=0.3, span=0.3, alpha_0_base=-2.0,
+             alpha_stall_P_base=14.0, alpha_stall_N_base=-9.0, deflection_limit=30.0, **_SURF_COMMON),
+        dict(name="horizontal_tail", r=(-1.1, 0.0, 0.0), lift=(0, 0, 1), chord=0.2, span=0.625, alpha_0_base=0.0,
+             alpha_stall_P_base=9.0, alpha_stall_N_base=-9.0, deflection_limit=20.0, **_SURF_COMMON),
+        dict(name="vertical_tail", r=(-1.1, 0.0, 0.15), lift=(0, 1, 0), chord=0.2, span=0.312, alpha_0_base=0.0,
+             alpha_stall_P_base=9.0, alpha_stall_N_base=-9.0, deflection_limit=20.0, **_SURF_COMMON),
+        dict(name="main_wing", r=(-0.5, 0.0, 0.0), lift=(0, 0, 1), chord=0.3, span=1.6, alpha_0_base=-2.0,
+             alpha_stall_P_base=14.0, alpha_stall_N_base=-9.0, deflection_limit=0.0, **_SURF_COMMON),
+    ],
+    "assist_ids": (0, 0, 1, 2, 1, 3),                   # drones/fixedwing.py:143
+    "assist_signs": (1.0, -1.0, 1.0, -1.0, -1.0, 1.0),  # drones/fixedwing.py:144
+    "starting_velocity": (20.0, 0.0, 0.0),              # drones/fixedwing.py:35
+    "control_hz": 120,                                  # drones/fixedwing.py:24
+}
+
+WORLD: dict[str, Any] = {
+    "physics_hz": 240,         # core/aviary.py:79
+    "gravity_z": -9.81,        # core/aviary.py:226
+    "world_scale": 1.0,        # core/aviary.py:80
+    # [BULLET-FROM-MEMORY]: named so they can be corrected
+    "use_gyro_term": True,     # btMultiBody::m_useGyroTerm
+    "max_coord_vel": 100.0,    # btMultiBody::m_maxCoordinateVelocity
+    "plane_half_xy": 15.0,     # pybullet_data plane.urdf collision box 30 x 30 x 10, centre z = -5
+    "plane_half_z": 5.0,
+}
+
+
+def quat_from_euler(rpy):
+    """pybullet getQuaternionFromEuler (x, y, z, w)."""
+    phi, the, psi = (0.5 * float(a) for a in rpy)
+    q = np.array([
+        math.sin(phi) * math.cos(the) * math.cos(psi) - math.cos(phi) * math.sin(the) * math.sin(psi),
+        math.cos(phi) * math.sin(the) * math.cos(psi) + math.sin(phi) * math.cos(the) * math.sin(psi),
+        math.cos(phi) * math.cos(the) * math.sin(psi) - math.sin(phi) * math.sin(the) * math.cos(psi),
+        math.cos(phi) * math.cos(the) * math.cos(psi) + math.sin(phi) * math.sin(the) * math.sin(psi),
+    ])
+    return q / np.linalg.norm(q)
+
+
+def _sym6(M):
+    return [M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]]
+
+
+def _fill(arr, vals):
+    for i, v in enumerate(vals):
+        arr[i] = v
+
+
+def _set_body(P, links, own_inertia, boxes):
+    """links: [(mass, r)], own_inertia: 3x3 sum of link inertias (base frame, about their own COMs)."""
+    m = np.array([l[0] for l in links], dtype=np.float64)
+    r = np.array([l[1] for l in links], dtype=np.float64)
+    M = m.sum()
+    com = (m[:, None] * r).sum(0) / M
+    I_pa = np.zeros((3, 3))
+    for mi, ri in zip(m, r):
+        d = ri - com
+        I_pa += mi * ((d @ d) * np.eye(3) - np.outer(d, d))
+    I_inv = np.linalg.inv(own_inertia + I_pa)
+    P.inv_mass = 1.0 / M
+    _fill(P.com, com)
+    _fill(P.I_own, _sym6(own_inertia))
+    _fill(P.I_pa, _sym6(I_pa))
+    _fill(P.I_inv, _sym6(I_inv))
+    P.has_com_offset = int(np.abs(com).max() > 0.0)
+    P.n_boxes = len(boxes)
+    rad = 0.0
+    for k, (c, size) in enumerate(boxes):
+        h = 0.5 * np.array(size, dtype=np.float64)
+        _fill(P.boxes[k].c, c)
+        _fill(P.boxes[k].h, h)
+        rad = max(rad, float(np.linalg.norm(np.abs(np.array(c)) + h)))
+    # nudged up so that fp32 rounding can never make the early-out stricter than the exact test
+    P.bound_radius = rad * (1.0 + 1e-6)
+
+
+def _set_pid(dst, kp, ki, kd, lim):
+    _fill(dst.kp, kp); _fill(dst.ki, ki); _fill(dst.kd, kd); _fill(dst.lim, lim)
+
+
+def build_params(
+    vehicle: str,
+    task: str = "none",
+    *,
+    flight_mode: int = 0,
+    noise: str = "philox",
+    autoreset: str = "next_step",
+    seed: int = 0,
+    angle_representation: str = "quaternion",
+    sparse_reward: bool = False,
+    flight_dome_size: float | None = None,
+    max_duration_seconds: float | None = None,
+    agent_hz: int | None = None,
+    num_targets: int = 4,
+    goal_reach_distance: float | None = None,
+    start_pos=None,
+    start_orn=None,
+    vehicle_options: dict | None = None,
+    world_options: dict | None = None,
+) -> L.PfParams:
+    """vehicle in {'quadx','fixedwing'}; task in {'none','hover','waypoints'}."""
+    W = dict(WORLD, **(world_options or {}))
+    P = L.PfParams()
+    P.noise_mode = {"off": L.NOISE_OFF, "inject": L.NOISE_INJECT, "philox": L.NOISE_PHILOX}[noise]
+    P.autoreset = {"off": L.AUTORESET_OFF, "disabled": L.AUTORESET_OFF, "next_step": L.AUTORESET_NEXT_STEP,
+                   "same_step": L.AUTORESET_SAME_STEP}[autoreset]
+    P.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    if angle_representation not in ("euler", "quaternion"):
+        raise ValueError(f"angle_representation must be either `euler` or `quaternion`, not {angle_representation}")
+    P.angle_repr = 1 if angle_representation == "quaternion" else 0
+    P.sparse_reward = int(bool(sparse_reward))
+    P.flight_mode = int(flight_mode)
+    dt = 1.0 / W["physics_hz"]
+    P.dt = dt
+    P.gravity_z = W["gravity_z"]
+    P.max_coord_vel = W["max_coord_vel"]
+    P.use_gyro_term = int(bool(W["use_gyro_term"]))
+    P.plane_half_xy = W["plane_half_xy"] * W["world_scale"]
+    P.plane_half_z = W["plane_half_z"] * W["world_scale"]
+    P.settle_steps = 10  # gym_envs/quadx_envs/quadx_base_env.py:209
+
+    if vehicle == "quadx":
+        V = copy.deepcopy(CF2X)
+        V.update(vehicle_options or {})
+        P.vehicle = L.QUADX
+        _set_body(P, [(V["mass"], (0.0, 0.0, 0.0))], np.diag(V["inertia_diag"]).astype(np.float64), V["collision_boxes"])
+        P.n_motors = 4
+        max_rpm = math.sqrt(V["total_thrust"] / (4.0 * V["thrust_coef"]))  # drones/quadx.py:111-113
+        for i in range(4):
+            _fill(P.motor_r[i], V["motor_r"][i])
+            _fill(P.thrust_unit[i], (0.0, 0.0, 1.0))
+            P.motor_dt_over_tau[i] = dt / V["motor_tau"]
+            P.motor_fmax[i] = V["thrust_coef"] * max_rpm**2
+            P.motor_tmax[i] = V["torque_signs"][i] * V["torque_coef"] * max_rpm**2
+            P.motor_noise[i] = V["noise_ratio"]
+            _fill(P.motor_map[i], V["motor_map"][i])
+        _fill(P.drag_const, [0.5 * 1.225 * V["drag_coef_xyz"] * V["drag_area_xyz"]] * 3)  # boring_bodies.py:63
+        P.drag_coef_pqr = V["drag_coef_pqr"]
+        for k, name in enumerate(("ang_vel", "ang_pos", "lin_vel", "lin_pos")):
+            _set_pid(P.pid[k], *V["pid"][name])
+        _set_pid(P.zpid[0], *V["pid"]["z_vel"])
+        _set_pid(P.zpid[1], *V["pid"]["z_pos"])
+        default_start, start_vel = (0.0, 0.0, 1.0), (0.0, 0.0, 0.0)  # quadx_base_env.py:23
+        xyz, thr = math.pi, 0.8  # quadx_base_env.py:80-102
+        if flight_mode == -1:
+            low, high = (0.0, 0.0, 0.0, 0.0), (thr, thr, thr, thr)
+        else:
+            low, high = (-xyz, -xyz, -xyz, 0.0), (xyz, xyz, xyz, thr)
+    elif vehicle == "fixedwing":
+        V = copy.deepcopy(FIXEDWING)
+        V.update(vehicle_options or {})
+        P.vehicle = L.FIXEDWING
+        _set_body(P, V["links"], np.zeros((3, 3)), V["collision_boxes"])
+        P.n_motors = 1
+        max_rpm = math.sqrt(V["total_thrust"] / V["thrust_coef"])  # drones/fixedwing.py:152-154
+        _fill(P.motor_r[0], V["motor_r"])
+        _fill(P.thrust_unit[0], V["thrust_unit"])
+        P.motor_dt_over_tau[0] = dt / V["motor_tau"]
+        P.motor_fmax[0] = V["thrust_coef"] * max_rpm**2
+        P.motor_tmax[0] = V["torque_coef"] * max_rpm**2
+        P.motor_noise[0] = V["noise_ratio"]
+        P.n_surf = len(V["surfaces"])
+        assert P.n_surf == L.PF_MAX_SURF
+        for i, s in enumerate(V["surfaces"]):  # abstractions/lifting_surfaces.py:228-239
+            S = P.surf[i]
+            lift = np.array(s["lift"], dtype=np.float64)
+            drag = np.array((1.0, 0.0, 0.0))
+            aspect = s["span"] / s["chord"]
+            Cl3D = s["Cl_alpha_2D"] * (aspect / (aspect + ((2.0 * (aspect + 4.0)) / (aspect + 2.0))))
+            theta_f = math.acos(2.0 * s["flap_to_chord"] - 1.0)
+            aero_tau = 1.0 - ((theta_f - math.sin(theta_f)) / math.pi)
+            _fill(S.r, s["r"]); _fill(S.lift, lift); _fill(S.drag, drag); _fill(S.torque, np.cross(lift, drag))
+            S.Cl_alpha_3D = Cl3D
+            S.inv_Cl_alpha_3D = 1.0 / Cl3D
+            S.aero_tau_eta = aero_tau * s["eta"]
+            S.flap_to_chord = s["flap_to_chord"]
+            S.inv_pi_aspect = 1.0 / (math.pi * aspect)
+            S.exp_term = 0.41 * (1.0 - math.exp(-17.0 / aspect))
+            S.alpha_0_base = math.radians(s["alpha_0_base"])
+            S.alpha_stall_P_base = math.radians(s["alpha_stall_P_base"])
+            S.alpha_stall_N_base = math.radians(s["alpha_stall_N_base"])
+            S.Cd_0 = s["Cd_0"]
+            S.deflection_limit_rad = math.radians(s["deflection_limit"])
+            S.dt_over_tau = dt / s["tau"]
+            S.half_rho_area = 0.5 * 1.225 * s["chord"] * s["span"]
+            S.chord = s["chord"]
+        _fill(P.assist_ids, V["assist_ids"])
+        _fill(P.assist_signs, V["assist_signs"])
+        default_start, start_vel = (0.0, 0.0, 10.0), V["starting_velocity"]  # fixedwing_waypoints_env.py:63
+        low, high = (-1.0,) * 4, (1.0,) * 4  # fixedwing_base_env.py:78-80
+    else:
+        raise ValueError(f"unknown vehicle {vehicle!r}")
+
+    control_hz = V["control_hz"]
+    if W["physics_hz"] % control_hz != 0:  # base_drone.py:95-98
+        raise ValueError(f"`physics_hz` ({W['physics_hz']}) must be multiple of `control_hz` ({control_hz}).")
+    P.ticks_per_control = W["physics_hz"] // control_hz
+    P.control_period = 1.0 / control_hz
+    P.inv_control_period = float(control_hz)
+    _fill(P.action_low, low)
+    _fill(P.action_high, high)
+
+    # ---- task constants (defaults of the reference's env constructors)
+    if task == "none":
+        P.task = L.TASK_NONE
+        d_dome, d_dur, d_hz, d_reach = math.inf, 10.0, 30, 0.2
+        P.env_step_ratio = 1
+    elif task == "hover":  # quadx_hover_env.py:32-37
+        P.task = L.TASK_HOVER
+        d_dome, d_dur, d_hz, d_reach = 3.0, 10.0, 40, 0.2
+    elif task == "waypoints":
+        P.task = L.TASK_WAYPOINTS
+        if vehicle == "quadx":  # quadx_waypoints_env.py:38-47,87
+            d_dome, d_dur, d_hz, d_reach = 5.0, 10.0, 30, 0.2
+            P.min_height, P.wp_dist_reward, P.wp_yaw_penalty = 0.1, 0.1, 0.01
+        else:  # fixedwing_waypoints_env.py:36-45,81
+            d_dome, d_dur, d_hz, d_reach = 100.0, 120.0, 30, 2.0
+            P.min_height, P.wp_dist_reward, P.wp_yaw_penalty = 0.5, 1.0, 0.0
+            P.throttle_remap = 1
+        P.num_targets = int(num_targets)
+    else:
+        raise ValueError(f"unknown task {task!r}")
+    hz = d_hz if agent_hz is None else int(agent_hz)
+    if 120 % hz != 0:  # quadx_base_env.py:47-52
+        lowest = int(120 / (int(120 / hz) + 1))
+        highest = int(120 / int(120 / hz))
+        raise ValueError(f"`agent_hz` must be round denominator of 120, try {lowest} or {highest}.")
+    dur = d_dur if max_duration_seconds is None else float(max_duration_seconds)
+    P.max_steps = int(hz * dur)
+    if task != "none":
+        P.env_step_ratio = int(120 / hz)
+    dome = d_dome if flight_dome_size is None else float(flight_dome_size)
+    P.dome = min(dome, 3.0e38)
+    P.goal_reach_distance = d_reach if goal_reach_distance is None else float(goal_reach_distance)
+    _fill(P.start_pos, default_start if start_pos is None else start_pos)
+    _fill(P.start_quat, quat_from_euler((0.0, 0.0, 0.0) if start_orn is None else start_orn))
+    _fill(P.start_vel, start_vel)
+    return P

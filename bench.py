@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: env-steps/sec of the fused QuadX-Hover env step.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
+Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json metric): PyFlyt/QuadX-Hover (flight mode 0, 40 Hz agent -> 6 physics ticks
+and 3 control ticks per env step, quaternion observation, dense reward), batch 65 536 drones PER
+GPU (weak scaling, config[4]: 524 288 over 8 GPUs), motor noise ON (counter-based Philox,
+xi ~ N(4,1) as in motors.py:134-138), uniformly random actions in the action box, NEXT_STEP
+auto-reset (gymnasium VectorEnv default) with its 20 settle ticks inside the timed region.
+One "step" = one pf_env_step launch over the whole per-GPU batch: actions [n,4] read from HBM,
+obs [n,21] / reward / terminated / truncated written to HBM, persistent state round-trips HBM.
+The batch shards embarrassingly: no collective in the timed loop.
+
+The K timed steps are replayed from HIP graphs (launch-bound inner loop -> hipGraph), each graph
+node one env step reading its own pre-generated action batch (inputs resident in HBM).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic HBM bytes per env step per lane:
+#   reads  128 B = 7 state float4 groups (112) + action float4 (16)
+#   writes 202 B = 7 state groups (112) + obs 21 f32 (84) + reward (4) + terminated (1) + truncated (1)
+ALGO_BYTES = {"hover": 330, "quadx_waypoints": 442, "fixedwing_waypoints": 418}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=65536, help="lanes per GPU")
+    ap.add_argument("--env", default="hover", choices=["hover", "quadx_waypoints", "fixedwing_waypoints"])
+    ap.add_argument("--noise", default="philox", choices=["philox", "off"])
+    ap.add_argument("--graph-steps", type=int, default=100, help="env steps captured per HIP graph")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_engine(env, batch, device, lane_offset, noise):
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    vehicle, task = {"hover": ("quadx", "hover"), "quadx_waypoints": ("quadx", "waypoints"),
+                     "fixedwing_waypoints": ("fixedwing", "waypoints")}[env]
+    P = build_params(vehicle, task, noise=noise, autoreset="next_step", seed=0)
+    return BatchEngine(P, batch, device=device, lane_offset=lane_offset)
+
+
+def cpu_baseline(env, noise, seconds):
+    """The fp64 oracle (a port, not the reference itself) on the host cores, OpenMP over lanes,
+    same tick structure and auto-reset, bounded to ~`seconds` of wall time."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    n = 4096
+    mode = O.NOISE_PHILOX if noise == "philox" else O.NOISE_OFF
+    P = O.make_params(env, noise_mode=mode, seed=0)
+    ob = O.OracleBatch(P, n)
+    ob.reset()
+    rng = np.random.default_rng(0)
+    low = np.array([-np.pi] * 3 + [0.0]) if env != "fixedwing_waypoints" else -np.ones(4)
+    high = np.array([np.pi] * 3 + [0.8]) if env != "fixedwing_waypoints" else np.ones(4)
+    acts = [rng.uniform(low, high, size=(n, 4)).astype(np.float32) for _ in range(16)]
+    ob.step(acts[0], autoreset=1)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < seconds:
+        ob.step(acts[k % 16], autoreset=1)
+        k += 1
+    dt = time.perf_counter() - t0
+    cores = O.lib().orc_num_threads()
+    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"fp64 C restatement (oracle/uav_oracle.c), {env}, batch {n}, {k} steps in {dt:.1f} s, OpenMP over lanes"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    n = args.batch
+    eng = make_engine(args.env, n, device, lane_offset=rank * n, noise=args.noise)
+    g = max(1, min(args.graph_steps, args.steps))
+    ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(g)]
+    for i, a in enumerate(ring):
+        eng.sample_actions(a, i)
+    eng.env_reset()
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.Stream(device=device)
+    graph = None
+    with torch.cuda.stream(stream):
+        for i in range(min(args.warmup, g)):  # also warms the kernel before capture
+            eng.env_step(ring[i % g])
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(g):
+                    eng.env_step(ring[i])
+
+        def run(k):
+            done = 0
+            if graph is not None:
+                while k - done >= g:
+                    graph.replay()
+                    done += g
+            while done < k:
+                eng.env_step(ring[done % g])
+                done += 1
+
+        run(max(0, args.warmup - min(args.warmup, g)))
+        stream.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run(args.steps)
+        ev1.record(stream)
+        stream.synchronize()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+    ev_ms = ev0.elapsed_time(ev1)
+    t = torch.tensor([wall, ev_ms * 1e-3], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max, ev_max = float(t[0]), float(t[1])
+
+    # sanity: the simulation actually advanced and stayed finite
+    ints = eng.ints()
+    assert torch.isfinite(eng.obs).all(), "non-finite observation"
+    assert int(ints[:, 2].min()) >= args.steps, "event counter did not advance"
+
+    if rank == 0:
+        total_lanes = n * world
+        value = total_lanes * args.steps / wall_max
+        per_launch_s = ev_max / args.steps  # HIP events on the launch stream, per pf_env_step launch
+        algo = ALGO_BYTES[args.env] * n
+        achieved = algo / per_launch_s / 1e9
+        out = {
+            "metric": "env-steps/sec (whole node), QuadX-Hover batch=65536 per GPU" if args.env == "hover" else f"env-steps/sec (whole node), {args.env}",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PyFlyt/QuadX-Hover-v4 semantics, flight_mode 0, batch {n}/GPU x {world} GPU(s), "
+                                   f"random actions, motor noise {args.noise}, NEXT_STEP auto-reset"
+                       if args.env == "hover" else f"{args.env}, batch {n}/GPU x {world}",
+                       "batch_per_gpu": n, "global_batch": total_lanes, "ticks_per_env_step": eng.ticks_per_step,
+                       "launch": "hipGraph" if graph is not None else "eager", "parallelism": f"dp{world} (independent lanes, no collective)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pf::env_kernel", "algorithmic_bytes_per_launch": algo,
+                         "launch_us": per_launch_s * 1e6},
+        }
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("env") == args.env and rec.get("batch") == n:
+                    out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.env, args.noise, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,11 +11,13 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
 #include "../../include/pyflyt_amd.h"
 #include "uav_vehicles.hpp"
+#include "quadx_fast.hpp"
 
 namespace pf {
 
@@ -421,6 +423,13 @@ struct pf_ctx {
   int device;
   uint64_t lane0;
   char err[256];
+  // hot-path specialisation (quadx_fast.hpp)
+  bool fast;
+  pf::QuadK K;
+  pf_params* P_dev;  // device copy of P for the rarely-taken floor-contact path
+  int lpw;           // live lanes per wavefront (64, 32 or 16)
+  int wps;           // register budget: waves per SIMD the kernel variant is compiled for (2 or 4)
+  int n_simd;
 };
 static thread_local char g_err[256] = "";
 
@@ -440,6 +449,17 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
     if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); \
   } while (0)
 
+template <int TASK>
+static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
+  const int lpw = ctx->lpw;
+  const int grid = (ctx->n + lpw - 1) / lpw;
+#define PF_FAST(L, W) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, L, W>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
+  const int wps = ctx->wps;
+  if (lpw == 64) { if (wps >= 4) PF_FAST(64, 4); else PF_FAST(64, 2); }
+  else if (lpw == 32) { if (wps >= 4) PF_FAST(32, 4); else PF_FAST(32, 2); }
+  else { if (wps >= 4) PF_FAST(16, 4); else PF_FAST(16, 2); }
+#undef PF_FAST
+}
 template <class VEH, int TASK>
 static void launch_env_t(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
@@ -476,10 +496,33 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
+  c->P_dev = nullptr; c->lpw = 64; c->wps = 2; c->n_simd = 1024;
+  c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
+  if (c->fast) {
+    int cur = -1;
+    hipGetDevice(&cur);
+    hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_simd = prop.multiProcessorCount * 4;
+    hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
+    if (e == hipSuccess) e = hipMemcpy(c->P_dev, &P, sizeof(pf_params), hipMemcpyHostToDevice);
+    if (cur >= 0) hipSetDevice(cur);
+    if (e != hipSuccess) { delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
+    // Under-fill wavefronts when the batch cannot give every SIMD several full waves: a wave's
+    // dependent-instruction latency is then hidden by its neighbours instead of idling the SIMD.
+    const long want = 4L * c->n_simd;
+    c->lpw = (n_lanes / 64 >= want) ? 64 : ((n_lanes / 32 >= want) ? 32 : 16);
+    if (const char* o = getenv("PF_LPW")) { int v = atoi(o); if (v == 64 || v == 32 || v == 16) c->lpw = v; }
+    if (const char* o = getenv("PF_WPS")) { int v = atoi(o); if (v == 2 || v == 4) c->wps = v; }
+  }
   *out = c;
   return PF_OK;
 }
-void pf_ctx_destroy(pf_ctx* ctx) { delete ctx; }
+void pf_ctx_destroy(pf_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->P_dev) hipFree(ctx->P_dev);
+  delete ctx;
+}
 int pf_state_groups(const pf_ctx* ctx) { return ctx->P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : pf::Fixedwing::GROUPS; }
 int pf_obs_dim(const pf_ctx* ctx) {
   const pf_params& P = ctx->P;
@@ -507,7 +550,10 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
   int rc = ensure_device(ctx);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (P.vehicle == PF_QUADX) {
+  if (ctx->fast) {
+    if (P.task == PF_TASK_HOVER) launch_fast<PF_TASK_HOVER>(ctx, b, op, mask, s);
+    else launch_fast<PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
+  } else if (P.vehicle == PF_QUADX) {
     if (P.task == PF_TASK_HOVER) launch_env_t<pf::QuadX, PF_TASK_HOVER>(ctx, b, op, mask, s);
     else launch_env_t<pf::QuadX, PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
   } else {

@@ -1,0 +1,534 @@
+// quadx_fast.hpp -- the hand-tuned hot kernel: QuadX, flight mode 0 (rate PID + thrust), Hover and
+// Waypoints tasks. This is the kernel BASELINE.json's metric is quoted on.
+//
+// What makes it lean (measured with rocprofv3 PMC, profiles/):
+//   * a compact, vehicle-specific constant block (QuadK, ~60 dwords) instead of the generic
+//     pf_params, so every constant lives in SGPRs (no SGPR->VGPR spill traffic);
+//   * structural facts the reference hard-codes (quadx.py:94-101,130-137: +z thrust axis, torque
+//     signs, the +-1 motor map; identical motors) are compile-time, not data;
+//   * no libm: v_rcp/v_rsq/v_sqrt, polynomial atan2, half-angle algebra for the observation
+//     quaternion, polynomial exponential map;
+//   * the reset's 10 settle Aviary steps collapse to a 20-tick vertical recurrence when the spawn
+//     pose is level and at rest (always true for the Hover/Waypoints envs), so lanes that
+//     auto-reset cost ~1/4 of an env step instead of 3x one;
+//   * LPW (lanes per wave): for batches smaller than the machine (65 536 drones = one wave per
+//     SIMD on 256 CUs x 4 SIMDs) waves are launched under-filled (16 or 32 live lanes) so that
+//     every SIMD holds several waves and their dependent-instruction latencies overlap.
+#pragma once
+#include "../../include/pyflyt_amd.h"
+#include "uav_device.hpp"
+
+namespace pf {
+
+struct QuadK {
+  // integrator
+  float dt, half_dt, gravity_z, vmax, inv_mass;
+  float I[3], iI[3];           // diagonal inertia and its inverse (cf2x.urdf:14)
+  float use_gyro;              // 1.0 / 0.0
+  float bound_radius;
+  // motors (identical): motors.py:131-138,182-193
+  float m_a, m_noise, fmax, tmax;
+  float ryf[4], rxf[4];        // r_y*fmax, -r_x*fmax per motor (torque arms)
+  float drag[3], pqr;          // boring_bodies.py:63, cf2x.yaml:11
+  // rate PID (cf2x.yaml:13-19): kp, ki*T, kd/T, lim
+  float kp[3], kiT[3], kdT[3], lim[3];
+  // env
+  float start_pos[3], start_quat[4];
+  float dome2, goal_reach, min_height, dome09m1;
+  float wp_dist_reward, wp_yaw_penalty;
+  int32_t task_sparse, angle_repr, num_targets, max_steps, env_step_ratio, settle_steps, tpc;
+  int32_t noise_mode, autoreset, fast_settle;
+  uint32_t seed_lo, seed_hi;
+};
+
+// Fill QuadK from the ABI struct; returns false when the configuration needs the generic kernel.
+inline bool quadk_from_params(const pf_params& P, QuadK& K) {
+  if (P.vehicle != PF_QUADX || P.flight_mode != 0) return false;
+  if (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS) return false;
+  if (P.has_com_offset) return false;
+  if (P.I_own[1] != 0.f || P.I_own[2] != 0.f || P.I_own[4] != 0.f) return false;  // diagonal inertia only
+  for (int k = 0; k < 6; ++k)
+    if (P.I_pa[k] != 0.f) return false;
+  const float ref_map[4][4] = {{-1, -1, -1, 1}, {1, 1, -1, 1}, {1, -1, 1, 1}, {-1, 1, 1, 1}};
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j)
+      if (P.motor_map[i][j] != ref_map[i][j]) return false;
+    if (P.motor_dt_over_tau[i] != P.motor_dt_over_tau[0] || P.motor_noise[i] != P.motor_noise[0] ||
+        P.motor_fmax[i] != P.motor_fmax[0]) return false;
+    if (P.thrust_unit[i][0] != 0.f || P.thrust_unit[i][1] != 0.f || P.thrust_unit[i][2] != 1.f) return false;
+  }
+  if (!(P.motor_tmax[0] == P.motor_tmax[1] && P.motor_tmax[2] == P.motor_tmax[3] && P.motor_tmax[0] == -P.motor_tmax[2] &&
+        P.motor_tmax[0] <= 0.f)) return false;
+  if (P.n_boxes != 1 || P.num_targets > 4) return false;
+  K.dt = P.dt; K.half_dt = 0.5f * P.dt; K.gravity_z = P.gravity_z; K.vmax = P.max_coord_vel; K.inv_mass = P.inv_mass;
+  K.I[0] = P.I_own[0]; K.I[1] = P.I_own[3]; K.I[2] = P.I_own[5];
+  K.iI[0] = P.I_inv[0]; K.iI[1] = P.I_inv[3]; K.iI[2] = P.I_inv[5];
+  K.use_gyro = P.use_gyro_term ? 1.f : 0.f;
+  K.bound_radius = P.bound_radius;
+  K.m_a = P.motor_dt_over_tau[0]; K.m_noise = P.motor_noise[0]; K.fmax = P.motor_fmax[0]; K.tmax = P.motor_tmax[2];
+  for (int i = 0; i < 4; ++i) { K.ryf[i] = P.motor_r[i][1] * P.motor_fmax[0]; K.rxf[i] = -P.motor_r[i][0] * P.motor_fmax[0]; }
+  for (int k = 0; k < 3; ++k) {
+    K.drag[k] = P.drag_const[k];
+    K.kp[k] = P.pid[0].kp[k]; K.kiT[k] = P.pid[0].ki[k] * P.control_period; K.kdT[k] = P.pid[0].kd[k] * P.inv_control_period;
+    K.lim[k] = P.pid[0].lim[k];
+    K.start_pos[k] = P.start_pos[k];
+  }
+  K.pqr = P.drag_coef_pqr;
+  for (int k = 0; k < 4; ++k) K.start_quat[k] = P.start_quat[k];
+  K.dome2 = P.dome * P.dome; K.goal_reach = P.goal_reach_distance; K.min_height = P.min_height;
+  K.dome09m1 = P.dome * 0.9f - 1.0f;
+  K.wp_dist_reward = P.wp_dist_reward; K.wp_yaw_penalty = P.wp_yaw_penalty;
+  K.task_sparse = P.sparse_reward; K.angle_repr = P.angle_repr; K.num_targets = P.num_targets; K.max_steps = P.max_steps;
+  K.env_step_ratio = P.env_step_ratio; K.settle_steps = P.settle_steps; K.tpc = P.ticks_per_control;
+  K.noise_mode = P.noise_mode; K.autoreset = P.autoreset;
+  K.seed_lo = (uint32_t)P.seed; K.seed_hi = (uint32_t)(P.seed >> 32);
+  // level spawn at rest, far enough above the floor that the settle free-fall cannot touch it
+  const float fall = 0.5f * 9.81f * (P.settle_steps * P.ticks_per_control * P.dt) * (P.settle_steps * P.ticks_per_control * P.dt);
+  K.fast_settle = (P.start_quat[0] == 0.f && P.start_quat[1] == 0.f && P.start_vel[0] == 0.f && P.start_vel[1] == 0.f &&
+                   P.start_vel[2] == 0.f && P.start_pos[2] - 2.0f * fall - 0.05f > P.bound_radius && P.gravity_z < 0.f)
+                      ? 1 : 0;
+  return true;
+}
+
+// Full 15-axis box test against the ground box, kept out of line: it runs only for waves that have
+// a lane within one bounding radius of the floor.
+__device__ __noinline__ bool quad_floor_contact(float px, float py, float pz, quat q, float hx, float hy, float hz,
+                                                float plane_xy, float plane_z) {
+  m3 R = rot_from_quat(q);
+  const float ha[3] = {hx, hy, hz};
+  const float hb[3] = {plane_xy, plane_xy, plane_z};
+  return box_overlaps_aabb(v3{px, py, pz}, R, ha, v3{0.f, 0.f, -plane_z}, hb);
+}
+
+struct QuadHot {
+  v3 p; quat q; v3 v, w;
+  float thr[4];
+  float I[3], E[3];
+  m3 R; v3 wb, vb;
+  float pwm[4];
+  bool contact_now, contact_step;
+
+  PF_DEV void derive() {
+    // rot_from_quat with 2/|q|^2 through v_rcp
+    float d = fmaf(q.x, q.x, fmaf(q.y, q.y, fmaf(q.z, q.z, q.w * q.w)));
+    float s = 2.0f * frcp(d);
+    float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+    float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    R = m3{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+    wb = mulT(R, w);
+    vb = mulT(R, v);
+  }
+  // update_control, mode 0 (quadx.py:437-438,472,482-493)
+  PF_DEV void control(const QuadK& K, float s0, float s1, float s2, float s3) {
+    const float st[3] = {wb.x, wb.y, wb.z};
+    const float sp[3] = {s0, s1, s2};
+    float a[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // pid.py:81-94
+      float e = sp[k] - st[k];
+      I[k] = med3(fmaf(K.kiT[k], e, I[k]), -K.lim[k], K.lim[k]);
+      float d = K.kdT[k] * (e - E[k]);
+      E[k] = e;
+      a[k] = med3(fmaf(K.kp[k], e, I[k]) + d, -K.lim[k], K.lim[k]);
+    }
+    float z = med3(s3, 0.0f, 1.0f);
+    pwm[0] = z - a[0] - a[1] - a[2];
+    pwm[1] = z + a[0] + a[1] - a[2];
+    pwm[2] = z + a[0] - a[1] + a[2];
+    pwm[3] = z - a[0] + a[1] + a[2];
+    float hi = __builtin_fmaxf(__builtin_fmaxf(pwm[0], pwm[1]), __builtin_fmaxf(pwm[2], pwm[3]));
+    float lo = __builtin_fminf(__builtin_fminf(pwm[0], pwm[1]), __builtin_fminf(pwm[2], pwm[3]));
+    if (hi != lo) {
+      float pmax = __builtin_fminf(hi, 1.0f), pmin = __builtin_fmaxf(lo, 0.05f);
+      float ka = (pmin - lo) * frcp(pmax - lo), ks = (hi - pmax) * frcp(hi - pmin);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pwm[i] += ka * (pmax - pwm[i]) - ks * (pwm[i] - pmin);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pwm[i] = med3(pwm[i], 0.05f, 1.0f);
+  }
+  // one physics tick: update_physics (quadx.py:495-510) + stepSimulation + update_state (:512-535)
+  PF_DEV void tick(const QuadK& K, float xi, const pf_params* Pfull) {
+    const float s = fmaf(xi, K.m_noise, 1.0f);
+    float k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = fmaf(K.m_a, pwm[i] - thr[i], thr[i]) * s;
+      thr[i] = t;
+      k[i] = t * __builtin_fabsf(t);
+    }
+    float Fz = K.fmax * ((k[0] + k[1]) + (k[2] + k[3]));
+    v3 tau{fmaf(K.ryf[0], k[0], fmaf(K.ryf[1], k[1], fmaf(K.ryf[2], k[2], K.ryf[3] * k[3]))),
+           fmaf(K.rxf[0], k[0], fmaf(K.rxf[1], k[1], fmaf(K.rxf[2], k[2], K.rxf[3] * k[3]))),
+           K.tmax * ((k[2] + k[3]) - (k[0] + k[1]))};
+    v3 F{-K.drag[0] * (vb.x * __builtin_fabsf(vb.x)), -K.drag[1] * (vb.y * __builtin_fabsf(vb.y)),
+         fmaf(-K.drag[2], vb.z * __builtin_fabsf(vb.z), Fz)};
+    const float pq = contact_now ? 0.0f : K.pqr;
+    tau.x = fmaf(-pq, wb.x * __builtin_fabsf(wb.x), tau.x);
+    tau.y = fmaf(-pq, wb.y * __builtin_fabsf(wb.y), tau.y);
+    tau.z = fmaf(-pq, wb.z * __builtin_fabsf(wb.z), tau.z);
+    // collision detection at the pre-integration pose
+    bool near = (p.z - K.bound_radius) <= 0.0f;
+    contact_now = false;
+    if (__any(near)) {
+      if (near)
+        contact_now = quad_floor_contact(p.x, p.y, p.z, q, Pfull->boxes[0].h[0], Pfull->boxes[0].h[1], Pfull->boxes[0].h[2],
+                                         Pfull->plane_half_xy, Pfull->plane_half_z);
+    }
+    // Newton-Euler in the body frame, diagonal inertia, COM at the base origin
+    v3 h{K.I[0] * wb.x, K.I[1] * wb.y, K.I[2] * wb.z};
+    v3 g = K.use_gyro * cross(wb, h);
+    v3 wdb{K.iI[0] * (tau.x - g.x), K.iI[1] * (tau.y - g.y), K.iI[2] * (tau.z - g.z)};
+    v3 wd = mul(R, wdb);
+    v3 a = mul(R, K.inv_mass * F);
+    a.z += K.gravity_z;
+    w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
+    v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
+    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z)};
+    q = quat_integrate(q, w, K.half_dt);
+    derive();
+    contact_step |= contact_now;
+  }
+};
+
+// Philox-backed per-lane normal source with a 4-deep cache (one Philox call per 4 ticks).
+struct FastNoise {
+  int mode;
+  const float* xi;
+  size_t n, lane;
+  uint32_t k0, k1, c0, c1, stream;
+  f4 z;
+  PF_DEV void begin(uint32_t ctr, uint32_t strm, const float* inj) { c1 = ctr; stream = strm; xi = inj; }
+  PF_DEV float get(int flat) {
+    if (mode == PF_NOISE_OFF) return 0.0f;
+    if (mode == PF_NOISE_INJECT) return xi[(size_t)flat * n + lane];
+    if ((flat & 3) == 0) z = normal4(philox4x32(k0, k1, c0, c1, (uint32_t)(flat >> 2), stream));
+    return 4.0f + pick4(z, (uint32_t)flat & 3u);
+  }
+  PF_DEV f4 uniforms(int call, uint32_t strm) const { return uniform4(philox4x32(k0, k1, c0, c1, (uint32_t)call, strm)); }
+};
+
+template <int TASK, int LPW, int WPS>
+__global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
+                                                               const int n, const uint64_t lane0, const int op,
+                                                               const uint8_t* __restrict__ mask) {
+  constexpr int kMaxD = 13 + 4 + 4 + 12;
+  __shared__ float tile[LPW * kMaxD];
+  const int tid = threadIdx.x;
+  const int wave_base = blockIdx.x * LPW;
+  const int lane = wave_base + tid;
+  const bool valid = (tid < LPW) && (lane < n);
+  const size_t li = valid ? (size_t)lane : (size_t)(n - 1);
+  const size_t N = (size_t)n;
+  const float4* Sin = reinterpret_cast<const float4*>(B.state);
+  float4* Sout = reinterpret_cast<float4*>(B.state);
+
+  QuadHot V;
+  float tgt[4][3];
+  float new_dist, old_dist;
+  int step_count, flags, n_left;
+  uint32_t rng_ctr;
+  {
+    float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li],
+           g5 = Sin[5 * N + li], gi = Sin[6 * N + li];
+    V.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
+    V.q = quat{g1.x, g1.y, g1.z, g1.w};
+    V.v = v3{g2.x, g2.y, g2.z};
+    V.w = v3{g2.w, g3.x, g3.y};
+    V.thr[0] = g3.z; V.thr[1] = g3.w; V.thr[2] = g4.x; V.thr[3] = g4.y;
+    V.I[0] = g4.z; V.I[1] = g4.w; V.I[2] = g5.x;
+    V.E[0] = g5.y; V.E[1] = g5.z; V.E[2] = g5.w;
+    step_count = __float_as_int(gi.x); flags = __float_as_int(gi.y); rng_ctr = (uint32_t)__float_as_int(gi.z);
+    n_left = __float_as_int(gi.w);
+    if (TASK == PF_TASK_WAYPOINTS) {
+      float4 a = Sin[12 * N + li], b = Sin[13 * N + li], c = Sin[14 * N + li];
+      tgt[0][0] = a.x; tgt[0][1] = a.y; tgt[0][2] = a.z; tgt[1][0] = a.w;
+      tgt[1][1] = b.x; tgt[1][2] = b.y; tgt[2][0] = b.z; tgt[2][1] = b.w;
+      tgt[2][2] = c.x; tgt[3][0] = c.y; tgt[3][1] = c.z; tgt[3][2] = c.w;
+    }
+  }
+  old_dist = new_dist;
+  V.contact_now = (flags & PF_F_CONTACT) != 0;
+  V.contact_step = false;
+  V.derive();
+  bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
+
+  FastNoise nz;
+  nz.mode = K.noise_mode; nz.n = N; nz.lane = li; nz.k0 = K.seed_lo; nz.k1 = K.seed_hi; nz.c0 = (uint32_t)(lane0 + li);
+  nz.xi = nullptr; nz.c1 = 0; nz.stream = 0;
+
+  bool active, do_reset;
+  if (op == 1) {
+    do_reset = (mask == nullptr) || (mask[li] != 0);
+    active = do_reset;
+  } else {
+    do_reset = (K.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc);
+    active = true;
+  }
+  active = active && valid;
+
+  float sp0 = 0.f, sp1 = 0.f, sp2 = 0.f, sp3 = 0.f;
+  float act0 = 0.f, act1 = 0.f, act2 = 0.f, act3 = 0.f;
+  float reward = 0.0f;
+  bool settling = false, pop_pending = false;
+  int remaining = 0, done_its = 0;
+  const int D = (K.angle_repr ? 13 : 12) + 8 + (TASK == PF_TASK_WAYPOINTS ? 3 * K.num_targets : 0);
+
+  auto pop_target = [&]() {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tgt[k][c] = tgt[k + 1][c];
+    n_left -= 1;
+  };
+  // begin_reset (+ waypoint sampling + set_mode(0)): quadx_base_env.py:149-206
+  auto begin_reset = [&]() {
+    V.p = v3{K.start_pos[0], K.start_pos[1], K.start_pos[2]};
+    V.q = quat{K.start_quat[0], K.start_quat[1], K.start_quat[2], K.start_quat[3]};
+    V.v = v3{0.f, 0.f, 0.f}; V.w = v3{0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { V.thr[k] = 0.f; V.pwm[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { V.I[k] = 0.f; V.E[k] = 0.f; }
+    V.contact_now = false; V.contact_step = false;
+    V.derive();
+    step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
+    act0 = act1 = act2 = act3 = 0.f;
+    nz.begin(rng_ctr, 1u, B.xi_reset);
+    if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
+      const int nt = K.num_targets;
+      n_left = nt;
+      new_dist = INFINITY; old_dist = INFINITY;
+      f4 u0, u1, u2;
+      const bool inj = (K.noise_mode == PF_NOISE_INJECT) && (B.u_targets != nullptr);
+      if (!inj) { u0 = nz.uniforms(0, 2u); u1 = nz.uniforms(1, 2u); u2 = nz.uniforms(2, 2u); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < nt) {
+          float theta, phi, dist;
+          if (inj) {
+            theta = B.u_targets[(size_t)i * N + li];
+            phi = B.u_targets[(size_t)(nt + i) * N + li];
+            dist = B.u_targets[(size_t)(2 * nt + i) * N + li];
+          } else {
+            auto u = [&](int flat) { return pick4(flat < 4 ? u0 : (flat < 8 ? u1 : u2), (uint32_t)flat & 3u); };
+            theta = (2.0f * kPi) * u(i);
+            phi = (2.0f * kPi) * u(nt + i);
+            dist = fmaf(K.dome09m1, u(2 * nt + i), 1.0f);
+          }
+          float st, ct, sph, cph;
+          sincosf(theta, &st, &ct);
+          sincosf(phi, &sph, &cph);
+          float zz = __builtin_fabsf(dist * cph);
+          tgt[i][0] = dist * sph * ct; tgt[i][1] = dist * sph * st; tgt[i][2] = zz > K.min_height ? zz : K.min_height;
+        }
+      }
+    }
+    sp0 = 0.f; sp1 = 0.f; sp2 = 0.f; sp3 = -1.0f;  // quadx.py:276-278
+    settling = true; remaining = K.settle_steps; done_its = 0;
+    if (K.fast_settle) {
+      // Level spawn at rest under the mode-0 default setpoint: rate error 0 -> cmd 0 -> pwm 0.05 on
+      // all four motors (quadx.py:488 branch skipped, :493 clip); equal thrusts cancel every
+      // torque exactly, so the 20 settle ticks are a vertical (z, vz, throttle) recurrence.
+      float thr = 0.f, vz = 0.f, z = V.p.z;
+      const int nt2 = K.settle_steps * K.tpc;
+      for (int t = 0; t < nt2; ++t) {
+        float s = fmaf(nz.get(t), K.m_noise, 1.0f);
+        thr = fmaf(K.m_a, 0.05f - thr, thr) * s;
+        float kk = thr * __builtin_fabsf(thr);
+        float Fz = fmaf(-K.drag[2], vz * __builtin_fabsf(vz), 4.0f * (K.fmax * kk));
+        float az = fmaf(K.inv_mass, Fz, K.gravity_z);
+        vz = med3(fmaf(az, K.dt, vz), -K.vmax, K.vmax);
+        z = fmaf(K.dt, vz, z);
+      }
+      V.p.z = z; V.v.z = vz;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { V.thr[k] = thr; V.pwm[k] = 0.05f; }
+      V.derive();
+      remaining = 0; done_its = K.settle_steps;
+    }
+  };
+  auto wp_distance = [&]() {  // waypoint_handler.py:135-142; ||R^T d|| = ||d||
+    if (TASK != PF_TASK_WAYPOINTS) return;
+    if (pop_pending) { pop_target(); pop_pending = false; }
+    float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
+    old_dist = new_dist;
+    new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+  };
+  auto term_trunc_reward = [&]() {
+    if (step_count > K.max_steps) trunc = true;
+    if (V.contact_step) { reward = -100.0f; flags |= PF_F_INFO_COLLISION; term = true; }
+    if (dot(V.p, V.p) > K.dome2) { reward = -100.0f; flags |= PF_F_INFO_OOB; term = true; }
+    if (TASK == PF_TASK_HOVER) {
+      if (!K.task_sparse) {  // quadx_hover_env.py:120-138
+        float dz = V.p.z - 1.0f;
+        float lin = fsqrt(fmaf(V.p.x, V.p.x, fmaf(V.p.y, V.p.y, dz * dz)));
+        // roll, pitch of getEulerFromQuaternion (gimbal branch: roll = 0, |pitch| = pi/2)
+        quat q = V.q;
+        float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+        float sarg = -2.0f * (q.x * q.z - q.w * q.y) * frcp(sqx + sqy + sqz + squ);
+        bool gim = __builtin_fabsf(sarg) >= 0.99999f;
+        float roll = gim ? 0.0f : fast_atan2(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+        float pitch = gim ? __builtin_copysignf(0.5f * kPi, sarg) : fast_asin(sarg);
+        float ang = fsqrt(fmaf(roll, roll, pitch * pitch));
+        reward -= 0.01f * (V.wb.z * V.wb.z);
+        reward -= lin + ang;
+        reward += 1.0f;
+      }
+    } else {
+      if (!K.task_sparse) {  // quadx_waypoints_env.py:183-192
+        float progress = (isinf(old_dist + new_dist)) ? 0.0f : old_dist - new_dist;
+        reward += __builtin_fmaxf(3.0f * progress, 0.0f);
+        reward += K.wp_dist_reward * frcp(new_dist);
+        reward -= K.wp_yaw_penalty * (V.wb.z * V.wb.z);
+      }
+      if (new_dist < K.goal_reach) {
+        reward = 100.0f;
+        pop_pending = true;
+        if (n_left - 1 == 0) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
+      }
+    }
+  };
+  // observation row (Appendix A of SURVEY.md) -> LDS tile. The attitude quaternion is
+  // getQuaternionFromEuler(getEulerFromQuaternion(q)) (quadx_base_env.py:243), computed without trig.
+  auto write_obs_row = [&]() {
+    float* row = tile + tid * D;
+    quat q = V.q;
+    float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+    float id = frcp(sqx + sqy + sqz + squ);
+    float sarg = -2.0f * (q.x * q.z - q.w * q.y) * id;
+    quat qe;
+    v3 rpy;
+    if (__builtin_fabsf(sarg) >= 0.99999f) {  // gimbal-lock branch of pybullet, rare: library trig
+      rpy = euler_from_quat(q);
+      qe = quat_from_euler(rpy);
+    } else {
+      float ar = 2.0f * (q.y * q.z + q.w * q.x), br = squ - sqx - sqy + sqz;
+      float ay = 2.0f * (q.x * q.y + q.w * q.z), by = squ + sqx - sqy - sqz;
+      float hr = frsq(fmaf(ar, ar, br * br)), hy = frsq(fmaf(ay, ay, by * by));
+      float cr, sr, cp, sp, cy, sy;
+      half_angle(br * hr, ar * hr, cr, sr);
+      half_angle(fsqrt((1.0f - sarg) * (1.0f + sarg)), sarg, cp, sp);
+      half_angle(by * hy, ay * hy, cy, sy);
+      quat t{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+      float inv = frsq(fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w))));
+      qe = quat{t.x * inv, t.y * inv, t.z * inv, t.w * inv};
+      if (!K.angle_repr) rpy = v3{fast_atan2(ar, br), fast_asin(sarg), fast_atan2(ay, by)};
+    }
+    int k = 0;
+    row[k++] = V.wb.x; row[k++] = V.wb.y; row[k++] = V.wb.z;
+    if (K.angle_repr) { row[k++] = qe.x; row[k++] = qe.y; row[k++] = qe.z; row[k++] = qe.w; }
+    else { row[k++] = rpy.x; row[k++] = rpy.y; row[k++] = rpy.z; }
+    row[k++] = V.vb.x; row[k++] = V.vb.y; row[k++] = V.vb.z;
+    row[k++] = V.p.x; row[k++] = V.p.y; row[k++] = V.p.z;
+    row[k++] = act0; row[k++] = act1; row[k++] = act2; row[k++] = act3;
+    row[k++] = V.thr[0]; row[k++] = V.thr[1]; row[k++] = V.thr[2]; row[k++] = V.thr[3];
+    if (TASK == PF_TASK_WAYPOINTS) {
+      m3 Re = rot_from_quat(qe);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < K.num_targets) {
+          v3 d = mulT(Re, v3{tgt[i][0] - V.p.x, tgt[i][1] - V.p.y, tgt[i][2] - V.p.z});
+          bool live = i < n_left;
+          row[k++] = live ? d.x : 0.0f; row[k++] = live ? d.y : 0.0f; row[k++] = live ? d.z : 0.0f;
+        }
+      }
+    }
+  };
+  auto flush_tile = [&](float* out, bool all_rows) {
+    __syncthreads();
+    if (all_rows) {
+      const int rows = min(LPW, n - wave_base);
+      const int total = rows * D;
+      float* g = out + (size_t)wave_base * D;
+      const int n4 = total >> 2;
+      const float4* t4 = reinterpret_cast<const float4*>(tile);
+      float4* g4 = reinterpret_cast<float4*>(g);
+      for (int i = tid; i < n4; i += 64) g4[i] = t4[i];
+      for (int i = (n4 << 2) + tid; i < total; i += 64) g[i] = tile[i];
+    } else if (active) {
+      float* g = out + (size_t)lane * D;
+      const float* row = tile + tid * D;
+      for (int k = 0; k < D; ++k) g[k] = row[k];
+    }
+    __syncthreads();
+  };
+
+  if (active) {
+    if (do_reset) {
+      begin_reset();
+    } else {
+      const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+      act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
+      sp0 = a.x; sp1 = a.y; sp2 = a.z; sp3 = a.w;
+      reward = -0.1f;
+      remaining = (term || trunc) ? 0 : K.env_step_ratio;
+      nz.begin(rng_ctr, 0u, B.xi);
+    }
+  }
+  const bool wave_all = __all(active || !(tid < LPW && lane < n)) && ((wave_base * D) % 4 == 0);
+  float out_reward = 0.0f;
+  bool out_term = false, out_trunc = false;
+  for (int phase = 0; phase < 2; ++phase) {
+    while (__any(remaining > 0)) {
+      if (remaining > 0) {
+        V.contact_step = false;
+        V.control(K, sp0, sp1, sp2, sp3);
+        for (int t = 0; t < K.tpc; ++t) V.tick(K, nz.get(done_its * K.tpc + t), Pfull);
+        remaining -= 1;
+        done_its += 1;
+        if (!settling) {
+          wp_distance();
+          term_trunc_reward();
+          if (term || trunc) remaining = 0;
+        }
+      }
+    }
+    if (phase == 1) break;
+    const bool stepped = active && !settling && op == 0;
+    if (stepped) {
+      step_count += 1;
+      rng_ctr += 1;
+      out_reward = reward; out_term = term; out_trunc = trunc;
+    }
+    const bool same = stepped && K.autoreset == PF_AUTORESET_SAME_STEP && (term || trunc);
+    if (!__any(same)) break;
+    if (B.final_obs != nullptr) {
+      if (active) write_obs_row();
+      flush_tile(B.final_obs, wave_all);
+    }
+    if (same) begin_reset();
+  }
+  if (active && settling) {
+    wp_distance();
+    rng_ctr += 1;
+  }
+  if (active) {
+    write_obs_row();
+    if (pop_pending) { pop_target(); pop_pending = false; }
+    flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
+            (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
+    Sout[0 * N + li] = float4{V.p.x, V.p.y, V.p.z, new_dist};
+    Sout[1 * N + li] = float4{V.q.x, V.q.y, V.q.z, V.q.w};
+    Sout[2 * N + li] = float4{V.v.x, V.v.y, V.v.z, V.w.x};
+    Sout[3 * N + li] = float4{V.w.y, V.w.z, V.thr[0], V.thr[1]};
+    Sout[4 * N + li] = float4{V.thr[2], V.thr[3], V.I[0], V.I[1]};
+    Sout[5 * N + li] = float4{V.I[2], V.E[0], V.E[1], V.E[2]};
+    Sout[6 * N + li] = float4{__int_as_float(step_count), __int_as_float(flags), __int_as_float((int)rng_ctr), __int_as_float(n_left)};
+    if (TASK == PF_TASK_WAYPOINTS) {
+      Sout[12 * N + li] = float4{tgt[0][0], tgt[0][1], tgt[0][2], tgt[1][0]};
+      Sout[13 * N + li] = float4{tgt[1][1], tgt[1][2], tgt[2][0], tgt[2][1]};
+      Sout[14 * N + li] = float4{tgt[2][2], tgt[3][0], tgt[3][1], tgt[3][2]};
+    }
+    if (op == 0) {
+      B.reward[li] = out_reward;
+      B.terminated[li] = out_term ? 1 : 0;
+      B.truncated[li] = out_trunc ? 1 : 0;
+    }
+  }
+  flush_tile(B.obs, wave_all);
+}
+
+}  // namespace pf

@@ -82,6 +82,46 @@ PF_DEV quat quat_from_euler(v3 e) {
   return quat{q.x * inv, q.y * inv, q.z * inv, q.w * inv};
 }
 
+// ---------------------------------------------------------------- lean math for the hot kernels
+PF_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
+PF_DEV float frsq(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
+PF_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); } // v_sqrt_f32, 1 ulp
+PF_DEV float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+// atan2 with a degree-8 minimax polynomial in t^2 on [0,1] (max abs error 1.2e-7 rad in fp32):
+// a handful of FMAs instead of the library routine. atan2(0,0) = 0.
+PF_DEV float fast_atan2(float y, float x) {
+  float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+  float t = mn * frcp(mx);
+  t = (mx == 0.0f) ? 0.0f : t;
+  float s = t * t;
+  float p = fmaf(s, 0.0029035410843789577f, -0.016282962635159492f);
+  p = fmaf(s, p, 0.04303929582238197f);
+  p = fmaf(s, p, -0.07533670216798782f);
+  p = fmaf(s, p, 0.10654674470424652f);
+  p = fmaf(s, p, -0.14207133650779724f);
+  p = fmaf(s, p, 0.19993053376674652f);
+  p = fmaf(s, p, -0.3333309292793274f);
+  p = fmaf(s, p, 1.0f);
+  float r = p * t;
+  r = (ay > ax) ? (0.5f * kPi - r) : r;
+  r = (x < 0.0f) ? (kPi - r) : r;
+  return __builtin_copysignf(r, y);
+}
+PF_DEV float fast_asin(float x) {  // asin(x) = atan2(x, sqrt((1-x)(1+x)))
+  return fast_atan2(x, fsqrt(__builtin_fmaxf((1.0f - x) * (1.0f + x), 0.0f)));
+}
+// cos(t/2), sin(t/2) of an angle t in (-pi, pi] given (cos t, sin t): no trig, no cancellation
+PF_DEV void half_angle(float c, float s, float& ch, float& sh) {
+  if (c >= 0.0f) {
+    ch = fsqrt(0.5f * (1.0f + c));
+    sh = 0.5f * s * frcp(ch);
+  } else {
+    sh = __builtin_copysignf(fsqrt(0.5f * (1.0f - c)), s);
+    ch = 0.5f * s * frcp(sh);
+  }
+}
+
 // q <- exp(w dt/2) (x) q, normalised: btMultiBody::stepPositionsMultiDof. The half-angle
 // theta = |w| dt/2 is bounded by sqrt(3)*max_coord_vel*dt/2 <= pi/8 (enforced at context creation),
 // so sin(theta)/theta and cos(theta) are short even polynomials in theta^2: no sqrt, no trig.

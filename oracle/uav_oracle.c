@@ -79,20 +79,31 @@ void orc_uniform4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
   orc_philox4x32(key, c0, c1, c2, c3, r);
   for (int i = 0; i < 4; ++i) u[i] = u24(r[i]);
 }
-/* Box-Muller on pairs (r0,r1) -> (z0,z1), (r2,r3) -> (z2,z3) */
+/* Motor-noise normals: each 32-bit Philox word yields one Box-Muller pair from two 16-bit
+ * uniforms (radius from the low half, angle from the high half), i.e. 8 normals per Philox call.
+ * 16-bit resolution (|z| <= 4.85, bulk granularity ~1e-4) is far below what a 2 % multiplicative
+ * motor noise can resolve and halves the RNG cost on the device. Same definition in
+ * pyflyt_amd/csrc/uav_device.hpp:normal8. */
+void orc_normal8(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double z[8]) {
+  uint32_t r[4];
+  orc_philox4x32(key, c0, c1, c2, c3, r);
+  for (int i = 0; i < 4; ++i) {
+    double u1 = ((double)(r[i] & 0xFFFFu) + 0.5) * (1.0 / 65536.0);
+    double u2 = (double)(r[i] >> 16) * (1.0 / 65536.0);
+    double rad = sqrt(-2.0 * log(u1));
+    z[2 * i] = rad * cos(2.0 * PI * u2);
+    z[2 * i + 1] = rad * sin(2.0 * PI * u2);
+  }
+}
 void orc_normal4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double z[4]) {
-  double u[4];
-  orc_uniform4(key, c0, c1, c2, c3, u);
-  double ra = sqrt(-2.0 * log(u[0])), rb = sqrt(-2.0 * log(u[2]));
-  z[0] = ra * cos(2.0 * PI * u[1]);
-  z[1] = ra * sin(2.0 * PI * u[1]);
-  z[2] = rb * cos(2.0 * PI * u[3]);
-  z[3] = rb * sin(2.0 * PI * u[3]);
+  double z8[8];
+  orc_normal8(key, c0, c1, c2, c3, z8);
+  for (int i = 0; i < 4; ++i) z[i] = z8[i];
 }
 static double lane_normal(const orc_params* P, const orc_lane* L, uint32_t flat_idx, uint32_t stream) {
-  double z[4];
-  orc_normal4(P->seed, (uint32_t)L->lane_id, L->rng_ctr, flat_idx >> 2, stream, z);
-  return z[flat_idx & 3];
+  double z[8];
+  orc_normal8(P->seed, (uint32_t)L->lane_id, L->rng_ctr, flat_idx >> 3, stream, z);
+  return z[flat_idx & 7];
 }
 static double lane_uniform(const orc_params* P, const orc_lane* L, uint32_t flat_idx, uint32_t stream) {
   double u[4];

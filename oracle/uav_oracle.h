@@ -188,6 +188,7 @@ void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], 
 
 /* ---------- RNG (same integer stream as the device) ---------- */
 void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
+void orc_normal8(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double z[8]);
 void orc_normal4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double z[4]);
 void orc_uniform4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double u[4]);
 

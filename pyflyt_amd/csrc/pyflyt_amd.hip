@@ -455,9 +455,9 @@ static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t*
   const int grid = (ctx->n + lpw - 1) / lpw;
 #define PF_FAST(L, W) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, L, W>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
   const int wps = ctx->wps;
-  if (lpw == 64) { if (wps >= 4) PF_FAST(64, 4); else PF_FAST(64, 2); }
-  else if (lpw == 32) { if (wps >= 4) PF_FAST(32, 4); else PF_FAST(32, 2); }
-  else { if (wps >= 4) PF_FAST(16, 4); else PF_FAST(16, 2); }
+  (void)wps;
+  if (lpw == 64) PF_FAST(64, 2);
+  else PF_FAST(32, 2);
 #undef PF_FAST
 }
 template <class VEH, int TASK>
@@ -508,11 +508,10 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     if (e == hipSuccess) e = hipMemcpy(c->P_dev, &P, sizeof(pf_params), hipMemcpyHostToDevice);
     if (cur >= 0) hipSetDevice(cur);
     if (e != hipSuccess) { delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
-    // Under-fill wavefronts when the batch cannot give every SIMD several full waves: a wave's
-    // dependent-instruction latency is then hidden by its neighbours instead of idling the SIMD.
-    const long want = 4L * c->n_simd;
-    c->lpw = (n_lanes / 64 >= want) ? 64 : ((n_lanes / 32 >= want) ? 32 : 16);
-    if (const char* o = getenv("PF_LPW")) { int v = atoi(o); if (v == 64 || v == 32 || v == 16) c->lpw = v; }
+    // (measured on MI355X, profiles/: the kernel is VALU-issue bound, so full 64-lane waves win at
+    // every batch size; the 32-lane variant is kept for experiments via PF_LPW=32)
+    c->lpw = 64;
+    if (const char* o = getenv("PF_LPW")) { int v = atoi(o); if (v == 64 || v == 32) c->lpw = v; }
     if (const char* o = getenv("PF_WPS")) { int v = atoi(o); if (v == 2 || v == 4) c->wps = v; }
   }
   *out = c;

@@ -193,19 +193,20 @@ struct QuadHot {
   }
 };
 
-// Philox-backed per-lane normal source with a 4-deep cache (one Philox call per 4 ticks).
+// Philox-backed per-lane normal source with an 8-deep cache (one Philox call per 8 ticks: a
+// Hover step's 6 ticks or a Waypoints step's 8 ticks need exactly one call).
 struct FastNoise {
   int mode;
   const float* xi;
   size_t n, lane;
   uint32_t k0, k1, c0, c1, stream;
-  f4 z;
+  f8 z;
   PF_DEV void begin(uint32_t ctr, uint32_t strm, const float* inj) { c1 = ctr; stream = strm; xi = inj; }
   PF_DEV float get(int flat) {
     if (mode == PF_NOISE_OFF) return 0.0f;
     if (mode == PF_NOISE_INJECT) return xi[(size_t)flat * n + lane];
-    if ((flat & 3) == 0) z = normal4(philox4x32(k0, k1, c0, c1, (uint32_t)(flat >> 2), stream));
-    return 4.0f + pick4(z, (uint32_t)flat & 3u);
+    if ((flat & 7) == 0) z = normal8(philox4x32(k0, k1, c0, c1, (uint32_t)(flat >> 3), stream));
+    return 4.0f + pick8(z, (uint32_t)flat & 7u);
   }
   PF_DEV f4 uniforms(int call, uint32_t strm) const { return uniform4(philox4x32(k0, k1, c0, c1, (uint32_t)call, strm)); }
 };
@@ -215,7 +216,11 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
                                                                const int n, const uint64_t lane0, const int op,
                                                                const uint8_t* __restrict__ mask) {
   constexpr int kMaxD = 13 + 4 + 4 + 12;
+  constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
   __shared__ float tile[LPW * kMaxD];
+  __shared__ float sxi[64 * kSettleMax];
+  __shared__ int spos[64];
+  __shared__ uint32_t sctr[64];
   const int tid = threadIdx.x;
   const int wave_base = blockIdx.x * LPW;
   const int lane = wave_base + tid;
@@ -283,6 +288,35 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       for (int c = 0; c < 3; ++c) tgt[k][c] = tgt[k + 1][c];
     n_left -= 1;
   };
+  // Settle-phase motor noise, generated cooperatively: the few lanes of a wave that reset in this
+  // call need settle_ticks normals each (3 Philox calls per lane); instead of every resetting lane
+  // walking through its calls serially while the other lanes idle, the (lane, call) pairs are dealt
+  // out over all 64 lanes, evaluated in one pass and handed back through LDS. Wave-uniform call.
+  const int settle_ticks = K.settle_steps * K.tpc;
+  const bool coop = K.fast_settle && K.noise_mode == PF_NOISE_PHILOX && settle_ticks <= kSettleMax;
+  auto prepare_settle_noise = [&](bool reset_now) {
+    if (!coop) return;
+    const unsigned long long m = __ballot(reset_now);
+    if (m == 0ull) return;
+    const int r = __popcll(m);
+    if (reset_now) {
+      spos[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+      sctr[tid] = rng_ctr;
+    }
+    __syncthreads();
+    const int ncall = (settle_ticks + 7) >> 3;
+    for (int base = 0; base < r * ncall; base += 64) {
+      const int j = base + tid;
+      if (j < r * ncall) {
+        const int which = j / ncall, call = j - which * ncall;
+        const int src = spos[which];
+        f8 z = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, 1u));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sxi[src * kSettleMax + call * 8 + e] = z.v[e];
+      }
+    }
+    __syncthreads();
+  };
   // begin_reset (+ waypoint sampling + set_mode(0)): quadx_base_env.py:149-206
   auto begin_reset = [&]() {
     V.p = v3{K.start_pos[0], K.start_pos[1], K.start_pos[2]};
@@ -335,7 +369,8 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       float thr = 0.f, vz = 0.f, z = V.p.z;
       const int nt2 = K.settle_steps * K.tpc;
       for (int t = 0; t < nt2; ++t) {
-        float s = fmaf(nz.get(t), K.m_noise, 1.0f);
+        const float xi = coop ? 4.0f + sxi[tid * kSettleMax + t] : nz.get(t);
+        float s = fmaf(xi, K.m_noise, 1.0f);
         thr = fmaf(K.m_a, 0.05f - thr, thr) * s;
         float kk = thr * __builtin_fabsf(thr);
         float Fz = fmaf(-K.drag[2], vz * __builtin_fabsf(vz), 4.0f * (K.fmax * kk));
@@ -456,6 +491,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
     __syncthreads();
   };
 
+  prepare_settle_noise(active && do_reset);
   if (active) {
     if (do_reset) {
       begin_reset();
@@ -499,6 +535,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       if (active) write_obs_row();
       flush_tile(B.final_obs, wave_all);
     }
+    prepare_settle_noise(same);
     if (same) begin_reset();
   }
   if (active && settling) {

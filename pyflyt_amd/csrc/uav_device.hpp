@@ -197,12 +197,32 @@ struct f4 {
   float a, b, c, d;
 };
 PF_DEV f4 uniform4(u32x4 r) { return f4{u01(r.a), u01(r.b), u01(r.c), u01(r.d)}; }
-// Box-Muller on (a,b) and (c,d). v_sin/v_cos take revolutions: sin(2 pi u) = __builtin_amdgcn_sinf(u).
-PF_DEV f4 normal4(u32x4 r) {
-  f4 u = uniform4(r);
-  float ra = sqrtf(-2.0f * __logf(u.a)), rb = sqrtf(-2.0f * __logf(u.c));
-  return f4{ra * __builtin_amdgcn_cosf(u.b), ra * __builtin_amdgcn_sinf(u.b), rb * __builtin_amdgcn_cosf(u.d),
-            rb * __builtin_amdgcn_sinf(u.d)};
+// Motor-noise normals: one Box-Muller pair per 32-bit Philox word from two 16-bit uniforms
+// (radius: low half, angle: high half) -> 8 normals per Philox call; see oracle orc_normal8.
+// v_sin/v_cos take revolutions: sin(2 pi u) = __builtin_amdgcn_sinf(u).
+struct f8 {
+  float v[8];
+};
+PF_DEV void bm16(uint32_t w, float& z0, float& z1) {
+  float u1 = ((float)(w & 0xFFFFu) + 0.5f) * (1.0f / 65536.0f);
+  float u2 = (float)(w >> 16) * (1.0f / 65536.0f);
+  float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u = -2 ln2 log2 u
+  z0 = rad * __builtin_amdgcn_cosf(u2);
+  z1 = rad * __builtin_amdgcn_sinf(u2);
+}
+PF_DEV f8 normal8(u32x4 r) {
+  f8 z;
+  bm16(r.a, z.v[0], z.v[1]);
+  bm16(r.b, z.v[2], z.v[3]);
+  bm16(r.c, z.v[4], z.v[5]);
+  bm16(r.d, z.v[6], z.v[7]);
+  return z;
+}
+PF_DEV float pick8(const f8& z, uint32_t i) {
+  float a = (i & 1u) ? z.v[1] : z.v[0], b = (i & 1u) ? z.v[3] : z.v[2];
+  float c = (i & 1u) ? z.v[5] : z.v[4], d = (i & 1u) ? z.v[7] : z.v[6];
+  float lo = (i & 2u) ? b : a, hi = (i & 2u) ? d : c;
+  return (i & 4u) ? hi : lo;
 }
 PF_DEV float pick4(f4 v, uint32_t i) {
   float lo = (i & 1u) ? v.b : v.a, hi = (i & 1u) ? v.d : v.c;

@@ -18,19 +18,19 @@ struct Noise {
   uint32_t k0, k1, c0, c1, stream;
   float nmot;
   int cached;
-  f4 z;
+  f8 z;
   PF_DEV void begin_event(uint32_t ctr, uint32_t strm, const float* inj) {
     c1 = ctr; stream = strm; xi = inj; cached = -1;
   }
   PF_DEV float get(int flat) {
     if (mode == PF_NOISE_OFF) return 0.0f;
     if (mode == PF_NOISE_INJECT) return xi[(size_t)flat * n + lane];
-    int call = flat >> 2;
+    int call = flat >> 3;
     if (call != cached) {
-      z = normal4(philox4x32(k0, k1, c0, c1, (uint32_t)call, stream));
+      z = normal8(philox4x32(k0, k1, c0, c1, (uint32_t)call, stream));
       cached = call;
     }
-    return nmot + pick4(z, (uint32_t)flat & 3u);
+    return nmot + pick8(z, (uint32_t)flat & 7u);
   }
   PF_DEV float uniform(int flat, uint32_t strm) const {  // uncached, for reset-time sampling
     f4 u = uniform4(philox4x32(k0, k1, c0, c1, (uint32_t)(flat >> 2), strm));

@@ -169,6 +169,8 @@ int pf_env_step(pf_ctx* ctx, const pf_buffers* b, void* stream);
  * set_all_setpoints :470-478 folded in (b->setpoints), state/aux_state :335-369 -> out_state/out_aux.
  * n_steps Aviary steps are fused in one launch (setpoints held, as the reference holds them). */
 int pf_aviary_reset(pf_ctx* ctx, const pf_buffers* b, void* stream);
+/* setpoints_out: [n][4] (or [n][6] for fixedwing mode -1), read-modify-written with the mode's default
+ * setpoint (quadx.py:275-290) */
 int pf_aviary_set_mode(pf_ctx* ctx, const pf_buffers* b, int mode, float* setpoints_out, void* stream);
 int pf_aviary_step(pf_ctx* ctx, const pf_buffers* b, int n_steps, void* stream);
 

@@ -1,0 +1,148 @@
+"""Batched `Aviary`: the reference's simulation orchestrator (core/aviary.py:47-531) for N drones
+that each live in their OWN world (independent lanes), stepped by the HIP kernels.
+
+Same surface as the reference where it is on the hot path:
+  Aviary(start_pos[N,3], start_orn[N,3], drone_type, drone_options=..., physics_hz=240,
+         world_scale=1.0, seed=...)                           core/aviary.py:69-216
+  reset()                                                     :218-312
+  set_mode(int) / set_setpoint(i, sp) / set_all_setpoints(sp) :440-478
+  step()                                                      :480-531
+  state(i) (4,3) / aux_state(i) / all_states / all_aux_states :335-421
+  contact_array  -> per-drone bool "touches the floor" (the reference's body-pair matrix collapses
+                    to this because every drone is alone in its world)
+Not carried over (out of scope): rendering/cameras, custom Python controllers,
+wind-field callbacks, mixed drone types, partial arming, drone-drone contact.
+"""
+from __future__ import annotations
+
+from typing import Any, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..engine import BatchEngine
+from ..params import build_params, quat_from_euler
+
+
+class AviaryInitException(Exception):
+    """Mirrors core/aviary.py:21-44."""
+
+
+class Aviary:
+    def __init__(self, start_pos, start_orn, drone_type: str | Sequence[str] = "quadx", drone_options: dict | None = None,
+                 wind_type=None, wind_options=None, render: bool = False, physics_hz: int = 240, world_scale: float = 1.0,
+                 seed: None | int = None, device="cuda:0", motor_noise: bool = True, lane_offset: int = 0):
+        start_pos = np.asarray(start_pos, dtype=np.float64)
+        start_orn = np.asarray(start_orn, dtype=np.float64)
+        if len(start_pos.shape) != 2 or start_pos.shape[-1] != 3:  # core/aviary.py:125-128
+            raise AviaryInitException(f"start_pos must be shape (n, 3), currently {start_pos.shape}.")
+        if start_orn.shape != start_pos.shape:  # :129-136
+            raise AviaryInitException(f"start_orn must be same shape as start_pos, currently {start_orn.shape}.")
+        if not isinstance(drone_type, str):
+            kinds = set(drone_type)
+            if len(kinds) != 1:
+                raise AviaryInitException("the batched Aviary needs one drone type for the whole batch")
+            drone_type = kinds.pop()
+        if drone_type not in ("quadx", "fixedwing"):
+            raise AviaryInitException(f"drone_type {drone_type!r} is not on the batched hot path (quadx, fixedwing)")
+        if render or wind_type is not None:
+            raise AviaryInitException("rendering and wind fields are out of scope for the batched GPU path")
+        del wind_options
+        self.num_drones = start_pos.shape[0]
+        self.drone_type = drone_type
+        self.device = torch.device(device)
+        self.physics_hz = int(physics_hz)
+        opts = dict(drone_options or {})
+        vopts: dict[str, Any] = {}
+        if "control_hz" in opts:
+            vopts["control_hz"] = int(opts.pop("control_hz"))
+        if "starting_velocity" in opts:
+            vopts["starting_velocity"] = tuple(opts.pop("starting_velocity"))
+        for k in ("use_camera", "use_gimbal", "camera_fps"):
+            opts.pop(k, None)
+        vopts.update(opts)
+        P = build_params(drone_type, "none", noise="philox" if motor_noise else "off", autoreset="off",
+                         seed=0 if seed is None else int(seed), vehicle_options=vopts,
+                         world_options={"physics_hz": self.physics_hz, "world_scale": float(world_scale)})
+        self.engine = BatchEngine(P, self.num_drones, device=self.device, lane_offset=lane_offset)
+        pose = np.concatenate([start_pos, np.stack([quat_from_euler(o) for o in start_orn])], axis=1)
+        self._start_pose = torch.tensor(pose, dtype=torch.float32, device=self.device).contiguous()
+        self.start_pos, self.start_orn = start_pos, start_orn
+        self.updates_per_step = P.ticks_per_control  # core/aviary.py:288-289
+        self.step_period = 1.0 / (self.physics_hz / P.ticks_per_control)
+        self._sp_dim = 4
+        self.setpoints = torch.zeros(self.num_drones, 4, dtype=torch.float32, device=self.device)
+        self.reset()
+
+    # ------------------------------------------------------------------ core/aviary.py:218-312
+    def reset(self) -> None:
+        self.physics_steps = 0
+        self.aviary_steps = 0
+        self.elapsed_time = 0.0
+        self.engine.state.zero_()
+        self.engine.aviary_reset(self._start_pose)
+        self.mode = 0
+        self._set_sp_dim(4)
+        self.setpoints.zero_()
+
+    def _set_sp_dim(self, d):
+        if d != self._sp_dim:
+            self._sp_dim = d
+            self.setpoints = torch.zeros(self.num_drones, d, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ :440-478
+    def set_mode(self, flight_modes: int) -> None:
+        if not isinstance(flight_modes, (int, np.integer)):
+            raise NotImplementedError("per-drone flight modes are not supported: the mode is uniform over the batch")
+        mode = int(flight_modes)
+        lo, hi = (-1, 7) if self.drone_type == "quadx" else (-1, 0)
+        if mode < lo or mode > hi:
+            raise ValueError(f"`mode` must be between {lo} and {hi}, got {mode}.")  # quadx.py:260-263
+        self._set_sp_dim(6 if (self.drone_type == "fixedwing" and mode == -1) else 4)
+        self.engine.aviary_set_mode(mode, self.setpoints)
+        self.mode = mode
+
+    def set_setpoint(self, index: int, setpoint) -> None:
+        self.setpoints[index] = torch.as_tensor(np.asarray(setpoint), dtype=torch.float32, device=self.device)
+
+    def set_all_setpoints(self, setpoints) -> None:
+        sp = setpoints if torch.is_tensor(setpoints) else torch.as_tensor(np.asarray(setpoints))
+        self.setpoints.copy_(sp.to(device=self.device, dtype=torch.float32).reshape(self.num_drones, self._sp_dim))
+
+    def set_armed(self, settings) -> None:
+        if isinstance(settings, (list, tuple)) and not all(settings) or (not isinstance(settings, (list, tuple)) and not settings):
+            raise NotImplementedError("disarming drones is not part of the batched hot path")
+
+    # ------------------------------------------------------------------ :480-531
+    def step(self, n_steps: int = 1) -> None:
+        """One (or n fused) `Aviary.step()`: control + ticks_per_control physics ticks per drone."""
+        self.engine.aviary_step(self.setpoints, n_steps=n_steps)
+        self.physics_steps += n_steps * self.updates_per_step
+        self.aviary_steps += n_steps
+        self.elapsed_time = self.physics_steps / self.physics_hz
+
+    # ------------------------------------------------------------------ :335-421
+    @property
+    def all_states(self) -> torch.Tensor:
+        """[N, 4, 3]: ang_vel, ang_pos, lin_vel (body frame), lin_pos rows, as DroneClass.state."""
+        return self.engine.out_state.view(self.num_drones, 4, 3)
+
+    @property
+    def all_aux_states(self) -> torch.Tensor:
+        return self.engine.out_aux
+
+    def state(self, index: int) -> torch.Tensor:
+        return self.all_states[index]
+
+    def aux_state(self, index: int) -> torch.Tensor:
+        return self.all_aux_states[index]
+
+    @property
+    def contact_array(self) -> torch.Tensor:
+        return self.engine.out_contact
+
+    def disconnect(self) -> None:
+        self.engine.close()
+
+    close = disconnect

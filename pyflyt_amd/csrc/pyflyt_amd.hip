@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(kWave) aviary_reset_kernel(const pf_params P, 
 
 template <class VEH>
 __global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params P, const pf_buffers B, const int n,
-                                                                const int old_mode, const int new_mode, float* sp_out) {
+                                                                const int sp_dim, const int new_mode, float* sp_out) {
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   VEH V;
@@ -348,12 +348,13 @@ __global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params 
   V.b.rpy = euler_from_quat(V.b.q);
   float sp[6] = {0, 0, 0, 0, 0, 0};
   if (sp_out)
-    for (int k = 0; k < VEH::SP; ++k) sp[k] = sp_out[(size_t)lane * VEH::SP + k];
+    for (int k = 0; k < 6; ++k)
+      if (k < sp_dim) sp[k] = sp_out[(size_t)lane * sp_dim + k];
   V.set_mode(new_mode, sp);
   V.store(reinterpret_cast<float4*>(B.state), (size_t)n, (size_t)lane, 7, nd, ints);
   if (sp_out)
-    for (int k = 0; k < VEH::SP; ++k) sp_out[(size_t)lane * VEH::SP + k] = sp[k];
-  (void)old_mode;
+    for (int k = 0; k < 6; ++k)
+      if (k < sp_dim) sp_out[(size_t)lane * sp_dim + k] = sp[k];
   (void)P;
 }
 
@@ -589,10 +590,11 @@ int pf_aviary_set_mode(pf_ctx* ctx, const pf_buffers* b, int mode, float* setpoi
   if (rc) return rc;
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
   hipStream_t s = (hipStream_t)stream;
+  const int sp_dim = (ctx->P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4;  // fixedwing.py:221-224
   if (ctx->P.vehicle == PF_QUADX)
-    hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->P.flight_mode, mode, setpoints_out);
+    hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, sp_dim, mode, setpoints_out);
   else
-    hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->P.flight_mode, mode, setpoints_out);
+    hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, sp_dim, mode, setpoints_out);
   ctx->P.flight_mode = mode;
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;

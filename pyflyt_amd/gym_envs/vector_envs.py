@@ -1,0 +1,217 @@
+"""Gymnasium-VectorEnv-shaped façades over the fused HIP env step.
+
+They mirror, per lane, the reference's single-env classes (file:line under /root/reference/PyFlyt/):
+  QuadXHoverVecEnv        <- gym_envs/quadx_envs/quadx_hover_env.py:10-138 (+ quadx_base_env.py)
+  QuadXWaypointsVecEnv    <- gym_envs/quadx_envs/quadx_waypoints_env.py:11-204
+  FixedwingWaypointsVecEnv<- gym_envs/fixedwing_envs/fixedwing_waypoints_env.py:11-190
+with the same constructor keywords, action/observation layouts, reward, termination and info keys.
+The reference has no vector env; the batch dimension and auto-reset follow gymnasium.vector
+(num_envs, single_*_space, reset(seed=, options=), step(actions) -> 5-tuple, autoreset_mode).
+
+Tensors are torch.float32 / torch.bool on the ROCm device and are views of buffers the kernels
+write in place: copy them if you need them after the next step().
+"""
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..engine import BatchEngine
+from ..params import build_params
+from ..spaces import Box, Dict, batch_box
+
+
+class _VecEnvBase:
+    metadata = {"render_modes": [], "autoreset_mode": "next_step"}
+    _vehicle = "quadx"
+    _task = "hover"
+
+    def __init__(self, num_envs: int, *, device="cuda:0", seed: int = 0, autoreset_mode: str = "next_step",
+                 motor_noise: bool = True, lane_offset: int = 0, render_mode=None, **task_kwargs):
+        if render_mode is not None:
+            raise ValueError("rendering is out of scope for the batched GPU path (SURVEY.md section 2: Camera)")
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        self._kwargs = dict(task_kwargs)
+        self._autoreset_mode = {"next_step": "next_step", "same_step": "same_step", "disabled": "off", "off": "off"}[str(autoreset_mode).lower()]
+        self.metadata = dict(self.metadata, autoreset_mode=autoreset_mode)
+        self._noise = "philox" if motor_noise else "off"
+        self._lane_offset = int(lane_offset)
+        self._seed = int(seed)
+        self._build(self._seed)
+        P = self.engine.params
+        att = (13 if P.angle_repr else 12)
+        aux = 4 if P.vehicle == L.QUADX else 6
+        self.attitude_dim = att + 4 + aux
+        self.single_action_space = Box(low=np.array(list(P.action_low), dtype=np.float32),
+                                       high=np.array(list(P.action_high), dtype=np.float32), dtype=np.float32)
+        self.action_space = batch_box(self.single_action_space, self.num_envs)
+        self._make_obs_space()
+        self._needs_reset = True
+
+    # ------------------------------------------------------------------ construction
+    def _build(self, seed):
+        P = build_params(self._vehicle, self._task, noise=self._noise, autoreset=self._autoreset_mode, seed=seed, **self._kwargs)
+        self.engine = BatchEngine(P, self.num_envs, device=self.device, lane_offset=self._lane_offset)
+
+    def _make_obs_space(self):
+        self.single_observation_space = Box(low=-np.inf, high=np.inf, shape=(self.attitude_dim,), dtype=np.float32)
+        self.observation_space = batch_box(self.single_observation_space, self.num_envs)
+
+    # ------------------------------------------------------------------ gymnasium.vector API
+    def reset(self, *, seed: int | None = None, options: dict | None = None):
+        """Reset every env (or the subset in options['reset_mask']). A new `seed` re-keys the
+        counter-based RNG (motor noise, waypoint sampling); same seed => bit-identical rollouts
+        (mirrors tests/test_gym_envs.py:92-112 of the reference)."""
+        mask = None if not options else options.get("reset_mask")
+        if seed is not None and int(seed) != self._seed:
+            if mask is not None:
+                raise ValueError("cannot re-seed and partially reset in one call")
+            self._seed = int(seed)
+            self.engine.close()
+            self._build(self._seed)
+        elif seed is not None and mask is None:
+            # same seed: restart the event counters so that the rollout repeats exactly
+            self.engine.state.zero_()
+        if mask is not None and not torch.is_tensor(mask):
+            mask = torch.as_tensor(np.asarray(mask), dtype=torch.bool, device=self.device)
+        self.engine.env_reset(mask=mask)
+        self._needs_reset = False
+        return self._obs(self.engine.obs), self._infos()
+
+    def step(self, actions):
+        if self._needs_reset:
+            raise RuntimeError("call reset() before step()")
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.device)
+        actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        obs, rew, term, trunc = self.engine.env_step(actions)
+        infos = self._infos()
+        if self.engine.final_obs is not None:
+            infos["final_obs"] = self._obs(self.engine.final_obs)
+        return self._obs(obs), rew, term, trunc, infos
+
+    def close(self):
+        self.engine.close()
+
+    def sample_actions(self, step_index: int = 0):
+        """Device-side uniform sample of the action box (the role of action_space.sample())."""
+        out = torch.empty(self.num_envs, 4, dtype=torch.float32, device=self.device)
+        return self.engine.sample_actions(out, step_index)
+
+    # ------------------------------------------------------------------ helpers
+    def _obs(self, buf):
+        return buf
+
+    def _infos(self) -> dict[str, Any]:
+        f = self.engine.flags()
+        return {
+            "out_of_bounds": (f & L.F_INFO_OOB) != 0,      # quadx_base_env.py:266
+            "collision": (f & L.F_INFO_COLLISION) != 0,    # quadx_base_env.py:260
+            "env_complete": (f & L.F_INFO_COMPLETE) != 0,  # quadx_waypoints_env.py:203
+        }
+
+    @property
+    def step_count(self):
+        return self.engine.ints()[:, 0]
+
+
+class QuadXHoverVecEnv(_VecEnvBase):
+    """PyFlyt/QuadX-Hover-v4, batched. Keywords as quadx_hover_env.py:32-41."""
+    _vehicle, _task = "quadx", "hover"
+
+    def __init__(self, num_envs: int, *, sparse_reward: bool = False, flight_mode: int = 0, flight_dome_size: float = 3.0,
+                 max_duration_seconds: float = 10.0, angle_representation: str = "quaternion", agent_hz: int = 40, **kw):
+        super().__init__(num_envs, sparse_reward=sparse_reward, flight_mode=flight_mode, flight_dome_size=flight_dome_size,
+                         max_duration_seconds=max_duration_seconds, angle_representation=angle_representation,
+                         agent_hz=agent_hz, **kw)
+
+
+class _WaypointsMixin:
+    def _make_obs_space(self):
+        nt = self.engine.params.num_targets
+        dome = self.engine.params.dome
+        self.num_targets = nt
+        if self._flatten:
+            width = self.attitude_dim + 3 * self._context_length
+            self.single_observation_space = Box(low=-np.inf, high=np.inf, shape=(width,), dtype=np.float32)
+            self.observation_space = batch_box(self.single_observation_space, self.num_envs)
+        else:
+            self.single_observation_space = Dict({
+                "attitude": Box(low=-np.inf, high=np.inf, shape=(self.attitude_dim,), dtype=np.float32),
+                "target_deltas": Box(low=-2 * dome, high=2 * dome, shape=(nt, 3), dtype=np.float32),
+            })
+            self.observation_space = Dict({
+                "attitude": batch_box(self.single_observation_space["attitude"], self.num_envs),
+                "target_deltas": batch_box(self.single_observation_space["target_deltas"], self.num_envs),
+            })
+
+    def _obs(self, buf):
+        a = self.attitude_dim
+        if self._flatten:  # gym_envs/utils/flatten_waypoint_env.py:42-62
+            ctx = self._context_length
+            have = min(ctx, self.num_targets)
+            if have == ctx:
+                return buf[:, : a + 3 * ctx]
+            pad = torch.zeros(buf.shape[0], 3 * (ctx - have), dtype=buf.dtype, device=buf.device)
+            return torch.cat([buf[:, : a + 3 * have], pad], dim=1)
+        # the reference's variable-length Sequence becomes a fixed [num_targets, 3] block whose rows
+        # past the remaining targets are zero (flatten_waypoint_env.py:49-56 padding convention)
+        return {"attitude": buf[:, :a], "target_deltas": buf[:, a:].view(-1, self.num_targets, 3)}
+
+    def _infos(self):
+        infos = super()._infos()
+        n_left = self.engine.ints()[:, 3]
+        infos["num_targets_reached"] = self.num_targets - n_left  # quadx_waypoints_env.py:204
+        return infos
+
+
+class QuadXWaypointsVecEnv(_WaypointsMixin, _VecEnvBase):
+    """PyFlyt/QuadX-Waypoints-v4, batched. Keywords as quadx_waypoints_env.py:36-49 (yaw targets are
+    not supported). flatten=True returns FlattenWaypointEnv-style rows [attitude, ctx deltas]."""
+    _vehicle, _task = "quadx", "waypoints"
+
+    def __init__(self, num_envs: int, *, sparse_reward: bool = False, num_targets: int = 4, use_yaw_targets: bool = False,
+                 goal_reach_distance: float = 0.2, goal_reach_angle: float = 0.1, flight_mode: int = 0,
+                 flight_dome_size: float = 5.0, max_duration_seconds: float = 10.0, angle_representation: str = "quaternion",
+                 agent_hz: int = 30, flatten: bool = False, context_length: int = 2, **kw):
+        if use_yaw_targets:
+            raise NotImplementedError("use_yaw_targets=True is not part of the batched hot path")
+        del goal_reach_angle
+        self._flatten, self._context_length = bool(flatten), int(context_length)
+        super().__init__(num_envs, sparse_reward=sparse_reward, num_targets=num_targets, goal_reach_distance=goal_reach_distance,
+                         flight_mode=flight_mode, flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds,
+                         angle_representation=angle_representation, agent_hz=agent_hz, **kw)
+
+
+class FixedwingWaypointsVecEnv(_WaypointsMixin, _VecEnvBase):
+    """PyFlyt/Fixedwing-Waypoints-v4, batched. Keywords as fixedwing_waypoints_env.py:36-47."""
+    _vehicle, _task = "fixedwing", "waypoints"
+
+    def __init__(self, num_envs: int, *, sparse_reward: bool = False, num_targets: int = 4, goal_reach_distance: float = 2.0,
+                 flight_mode: int = 0, flight_dome_size: float = 100.0, max_duration_seconds: float = 120.0,
+                 angle_representation: str = "quaternion", agent_hz: int = 30, flatten: bool = False,
+                 context_length: int = 2, **kw):
+        self._flatten, self._context_length = bool(flatten), int(context_length)
+        super().__init__(num_envs, sparse_reward=sparse_reward, num_targets=num_targets, goal_reach_distance=goal_reach_distance,
+                         flight_mode=flight_mode, flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds,
+                         angle_representation=angle_representation, agent_hz=agent_hz, **kw)
+
+
+_REGISTRY = {
+    # ids as registered by the reference, gym_envs/__init__.py:8-43
+    "PyFlyt/QuadX-Hover-v4": QuadXHoverVecEnv,
+    "PyFlyt/QuadX-Waypoints-v4": QuadXWaypointsVecEnv,
+    "PyFlyt/Fixedwing-Waypoints-v4": FixedwingWaypointsVecEnv,
+}
+
+
+def make_vec(env_id: str, num_envs: int, **kwargs):
+    """The batched counterpart of `gymnasium.make_vec(id, num_envs=...)` for the supported ids."""
+    if env_id not in _REGISTRY:
+        raise KeyError(f"{env_id!r} is not on the batched hot path; available: {sorted(_REGISTRY)}")
+    return _REGISTRY[env_id](num_envs, **kwargs)

@@ -1,0 +1,929 @@
+/*
+ * uav_oracle.c -- TEST INFRASTRUCTURE ONLY. fp64 scalar restatement of the PyFlyt Aviary.step()
+ * hot path (one drone at a time) + the slice of Bullet it drives. See uav_oracle_f32.h for the
+ * parity status. Citations are file:line under /root/reference/PyFlyt/ unless noted.
+ *
+ * Nothing in pyflyt_amd/ (the product) may include, link or call this file.
+ */
+#include "uav_oracle_f32.h"
+
+#include <math.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------ small helpers */
+static inline float sgn(float x) { return (float)((x > 0.0) - (x < 0.0)); } /* np.sign */
+static inline float clipd(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline void cross3(const float a[3], const float b[3], float o[3]) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void matvec(const float M[3][3], const float x[3], float o[3]) {
+  float a = M[0][0] * x[0] + M[0][1] * x[1] + M[0][2] * x[2];
+  float b = M[1][0] * x[0] + M[1][1] * x[1] + M[1][2] * x[2];
+  float c = M[2][0] * x[0] + M[2][1] * x[1] + M[2][2] * x[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+static inline void matTvec(const float M[3][3], const float x[3], float o[3]) {
+  float a = M[0][0] * x[0] + M[1][0] * x[1] + M[2][0] * x[2];
+  float b = M[0][1] * x[0] + M[1][1] * x[1] + M[2][1] * x[2];
+  float c = M[0][2] * x[0] + M[1][2] * x[1] + M[2][2] * x[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+static void inv3(const float A[3][3], float B[3][3]) {
+  float c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+  float c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+  float c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+  float det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+  float id = 1.0 / det;
+  B[0][0] = c00 * id;
+  B[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * id;
+  B[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * id;
+  B[1][0] = c01 * id;
+  B[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * id;
+  B[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * id;
+  B[2][0] = c02 * id;
+  B[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * id;
+  B[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * id;
+}
+
+/* ------------------------------------------------------------------ RNG: Philox4x32-10
+ * Counter-based generator (Salmon et al., SC'11), the integer stream is bit-identical to the
+ * device implementation (pyflyt_amd/csrc/uav_rng.hpp). The reference threads a numpy PCG64
+ * Generator through its components (motors.py:134-138, waypoint_handler.py:72-83); that stream
+ * cannot be matched on a GPU, so parity runs either inject the normals or share this Philox
+ * stream (RNG row). */
+void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* 23-bit uniform in (0,1): (k + 0.5) * 2^-23, k < 2^23 -- exactly representable in fp32 and fp64 */
+static inline float u24(uint32_t x) { return ((float)(x >> 9) + 0.5) * (1.0 / 8388608.0); }
+void orc_uniform4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float u[4]) {
+  uint32_t r[4];
+  orc_philox4x32(key, c0, c1, c2, c3, r);
+  for (int i = 0; i < 4; ++i) u[i] = u24(r[i]);
+}
+/* Motor-noise normals: each 32-bit Philox word yields one Box-Muller pair from two 16-bit
+ * uniforms (radius from the low half, angle from the high half), i.e. 8 normals per Philox call.
+ * 16-bit resolution (|z| <= 4.85, bulk granularity ~1e-4) is far below what a 2 % multiplicative
+ * motor noise can resolve and halves the RNG cost on the device. Same definition in
+ * pyflyt_amd/csrc/uav_device.hpp:normal8. */
+void orc_normal8(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float z[8]) {
+  uint32_t r[4];
+  orc_philox4x32(key, c0, c1, c2, c3, r);
+  for (int i = 0; i < 4; ++i) {
+    float u1 = ((float)(r[i] & 0xFFFFu) + 0.5) * (1.0 / 65536.0);
+    float u2 = (float)(r[i] >> 16) * (1.0 / 65536.0);
+    float rad = sqrt(-2.0 * log(u1));
+    z[2 * i] = rad * cos(2.0 * PI * u2);
+    z[2 * i + 1] = rad * sin(2.0 * PI * u2);
+  }
+}
+void orc_normal4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float z[4]) {
+  float z8[8];
+  orc_normal8(key, c0, c1, c2, c3, z8);
+  for (int i = 0; i < 4; ++i) z[i] = z8[i];
+}
+static float lane_normal(const orc_params* P, const orc_lane* L, uint32_t flat_idx, uint32_t stream) {
+  float z[8];
+  orc_normal8(P->seed, (uint32_t)L->lane_id, L->rng_ctr, flat_idx >> 3, stream, z);
+  return z[flat_idx & 7];
+}
+static float lane_uniform(const orc_params* P, const orc_lane* L, uint32_t flat_idx, uint32_t stream) {
+  float u[4];
+  orc_uniform4(P->seed, (uint32_t)L->lane_id, L->rng_ctr, flat_idx >> 2, stream, u);
+  return u[flat_idx & 3];
+}
+
+/* ------------------------------------------------------------------ Bullet helpers
+ * [BULLET-FROM-MEMORY] pybullet.c getQuaternionFromEuler / getEulerFromQuaternion,
+ * btMatrix3x3::setRotation. Quaternion order (x,y,z,w). Call sites: base_drone.py:115,
+ * quadx.py:521,526, quadx_base_env.py:243, waypoint_handler.py:135. */
+void orc_quat_from_euler(const float rpy[3], float q[4]) {
+  float phi = rpy[0] / 2.0, the = rpy[1] / 2.0, psi = rpy[2] / 2.0;
+  q[0] = sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi);
+  q[1] = cos(phi) * sin(the) * cos(psi) + sin(phi) * cos(the) * sin(psi);
+  q[2] = cos(phi) * cos(the) * sin(psi) - sin(phi) * sin(the) * cos(psi);
+  q[3] = cos(phi) * cos(the) * cos(psi) + sin(phi) * sin(the) * sin(psi);
+  float len = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] /= len; q[1] /= len; q[2] /= len; q[3] /= len;
+}
+void orc_euler_from_quat(const float q[4], float rpy[3]) {
+  float sqx = q[0] * q[0], sqy = q[1] * q[1], sqz = q[2] * q[2], squ = q[3] * q[3];
+  float sarg = -2.0 * (q[0] * q[2] - q[3] * q[1]) / (sqx + sqy + sqz + squ);
+  if (sarg <= -0.99999) {
+    rpy[0] = 0.0; rpy[1] = -0.5 * PI; rpy[2] = 2.0 * atan2(q[0], -q[1]);
+  } else if (sarg >= 0.99999) {
+    rpy[0] = 0.0; rpy[1] = 0.5 * PI; rpy[2] = 2.0 * atan2(-q[0], q[1]);
+  } else {
+    rpy[0] = atan2(2.0 * (q[1] * q[2] + q[3] * q[0]), squ - sqx - sqy + sqz);
+    rpy[1] = asin(sarg);
+    rpy[2] = atan2(2.0 * (q[0] * q[1] + q[3] * q[2]), squ + sqx - sqy - sqz);
+  }
+}
+void orc_matrix_from_quat(const float q[4], float R[3][3]) {
+  float d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  float s = 2.0 / d;
+  float xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+  float wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+  float xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+  float yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+  R[0][0] = 1.0 - (yy + zz); R[0][1] = xy - wz; R[0][2] = xz + wy;
+  R[1][0] = xy + wz; R[1][1] = 1.0 - (xx + zz); R[1][2] = yz - wx;
+  R[2][0] = xz - wy; R[2][1] = yz + wx; R[2][2] = 1.0 - (xx + yy);
+}
+
+/* Contact reporting -- [BULLET-FROM-MEMORY] btBoxBoxDetector (ODE dBoxBox2): two boxes produce
+ * manifold points iff none of the 15 separating-axis tests separates them (face axes: s > 0,
+ * edge axes: s > SIMD_EPSILON with |R| fudged by 1e-5). Box a is oriented (centre ca, axes = the
+ * columns of Ra, half extents ha); box b is world-axis-aligned (cb, hb). aviary.py:523-525. */
+int orc_box_box_overlap(const float ca[3], const float Ra[3][3], const float ha[3],
+                        const float cb[3], const float hb[3]) {
+  float t[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+  float Q[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Q[i][j] = fabs(Ra[i][j]);
+  for (int i = 0; i < 3; ++i) { /* faces of the axis-aligned box */
+    float rad = hb[i] + Q[i][0] * ha[0] + Q[i][1] * ha[1] + Q[i][2] * ha[2];
+    if (fabs(t[i]) - rad > 0.0) return 0;
+  }
+  for (int j = 0; j < 3; ++j) { /* faces of the oriented box */
+    float proj = t[0] * Ra[0][j] + t[1] * Ra[1][j] + t[2] * Ra[2][j];
+    float rad = ha[j] + Q[0][j] * hb[0] + Q[1][j] * hb[1] + Q[2][j] * hb[2];
+    if (fabs(proj) - rad > 0.0) return 0;
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Q[i][j] += 1e-5;
+  for (int i = 0; i < 3; ++i) { /* edge x edge: e_i x a_j */
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+    for (int j = 0; j < 3; ++j) {
+      int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      float expr1 = t[i2] * Ra[i1][j] - t[i1] * Ra[i2][j];
+      float rad = hb[i1] * Q[i2][j] + hb[i2] * Q[i1][j] + ha[j1] * Q[i][j2] + ha[j2] * Q[i][j1];
+      if (fabs(expr1) - rad > 2.220446049250313e-16) return 0;
+    }
+  }
+  return 1;
+}
+int orc_contact_plane(const orc_params* P, const float p[3], const float q[4]) {
+  /* ground = plane.urdf collision box (30,30,10)*world_scale centred at z=-5*world_scale,
+   * aviary.py:240-242. Cheap exact early-out on the bounding sphere. */
+  if (p[2] - P->bound_radius > 0.0) return 0;
+  float R[3][3];
+  orc_matrix_from_quat(q, R);
+  float cb[3] = {0.0, 0.0, -P->world.plane_half_z};
+  float hb[3] = {P->world.plane_half_xy, P->world.plane_half_xy, P->world.plane_half_z};
+  for (int k = 0; k < P->n_boxes; ++k) {
+    float off[3], ca[3];
+    matvec(R, P->boxes[k].c, off);
+    ca[0] = p[0] + off[0]; ca[1] = p[1] + off[1]; ca[2] = p[2] + off[2];
+    if (orc_box_box_overlap(ca, R, P->boxes[k].h, cb, hb)) return 1;
+  }
+  return 0;
+}
+
+/* One free-body tick of Bullet's multibody world = the arithmetic behind `stepSimulation`
+ * (aviary.py:516) for a base with only fixed, possibly massive, child links.
+ * [BULLET-FROM-MEMORY] btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof ->
+ * applyDeltaVeeMultiDof (per-coordinate clamp) -> stepPositionsMultiDof (exp-map quaternion).
+ * F_b: net external force in the base frame (gravity excluded); tau_b: net external torque about
+ * the BASE ORIGIN in the base frame. State (p, v) is that of the base origin, as Bullet keeps it. */
+void orc_rigid_tick(const orc_params* P, float p[3], float q[4], float v[3], float w[3],
+                    const float F_b[3], const float tau_b[3]) {
+  const float dt = P->world.dt;
+  float R[3][3];
+  orc_matrix_from_quat(q, R);
+  float w_b[3];
+  matTvec(R, w, w_b);
+  /* torque about the composite COM */
+  float cxF[3], tau_c[3];
+  cross3(P->com, F_b, cxF);
+  for (int i = 0; i < 3; ++i) tau_c[i] = tau_b[i] - cxF[i];
+  /* gyroscopic bias: w x (I w); the links' own-inertia part is gated by m_useGyroTerm, the
+   * point-mass (m w x v) part is unconditional in Bullet's ABA */
+  float Iw[3], g1[3], g2[3] = {0, 0, 0};
+  matvec(P->I_pa, w_b, Iw);
+  cross3(w_b, Iw, g1);
+  if (P->world.use_gyro_term) {
+    matvec(P->I_own, w_b, Iw);
+    cross3(w_b, Iw, g2);
+  }
+  float rhs[3], wdot_b[3], wdot[3];
+  for (int i = 0; i < 3; ++i) rhs[i] = tau_c[i] - g1[i] - g2[i];
+  matvec(P->I_inv, rhs, wdot_b);
+  matvec(R, wdot_b, wdot);
+  /* linear acceleration of the COM, then of the base origin */
+  float F_w[3], a[3];
+  matvec(R, F_b, F_w);
+  a[0] = F_w[0] / P->mass; a[1] = F_w[1] / P->mass; a[2] = F_w[2] / P->mass + P->world.gravity_z;
+  float c_w[3], t1[3], t2[3], t3[3];
+  matvec(R, P->com, c_w);
+  cross3(wdot, c_w, t1);
+  cross3(w, c_w, t2);
+  cross3(w, t2, t3);
+  for (int i = 0; i < 3; ++i) a[i] = a[i] - t1[i] - t3[i];
+  /* v += a dt with the per-coordinate clamp (order: omega then velocity) */
+  const float vmax = P->world.max_coord_vel;
+  for (int i = 0; i < 3; ++i) w[i] = clipd(w[i] + wdot[i] * dt, -vmax, vmax);
+  for (int i = 0; i < 3; ++i) v[i] = clipd(v[i] + a[i] * dt, -vmax, vmax);
+  /* x += v dt (semi-implicit Euler: new velocity) */
+  for (int i = 0; i < 3; ++i) p[i] += dt * v[i];
+  /* q <- exp(w dt / 2) * q with world-frame w, then normalise */
+  float fAngle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (fAngle * dt > 0.25 * PI) fAngle = 0.25 * PI / dt; /* ANGULAR_MOTION_THRESHOLD */
+  float ax[3], k;
+  if (fAngle < 0.001)
+    k = 0.5 * dt - (dt * dt * dt) * 0.020833333333 * fAngle * fAngle;
+  else
+    k = sin(0.5 * fAngle * dt) / fAngle;
+  ax[0] = w[0] * k; ax[1] = w[1] * k; ax[2] = w[2] * k;
+  float cw = cos(fAngle * dt * 0.5);
+  float nq[4];
+  nq[0] = cw * q[0] + ax[0] * q[3] + ax[1] * q[2] - ax[2] * q[1];
+  nq[1] = cw * q[1] + ax[1] * q[3] + ax[2] * q[0] - ax[0] * q[2];
+  nq[2] = cw * q[2] + ax[2] * q[3] + ax[0] * q[1] - ax[1] * q[0];
+  nq[3] = cw * q[3] - ax[0] * q[0] - ax[1] * q[1] - ax[2] * q[2];
+  float inv = 1.0 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+  for (int i = 0; i < 4; ++i) q[i] = nq[i] * inv;
+}
+
+/* ------------------------------------------------------------------ PID  (abstractions/pid.py:70-94) */
+void orc_pid_step(const float* kp, const float* ki, const float* kd, const float* lim,
+                  float period, int n, float* I, float* E, const float* state,
+                  const float* setpoint, float* out) {
+  float tmp[3];
+  for (int i = 0; i < n; ++i) {
+    float error = setpoint[i] - state[i];
+    float proportional = kp[i] * error;
+    I[i] = clipd(I[i] + ki[i] * error * period, -lim[i], lim[i]);
+    float derivative = kd[i] * (error - E[i]) / period;
+    E[i] = error;
+    tmp[i] = clipd(proportional + I[i] + derivative, -lim[i], lim[i]);
+  }
+  for (int i = 0; i < n; ++i) out[i] = tmp[i];
+}
+static void pidn(const orc_params* P, orc_lane* L, int k, int n, const float* state, float* io) {
+  const orc_pid_gains* g = &P->pid[k];
+  orc_pid_step(g->kp, g->ki, g->kd, g->lim, P->control_period, n, L->pid_I[k], L->pid_E[k], state, io, io);
+}
+static float zpid(const orc_params* P, orc_lane* L, int k, float state, float sp) {
+  const orc_pid_gains* g = &P->zpid[k];
+  float out;
+  orc_pid_step(g->kp, g->ki, g->kd, g->lim, P->control_period, 1, &L->zpid_I[k], &L->zpid_E[k], &state, &sp, &out);
+  return out;
+}
+
+/* ------------------------------------------------------------------ QuadX control
+ * motor mixing + saturation: drones/quadx.py:482-493 */
+void orc_quadx_mix(const orc_params* P, const float cmd[4], float pwm[4]) {
+  for (int i = 0; i < 4; ++i) {
+    float s = 0.0;
+    for (int j = 0; j < 4; ++j) s += P->motor_map[i][j] * cmd[j];
+    pwm[i] = s;
+  }
+  float high = pwm[0], low = pwm[0];
+  for (int i = 1; i < 4; ++i) {
+    if (pwm[i] > high) high = pwm[i];
+    if (pwm[i] < low) low = pwm[i];
+  }
+  if (high != low) {
+    float pwm_max = high < 1.0 ? high : 1.0, pwm_min = low > 0.05 ? low : 0.05;
+    for (int i = 0; i < 4; ++i) {
+      float add = (pwm_min - low) / (pwm_max - low) * (pwm_max - pwm[i]);
+      float sub = (high - pwm_max) / (high - pwm_min) * (pwm[i] - pwm_min);
+      pwm[i] += add - sub;
+    }
+  }
+  for (int i = 0; i < 4; ++i) pwm[i] = clipd(pwm[i], 0.05, 1.0);
+}
+/* drones/quadx.py:401-493 (the physics_step % ratio gate lives in orc_aviary_step) */
+void orc_quadx_control(const orc_params* P, orc_lane* L) {
+  float a[3] = {L->setpoint[0], L->setpoint[1], L->setpoint[2]};
+  float z = L->setpoint[3];
+  const int mode = L->mode;
+  if (mode == -1) { /* quadx.py:432-434 */
+    for (int i = 0; i < 3; ++i) L->pwm[i] = a[i];
+    L->pwm[3] = z;
+    return;
+  }
+  const float* w_b = L->w_b;
+  const float* rpy = L->rpy;
+  const float* v_b = L->v_b;
+  const float* pos = L->p;
+  if (mode == 0 || mode == 2) {
+    pidn(P, L, 0, 3, w_b, a);
+  } else if (mode == 1 || mode == 3) {
+    pidn(P, L, 1, 3, rpy, a);
+    pidn(P, L, 0, 3, w_b, a);
+  } else if (mode == 4 || mode == 5 || mode == 6) {
+    if (mode == 6) { /* quadx.py:448-451 */
+      float c = cos(rpy[2]), s = sin(rpy[2]);
+      float a0 = c * a[0] + s * a[1], a1 = -s * a[0] + c * a[1];
+      a[0] = a0; a[1] = a1;
+    }
+    pidn(P, L, 2, 2, v_b, a);
+    { float t0 = -a[1], t1 = a[0]; a[0] = t0; a[1] = t1; }
+    pidn(P, L, 1, 2, rpy, a);
+    pidn(P, L, 0, 3, w_b, a);
+  } else if (mode == 7) {
+    pidn(P, L, 3, 2, pos, a);
+    float c = cos(rpy[2]), s = sin(rpy[2]);
+    float a0 = c * a[0] + s * a[1], a1 = -s * a[0] + c * a[1];
+    a[0] = a0; a[1] = a1;
+    pidn(P, L, 2, 2, v_b, a);
+    { float t0 = -a[1], t1 = a[0]; a[0] = t0; a[1] = t1; }
+    pidn(P, L, 1, 3, rpy, a);
+    pidn(P, L, 0, 3, w_b, a);
+  }
+  /* height controllers, quadx.py:471-479 */
+  if (mode == 0) {
+    z = clipd(z, 0.0, 1.0);
+  } else if (mode == 1 || mode == 5 || mode == 6) {
+    z = zpid(P, L, 0, v_b[2], z);
+    z = clipd(z, 0.0, 1.0);
+  } else {
+    z = zpid(P, L, 1, pos[2], z);
+    z = zpid(P, L, 0, v_b[2], z);
+    z = clipd(z, 0.0, 1.0);
+  }
+  float cmd[4] = {a[0], a[1], a[2], z};
+  orc_quadx_mix(P, cmd, L->pwm);
+}
+
+/* ------------------------------------------------------------------ Motors (abstractions/motors.py:110-195) */
+void orc_motors_update(const orc_params* P, float* throttle, const float* pwm, float xi,
+                       float thrust[4][3], float torque[4][3]) {
+  for (int i = 0; i < P->n_motors; ++i) {
+    throttle[i] += (P->world.dt / P->motor_tau[i]) * (pwm[i] - throttle[i]); /* :131 */
+    throttle[i] += xi * throttle[i] * P->noise_ratio[i];                     /* :134-138 */
+    float rpm = throttle[i] * P->max_rpm[i];
+    for (int k = 0; k < 3; ++k) {
+      float rpm_const = (rpm * rpm) * sgn(rpm) * P->thrust_unit[i][k]; /* :189 */
+      thrust[i][k] = rpm_const * P->thrust_coef[i];
+      torque[i][k] = rpm_const * P->torque_coef[i];
+    }
+  }
+}
+/* abstractions/boring_bodies.py:113-119 */
+void orc_body_drag(const orc_params* P, const float v_b[3], float F[3]) {
+  for (int k = 0; k < 3; ++k) F[k] = -sgn(v_b[k]) * P->drag_const[k] * (v_b[k] * v_b[k]);
+}
+
+/* ------------------------------------------------------------------ Lifting surface
+ * abstractions/lifting_surfaces.py:349-448 (aero data) */
+void orc_surface_aero(const orc_surface* S, float alpha, float actuation, float out[3]) {
+  float deflection_radians = (actuation * S->deflection_limit) * (PI / 180.0); /* np.deg2rad */
+  float delta_Cl = S->Cl_alpha_3D * S->aero_tau * S->eta * deflection_radians;
+  float delta_Cl_max = S->flap_to_chord * delta_Cl;
+  float Cl_max_P = S->Cl_alpha_3D * (S->alpha_stall_P_base - S->alpha_0_base) + delta_Cl_max;
+  float Cl_max_N = S->Cl_alpha_3D * (S->alpha_stall_N_base - S->alpha_0_base) + delta_Cl_max;
+  float alpha_0 = S->alpha_0_base - (delta_Cl / S->Cl_alpha_3D);
+  float alpha_stall_P = alpha_0 + (Cl_max_P / S->Cl_alpha_3D);
+  float alpha_stall_N = alpha_0 + (Cl_max_N / S->Cl_alpha_3D);
+  float Cl, Cd, CM;
+  if (alpha_stall_N < alpha && alpha < alpha_stall_P) { /* :397-406 */
+    Cl = S->Cl_alpha_3D * (alpha - alpha_0);
+    float alpha_i = Cl / (PI * S->aspect);
+    float alpha_eff = alpha - alpha_0 - alpha_i;
+    float CT = S->Cd_0 * cos(alpha_eff);
+    float CN = (Cl + (CT * sin(alpha_eff))) / cos(alpha_eff);
+    Cd = (CN * sin(alpha_eff)) + (CT * cos(alpha_eff));
+    CM = -CN * (0.25 - (0.175 * (1.0 - ((2.0 * alpha_eff) / PI))));
+    out[0] = Cl; out[1] = Cd; out[2] = CM;
+    return;
+  }
+  float alpha_i;
+  if (alpha > 0.0) { /* :409-416, np.interp over two points (clamped at the ends) */
+    float Cl_stall = S->Cl_alpha_3D * (alpha_stall_P - alpha_0);
+    float alpha_i_at_stall = Cl_stall / (PI * S->aspect);
+    float x0 = alpha_stall_P, x1 = PI / 2.0;
+    if (alpha <= x0) alpha_i = alpha_i_at_stall;
+    else if (alpha >= x1) alpha_i = 0.0;
+    else alpha_i = alpha_i_at_stall + (0.0 - alpha_i_at_stall) / (x1 - x0) * (alpha - x0);
+  } else { /* :417-425 */
+    float Cl_stall = S->Cl_alpha_3D * (alpha_stall_N - alpha_0);
+    float alpha_i_at_stall = Cl_stall / (PI * S->aspect);
+    float x0 = -PI / 2.0, x1 = alpha_stall_N;
+    if (alpha <= x0) alpha_i = 0.0;
+    else if (alpha >= x1) alpha_i = alpha_i_at_stall;
+    else alpha_i = 0.0 + (alpha_i_at_stall - 0.0) / (x1 - x0) * (alpha - x0);
+  }
+  float alpha_eff = alpha - alpha_0 - alpha_i;
+  float Cd_90 = ((-4.26e-2) * (deflection_radians * deflection_radians)) + ((2.1e-1) * deflection_radians) + 1.98;
+  float CN = Cd_90 * sin(alpha_eff) *
+              (1.0 / (0.56 + 0.44 * fabs(sin(alpha_eff))) - 0.41 * (1.0 - exp(-17.0 / S->aspect)));
+  float CT = 0.5 * S->Cd_0 * cos(alpha_eff);
+  Cl = (CN * cos(alpha_eff)) - (CT * sin(alpha_eff));
+  Cd = (CN * sin(alpha_eff)) + (CT * cos(alpha_eff));
+  CM = -CN * (0.25 - (0.175 * (1.0 - ((2.0 * fabs(alpha_eff)) / PI))));
+  out[0] = Cl; out[1] = Cd; out[2] = CM;
+}
+/* lifting_surfaces.py:326-347 (alpha, V) and :450-498 (force, torque); actuation already updated */
+void orc_surface_force(const orc_surface* S, const float v_local[3], float actuation,
+                       float F[3], float T[3]) {
+  float freestream_speed = sqrt(dot3(v_local, v_local));
+  float lifting_airspeed = dot3(v_local, S->lift_unit);
+  float forward_airspeed = dot3(v_local, S->drag_unit);
+  float alpha = atan2(-lifting_airspeed, forward_airspeed);
+  float c[3];
+  orc_surface_aero(S, alpha, actuation, c);
+  float Q = S->half_rho * (freestream_speed * freestream_speed);
+  float Q_area = Q * S->area;
+  float lift = c[0] * Q_area, drag = c[1] * Q_area;
+  float force_normal = (lift * cos(alpha)) + (drag * sin(alpha));
+  float force_parallel = (lift * sin(alpha)) - (drag * cos(alpha));
+  for (int k = 0; k < 3; ++k) {
+    F[k] = S->lift_unit[k] * force_normal + S->drag_unit[k] * force_parallel;
+    T[k] = Q_area * c[2] * S->chord * S->torque_unit[k];
+  }
+}
+
+/* ------------------------------------------------------------------ parameter sets */
+static void world_defaults(orc_world* W) {
+  W->dt = 1.0 / 240.0;       /* aviary.py:79 */
+  W->gravity_z = -9.81;      /* aviary.py:226 */
+  W->use_gyro_term = 1;      /* [BULLET-FROM-MEMORY] */
+  W->max_coord_vel = 100.0;  /* [BULLET-FROM-MEMORY] */
+  W->plane_half_xy = 15.0;   /* [BULLET-FROM-MEMORY] pybullet_data plane.urdf */
+  W->plane_half_z = 5.0;
+  W->ticks_per_control = 2;  /* 240/120, quadx.py:27-28 */
+}
+static void set_pid(orc_pid_gains* g, int n, const float* kp, const float* ki, const float* kd, const float* lim) {
+  memset(g, 0, sizeof(*g));
+  for (int i = 0; i < n; ++i) { g->kp[i] = kp[i]; g->ki[i] = ki[i]; g->kd[i] = kd[i]; g->lim[i] = lim[i]; }
+}
+void orc_finalize(orc_params* P) {
+  float I[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) I[i][j] = P->I_own[i][j] + P->I_pa[i][j];
+  inv3(I, P->I_inv);
+  float r = 0.0;
+  for (int k = 0; k < P->n_boxes; ++k) {
+    float m = 0.0;
+    for (int s = 0; s < 8; ++s) {
+      float x = P->boxes[k].c[0] + ((s & 1) ? 1 : -1) * P->boxes[k].h[0];
+      float y = P->boxes[k].c[1] + ((s & 2) ? 1 : -1) * P->boxes[k].h[1];
+      float z = P->boxes[k].c[2] + ((s & 4) ? 1 : -1) * P->boxes[k].h[2];
+      float d = sqrt(x * x + y * y + z * z);
+      if (d > m) m = d;
+    }
+    if (m > r) r = m;
+  }
+  P->bound_radius = r;
+  for (int i = 0; i < P->n_surf; ++i) { /* lifting_surfaces.py:228-239 */
+    orc_surface* S = &P->surf[i];
+    S->half_rho = 0.5 * 1.225;
+    S->area = S->chord * S->span;
+    S->aspect = S->span / S->chord;
+    S->Cl_alpha_3D = S->Cl_alpha_2D * (S->aspect / (S->aspect + ((2.0 * (S->aspect + 4.0)) / (S->aspect + 2.0))));
+    S->theta_f = acos(2.0 * S->flap_to_chord - 1.0);
+    S->aero_tau = 1 - ((S->theta_f - sin(S->theta_f)) / PI);
+    cross3(S->lift_unit, S->drag_unit, S->torque_unit);
+  }
+}
+
+void orc_params_quadx(orc_params* P) {
+  memset(P, 0, sizeof(*P));
+  P->vehicle = ORC_QUADX;
+  world_defaults(&P->world);
+  /* cf2x.urdf:13-14 */
+  P->mass = 0.027;
+  P->I_own[0][0] = 1.4e-5; P->I_own[1][1] = 1.4e-5; P->I_own[2][2] = 2.17e-5;
+  /* cf2x.urdf:30-36 collision box 0.09 x 0.09 x 0.02 on the base */
+  P->n_boxes = 1;
+  P->boxes[0].h[0] = 0.045; P->boxes[0].h[1] = 0.045; P->boxes[0].h[2] = 0.01;
+  /* cf2x.yaml:1-6, quadx.py:93-128 */
+  const float total_thrust = 2.0, thrust_coef = 3.16e-10, torque_coef = 7.94e-12, noise = 0.02, tau = 0.01;
+  P->n_motors = 4;
+  const float rx[4] = {0.028, -0.028, 0.028, -0.028}; /* cf2x.urdf:42,54,66,78 */
+  const float ry[4] = {-0.028, 0.028, 0.028, -0.028};
+  const float tq[4] = {-1, -1, +1, +1};               /* quadx.py:94-101 */
+  for (int i = 0; i < 4; ++i) {
+    P->motor_r[i][0] = rx[i]; P->motor_r[i][1] = ry[i]; P->motor_r[i][2] = 0.0;
+    P->thrust_unit[i][2] = 1.0;
+    P->thrust_coef[i] = thrust_coef;
+    P->torque_coef[i] = tq[i] * torque_coef;
+    P->max_rpm[i] = 1.0 * sqrt(total_thrust / (4 * thrust_coef)); /* quadx.py:111-113 */
+    P->motor_tau[i] = tau;
+    P->noise_ratio[i] = 1.0 * noise;
+  }
+  const float M[4][4] = {{-1, -1, -1, +1}, {+1, +1, -1, +1}, {+1, -1, +1, +1}, {-1, +1, +1, +1}}; /* quadx.py:130-137 */
+  memcpy(P->motor_map, M, sizeof(M));
+  for (int k = 0; k < 3; ++k) P->drag_const[k] = 0.5 * 1.225 * 3.0 * 4.0e-4; /* boring_bodies.py:63, cf2x.yaml:9-10 */
+  P->drag_coef_pqr = 1.0e-4;                                                  /* cf2x.yaml:11 */
+  { /* cf2x.yaml:13-54 */
+    const float kp0[3] = {4.0e-2, 4.0e-2, 8.0e-2}, ki0[3] = {5.0e-7, 5.0e-7, 2.7e-4}, kd0[3] = {1.0e-4, 1.0e-4, 0.0}, l0[3] = {1, 1, 1};
+    const float kp1[3] = {2, 2, 2}, z3[3] = {0, 0, 0}, l1[3] = {3, 3, 3};
+    const float kp2[2] = {0.8, 0.8}, ki2[2] = {0.3, 0.3}, kd2[2] = {0.5, 0.5}, l2[2] = {0.4, 0.4};
+    const float kp3[2] = {1, 1}, l3[2] = {2, 2};
+    set_pid(&P->pid[0], 3, kp0, ki0, kd0, l0);
+    set_pid(&P->pid[1], 3, kp1, z3, z3, l1);
+    set_pid(&P->pid[2], 2, kp2, ki2, kd2, l2);
+    set_pid(&P->pid[3], 2, kp3, z3, z3, l3);
+    const float zvkp = 2.0, zvki = 0.5, zvkd = 0.05, zvl = 1.0;
+    const float zpkp = 1.0, zero = 0.0, zpl = 1.0;
+    set_pid(&P->zpid[0], 1, &zvkp, &zvki, &zvkd, &zvl);
+    set_pid(&P->zpid[1], 1, &zpkp, &zero, &zero, &zpl);
+  }
+  P->control_period = 1.0 / 120.0; /* quadx.py:27 */
+  P->start_pos[2] = 1.0;           /* quadx_base_env.py:23 */
+  P->settle_steps = 10;
+  P->angle_repr = 1;
+  orc_finalize(P);
+}
+
+void orc_params_fixedwing(orc_params* P) {
+  memset(P, 0, sizeof(*P));
+  P->vehicle = ORC_FIXEDWING;
+  world_defaults(&P->world);
+  /* fixedwing.urdf: point masses at link origins, all link inertias zero */
+  const float m[7] = {0.3, 0.1, 0.05, 0.2, 0.2, 0.5, 1.0}; /* base, h-tail, v-tail, L-ail, R-ail, main, fuselage */
+  const float r[7][3] = {{0, 0, 0}, {-1.1, 0, 0}, {-1.1, 0, 0.15}, {-0.5, 0.95, 0}, {-0.5, -0.95, 0}, {-0.5, 0, 0}, {-0.45, 0, 0}};
+  float M = 0, c[3] = {0, 0, 0};
+  for (int i = 0; i < 7; ++i) { M += m[i]; for (int k = 0; k < 3; ++k) c[k] += m[i] * r[i][k]; }
+  for (int k = 0; k < 3; ++k) c[k] /= M;
+  P->mass = M;
+  memcpy(P->com, c, sizeof(c));
+  for (int i = 0; i < 7; ++i) {
+    float d[3] = {r[i][0] - c[0], r[i][1] - c[1], r[i][2] - c[2]};
+    float d2 = dot3(d, d);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) P->I_pa[a][b] += m[i] * ((a == b ? d2 : 0.0) - d[a] * d[b]);
+  }
+  /* collision boxes: fixedwing.urdf:44-49,70-75,96-101,122-127,148-153,174-179 */
+  const float bc[6][3] = {{-1.1, 0, 0}, {-1.1, 0, 0.15}, {-0.5, 0.95, 0}, {-0.5, -0.95, 0}, {-0.5, 0, 0}, {-0.45, 0, 0}};
+  const float bs[6][3] = {{0.3, 0.6, 0.05}, {0.3, 0.05, 0.3}, {0.31, 0.3, 0.06}, {0.31, 0.3, 0.06}, {0.3, 1.8, 0.05}, {1.4, 0.2, 0.2}};
+  P->n_boxes = 6;
+  for (int i = 0; i < 6; ++i)
+    for (int k = 0; k < 3; ++k) { P->boxes[i].c[k] = bc[i][k]; P->boxes[i].h[k] = 0.5 * bs[i][k]; }
+  /* motor: fixedwing.yaml:1-6, fixedwing.py:147-168 */
+  P->n_motors = 1;
+  P->thrust_unit[0][0] = 1.0;
+  P->thrust_coef[0] = 3.16e-10;
+  P->torque_coef[0] = 7.94e-12;
+  P->max_rpm[0] = 1.0 * sqrt(18.0 / 3.16e-10);
+  P->motor_tau[0] = 0.01;
+  P->noise_ratio[0] = 0.02;
+  /* surfaces: fixedwing.py:80-138 order, fixedwing.yaml:8-71 */
+  P->n_surf = 5;
+  const float sr[5][3] = {{-0.5, 0.95, 0}, {-0.5, -0.95, 0}, {-1.1, 0, 0}, {-1.1, 0, 0.15}, {-0.5, 0, 0}};
+  const float chord[5] = {0.3, 0.3, 0.2, 0.2, 0.3}, span[5] = {0.3, 0.3, 0.625, 0.312, 1.6};
+  const float a0[5] = {-2, -2, 0, 0, -2}, asp[5] = {14, 14, 9, 9, 14}, asn[5] = {-9, -9, -9, -9, -9};
+  const float lim[5] = {30, 30, 20, 20, 0};
+  for (int i = 0; i < 5; ++i) {
+    orc_surface* S = &P->surf[i];
+    memcpy(S->r, sr[i], sizeof(S->r));
+    S->lift_unit[2] = 1.0;
+    if (i == 3) { S->lift_unit[2] = 0.0; S->lift_unit[1] = 1.0; } /* v-tail, fixedwing.py:121 */
+    S->drag_unit[0] = 1.0;
+    S->Cl_alpha_2D = 6.283; S->chord = chord[i]; S->span = span[i]; S->flap_to_chord = 0.3; S->eta = 0.65;
+    S->alpha_0_base = a0[i] * (PI / 180.0);
+    S->alpha_stall_P_base = asp[i] * (PI / 180.0);
+    S->alpha_stall_N_base = asn[i] * (PI / 180.0);
+    S->Cd_0 = 0.01; S->deflection_limit = lim[i]; S->tau = 0.05;
+  }
+  const int ids[6] = {0, 0, 1, 2, 1, 3};           /* fixedwing.py:143 */
+  const float sg[6] = {1, -1, 1, -1, -1, 1};      /* fixedwing.py:144 */
+  memcpy(P->assist_ids, ids, sizeof(ids));
+  memcpy(P->assist_signs, sg, sizeof(sg));
+  P->control_period = 1.0 / 120.0;
+  P->start_pos[2] = 10.0;   /* fixedwing_waypoints_env.py:63 */
+  P->start_vel[0] = 20.0;   /* fixedwing.py:35 */
+  P->settle_steps = 10;
+  P->angle_repr = 1;
+  orc_finalize(P);
+}
+void orc_task_hover(orc_params* P) { /* quadx_hover_env.py:32-37 */
+  P->task = ORC_TASK_HOVER;
+  P->flight_mode = 0; P->dome = 3.0; P->max_steps = 400; P->env_step_ratio = 3;
+  P->start_pos[0] = 0; P->start_pos[1] = 0; P->start_pos[2] = 1.0;
+  P->sparse_reward = 0; P->angle_repr = 1; P->num_targets = 0; P->collide_any = 0; P->throttle_remap = 0;
+}
+void orc_task_quadx_waypoints(orc_params* P) { /* quadx_waypoints_env.py:38-47,87 */
+  P->task = ORC_TASK_WAYPOINTS;
+  P->flight_mode = 0; P->dome = 5.0; P->max_steps = 300; P->env_step_ratio = 4;
+  P->start_pos[0] = 0; P->start_pos[1] = 0; P->start_pos[2] = 1.0;
+  P->sparse_reward = 0; P->angle_repr = 1; P->num_targets = 4; P->goal_reach_distance = 0.2;
+  P->min_height = 0.1; P->collide_any = 0; P->throttle_remap = 0;
+  P->wp_dist_reward = 0.1; P->wp_yaw_penalty = 0.01;
+}
+void orc_task_fixedwing_waypoints(orc_params* P) { /* fixedwing_waypoints_env.py:36-45,63,81 */
+  P->task = ORC_TASK_WAYPOINTS;
+  P->flight_mode = 0; P->dome = 100.0; P->max_steps = 3600; P->env_step_ratio = 4;
+  P->start_pos[0] = 0; P->start_pos[1] = 0; P->start_pos[2] = 10.0;
+  P->sparse_reward = 0; P->angle_repr = 1; P->num_targets = 4; P->goal_reach_distance = 2.0;
+  P->min_height = 0.5; P->collide_any = 1; P->throttle_remap = 1;
+  P->wp_dist_reward = 1.0; P->wp_yaw_penalty = 0.0;
+}
+
+/* ------------------------------------------------------------------ lane level */
+/* quadx.py:512-535 / fixedwing.py:266-291 */
+void orc_update_state(const orc_params* P, orc_lane* L) {
+  float R[3][3];
+  orc_matrix_from_quat(L->q, R);
+  matTvec(R, L->v, L->v_b);   /* rotation = R^T (quadx.py:521-523) */
+  matTvec(R, L->w, L->w_b);
+  orc_euler_from_quat(L->q, L->rpy);
+  for (int i = 0; i < P->n_surf; ++i) { /* lifting_surfaces.py:73-110 */
+    float rw[3], wxr[3], lv[3];
+    matvec(R, P->surf[i].r, rw);
+    cross3(L->w, rw, wxr);
+    for (int k = 0; k < 3; ++k) lv[k] = L->v[k] + wxr[k];
+    matTvec(R, lv, L->surf_v[i]);
+  }
+}
+/* quadx.py:233-373 ; fixedwing.py:206-227 */
+void orc_set_mode(const orc_params* P, orc_lane* L, int mode) {
+  L->mode = mode;
+  if (P->vehicle == ORC_FIXEDWING) {
+    for (int i = 0; i < 6; ++i) L->setpoint[i] = 0.0;
+    return;
+  }
+  if (mode == -1) return;
+  for (int i = 0; i < 6; ++i) L->setpoint[i] = 0.0;
+  if (mode == 0) {
+    L->setpoint[3] = -1.0;
+  } else if (mode == 1 || mode == 5 || mode == 6) {
+  } else if (mode == 7) {
+    L->setpoint[0] = L->p[0]; L->setpoint[1] = L->p[1]; L->setpoint[2] = L->rpy[2]; L->setpoint[3] = L->p[2];
+  } else {
+    L->setpoint[3] = L->p[2];
+  }
+  /* fresh PID objects (z_PIDs are NOT re-created, quadx.py:206) */
+  memset(L->pid_I, 0, sizeof(L->pid_I));
+  memset(L->pid_E, 0, sizeof(L->pid_E));
+}
+/* aviary.py:218-312 + quadx.py:222-231 / fixedwing.py:194-204 */
+void orc_aviary_reset(const orc_params* P, orc_lane* L, uint64_t lane_id) {
+  uint32_t ctr = L->rng_ctr;
+  memset(L, 0, sizeof(*L));
+  L->rng_ctr = ctr;
+  L->lane_id = lane_id;
+  for (int k = 0; k < 3; ++k) { L->p[k] = P->start_pos[k]; L->v[k] = P->start_vel[k]; }
+  orc_quat_from_euler(P->start_rpy, L->q); /* base_drone.py:115 */
+  orc_set_mode(P, L, 0);
+  for (int i = 0; i < 6; ++i) L->setpoint[i] = 0.0; /* quadx.py:225 */
+  memset(L->zpid_I, 0, sizeof(L->zpid_I));
+  memset(L->zpid_E, 0, sizeof(L->zpid_E));
+  orc_update_state(P, L);
+}
+
+static float tick_noise(const orc_params* P, const orc_lane* L, const float* xi, int t, uint32_t flat, uint32_t stream) {
+  if (P->noise_mode == ORC_NOISE_OFF) return 0.0;
+  /* np_random.normal(*throttle.shape) == normal(loc=num_motors, scale=1): motors.py:135.
+   * Injected samples are the raw draws xi ~ N(num_motors, 1). */
+  if (P->noise_mode == ORC_NOISE_INJECT) return xi[t];
+  return (float)P->n_motors + lane_normal(P, L, flat, stream);
+}
+
+/* aviary.py:480-531 */
+void orc_aviary_step(const orc_params* P, orc_lane* L, const float* xi, uint32_t flat_base, uint32_t stream) {
+  L->contact_step = 0; /* :507 */
+  for (int t = 0; t < P->world.ticks_per_control; ++t) {
+    /* update_control */
+    if (L->physics_steps % P->world.ticks_per_control == 0) {
+      if (P->vehicle == ORC_QUADX) {
+        orc_quadx_control(P, L);
+      } else if (L->mode == -1) { /* fixedwing.py:241-243 */
+        for (int i = 0; i < 6; ++i) L->cmd[i] = L->setpoint[i];
+      } else { /* fixedwing.py:246-250 */
+        for (int i = 0; i < 6; ++i) L->cmd[i] = L->setpoint[P->assist_ids[i]] * P->assist_signs[i];
+      }
+    }
+    /* update_physics */
+    float F_b[3] = {0, 0, 0}, T_b[3] = {0, 0, 0};
+    float thrust[4][3], torque[4][3];
+    float noise = tick_noise(P, L, xi, t, flat_base + (uint32_t)t, stream);
+    if (P->vehicle == ORC_QUADX) {
+      float Fd[3];
+      orc_body_drag(P, L->v_b, Fd); /* quadx.py:498, body link at the origin */
+      for (int k = 0; k < 3; ++k) F_b[k] += Fd[k];
+      orc_motors_update(P, L->throttle, L->pwm, noise, thrust, torque); /* quadx.py:499 */
+      for (int i = 0; i < 4; ++i) {
+        float rxf[3];
+        cross3(P->motor_r[i], thrust[i], rxf);
+        for (int k = 0; k < 3; ++k) { F_b[k] += thrust[i][k]; T_b[k] += rxf[k] + torque[i][k]; }
+      }
+      if (!L->contact_now) { /* quadx.py:502-510 */
+        for (int k = 0; k < 3; ++k) T_b[k] += -sgn(L->w_b[k]) * P->drag_coef_pqr * (L->w_b[k] * L->w_b[k]);
+      }
+    } else {
+      for (int i = 0; i < P->n_surf; ++i) { /* fixedwing.py:263, lifting_surfaces.py:266-324 */
+        const orc_surface* S = &P->surf[i];
+        L->actuation[i] += (P->world.dt / S->tau) * (L->cmd[i] - L->actuation[i]);
+        float F[3], T[3], rxf[3];
+        orc_surface_force(S, L->surf_v[i], L->actuation[i], F, T);
+        cross3(S->r, F, rxf);
+        for (int k = 0; k < 3; ++k) { F_b[k] += F[k]; T_b[k] += rxf[k] + T[k]; }
+      }
+      orc_motors_update(P, L->throttle, &L->cmd[5], noise, thrust, torque); /* fixedwing.py:264 */
+      float rxf[3];
+      cross3(P->motor_r[0], thrust[0], rxf);
+      for (int k = 0; k < 3; ++k) { F_b[k] += thrust[0][k]; T_b[k] += rxf[k] + torque[0][k]; }
+    }
+    /* stepSimulation: collision detection at the pre-integration pose, then the free-body tick */
+    L->contact_now = orc_contact_plane(P, L->p, L->q);
+    orc_rigid_tick(P, L->p, L->q, L->v, L->w, F_b, T_b);
+    orc_update_state(P, L);
+    if (L->contact_now) L->contact_step = 1; /* :523-525 */
+    L->physics_steps += 1;
+  }
+}
+
+/* gym_envs/utils/waypoint_handler.py:53-89 ; injected draws: u[0:n]=theta, u[n:2n]=phi,
+ * u[2n:3n]=dist (already scaled, in the reference's draw order :72-75) */
+static void sample_targets(const orc_params* P, orc_lane* L, const float* u_inj) {
+  int n = P->num_targets;
+  L->n_targets_left = n;
+  L->new_dist = INFINITY; L->old_dist = INFINITY;
+  for (int i = 0; i < n; ++i) {
+    float theta, phi, dist;
+    if (u_inj == 0) {
+      theta = (2.0 * PI) * lane_uniform(P, L, (uint32_t)i, 2);
+      phi = (2.0 * PI) * lane_uniform(P, L, (uint32_t)(n + i), 2);
+      dist = 1.0 + (P->dome * 0.9 - 1.0) * lane_uniform(P, L, (uint32_t)(2 * n + i), 2);
+    } else {
+      theta = u_inj[i]; phi = u_inj[n + i]; dist = u_inj[2 * n + i];
+    }
+    float x = dist * sin(phi) * cos(theta), y = dist * sin(phi) * sin(theta), z = fabs(dist * cos(phi));
+    L->targets[i][0] = x; L->targets[i][1] = y; L->targets[i][2] = z > P->min_height ? z : P->min_height;
+  }
+}
+/* waypoint_handler.py:117-158: distance_to_targets (no yaw targets) */
+static void compute_deltas(const orc_params* P, orc_lane* L, float deltas[][3]) {
+  float qe[4], R[3][3];
+  orc_quat_from_euler(L->rpy, qe); /* quadx_base_env.py:243 */
+  orc_matrix_from_quat(qe, R);
+  for (int i = 0; i < L->n_targets_left; ++i) {
+    float d[3] = {L->targets[i][0] - L->p[0], L->targets[i][1] - L->p[1], L->targets[i][2] - L->p[2]};
+    matTvec(R, d, deltas[i]); /* row-vector @ R */
+  }
+  (void)P;
+}
+int orc_obs_dim(const orc_params* P) {
+  int att = (P->angle_repr ? 13 : 12) + 4 + (P->vehicle == ORC_QUADX ? 4 : 6);
+  return att + (P->task == ORC_TASK_WAYPOINTS ? 3 * P->num_targets : 0);
+}
+/* quadx_hover_env.py:85-115 ; quadx_waypoints_env.py:125-175 ; flatten_waypoint_env.py:42-62.
+ * compute_state(): builds the observation (cached in the lane, as the reference caches
+ * self.state) and, for waypoint envs, updates old/new distance (waypoint_handler.py:141-142). */
+static void env_compute_state(const orc_params* P, orc_lane* L) {
+  float* obs = L->obs;
+  int k = 0;
+  for (int i = 0; i < 3; ++i) obs[k++] = L->w_b[i];
+  if (P->angle_repr) {
+    float qe[4];
+    orc_quat_from_euler(L->rpy, qe);
+    for (int i = 0; i < 4; ++i) obs[k++] = qe[i];
+  } else {
+    for (int i = 0; i < 3; ++i) obs[k++] = L->rpy[i];
+  }
+  for (int i = 0; i < 3; ++i) obs[k++] = L->v_b[i];
+  for (int i = 0; i < 3; ++i) obs[k++] = L->p[i];
+  for (int i = 0; i < 4; ++i) obs[k++] = L->action[i];
+  if (P->vehicle == ORC_QUADX) {
+    for (int i = 0; i < 4; ++i) obs[k++] = L->throttle[i];
+  } else { /* fixedwing.py:289-291 */
+    for (int i = 0; i < 5; ++i) obs[k++] = L->actuation[i];
+    obs[k++] = L->throttle[0];
+  }
+  if (P->task == ORC_TASK_WAYPOINTS) {
+    float deltas[ORC_MAX_TARGETS][3];
+    compute_deltas(P, L, deltas);
+    for (int i = 0; i < P->num_targets; ++i)
+      for (int c = 0; c < 3; ++c) obs[k++] = (i < L->n_targets_left) ? deltas[i][c] : 0.0;
+    L->old_dist = L->new_dist;
+    L->new_dist = sqrt(dot3(deltas[0], deltas[0]));
+  }
+}
+void orc_env_obs(const orc_params* P, const orc_lane* L, float* obs) {
+  memcpy(obs, L->obs, sizeof(float) * (size_t)orc_obs_dim(P));
+}
+/* quadx_base_env.py:251-267 + hover :117-138 + waypoints :177-204 + fixedwing_waypoints :169-190 */
+static void env_term_trunc_reward(const orc_params* P, orc_lane* L) {
+  if (L->step_count > P->max_steps) L->truncated = 1;
+  if (L->contact_step) { L->reward = -100.0; L->info_collision = 1; L->terminated = 1; }
+  if (sqrt(dot3(L->p, L->p)) > P->dome) { L->reward = -100.0; L->info_oob = 1; L->terminated = 1; }
+  if (P->task == ORC_TASK_HOVER) {
+    if (!P->sparse_reward) {
+      float d[3] = {L->p[0] - 0.0, L->p[1] - 0.0, L->p[2] - 1.0};
+      float linear_distance = sqrt(dot3(d, d));
+      float yaw_rate = fabs(L->w_b[2]);
+      L->reward -= 0.01 * (yaw_rate * yaw_rate);
+      float angular_distance = sqrt(L->rpy[0] * L->rpy[0] + L->rpy[1] * L->rpy[1]);
+      L->reward -= linear_distance + angular_distance;
+      L->reward += 1.0;
+    }
+  } else if (P->task == ORC_TASK_WAYPOINTS) {
+    if (!P->sparse_reward) {
+      float progress = (isinf(L->old_dist + L->new_dist)) ? 0.0 : L->old_dist - L->new_dist;
+      float pr = 3.0 * progress;
+      L->reward += pr > 0.0 ? pr : 0.0;
+      L->reward += P->wp_dist_reward / L->new_dist;
+      if (P->wp_yaw_penalty != 0.0) {
+        float yaw_rate = fabs(L->w_b[2]);
+        L->reward -= P->wp_yaw_penalty * (yaw_rate * yaw_rate);
+      }
+    }
+    if (L->new_dist < P->goal_reach_distance) { /* target_reached, waypoint_handler.py:167-179 */
+      L->reward = 100.0;
+      for (int i = 1; i < L->n_targets_left; ++i) memcpy(L->targets[i - 1], L->targets[i], sizeof(L->targets[0]));
+      L->n_targets_left -= 1;
+      int all = (L->n_targets_left == 0);
+      if (all) L->truncated = 1;
+      L->info_complete = all;
+      L->num_targets_reached = P->num_targets - L->n_targets_left;
+    }
+  }
+}
+
+/* quadx_base_env.py:149-212 (+ quadx_waypoints_env.py:120-123) */
+void orc_env_reset(const orc_params* P, orc_lane* L, uint64_t lane_id, const float* xi_reset, const float* u_targets) {
+  orc_aviary_reset(P, L, lane_id);
+  if (P->task == ORC_TASK_WAYPOINTS) sample_targets(P, L, u_targets);
+  orc_set_mode(P, L, P->flight_mode);
+  const int tpc = P->world.ticks_per_control;
+  for (int s = 0; s < P->settle_steps; ++s)
+    orc_aviary_step(P, L, xi_reset ? xi_reset + s * tpc : 0, (uint32_t)(s * tpc), 1);
+  env_compute_state(P, L);
+  L->rng_ctr += 1;
+}
+/* quadx_base_env.py:269-301 ; fixedwing_base_env.py:244-278 */
+void orc_env_step(const orc_params* P, orc_lane* L, const float action[4], const float* xi) {
+  for (int i = 0; i < 4; ++i) { L->action[i] = action[i]; L->setpoint[i] = action[i]; }
+  if (P->throttle_remap) L->setpoint[3] = (action[3] / 2.0) + 0.5;
+  L->reward = -0.1;
+  const int tpc = P->world.ticks_per_control;
+  for (int s = 0; s < P->env_step_ratio; ++s) {
+    if (L->terminated || L->truncated) break;
+    orc_aviary_step(P, L, xi ? xi + s * tpc : 0, (uint32_t)(s * tpc), 0);
+    env_compute_state(P, L);
+    env_term_trunc_reward(P, L);
+  }
+  L->step_count += 1;
+  L->rng_ctr += 1;
+}
+
+/* ------------------------------------------------------------------ batch level */
+void orc_env_reset_batch(const orc_params* P, orc_lane* L, int n, uint64_t lane0, const uint8_t* mask,
+                         const float* xi_reset, const float* u_targets) {
+  const int nr = P->settle_steps * P->world.ticks_per_control, nu = 3 * P->num_targets;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    if (mask && !mask[i]) continue;
+    orc_env_reset(P, &L[i], lane0 + (uint64_t)i, xi_reset ? xi_reset + (size_t)i * nr : 0,
+                  u_targets ? u_targets + (size_t)i * nu : 0);
+  }
+}
+void orc_env_step_batch(const orc_params* P, orc_lane* L, int n, const float* actions, const float* xi,
+                        const float* xi_reset, const float* u_targets, int autoreset, float* obs,
+                        float* reward, uint8_t* term, uint8_t* trunc, float* final_obs) {
+  const int D = orc_obs_dim(P);
+  const int ns = P->env_step_ratio * P->world.ticks_per_control;
+  const int nr = P->settle_steps * P->world.ticks_per_control, nu = 3 * P->num_targets;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    orc_lane* l = &L[i];
+    const float* xr = xi_reset ? xi_reset + (size_t)i * nr : 0;
+    const float* ut = u_targets ? u_targets + (size_t)i * nu : 0;
+    if (autoreset == 1 && (l->terminated || l->truncated)) { /* gymnasium NEXT_STEP */
+      orc_env_reset(P, l, l->lane_id, xr, ut);
+      orc_env_obs(P, l, obs + (size_t)i * D);
+      reward[i] = 0.0; term[i] = 0; trunc[i] = 0;
+      continue;
+    }
+    float a[4] = {actions[4 * i + 0], actions[4 * i + 1], actions[4 * i + 2], actions[4 * i + 3]};
+    orc_env_step(P, l, a, xi ? xi + (size_t)i * ns : 0);
+    reward[i] = l->reward; term[i] = (uint8_t)l->terminated; trunc[i] = (uint8_t)l->truncated;
+    if (autoreset == 2 && (l->terminated || l->truncated)) { /* SAME_STEP */
+      if (final_obs) orc_env_obs(P, l, final_obs + (size_t)i * D);
+      orc_env_reset(P, l, l->lane_id, xr, ut);
+    }
+    orc_env_obs(P, l, obs + (size_t)i * D);
+  }
+}
+int orc_sizeof_lane(void) { return (int)sizeof(orc_lane); }
+int orc_sizeof_params(void) { return (int)sizeof(orc_params); }
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

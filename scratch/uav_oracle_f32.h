@@ -1,0 +1,228 @@
+/*
+ * uav_oracle.h -- TEST INFRASTRUCTURE ONLY (parity oracle, fp64, scalar, one drone at a time).
+ *
+ * CPU restatement of the PyFlyt `Aviary.step()` hot path (reference @ /root/reference, v0.30.0)
+ * and of the slice of Bullet's free-multibody step that PyFlyt drives underneath it.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product path (pyflyt_amd/) never links, imports or calls it.
+ *
+ * PARITY STATUS
+ *   - PyFlyt-side arithmetic (PID, mixer, motors, drag, lifting surfaces, env logic): pinned
+ *     against golden vectors generated in the build container by importing the reference's own
+ *     Python (tests/golden/gen_*.py).
+ *   - Bullet-side arithmetic (integrator, contact reporting, quaternion/Euler helpers):
+ *     "parity unpinned" -- pybullet (unpinned dependency, pyproject.toml:19) is absent from
+ *     /root/reference and from the container; those functions restate Bullet3's published
+ *     algorithm from memory and are marked [BULLET-FROM-MEMORY]; every doubtful constant is a
+ *     named parameter in orc_world.
+ */
+#ifndef UAV_ORACLE_H
+#define UAV_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_TARGETS 8
+#define ORC_MAX_BOXES 8
+#define ORC_MAX_SURF 5
+
+enum { ORC_QUADX = 0, ORC_FIXEDWING = 1 };
+enum { ORC_TASK_NONE = 0, ORC_TASK_HOVER = 1, ORC_TASK_WAYPOINTS = 2 };
+enum { ORC_NOISE_OFF = 0, ORC_NOISE_INJECT = 1, ORC_NOISE_PHILOX = 2 };
+
+/* World / integrator knobs -- aviary.py:225-242 + [BULLET-FROM-MEMORY] defaults */
+typedef struct {
+  float dt;                 /* 1/physics_hz, aviary.py:79,164 */
+  float gravity_z;          /* -9.81, aviary.py:226 */
+  int use_gyro_term;         /* btMultiBody::m_useGyroTerm, believed default true */
+  float max_coord_vel;      /* btMultiBody::m_maxCoordinateVelocity = 100 */
+  float plane_half_xy;      /* plane.urdf collision box 30x30x10 -> 15 * world_scale */
+  float plane_half_z;       /* 5 * world_scale; box centre at z = -plane_half_z */
+  int ticks_per_control;     /* physics_hz / control_hz = 2, base_drone.py:102 */
+} orc_world;
+
+typedef struct {
+  float kp[3], ki[3], kd[3], lim[3];
+} orc_pid_gains;
+
+typedef struct {
+  float c[3];  /* centre in base frame */
+  float h[3];  /* half extents */
+} orc_box;
+
+/* One lifting surface -- lifting_surfaces.py:141-239, fixedwing.yaml:8-71 */
+typedef struct {
+  float r[3];          /* link COM offset in base frame (fixedwing.urdf joint origins) */
+  float lift_unit[3], drag_unit[3], torque_unit[3];
+  float Cl_alpha_2D, chord, span, flap_to_chord, eta;
+  float alpha_0_base, alpha_stall_P_base, alpha_stall_N_base; /* radians (deg2rad applied) */
+  float Cd_0, deflection_limit /* degrees */, tau;
+  /* precomputed (lifting_surfaces.py:228-239) */
+  float half_rho, area, aspect, Cl_alpha_3D, theta_f, aero_tau;
+} orc_surface;
+
+typedef struct {
+  int vehicle;               /* ORC_QUADX / ORC_FIXEDWING */
+  orc_world world;
+
+  /* composite rigid body (cf2x.urdf:13-14 ; fixedwing.urdf point masses) */
+  float mass;
+  float com[3];             /* composite COM in base frame */
+  float I_own[3][3];        /* sum of the links' own inertia tensors (gyro-term flag applies) */
+  float I_pa[3][3];         /* parallel-axis part about the composite COM */
+  float I_inv[3][3];        /* (I_own + I_pa)^-1 */
+  int n_boxes;
+  orc_box boxes[ORC_MAX_BOXES];
+  float bound_radius;       /* sphere around base origin containing all boxes */
+
+  /* motors -- motors.py, quadx.py:93-128, fixedwing.py:147-168 */
+  int n_motors;
+  float motor_r[4][3];      /* link COM offsets (cf2x.urdf:42,54,66,78) */
+  float thrust_unit[4][3];
+  float thrust_coef[4], torque_coef[4], max_rpm[4], motor_tau[4], noise_ratio[4];
+
+  /* quadx only */
+  float motor_map[4][4];    /* quadx.py:130-137 */
+  float drag_const[3];      /* 0.5*1.225*Cd*A, boring_bodies.py:63 */
+  float drag_coef_pqr;      /* cf2x.yaml:11 */
+  orc_pid_gains pid[4];      /* 0 ang_vel 1 ang_pos 2 lin_vel 3 lin_pos */
+  orc_pid_gains zpid[2];     /* 0 z_vel 1 z_pos  (quadx.py:205: z_PIDs=[z_vel,z_pos]) */
+  float control_period;     /* 1/control_hz */
+
+  /* fixedwing only */
+  int n_surf;
+  orc_surface surf[ORC_MAX_SURF]; /* order: L-ail, R-ail, h-tail, v-tail, main (fixedwing.py:80-138) */
+  int assist_ids[6];
+  float assist_signs[6];
+
+  /* env (task) constants */
+  int task;
+  int flight_mode;
+  float start_pos[3], start_rpy[3], start_vel[3];
+  float dome;
+  int max_steps;
+  int env_step_ratio;
+  int settle_steps;          /* 10 Aviary steps, quadx_base_env.py:209 */
+  int sparse_reward;
+  int angle_repr;            /* 0 euler, 1 quaternion */
+  int num_targets;
+  float goal_reach_distance;
+  float min_height;
+  float throttle_remap;     /* 1 -> a[3]/2+0.5 (fixedwing_base_env.py:260) */
+  int collide_any;           /* fixedwing: any contact ; quadx: contact with plane (same thing here) */
+  float wp_dist_reward;     /* 0.1 quadx, 1.0 fixedwing */
+  float wp_yaw_penalty;     /* 0.01 quadx, 0 fixedwing */
+
+  /* noise */
+  int noise_mode;
+  uint64_t seed;
+} orc_params;
+
+typedef struct {
+  /* Bullet base state */
+  float p[3], q[4], v[3], w[3];
+  /* derived by update_state (quadx.py:512-535) */
+  float w_b[3], rpy[3], v_b[3];
+  float surf_v[ORC_MAX_SURF][3];
+  /* actuators */
+  float throttle[4];
+  float actuation[ORC_MAX_SURF];
+  float pwm[4];
+  float cmd[6];
+  float setpoint[6];
+  /* controllers */
+  float pid_I[4][3], pid_E[4][3];
+  float zpid_I[2], zpid_E[2];
+  int mode;
+  int physics_steps;
+  int contact_now;    /* len(getContactPoints())>0 after the last stepSimulation */
+  int contact_step;   /* contact_array after the last Aviary.step */
+  /* env */
+  int step_count, terminated, truncated;
+  int info_oob, info_collision, info_complete, num_targets_reached;
+  float reward;
+  float action[4];
+  float targets[ORC_MAX_TARGETS][3];
+  int n_targets_left;
+  float new_dist, old_dist;
+  /* observation as left by the last compute_state() (quadx_hover_env.py:85-115): the reference
+   * returns this cached vector, e.g. the target deltas still include a waypoint reached in the
+   * same step (quadx_waypoints_env.py:171-175 precedes :195-199) */
+  float obs[48];
+  /* rng */
+  uint32_t rng_ctr;
+  uint64_t lane_id;
+} orc_lane;
+
+/* ---------- parameter sets (numbers copied from the reference's YAML/URDF, cited in .c) ---------- */
+void orc_params_quadx(orc_params* P);
+void orc_params_fixedwing(orc_params* P);
+void orc_task_hover(orc_params* P);
+void orc_task_quadx_waypoints(orc_params* P);
+void orc_task_fixedwing_waypoints(orc_params* P);
+void orc_finalize(orc_params* P); /* recompute derived quantities after edits */
+
+/* ---------- components (golden-checked one by one) ---------- */
+void orc_pid_step(const float* kp, const float* ki, const float* kd, const float* lim,
+                  float period, int n, float* I, float* E, const float* state,
+                  const float* setpoint, float* out);
+void orc_quadx_mix(const orc_params* P, const float cmd[4], float pwm[4]);
+void orc_quadx_control(const orc_params* P, orc_lane* L);
+void orc_motors_update(const orc_params* P, float* throttle, const float* pwm, float xi,
+                       float thrust[4][3], float torque[4][3]);
+void orc_body_drag(const orc_params* P, const float v_b[3], float F[3]);
+void orc_surface_aero(const orc_surface* S, float alpha, float actuation, float out_ClCdCM[3]);
+void orc_surface_force(const orc_surface* S, const float v_local[3], float actuation,
+                       float F[3], float T[3]);
+void orc_quat_from_euler(const float rpy[3], float q[4]);
+void orc_euler_from_quat(const float q[4], float rpy[3]);
+void orc_matrix_from_quat(const float q[4], float R[3][3]);
+int orc_contact_plane(const orc_params* P, const float p[3], const float q[4]);
+int orc_box_box_overlap(const float ca[3], const float Ra[3][3], const float ha[3],
+                        const float cb[3], const float hb[3]);
+void orc_rigid_tick(const orc_params* P, float p[3], float q[4], float v[3], float w[3],
+                    const float F_b[3], const float tau_b[3]);
+
+/* ---------- RNG (same integer stream as the device) ---------- */
+void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
+void orc_normal8(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float z[8]);
+void orc_normal4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float z[4]);
+void orc_uniform4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, float u[4]);
+
+/* ---------- lane level ---------- */
+void orc_update_state(const orc_params* P, orc_lane* L);
+void orc_set_mode(const orc_params* P, orc_lane* L, int mode);
+/* Aviary.reset + drone.reset + update_state (aviary.py:218-312) */
+void orc_aviary_reset(const orc_params* P, orc_lane* L, uint64_t lane_id);
+/* one Aviary.step (aviary.py:480-531); xi: ticks_per_control normals (ORC_NOISE_INJECT) or NULL */
+void orc_aviary_step(const orc_params* P, orc_lane* L, const float* xi,
+                     uint32_t rng_call_base, uint32_t rng_stream);
+/* env.reset(): begin_reset + waypoint sampling + end_reset (quadx_base_env.py:149-212);
+ * xi_reset: settle_steps*ticks_per_control normals, u_targets: 3*num_targets uniforms (inject mode) */
+void orc_env_reset(const orc_params* P, orc_lane* L, uint64_t lane_id, const float* xi_reset,
+                   const float* u_targets);
+/* env.step(action) (quadx_base_env.py:269-301); xi: env_step_ratio*ticks_per_control normals */
+void orc_env_step(const orc_params* P, orc_lane* L, const float action[4], const float* xi);
+int orc_obs_dim(const orc_params* P);
+/* flattened obs: attitude (+ num_targets*3 zero-padded deltas for waypoint tasks) */
+void orc_env_obs(const orc_params* P, const orc_lane* L, float* obs);
+
+/* ---------- batch level (OpenMP over lanes) ---------- */
+/* autoreset: 0 none, 1 next-step (gymnasium default), 2 same-step */
+void orc_env_reset_batch(const orc_params* P, orc_lane* L, int n, uint64_t lane0,
+                         const uint8_t* mask, const float* xi_reset, const float* u_targets);
+void orc_env_step_batch(const orc_params* P, orc_lane* L, int n, const float* actions,
+                        const float* xi, const float* xi_reset, const float* u_targets,
+                        int autoreset, float* obs, float* reward, uint8_t* term, uint8_t* trunc,
+                        float* final_obs);
+int orc_sizeof_lane(void);
+int orc_sizeof_params(void);
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

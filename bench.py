@@ -92,9 +92,9 @@ def main():
     args = parse()
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from pyflyt_amd.dist import env_rank_world, weak_shard
+
+    rank, local_rank, world = env_rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -107,8 +107,9 @@ def main():
 
         dist.init_process_group("nccl", device_id=device)
 
-    n = args.batch
-    eng = make_engine(args.env, n, device, lane_offset=rank * n, noise=args.noise)
+    shard = weak_shard(args.batch, rank, world)  # per-GPU slice; no collective in the timed loop
+    n = shard.lanes
+    eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise)
     g = max(1, min(args.graph_steps, args.steps))
     ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(g)]
     for i, a in enumerate(ring):

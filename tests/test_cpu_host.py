@@ -1,0 +1,132 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, the parameter tables agree with the oracle's, the product refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+
+    g.build()
+    return True
+
+
+def test_library_exports_every_declared_symbol(built):
+    from pyflyt_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "pyflyt_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pf_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 14
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/pyflyt_amd.h but not exported"
+    assert set(_lib.EXPORTS) == declared
+    L = _lib.lib()  # also checks struct sizes and the ABI version
+    assert L.pf_abi_version() == 1
+
+
+def test_no_cpu_fallback(built):
+    import torch
+
+    from pyflyt_amd import PyFlytAmdError, build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(PyFlytAmdError):
+        BatchEngine(build_params("quadx", "hover"), 64)
+    # the C entry point itself refuses as well
+    from pyflyt_amd import _lib
+
+    ctx = C.c_void_p()
+    P = build_params("quadx", "hover")
+    rc = _lib.lib().pf_ctx_create(C.byref(P), 64, 0, 0, C.byref(ctx))
+    assert rc != 0 and b"no HIP device" in _lib.lib().pf_last_error(None)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "pyflyt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "uav_oracle.h" not in src, f
+
+
+def sym(a):
+    return np.array([[a[0], a[1], a[2]], [a[1], a[3], a[4]], [a[2], a[4], a[5]]])
+
+
+@pytest.mark.parametrize("vehicle,env", [("quadx", "hover"), ("quadx", "quadx_waypoints"), ("fixedwing", "fixedwing_waypoints")])
+def test_param_tables_agree_with_oracle(vehicle, env):
+    """Two independent transcriptions of the reference's YAML/URDF numbers (pyflyt_amd/params.py in
+    Python, oracle/uav_oracle.c in C) must agree; the C side is golden-checked against the reference."""
+    from oracle import oracle as O
+    from pyflyt_amd import build_params
+
+    task = "hover" if env == "hover" else "waypoints"
+    P = build_params(vehicle, task)
+    R = O.make_params(env)
+    f = np.float32
+    assert np.isclose(P.inv_mass, 1.0 / R.mass, rtol=1e-6)
+    np.testing.assert_allclose(list(P.com), list(R.com), rtol=1e-6, atol=1e-9)
+    I_ref = np.array([list(r) for r in R.I_own]) + np.array([list(r) for r in R.I_pa])
+    np.testing.assert_allclose(sym(P.I_own) + sym(P.I_pa), I_ref, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(sym(P.I_inv), np.array([list(r) for r in R.I_inv]), rtol=1e-5)
+    assert P.n_boxes == R.n_boxes and P.n_motors == R.n_motors and P.n_surf == R.n_surf
+    assert P.bound_radius >= f(R.bound_radius)
+    for i in range(P.n_motors):
+        np.testing.assert_allclose(P.motor_fmax[i], R.thrust_coef[i] * R.max_rpm[i] ** 2, rtol=1e-6)
+        np.testing.assert_allclose(P.motor_tmax[i], R.torque_coef[i] * R.max_rpm[i] ** 2, rtol=1e-6)
+        np.testing.assert_allclose(P.motor_dt_over_tau[i], R.world.dt / R.motor_tau[i], rtol=1e-6)
+        np.testing.assert_allclose(list(P.motor_r[i]), list(R.motor_r[i]), atol=1e-9)
+    if vehicle == "quadx":
+        np.testing.assert_allclose(list(P.drag_const), list(R.drag_const), rtol=1e-6)
+        for k in range(4):
+            for name in ("kp", "ki", "kd", "lim"):
+                np.testing.assert_allclose(list(getattr(P.pid[k], name)), list(getattr(R.pid[k], name)), rtol=1e-6)
+        for k in range(2):
+            np.testing.assert_allclose(P.zpid[k].kp[0], R.zpid[k].kp[0]); np.testing.assert_allclose(P.zpid[k].kd[0], R.zpid[k].kd[0])
+        np.testing.assert_allclose(np.array([list(r) for r in P.motor_map]), np.array([list(r) for r in R.motor_map]))
+    else:
+        for i in range(5):
+            S, T = P.surf[i], R.surf[i]
+            np.testing.assert_allclose(S.Cl_alpha_3D, T.Cl_alpha_3D, rtol=1e-6)
+            np.testing.assert_allclose(S.aero_tau_eta, T.aero_tau * T.eta, rtol=1e-6)
+            np.testing.assert_allclose(S.half_rho_area, T.half_rho * T.area, rtol=1e-6)
+            np.testing.assert_allclose(S.inv_pi_aspect, 1.0 / (np.pi * T.aspect), rtol=1e-6)
+            np.testing.assert_allclose([S.alpha_0_base, S.alpha_stall_P_base, S.alpha_stall_N_base],
+                                       [T.alpha_0_base, T.alpha_stall_P_base, T.alpha_stall_N_base], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(list(S.r), list(T.r), atol=1e-9)
+            np.testing.assert_allclose(list(S.torque), list(T.torque_unit), atol=1e-9)
+        assert list(P.assist_ids) == list(R.assist_ids)
+    assert P.max_steps == R.max_steps and P.env_step_ratio == R.env_step_ratio and P.settle_steps == R.settle_steps
+    assert np.isclose(P.dome, R.dome) and P.num_targets == R.num_targets
+    assert np.isclose(P.goal_reach_distance, R.goal_reach_distance) or task == "hover"
+
+
+def test_build_params_validation():
+    from pyflyt_amd import build_params
+
+    with pytest.raises(ValueError, match="agent_hz"):  # quadx_base_env.py:47-52
+        build_params("quadx", "hover", agent_hz=50)
+    with pytest.raises(ValueError, match="angle_representation"):
+        build_params("quadx", "hover", angle_representation="matrix")
+    with pytest.raises(ValueError):
+        build_params("rocket", "hover")
+    P = build_params("quadx", "hover", agent_hz=30, max_duration_seconds=5.0)
+    assert P.env_step_ratio == 4 and P.max_steps == 150
+
+
+def test_quadk_hot_path_selection(built):
+    """The specialised kernel is chosen exactly for the configurations it implements."""
+    src = open(os.path.join(ROOT, "pyflyt_amd", "csrc", "quadx_fast.hpp")).read()
+    assert "P.flight_mode != 0" in src and "PF_TASK_HOVER" in src

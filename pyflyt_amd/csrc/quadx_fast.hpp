@@ -205,7 +205,8 @@ struct FastNoise {
   PF_DEV float get(int flat) {
     if (mode == PF_NOISE_OFF) return 0.0f;
     if (mode == PF_NOISE_INJECT) return xi[(size_t)flat * n + lane];
-    if ((flat & 7) == 0) z = normal8(philox4x32(k0, k1, c0, c1, (uint32_t)(flat >> 3), stream));
+    if ((flat & 7) == 0 && !(flat == 0 && stream == 0u))  // (stream 0, call 0) is pre-generated by the kernel prologue
+      z = normal8(philox4x32(k0, k1, c0, c1, (uint32_t)(flat >> 3), stream));
     return 4.0f + pick8(z, (uint32_t)flat & 7u);
   }
   PF_DEV f4 uniforms(int call, uint32_t strm) const { return uniform4(philox4x32(k0, k1, c0, c1, (uint32_t)call, strm)); }
@@ -235,9 +236,16 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
   float new_dist, old_dist;
   int step_count, flags, n_left;
   uint32_t rng_ctr;
+  f8 z_pre;
   {
+    // the int group is requested first: loads complete in order, so the step's Philox call (which
+    // needs only the event counter) runs while the rest of the state is still in flight
+    float4 gi = Sin[6 * N + li];
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li],
-           g5 = Sin[5 * N + li], gi = Sin[6 * N + li];
+           g5 = Sin[5 * N + li];
+    rng_ctr = (uint32_t)__float_as_int(gi.z);
+    if (K.noise_mode == PF_NOISE_PHILOX && op == 0)
+      z_pre = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
     V.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
     V.q = quat{g1.x, g1.y, g1.z, g1.w};
     V.v = v3{g2.x, g2.y, g2.z};
@@ -288,6 +296,14 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       for (int c = 0; c < 3; ++c) tgt[k][c] = tgt[k + 1][c];
     n_left -= 1;
   };
+  // One wave per workgroup: LDS operations of a wave execute in issue order, so the row writes only
+  // have to be retired (lgkmcnt) and not reordered by the compiler before the tile is read back --
+  // no s_barrier and, unlike __syncthreads(), no wait on outstanding global stores.
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt/expcnt untouched
+    __builtin_amdgcn_wave_barrier();
+  };
   // Settle-phase motor noise, generated cooperatively: the few lanes of a wave that reset in this
   // call need settle_ticks normals each (3 Philox calls per lane); instead of every resetting lane
   // walking through its calls serially while the other lanes idle, the (lane, call) pairs are dealt
@@ -303,7 +319,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       spos[__popcll(m & ((1ull << tid) - 1ull))] = tid;
       sctr[tid] = rng_ctr;
     }
-    __syncthreads();
+    lds_sync();
     const int ncall = (settle_ticks + 7) >> 3;
     for (int base = 0; base < r * ncall; base += 64) {
       const int j = base + tid;
@@ -315,7 +331,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
         for (int e = 0; e < 8; ++e) sxi[src * kSettleMax + call * 8 + e] = z.v[e];
       }
     }
-    __syncthreads();
+    lds_sync();
   };
   // begin_reset (+ waypoint sampling + set_mode(0)): quadx_base_env.py:149-206
   auto begin_reset = [&]() {
@@ -368,8 +384,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       // torque exactly, so the 20 settle ticks are a vertical (z, vz, throttle) recurrence.
       float thr = 0.f, vz = 0.f, z = V.p.z;
       const int nt2 = K.settle_steps * K.tpc;
-      for (int t = 0; t < nt2; ++t) {
-        const float xi = coop ? 4.0f + sxi[tid * kSettleMax + t] : nz.get(t);
+      auto settle_tick = [&](float xi) {
         float s = fmaf(xi, K.m_noise, 1.0f);
         thr = fmaf(K.m_a, 0.05f - thr, thr) * s;
         float kk = thr * __builtin_fabsf(thr);
@@ -377,7 +392,16 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
         float az = fmaf(K.inv_mass, Fz, K.gravity_z);
         vz = med3(fmaf(az, K.dt, vz), -K.vmax, K.vmax);
         z = fmaf(K.dt, vz, z);
+      };
+      int t = 0;
+      if (coop) {  // four draws per LDS read (ds_read_b128), four ticks per trip
+        const float4* x4 = reinterpret_cast<const float4*>(sxi + tid * kSettleMax);
+        for (; t + 4 <= nt2; t += 4) {
+          const float4 x = x4[t >> 2];
+          settle_tick(4.0f + x.x); settle_tick(4.0f + x.y); settle_tick(4.0f + x.z); settle_tick(4.0f + x.w);
+        }
       }
+      for (; t < nt2; ++t) settle_tick(coop ? 4.0f + sxi[tid * kSettleMax + t] : nz.get(t));
       V.p.z = z; V.v.z = vz;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { V.thr[k] = thr; V.pwm[k] = 0.05f; }
@@ -473,7 +497,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
     }
   };
   auto flush_tile = [&](float* out, bool all_rows) {
-    __syncthreads();
+    lds_sync();
     if (all_rows) {
       const int rows = min(LPW, n - wave_base);
       const int total = rows * D;
@@ -481,14 +505,22 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       const int n4 = total >> 2;
       const float4* t4 = reinterpret_cast<const float4*>(tile);
       float4* g4 = reinterpret_cast<float4*>(g);
-      for (int i = tid; i < n4; i += 64) g4[i] = t4[i];
-      for (int i = (n4 << 2) + tid; i < total; i += 64) g[i] = tile[i];
+      // streamed out: the observation is consumed by the policy, not by the next env step, so it
+      // should not displace the persistent state from L2
+      for (int i = tid; i < n4; i += 64) {
+        float4 t = t4[i];
+        __builtin_nontemporal_store(t.x, &g[4 * i + 0]);
+        __builtin_nontemporal_store(t.y, &g[4 * i + 1]);
+        __builtin_nontemporal_store(t.z, &g[4 * i + 2]);
+        __builtin_nontemporal_store(t.w, &g[4 * i + 3]);
+      }
+      for (int i = (n4 << 2) + tid; i < total; i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
     } else if (active) {
       float* g = out + (size_t)lane * D;
       const float* row = tile + tid * D;
       for (int k = 0; k < D; ++k) g[k] = row[k];
     }
-    __syncthreads();
+    lds_sync();
   };
 
   prepare_settle_noise(active && do_reset);
@@ -502,6 +534,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       reward = -0.1f;
       remaining = (term || trunc) ? 0 : K.env_step_ratio;
       nz.begin(rng_ctr, 0u, B.xi);
+      nz.z = z_pre;  // call 0 of this event, generated during the state load
     }
   }
   const bool wave_all = __all(active || !(tid < LPW && lane < n)) && ((wave_base * D) % 4 == 0);
@@ -542,8 +575,10 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
     wp_distance();
     rng_ctr += 1;
   }
+  // observation tile first, persistent state after it: nothing waits on the state stores
+  if (active) write_obs_row();
+  flush_tile(B.obs, wave_all);
   if (active) {
-    write_obs_row();
     if (pop_pending) { pop_target(); pop_pending = false; }
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
             (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
@@ -565,7 +600,6 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       B.truncated[li] = out_trunc ? 1 : 0;
     }
   }
-  flush_tile(B.obs, wave_all);
 }
 
 }  // namespace pf

@@ -452,13 +452,11 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
-  const int lpw = ctx->lpw;
-  const int grid = (ctx->n + lpw - 1) / lpw;
-#define PF_FAST(L, W) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, L, W>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
-  const int wps = ctx->wps;
-  (void)wps;
-  if (lpw == 64) PF_FAST(64, 2);
-  else PF_FAST(32, 2);
+  const int grid = (ctx->n + 63) / 64;
+#define PF_FAST(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
+  if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
+  else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
+  else PF_FAST(PF_NOISE_OFF);
 #undef PF_FAST
 }
 template <class VEH, int TASK>

@@ -11,10 +11,13 @@
 //   * the reset's 10 settle Aviary steps collapse to a 20-tick vertical recurrence when the spawn
 //     pose is level and at rest (always true for the Hover/Waypoints envs), so lanes that
 //     auto-reset cost ~1/4 of an env step instead of 3x one;
-//   * LPW (lanes per wave): for batches smaller than the machine (65 536 drones = one wave per
-//     SIMD on 256 CUs x 4 SIMDs) waves are launched under-filled (16 or 32 live lanes) so that
-//     every SIMD holds several waves and their dependent-instruction latencies overlap.
+//   * flat control flow (one predicate per Aviary step) so the register allocator emits no PHI
+//     copies; obs tile flushed before the state stores with an LDS-only sync; non-temporal obs
+//     stores; the step's Philox call issued while the state loads are in flight.
+//   (Tried and rejected, profiles/README.md: under-filled 16/32-lane waves, 128-VGPR variants.)
 #pragma once
+#include <cstdlib>
+
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
 
@@ -60,6 +63,8 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   if (!(P.motor_tmax[0] == P.motor_tmax[1] && P.motor_tmax[2] == P.motor_tmax[3] && P.motor_tmax[0] == -P.motor_tmax[2] &&
         P.motor_tmax[0] <= 0.f)) return false;
   if (P.n_boxes != 1 || P.num_targets > 4) return false;
+  if (P.ticks_per_control != 2 || P.env_step_ratio > 4 || P.env_step_ratio < 1) return false;
+  if ((P.settle_steps * 2) % 4 != 0 || P.settle_steps * 2 > 24) return false;
   K.dt = P.dt; K.half_dt = 0.5f * P.dt; K.gravity_z = P.gravity_z; K.vmax = P.max_coord_vel; K.inv_mass = P.inv_mass;
   K.I[0] = P.I_own[0]; K.I[1] = P.I_own[3]; K.I[2] = P.I_own[5];
   K.iI[0] = P.I_inv[0]; K.iI[1] = P.I_inv[3]; K.iI[2] = P.I_inv[5];
@@ -87,7 +92,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.fast_settle = (P.start_quat[0] == 0.f && P.start_quat[1] == 0.f && P.start_vel[0] == 0.f && P.start_vel[1] == 0.f &&
                    P.start_vel[2] == 0.f && P.start_pos[2] - 2.0f * fall - 0.05f > P.bound_radius && P.gravity_z < 0.f)
                       ? 1 : 0;
-  return true;
+  return K.fast_settle != 0;  // the hot kernel only implements the level-spawn settle recurrence
 }
 
 // Full 15-axis box test against the ground box, kept out of line: it runs only for waves that have
@@ -193,39 +198,28 @@ struct QuadHot {
   }
 };
 
-// Philox-backed per-lane normal source with an 8-deep cache (one Philox call per 8 ticks: a
-// Hover step's 6 ticks or a Waypoints step's 8 ticks need exactly one call).
-struct FastNoise {
-  int mode;
-  const float* xi;
-  size_t n, lane;
-  uint32_t k0, k1, c0, c1, stream;
-  f8 z;
-  PF_DEV void begin(uint32_t ctr, uint32_t strm, const float* inj) { c1 = ctr; stream = strm; xi = inj; }
-  PF_DEV float get(int flat) {
-    if (mode == PF_NOISE_OFF) return 0.0f;
-    if (mode == PF_NOISE_INJECT) return xi[(size_t)flat * n + lane];
-    if ((flat & 7) == 0 && !(flat == 0 && stream == 0u))  // (stream 0, call 0) is pre-generated by the kernel prologue
-      z = normal8(philox4x32(k0, k1, c0, c1, (uint32_t)(flat >> 3), stream));
-    return 4.0f + pick8(z, (uint32_t)flat & 7u);
-  }
-  PF_DEV f4 uniforms(int call, uint32_t strm) const { return uniform4(philox4x32(k0, k1, c0, c1, (uint32_t)call, strm)); }
-};
-
-template <int TASK, int LPW, int WPS>
-__global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
-                                                               const int n, const uint64_t lane0, const int op,
-                                                               const uint8_t* __restrict__ mask) {
+// ------------------------------------------------------------------------------------------
+// The kernel. Control flow is deliberately flat -- a prologue, one uniform-trip-count loop over the
+// env step's Aviary steps with a single per-lane predicate, an epilogue -- because every extra
+// divergent region costs the register allocator a round of PHI copies per iteration (the first,
+// state-machine shaped version spent ~300 of its ~1 150 instructions per Aviary step on v_mov).
+// Specialised at compile time on the task and the noise source; requires (checked by
+// quadk_from_params) ticks_per_control == 2, env_step_ratio <= 4, a level spawn at rest and
+// settle_ticks a multiple of 4 and <= 24.
+template <int TASK, int NOISE>
+__global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
+                                                             const int n, const uint64_t lane0, const int op,
+                                                             const uint8_t* __restrict__ mask) {
   constexpr int kMaxD = 13 + 4 + 4 + 12;
   constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
-  __shared__ float tile[LPW * kMaxD];
+  __shared__ float tile[64 * kMaxD];
   __shared__ float sxi[64 * kSettleMax];
   __shared__ int spos[64];
   __shared__ uint32_t sctr[64];
   const int tid = threadIdx.x;
-  const int wave_base = blockIdx.x * LPW;
+  const int wave_base = blockIdx.x * 64;
   const int lane = wave_base + tid;
-  const bool valid = (tid < LPW) && (lane < n);
+  const bool valid = lane < n;
   const size_t li = valid ? (size_t)lane : (size_t)(n - 1);
   const size_t N = (size_t)n;
   const float4* Sin = reinterpret_cast<const float4*>(B.state);
@@ -236,7 +230,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
   float new_dist, old_dist;
   int step_count, flags, n_left;
   uint32_t rng_ctr;
-  f8 z_pre;
+  f8 zn;  // this step's motor-noise normals (Philox call 0 of the event)
   {
     // the int group is requested first: loads complete in order, so the step's Philox call (which
     // needs only the event counter) runs while the rest of the state is still in flight
@@ -244,8 +238,9 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li],
            g5 = Sin[5 * N + li];
     rng_ctr = (uint32_t)__float_as_int(gi.z);
-    if (K.noise_mode == PF_NOISE_PHILOX && op == 0)
-      z_pre = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
+    if (NOISE == PF_NOISE_PHILOX) {
+      if (op == 0) zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
+    }
     V.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
     V.q = quat{g1.x, g1.y, g1.z, g1.w};
     V.v = v3{g2.x, g2.y, g2.z};
@@ -253,7 +248,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
     V.thr[0] = g3.z; V.thr[1] = g3.w; V.thr[2] = g4.x; V.thr[3] = g4.y;
     V.I[0] = g4.z; V.I[1] = g4.w; V.I[2] = g5.x;
     V.E[0] = g5.y; V.E[1] = g5.z; V.E[2] = g5.w;
-    step_count = __float_as_int(gi.x); flags = __float_as_int(gi.y); rng_ctr = (uint32_t)__float_as_int(gi.z);
+    step_count = __float_as_int(gi.x); flags = __float_as_int(gi.y);
     n_left = __float_as_int(gi.w);
     if (TASK == PF_TASK_WAYPOINTS) {
       float4 a = Sin[12 * N + li], b = Sin[13 * N + li], c = Sin[14 * N + li];
@@ -268,10 +263,6 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
   V.derive();
   bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
 
-  FastNoise nz;
-  nz.mode = K.noise_mode; nz.n = N; nz.lane = li; nz.k0 = K.seed_lo; nz.k1 = K.seed_hi; nz.c0 = (uint32_t)(lane0 + li);
-  nz.xi = nullptr; nz.c1 = 0; nz.stream = 0;
-
   bool active, do_reset;
   if (op == 1) {
     do_reset = (mask == nullptr) || (mask[li] != 0);
@@ -281,13 +272,14 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
     active = true;
   }
   active = active && valid;
+  do_reset = do_reset && active;
 
-  float sp0 = 0.f, sp1 = 0.f, sp2 = 0.f, sp3 = 0.f;
   float act0 = 0.f, act1 = 0.f, act2 = 0.f, act3 = 0.f;
   float reward = 0.0f;
-  bool settling = false, pop_pending = false;
-  int remaining = 0, done_its = 0;
+  bool pop_pending = false;
+  bool was_reset = false;
   const int D = (K.angle_repr ? 13 : 12) + 8 + (TASK == PF_TASK_WAYPOINTS ? 3 * K.num_targets : 0);
+  const int settle_ticks = K.settle_steps * 2;
 
   auto pop_target = [&]() {
 #pragma unroll
@@ -308,10 +300,8 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
   // call need settle_ticks normals each (3 Philox calls per lane); instead of every resetting lane
   // walking through its calls serially while the other lanes idle, the (lane, call) pairs are dealt
   // out over all 64 lanes, evaluated in one pass and handed back through LDS. Wave-uniform call.
-  const int settle_ticks = K.settle_steps * K.tpc;
-  const bool coop = K.fast_settle && K.noise_mode == PF_NOISE_PHILOX && settle_ticks <= kSettleMax;
   auto prepare_settle_noise = [&](bool reset_now) {
-    if (!coop) return;
+    if (NOISE != PF_NOISE_PHILOX) return;
     const unsigned long long m = __ballot(reset_now);
     if (m == 0ull) return;
     const int r = __popcll(m);
@@ -328,32 +318,56 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
         const int src = spos[which];
         f8 z = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, 1u));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sxi[src * kSettleMax + call * 8 + e] = z.v[e];
+        for (int e = 0; e < 8; ++e) sxi[src * kSettleMax + call * 8 + e] = 4.0f + z.v[e];
       }
     }
     lds_sync();
   };
-  // begin_reset (+ waypoint sampling + set_mode(0)): quadx_base_env.py:149-206
-  auto begin_reset = [&]() {
-    V.p = v3{K.start_pos[0], K.start_pos[1], K.start_pos[2]};
+  // env.reset() for this lane: begin_reset + waypoint sampling + set_mode(0) + the settle phase
+  // (quadx_base_env.py:149-212). Level spawn at rest under the mode-0 default setpoint
+  // (quadx.py:276-278): rate error 0 -> cmd 0 -> pwm 0.05 on all four motors (quadx.py:488 branch
+  // skipped, :493 clip); equal thrusts cancel every torque exactly, so the settle ticks are a
+  // vertical (z, vz, throttle) recurrence.
+  auto reset_lane = [&]() {
+    float thr = 0.f, vz = 0.f, z = K.start_pos[2];
+    auto settle_tick = [&](float xi) {
+      float s = fmaf(xi, K.m_noise, 1.0f);
+      thr = fmaf(K.m_a, 0.05f - thr, thr) * s;
+      float kk = thr * __builtin_fabsf(thr);
+      float Fz = fmaf(-K.drag[2], vz * __builtin_fabsf(vz), 4.0f * (K.fmax * kk));
+      float az = fmaf(K.inv_mass, Fz, K.gravity_z);
+      vz = med3(fmaf(az, K.dt, vz), -K.vmax, K.vmax);
+      z = fmaf(K.dt, vz, z);
+    };
+    for (int t = 0; t < settle_ticks; t += 4) {  // four draws per read, four ticks per trip
+      float4 x;
+      if (NOISE == PF_NOISE_PHILOX) x = reinterpret_cast<const float4*>(sxi + tid * kSettleMax)[t >> 2];
+      else if (NOISE == PF_NOISE_INJECT) x = float4{B.xi_reset[(size_t)(t + 0) * N + li], B.xi_reset[(size_t)(t + 1) * N + li],
+                                                    B.xi_reset[(size_t)(t + 2) * N + li], B.xi_reset[(size_t)(t + 3) * N + li]};
+      else x = float4{0.f, 0.f, 0.f, 0.f};
+      settle_tick(x.x); settle_tick(x.y); settle_tick(x.z); settle_tick(x.w);
+    }
+    V.p = v3{K.start_pos[0], K.start_pos[1], z};
     V.q = quat{K.start_quat[0], K.start_quat[1], K.start_quat[2], K.start_quat[3]};
-    V.v = v3{0.f, 0.f, 0.f}; V.w = v3{0.f, 0.f, 0.f};
+    V.v = v3{0.f, 0.f, vz}; V.w = v3{0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { V.thr[k] = 0.f; V.pwm[k] = 0.f; }
+    for (int k = 0; k < 4; ++k) { V.thr[k] = thr; V.pwm[k] = 0.05f; }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { V.I[k] = 0.f; V.E[k] = 0.f; }
     V.contact_now = false; V.contact_step = false;
     V.derive();
     step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
     act0 = act1 = act2 = act3 = 0.f;
-    nz.begin(rng_ctr, 1u, B.xi_reset);
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = K.num_targets;
       n_left = nt;
-      new_dist = INFINITY; old_dist = INFINITY;
       f4 u0, u1, u2;
-      const bool inj = (K.noise_mode == PF_NOISE_INJECT) && (B.u_targets != nullptr);
-      if (!inj) { u0 = nz.uniforms(0, 2u); u1 = nz.uniforms(1, 2u); u2 = nz.uniforms(2, 2u); }
+      const bool inj = (NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr);
+      if (!inj) {
+        u0 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 2u));
+        u1 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 1u, 2u));
+        u2 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 2u, 2u));
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < nt) {
@@ -375,80 +389,13 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
           tgt[i][0] = dist * sph * ct; tgt[i][1] = dist * sph * st; tgt[i][2] = zz > K.min_height ? zz : K.min_height;
         }
       }
+      // end_reset's compute_state: distance to the first target (old distance = inf)
+      float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
+      old_dist = INFINITY;
+      new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
     }
-    sp0 = 0.f; sp1 = 0.f; sp2 = 0.f; sp3 = -1.0f;  // quadx.py:276-278
-    settling = true; remaining = K.settle_steps; done_its = 0;
-    if (K.fast_settle) {
-      // Level spawn at rest under the mode-0 default setpoint: rate error 0 -> cmd 0 -> pwm 0.05 on
-      // all four motors (quadx.py:488 branch skipped, :493 clip); equal thrusts cancel every
-      // torque exactly, so the 20 settle ticks are a vertical (z, vz, throttle) recurrence.
-      float thr = 0.f, vz = 0.f, z = V.p.z;
-      const int nt2 = K.settle_steps * K.tpc;
-      auto settle_tick = [&](float xi) {
-        float s = fmaf(xi, K.m_noise, 1.0f);
-        thr = fmaf(K.m_a, 0.05f - thr, thr) * s;
-        float kk = thr * __builtin_fabsf(thr);
-        float Fz = fmaf(-K.drag[2], vz * __builtin_fabsf(vz), 4.0f * (K.fmax * kk));
-        float az = fmaf(K.inv_mass, Fz, K.gravity_z);
-        vz = med3(fmaf(az, K.dt, vz), -K.vmax, K.vmax);
-        z = fmaf(K.dt, vz, z);
-      };
-      int t = 0;
-      if (coop) {  // four draws per LDS read (ds_read_b128), four ticks per trip
-        const float4* x4 = reinterpret_cast<const float4*>(sxi + tid * kSettleMax);
-        for (; t + 4 <= nt2; t += 4) {
-          const float4 x = x4[t >> 2];
-          settle_tick(4.0f + x.x); settle_tick(4.0f + x.y); settle_tick(4.0f + x.z); settle_tick(4.0f + x.w);
-        }
-      }
-      for (; t < nt2; ++t) settle_tick(coop ? 4.0f + sxi[tid * kSettleMax + t] : nz.get(t));
-      V.p.z = z; V.v.z = vz;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { V.thr[k] = thr; V.pwm[k] = 0.05f; }
-      V.derive();
-      remaining = 0; done_its = K.settle_steps;
-    }
-  };
-  auto wp_distance = [&]() {  // waypoint_handler.py:135-142; ||R^T d|| = ||d||
-    if (TASK != PF_TASK_WAYPOINTS) return;
-    if (pop_pending) { pop_target(); pop_pending = false; }
-    float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
-    old_dist = new_dist;
-    new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-  };
-  auto term_trunc_reward = [&]() {
-    if (step_count > K.max_steps) trunc = true;
-    if (V.contact_step) { reward = -100.0f; flags |= PF_F_INFO_COLLISION; term = true; }
-    if (dot(V.p, V.p) > K.dome2) { reward = -100.0f; flags |= PF_F_INFO_OOB; term = true; }
-    if (TASK == PF_TASK_HOVER) {
-      if (!K.task_sparse) {  // quadx_hover_env.py:120-138
-        float dz = V.p.z - 1.0f;
-        float lin = fsqrt(fmaf(V.p.x, V.p.x, fmaf(V.p.y, V.p.y, dz * dz)));
-        // roll, pitch of getEulerFromQuaternion (gimbal branch: roll = 0, |pitch| = pi/2)
-        quat q = V.q;
-        float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
-        float sarg = -2.0f * (q.x * q.z - q.w * q.y) * frcp(sqx + sqy + sqz + squ);
-        bool gim = __builtin_fabsf(sarg) >= 0.99999f;
-        float roll = gim ? 0.0f : fast_atan2(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
-        float pitch = gim ? __builtin_copysignf(0.5f * kPi, sarg) : fast_asin(sarg);
-        float ang = fsqrt(fmaf(roll, roll, pitch * pitch));
-        reward -= 0.01f * (V.wb.z * V.wb.z);
-        reward -= lin + ang;
-        reward += 1.0f;
-      }
-    } else {
-      if (!K.task_sparse) {  // quadx_waypoints_env.py:183-192
-        float progress = (isinf(old_dist + new_dist)) ? 0.0f : old_dist - new_dist;
-        reward += __builtin_fmaxf(3.0f * progress, 0.0f);
-        reward += K.wp_dist_reward * frcp(new_dist);
-        reward -= K.wp_yaw_penalty * (V.wb.z * V.wb.z);
-      }
-      if (new_dist < K.goal_reach) {
-        reward = 100.0f;
-        pop_pending = true;
-        if (n_left - 1 == 0) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
-      }
-    }
+    rng_ctr += 1;
+    was_reset = true;
   };
   // observation row (Appendix A of SURVEY.md) -> LDS tile. The attitude quaternion is
   // getQuaternionFromEuler(getEulerFromQuaternion(q)) (quadx_base_env.py:243), computed without trig.
@@ -496,15 +443,15 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       }
     }
   };
-  auto flush_tile = [&](float* out, bool all_rows) {
+  const bool wave_all = __all(active || !valid);
+  auto flush_tile = [&](float* out) {
     lds_sync();
-    if (all_rows) {
-      const int rows = min(LPW, n - wave_base);
+    if (wave_all) {
+      const int rows = min(64, n - wave_base);
       const int total = rows * D;
       float* g = out + (size_t)wave_base * D;
       const int n4 = total >> 2;
       const float4* t4 = reinterpret_cast<const float4*>(tile);
-      float4* g4 = reinterpret_cast<float4*>(g);
       // streamed out: the observation is consumed by the policy, not by the next env step, so it
       // should not displace the persistent state from L2
       for (int i = tid; i < n4; i += 64) {
@@ -515,7 +462,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
         __builtin_nontemporal_store(t.w, &g[4 * i + 3]);
       }
       for (int i = (n4 << 2) + tid; i < total; i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
-    } else if (active) {
+    } else if (active) {  // partial (masked reset): this lane writes its own row
       float* g = out + (size_t)lane * D;
       const float* row = tile + tid * D;
       for (int k = 0; k < D; ++k) g[k] = row[k];
@@ -523,61 +470,95 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
     lds_sync();
   };
 
-  prepare_settle_noise(active && do_reset);
-  if (active) {
-    if (do_reset) {
-      begin_reset();
-    } else {
-      const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
-      act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
-      sp0 = a.x; sp1 = a.y; sp2 = a.z; sp3 = a.w;
-      reward = -0.1f;
-      remaining = (term || trunc) ? 0 : K.env_step_ratio;
-      nz.begin(rng_ctr, 0u, B.xi);
-      nz.z = z_pre;  // call 0 of this event, generated during the state load
-    }
+  // ---------------------------------------------------------------- reset (NEXT_STEP / explicit)
+  prepare_settle_noise(do_reset);
+  if (do_reset) reset_lane();
+
+  // ---------------------------------------------------------------- the env step
+  const bool stepping = active && !was_reset && op == 0;
+  float sp0 = 0.f, sp1 = 0.f, sp2 = 0.f, sp3 = 0.f;
+  if (stepping) {
+    const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+    act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
+    sp0 = a.x; sp1 = a.y; sp2 = a.z; sp3 = a.w;
+    reward = -0.1f;
   }
-  const bool wave_all = __all(active || !(tid < LPW && lane < n)) && ((wave_base * D) % 4 == 0);
-  float out_reward = 0.0f;
-  bool out_term = false, out_trunc = false;
-  for (int phase = 0; phase < 2; ++phase) {
-    while (__any(remaining > 0)) {
-      if (remaining > 0) {
-        V.contact_step = false;
-        V.control(K, sp0, sp1, sp2, sp3);
-        for (int t = 0; t < K.tpc; ++t) V.tick(K, nz.get(done_its * K.tpc + t), Pfull);
-        remaining -= 1;
-        done_its += 1;
-        if (!settling) {
-          wp_distance();
-          term_trunc_reward();
-          if (term || trunc) remaining = 0;
+  bool go = stepping && !(term || trunc);  // quadx_base_env.py:289-290
+  for (int s = 0; s < K.env_step_ratio; ++s) {
+    if (!__any(go)) break;
+    if (go) {
+      float xi0, xi1;
+      if (NOISE == PF_NOISE_PHILOX) { xi0 = 4.0f + pick8(zn, (uint32_t)(2 * s)); xi1 = 4.0f + pick8(zn, (uint32_t)(2 * s + 1)); }
+      else if (NOISE == PF_NOISE_INJECT) { xi0 = B.xi[(size_t)(2 * s) * N + li]; xi1 = B.xi[(size_t)(2 * s + 1) * N + li]; }
+      else { xi0 = 0.f; xi1 = 0.f; }
+      // one Aviary.step (aviary.py:480-531): control on the first tick, pwm held on the second
+      V.contact_step = false;
+      V.control(K, sp0, sp1, sp2, sp3);
+      V.tick(K, xi0, Pfull);
+      V.tick(K, xi1, Pfull);
+      // compute_state side effects + compute_term_trunc_reward
+      if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:135-142; ||R^T d|| = ||d||
+        if (pop_pending) { pop_target(); pop_pending = false; }
+        float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
+        old_dist = new_dist;
+        new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+      }
+      if (step_count > K.max_steps) trunc = true;                                          // quadx_base_env.py:254
+      if (V.contact_step) { reward = -100.0f; flags |= PF_F_INFO_COLLISION; term = true; } // :258-261
+      if (dot(V.p, V.p) > K.dome2) { reward = -100.0f; flags |= PF_F_INFO_OOB; term = true; } // :264-267
+      if (TASK == PF_TASK_HOVER) {
+        if (!K.task_sparse) {  // quadx_hover_env.py:120-138
+          float dz = V.p.z - 1.0f;
+          float lin = fsqrt(fmaf(V.p.x, V.p.x, fmaf(V.p.y, V.p.y, dz * dz)));
+          // roll, pitch of getEulerFromQuaternion (gimbal branch: roll = 0, |pitch| = pi/2)
+          quat q = V.q;
+          float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+          float sarg = -2.0f * (q.x * q.z - q.w * q.y) * frcp(sqx + sqy + sqz + squ);
+          bool gim = __builtin_fabsf(sarg) >= 0.99999f;
+          float roll = gim ? 0.0f : fast_atan2(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+          float pitch = gim ? __builtin_copysignf(0.5f * kPi, sarg) : fast_asin(sarg);
+          float ang = fsqrt(fmaf(roll, roll, pitch * pitch));
+          reward -= 0.01f * (V.wb.z * V.wb.z);
+          reward -= lin + ang;
+          reward += 1.0f;
+        }
+      } else {
+        if (!K.task_sparse) {  // quadx_waypoints_env.py:183-192
+          float progress = (isinf(old_dist + new_dist)) ? 0.0f : old_dist - new_dist;
+          reward += __builtin_fmaxf(3.0f * progress, 0.0f);
+          reward += K.wp_dist_reward * frcp(new_dist);
+          reward -= K.wp_yaw_penalty * (V.wb.z * V.wb.z);
+        }
+        if (new_dist < K.goal_reach) {  // :195-204; the observation of this step still shows the target
+          reward = 100.0f;
+          pop_pending = true;
+          if (n_left - 1 == 0) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
         }
       }
+      go = !(term || trunc);
     }
-    if (phase == 1) break;
-    const bool stepped = active && !settling && op == 0;
-    if (stepped) {
-      step_count += 1;
-      rng_ctr += 1;
-      out_reward = reward; out_term = term; out_trunc = trunc;
-    }
-    const bool same = stepped && K.autoreset == PF_AUTORESET_SAME_STEP && (term || trunc);
-    if (!__any(same)) break;
-    if (B.final_obs != nullptr) {
-      if (active) write_obs_row();
-      flush_tile(B.final_obs, wave_all);
-    }
-    prepare_settle_noise(same);
-    if (same) begin_reset();
   }
-  if (active && settling) {
-    wp_distance();
-    rng_ctr += 1;
+  const float out_reward = stepping ? reward : 0.0f;
+  const bool out_term = stepping && term, out_trunc = stepping && trunc;
+  if (stepping) { step_count += 1; rng_ctr += 1; }  // quadx_base_env.py:299
+
+  // ---------------------------------------------------------------- SAME_STEP auto-reset
+  if (K.autoreset == PF_AUTORESET_SAME_STEP) {
+    const bool same = stepping && (term || trunc);
+    if (__any(same)) {
+      if (B.final_obs != nullptr) {  // terminal observation, before the state is re-initialised
+        if (active) write_obs_row();
+        flush_tile(B.final_obs);
+      }
+      prepare_settle_noise(same);
+      if (same) reset_lane();
+    }
   }
+
+  // ---------------------------------------------------------------- outputs
   // observation tile first, persistent state after it: nothing waits on the state stores
   if (active) write_obs_row();
-  flush_tile(B.obs, wave_all);
+  flush_tile(B.obs);
   if (active) {
     if (pop_pending) { pop_target(); pop_pending = false; }
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
@@ -594,7 +575,7 @@ __global__ void __launch_bounds__(64, WPS) quadx_m0_env_kernel(const QuadK K, co
       Sout[13 * N + li] = float4{tgt[1][1], tgt[1][2], tgt[2][0], tgt[2][1]};
       Sout[14 * N + li] = float4{tgt[2][2], tgt[3][0], tgt[3][1], tgt[3][2]};
     }
-    if (op == 0) {
+    if (op == 0) {  // a NEXT_STEP reset call reports (r=0, not done), gymnasium's convention
       B.reward[li] = out_reward;
       B.terminated[li] = out_term ? 1 : 0;
       B.truncated[li] = out_trunc ? 1 : 0;

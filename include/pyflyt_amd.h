@@ -36,7 +36,7 @@ extern "C" {
 
 enum pf_status { PF_OK = 0, PF_ERR_ARG = -1, PF_ERR_UNSUPPORTED = -2, PF_ERR_NO_DEVICE = -3 };
 enum pf_vehicle { PF_QUADX = 0, PF_FIXEDWING = 1 };
-enum pf_task { PF_TASK_NONE = 0, PF_TASK_HOVER = 1, PF_TASK_WAYPOINTS = 2 };
+enum pf_task { PF_TASK_NONE = 0, PF_TASK_HOVER = 1, PF_TASK_WAYPOINTS = 2, PF_TASK_MA_HOVER = 3 };
 enum pf_noise { PF_NOISE_OFF = 0, PF_NOISE_INJECT = 1, PF_NOISE_PHILOX = 2 };
 enum pf_autoreset { PF_AUTORESET_OFF = 0, PF_AUTORESET_NEXT_STEP = 1, PF_AUTORESET_SAME_STEP = 2 };
 

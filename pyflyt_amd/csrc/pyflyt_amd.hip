@@ -26,20 +26,20 @@ constexpr int kMaxObs = 36;  // 13 + 4 + 6 + 3*4 = 35
 
 enum { OP_STEP = 0, OP_RESET = 1 };
 
-// ------------------------------------------------------------------ waypoint task state
-template <int TASK>
-struct Targets {
+// ------------------------------------------------------------------ per-task side block
+// 12 floats per lane in state groups G_TGT..G_TGT+2:
+//   waypoint tasks : the 4 x 3 target positions (waypoint_handler.py:70-83)
+//   MA hover       : spawn position (3), spawn quaternion (4), the action of the previous call (4)
+struct SideBlock {
   float t[4][3];
   int n_left;
   PF_DEV void load(const float4* S, size_t n, size_t i, int g) {
-    if (TASK != PF_TASK_WAYPOINTS) return;
     float4 a = S[(size_t)(g + 0) * n + i], b = S[(size_t)(g + 1) * n + i], c = S[(size_t)(g + 2) * n + i];
     t[0][0] = a.x; t[0][1] = a.y; t[0][2] = a.z; t[1][0] = a.w;
     t[1][1] = b.x; t[1][2] = b.y; t[2][0] = b.z; t[2][1] = b.w;
     t[2][2] = c.x; t[3][0] = c.y; t[3][1] = c.z; t[3][2] = c.w;
   }
   PF_DEV void store(float4* S, size_t n, size_t i, int g) const {
-    if (TASK != PF_TASK_WAYPOINTS) return;
     S[(size_t)(g + 0) * n + i] = float4{t[0][0], t[0][1], t[0][2], t[1][0]};
     S[(size_t)(g + 1) * n + i] = float4{t[1][1], t[1][2], t[2][0], t[2][1]};
     S[(size_t)(g + 2) * n + i] = float4{t[2][2], t[3][0], t[3][1], t[3][2]};
@@ -53,17 +53,25 @@ struct Targets {
   }
 };
 
-// ------------------------------------------------------------------ the fused env kernel
-// Per lane this is a small state machine over "Aviary steps":
-//   step phase   : env_step_ratio Aviary steps, each followed by compute_state +
-//                  compute_term_trunc_reward (quadx_base_env.py:287-296), early exit on term/trunc;
-//   settle phase : after a (auto-)reset, settle_steps Aviary steps with the mode's default
-//                  setpoint (quadx_base_env.py:209-210).
-// Both phases run through the single inlined aviary_step() below; the loop trip count is the
-// wave-wide maximum of what the lanes still have to do.
+// One Aviary.step out of line: used only by the rarely taken SAME_STEP settle loop so that the hot
+// loop below keeps the single inlined copy.
+template <class VEH, int MODE_T>
+__device__ __noinline__ void aviary_step_outlined(VEH* V, const pf_params* P, const float* sp, Noise* nz, int flat_base) {
+  V->template aviary_step<MODE_T>(*P, sp, *nz, flat_base);
+}
+
+// ------------------------------------------------------------------ the generic fused env kernel
+// Every (vehicle, task, flight mode) the specialised QuadX mode-0 kernel (quadx_fast.hpp) does not
+// cover. Flat control flow: reset preamble, ONE loop of Aviary steps with a single per-lane
+// predicate (stepping lanes run env_step_ratio iterations with the env logic, lanes that are being
+// reset run their settle iterations through the same loop body), epilogue.
+// `tmpl`: a settled spawn state (GROUPS float4s) computed once per context when the settle phase
+// cannot depend on the lane (Fixedwing: the settle throttle command is 0, so motor noise has
+// nothing to scale; any vehicle with noise off) -- a reset is then a copy.
 template <class VEH, int TASK, int MODE_T>
 __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_buffers B, const int n,
-                                                    const uint64_t lane0, const int op, const uint8_t* mask) {
+                                                    const uint64_t lane0, const int op, const uint8_t* mask,
+                                                    const float4* __restrict__ tmpl) {
   __shared__ float tile[kWave * kMaxObs];
   const int tid = threadIdx.x;
   const int wave_base = blockIdx.x * kWave;
@@ -74,13 +82,16 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   const float4* Sin = reinterpret_cast<const float4*>(B.state);
   float4* Sout = reinterpret_cast<float4*>(B.state);
   const int mode = (MODE_T == kRuntimeMode) ? P.flight_mode : MODE_T;
+  constexpr bool kSide = (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER);
 
   VEH V;
-  Targets<TASK> tg;
+  SideBlock tg;
   float new_dist;
   int4 ints;
   V.load(Sin, N, li, mode, new_dist, ints);
-  tg.load(Sin, N, li, VEH::G_TGT);
+  if (kSide) tg.load(Sin, N, li, VEH::G_TGT);
+  float4 ma_past = float4{0.f, 0.f, 0.f, 0.f};  // MA hover: self.past_actions (ma_quadx_base_env.py:326)
+  if (TASK == PF_TASK_MA_HOVER) ma_past = Sin[(size_t)(VEH::G_TGT + 3) * N + li];
   int step_count = ints.x, flags = ints.y;
   uint32_t rng_ctr = (uint32_t)ints.z;
   tg.n_left = ints.w;
@@ -92,7 +103,6 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
   nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
 
-  // what does this lane do in this launch?
   bool active, do_reset;
   if (op == OP_RESET) {
     do_reset = (mask == nullptr) || (mask[li] != 0);
@@ -102,22 +112,35 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     active = true;
   }
   active = active && valid;
+  do_reset = do_reset && active;
 
   float sp[6] = {0, 0, 0, 0, 0, 0};
-  float act4[4] = {0, 0, 0, 0};
+  float act4[4] = {0, 0, 0, 0};   // action slots of the observation
   float reward = 0.0f;
-  bool settling = false;
-  int remaining = 0, done_its = 0;
   bool pop_pending = false;
   bool rpy_valid = false;
-  const int D = ((P.angle_repr ? 13 : 12) + 4 + VEH::AUX) + (TASK == PF_TASK_WAYPOINTS ? 3 * P.num_targets : 0);
+  const int D = (P.angle_repr ? 13 : 12) + 4 + VEH::AUX +
+                (TASK == PF_TASK_WAYPOINTS ? 3 * P.num_targets : (TASK == PF_TASK_MA_HOVER ? 3 : 0));
 
-  // begin_reset + waypoint sampling + set_mode (quadx_base_env.py:149-206)
+  // env.reset() up to (not including) the settle phase: quadx_base_env.py:149-206,
+  // ma_quadx_base_env.py:206-241. Returns with `sp` = the mode's default setpoint.
   auto begin_reset = [&]() {
-    V.reset(P, nullptr, sp);
+    if (tmpl != nullptr) {
+      float nd_;
+      int4 i_;
+      V.load(tmpl, 1, 0, 7, nd_, i_);  // settled spawn state incl. controller memories (mode 7 == every group)
+      V.b.rpy = euler_from_quat_fast(V.b.q);
+    } else if (TASK == PF_TASK_MA_HOVER) {
+      const float pose[7] = {tg.t[0][0], tg.t[0][1], tg.t[0][2], tg.t[1][0], tg.t[1][1], tg.t[1][2], tg.t[2][0]};
+      V.reset(P, pose, sp);
+      V.set_mode(mode, sp);
+    } else {
+      V.reset(P, nullptr, sp);
+      V.set_mode(mode, sp);
+    }
     rpy_valid = true;
     step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
-    act4[0] = act4[1] = act4[2] = act4[3] = 0.0f;
+    if (TASK != PF_TASK_MA_HOVER) act4[0] = act4[1] = act4[2] = act4[3] = 0.0f;
     nz.begin_event(rng_ctr, 1u, B.xi_reset);
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = P.num_targets;
@@ -144,23 +167,31 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
         }
       }
     }
-    V.set_mode(mode, sp);
-    settling = true; remaining = P.settle_steps; done_its = 0;
   };
-  // compute_state (quadx_hover_env.py:85-115 / quadx_waypoints_env.py:127-175): only the
-  // waypoint bookkeeping has side effects; the observation vector itself is assembled at the end
+  // compute_state's waypoint bookkeeping (waypoint_handler.py:135-142); ||R^T d|| = ||d||
   auto wp_distance = [&]() {
     if (TASK != PF_TASK_WAYPOINTS) return;
     if (pop_pending) { tg.pop(); pop_pending = false; }
-    m3 Re = rot_from_quat(quat_from_euler(V.b.rpy));  // quadx_base_env.py:243, waypoint_handler.py:135
-    v3 d = mulT(Re, v3{tg.t[0][0] - V.b.p.x, tg.t[0][1] - V.b.p.y, tg.t[0][2] - V.b.p.z});
+    float dx = tg.t[0][0] - V.b.p.x, dy = tg.t[0][1] - V.b.p.y, dz = tg.t[0][2] - V.b.p.z;
     old_dist = new_dist;
-    new_dist = sqrtf(dot(d, d));
+    new_dist = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
   };
-  // compute_term_trunc_reward (quadx_base_env.py:251-267, quadx_hover_env.py:117-138,
-  // quadx_waypoints_env.py:177-204, fixedwing_waypoints_env.py:169-190)
+  // compute_term_trunc_reward: quadx_base_env.py:251-267, quadx_hover_env.py:117-138,
+  // quadx_waypoints_env.py:177-204, fixedwing_waypoints_env.py:169-190, ma_quadx_hover_env.py:168-205
   auto term_trunc_reward = [&]() {
     if (step_count > P.max_steps) trunc = true;
+    if (TASK == PF_TASK_MA_HOVER) {
+      if (V.b.contact_step) { reward -= 100.0f; flags |= PF_F_INFO_COLLISION; term = true; }
+      if (sqrtf(dot(V.b.p, V.b.p)) > P.dome) { reward -= 100.0f; flags |= PF_F_INFO_OOB; term = true; }
+      if (!P.sparse_reward) {
+        v3 d{V.b.p.x - tg.t[0][0], V.b.p.y - tg.t[0][1], V.b.p.z - tg.t[0][2]};
+        float lin = sqrtf(dot(d, d));
+        float ang = sqrtf(fmaf(V.b.rpy.x, V.b.rpy.x, V.b.rpy.y * V.b.rpy.y));
+        reward -= lin + ang * 0.1f;
+        reward += 1.0f;
+      }
+      return;
+    }
     if (V.b.contact_step) { reward = -100.0f; flags |= PF_F_INFO_COLLISION; term = true; }
     if (sqrtf(dot(V.b.p, V.b.p)) > P.dome) { reward = -100.0f; flags |= PF_F_INFO_OOB; term = true; }
     if (TASK == PF_TASK_HOVER) {
@@ -186,26 +217,33 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
       if (new_dist < P.goal_reach_distance) {
         reward = 100.0f;
         pop_pending = true;  // the observation of this step still shows the reached target
-        bool all = (tg.n_left - 1) == 0;
-        if (all) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
+        if ((tg.n_left - 1) == 0) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
       }
     }
   };
   // flattened observation row of this lane -> LDS tile (Appendix A of SURVEY.md)
   auto write_obs_row = [&]() {
+    if (!rpy_valid) { V.b.rpy = euler_from_quat_fast(V.b.q); rpy_valid = true; }
     float* row = tile + tid * D;
     int k = 0;
     row[k++] = V.b.wb.x; row[k++] = V.b.wb.y; row[k++] = V.b.wb.z;
-    quat qe = quat_from_euler(V.b.rpy);
+    quat qe = canon_quat(V.b.q);
     if (P.angle_repr) { row[k++] = qe.x; row[k++] = qe.y; row[k++] = qe.z; row[k++] = qe.w; }
     else { row[k++] = V.b.rpy.x; row[k++] = V.b.rpy.y; row[k++] = V.b.rpy.z; }
     row[k++] = V.b.vb.x; row[k++] = V.b.vb.y; row[k++] = V.b.vb.z;
     row[k++] = V.b.p.x; row[k++] = V.b.p.y; row[k++] = V.b.p.z;
-    row[k++] = act4[0]; row[k++] = act4[1]; row[k++] = act4[2]; row[k++] = act4[3];
     float aux[VEH::AUX];
     V.aux(aux);
+    if (TASK == PF_TASK_MA_HOVER) {  // ma_quadx_hover_env.py:141-166: aux, past action, start_pos
 #pragma unroll
-    for (int a = 0; a < VEH::AUX; ++a) row[k++] = aux[a];
+      for (int a = 0; a < VEH::AUX; ++a) row[k++] = aux[a];
+      row[k++] = ma_past.x; row[k++] = ma_past.y; row[k++] = ma_past.z; row[k++] = ma_past.w;
+      row[k++] = tg.t[0][0]; row[k++] = tg.t[0][1]; row[k++] = tg.t[0][2];
+    } else {
+      row[k++] = act4[0]; row[k++] = act4[1]; row[k++] = act4[2]; row[k++] = act4[3];
+#pragma unroll
+      for (int a = 0; a < VEH::AUX; ++a) row[k++] = aux[a];
+    }
     if (TASK == PF_TASK_WAYPOINTS) {
       m3 Re = rot_from_quat(qe);
 #pragma unroll
@@ -218,98 +256,133 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
       }
     }
   };
-  // tile -> global, full-width. Rows [wave_base, wave_base+rows) are contiguous in the output.
-  auto flush_tile = [&](float* out, bool all_rows) {
-    __syncthreads();
-    if (all_rows) {
+  const bool wave_all = __all(active || !valid);
+  // tile -> global with full-width stores; LDS-only sync (one wave per workgroup, see quadx_fast.hpp)
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto flush_tile = [&](float* out) {
+    lds_sync();
+    if (wave_all) {
       const int rows = min(kWave, n - wave_base);
       const int total = rows * D;
       float* g = out + (size_t)wave_base * D;
       const int n4 = total >> 2;
       const float4* t4 = reinterpret_cast<const float4*>(tile);
-      float4* g4 = reinterpret_cast<float4*>(g);
-      for (int i = tid; i < n4; i += kWave) g4[i] = t4[i];
-      for (int i = (n4 << 2) + tid; i < total; i += kWave) g[i] = tile[i];
+      for (int i = tid; i < n4; i += kWave) {
+        float4 t = t4[i];
+        __builtin_nontemporal_store(t.x, &g[4 * i + 0]);
+        __builtin_nontemporal_store(t.y, &g[4 * i + 1]);
+        __builtin_nontemporal_store(t.z, &g[4 * i + 2]);
+        __builtin_nontemporal_store(t.w, &g[4 * i + 3]);
+      }
+      for (int i = (n4 << 2) + tid; i < total; i += kWave) __builtin_nontemporal_store(tile[i], &g[i]);
     } else if (active) {  // partial (masked reset): this lane writes its own row
       float* g = out + (size_t)lane * D;
       const float* row = tile + tid * D;
       for (int k = 0; k < D; ++k) g[k] = row[k];
     }
-    __syncthreads();
+    lds_sync();
   };
 
-  if (active) {
-    if (do_reset) {
-      begin_reset();
+  // ---------------------------------------------------------------- what each lane runs
+  bool settling = false;  // in the settle phase of a reset (no env logic after an Aviary step)
+  int my_its = 0;         // Aviary steps this lane still has to run in the loop below
+  if (do_reset) {
+    begin_reset();
+    settling = true;
+    my_its = (tmpl != nullptr) ? 0 : P.settle_steps;
+  } else if (active) {
+    const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+    if (TASK == PF_TASK_MA_HOVER) {  // past <- current, current <- action (ma_quadx_base_env.py:326-332)
+      ma_past = float4{tg.t[2][1], tg.t[2][2], tg.t[3][0], tg.t[3][1]};
+      tg.t[2][1] = a.x; tg.t[2][2] = a.y; tg.t[3][0] = a.z; tg.t[3][1] = a.w;
+      reward = 0.0f;
+      term = false; trunc = false;  // per-call flags (ma_quadx_base_env.py:336-337)
+      my_its = P.env_step_ratio;    // no early exit in the multi-agent base (:342-361)
     } else {
-      const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
       act4[0] = a.x; act4[1] = a.y; act4[2] = a.z; act4[3] = a.w;
-      sp[0] = a.x; sp[1] = a.y; sp[2] = a.z;
-      sp[3] = P.throttle_remap ? fmaf(a.w, 0.5f, 0.5f) : a.w;  // fixedwing_base_env.py:260
       reward = -0.1f;
-      remaining = (term || trunc) ? 0 : P.env_step_ratio;
-      nz.begin_event(rng_ctr, 0u, B.xi);
+      my_its = (term || trunc) ? 0 : P.env_step_ratio;  // quadx_base_env.py:289-290
     }
+    sp[0] = a.x; sp[1] = a.y; sp[2] = a.z;
+    sp[3] = P.throttle_remap ? fmaf(a.w, 0.5f, 0.5f) : a.w;  // fixedwing_base_env.py:260
+    nz.begin_event(rng_ctr, 0u, B.xi);
   }
 
-  // lanes past the end of the batch never write; a wave whose in-range lanes are all active can
-  // flush its observation tile with full-width stores
-  const bool wave_all = __all(active || !valid);
-  float out_reward = 0.0f;
-  bool out_term = false, out_trunc = false;
-  for (int phase = 0; phase < 2; ++phase) {
-    while (__any(remaining > 0)) {
-      if (remaining > 0) {
-        V.template aviary_step<MODE_T>(P, sp, nz, done_its * P.ticks_per_control);
-        rpy_valid = true;
-        remaining -= 1;
-        done_its += 1;
-        if (!settling) {
-          wp_distance();
-          term_trunc_reward();
-          if (term || trunc) remaining = 0;
-        }
+  int it = 0;
+  while (__any(my_its > 0)) {
+    if (my_its > 0) {
+      V.template aviary_step<MODE_T>(P, sp, nz, it * P.ticks_per_control);
+      rpy_valid = true;
+      my_its -= 1;
+      if (!settling) {
+        wp_distance();
+        term_trunc_reward();
+        if (TASK != PF_TASK_MA_HOVER && (term || trunc)) my_its = 0;
       }
     }
-    if (phase == 1) break;
-    // ---- end of the step phase
-    const bool stepped = active && !settling && op == OP_STEP;
-    if (stepped) {
-      step_count += 1;  // quadx_base_env.py:299
-      rng_ctr += 1;
-      out_reward = reward; out_term = term; out_trunc = trunc;
-    }
-    const bool same = stepped && P.autoreset == PF_AUTORESET_SAME_STEP && (term || trunc);
-    if (!__any(same)) break;
-    if (B.final_obs != nullptr) {  // terminal observation, before the state is re-initialised
-      if (!rpy_valid) { V.b.rpy = euler_from_quat(V.b.q); rpy_valid = true; }
-      if (active) write_obs_row();
-      flush_tile(B.final_obs, wave_all);
-    }
-    if (same) begin_reset();  // the lane restarts inside the same call (quadx_base_env.py:149-212)
+    it += 1;
   }
+  const bool stepped = active && !settling && op == OP_STEP;
+  const float out_reward = stepped ? reward : 0.0f;
+  const bool out_term = stepped && term, out_trunc = stepped && trunc;
+  if (stepped) { step_count += 1; rng_ctr += 1; }  // quadx_base_env.py:299
 
+  // ---------------------------------------------------------------- SAME_STEP auto-reset (rare path)
+  if (P.autoreset == PF_AUTORESET_SAME_STEP) {
+    const bool same = stepped && (term || trunc);
+    if (__any(same)) {
+      if (B.final_obs != nullptr) {  // terminal observation, before the state is re-initialised
+        if (active) write_obs_row();
+        flush_tile(B.final_obs);
+      }
+      if (same) {
+        begin_reset();
+        settling = true;
+        if (tmpl == nullptr)
+          for (int s = 0; s < P.settle_steps; ++s) aviary_step_outlined<VEH, MODE_T>(&V, &P, sp, &nz, s * P.ticks_per_control);
+      }
+    }
+  }
   if (active && settling) {  // end_reset: compute_state after the settle steps (quadx_base_env.py:212)
     wp_distance();
     rng_ctr += 1;
   }
-  if (active && !rpy_valid) { V.b.rpy = euler_from_quat(V.b.q); rpy_valid = true; }
 
-  // ---- outputs
+  // ---------------------------------------------------------------- outputs: obs tile first, state after
+  if (active) write_obs_row();
+  flush_tile(B.obs);
   if (active) {
-    write_obs_row();
     if (pop_pending) { tg.pop(); pop_pending = false; }
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
             (trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0);
     V.store(Sout, N, li, mode, new_dist, int4{step_count, flags, (int)rng_ctr, tg.n_left});
-    tg.store(Sout, N, li, VEH::G_TGT);
+    if (kSide) tg.store(Sout, N, li, VEH::G_TGT);
+    if (TASK == PF_TASK_MA_HOVER) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = ma_past;
     if (op == OP_STEP) {  // a NEXT_STEP reset call reports (r=0, not done), gymnasium's convention
       B.reward[li] = out_reward;
       B.terminated[li] = out_term ? 1 : 0;
       B.truncated[li] = out_trunc ? 1 : 0;
     }
   }
-  flush_tile(B.obs, wave_all);
+}
+
+// Settled spawn state for contexts whose settle phase is lane-independent (see env_kernel).
+template <class VEH>
+__global__ void settle_template_kernel(const pf_params P, float4* tmpl) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  VEH V;
+  float sp[6] = {0, 0, 0, 0, 0, 0};
+  V.reset(P, nullptr, sp);
+  V.set_mode(P.flight_mode, sp);
+  Noise nz;
+  nz.mode = PF_NOISE_OFF; nz.n = 1; nz.lane = 0; nz.k0 = nz.k1 = nz.c0 = 0; nz.nmot = 0.f; nz.cached = -1; nz.xi = nullptr;
+  nz.begin_event(0u, 1u, nullptr);
+  for (int s = 0; s < P.settle_steps; ++s) V.template aviary_step<kRuntimeMode>(P, sp, nz, 0);
+  V.store(tmpl, 1, 0, 7, INFINITY, int4{0, 0, 0, 0});
 }
 
 // ------------------------------------------------------------------ Aviary-level kernels
@@ -369,7 +442,7 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   int4 ints;
   const int mode = P.flight_mode;
   V.load(reinterpret_cast<const float4*>(B.state), N, li, mode, nd, ints);
-  V.b.rpy = euler_from_quat(V.b.q);
+  V.b.rpy = euler_from_quat_fast(V.b.q);
   uint32_t rng_ctr = (uint32_t)ints.z;
   Noise nz;
   nz.mode = P.noise_mode; nz.n = n; nz.lane = lane;
@@ -428,6 +501,7 @@ struct pf_ctx {
   bool fast;
   pf::QuadK K;
   pf_params* P_dev;  // device copy of P for the rarely-taken floor-contact path
+  float4* tmpl;      // settled spawn state for lane-independent resets (env_kernel), or null
   int lpw;           // live lanes per wavefront (64, 32 or 16)
   int wps;           // register budget: waves per SIMD the kernel variant is compiled for (2 or 4)
   int n_simd;
@@ -463,9 +537,9 @@ template <class VEH, int TASK>
 static void launch_env_t(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
   if (ctx->P.vehicle == PF_QUADX && ctx->P.flight_mode == 0)
-    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, 0>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask);
+    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, 0>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl);
   else
-    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, pf::kRuntimeMode>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask);
+    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, pf::kRuntimeMode>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl);
 }
 extern "C" {
 
@@ -486,7 +560,8 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     return fail(nullptr, PF_ERR_UNSUPPORTED, "num_targets must be in 1..4");
   if (P.vehicle == PF_QUADX && (P.flight_mode < -1 || P.flight_mode > 7)) return fail(nullptr, PF_ERR_ARG, "quadx flight_mode must be in -1..7");
   if (P.vehicle == PF_FIXEDWING && (P.flight_mode < -1 || P.flight_mode > 0)) return fail(nullptr, PF_ERR_ARG, "fixedwing flight_mode must be -1 or 0");
-  if (P.vehicle == PF_FIXEDWING && P.task == PF_TASK_HOVER) return fail(nullptr, PF_ERR_UNSUPPORTED, "no fixedwing hover task in the reference");
+  if (P.vehicle == PF_FIXEDWING && (P.task == PF_TASK_HOVER || P.task == PF_TASK_MA_HOVER)) return fail(nullptr, PF_ERR_UNSUPPORTED, "no fixedwing hover task in the reference");
+  if (P.task == PF_TASK_MA_HOVER && P.autoreset != PF_AUTORESET_OFF) return fail(nullptr, PF_ERR_ARG, "the multi-agent env has no auto-reset (PettingZoo parallel API)");
   if (P.task != PF_TASK_NONE && P.vehicle == PF_FIXEDWING && P.flight_mode != 0) return fail(nullptr, PF_ERR_UNSUPPORTED, "fixedwing env uses flight_mode 0");
   // quat_integrate()'s polynomial range: |w| dt / 2 <= pi/8 given the per-coordinate clamp
   if (1.7320508f * P.max_coord_vel * P.dt * 0.5f > 0.3926991f + 1e-6f)
@@ -495,7 +570,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
-  c->P_dev = nullptr; c->lpw = 64; c->wps = 2; c->n_simd = 1024;
+  c->P_dev = nullptr; c->tmpl = nullptr; c->lpw = 64; c->wps = 2; c->n_simd = 1024;
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
   if (c->fast) {
     int cur = -1;
@@ -513,19 +588,38 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     if (const char* o = getenv("PF_LPW")) { int v = atoi(o); if (v == 64 || v == 32) c->lpw = v; }
     if (const char* o = getenv("PF_WPS")) { int v = atoi(o); if (v == 2 || v == 4) c->wps = v; }
   }
+  if (!c->fast && (P.task == PF_TASK_HOVER || P.task == PF_TASK_WAYPOINTS) &&
+      (P.vehicle == PF_FIXEDWING || P.noise_mode == PF_NOISE_OFF)) {
+    // the settle phase cannot depend on the lane (fixedwing: throttle command 0 during settle, so the
+    // motor noise scales nothing; or noise off): settle once here, resets copy the result
+    int cur = -1;
+    hipGetDevice(&cur);
+    hipSetDevice(device);
+    const int groups = P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : pf::Fixedwing::GROUPS;
+    hipError_t e = hipMalloc((void**)&c->tmpl, sizeof(float4) * groups);
+    if (e == hipSuccess) e = hipMemset(c->tmpl, 0, sizeof(float4) * groups);
+    if (e == hipSuccess) {
+      if (P.vehicle == PF_QUADX) hipLaunchKernelGGL(pf::settle_template_kernel<pf::QuadX>, dim3(1), dim3(64), 0, 0, P, c->tmpl);
+      else hipLaunchKernelGGL(pf::settle_template_kernel<pf::Fixedwing>, dim3(1), dim3(64), 0, 0, P, c->tmpl);
+      e = hipDeviceSynchronize();
+    }
+    if (cur >= 0) hipSetDevice(cur);
+    if (e != hipSuccess) { if (c->tmpl) hipFree(c->tmpl); delete c; return hip_fail(nullptr, e, "pf_ctx_create: settle template"); }
+  }
   *out = c;
   return PF_OK;
 }
 void pf_ctx_destroy(pf_ctx* ctx) {
   if (!ctx) return;
   if (ctx->P_dev) hipFree(ctx->P_dev);
+  if (ctx->tmpl) hipFree(ctx->tmpl);
   delete ctx;
 }
 int pf_state_groups(const pf_ctx* ctx) { return ctx->P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : pf::Fixedwing::GROUPS; }
 int pf_obs_dim(const pf_ctx* ctx) {
   const pf_params& P = ctx->P;
   int aux = P.vehicle == PF_QUADX ? 4 : 6;
-  return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? 3 * P.num_targets : 0);
+  return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? 3 * P.num_targets : (P.task == PF_TASK_MA_HOVER ? 3 : 0));
 }
 int pf_n_lanes(const pf_ctx* ctx) { return ctx->n; }
 
@@ -553,6 +647,7 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
     else launch_fast<PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
   } else if (P.vehicle == PF_QUADX) {
     if (P.task == PF_TASK_HOVER) launch_env_t<pf::QuadX, PF_TASK_HOVER>(ctx, b, op, mask, s);
+    else if (P.task == PF_TASK_MA_HOVER) launch_env_t<pf::QuadX, PF_TASK_MA_HOVER>(ctx, b, op, mask, s);
     else launch_env_t<pf::QuadX, PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
   } else {
     launch_env_t<pf::Fixedwing, PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);

@@ -113,13 +113,46 @@ PF_DEV float fast_asin(float x) {  // asin(x) = atan2(x, sqrt((1-x)(1+x)))
 }
 // cos(t/2), sin(t/2) of an angle t in (-pi, pi] given (cos t, sin t): no trig, no cancellation
 PF_DEV void half_angle(float c, float s, float& ch, float& sh) {
-  if (c >= 0.0f) {
-    ch = fsqrt(0.5f * (1.0f + c));
-    sh = 0.5f * s * frcp(ch);
-  } else {
-    sh = __builtin_copysignf(fsqrt(0.5f * (1.0f - c)), s);
-    ch = 0.5f * s * frcp(sh);
-  }
+  // a = sqrt((1+|c|)/2) is cos(t/2) when c >= 0 and |sin(t/2)| otherwise; the partner follows from
+  // sin t = 2 sin(t/2) cos(t/2). Branch-free (selects), so it stays in registers.
+  const float a = fsqrt(0.5f * (1.0f + __builtin_fabsf(c)));
+  const float b = 0.5f * s * frcp(a);
+  const bool pos = c >= 0.0f;
+  ch = pos ? a : __builtin_fabsf(b);
+  sh = pos ? b : __builtin_copysignf(a, s);
+}
+
+// sin/cos of a small angle (|x| <= 1: error < 2e-8) by Taylor polynomials, no range reduction
+PF_DEV void sincos_small(float x, float& sn, float& cs) {
+  const float t = x * x;
+  sn = x * fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, -2.5052108e-8f, 2.7557319e-6f), -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
+  cs = fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, 2.0876757e-9f, -2.7557319e-7f), 2.4801587e-5f), -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
+}
+// getEulerFromQuaternion without libm (polynomial atan2/asin, 1.2e-7 rad); same branches
+PF_DEV v3 euler_from_quat_fast(quat q) {
+  float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+  float sarg = -2.0f * (q.x * q.z - q.w * q.y) * frcp(sqx + sqy + sqz + squ);
+  if (sarg <= -0.99999f) return v3{0.0f, -0.5f * kPi, 2.0f * fast_atan2(q.x, -q.y)};
+  if (sarg >= 0.99999f) return v3{0.0f, 0.5f * kPi, 2.0f * fast_atan2(-q.x, q.y)};
+  return v3{fast_atan2(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz), fast_asin(sarg),
+            fast_atan2(2.0f * (q.x * q.y + q.w * q.z), squ + sqx - sqy - sqz)};
+}
+// getQuaternionFromEuler(getEulerFromQuaternion(q)) (quadx_base_env.py:243) by half-angle algebra;
+// the gimbal-lock branch (|sin pitch| >= 0.99999) falls back to the trigonometric definition.
+PF_DEV quat canon_quat(quat q) {
+  float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+  float sarg = -2.0f * (q.x * q.z - q.w * q.y) * frcp(sqx + sqy + sqz + squ);
+  if (__builtin_fabsf(sarg) >= 0.99999f) return quat_from_euler(euler_from_quat(q));
+  float ar = 2.0f * (q.y * q.z + q.w * q.x), br = squ - sqx - sqy + sqz;
+  float ay = 2.0f * (q.x * q.y + q.w * q.z), by = squ + sqx - sqy - sqz;
+  float hr = frsq(fmaf(ar, ar, br * br)), hy = frsq(fmaf(ay, ay, by * by));
+  float cr, sr, cp, sp, cy, sy;
+  half_angle(br * hr, ar * hr, cr, sr);
+  half_angle(fsqrt((1.0f - sarg) * (1.0f + sarg)), sarg, cp, sp);
+  half_angle(by * hy, ay * hy, cy, sy);
+  quat t{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+  float inv = frsq(fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w))));
+  return quat{t.x * inv, t.y * inv, t.z * inv, t.w * inv};
 }
 
 // q <- exp(w dt/2) (x) q, normalised: btMultiBody::stepPositionsMultiDof. The half-angle

@@ -114,7 +114,7 @@ struct Body {
     contact_now = false;
     contact_step = false;
     derive();
-    rpy = euler_from_quat(q);
+    rpy = euler_from_quat_fast(q);
   }
 };
 
@@ -124,7 +124,7 @@ struct Body {
 constexpr int kRuntimeMode = 100;
 
 struct QuadX {
-  static constexpr int GROUPS = 15, G_INT = 6, G_TGT = 12, AUX = 4, SP = 4;
+  static constexpr int GROUPS = 16, G_INT = 6, G_TGT = 12, AUX = 4, SP = 4;  // g15: MA-hover past action
   Body b;
   float thr[4];
   float pwm[4];
@@ -161,7 +161,7 @@ struct QuadX {
     b.contact_now = (ints.y & PF_F_CONTACT) != 0;
     b.contact_step = false;
     b.derive();
-    if (needs_cascade(mode)) b.rpy = euler_from_quat(b.q);
+    if (needs_cascade(mode)) b.rpy = euler_from_quat_fast(b.q);
     else b.rpy = v3{0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) pwm[k] = 0.0f;
@@ -301,7 +301,7 @@ struct QuadX {
     b.contact_step = false;
     control<MODE_T>(P, sp);
     for (int t = 0; t < P.ticks_per_control; ++t) tick(P, nz.get(flat_base + t));
-    b.rpy = euler_from_quat(b.q);
+    b.rpy = euler_from_quat_fast(b.q);
   }
   PF_DEV void aux(float* o) const {
 #pragma unroll
@@ -353,12 +353,20 @@ struct Fixedwing {
     thr = 0.0f;
     set_mode(0, sp);
   }
-  // lifting_surfaces.py:266-498 for one surface; returns force & torque in the (axis-aligned) link frame
+  // lifting_surfaces.py:266-498 for one surface; returns force & torque in the (axis-aligned) link
+  // frame. libm-free: (cos a, sin a) come from the velocity components, the effective angle of attack
+  // a_eff = a - (a_0 + a_i) by the angle-difference identities with a small-angle polynomial for the
+  // second operand (|a_0 + a_i| < 0.8 rad for any surface the model admits), a itself (needed for the
+  // regime tests and CM) from the polynomial atan2.
   PF_DEV void surface(const pf_surface& S, v3 vloc, float a, v3& F, v3& T) const {
     v3 lift{S.lift[0], S.lift[1], S.lift[2]}, drag{S.drag[0], S.drag[1], S.drag[2]};
     float V2 = dot(vloc, vloc);
     float la = dot(vloc, lift), fa = dot(vloc, drag);
-    float alpha = atan2f(-la, fa);  // :342-345
+    float h2 = fmaf(la, la, fa * fa);
+    float ih = frsq(h2);
+    const bool still = !(h2 > 0.0f);
+    float ca = still ? 1.0f : fa * ih, sa = still ? 0.0f : -la * ih;
+    float alpha = fast_atan2(-la, fa);  // :342-345
     // :386-394
     float defl = a * S.deflection_limit_rad;
     float dCl = S.Cl_alpha_3D * S.aero_tau_eta * defl;
@@ -367,33 +375,36 @@ struct Fixedwing {
     float ClmaxN = fmaf(S.Cl_alpha_3D, S.alpha_stall_N_base - S.alpha_0_base, dClmax);
     float a0 = S.alpha_0_base - dCl * S.inv_Cl_alpha_3D;
     float aP = fmaf(ClmaxP, S.inv_Cl_alpha_3D, a0), aN = fmaf(ClmaxN, S.inv_Cl_alpha_3D, a0);
+    const bool linear = (aN < alpha) && (alpha < aP);
+    // induced angle: linear regime :397-399, post-stall two-point np.interp :409-425
+    float Cl_lin = S.Cl_alpha_3D * (alpha - a0);
+    float ai;
+    if (linear) {
+      ai = Cl_lin * S.inv_pi_aspect;
+    } else if (alpha > 0.0f) {
+      float ai_stall = S.Cl_alpha_3D * (aP - a0) * S.inv_pi_aspect;
+      float x0 = aP, x1 = 0.5f * kPi;
+      ai = (alpha <= x0) ? ai_stall : (alpha >= x1 ? 0.0f : ai_stall - ai_stall * frcp(x1 - x0) * (alpha - x0));
+    } else {
+      float ai_stall = S.Cl_alpha_3D * (aN - a0) * S.inv_pi_aspect;
+      float x0 = -0.5f * kPi, x1 = aN;
+      ai = (alpha <= x0) ? 0.0f : (alpha >= x1 ? ai_stall : ai_stall * frcp(x1 - x0) * (alpha - x0));
+    }
+    const float x = a0 + ai;
+    const float ae = alpha - x;
+    float sx, cx;
+    sincos_small(x, sx, cx);
+    const float se = sa * cx - ca * sx, ce = fmaf(ca, cx, sa * sx);
     float Cl, Cd, CM;
-    if (aN < alpha && alpha < aP) {  // :397-406
-      Cl = S.Cl_alpha_3D * (alpha - a0);
-      float ai = Cl * S.inv_pi_aspect;
-      float ae = alpha - a0 - ai;
-      float se, ce;
-      sincosf(ae, &se, &ce);
+    if (linear) {  // :397-406
+      Cl = Cl_lin;
       float CT = S.Cd_0 * ce;
-      float CN = (Cl + CT * se) / ce;
+      float CN = (Cl + CT * se) * frcp(ce);
       Cd = CN * se + CT * ce;
       CM = -CN * (0.25f - 0.175f * (1.0f - 2.0f * ae * (1.0f / kPi)));
-    } else {  // :409-448
-      float ai;
-      if (alpha > 0.0f) {
-        float ai_stall = S.Cl_alpha_3D * (aP - a0) * S.inv_pi_aspect;
-        float x0 = aP, x1 = 0.5f * kPi;
-        ai = (alpha <= x0) ? ai_stall : (alpha >= x1 ? 0.0f : ai_stall - ai_stall / (x1 - x0) * (alpha - x0));
-      } else {
-        float ai_stall = S.Cl_alpha_3D * (aN - a0) * S.inv_pi_aspect;
-        float x0 = -0.5f * kPi, x1 = aN;
-        ai = (alpha <= x0) ? 0.0f : (alpha >= x1 ? ai_stall : ai_stall / (x1 - x0) * (alpha - x0));
-      }
-      float ae = alpha - a0 - ai;
-      float se, ce;
-      sincosf(ae, &se, &ce);
+    } else {  // :427-448
       float Cd90 = fmaf(-4.26e-2f, defl * defl, fmaf(2.1e-1f, defl, 1.98f));
-      float CN = Cd90 * se * (1.0f / (0.56f + 0.44f * __builtin_fabsf(se)) - S.exp_term);
+      float CN = Cd90 * se * (frcp(0.56f + 0.44f * __builtin_fabsf(se)) - S.exp_term);
       float CT = 0.5f * S.Cd_0 * ce;
       Cl = CN * ce - CT * se;
       Cd = CN * se + CT * ce;
@@ -402,8 +413,6 @@ struct Fixedwing {
     // :485-498
     float QA = S.half_rho_area * V2;
     float L = Cl * QA, D = Cd * QA;
-    float sa, ca;
-    sincosf(alpha, &sa, &ca);
     float fn = L * ca + D * sa, fp = L * sa - D * ca;
     F = v3{lift.x * fn + drag.x * fp, lift.y * fn + drag.y * fp, lift.z * fn + drag.z * fp};
     float tm = QA * CM * S.chord;
@@ -456,7 +465,7 @@ struct Fixedwing {
     b.contact_step = false;
     control<MODE_T>(P, sp);
     for (int t = 0; t < P.ticks_per_control; ++t) tick(P, nz.get(flat_base + t));
-    b.rpy = euler_from_quat(b.q);
+    b.rpy = euler_from_quat_fast(b.q);
   }
   PF_DEV void aux(float* o) const {
 #pragma unroll

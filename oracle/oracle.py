@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "libuav_oracle.so")
 
 MAX_TARGETS, MAX_BOXES, MAX_SURF = 8, 8, 5
 QUADX, FIXEDWING = 0, 1
-TASK_NONE, TASK_HOVER, TASK_WAYPOINTS = 0, 1, 2
+TASK_NONE, TASK_HOVER, TASK_WAYPOINTS, TASK_MA_HOVER = 0, 1, 2, 3
 NOISE_OFF, NOISE_INJECT, NOISE_PHILOX = 0, 1, 2
 
 d3 = C.c_double * 3
@@ -84,7 +84,7 @@ class Lane(C.Structure):
         ("step_count", C.c_int), ("terminated", C.c_int), ("truncated", C.c_int),
         ("info_oob", C.c_int), ("info_collision", C.c_int), ("info_complete", C.c_int),
         ("num_targets_reached", C.c_int),
-        ("reward", C.c_double), ("action", C.c_double * 4),
+        ("reward", C.c_double), ("action", C.c_double * 4), ("past_action", C.c_double * 4),
         ("targets", d3 * MAX_TARGETS), ("n_targets_left", C.c_int),
         ("new_dist", C.c_double), ("old_dist", C.c_double),
         ("obs", C.c_double * 48),
@@ -141,7 +141,7 @@ def lib():
         L.orc_env_step_batch.argtypes = [PP, LP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for f in ("orc_params_quadx", "orc_params_fixedwing", "orc_task_hover", "orc_task_quadx_waypoints",
-                  "orc_task_fixedwing_waypoints", "orc_finalize"):
+                  "orc_task_fixedwing_waypoints", "orc_task_ma_hover", "orc_finalize"):
             getattr(L, f).argtypes = [PP]
         _lib = L
     return _lib
@@ -159,7 +159,7 @@ def make_params(env: str, noise_mode: int = NOISE_OFF, seed: int = 0, **override
     """env in {'quadx', 'fixedwing', 'hover', 'quadx_waypoints', 'fixedwing_waypoints'}."""
     L = lib()
     P = Params()
-    if env in ("quadx", "hover", "quadx_waypoints"):
+    if env in ("quadx", "hover", "quadx_waypoints", "ma_hover"):
         L.orc_params_quadx(C.byref(P))
     else:
         L.orc_params_fixedwing(C.byref(P))
@@ -169,6 +169,8 @@ def make_params(env: str, noise_mode: int = NOISE_OFF, seed: int = 0, **override
         L.orc_task_quadx_waypoints(C.byref(P))
     elif env == "fixedwing_waypoints":
         L.orc_task_fixedwing_waypoints(C.byref(P))
+    elif env == "ma_hover":
+        L.orc_task_ma_hover(C.byref(P))
     P.noise_mode = noise_mode
     P.seed = seed
     for k, v in overrides.items():

@@ -632,6 +632,12 @@ void orc_task_fixedwing_waypoints(orc_params* P) { /* fixedwing_waypoints_env.py
   P->wp_dist_reward = 1.0; P->wp_yaw_penalty = 0.0;
 }
 
+void orc_task_ma_hover(orc_params* P) { /* pz_envs/quadx_envs/ma_quadx_hover_env.py:36-52 */
+  P->task = ORC_TASK_MA_HOVER;
+  P->flight_mode = 0; P->dome = 10.0; P->max_steps = 1200; P->env_step_ratio = 3;
+  P->sparse_reward = 0; P->angle_repr = 1; P->num_targets = 0; P->collide_any = 0; P->throttle_remap = 0;
+}
+
 /* ------------------------------------------------------------------ lane level */
 /* quadx.py:512-535 / fixedwing.py:266-291 */
 void orc_update_state(const orc_params* P, orc_lane* L) {
@@ -672,8 +678,15 @@ void orc_set_mode(const orc_params* P, orc_lane* L, int mode) {
 /* aviary.py:218-312 + quadx.py:222-231 / fixedwing.py:194-204 */
 void orc_aviary_reset(const orc_params* P, orc_lane* L, uint64_t lane_id) {
   uint32_t ctr = L->rng_ctr;
+  double keep[8];
+  memcpy(keep, L->action, sizeof(double) * 4);
+  memcpy(keep + 4, L->past_action, sizeof(double) * 4);
   memset(L, 0, sizeof(*L));
   L->rng_ctr = ctr;
+  if (P->task == ORC_TASK_MA_HOVER) { /* current/past actions are created once in __init__ (ma_quadx_base_env.py:139-150) */
+    memcpy(L->action, keep, sizeof(double) * 4);
+    memcpy(L->past_action, keep + 4, sizeof(double) * 4);
+  }
   L->lane_id = lane_id;
   for (int k = 0; k < 3; ++k) { L->p[k] = P->start_pos[k]; L->v[k] = P->start_vel[k]; }
   orc_quat_from_euler(P->start_rpy, L->q); /* base_drone.py:115 */
@@ -778,6 +791,7 @@ static void compute_deltas(const orc_params* P, orc_lane* L, double deltas[][3])
 }
 int orc_obs_dim(const orc_params* P) {
   int att = (P->angle_repr ? 13 : 12) + 4 + (P->vehicle == ORC_QUADX ? 4 : 6);
+  if (P->task == ORC_TASK_MA_HOVER) return att + 3;
   return att + (P->task == ORC_TASK_WAYPOINTS ? 3 * P->num_targets : 0);
 }
 /* quadx_hover_env.py:85-115 ; quadx_waypoints_env.py:125-175 ; flatten_waypoint_env.py:42-62.
@@ -796,6 +810,12 @@ static void env_compute_state(const orc_params* P, orc_lane* L) {
   }
   for (int i = 0; i < 3; ++i) obs[k++] = L->v_b[i];
   for (int i = 0; i < 3; ++i) obs[k++] = L->p[i];
+  if (P->task == ORC_TASK_MA_HOVER) { /* ma_quadx_hover_env.py:141-166: aux, past action, start_pos */
+    for (int i = 0; i < 4; ++i) obs[k++] = L->throttle[i];
+    for (int i = 0; i < 4; ++i) obs[k++] = L->past_action[i];
+    for (int i = 0; i < 3; ++i) obs[k++] = P->start_pos[i];
+    return;
+  }
   for (int i = 0; i < 4; ++i) obs[k++] = L->action[i];
   if (P->vehicle == ORC_QUADX) {
     for (int i = 0; i < 4; ++i) obs[k++] = L->throttle[i];
@@ -818,6 +838,18 @@ void orc_env_obs(const orc_params* P, const orc_lane* L, double* obs) {
 /* quadx_base_env.py:251-267 + hover :117-138 + waypoints :177-204 + fixedwing_waypoints :169-190 */
 static void env_term_trunc_reward(const orc_params* P, orc_lane* L) {
   if (L->step_count > P->max_steps) L->truncated = 1;
+  if (P->task == ORC_TASK_MA_HOVER) { /* ma_quadx_hover_env.py:168-205: additive penalties */
+    if (L->contact_step) { L->reward -= 100.0; L->info_collision = 1; L->terminated = 1; }
+    if (sqrt(dot3(L->p, L->p)) > P->dome) { L->reward -= 100.0; L->info_oob = 1; L->terminated = 1; }
+    if (!P->sparse_reward) {
+      double d[3] = {L->p[0] - P->start_pos[0], L->p[1] - P->start_pos[1], L->p[2] - P->start_pos[2]};
+      double linear_distance = sqrt(dot3(d, d));
+      double angular_distance = sqrt(L->rpy[0] * L->rpy[0] + L->rpy[1] * L->rpy[1]);
+      L->reward -= linear_distance + angular_distance * 0.1;
+      L->reward += 1.0;
+    }
+    return;
+  }
   if (L->contact_step) { L->reward = -100.0; L->info_collision = 1; L->terminated = 1; }
   if (sqrt(dot3(L->p, L->p)) > P->dome) { L->reward = -100.0; L->info_oob = 1; L->terminated = 1; }
   if (P->task == ORC_TASK_HOVER) {
@@ -866,6 +898,19 @@ void orc_env_reset(const orc_params* P, orc_lane* L, uint64_t lane_id, const dou
 }
 /* quadx_base_env.py:269-301 ; fixedwing_base_env.py:244-278 */
 void orc_env_step(const orc_params* P, orc_lane* L, const double action[4], const double* xi) {
+  if (P->task == ORC_TASK_MA_HOVER) { /* ma_quadx_base_env.py:309-371, one agent */
+    for (int i = 0; i < 4; ++i) { L->past_action[i] = L->action[i]; L->action[i] = action[i]; L->setpoint[i] = action[i]; }
+    L->reward = 0.0; L->terminated = 0; L->truncated = 0;
+    const int tpc2 = P->world.ticks_per_control;
+    for (int s = 0; s < P->env_step_ratio; ++s) { /* no early exit */
+      orc_aviary_step(P, L, xi ? xi + s * tpc2 : 0, (uint32_t)(s * tpc2), 0);
+      env_term_trunc_reward(P, L);
+      env_compute_state(P, L);
+    }
+    L->step_count += 1;
+    L->rng_ctr += 1;
+    return;
+  }
   for (int i = 0; i < 4; ++i) { L->action[i] = action[i]; L->setpoint[i] = action[i]; }
   if (P->throttle_remap) L->setpoint[3] = (action[3] / 2.0) + 0.5;
   L->reward = -0.1;

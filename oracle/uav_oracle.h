@@ -30,7 +30,7 @@ extern "C" {
 #define ORC_MAX_SURF 5
 
 enum { ORC_QUADX = 0, ORC_FIXEDWING = 1 };
-enum { ORC_TASK_NONE = 0, ORC_TASK_HOVER = 1, ORC_TASK_WAYPOINTS = 2 };
+enum { ORC_TASK_NONE = 0, ORC_TASK_HOVER = 1, ORC_TASK_WAYPOINTS = 2, ORC_TASK_MA_HOVER = 3 };
 enum { ORC_NOISE_OFF = 0, ORC_NOISE_INJECT = 1, ORC_NOISE_PHILOX = 2 };
 
 /* World / integrator knobs -- aviary.py:225-242 + [BULLET-FROM-MEMORY] defaults */
@@ -145,6 +145,7 @@ typedef struct {
   int info_oob, info_collision, info_complete, num_targets_reached;
   double reward;
   double action[4];
+  double past_action[4]; /* MA hover: self.past_actions (ma_quadx_base_env.py:326), survives resets */
   double targets[ORC_MAX_TARGETS][3];
   int n_targets_left;
   double new_dist, old_dist;
@@ -163,6 +164,7 @@ void orc_params_fixedwing(orc_params* P);
 void orc_task_hover(orc_params* P);
 void orc_task_quadx_waypoints(orc_params* P);
 void orc_task_fixedwing_waypoints(orc_params* P);
+void orc_task_ma_hover(orc_params* P);
 void orc_finalize(orc_params* P); /* recompute derived quantities after edits */
 
 /* ---------- components (golden-checked one by one) ---------- */

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libpyflyt_amd.so")
 
 PF_MAX_BOXES, PF_MAX_SURF = 8, 5
 QUADX, FIXEDWING = 0, 1
-TASK_NONE, TASK_HOVER, TASK_WAYPOINTS = 0, 1, 2
+TASK_NONE, TASK_HOVER, TASK_WAYPOINTS, TASK_MA_HOVER = 0, 1, 2, 3
 NOISE_OFF, NOISE_INJECT, NOISE_PHILOX = 0, 1, 2
 AUTORESET_OFF, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
 F_TERMINATED, F_TRUNCATED, F_CONTACT, F_INFO_COLLISION, F_INFO_OOB, F_INFO_COMPLETE = 1, 2, 4, 8, 16, 32

@@ -166,7 +166,7 @@ def build_params(
     vehicle_options: dict | None = None,
     world_options: dict | None = None,
 ) -> L.PfParams:
-    """vehicle in {'quadx','fixedwing'}; task in {'none','hover','waypoints'}."""
+    """vehicle in {'quadx','fixedwing'}; task in {'none','hover','waypoints','ma_hover'}."""
     W = dict(WORLD, **(world_options or {}))
     P = L.PfParams()
     P.noise_mode = {"off": L.NOISE_OFF, "inject": L.NOISE_INJECT, "philox": L.NOISE_PHILOX}[noise]
@@ -276,6 +276,9 @@ def build_params(
     elif task == "hover":  # quadx_hover_env.py:32-37
         P.task = L.TASK_HOVER
         d_dome, d_dur, d_hz, d_reach = 3.0, 10.0, 40, 0.2
+    elif task == "ma_hover":  # pz_envs/quadx_envs/ma_quadx_hover_env.py:36-52
+        P.task = L.TASK_MA_HOVER
+        d_dome, d_dur, d_hz, d_reach = 10.0, 30.0, 40, 0.2
     elif task == "waypoints":
         P.task = L.TASK_WAYPOINTS
         if vehicle == "quadx":  # quadx_waypoints_env.py:38-47,87

@@ -1,0 +1,120 @@
+"""PettingZoo-ParallelEnv-shaped façade of the multi-agent QuadX hover env
+(pz_envs/quadx_envs/ma_quadx_base_env.py:17-371, ma_quadx_hover_env.py:14-205).
+
+Same constructor keywords, agent naming ("uav_i"), dict-in/dict-out `reset()` / `step()`, observation
+layout [ang_vel, quat|rpy, lin_vel, lin_pos, throttle(4), past action(4), start_pos(3)], additive
+-100 penalties, per-call term/trunc flags, culling of finished agents. One difference, by scope
+(SURVEY.md section 8(a) row 22, 8(f)-2): the reference puts all agents in ONE Bullet world so they can
+collide with each other; here every agent is an independent lane (no drone-drone contact).
+
+`num_envs` independent copies of the whole multi-agent env are stepped at once: dict values are
+tensors of shape [num_envs, ...] (squeezed to the reference's per-agent vectors when num_envs == 1).
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..engine import BatchEngine
+from ..params import build_params, quat_from_euler
+from ..spaces import Box
+
+
+class MAQuadXHoverEnv:
+    metadata = {"render_modes": [], "name": "ma_quadx_hover"}
+
+    def __init__(self, start_pos=np.array([[-1.0, -1.0, 1.0], [1.0, -1.0, 1.0], [-1.0, 1.0, 1.0], [1.0, 1.0, 1.0]]),
+                 start_orn=np.zeros((4, 3)), sparse_reward: bool = False, flight_mode: int = 0, flight_dome_size: float = 10.0,
+                 max_duration_seconds: float = 30.0, angle_representation: str = "quaternion", agent_hz: int = 40,
+                 render_mode=None, num_envs: int = 1, device="cuda:0", seed: int = 0, motor_noise: bool = True):
+        if render_mode is not None:
+            raise ValueError("rendering is out of scope for the batched GPU path")
+        start_pos, start_orn = np.asarray(start_pos, dtype=np.float64), np.asarray(start_orn, dtype=np.float64)
+        assert len(start_pos.shape) == 2 and start_pos.shape[-1] == 3, f"Expected `start_pos` to be of shape [num_agents, 3], got {start_pos.shape}."
+        assert start_pos.shape == start_orn.shape, f"Expected `start_pos` to be of shape [num_agents, 3], got {start_pos.shape}."
+        if 120 % agent_hz != 0:  # ma_quadx_base_env.py:60-65
+            lowest, highest = int(120 / (int(120 / agent_hz) + 1)), int(120 / int(120 / agent_hz))
+            raise AssertionError(f"`agent_hz` must be round denominator of 120, try {lowest} or {highest}.")
+        self.start_pos, self.start_orn = start_pos, start_orn
+        self.num_possible_agents = len(start_pos)
+        self.possible_agents = ["uav_" + str(r) for r in range(self.num_possible_agents)]
+        self.agent_name_mapping = dict(zip(self.possible_agents, range(self.num_possible_agents)))
+        self.agents: list[str] = []
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        self._kw = dict(flight_mode=flight_mode, flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds,
+                        angle_representation=angle_representation, agent_hz=agent_hz, sparse_reward=sparse_reward)
+        self._noise = "philox" if motor_noise else "off"
+        self._seed = int(seed)
+        self._build(self._seed)
+        att = 13 if angle_representation == "quaternion" else 12
+        xyz, thr = np.pi, 0.8
+        self._action_space = Box(low=np.array([-xyz, -xyz, -xyz, 0.0], dtype=np.float32),
+                                 high=np.array([xyz, xyz, xyz, thr], dtype=np.float32), dtype=np.float32)
+        self._observation_space = Box(low=-np.inf, high=np.inf, shape=(att + 4 + 4 + 3,), dtype=np.float32)
+        self.max_steps = self.engine.params.max_steps
+        self.step_count = 0
+
+    def _build(self, seed):
+        A, E = self.num_possible_agents, self.num_envs
+        P = build_params("quadx", "ma_hover", noise=self._noise, autoreset="off", seed=seed, **self._kw)
+        self.engine = BatchEngine(P, A * E, device=self.device)
+        # lane = env * A + agent; the per-lane spawn lives in the state's side block
+        pose = np.concatenate([self.start_pos, np.stack([quat_from_euler(o) for o in self.start_orn])], axis=1)  # [A,7]
+        side = np.zeros((A * E, 12), dtype=np.float32)
+        side[:, :7] = np.tile(pose, (E, 1))
+        st = self.engine.state
+        st[12:15] = torch.tensor(side, device=self.device).view(A * E, 3, 4).permute(1, 0, 2)
+
+    def observation_space(self, agent: Any = None):
+        return self._observation_space
+
+    def action_space(self, agent: Any = None):
+        return self._action_space
+
+    def close(self):
+        self.engine.close()
+
+    def _split(self, t):
+        """[E*A, ...] -> per-agent views [E, ...] (squeezed when E == 1)."""
+        A, E = self.num_possible_agents, self.num_envs
+        t = t.view(E, A, *t.shape[1:])
+        return [t[:, i].squeeze(0) if E == 1 else t[:, i] for i in range(A)]
+
+    # ------------------------------------------------------------------ ma_quadx_hover_env.py:99-121
+    def reset(self, seed=None, options=None):
+        if seed is not None and int(seed) != self._seed:
+            self._seed = int(seed)
+            keep = self.engine.state[12:16].clone()  # spawn poses and the action memories survive
+            self.engine.close()
+            self._build(self._seed)
+            self.engine.state[12:16] = keep
+        self.step_count = 0
+        self.agents = self.possible_agents[:]
+        self.engine.env_reset()
+        obs = self._split(self.engine.obs)
+        return {ag: obs[i] for i, ag in enumerate(self.possible_agents)}, {ag: dict() for ag in self.agents}
+
+    # ------------------------------------------------------------------ ma_quadx_base_env.py:309-371
+    def step(self, actions: dict):
+        A, E = self.num_possible_agents, self.num_envs
+        act = torch.zeros(E, A, 4, dtype=torch.float32, device=self.device)  # current_actions *= 0 (:329)
+        for k, v in actions.items():
+            v = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v), dtype=torch.float32)
+            act[:, self.agent_name_mapping[k]] = v.to(self.device).view(E, 4)
+        obs, rew, term, trunc = self.engine.env_step(act.view(E * A, 4))
+        o, r, t, u = self._split(obs), self._split(rew), self._split(term), self._split(trunc)
+        f = self._split(self.engine.flags())
+        observations, rewards, terminations, truncations, infos = {}, {}, {}, {}, {}
+        for ag in self.agents:
+            i = self.agent_name_mapping[ag]
+            observations[ag], rewards[ag], terminations[ag], truncations[ag] = o[i], r[i], t[i], u[i]
+            infos[ag] = {"collision": (f[i] & L.F_INFO_COLLISION) != 0, "out_of_bounds": (f[i] & L.F_INFO_OOB) != 0}
+        self.step_count += 1
+        # cull finished agents (:365-369); with num_envs > 1 an agent stays listed until it has finished
+        # in every copy (its per-copy flags are in terminations/truncations)
+        self.agents = [ag for ag in self.agents if not bool((terminations[ag] | truncations[ag]).all())]
+        return observations, rewards, terminations, truncations, infos

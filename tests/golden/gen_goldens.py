@@ -278,9 +278,60 @@ def gen_envs():
     save("env_fixedwing_waypoints_gentle", **run_env(lambda: FixedwingWaypointsEnv(goal_reach_distance=40.0), 400, 6, gentle_fw_action, num_targets=4, ticks=8))
 
 
+def gen_ma_hover():
+    """pz_envs/quadx_envs/ma_quadx_hover_env.py driven through its PettingZoo dict API: 4 agents in one
+    (fake-Bullet) world -- drone-drone contact is not restated, so agents are independent lanes. The
+    shared np_random draws one motor-noise scalar per drone per tick, in drone order."""
+    from PyFlyt.pz_envs.quadx_envs.ma_quadx_hover_env import MAQuadXHoverEnv
+
+    made = []
+    orig = np.random.default_rng
+
+    def recording_default_rng(seed=None):
+        r = ref_stubs.RecordingRNG(orig(seed))
+        made.append(r)
+        return r
+
+    np.random.default_rng = recording_default_rng
+    try:
+        env = MAQuadXHoverEnv(flight_dome_size=2.5, max_duration_seconds=1.0)  # small dome/duration: both exits occur
+        rng = orig(123)
+        rec = dict(action=[], obs=[], reward=[], term=[], trunc=[], xi=[], alive=[], reset_before=[], reset_obs=[], reset_xi=[])
+
+        def do_reset(seed):
+            obs, infos = env.reset(seed=seed)
+            r = made[-1]
+            rec["reset_obs"].append(np.stack([obs[a] for a in env.possible_agents]))
+            rec["reset_xi"].append(r.drain("normal").reshape(-1, 4))  # [tick][drone]
+            return r
+
+        r = do_reset(0)
+        n_ag = len(env.possible_agents)
+        for k in range(90):
+            if len(env.agents) == 0:
+                rec["reset_before"].append(k)
+                r = do_reset(k)
+            alive = [a in env.agents for a in env.possible_agents]
+            acts = {a: np.array([*rng.uniform(-1.0, 1.0, size=3), rng.uniform(0.2, 0.7)]) for a in env.agents}
+            obs, rew, term, trunc, infos = env.step(acts)
+            A = np.zeros((n_ag, 4)); O = np.full((n_ag, 24), np.nan); R = np.full(n_ag, np.nan)
+            T = np.zeros(n_ag, bool); U = np.zeros(n_ag, bool)
+            for i, a in enumerate(env.possible_agents):
+                if a in acts:
+                    A[i] = acts[a]; O[i] = obs[a]; R[i] = rew[a]; T[i] = term[a]; U[i] = trunc[a]
+            rec["action"].append(A); rec["obs"].append(O); rec["reward"].append(R); rec["term"].append(T); rec["trunc"].append(U)
+            rec["alive"].append(alive)
+            rec["xi"].append(r.drain("normal").reshape(-1, 4))
+        save("env_ma_quadx_hover", start_pos=env.start_pos, start_orn=env.start_orn, dome=2.5, max_steps=env.max_steps,
+             **{k: np.array(v) for k, v in rec.items()})
+    finally:
+        np.random.default_rng = orig
+
+
 if __name__ == "__main__":
     gen_pid()
     gen_aero_and_motors()
     gen_aviary()
     gen_envs()
     gen_envs_crash()
+    gen_ma_hover()

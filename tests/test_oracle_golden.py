@@ -198,3 +198,43 @@ def test_env_trajectory(golden_dir, name, env, over):
         seen["complete"] += int(g["info_complete"][k]); seen["reached"] = max(seen["reached"], int(g["info_ntr"][k]))
     assert ri == len(g["reset_obs"])
     print(name, seen)
+
+
+def test_ma_quadx_hover_trajectory(golden_dir):
+    """pz_envs MAQuadXHoverEnv through its dict API (4 agents as 4 independent lanes)."""
+    g = load(golden_dir, "env_ma_quadx_hover")
+    lib = O.lib()
+    n = g["start_pos"].shape[0]
+    Ps = [O.make_params("ma_hover", noise_mode=O.NOISE_INJECT, start_pos=g["start_pos"][i], start_rpy=g["start_orn"][i],
+                        dome=float(g["dome"]), max_steps=int(g["max_steps"])) for i in range(n)]
+    Ls = [O.Lane() for _ in range(n)]
+    D = lib.orc_obs_dim(C.byref(Ps[0]))
+    assert D == 24
+    resets = set(int(k) for k in g["reset_before"])
+    ri = 0
+
+    def do_reset():
+        nonlocal ri
+        for i in range(n):
+            xr = np.ascontiguousarray(g["reset_xi"][ri][:, i])
+            lib.orc_env_reset(C.byref(Ps[i]), C.byref(Ls[i]), i, dp(xr), None)
+            obs = np.frombuffer(Ls[i].obs, dtype=np.float64, count=D)
+            np.testing.assert_allclose(obs, g["reset_obs"][ri][i], atol=TOL)
+        ri += 1
+
+    do_reset()
+    seen_term = 0
+    for k in range(len(g["action"])):
+        if k in resets:
+            do_reset()
+        for i in range(n):
+            a = np.ascontiguousarray(g["action"][k][i])
+            xi = np.ascontiguousarray(g["xi"][k][:, i])
+            lib.orc_env_step(C.byref(Ps[i]), C.byref(Ls[i]), dp(a), dp(xi))
+            if g["alive"][k][i]:
+                obs = np.frombuffer(Ls[i].obs, dtype=np.float64, count=D)
+                np.testing.assert_allclose(obs, g["obs"][k][i], atol=TOL, err_msg=f"step {k} agent {i}")
+                assert abs(Ls[i].reward - g["reward"][k][i]) < 1e-9
+                assert bool(Ls[i].terminated) == bool(g["term"][k][i]) and bool(Ls[i].truncated) == bool(g["trunc"][k][i])
+                seen_term += int(g["term"][k][i])
+    assert seen_term >= 4 and ri == len(g["reset_obs"])

@@ -526,11 +526,16 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
-  const int grid = (ctx->n + 63) / 64;
-#define PF_FAST(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
-  if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
-  else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
-  else PF_FAST(PF_NOISE_OFF);
+  const int lpw = ctx->lpw;
+  const int grid = (ctx->n + lpw - 1) / lpw;
+#define PF_FAST(NZ, L) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, L>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
+  if (lpw == 32) {  // experiment switch PF_LPW=32 (Philox only)
+    PF_FAST(PF_NOISE_PHILOX, 32);
+  } else {
+    if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX, 64);
+    else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT, 64);
+    else PF_FAST(PF_NOISE_OFF, 64);
+  }
 #undef PF_FAST
 }
 template <class VEH, int TASK>

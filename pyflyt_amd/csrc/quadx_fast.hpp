@@ -206,20 +206,20 @@ struct QuadHot {
 // Specialised at compile time on the task and the noise source; requires (checked by
 // quadk_from_params) ticks_per_control == 2, env_step_ratio <= 4, a level spawn at rest and
 // settle_ticks a multiple of 4 and <= 24.
-template <int TASK, int NOISE>
+template <int TASK, int NOISE, int LPW>
 __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
                                                              const uint8_t* __restrict__ mask) {
   constexpr int kMaxD = 13 + 4 + 4 + 12;
   constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
-  __shared__ float tile[64 * kMaxD];
+  __shared__ float tile[LPW * kMaxD];
   __shared__ float sxi[64 * kSettleMax];
   __shared__ int spos[64];
   __shared__ uint32_t sctr[64];
   const int tid = threadIdx.x;
-  const int wave_base = blockIdx.x * 64;
+  const int wave_base = blockIdx.x * LPW;
   const int lane = wave_base + tid;
-  const bool valid = lane < n;
+  const bool valid = (tid < LPW) && (lane < n);
   const size_t li = valid ? (size_t)lane : (size_t)(n - 1);
   const size_t N = (size_t)n;
   const float4* Sin = reinterpret_cast<const float4*>(B.state);
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   auto flush_tile = [&](float* out) {
     lds_sync();
     if (wave_all) {
-      const int rows = min(64, n - wave_base);
+      const int rows = min(LPW, n - wave_base);
       const int total = rows * D;
       float* g = out + (size_t)wave_base * D;
       const int n4 = total >> 2;

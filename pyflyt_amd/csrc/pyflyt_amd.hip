@@ -71,9 +71,12 @@ __device__ __noinline__ void aviary_step_outlined(VEH* V, const pf_params* P, co
 template <class VEH, int TASK, int MODE_T>
 __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_buffers B, const int n,
                                                     const uint64_t lane0, const int op, const uint8_t* mask,
-                                                    const float4* __restrict__ tmpl) {
+                                                    const float4* __restrict__ tmpl, const pf_params* __restrict__ Pdev) {
   __shared__ float tile[kWave * kMaxObs];
+  __shared__ float ktab[VEH::TABLE_FLOATS];
   const int tid = threadIdx.x;
+  VEH::fill_table(ktab, Pdev, tid);
+  __syncthreads();
   const int wave_base = blockIdx.x * kWave;
   const int lane = wave_base + tid;
   const bool valid = lane < n;
@@ -85,6 +88,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   constexpr bool kSide = (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER);
 
   VEH V;
+  V.bind(ktab);
   SideBlock tg;
   float new_dist;
   int4 ints;
@@ -342,8 +346,15 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
       if (same) {
         begin_reset();
         settling = true;
-        if (tmpl == nullptr)
-          for (int s = 0; s < P.settle_steps; ++s) aviary_step_outlined<VEH, MODE_T>(&V, &P, sp, &nz, s * P.ticks_per_control);
+        if (tmpl == nullptr) {
+          // through copies: handing &V itself to an out-of-line call would pin the whole vehicle
+          // state in scratch memory for the entire kernel (measured: 1.9 KB/lane, 2x slower)
+          VEH Vc = V;
+          Noise nc = nz;
+          float spc[6] = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]};
+          for (int s = 0; s < P.settle_steps; ++s) aviary_step_outlined<VEH, MODE_T>(&Vc, Pdev, spc, &nc, s * P.ticks_per_control);
+          V = Vc;
+        }
       }
     }
   }
@@ -372,9 +383,13 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
 
 // Settled spawn state for contexts whose settle phase is lane-independent (see env_kernel).
 template <class VEH>
-__global__ void settle_template_kernel(const pf_params P, float4* tmpl) {
+__global__ void settle_template_kernel(const pf_params P, float4* tmpl, const pf_params* __restrict__ Pdev) {
+  __shared__ float ktab[VEH::TABLE_FLOATS];
+  VEH::fill_table(ktab, Pdev, threadIdx.x);
+  __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   VEH V;
+  V.bind(ktab);
   float sp[6] = {0, 0, 0, 0, 0, 0};
   V.reset(P, nullptr, sp);
   V.set_mode(P.flight_mode, sp);
@@ -433,11 +448,16 @@ __global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params 
 
 template <class VEH>
 __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, const pf_buffers B, const int n,
-                                                            const uint64_t lane0, const int n_steps) {
+                                                            const uint64_t lane0, const int n_steps,
+                                                            const pf_params* __restrict__ Pdev) {
+  __shared__ float ktab[VEH::TABLE_FLOATS];
+  VEH::fill_table(ktab, Pdev, threadIdx.x);
+  __syncthreads();
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   const size_t li = lane, N = n;
   VEH V;
+  V.bind(ktab);
   float nd;
   int4 ints;
   const int mode = P.flight_mode;
@@ -542,9 +562,9 @@ template <class VEH, int TASK>
 static void launch_env_t(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
   if (ctx->P.vehicle == PF_QUADX && ctx->P.flight_mode == 0)
-    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, 0>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl);
+    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, 0>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl, ctx->P_dev);
   else
-    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, pf::kRuntimeMode>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl);
+    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, pf::kRuntimeMode>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl, ctx->P_dev);
 }
 extern "C" {
 
@@ -577,21 +597,22 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
   c->P_dev = nullptr; c->tmpl = nullptr; c->lpw = 64; c->wps = 2; c->n_simd = 1024;
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
-  if (c->fast) {
+  {  // device copy of the parameter block (LDS constant tables, the out-of-line floor test)
     int cur = -1;
-    hipGetDevice(&cur);
-    hipSetDevice(device);
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_simd = prop.multiProcessorCount * 4;
     hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
     if (e == hipSuccess) e = hipMemcpy(c->P_dev, &P, sizeof(pf_params), hipMemcpyHostToDevice);
-    if (cur >= 0) hipSetDevice(cur);
+    if (cur >= 0) (void)hipSetDevice(cur);
     if (e != hipSuccess) { delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
+  }
+  if (c->fast) {
     // (measured on MI355X, profiles/: the kernel is VALU-issue bound, so full 64-lane waves win at
     // every batch size; the 32-lane variant is kept for experiments via PF_LPW=32)
     c->lpw = 64;
     if (const char* o = getenv("PF_LPW")) { int v = atoi(o); if (v == 64 || v == 32) c->lpw = v; }
-    if (const char* o = getenv("PF_WPS")) { int v = atoi(o); if (v == 2 || v == 4) c->wps = v; }
   }
   if (!c->fast && (P.task == PF_TASK_HOVER || P.task == PF_TASK_WAYPOINTS) &&
       (P.vehicle == PF_FIXEDWING || P.noise_mode == PF_NOISE_OFF)) {
@@ -604,8 +625,8 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     hipError_t e = hipMalloc((void**)&c->tmpl, sizeof(float4) * groups);
     if (e == hipSuccess) e = hipMemset(c->tmpl, 0, sizeof(float4) * groups);
     if (e == hipSuccess) {
-      if (P.vehicle == PF_QUADX) hipLaunchKernelGGL(pf::settle_template_kernel<pf::QuadX>, dim3(1), dim3(64), 0, 0, P, c->tmpl);
-      else hipLaunchKernelGGL(pf::settle_template_kernel<pf::Fixedwing>, dim3(1), dim3(64), 0, 0, P, c->tmpl);
+      if (P.vehicle == PF_QUADX) hipLaunchKernelGGL(pf::settle_template_kernel<pf::QuadX>, dim3(1), dim3(64), 0, 0, P, c->tmpl, c->P_dev);
+      else hipLaunchKernelGGL(pf::settle_template_kernel<pf::Fixedwing>, dim3(1), dim3(64), 0, 0, P, c->tmpl, c->P_dev);
       e = hipDeviceSynchronize();
     }
     if (cur >= 0) hipSetDevice(cur);
@@ -706,9 +727,9 @@ int pf_aviary_step(pf_ctx* ctx, const pf_buffers* b, int n_steps, void* stream) 
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
   hipStream_t s = (hipStream_t)stream;
   if (ctx->P.vehicle == PF_QUADX)
-    hipLaunchKernelGGL(pf::aviary_step_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps);
+    hipLaunchKernelGGL(pf::aviary_step_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps, ctx->P_dev);
   else
-    hipLaunchKernelGGL(pf::aviary_step_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps);
+    hipLaunchKernelGGL(pf::aviary_step_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps, ctx->P_dev);
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;
 }

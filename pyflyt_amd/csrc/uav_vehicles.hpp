@@ -125,6 +125,9 @@ constexpr int kRuntimeMode = 100;
 
 struct QuadX {
   static constexpr int GROUPS = 16, G_INT = 6, G_TGT = 12, AUX = 4, SP = 4;  // g15: MA-hover past action
+  static constexpr int TABLE_FLOATS = 4;  // no LDS constant table
+  static PF_DEV void fill_table(float*, const pf_params*, int) {}
+  PF_DEV void bind(const float*) {}
   Body b;
   float thr[4];
   float pwm[4];
@@ -313,6 +316,32 @@ struct QuadX {
 // Fixedwing: drones/fixedwing.py + abstractions/lifting_surfaces.py
 struct Fixedwing {
   static constexpr int GROUPS = 9, G_INT = 5, G_TGT = 6, AUX = 6, SP = 6;
+  // The five lifting surfaces carry 26 constants each -- far more than fit in SGPRs next to the
+  // rest of the kernel (the first version spilled 1.9 KB/lane to scratch). They live in an LDS table
+  // (32-float rows, one per surface) filled once per workgroup; tick() walks the surfaces in a real
+  // loop and fetches one row (7 broadcast ds_read_b128) per iteration.
+  static constexpr int TABLE_STRIDE = 32, TABLE_FLOATS = PF_MAX_SURF * TABLE_STRIDE;
+  static PF_DEV void fill_table(float* tab, const pf_params* Pdev, int tid) {
+    constexpr int kF = (int)(sizeof(pf_surface) / sizeof(float));
+    static_assert(kF == 26, "pf_surface layout changed: update Fixedwing::row()");
+    const float* src = reinterpret_cast<const float*>(Pdev->surf);
+    for (int i = tid; i < PF_MAX_SURF * kF; i += 64) tab[(i / kF) * TABLE_STRIDE + (i % kF)] = src[i];
+  }
+  const float* sk;
+  PF_DEV void bind(const float* tab) { sk = tab; }
+  static PF_DEV pf_surface row(const float* r) {
+    const float4* c = reinterpret_cast<const float4*>(r);
+    const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6];
+    pf_surface S;
+    S.r[0] = c0.x; S.r[1] = c0.y; S.r[2] = c0.z; S.lift[0] = c0.w;
+    S.lift[1] = c1.x; S.lift[2] = c1.y; S.drag[0] = c1.z; S.drag[1] = c1.w;
+    S.drag[2] = c2.x; S.torque[0] = c2.y; S.torque[1] = c2.z; S.torque[2] = c2.w;
+    S.Cl_alpha_3D = c3.x; S.inv_Cl_alpha_3D = c3.y; S.aero_tau_eta = c3.z; S.flap_to_chord = c3.w;
+    S.inv_pi_aspect = c4.x; S.exp_term = c4.y; S.alpha_0_base = c4.z; S.alpha_stall_P_base = c4.w;
+    S.alpha_stall_N_base = c5.x; S.Cd_0 = c5.y; S.deflection_limit_rad = c5.z; S.dt_over_tau = c5.w;
+    S.half_rho_area = c6.x; S.chord = c6.y;
+    return S;
+  }
   Body b;
   float act[5];
   float thr;
@@ -436,14 +465,19 @@ struct Fixedwing {
   }
   PF_DEV void tick(const pf_params& P, float xi) {
     v3 F{0.0f, 0.0f, 0.0f}, tau{0.0f, 0.0f, 0.0f};
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < PF_MAX_SURF; ++i) {
-      const pf_surface& S = P.surf[i];
-      act[i] = fmaf(S.dt_over_tau, cmd[i] - act[i], act[i]);  // lifting_surfaces.py:277
+      const pf_surface S = row(sk + i * TABLE_STRIDE);
+      // act[i] / cmd[i] by selects: a dynamically indexed register array would go to scratch
+      float ai = i == 0 ? act[0] : (i == 1 ? act[1] : (i == 2 ? act[2] : (i == 3 ? act[3] : act[4])));
+      const float ci = i == 0 ? cmd[0] : (i == 1 ? cmd[1] : (i == 2 ? cmd[2] : (i == 3 ? cmd[3] : cmd[4])));
+      ai = fmaf(S.dt_over_tau, ci - ai, ai);  // lifting_surfaces.py:277
+      act[0] = i == 0 ? ai : act[0]; act[1] = i == 1 ? ai : act[1]; act[2] = i == 2 ? ai : act[2];
+      act[3] = i == 3 ? ai : act[3]; act[4] = i == 4 ? ai : act[4];
       v3 r{S.r[0], S.r[1], S.r[2]};
       v3 vloc = b.vb + cross(b.wb, r);  // lifting_surfaces.py:73-110
       v3 f, t;
-      surface(S, vloc, act[i], f, t);
+      surface(S, vloc, ai, f, t);
       F = F + f;
       tau = tau + cross(r, f) + t;
     }

@@ -84,8 +84,17 @@ def cpu_baseline(env, noise, seconds):
         k += 1
     dt = time.perf_counter() - t0
     cores = O.lib().orc_num_threads()
+    # BASELINE.md B1 (config 1 plumbing): one env, 1000 random-action steps with reset on term/trunc, one core
+    one = O.OracleBatch(P, 1)
+    one.reset()
+    t1 = time.perf_counter()
+    for j in range(1000):
+        one.step(acts[j % 16][:1], autoreset=1)
+    dt1 = time.perf_counter() - t1
     return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"fp64 C restatement (oracle/uav_oracle.c), {env}, batch {n}, {k} steps in {dt:.1f} s, OpenMP over lanes"}
+            "sample": f"fp64 C restatement (oracle/uav_oracle.c), {env}, batch {n}, {k} steps in {dt:.1f} s, OpenMP over lanes",
+            "single_env_1core": {"value": 1000 / dt1, "unit": "env-steps/s", "cores": 1,
+                                 "sample": "1 env, 1000 steps, NEXT_STEP auto-reset, incl. ctypes call overhead per step"}}
 
 
 def main():

@@ -153,3 +153,62 @@ def test_shard_invariance():
             assert torch.equal(rf[j], torch.cat([rl[j], rh[j]]))
     for e in (full, lo, hi):
         e.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 1000])
+@pytest.mark.parametrize("env_id", IDS)
+def test_ragged_batch_sizes_match_oracle(env_id, n):
+    """Batches that are not a multiple of the 64-lane wavefront (incl. a single env): the tail wave's
+    masked lanes and the bounded tile flush must not disturb the real lanes."""
+    from oracle import oracle as O
+    from pyflyt_amd.gym_envs import make_vec
+
+    name = {"PyFlyt/QuadX-Hover-v4": "hover", "PyFlyt/QuadX-Waypoints-v4": "quadx_waypoints",
+            "PyFlyt/Fixedwing-Waypoints-v4": "fixedwing_waypoints"}[env_id]
+    env = make_vec(env_id, n, seed=21, flatten=False) if "Waypoints" in env_id else make_vec(env_id, n, seed=21)
+    orc = O.OracleBatch(O.make_params(name, noise_mode=O.NOISE_PHILOX, seed=21), n)
+    og = flat(env.reset(seed=21)[0]).cpu().numpy()
+    assert np.abs(og - orc.reset()).max() < 1e-3
+    for k in range(12):
+        a = env.sample_actions(k)
+        o, r, t, u, _ = env.step(a)
+        ro, rr, rt, ru, _ = orc.step(a.cpu().numpy(), autoreset=1)
+        assert flat(o).shape[0] == n and r.shape == (n,)
+        scale = np.maximum(1.0, np.abs(ro))
+        assert (np.abs(flat(o).cpu().numpy() - ro) / scale).max() < 1e-3
+        assert (t.cpu().numpy() == rt).all() and (u.cpu().numpy() == ru).all()
+    env.close()
+
+
+def test_argument_errors():
+    from pyflyt_amd import PyFlytAmdError, build_params
+    from pyflyt_amd.engine import BatchEngine
+    from pyflyt_amd.gym_envs import QuadXHoverVecEnv, make_vec
+
+    env = QuadXHoverVecEnv(64, seed=0)
+    with pytest.raises(RuntimeError):
+        env.step(env.sample_actions(0))  # step before reset
+    env.reset()
+    with pytest.raises(ValueError):
+        env.engine.env_step(torch.zeros(64, 3, device=env.device))  # wrong action shape
+    with pytest.raises(ValueError):
+        env.engine.env_step(torch.zeros(64, 4, device=env.device, dtype=torch.float64))  # wrong dtype
+    with pytest.raises(KeyError):
+        make_vec("PyFlyt/Rocket-Landing-v4", 4)
+    with pytest.raises(PyFlytAmdError):
+        BatchEngine(build_params("quadx", "hover"), 0)  # n_lanes <= 0 is rejected by pf_ctx_create
+    env.close()
+
+
+def test_large_batch_runs():
+    """A million environments on one GPU (240 MB of state): finite outputs, all lanes advance."""
+    from pyflyt_amd.gym_envs import QuadXHoverVecEnv
+
+    n = 1 << 20
+    env = QuadXHoverVecEnv(n, seed=0)
+    env.reset(seed=0)
+    for k in range(3):
+        obs, rew, term, trunc, info = env.step(env.sample_actions(k))
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert int(env.engine.ints()[:, 2].min()) == 4  # 1 reset event + 3 step events on every lane
+    env.close()

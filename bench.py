@@ -111,7 +111,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PF_BENCH_FORCE_DIST") == "1":  # (the env switch exercises the RCCL path on a 1-GPU box)
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=device)
@@ -192,7 +192,7 @@ def main():
                        "launch": "hipGraph" if graph is not None else "eager", "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "pf::env_kernel", "algorithmic_bytes_per_launch": algo,
+                         "kernel": "pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::env_kernel<Fixedwing>", "algorithmic_bytes_per_launch": algo,
                          "launch_us": per_launch_s * 1e6},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")

@@ -114,10 +114,9 @@ struct QuadHot {
   bool contact_now, contact_step;
 
   PF_DEV void derive() {
-    // rot_from_quat with 2/|q|^2 through v_rcp
-    float d = fmaf(q.x, q.x, fmaf(q.y, q.y, fmaf(q.z, q.z, q.w * q.w)));
-    float s = 2.0f * frcp(d);
-    float xs = q.x * s, ys = q.y * s, zs = q.z * s;
+    // btMatrix3x3::setRotation scales by 2/|q|^2; q leaves quat_integrate()/the spawn normalised to
+    // 1 ulp, so the factor is 2 to fp32 rounding and the reciprocal (a quarter-rate op) is skipped
+    float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
     float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
     float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
     float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
@@ -184,7 +183,8 @@ struct QuadHot {
     }
     // Newton-Euler in the body frame, diagonal inertia, COM at the base origin
     v3 h{K.I[0] * wb.x, K.I[1] * wb.y, K.I[2] * wb.z};
-    v3 g = K.use_gyro * cross(wb, h);
+    v3 g = cross(wb, h);
+    if (K.use_gyro == 0.0f) g = v3{0.f, 0.f, 0.f};  // uniform branch
     v3 wdb{K.iI[0] * (tau.x - g.x), K.iI[1] * (tau.y - g.y), K.iI[2] * (tau.z - g.z)};
     v3 wd = mul(R, wdb);
     v3 a = mul(R, K.inv_mass * F);

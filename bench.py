@@ -192,7 +192,7 @@ def main():
                        "launch": "hipGraph" if graph is not None else "eager", "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::env_kernel<Fixedwing>", "algorithmic_bytes_per_launch": algo,
+                         "kernel": "pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel", "algorithmic_bytes_per_launch": algo,
                          "launch_us": per_launch_s * 1e6},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")

@@ -1,0 +1,567 @@
+// fixedwing_fast.hpp -- the specialised kernel for BASELINE.json's config[3]: Fixedwing, flight mode 0
+// (fixedwing.py:229-259), Waypoints task (fixedwing_waypoints_env.py), the reference airframe's
+// structure (fixedwing.py:80-168, fixedwing.urdf).
+//
+// The generic env_kernel<Fixedwing> spent 13 700 VALU instructions per wave per env step (8 physics
+// ticks; rocprofv3 PMC, profiles/README.md) -- issue-bound like every kernel here, so the lever is the
+// instruction count. What this kernel folds away:
+//   * structure the reference hard-codes is compile-time: every surface's forward unit is +x, the lift
+//     unit is +z (ailerons, h-tail, main wing) or +y (v-tail), so the dot products, the force
+//     re-assembly and r x f lose their zero terms; the control-surface mixing [0,0,1,2,1,3] x
+//     [+,-,+,-,-,+] (fixedwing.py:143-144) is applied once per env step; the motor sits at the base
+//     origin and pushes along +x;
+//   * per-surface constants are pre-combined on the host (FwSurf: the flap-shifted zero-lift and stall
+//     angles are affine in the deflection) and fetched per surface with scalar loads -- 16 SGPRs live
+//     for one surface at a time instead of 130 constants at once (the first generic version spilled
+//     1.9 KB/lane, the second staged them through an LDS table);
+//   * the post-stall branches (lifting_surfaces.py:409-448) run only in waves where some lane is
+//     stalled (wave-uniform test), side-symmetric so one interpolation serves both signs;
+//   * one gyroscopic inertia (I_pa + I_own) instead of two products, rotation scale 2 for the unit
+//     quaternion, Euler angles only in the epilogue;
+//   * resets copy the context's settled spawn state (the settle throttle command is 0, so the motor
+//     noise scales nothing: pyflyt_amd.hip, settle_template_kernel).
+#pragma once
+#include "../../include/pyflyt_amd.h"
+#include "uav_device.hpp"
+
+namespace pf {
+
+struct FwSurf {  // 16 floats, one s_load_dwordx16 per surface per tick
+  float rx, ry, rz;        // link COM in the base frame (fixedwing.urdf:58,84,110,136,162)
+  float cl3d;              // Cl_alpha_3D (lifting_surfaces.py:228-232)
+  float a0b, aPb, aNb;     // alpha_0 / alpha_stall_P / alpha_stall_N bases [rad]
+  float tau_eta;           // a0 = a0b - tau_eta * defl                       (:386-394)
+  float c1;                // aP = aPb + c1 * defl, aN = aNb + c1 * defl, c1 = (flap_to_chord - 1) * tau_eta
+  float ipa;               // 1 / (pi * aspect)
+  float exp_term, cd0;     // :436, :402
+  float defl_lim;          // deflection limit [rad]
+  float dt_tau;            // dt / tau of the actuator (:277)
+  float hra;               // 0.5 * rho * area
+  float chord;
+};
+
+struct FwBody {  // 32 floats behind the five FwSurf rows, two s_load_dwordx16 per tick
+  float dt, half_dt, gravity_z, vmax, inv_mass;
+  float H[6], iI[6];       // gyroscopic inertia I_pa (+ I_own if use_gyro) and inverse inertia, symmetric 6
+  float com[3];
+  float bound_radius;
+  float m_a, m_noise, fmax, tmax;   // the single motor (fixedwing.py:147-168)
+  float pad[7];
+};
+struct FwTable {
+  FwSurf surf[5];
+  FwBody body;
+};
+static_assert(sizeof(FwSurf) == 64 && sizeof(FwBody) == 128, "constant table rows are whole s_load_dwordx16 units");
+
+struct FwK {  // what stays in kernel-argument SGPRs for the whole kernel: env constants only
+  float dome2, goal_reach, min_height, dome09m1, wp_dist_reward;
+  int32_t task_sparse, angle_repr, num_targets, max_steps, env_step_ratio, throttle_remap;
+  int32_t noise_mode, autoreset;
+  uint32_t seed_lo, seed_hi;
+};
+
+// Fill FwK / FwTable from the ABI struct; false -> the configuration needs the generic kernel.
+inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
+  FwSurf* S = T.surf;
+  FwBody& Bd = T.body;
+  if (P.vehicle != PF_FIXEDWING || P.flight_mode != 0 || P.task != PF_TASK_WAYPOINTS) return false;
+  if (P.n_surf != 5 || P.n_motors != 1 || P.ticks_per_control != 2) return false;
+  if (P.env_step_ratio < 1 || P.env_step_ratio > 4 || P.num_targets < 1 || P.num_targets > 4) return false;
+  const int ids[6] = {0, 0, 1, 2, 1, 3};
+  const float sg[6] = {1.f, -1.f, 1.f, -1.f, -1.f, 1.f};
+  for (int k = 0; k < 6; ++k)
+    if (P.assist_ids[k] != ids[k] || P.assist_signs[k] != sg[k]) return false;
+  for (int i = 0; i < 5; ++i) {
+    const pf_surface& s = P.surf[i];
+    const float lz = (i == 3) ? 0.f : 1.f, ly = (i == 3) ? 1.f : 0.f;
+    if (s.drag[0] != 1.f || s.drag[1] != 0.f || s.drag[2] != 0.f) return false;
+    if (s.lift[0] != 0.f || s.lift[1] != ly || s.lift[2] != lz) return false;
+    // torque unit = lift x forward (lifting_surfaces.py:236)
+    if (s.torque[0] != 0.f || s.torque[1] != lz || s.torque[2] != -ly) return false;
+  }
+  if (P.motor_r[0][0] != 0.f || P.motor_r[0][1] != 0.f || P.motor_r[0][2] != 0.f) return false;
+  if (P.thrust_unit[0][0] != 1.f || P.thrust_unit[0][1] != 0.f || P.thrust_unit[0][2] != 0.f) return false;
+  if (P.wp_yaw_penalty != 0.f) return false;
+  Bd.dt = P.dt; Bd.half_dt = 0.5f * P.dt; Bd.gravity_z = P.gravity_z; Bd.vmax = P.max_coord_vel; Bd.inv_mass = P.inv_mass;
+  for (int k = 0; k < 6; ++k) { Bd.H[k] = P.I_pa[k] + (P.use_gyro_term ? P.I_own[k] : 0.f); Bd.iI[k] = P.I_inv[k]; }
+  for (int k = 0; k < 3; ++k) Bd.com[k] = P.has_com_offset ? P.com[k] : 0.f;
+  Bd.bound_radius = P.bound_radius;
+  Bd.m_a = P.motor_dt_over_tau[0]; Bd.m_noise = P.motor_noise[0]; Bd.fmax = P.motor_fmax[0]; Bd.tmax = P.motor_tmax[0];
+  for (int k = 0; k < 7; ++k) Bd.pad[k] = 0.f;
+  K.dome2 = P.dome * P.dome; K.goal_reach = P.goal_reach_distance; K.min_height = P.min_height;
+  K.dome09m1 = P.dome * 0.9f - 1.0f; K.wp_dist_reward = P.wp_dist_reward;
+  K.task_sparse = P.sparse_reward; K.angle_repr = P.angle_repr; K.num_targets = P.num_targets; K.max_steps = P.max_steps;
+  K.env_step_ratio = P.env_step_ratio; K.throttle_remap = P.throttle_remap;
+  K.noise_mode = P.noise_mode; K.autoreset = P.autoreset;
+  K.seed_lo = (uint32_t)P.seed; K.seed_hi = (uint32_t)(P.seed >> 32);
+  for (int i = 0; i < 5; ++i) {
+    const pf_surface& s = P.surf[i];
+    FwSurf& o = S[i];
+    o.rx = s.r[0]; o.ry = s.r[1]; o.rz = s.r[2];
+    o.cl3d = s.Cl_alpha_3D; o.a0b = s.alpha_0_base; o.aPb = s.alpha_stall_P_base; o.aNb = s.alpha_stall_N_base;
+    o.tau_eta = s.aero_tau_eta; o.c1 = (s.flap_to_chord - 1.0f) * s.aero_tau_eta;
+    o.ipa = s.inv_pi_aspect; o.exp_term = s.exp_term; o.cd0 = s.Cd_0; o.defl_lim = s.deflection_limit_rad;
+    o.dt_tau = s.dt_over_tau; o.hra = s.half_rho_area; o.chord = s.chord;
+  }
+  return true;
+}
+
+// 15-axis box tests of the airframe's collision boxes against the ground box; out of line, runs only
+// in waves that have a lane within one bounding radius of the floor.
+__device__ __noinline__ bool fw_floor_contact(float px, float py, float pz, m3 R, const pf_params* P) {
+  const float hb[3] = {P->plane_half_xy, P->plane_half_xy, P->plane_half_z};
+  const v3 cb{0.0f, 0.0f, -P->plane_half_z};
+  bool hit = false;
+  for (int k = 0; k < P->n_boxes; ++k) {
+    v3 c = v3{px, py, pz} + mul(R, v3{P->boxes[k].c[0], P->boxes[k].c[1], P->boxes[k].c[2]});
+    hit |= box_overlaps_aabb(c, R, P->boxes[k].h, cb, hb);
+  }
+  return hit;
+}
+
+typedef const FwSurf __attribute__((address_space(4))) * fw_surf_cptr;
+typedef const FwBody __attribute__((address_space(4))) * fw_body_cptr;
+PF_DEV FwBody fw_load_body(fw_body_cptr p) {
+  FwBody b;
+  b.dt = p->dt; b.half_dt = p->half_dt; b.gravity_z = p->gravity_z; b.vmax = p->vmax; b.inv_mass = p->inv_mass;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { b.H[k] = p->H[k]; b.iI[k] = p->iI[k]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) b.com[k] = p->com[k];
+  b.bound_radius = p->bound_radius; b.m_a = p->m_a; b.m_noise = p->m_noise; b.fmax = p->fmax; b.tmax = p->tmax;
+  return b;
+}
+PF_DEV FwSurf fw_load_surf(fw_surf_cptr p) {  // uniform address in the constant address space -> s_load_dwordx16
+  FwSurf S;
+  S.rx = p->rx; S.ry = p->ry; S.rz = p->rz; S.cl3d = p->cl3d; S.a0b = p->a0b; S.aPb = p->aPb; S.aNb = p->aNb;
+  S.tau_eta = p->tau_eta; S.c1 = p->c1; S.ipa = p->ipa; S.exp_term = p->exp_term; S.cd0 = p->cd0;
+  S.defl_lim = p->defl_lim; S.dt_tau = p->dt_tau; S.hra = p->hra; S.chord = p->chord;
+  return S;
+}
+
+struct FwHot {
+  v3 p; quat q; v3 v, w;
+  float act[5];
+  float thr;
+  float cmd[6];
+  m3 R; v3 wb, vb;
+  bool contact_now, contact_step;
+
+  PF_DEV void derive() {  // unit quaternion (quat_integrate / the settled template): scale 2
+    float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
+    float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
+    float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+    float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+    R = m3{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+    wb = mulT(R, w);
+    vb = mulT(R, v);
+  }
+  // One lifting surface (lifting_surfaces.py:73-110 local velocity, :266-498 coefficients and forces).
+  // LIFT_Y: the vertical tail (lift unit +y, torque unit -z); otherwise lift +z, torque +y.
+  // `a`: this surface's actuation after the first-order lag. Accumulates into F, tau (base frame,
+  // torque about the base origin).
+  template <bool LIFT_Y>
+  PF_DEV void surface(const FwSurf S, const float a, v3& F, v3& tau) const {
+    const float vx = vb.x + (wb.y * S.rz - wb.z * S.ry);
+    const float vy = vb.y + (wb.z * S.rx - wb.x * S.rz);
+    const float vz = vb.z + (wb.x * S.ry - wb.y * S.rx);
+    const float V2 = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
+    const float la = LIFT_Y ? vy : vz, fa = vx;
+    const float h2 = fmaf(la, la, fa * fa);
+    const float ih = frsq(h2);
+    const bool still = !(h2 > 0.0f);
+    const float ca = still ? 1.0f : fa * ih, sa = still ? 0.0f : -la * ih;
+    const float alpha = fast_atan2(-la, fa);  // :342-345
+    const float defl = a * S.defl_lim;        // :386
+    const float a0 = fmaf(-S.tau_eta, defl, S.a0b);
+    const float aP = fmaf(S.c1, defl, S.aPb), aN = fmaf(S.c1, defl, S.aNb);
+    const bool linear = (aN < alpha) && (alpha < aP);
+    const float Cl_lin = S.cl3d * (alpha - a0);
+    float ai = Cl_lin * S.ipa;  // :397-399
+    const bool any_stall = __any(!linear);
+    if (any_stall) {  // :409-425, two-point np.interp between the stall angle and +-pi/2
+      const bool pos = alpha > 0.0f;
+      const float as = pos ? aP : aN;
+      const float ai_stall = S.cl3d * (as - a0) * S.ipa;
+      const float edge = pos ? 0.5f * kPi : -0.5f * kPi;
+      // pos: alpha<=aP -> ai_stall, alpha>=pi/2 -> 0, else ai_stall*(1-(alpha-aP)/(pi/2-aP))
+      // neg: alpha<=-pi/2 -> 0, alpha>=aN -> ai_stall, else ai_stall*(alpha+pi/2)/(aN+pi/2)
+      const float tt = (edge - alpha) * frcp(edge - as);
+      const float ais = ai_stall * med3(tt, 0.0f, 1.0f);
+      ai = linear ? ai : ais;
+    }
+    const float x = a0 + ai;
+    const float ae = alpha - x;
+    float sx, cx;
+    sincos_small(x, sx, cx);
+    const float se = sa * cx - ca * sx, ce = fmaf(ca, cx, sa * sx);
+    // :397-406
+    float CT = S.cd0 * ce;
+    float CN = (Cl_lin + CT * se) * frcp(ce);
+    float Cl = Cl_lin;
+    float Cd = fmaf(CN, se, CT * ce);
+    float CM = -CN * (0.25f - 0.175f * (1.0f - (2.0f / kPi) * ae));
+    if (any_stall) {  // :427-448
+      const float Cd90 = fmaf(-4.26e-2f, defl * defl, fmaf(2.1e-1f, defl, 1.98f));
+      const float CNs = Cd90 * se * (frcp(fmaf(0.44f, __builtin_fabsf(se), 0.56f)) - S.exp_term);
+      const float CTs = 0.5f * S.cd0 * ce;
+      const float Cls = CNs * ce - CTs * se;
+      const float Cds = fmaf(CNs, se, CTs * ce);
+      const float CMs = -CNs * (0.25f - 0.175f * (1.0f - (2.0f / kPi) * __builtin_fabsf(ae)));
+      Cl = linear ? Cl : Cls; Cd = linear ? Cd : Cds; CM = linear ? CM : CMs;
+    }
+    // :485-498
+    const float QA = S.hra * V2;
+    const float L = Cl * QA, D = Cd * QA;
+    const float fn = fmaf(L, ca, D * sa), fp = L * sa - D * ca;  // along the lift unit / along +x
+    const float tm = QA * CM * S.chord;
+    F.x += fp;
+    if (LIFT_Y) {
+      F.y += fn;
+      tau.x -= S.rz * fn;
+      tau.y += S.rz * fp;
+      tau.z += fmaf(S.rx, fn, -S.ry * fp) - tm;
+    } else {
+      F.z += fn;
+      tau.x += S.ry * fn;
+      tau.y += fmaf(S.rz, fp, -S.rx * fn) + tm;
+      tau.z -= S.ry * fp;
+    }
+  }
+  // one physics tick: update_physics (fixedwing.py:261-264) + stepSimulation + update_state (:266-291)
+  PF_DEV void tick(fw_surf_cptr surf, const float xi, const pf_params* Pfull) {
+    v3 F{0.f, 0.f, 0.f}, tau{0.f, 0.f, 0.f};
+    // An opaque zero offset per tick keeps the per-surface constant loads inside the tick (16 SGPRs at
+    // a time, see the file header) instead of hoisted and spilled; the scheduling barriers keep the
+    // five surface bodies from being interleaved (which cost 255 VGPRs and scratch).
+    uint32_t zoff;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+    fw_surf_cptr sk = surf + zoff;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const FwSurf S = fw_load_surf(sk + i);
+      act[i] = fmaf(S.dt_tau, cmd[i] - act[i], act[i]);  // lifting_surfaces.py:277
+      if (i == 3) surface<true>(S, act[i], F, tau);
+      else surface<false>(S, act[i], F, tau);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const FwBody K = fw_load_body((fw_body_cptr)(sk + 5));
+    {  // motor (motors.py:110-195), at the base origin along +x
+      float t = fmaf(K.m_a, cmd[5] - thr, thr);
+      t = fmaf(xi * t, K.m_noise, t);
+      thr = t;
+      const float k = t * __builtin_fabsf(t);
+      F.x = fmaf(k, K.fmax, F.x);
+      tau.x = fmaf(k, K.tmax, tau.x);
+    }
+    // collision detection at the pre-integration pose
+    const bool near = (p.z - K.bound_radius) <= 0.0f;
+    contact_now = false;
+    if (__any(near)) {
+      if (near) contact_now = fw_floor_contact(p.x, p.y, p.z, R, Pfull);
+    }
+    // free-base multibody tick, composite of point masses: COM offset, full symmetric inertia
+    const v3 com{K.com[0], K.com[1], K.com[2]};
+    tau = tau - cross(com, F);
+    const v3 h = symmul(K.H, wb);
+    const v3 wdb = symmul(K.iI, tau - cross(wb, h));
+    const v3 wd = mul(R, wdb);
+    v3 a = K.inv_mass * mul(R, F);
+    a.z += K.gravity_z;
+    const v3 cw = mul(R, com);
+    a = a - cross(wd, cw) - cross(w, cross(w, cw));
+    w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
+    v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
+    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z)};
+    q = quat_integrate(q, w, K.half_dt);
+    derive();
+    contact_step |= contact_now;
+  }
+};
+
+// Same flat shape as quadx_m0_env_kernel (quadx_fast.hpp): prologue, one loop over the env step's
+// Aviary steps with a single per-lane predicate, epilogue. State groups: g0 p+dist, g1 q, g2 v+w.x,
+// g3 w.yz+act0,1, g4 act2..4+throttle, g5 ints, g6..8 the 4x3 targets (Fixedwing::load/store layout).
+template <int NOISE>
+__global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, const FwTable* table_g, const pf_buffers B,
+                                                                 const pf_params* __restrict__ Pfull, const float4* __restrict__ tmpl,
+                                                                 const int n, const uint64_t lane0, const int op,
+                                                                 const uint8_t* __restrict__ mask) {
+  constexpr int kMaxD = 13 + 4 + 6 + 12;
+  __shared__ float tile[64 * kMaxD];
+  const int tid = threadIdx.x;
+  const int wave_base = blockIdx.x * 64;
+  const int lane = wave_base + tid;
+  const bool valid = lane < n;
+  const size_t li = valid ? (size_t)lane : (size_t)(n - 1);
+  const size_t N = (size_t)n;
+  const float4* Sin = reinterpret_cast<const float4*>(B.state);
+  float4* Sout = reinterpret_cast<float4*>(B.state);
+  fw_surf_cptr surf = (fw_surf_cptr)(uintptr_t)table_g;
+
+  FwHot V;
+  float tgt[4][3];
+  float new_dist, old_dist;
+  int step_count, flags, n_left;
+  uint32_t rng_ctr;
+  f8 zn;
+  {
+    float4 gi = Sin[5 * N + li];
+    float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li];
+    rng_ctr = (uint32_t)__float_as_int(gi.z);
+    if (NOISE == PF_NOISE_PHILOX) {
+      if (op == 0) zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
+    }
+    V.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
+    V.q = quat{g1.x, g1.y, g1.z, g1.w};
+    V.v = v3{g2.x, g2.y, g2.z};
+    V.w = v3{g2.w, g3.x, g3.y};
+    V.act[0] = g3.z; V.act[1] = g3.w; V.act[2] = g4.x; V.act[3] = g4.y; V.act[4] = g4.z; V.thr = g4.w;
+    step_count = __float_as_int(gi.x); flags = __float_as_int(gi.y); n_left = __float_as_int(gi.w);
+    float4 a = Sin[6 * N + li], b = Sin[7 * N + li], c = Sin[8 * N + li];
+    tgt[0][0] = a.x; tgt[0][1] = a.y; tgt[0][2] = a.z; tgt[1][0] = a.w;
+    tgt[1][1] = b.x; tgt[1][2] = b.y; tgt[2][0] = b.z; tgt[2][1] = b.w;
+    tgt[2][2] = c.x; tgt[3][0] = c.y; tgt[3][1] = c.z; tgt[3][2] = c.w;
+  }
+  old_dist = new_dist;
+  V.contact_now = (flags & PF_F_CONTACT) != 0;
+  V.contact_step = false;
+  V.derive();
+  bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
+
+  bool active, do_reset;
+  if (op == 1) {
+    do_reset = (mask == nullptr) || (mask[li] != 0);
+    active = do_reset;
+  } else {
+    do_reset = (K.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc);
+    active = true;
+  }
+  active = active && valid;
+  do_reset = do_reset && active;
+
+  float act0 = 0.f, act1 = 0.f, act2 = 0.f, act3 = 0.f;
+  float reward = 0.0f;
+  bool pop_pending = false;
+  bool was_reset = false;
+  const int D = (K.angle_repr ? 13 : 12) + 4 + 6 + 3 * K.num_targets;
+
+  auto pop_target = [&]() {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tgt[k][c] = tgt[k + 1][c];
+    n_left -= 1;
+  };
+  auto lds_sync = [&]() {  // one wave per workgroup: see quadx_fast.hpp
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  };
+  // env.reset() for this lane (fixedwing_base_env.py:136-211 begin_reset/end_reset,
+  // fixedwing_waypoints_env.py:101-114): settled spawn state from the template, fresh waypoints.
+  auto reset_lane = [&]() {
+    const float4 t0 = tmpl[0], t1 = tmpl[1], t2 = tmpl[2], t3 = tmpl[3], t4 = tmpl[4];
+    V.p = v3{t0.x, t0.y, t0.z};
+    V.q = quat{t1.x, t1.y, t1.z, t1.w};
+    V.v = v3{t2.x, t2.y, t2.z};
+    V.w = v3{t2.w, t3.x, t3.y};
+    V.act[0] = t3.z; V.act[1] = t3.w; V.act[2] = t4.x; V.act[3] = t4.y; V.act[4] = t4.z; V.thr = t4.w;
+    V.contact_now = false; V.contact_step = false;
+    V.derive();
+    step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
+    act0 = act1 = act2 = act3 = 0.f;
+    const int nt = K.num_targets;  // waypoint_handler.py:53-83
+    n_left = nt;
+    f4 u0, u1, u2;
+    const bool inj = (NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr);
+    if (!inj) {
+      u0 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 2u));
+      u1 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 1u, 2u));
+      u2 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 2u, 2u));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < nt) {
+        float theta, phi, dist;  // theta, phi in turns
+        if (inj) {
+          theta = B.u_targets[(size_t)i * N + li] * (0.5f / kPi);  // injected as angles; turns below
+          phi = B.u_targets[(size_t)(nt + i) * N + li] * (0.5f / kPi);
+          dist = B.u_targets[(size_t)(2 * nt + i) * N + li];
+        } else {
+          auto u = [&](int flat) { return pick4(flat < 4 ? u0 : (flat < 8 ? u1 : u2), (uint32_t)flat & 3u); };
+          theta = u(i);
+          phi = u(nt + i);
+          dist = fmaf(K.dome09m1, u(2 * nt + i), 1.0f);
+        }
+        float st, ct, sph, cph;
+        sincos_turns(theta, st, ct);
+        sincos_turns(phi, sph, cph);
+        float zz = __builtin_fabsf(dist * cph);
+        tgt[i][0] = dist * sph * ct; tgt[i][1] = dist * sph * st; tgt[i][2] = zz > K.min_height ? zz : K.min_height;
+      }
+    }
+    float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
+    old_dist = INFINITY;
+    new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+    rng_ctr += 1;
+    was_reset = true;
+  };
+  // observation row (fixedwing_base_env.py:75-92,213-224; fixedwing_waypoints_env.py:116-167)
+  auto write_obs_row = [&]() {
+    float* row = tile + tid * D;
+    quat q = V.q;
+    float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+    float id = frcp(sqx + sqy + sqz + squ);
+    float sarg = -2.0f * (q.x * q.z - q.w * q.y) * id;
+    quat qe;
+    v3 rpy;
+    if (__builtin_fabsf(sarg) >= 0.99999f) {  // gimbal-lock branch of pybullet, rare: library trig
+      rpy = euler_from_quat(q);
+      qe = quat_from_euler(rpy);
+    } else {
+      float ar = 2.0f * (q.y * q.z + q.w * q.x), br = squ - sqx - sqy + sqz;
+      float ay = 2.0f * (q.x * q.y + q.w * q.z), by = squ + sqx - sqy - sqz;
+      float hr = frsq(fmaf(ar, ar, br * br)), hy = frsq(fmaf(ay, ay, by * by));
+      float cr, sr, cp, sp, cy, sy;
+      half_angle(br * hr, ar * hr, cr, sr);
+      half_angle(fsqrt((1.0f - sarg) * (1.0f + sarg)), sarg, cp, sp);
+      half_angle(by * hy, ay * hy, cy, sy);
+      quat t{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+      float inv = frsq(fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w))));
+      qe = quat{t.x * inv, t.y * inv, t.z * inv, t.w * inv};
+      if (!K.angle_repr) rpy = v3{fast_atan2(ar, br), fast_asin(sarg), fast_atan2(ay, by)};
+    }
+    int k = 0;
+    row[k++] = V.wb.x; row[k++] = V.wb.y; row[k++] = V.wb.z;
+    if (K.angle_repr) { row[k++] = qe.x; row[k++] = qe.y; row[k++] = qe.z; row[k++] = qe.w; }
+    else { row[k++] = rpy.x; row[k++] = rpy.y; row[k++] = rpy.z; }
+    row[k++] = V.vb.x; row[k++] = V.vb.y; row[k++] = V.vb.z;
+    row[k++] = V.p.x; row[k++] = V.p.y; row[k++] = V.p.z;
+    row[k++] = act0; row[k++] = act1; row[k++] = act2; row[k++] = act3;
+    row[k++] = V.act[0]; row[k++] = V.act[1]; row[k++] = V.act[2]; row[k++] = V.act[3]; row[k++] = V.act[4];
+    row[k++] = V.thr;
+    m3 Re = rot_from_quat(qe);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < K.num_targets) {
+        v3 d = mulT(Re, v3{tgt[i][0] - V.p.x, tgt[i][1] - V.p.y, tgt[i][2] - V.p.z});
+        bool live = i < n_left;
+        row[k++] = live ? d.x : 0.0f; row[k++] = live ? d.y : 0.0f; row[k++] = live ? d.z : 0.0f;
+      }
+    }
+  };
+  const bool wave_all = __all(active || !valid);
+  auto flush_tile = [&](float* out) {
+    lds_sync();
+    if (wave_all) {
+      const int rows = min(64, n - wave_base);
+      const int total = rows * D;
+      float* g = out + (size_t)wave_base * D;
+      const int n4 = total >> 2;
+      const float4* t4 = reinterpret_cast<const float4*>(tile);
+      for (int i = tid; i < n4; i += 64) {
+        float4 t = t4[i];
+        __builtin_nontemporal_store(t.x, &g[4 * i + 0]);
+        __builtin_nontemporal_store(t.y, &g[4 * i + 1]);
+        __builtin_nontemporal_store(t.z, &g[4 * i + 2]);
+        __builtin_nontemporal_store(t.w, &g[4 * i + 3]);
+      }
+      for (int i = (n4 << 2) + tid; i < total; i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
+    } else if (active) {
+      float* g = out + (size_t)lane * D;
+      const float* row = tile + tid * D;
+      for (int k = 0; k < D; ++k) g[k] = row[k];
+    }
+    lds_sync();
+  };
+
+  // ---------------------------------------------------------------- reset (NEXT_STEP / explicit)
+  if (do_reset) reset_lane();
+
+  // ---------------------------------------------------------------- the env step
+  const bool stepping = active && !was_reset && op == 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) V.cmd[k] = 0.f;
+  if (stepping) {
+    const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+    act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
+    const float thr_sp = K.throttle_remap ? fmaf(a.w, 0.5f, 0.5f) : a.w;  // fixedwing_base_env.py:260
+    // update_control, mode 0 (fixedwing.py:143-144,246-250): constant over the env step
+    V.cmd[0] = a.x; V.cmd[1] = -a.x; V.cmd[2] = a.y; V.cmd[3] = -a.z; V.cmd[4] = -a.y; V.cmd[5] = thr_sp;
+    reward = -0.1f;
+  }
+  bool go = stepping && !(term || trunc);  // fixedwing_base_env.py:262-263
+  for (int s = 0; s < K.env_step_ratio; ++s) {
+    if (!__any(go)) break;
+    if (go) {
+      float xi0, xi1;
+      if (NOISE == PF_NOISE_PHILOX) { xi0 = 1.0f + pick8(zn, (uint32_t)(2 * s)); xi1 = 1.0f + pick8(zn, (uint32_t)(2 * s + 1)); }
+      else if (NOISE == PF_NOISE_INJECT) { xi0 = B.xi[(size_t)(2 * s) * N + li]; xi1 = B.xi[(size_t)(2 * s + 1) * N + li]; }
+      else { xi0 = 0.f; xi1 = 0.f; }
+      V.contact_step = false;
+#pragma unroll 1
+      for (int t = 0; t < 2; ++t) V.tick(surf, t == 0 ? xi0 : xi1, Pfull);
+      // compute_state side effects + compute_term_trunc_reward
+      if (pop_pending) { pop_target(); pop_pending = false; }
+      float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
+      old_dist = new_dist;
+      new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+      if (step_count > K.max_steps) trunc = true;                                             // fixedwing_base_env.py:229
+      if (V.contact_step) { reward = -100.0f; flags |= PF_F_INFO_COLLISION; term = true; }    // :233-236
+      if (dot(V.p, V.p) > K.dome2) { reward = -100.0f; flags |= PF_F_INFO_OOB; term = true; } // :239-242
+      if (!K.task_sparse) {  // fixedwing_waypoints_env.py:174-178
+        float progress = (isinf(old_dist + new_dist)) ? 0.0f : old_dist - new_dist;
+        reward += __builtin_fmaxf(3.0f * progress, 0.0f);
+        reward += K.wp_dist_reward * frcp(new_dist);
+      }
+      if (new_dist < K.goal_reach) {  // :181-190
+        reward = 100.0f;
+        pop_pending = true;
+        if (n_left - 1 == 0) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
+      }
+      go = !(term || trunc);
+    }
+  }
+  const float out_reward = stepping ? reward : 0.0f;
+  const bool out_term = stepping && term, out_trunc = stepping && trunc;
+  if (stepping) { step_count += 1; rng_ctr += 1; }
+
+  // ---------------------------------------------------------------- SAME_STEP auto-reset
+  if (K.autoreset == PF_AUTORESET_SAME_STEP) {
+    const bool same = stepping && (term || trunc);
+    if (__any(same)) {
+      if (B.final_obs != nullptr) {
+        if (active) write_obs_row();
+        flush_tile(B.final_obs);
+      }
+      if (same) reset_lane();
+    }
+  }
+
+  // ---------------------------------------------------------------- outputs
+  if (active) write_obs_row();
+  flush_tile(B.obs);
+  if (active) {
+    if (pop_pending) { pop_target(); pop_pending = false; }
+    flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
+            (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
+    Sout[0 * N + li] = float4{V.p.x, V.p.y, V.p.z, new_dist};
+    Sout[1 * N + li] = float4{V.q.x, V.q.y, V.q.z, V.q.w};
+    Sout[2 * N + li] = float4{V.v.x, V.v.y, V.v.z, V.w.x};
+    Sout[3 * N + li] = float4{V.w.y, V.w.z, V.act[0], V.act[1]};
+    Sout[4 * N + li] = float4{V.act[2], V.act[3], V.act[4], V.thr};
+    Sout[5 * N + li] = float4{__int_as_float(step_count), __int_as_float(flags), __int_as_float((int)rng_ctr), __int_as_float(n_left)};
+    Sout[6 * N + li] = float4{tgt[0][0], tgt[0][1], tgt[0][2], tgt[1][0]};
+    Sout[7 * N + li] = float4{tgt[1][1], tgt[1][2], tgt[2][0], tgt[2][1]};
+    Sout[8 * N + li] = float4{tgt[2][2], tgt[3][0], tgt[3][1], tgt[3][2]};
+    if (op == 0) {
+      B.reward[li] = out_reward;
+      B.terminated[li] = out_term ? 1 : 0;
+      B.truncated[li] = out_trunc ? 1 : 0;
+    }
+  }
+}
+
+}  // namespace pf

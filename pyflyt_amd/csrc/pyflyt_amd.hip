@@ -18,6 +18,7 @@
 #include "../../include/pyflyt_amd.h"
 #include "uav_vehicles.hpp"
 #include "quadx_fast.hpp"
+#include "fixedwing_fast.hpp"
 
 namespace pf {
 
@@ -522,9 +523,11 @@ struct pf_ctx {
   pf::QuadK K;
   pf_params* P_dev;  // device copy of P for the rarely-taken floor-contact path
   float4* tmpl;      // settled spawn state for lane-independent resets (env_kernel), or null
-  int lpw;           // live lanes per wavefront (64, 32 or 16)
-  int wps;           // register budget: waves per SIMD the kernel variant is compiled for (2 or 4)
   int n_simd;
+  // Fixedwing-Waypoints specialisation (fixedwing_fast.hpp)
+  bool fast_fw;
+  pf::FwK FK;
+  pf::FwTable* surf_dev;  // pre-combined surface + body constants (scalar-loaded per tick)
 };
 static thread_local char g_err[256] = "";
 
@@ -546,16 +549,19 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
-  const int lpw = ctx->lpw;
-  const int grid = (ctx->n + lpw - 1) / lpw;
-#define PF_FAST(NZ, L) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, L>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
-  if (lpw == 32) {  // experiment switch PF_LPW=32 (Philox only)
-    PF_FAST(PF_NOISE_PHILOX, 32);
-  } else {
-    if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX, 64);
-    else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT, 64);
-    else PF_FAST(PF_NOISE_OFF, 64);
-  }
+  const int grid = (ctx->n + 63) / 64;
+#define PF_FAST(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
+  if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
+  else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
+  else PF_FAST(PF_NOISE_OFF);
+#undef PF_FAST
+}
+static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
+  const int grid = (ctx->n + 63) / 64;
+#define PF_FAST(NZ) hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, op, mask)
+  if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
+  else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
+  else PF_FAST(PF_NOISE_OFF);
 #undef PF_FAST
 }
 template <class VEH, int TASK>
@@ -595,8 +601,10 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
-  c->P_dev = nullptr; c->tmpl = nullptr; c->lpw = 64; c->wps = 2; c->n_simd = 1024;
+  c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr; c->n_simd = 1024;
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
+  pf::FwTable fsurf;
+  c->fast_fw = pf::fwk_from_params(P, c->FK, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;
   {  // device copy of the parameter block (LDS constant tables, the out-of-line floor test)
     int cur = -1;
     (void)hipGetDevice(&cur);
@@ -605,14 +613,12 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_simd = prop.multiProcessorCount * 4;
     hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
     if (e == hipSuccess) e = hipMemcpy(c->P_dev, &P, sizeof(pf_params), hipMemcpyHostToDevice);
+    if (e == hipSuccess && c->fast_fw) {
+      e = hipMalloc((void**)&c->surf_dev, sizeof(fsurf));
+      if (e == hipSuccess) e = hipMemcpy(c->surf_dev, &fsurf, sizeof(fsurf), hipMemcpyHostToDevice);
+    }
     if (cur >= 0) (void)hipSetDevice(cur);
     if (e != hipSuccess) { delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
-  }
-  if (c->fast) {
-    // (measured on MI355X, profiles/: the kernel is VALU-issue bound, so full 64-lane waves win at
-    // every batch size; the 32-lane variant is kept for experiments via PF_LPW=32)
-    c->lpw = 64;
-    if (const char* o = getenv("PF_LPW")) { int v = atoi(o); if (v == 64 || v == 32) c->lpw = v; }
   }
   if (!c->fast && (P.task == PF_TASK_HOVER || P.task == PF_TASK_WAYPOINTS) &&
       (P.vehicle == PF_FIXEDWING || P.noise_mode == PF_NOISE_OFF)) {
@@ -630,7 +636,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
       e = hipDeviceSynchronize();
     }
     if (cur >= 0) hipSetDevice(cur);
-    if (e != hipSuccess) { if (c->tmpl) hipFree(c->tmpl); delete c; return hip_fail(nullptr, e, "pf_ctx_create: settle template"); }
+    if (e != hipSuccess) { if (c->tmpl) hipFree(c->tmpl); if (c->surf_dev) hipFree(c->surf_dev); hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: settle template"); }
   }
   *out = c;
   return PF_OK;
@@ -639,6 +645,7 @@ void pf_ctx_destroy(pf_ctx* ctx) {
   if (!ctx) return;
   if (ctx->P_dev) hipFree(ctx->P_dev);
   if (ctx->tmpl) hipFree(ctx->tmpl);
+  if (ctx->surf_dev) hipFree(ctx->surf_dev);
   delete ctx;
 }
 int pf_state_groups(const pf_ctx* ctx) { return ctx->P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : pf::Fixedwing::GROUPS; }
@@ -671,6 +678,8 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
   if (ctx->fast) {
     if (P.task == PF_TASK_HOVER) launch_fast<PF_TASK_HOVER>(ctx, b, op, mask, s);
     else launch_fast<PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
+  } else if (ctx->fast_fw && ctx->tmpl) {
+    launch_fast_fw(ctx, b, op, mask, s);
   } else if (P.vehicle == PF_QUADX) {
     if (P.task == PF_TASK_HOVER) launch_env_t<pf::QuadX, PF_TASK_HOVER>(ctx, b, op, mask, s);
     else if (P.task == PF_TASK_MA_HOVER) launch_env_t<pf::QuadX, PF_TASK_MA_HOVER>(ctx, b, op, mask, s);

@@ -371,20 +371,20 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i < nt) {
-          float theta, phi, dist;
+          float theta, phi, dist;  // theta, phi in turns
           if (inj) {
-            theta = B.u_targets[(size_t)i * N + li];
-            phi = B.u_targets[(size_t)(nt + i) * N + li];
+            theta = B.u_targets[(size_t)i * N + li] * (0.5f / kPi);  // injected as angles; turns below
+            phi = B.u_targets[(size_t)(nt + i) * N + li] * (0.5f / kPi);
             dist = B.u_targets[(size_t)(2 * nt + i) * N + li];
           } else {
             auto u = [&](int flat) { return pick4(flat < 4 ? u0 : (flat < 8 ? u1 : u2), (uint32_t)flat & 3u); };
-            theta = (2.0f * kPi) * u(i);
-            phi = (2.0f * kPi) * u(nt + i);
+            theta = u(i);
+            phi = u(nt + i);
             dist = fmaf(K.dome09m1, u(2 * nt + i), 1.0f);
           }
           float st, ct, sph, cph;
-          sincosf(theta, &st, &ct);
-          sincosf(phi, &sph, &cph);
+          sincos_turns(theta, st, ct);
+          sincos_turns(phi, sph, cph);
           float zz = __builtin_fabsf(dist * cph);
           tgt[i][0] = dist * sph * ct; tgt[i][1] = dist * sph * st; tgt[i][2] = zz > K.min_height ? zz : K.min_height;
         }

@@ -128,6 +128,20 @@ PF_DEV void sincos_small(float x, float& sn, float& cs) {
   sn = x * fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, -2.5052108e-8f, 2.7557319e-6f), -1.9841270e-4f), 8.3333333e-3f), -1.6666667e-1f), 1.0f);
   cs = fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, 2.0876757e-9f, -2.7557319e-7f), 2.4801587e-5f), -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
 }
+// sin/cos of 2*pi*u for u in [0, 1] (an angle given in turns): quadrant reduction is exact in fp32
+// (u - k/4 with k = rint(4u)), the residual |r| <= pi/4 goes through the Taylor pair. ~30 instructions
+// against ~300 for two library sincosf calls; abs error < 1e-7.
+PF_DEV void sincos_turns(float u, float& sn, float& cs) {
+  const float k = __builtin_rintf(4.0f * u);
+  const float r = (2.0f * kPi) * fmaf(k, -0.25f, u);
+  float s, c;
+  sincos_small(r, s, c);
+  const int q = (int)k & 3;
+  const bool odd = (q & 1) != 0;
+  const float a = odd ? c : s, b = odd ? s : c;  // q=0: (s, c)  1: (c, -s)  2: (-s, -c)  3: (-c, s)
+  sn = (q & 2) ? -a : a;
+  cs = (q == 1 || q == 2) ? -b : b;
+}
 // getEulerFromQuaternion without libm (polynomial atan2/asin, 1.2e-7 rad); same branches
 PF_DEV v3 euler_from_quat_fast(quat q) {
   float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;

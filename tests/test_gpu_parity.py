@@ -193,3 +193,16 @@ def test_fixedwing_waypoints_reach():
 
     run_env_parity("fixedwing", "waypoints", "fixedwing_waypoints", 512, 300, "philox", "next_step", FW_LOW, FW_HIGH, seed=19,
                    gentle=gentle, goal_reach_distance=40.0)
+
+
+@pytest.mark.parametrize("vehicle,task,env_name,low,high", [
+    ("quadx", "hover", "hover", QUAD_LOW, QUAD_HIGH),
+    ("quadx", "waypoints", "quadx_waypoints", QUAD_LOW, QUAD_HIGH),
+    ("fixedwing", "waypoints", "fixedwing_waypoints", FW_LOW, FW_HIGH),
+])
+def test_generic_kernel_parity(monkeypatch, vehicle, task, env_name, low, high):
+    """The specialised kernels (quadx_fast.hpp, fixedwing_fast.hpp) are selected from the parameter
+    block; configurations outside their envelope run the generic env_kernel. PF_DISABLE_FAST forces
+    that path for the reference configurations so that it stays covered by the same oracle."""
+    monkeypatch.setenv("PF_DISABLE_FAST", "1")
+    run_env_parity(vehicle, task, env_name, 512, 100, "philox", "next_step", low, high, seed=37)

@@ -70,13 +70,38 @@ class Params(C.Structure):
         ("throttle_remap", C.c_double), ("collide_any", C.c_int),
         ("wp_dist_reward", C.c_double), ("wp_yaw_penalty", C.c_double),
         ("noise_mode", C.c_int), ("seed", C.c_uint64),
+        ("wind_fn", C.c_void_p),
     ]
+
+
+WIND_FN = C.CFUNCTYPE(None, C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+
+
+def set_wind(params: "Params", fn):
+    """Attach a wind field `fn(time: float, position: (n, 3) ndarray) -> (n, 3) ndarray` (the signature of
+    the reference's WindFieldClass.__call__, base_wind_field.py:46-55) to an oracle parameter block.
+    Returns the ctypes callback object, which the caller must keep alive while the params are in use.
+    The callback enters Python: step such lanes serially (n_threads irrelevant for OracleBatch of wind
+    tests, which loops in Python)."""
+    if fn is None:
+        params.wind_fn = None
+        return None
+
+    def _cb(t, pos, n, out):
+        p = np.ctypeslib.as_array(pos, shape=(n, 3)).copy()
+        w = np.asarray(fn(float(t), p), dtype=np.float64)
+        assert w.shape == (n, 3), w.shape
+        np.ctypeslib.as_array(out, shape=(n, 3))[:] = w
+
+    cb = WIND_FN(_cb)
+    params.wind_fn = C.cast(cb, C.c_void_p)
+    return cb
 
 
 class Lane(C.Structure):
     _fields_ = [
         ("p", d3), ("q", C.c_double * 4), ("v", d3), ("w", d3),
-        ("w_b", d3), ("rpy", d3), ("v_b", d3), ("surf_v", d3 * MAX_SURF),
+        ("w_b", d3), ("rpy", d3), ("v_b", d3), ("surf_v", d3 * MAX_SURF), ("drag_v_b", d3),
         ("throttle", C.c_double * 4), ("actuation", C.c_double * MAX_SURF),
         ("pwm", C.c_double * 4), ("cmd", C.c_double * 6), ("setpoint", C.c_double * 6),
         ("pid_I", d3 * 4), ("pid_E", d3 * 4), ("zpid_I", C.c_double * 2), ("zpid_E", C.c_double * 2),

@@ -646,11 +646,33 @@ void orc_update_state(const orc_params* P, orc_lane* L) {
   matTvec(R, L->v, L->v_b);   /* rotation = R^T (quadx.py:521-523) */
   matTvec(R, L->w, L->w_b);
   orc_euler_from_quat(L->q, L->rpy);
+  /* Aviary.elapsed_time is refreshed after update_state (aviary.py:528-529), so the wind is sampled
+   * at the time of the previous tick's end: physics_steps / physics_hz with physics_steps not yet
+   * incremented for this tick. */
+  const double now = (double)L->physics_steps * P->world.dt;
+  if (P->vehicle == ORC_QUADX) { /* boring_bodies.py:78-111: one body, the centre-of-mass link at the base origin */
+    double lv[3] = {L->v[0], L->v[1], L->v[2]};
+    if (P->wind_fn) {
+      double wnd[3];
+      P->wind_fn(now, L->p, 1, wnd);
+      for (int k = 0; k < 3; ++k) lv[k] -= wnd[k];
+    }
+    matTvec(R, lv, L->drag_v_b);
+  }
+  double pos[ORC_MAX_SURF][3], wnd[ORC_MAX_SURF][3];
+  if (P->n_surf > 0 && P->wind_fn) {
+    for (int i = 0; i < P->n_surf; ++i) {
+      double rw[3];
+      matvec(R, P->surf[i].r, rw);
+      for (int k = 0; k < 3; ++k) pos[i][k] = L->p[k] + rw[k];
+    }
+    P->wind_fn(now, &pos[0][0], P->n_surf, &wnd[0][0]);
+  }
   for (int i = 0; i < P->n_surf; ++i) { /* lifting_surfaces.py:73-110 */
     double rw[3], wxr[3], lv[3];
     matvec(R, P->surf[i].r, rw);
     cross3(L->w, rw, wxr);
-    for (int k = 0; k < 3; ++k) lv[k] = L->v[k] + wxr[k];
+    for (int k = 0; k < 3; ++k) lv[k] = L->v[k] + wxr[k] - (P->wind_fn ? wnd[i][k] : 0.0);
     matTvec(R, lv, L->surf_v[i]);
   }
 }
@@ -725,7 +747,7 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
     double noise = tick_noise(P, L, xi, t, flat_base + (uint32_t)t, stream);
     if (P->vehicle == ORC_QUADX) {
       double Fd[3];
-      orc_body_drag(P, L->v_b, Fd); /* quadx.py:498, body link at the origin */
+      orc_body_drag(P, L->drag_v_b, Fd); /* quadx.py:498, body link at the origin */
       for (int k = 0; k < 3; ++k) F_b[k] += Fd[k];
       orc_motors_update(P, L->throttle, L->pwm, noise, thrust, torque); /* quadx.py:499 */
       for (int i = 0; i < 4; ++i) {

@@ -119,6 +119,12 @@ typedef struct {
   /* noise */
   int noise_mode;
   uint64_t seed;
+
+  /* wind field (aviary.py:266-285,324-333; base_wind_field.py:10-69): called from update_state with
+   * the Aviary's elapsed time and the world positions of the n links it is sampled at (QuadX: the
+   * body link, boring_bodies.py:93-96; Fixedwing: the five surface links, lifting_surfaces.py:88-93);
+   * writes n x 3 wind velocities. NULL = no wind. */
+  void (*wind_fn)(double time, const double* pos /* n x 3 */, int n, double* out /* n x 3 */);
 } orc_params;
 
 typedef struct {
@@ -127,6 +133,7 @@ typedef struct {
   /* derived by update_state (quadx.py:512-535) */
   double w_b[3], rpy[3], v_b[3];
   double surf_v[ORC_MAX_SURF][3];
+  double drag_v_b[3]; /* BoringBodies.local_body_velocities: v_b with the wind subtracted (boring_bodies.py:92-111) */
   /* actuators */
   double throttle[4];
   double actuation[ORC_MAX_SURF];

@@ -127,12 +127,42 @@ def gen_aero_and_motors():
 
 
 # --------------------------------------------------------------------------- Aviary level
-def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True, drone_options=None):
+# wind field used for the wind goldens: time- and position-dependent, coefficients travel in the .npz
+WIND_COEF = np.array([1.5, 0.5, 2.0, 0.1, -0.8, 0.2, 0.3, 1.3, -0.05])
+
+
+def wind_from_coef(c):
+    def wind(time, position):
+        w = np.zeros_like(position)
+        w[:, 0] = c[0] + c[1] * np.sin(c[2] * time) + c[3] * position[:, 1]
+        w[:, 1] = c[4] + c[5] * position[:, 2]
+        w[:, 2] = c[6] * np.cos(c[7] * time) + c[8] * position[:, 0]
+        return w
+
+    return wind
+
+
+def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True, drone_options=None, wind=None):
+    """wind: None | "register" (Aviary.register_wind_field_function after construction, as
+    tests/test_core.py:266-296 does: the first tick still sees wind-free velocities) | "ctor"
+    (wind_type=<class>, as tests/test_core.py:299-340: the wind is sampled in reset())."""
     rng_env = ref_stubs.RecordingRNG(np.random.default_rng(seed))
     if not noise:
         rng_env.normal = lambda *a, **k: 0.0
+    extra = {}
+    if wind == "ctor":
+        class GoldenWind:
+            def __init__(self, np_random=None):
+                self.fn = wind_from_coef(WIND_COEF)
+
+            def __call__(self, time, position):
+                return self.fn(time, position)
+
+        extra = dict(wind_type=GoldenWind)
     env = Aviary(start_pos=np.array([start_pos]), start_orn=np.array([start_orn]), drone_type=drone_type,
-                 np_random=rng_env, drone_options=drone_options or {})
+                 np_random=rng_env, drone_options=drone_options or {}, **extra)
+    if wind == "register":
+        env.register_wind_field_function(wind_from_coef(WIND_COEF))
     env.set_mode(mode)
     rng = np.random.default_rng(seed + 1000)
     sp_dim = 4 if not (drone_type == "fixedwing" and mode == -1) else 6
@@ -171,7 +201,8 @@ def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True
         contacts.append(bool(np.any(env.contact_array)))
     return dict(states=np.array(states), aux=np.array(auxs), setpoints=np.array(sps), xi=np.array(xis),
                 contact=np.array(contacts), init_state=init_state, init_aux=init_aux, init_setpoint=init_sp,
-                mode=mode, start_pos=np.array(start_pos), start_orn=np.array(start_orn), noise=noise)
+                mode=mode, start_pos=np.array(start_pos), start_orn=np.array(start_orn), noise=noise,
+                wind_kind=np.array({None: 0, "register": 1, "ctor": 2}[wind]), wind_coef=WIND_COEF)
 
 
 def gen_aviary():
@@ -187,6 +218,18 @@ def gen_aviary():
     for mode in (0, -1):
         d = run_aviary("fixedwing", mode, 200, seed=200 + mode, start_pos=[0.0, 0.0, 10.0], start_orn=[0.02, 0.05, -0.3], noise=True)
         save(f"aviary_fixedwing_mode{mode}".replace("-1", "m1"), **d)
+
+
+def gen_wind():
+    # wind hook (aviary.py:266-285,324-333; boring_bodies.py:93-96; lifting_surfaces.py:88-93)
+    d = run_aviary("quadx", 6, 150, seed=41, start_pos=[0.3, -0.2, 1.5], start_orn=[0.05, -0.08, 0.6], noise=True, wind="register")
+    save("aviary_quadx_wind_register", **d)
+    d = run_aviary("quadx", 0, 100, seed=42, start_pos=[0.0, 0.0, 2.0], start_orn=[0.0, 0.0, 0.0], noise=True, wind="ctor")
+    save("aviary_quadx_wind_ctor", **d)
+    d = run_aviary("fixedwing", 0, 150, seed=43, start_pos=[0.0, 0.0, 10.0], start_orn=[0.02, 0.05, -0.3], noise=True, wind="ctor")
+    save("aviary_fixedwing_wind_ctor", **d)
+    d = run_aviary("fixedwing", 0, 100, seed=44, start_pos=[0.0, 0.0, 10.0], start_orn=[0.0, 0.0, 0.0], noise=True, wind="register")
+    save("aviary_fixedwing_wind_register", **d)
 
 
 # --------------------------------------------------------------------------- env level
@@ -329,9 +372,14 @@ def gen_ma_hover():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate selected groups only: python gen_goldens.py wind
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_pid()
     gen_aero_and_motors()
     gen_aviary()
     gen_envs()
     gen_envs_crash()
     gen_ma_hover()
+    gen_wind()

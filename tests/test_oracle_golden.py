@@ -119,6 +119,64 @@ def test_aviary_trajectory(golden_dir, name):
     assert worst < TOL, worst
 
 
+def wind_from_coef(c):
+    """The analytic wind field of the wind goldens (coefficients stored in the fixture)."""
+    def wind(time, position):
+        w = np.zeros_like(position)
+        w[:, 0] = c[0] + c[1] * np.sin(c[2] * time) + c[3] * position[:, 1]
+        w[:, 1] = c[4] + c[5] * position[:, 2]
+        w[:, 2] = c[6] * np.cos(c[7] * time) + c[8] * position[:, 0]
+        return w
+
+    return wind
+
+
+@pytest.mark.parametrize("name", ["aviary_quadx_wind_register", "aviary_quadx_wind_ctor",
+                                  "aviary_fixedwing_wind_ctor", "aviary_fixedwing_wind_register"])
+def test_aviary_wind_trajectory(golden_dir, name):
+    """Wind hook (aviary.py:266-285,324-333): sampled in update_state at the link positions with the
+    Aviary's (lagging) elapsed time, subtracted from the link velocities that feed the body drag
+    (boring_bodies.py:93-96) / the lifting surfaces (lifting_surfaces.py:88-93). wind_kind 1: the
+    field is registered after construction, so the reset-time velocities are wind-free; 2: given to
+    the constructor, sampled in reset()."""
+    g = load(golden_dir, name)
+    fw = "fixedwing" in name
+    P = O.make_params("fixedwing" if fw else "quadx", noise_mode=O.NOISE_INJECT,
+                      start_pos=g["start_pos"], start_rpy=g["start_orn"])
+    L = O.Lane()
+    lib = O.lib()
+    fn = wind_from_coef(g["wind_coef"])
+    keep = None
+    if int(g["wind_kind"]) == 2:
+        keep = O.set_wind(P, fn)
+    lib.orc_aviary_reset(C.byref(P), C.byref(L), 0)
+    if int(g["wind_kind"]) == 1:
+        keep = O.set_wind(P, fn)
+    lib.orc_set_mode(C.byref(P), C.byref(L), int(g["mode"]))
+    st, aux = lane_state(L, fw)
+    np.testing.assert_allclose(st, g["init_state"], atol=1e-14)
+    worst = 0.0
+    for k in range(len(g["states"])):
+        for i, x in enumerate(g["setpoints"][k]):
+            L.setpoint[i] = x
+        xi = np.ascontiguousarray(np.nan_to_num(g["xi"][k]))
+        lib.orc_aviary_step(C.byref(P), C.byref(L), dp(xi), 0, 0)
+        st, aux = lane_state(L, fw)
+        worst = max(worst, np.abs(st - g["states"][k]).max(), np.abs(aux - g["aux"][k]).max())
+    assert keep is not None
+    assert worst < TOL, worst
+    # and the wind matters: the same run without it must differ visibly
+    P2 = O.make_params("fixedwing" if fw else "quadx", noise_mode=O.NOISE_INJECT, start_pos=g["start_pos"], start_rpy=g["start_orn"])
+    L2 = O.Lane()
+    lib.orc_aviary_reset(C.byref(P2), C.byref(L2), 0)
+    lib.orc_set_mode(C.byref(P2), C.byref(L2), int(g["mode"]))
+    for k in range(len(g["states"])):
+        for i, x in enumerate(g["setpoints"][k]):
+            L2.setpoint[i] = x
+        lib.orc_aviary_step(C.byref(P2), C.byref(L2), dp(np.ascontiguousarray(np.nan_to_num(g["xi"][k]))), 0, 0)
+    assert np.abs(lane_state(L2, fw)[0] - g["states"][-1]).max() > 1e-3
+
+
 @pytest.mark.parametrize("name", ["aviary_quadx_drop", "aviary_fixedwing_drop"])
 def test_aviary_drop_contact(golden_dir, name):
     """Fall onto the floor: the contact flag must rise on the same Aviary step as in the

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 1
+#define PF_ABI_VERSION 2
 #define PF_MAX_TARGETS 8
 #define PF_MAX_BOXES 8
 #define PF_MAX_SURF 5
@@ -136,6 +136,11 @@ typedef struct pf_buffers {
   float* out_aux;          /* [n][4] quadx throttle | [n][6] fixedwing surfaces + throttle */
   uint8_t* out_contact;    /* [n] contact_array[planeId] after the step, or NULL */
   const float* start_pose; /* pf_aviary_reset: [n][7] per-lane spawn (pos xyz, quat xyzw) or NULL = pf_params */
+  /* wind field (pf_aviary_tick / pf_aviary_reset; ABI 2). K = pf_wind_links(): the links the reference
+   * samples its wind field at -- QuadX 1 (body link, boring_bodies.py:93-96), Fixedwing 5 (surface
+   * links, lifting_surfaces.py:88-93) */
+  const float* wind;       /* [n][K][3] world-frame wind velocity at those links as of the previous update_state, or NULL */
+  float* out_link_pos;     /* [n][K][3] world positions of those links after the call, or NULL */
 } pf_buffers;
 
 typedef struct pf_ctx pf_ctx;
@@ -173,6 +178,18 @@ int pf_aviary_reset(pf_ctx* ctx, const pf_buffers* b, void* stream);
  * setpoint (quadx.py:275-290) */
 int pf_aviary_set_mode(pf_ctx* ctx, const pf_buffers* b, int mode, float* setpoints_out, void* stream);
 int pf_aviary_step(pf_ctx* ctx, const pf_buffers* b, int n_steps, void* stream);
+
+/* ONE physics tick of Aviary.step (aviary.py:510-531), for callers that must get between the ticks:
+ * a wind field (aviary.py:266-285,324-333; base_wind_field.py) is sampled by the reference in every
+ * update_state at the link positions, and feeds the next tick's drag / aerodynamic velocities.
+ * tick_index = position of the tick inside the Aviary step (0 .. ticks_per_control-1): the controller
+ * runs at tick 0 (quadx.py:409), the motor commands are carried to the later ticks in state group 12
+ * (QuadX) or recomputed from the setpoint (Fixedwing, stateless mixing). b->wind (may be NULL) is
+ * subtracted from the link velocities; b->out_link_pos receives where to sample the field next;
+ * b->out_contact the contact verdict of this tick. PF_NOISE_INJECT: b->xi holds this tick's draws [n].
+ * The host side of the protocol is pyflyt_amd/core/aviary.py (Aviary.step with a wind field). */
+int pf_aviary_tick(pf_ctx* ctx, const pf_buffers* b, int tick_index, void* stream);
+int pf_wind_links(const pf_ctx* ctx);
 
 /* Synthetic uniform actions inside [action_low, action_high] for benchmark rollouts
  * (the role of env.action_space.sample(), tests/test_gym_envs.py:104), keyed by

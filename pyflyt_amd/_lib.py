@@ -71,13 +71,14 @@ class PfBuffers(C.Structure):
         ("xi", C.c_void_p), ("xi_reset", C.c_void_p), ("u_targets", C.c_void_p),
         ("setpoints", C.c_void_p), ("out_state", C.c_void_p), ("out_aux", C.c_void_p),
         ("out_contact", C.c_void_p), ("start_pose", C.c_void_p),
+        ("wind", C.c_void_p), ("out_link_pos", C.c_void_p),
     ]
 
 
 EXPORTS = (
     "pf_abi_version", "pf_sizeof_params", "pf_sizeof_buffers", "pf_last_error", "pf_ctx_create", "pf_ctx_destroy", "pf_state_groups", "pf_obs_dim",
     "pf_n_lanes", "pf_env_reset", "pf_env_step", "pf_aviary_reset", "pf_aviary_set_mode", "pf_aviary_step",
-    "pf_sample_actions",
+    "pf_sample_actions", "pf_aviary_tick", "pf_wind_links",
 )
 
 _lib = None
@@ -115,11 +116,13 @@ def lib():
     L.pf_aviary_set_mode.argtypes = [C.c_void_p, C.POINTER(PfBuffers), C.c_int, C.c_void_p, C.c_void_p]
     L.pf_aviary_step.argtypes = [C.c_void_p, C.POINTER(PfBuffers), C.c_int, C.c_void_p]
     L.pf_sample_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.pf_aviary_tick.argtypes = [C.c_void_p, C.POINTER(PfBuffers), C.c_int, C.c_void_p]
+    L.pf_wind_links.argtypes = [C.c_void_p]
     L.pf_sizeof_params.restype = C.c_size_t
     L.pf_sizeof_buffers.restype = C.c_size_t
     if L.pf_sizeof_params() != C.sizeof(PfParams) or L.pf_sizeof_buffers() != C.sizeof(PfBuffers):
         raise PyFlytAmdError("struct layout mismatch between pyflyt_amd/_lib.py and include/pyflyt_amd.h")
-    if L.pf_abi_version() != 1:
+    if L.pf_abi_version() != 2:
         raise PyFlytAmdError("ABI version mismatch between pyflyt_amd/_lib.py and libpyflyt_amd.so")
     _lib = L
     return L

@@ -10,8 +10,12 @@ Same surface as the reference where it is on the hot path:
   state(i) (4,3) / aux_state(i) / all_states / all_aux_states :335-421
   contact_array  -> per-drone bool "touches the floor" (the reference's body-pair matrix collapses
                     to this because every drone is alone in its world)
+  wind_type / wind_options / register_wind_field_function()   :266-285,324-333 -- the field is a
+                    function of (time, positions[M,3] device tensor) -> wind[M,3] device tensor,
+                    sampled after every physics tick exactly where and when the reference samples
+                    it (boring_bodies.py:93-96, lifting_surfaces.py:88-93)
 Not carried over (out of scope): rendering/cameras, custom Python controllers,
-wind-field callbacks, mixed drone types, partial arming, drone-drone contact.
+mixed drone types, partial arming, drone-drone contact.
 """
 from __future__ import annotations
 
@@ -46,9 +50,14 @@ class Aviary:
             drone_type = kinds.pop()
         if drone_type not in ("quadx", "fixedwing"):
             raise AviaryInitException(f"drone_type {drone_type!r} is not on the batched hot path (quadx, fixedwing)")
-        if render or wind_type is not None:
-            raise AviaryInitException("rendering and wind fields are out of scope for the batched GPU path")
-        del wind_options
+        if render:
+            raise AviaryInitException("rendering is out of scope for the batched GPU path")
+        if wind_type is not None and not callable(wind_type):  # core/aviary.py:270-285
+            if isinstance(wind_type, str):
+                raise AssertionError(f"Unknown wind field model {wind_type}.")
+            raise LookupError("Invalid setting for wind field.")
+        self.wind_type, self.wind_options = wind_type, dict(wind_options or {})
+        self.wind_field = None
         self.num_drones = start_pos.shape[0]
         self.drone_type = drone_type
         self.device = torch.device(device)
@@ -65,6 +74,7 @@ class Aviary:
         P = build_params(drone_type, "none", noise="philox" if motor_noise else "off", autoreset="off",
                          seed=0 if seed is None else int(seed), vehicle_options=vopts,
                          world_options={"physics_hz": self.physics_hz, "world_scale": float(world_scale)})
+        self._seed = 0 if seed is None else int(seed)
         self.engine = BatchEngine(P, self.num_drones, device=self.device, lane_offset=lane_offset)
         pose = np.concatenate([start_pos, np.stack([quat_from_euler(o) for o in start_orn])], axis=1)
         self._start_pose = torch.tensor(pose, dtype=torch.float32, device=self.device).contiguous()
@@ -85,6 +95,39 @@ class Aviary:
         self.mode = 0
         self._set_sp_dim(4)
         self.setpoints.zero_()
+        self._contact_acc = None
+        # wind field given to the constructor (core/aviary.py:266-285): built per reset with the
+        # Aviary's generator and options, and sampled by the reset's update_state at time 0
+        self.wind_field = None
+        self._wind = None
+        if self.wind_type is not None:
+            field = self.wind_type(np_random=np.random.default_rng(self._seed), **self.wind_options)
+            self._check_wind_field_validity(field)
+            self.wind_field = field
+            self._wind = self._sample_wind()
+
+    # ------------------------------------------------------------------ :324-333, base_wind_field.py:57-69
+    def _check_wind_field_validity(self, wind_field) -> None:
+        test = wind_field(0.0, torch.tensor([[0.0, 0.0, 1.0]] * 5, dtype=torch.float32, device=self.device))
+        assert torch.is_tensor(test), f"Returned wind velocity must be a torch.Tensor, got {type(test)}."
+        assert test.is_floating_point(), f"Returned wind velocity must be type float, got {test.dtype}."
+        assert tuple(test.shape) == (5, 3), f"Returned wind velocity must be array of shape (n, 3), got {tuple(test.shape)}."
+
+    def register_wind_field_function(self, wind_field) -> None:
+        """`wind_field(time: float, position: Tensor[M, 3]) -> Tensor[M, 3]`, device tensors. As in the
+        reference, a field registered after construction first acts on the tick after the next
+        update_state: the velocities left by reset() are wind-free."""
+        assert callable(wind_field), "`wind_field` function must be callable."
+        self._check_wind_field_validity(wind_field)
+        self.wind_field = wind_field
+        if self._wind is None:
+            self.engine._aviary_outputs()
+            self._wind = torch.zeros(self.num_drones, self.engine.wind_links, 3, dtype=torch.float32, device=self.device)
+
+    def _sample_wind(self) -> torch.Tensor:
+        pos = self.engine.link_pos
+        w = self.wind_field(self.elapsed_time, pos.view(-1, 3))
+        return w.to(dtype=torch.float32).reshape(pos.shape).contiguous()
 
     def _set_sp_dim(self, d):
         if d != self._sp_dim:
@@ -117,10 +160,28 @@ class Aviary:
     # ------------------------------------------------------------------ :480-531
     def step(self, n_steps: int = 1) -> None:
         """One (or n fused) `Aviary.step()`: control + ticks_per_control physics ticks per drone."""
+        if self.wind_field is not None:
+            return self._step_with_wind(n_steps)
+        self._contact_acc = None
         self.engine.aviary_step(self.setpoints, n_steps=n_steps)
         self.physics_steps += n_steps * self.updates_per_step
         self.aviary_steps += n_steps
         self.elapsed_time = self.physics_steps / self.physics_hz
+
+    def _step_with_wind(self, n_steps: int) -> None:
+        # the reference's per-tick order (aviary.py:510-531): control + forces (with the wind sampled by
+        # the previous update_state) -> stepSimulation -> update_state (samples the field at the new link
+        # positions with the not-yet-advanced elapsed_time) -> contact splice -> counters
+        for _ in range(n_steps):
+            acc = torch.zeros_like(self.engine.out_contact)
+            for t in range(self.updates_per_step):
+                self.engine.aviary_tick(self.setpoints, t, wind=self._wind)
+                acc |= self.engine.out_contact
+                self._wind = self._sample_wind()
+                self.physics_steps += 1
+                self.elapsed_time = self.physics_steps / self.physics_hz
+            self._contact_acc = acc
+            self.aviary_steps += 1
 
     # ------------------------------------------------------------------ :335-421
     @property
@@ -140,7 +201,7 @@ class Aviary:
 
     @property
     def contact_array(self) -> torch.Tensor:
-        return self.engine.out_contact
+        return self.engine.out_contact if self._contact_acc is None else self._contact_acc
 
     def disconnect(self) -> None:
         self.engine.close()

@@ -417,6 +417,14 @@ __global__ void __launch_bounds__(kWave) aviary_reset_kernel(const pf_params P, 
     o[0] = V.b.wb.x; o[1] = V.b.wb.y; o[2] = V.b.wb.z; o[3] = V.b.rpy.x; o[4] = V.b.rpy.y; o[5] = V.b.rpy.z;
     o[6] = V.b.vb.x; o[7] = V.b.vb.y; o[8] = V.b.vb.z; o[9] = V.b.p.x; o[10] = V.b.p.y; o[11] = V.b.p.z;
   }
+  if (B.out_link_pos) {
+#pragma unroll
+    for (int k = 0; k < VEH::WIND_LINKS; ++k) {
+      v3 lp = V.link_pos(P, k);
+      float* o = B.out_link_pos + ((size_t)lane * VEH::WIND_LINKS + k) * 3;
+      o[0] = lp.x; o[1] = lp.y; o[2] = lp.z;
+    }
+  }
   if (B.out_aux) {
     float aux[VEH::AUX];
     V.aux(aux);
@@ -495,6 +503,74 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
     for (int k = 0; k < VEH::AUX; ++k) B.out_aux[li * VEH::AUX + k] = aux[k];
   }
   if (B.out_contact) B.out_contact[li] = contact ? 1 : 0;
+}
+
+// One physics tick of Aviary.step (pf_aviary_tick): the wind-field protocol needs the host between
+// ticks. QuadX carries the motor commands of the step's control tick in state group 12.
+template <class VEH>
+__global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, const pf_buffers B, const int n,
+                                                            const uint64_t lane0, const int tick_index,
+                                                            const pf_params* __restrict__ Pdev) {
+  __shared__ float ktab[VEH::TABLE_FLOATS];
+  VEH::fill_table(ktab, Pdev, threadIdx.x);
+  __syncthreads();
+  const int lane = blockIdx.x * kWave + threadIdx.x;
+  if (lane >= n) return;
+  const size_t li = lane, N = n;
+  constexpr bool kQuad = VEH::AUX == 4;
+  constexpr int kCmdGroup = 12;
+  VEH V;
+  V.bind(ktab);
+  float nd;
+  int4 ints;
+  const int mode = P.flight_mode;
+  float4* S = reinterpret_cast<float4*>(B.state);
+  V.load(S, N, li, mode, nd, ints);
+  V.b.rpy = euler_from_quat_fast(V.b.q);
+  uint32_t rng_ctr = (uint32_t)ints.z;
+  Noise nz;
+  nz.mode = P.noise_mode; nz.n = n; nz.lane = lane;
+  nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
+  nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
+  nz.begin_event(rng_ctr, 0u, B.xi);
+  float sp[6] = {0, 0, 0, 0, 0, 0};
+  const int spn = (P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (k < spn) sp[k] = B.setpoints[li * spn + k];
+  if (tick_index == 0 || !kQuad) {
+    V.template control<kRuntimeMode>(P, sp);  // Fixedwing: stateless mixing, recomputed every tick
+  } else {
+    const float4 c = S[(size_t)kCmdGroup * N + li];
+    V.set_cmd(c);
+  }
+  const float xi = nz.get(P.noise_mode == PF_NOISE_INJECT ? 0 : tick_index);
+  V.tick(P, xi, B.wind ? B.wind + li * (size_t)(VEH::WIND_LINKS * 3) : nullptr);
+  V.b.rpy = euler_from_quat_fast(V.b.q);
+  if (tick_index == P.ticks_per_control - 1) rng_ctr += 1;
+  int flags = (ints.y & ~PF_F_CONTACT) | (V.b.contact_now ? PF_F_CONTACT : 0);
+  V.store(S, N, li, mode, nd, int4{ints.x, flags, (int)rng_ctr, ints.w});
+  if (kQuad) S[(size_t)kCmdGroup * N + li] = V.get_cmd();
+  if (B.out_state) {
+    float4* o = reinterpret_cast<float4*>(B.out_state + li * 12);
+    o[0] = float4{V.b.wb.x, V.b.wb.y, V.b.wb.z, V.b.rpy.x};
+    o[1] = float4{V.b.rpy.y, V.b.rpy.z, V.b.vb.x, V.b.vb.y};
+    o[2] = float4{V.b.vb.z, V.b.p.x, V.b.p.y, V.b.p.z};
+  }
+  if (B.out_aux) {
+    float aux[VEH::AUX];
+    V.aux(aux);
+    for (int k = 0; k < VEH::AUX; ++k) B.out_aux[li * VEH::AUX + k] = aux[k];
+  }
+  if (B.out_contact) B.out_contact[li] = V.b.contact_now ? 1 : 0;
+  if (B.out_link_pos) {
+#pragma unroll
+    for (int k = 0; k < VEH::WIND_LINKS; ++k) {
+      v3 lp = V.link_pos(P, k);
+      float* o = B.out_link_pos + (li * VEH::WIND_LINKS + k) * 3;
+      o[0] = lp.x; o[1] = lp.y; o[2] = lp.z;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) sample_actions_kernel(const pf_params P, float* actions, const int n,
@@ -742,6 +818,22 @@ int pf_aviary_step(pf_ctx* ctx, const pf_buffers* b, int n_steps, void* stream) 
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;
 }
+int pf_aviary_tick(pf_ctx* ctx, const pf_buffers* b, int tick_index, void* stream) {
+  if (!ctx || !b || !b->state || !b->setpoints) return fail(ctx, PF_ERR_ARG, "pf_aviary_tick: state and setpoints buffers are required");
+  if (tick_index < 0 || tick_index >= ctx->P.ticks_per_control) return fail(ctx, PF_ERR_ARG, "pf_aviary_tick: tick_index must be in [0, ticks_per_control)");
+  if (ctx->P.noise_mode == PF_NOISE_INJECT && !b->xi) return fail(ctx, PF_ERR_ARG, "pf_aviary_tick: PF_NOISE_INJECT needs b->xi");
+  int rc = ensure_device(ctx);
+  if (rc) return rc;
+  const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->P.vehicle == PF_QUADX)
+    hipLaunchKernelGGL(pf::aviary_tick_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, tick_index, ctx->P_dev);
+  else
+    hipLaunchKernelGGL(pf::aviary_tick_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, tick_index, ctx->P_dev);
+  PF_HIP(ctx, hipGetLastError());
+  return PF_OK;
+}
+int pf_wind_links(const pf_ctx* ctx) { return ctx->P.vehicle == PF_QUADX ? pf::QuadX::WIND_LINKS : pf::Fixedwing::WIND_LINKS; }
 int pf_sample_actions(pf_ctx* ctx, float* actions, uint32_t step_index, void* stream) {
   if (!ctx || !actions) return fail(ctx, PF_ERR_ARG, "pf_sample_actions: bad argument");
   int rc = ensure_device(ctx);

@@ -275,9 +275,15 @@ struct QuadX {
 #pragma unroll
     for (int i = 0; i < 4; ++i) pwm[i] = clampf(pwm[i], 0.05f, 1.0f);
   }
-  // update_physics + stepSimulation + update_state for one tick (quadx.py:495-535)
-  PF_DEV void tick(const pf_params& P, float xi) {
-    v3 F{-P.drag_const[0] * sq_signed(b.vb.x), -P.drag_const[1] * sq_signed(b.vb.y), -P.drag_const[2] * sq_signed(b.vb.z)};
+  // update_physics + stepSimulation + update_state for one tick (quadx.py:495-535).
+  // wind: world-frame wind at the body link as sampled by the previous update_state
+  // (boring_bodies.py:93-96), or null.
+  static constexpr int WIND_LINKS = 1;
+  PF_DEV v3 link_pos(const pf_params&, int) const { return b.p; }  // centre-of-mass link at the base origin
+  PF_DEV void tick(const pf_params& P, float xi, const float* wind = nullptr) {
+    v3 vd = b.vb;
+    if (wind) vd = vd - mulT(b.R, v3{wind[0], wind[1], wind[2]});
+    v3 F{-P.drag_const[0] * sq_signed(vd.x), -P.drag_const[1] * sq_signed(vd.y), -P.drag_const[2] * sq_signed(vd.z)};
     v3 tau{0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // motors.py:131-138,182-193
@@ -310,6 +316,9 @@ struct QuadX {
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = thr[k];
   }
+  // the motor commands held between the ticks of one Aviary step (pf_aviary_tick)
+  PF_DEV float4 get_cmd() const { return float4{pwm[0], pwm[1], pwm[2], pwm[3]}; }
+  PF_DEV void set_cmd(float4 c) { pwm[0] = c.x; pwm[1] = c.y; pwm[2] = c.z; pwm[3] = c.w; }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -463,7 +472,11 @@ struct Fixedwing {
       }
     }
   }
-  PF_DEV void tick(const pf_params& P, float xi) {
+  static constexpr int WIND_LINKS = PF_MAX_SURF;
+  PF_DEV v3 link_pos(const pf_params& P, int k) const {  // surface link COMs (lifting_surfaces.py:83-93)
+    return b.p + mul(b.R, v3{P.surf[k].r[0], P.surf[k].r[1], P.surf[k].r[2]});
+  }
+  PF_DEV void tick(const pf_params& P, float xi, const float* wind = nullptr) {
     v3 F{0.0f, 0.0f, 0.0f}, tau{0.0f, 0.0f, 0.0f};
 #pragma unroll 1
     for (int i = 0; i < PF_MAX_SURF; ++i) {
@@ -476,6 +489,7 @@ struct Fixedwing {
       act[3] = i == 3 ? ai : act[3]; act[4] = i == 4 ? ai : act[4];
       v3 r{S.r[0], S.r[1], S.r[2]};
       v3 vloc = b.vb + cross(b.wb, r);  // lifting_surfaces.py:73-110
+      if (wind) vloc = vloc - mulT(b.R, v3{wind[3 * i + 0], wind[3 * i + 1], wind[3 * i + 2]});
       v3 f, t;
       surface(S, vloc, ai, f, t);
       F = F + f;
@@ -506,6 +520,8 @@ struct Fixedwing {
     for (int k = 0; k < 5; ++k) o[k] = act[k];
     o[5] = thr;
   }
+  PF_DEV float4 get_cmd() const { return float4{0.f, 0.f, 0.f, 0.f}; }  // stateless mixing: nothing to carry
+  PF_DEV void set_cmd(float4) {}
 };
 
 }  // namespace pf

@@ -49,6 +49,8 @@ class BatchEngine:
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=self.device)
         self.truncated = torch.zeros(self.n, dtype=torch.bool, device=self.device)
         self.out_state = None
+        self.link_pos = None
+        self.wind_links = 0
         self.out_aux = None
         self.out_contact = None
         self._buf = L.PfBuffers()
@@ -68,7 +70,7 @@ class BatchEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _buffers(self, actions=None, xi=None, xi_reset=None, u_targets=None, setpoints=None, start_pose=None):
+    def _buffers(self, actions=None, xi=None, xi_reset=None, u_targets=None, setpoints=None, start_pose=None, wind=None):
         b = self._buf
         b.state = _ptr(self.state)
         b.actions = _ptr(actions)
@@ -85,6 +87,8 @@ class BatchEngine:
         b.out_aux = _ptr(self.out_aux)
         b.out_contact = _ptr(self.out_contact)
         b.start_pose = _ptr(start_pose)
+        b.wind = _ptr(wind)
+        b.out_link_pos = _ptr(self.link_pos)
         return b
 
     def _check_f32(self, t, shape, name):
@@ -137,6 +141,9 @@ class BatchEngine:
             self.out_state = torch.zeros(self.n, 12, dtype=torch.float32, device=self.device)
             self.out_aux = torch.zeros(self.n, aux, dtype=torch.float32, device=self.device)
             self.out_contact = torch.zeros(self.n, dtype=torch.bool, device=self.device)
+            # world positions of the links a wind field is sampled at (QuadX: body link; Fixedwing: 5 surfaces)
+            self.wind_links = int(self.lib.pf_wind_links(self._ctx))
+            self.link_pos = torch.zeros(self.n, self.wind_links, 3, dtype=torch.float32, device=self.device)
 
     def aviary_reset(self, start_pose=None):
         self._aviary_outputs()
@@ -158,6 +165,18 @@ class BatchEngine:
         b = self._buffers(setpoints=setpoints, xi=xi)
         with torch.cuda.device(self.device):
             L.check(self.lib.pf_aviary_step(self._ctx, C.byref(b), int(n_steps), self._stream()), self._ctx)
+        return self.out_state, self.out_aux
+
+    def aviary_tick(self, setpoints, tick_index: int, wind=None, xi=None):
+        """One physics tick of Aviary.step (pf_aviary_tick). `wind`: [n, wind_links, 3] world-frame wind
+        as sampled after the previous tick, or None. Fills out_state / out_aux / out_contact (this
+        tick's contact verdict) / link_pos (where to sample the field next)."""
+        self._aviary_outputs()
+        self._check_f32(wind, (self.n, self.wind_links, 3), "wind")
+        self._check_f32(xi, (self.n,), "xi")
+        b = self._buffers(setpoints=setpoints, xi=xi, wind=wind)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_aviary_tick(self._ctx, C.byref(b), int(tick_index), self._stream()), self._ctx)
         return self.out_state, self.out_aux
 
     # ------------------------------------------------------------------ state views

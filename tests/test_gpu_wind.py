@@ -1,0 +1,153 @@
+"""GPU parity of the wind-field hook (core/aviary.py:266-285,324-333; boring_bodies.py:93-96;
+lifting_surfaces.py:88-93): the batched Aviary, stepped tick by tick through `pf_aviary_tick` with a
+device-side wind function, against the fp64 oracle driven with the same analytic field (the oracle's
+wind semantics are pinned on goldens recorded from the reference: tests/test_oracle_golden.py).
+Both ways of attaching a field are covered: `wind_type=` (sampled in reset()) and
+`register_wind_field_function` (first tick wind-free)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as O  # noqa: E402
+
+from test_gpu_aviary import sample_setpoint  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+COEF = np.array([1.5, 0.5, 2.0, 0.1, -0.8, 0.2, 0.3, 1.3, -0.05])
+
+
+def wind_np(time, position):
+    c = COEF
+    w = np.zeros_like(position)
+    w[:, 0] = c[0] + c[1] * np.sin(c[2] * time) + c[3] * position[:, 1]
+    w[:, 1] = c[4] + c[5] * position[:, 2]
+    w[:, 2] = c[6] * np.cos(c[7] * time) + c[8] * position[:, 0]
+    return w
+
+
+def wind_torch(time, position):
+    c = COEF
+    w = torch.zeros_like(position)
+    w[:, 0] = c[0] + c[1] * float(np.sin(c[2] * time)) + c[3] * position[:, 1]
+    w[:, 1] = c[4] + c[5] * position[:, 2]
+    w[:, 2] = c[6] * float(np.cos(c[7] * time)) + c[8] * position[:, 0]
+    return w
+
+
+class WindField:  # the constructor protocol of core/aviary.py:277-283
+    def __init__(self, np_random=None, gain=1.0):
+        self.gain = gain
+
+    def __call__(self, time, position):
+        return self.gain * wind_torch(time, position)
+
+
+@pytest.mark.parametrize("drone,mode,kind", [("quadx", 6, "register"), ("quadx", 0, "ctor"), ("quadx", 7, "ctor"),
+                                             ("fixedwing", 0, "ctor"), ("fixedwing", 0, "register")])
+def test_aviary_wind_parity(drone, mode, kind):
+    from pyflyt_amd.core import Aviary
+
+    n, steps, seed = 96, 80, 70 + mode
+    rng = np.random.default_rng(seed)
+    z0 = 1.5 if drone == "quadx" else 10.0
+    start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(z0, z0 + 1.0, size=(n, 1))], axis=1)
+    start_orn = rng.uniform(-0.15, 0.15, size=(n, 3)) * np.array([1, 1, 5.0])
+    if kind == "ctor":
+        env = Aviary(start_pos, start_orn, drone_type=drone, seed=seed, wind_type=WindField, wind_options=dict(gain=1.0))
+    else:
+        env = Aviary(start_pos, start_orn, drone_type=drone, seed=seed)
+        env.register_wind_field_function(wind_torch)
+    env.set_mode(mode)
+
+    lib = O.lib()
+    Ps, Ls, keep = [], [], []
+    sp32 = start_pos.astype(np.float32).astype(np.float64)
+    for i in range(n):
+        P = O.make_params(drone, noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=sp32[i], start_rpy=start_orn[i])
+        L = O.Lane()
+        if kind == "ctor":
+            keep.append(O.set_wind(P, wind_np))
+        lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
+        if kind == "register":
+            keep.append(O.set_wind(P, wind_np))
+        lib.orc_set_mode(C.byref(P), C.byref(L), mode)
+        Ps.append(P); Ls.append(L)
+
+    def ref_state():
+        st = np.array([[list(L.w_b), list(L.rpy), list(L.v_b), list(L.p)] for L in Ls])
+        aux = np.array([list(L.actuation) + [L.throttle[0]] if drone == "fixedwing" else list(L.throttle) for L in Ls])
+        return st, aux
+
+    ok = np.ones(n, dtype=bool)
+    worst = 0.0
+    for k in range(steps):
+        if k % 20 == 5:
+            sp = sample_setpoint(rng, n, drone, mode).astype(np.float32)
+            env.set_all_setpoints(sp)
+            for i, L in enumerate(Ls):
+                for j in range(sp.shape[1]):
+                    L.setpoint[j] = float(sp[i, j])
+        env.step()
+        for P, L in zip(Ps, Ls):
+            lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+            L.rng_ctr += 1
+        st, aux = ref_state()
+        g = env.all_states.cpu().numpy().astype(np.float64)
+        ga = env.all_aux_states.cpu().numpy().astype(np.float64)
+        scale = np.maximum(1.0, np.linalg.norm(st, axis=2, keepdims=True))
+        e = np.maximum((np.abs(g - st) / scale).reshape(n, -1).max(1), np.abs(ga - aux).max(1))
+        contact = np.array([bool(L.contact_step) for L in Ls])
+        ok &= (e < RTOL) & (env.contact_array.cpu().numpy() == contact)
+        worst = max(worst, e[ok].max() if ok.any() else 0.0)
+        if k == 24:
+            assert ok.mean() >= 0.99, (k, 1 - ok.mean())
+    med = float(np.median(e))
+    print(f"wind {drone} mode {mode} {kind}: worst {worst:.2e}, dropped {1 - ok.mean():.4f}, median at end {med:.1e}")
+    assert med < RTOL
+    if drone == "fixedwing" or mode == 0:
+        assert ok.mean() >= 0.99
+    assert env.elapsed_time == pytest.approx(steps * env.updates_per_step / env.physics_hz)
+    env.disconnect()
+
+
+def test_wind_changes_the_flight_and_tick_path_equals_fused_path_without_wind():
+    """(i) zero wind through the tick-by-tick path == the fused pf_aviary_step path (same arithmetic,
+    launched per tick); (ii) a real wind moves the drone."""
+    from pyflyt_amd.core import Aviary
+
+    n = 64
+    pos = np.tile(np.array([[0.0, 0.0, 2.0]]), (n, 1)); orn = np.zeros((n, 3))
+    a = Aviary(pos, orn, drone_type="quadx", seed=3)
+    b = Aviary(pos, orn, drone_type="quadx", seed=3)
+    c = Aviary(pos, orn, drone_type="quadx", seed=3)
+    b.register_wind_field_function(lambda t, p: torch.zeros_like(p))
+    c.register_wind_field_function(lambda t, p: torch.tensor([3.0, 0.0, 0.0], device=p.device).expand_as(p).contiguous())
+    for e in (a, b, c):
+        e.set_mode(7)
+        e.set_all_setpoints(np.tile(np.array([[0.0, 0.0, 0.0, 2.0]]), (n, 1)))
+    for _ in range(120):
+        for e in (a, b, c):
+            e.step()
+    assert torch.allclose(a.all_states, b.all_states, atol=1e-6)
+    assert (c.all_states[:, 3, 0] - a.all_states[:, 3, 0]).abs().min() > 1e-3  # pushed downwind in x
+    for e in (a, b, c):
+        e.disconnect()
+
+
+def test_wind_field_validation():
+    from pyflyt_amd.core import Aviary
+
+    env = Aviary(np.array([[0.0, 0.0, 1.0]]), np.zeros((1, 3)), drone_type="quadx")
+    with pytest.raises(AssertionError):
+        env.register_wind_field_function(lambda t, p: p.cpu().numpy())         # not a tensor
+    with pytest.raises(AssertionError):
+        env.register_wind_field_function(lambda t, p: torch.zeros(4, 3, device=p.device))  # wrong shape
+    with pytest.raises(AssertionError):
+        Aviary(np.array([[0.0, 0.0, 1.0]]), np.zeros((1, 3)), drone_type="quadx", wind_type="Simple")
+    with pytest.raises(LookupError):
+        Aviary(np.array([[0.0, 0.0, 1.0]]), np.zeros((1, 3)), drone_type="quadx", wind_type=3)
+    env.disconnect()

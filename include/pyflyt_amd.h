@@ -51,7 +51,8 @@ typedef struct pf_pid {
 } pf_pid;
 
 typedef struct pf_box {
-  float c[3], h[3]; /* centre in the base frame, half extents */
+  float c[3], h[3]; /* centre in the base frame; box: half extents, cylinder: radius, radius, half length */
+  int32_t kind;     /* 0 box, 1 cylinder along the link z axis (primitive_drone.urdf:42-47 prop discs) */
 } pf_box;
 
 /* one lifting surface: abstractions/lifting_surfaces.py:141-239 (constants precomputed on host) */

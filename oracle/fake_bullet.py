@@ -84,6 +84,7 @@ class _Link:
         self.inertial_origin = np.zeros(3)
         self.joint_origin = np.zeros(3)
         self.boxes = []  # (centre in link frame, half extents)
+        self.cyls = []   # (centre in link frame, radius, half length), axis = link z
 
 
 class _Body:
@@ -118,6 +119,28 @@ class _Body:
                 centre = self.p + R @ ((l.joint_origin + c) * self.scale)
                 out.append((centre, R, h * self.scale))
         return out
+
+    def world_cyls(self):
+        R = matrix_from_quat(self.q)
+        out = []
+        for l in self.links:
+            for c, rad, hl in l.cyls:
+                centre = self.p + R @ ((l.joint_origin + c) * self.scale)
+                out.append((centre, R[:, 2].copy(), rad * self.scale, hl * self.scale))
+        return out
+
+
+def _cyl_aabb_overlap(c, axis, radius, half_len, cb, hb):
+    """Cylinder (centre c, unit axis, radius, half length) against a world-axis-aligned box:
+    separating-axis test on the box's three face normals with the cylinder's exact support extent
+    h|a_k| + r sqrt(1 - a_k^2) along each. Exact whenever the closest feature of the box is a face --
+    for the 30 m ground slab, everywhere except within one prop radius of its rim. [BULLET-FROM-MEMORY]:
+    Bullet runs GJK/EPA on the convex pair; the verdict compared here is penetration >= 0, as for boxes."""
+    for k in range(3):
+        ext = half_len * abs(axis[k]) + radius * np.sqrt(max(0.0, 1.0 - axis[k] * axis[k]))
+        if abs(c[k] - cb[k]) - (hb[k] + ext) > 0.0:
+            return False
+    return True
 
 
 def _box_box_overlap(ca, Ra, ha, cb, hb):
@@ -168,6 +191,9 @@ def parse_urdf(path):
             box = ce.find("geometry").find("box")
             if box is not None:
                 l.boxes.append((c, 0.5 * _vec(box.get("size"))))
+            cyl = ce.find("geometry").find("cylinder")
+            if cyl is not None:  # URDF cylinders stand along the link z axis
+                l.cyls.append((c, float(cyl.get("radius")), 0.5 * float(cyl.get("length"))))
         links[l.name] = l
         order.append(l.name)
     children = set()
@@ -345,6 +371,9 @@ class BulletClient:
                     assert np.allclose(Rb, np.eye(3))
                     for ca, Ra, ha in free.world_boxes():
                         if _box_box_overlap(ca, Ra, ha, cb, hb):
+                            hit = True
+                    for cc, ax, rad, hl in free.world_cyls():
+                        if _cyl_aabb_overlap(cc, ax, rad, hl, cb, hb):
                             hit = True
                 if hit:
                     self._contacts.append((0, idf, idr, -1, -1))

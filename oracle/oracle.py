@@ -35,7 +35,7 @@ class PidGains(C.Structure):
 
 
 class Box(C.Structure):
-    _fields_ = [("c", d3), ("h", d3)]
+    _fields_ = [("c", d3), ("h", d3), ("kind", C.c_int)]
 
 
 class Surface(C.Structure):
@@ -165,7 +165,7 @@ def lib():
         L.orc_env_reset_batch.argtypes = [PP, LP, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_step_batch.argtypes = [PP, LP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        for f in ("orc_params_quadx", "orc_params_fixedwing", "orc_task_hover", "orc_task_quadx_waypoints",
+        for f in ("orc_params_quadx", "orc_params_fixedwing", "orc_params_primitive_drone", "orc_task_hover", "orc_task_quadx_waypoints",
                   "orc_task_fixedwing_waypoints", "orc_task_ma_hover", "orc_finalize"):
             getattr(L, f).argtypes = [PP]
         _lib = L
@@ -184,7 +184,9 @@ def make_params(env: str, noise_mode: int = NOISE_OFF, seed: int = 0, **override
     """env in {'quadx', 'fixedwing', 'hover', 'quadx_waypoints', 'fixedwing_waypoints'}."""
     L = lib()
     P = Params()
-    if env in ("quadx", "hover", "quadx_waypoints", "ma_hover"):
+    if env == "primitive_drone":
+        L.orc_params_primitive_drone(C.byref(P))
+    elif env in ("quadx", "hover", "quadx_waypoints", "ma_hover"):
         L.orc_params_quadx(C.byref(P))
     else:
         L.orc_params_fixedwing(C.byref(P))

@@ -193,7 +193,23 @@ int orc_contact_plane(const orc_params* P, const double p[3], const double q[4])
     double off[3], ca[3];
     matvec(R, P->boxes[k].c, off);
     ca[0] = p[0] + off[0]; ca[1] = p[1] + off[1]; ca[2] = p[2] + off[2];
-    if (orc_box_box_overlap(ca, R, P->boxes[k].h, cb, hb)) return 1;
+    if (P->boxes[k].kind == 1) {
+      /* Cylinder along the link z axis against the ground slab: separating-axis test on the slab's
+       * three face normals with the cylinder's exact support extent h|a_k| + r sqrt(1 - a_k^2); exact
+       * except within one radius of the slab's rim. [BULLET-FROM-MEMORY]: Bullet runs GJK/EPA on this
+       * convex pair; as for the boxes, the verdict restated is penetration >= 0. */
+      const double r = P->boxes[k].h[0], hl = P->boxes[k].h[2];
+      int sep = 0;
+      for (int a = 0; a < 3; ++a) {
+        double ax = R[a][2];
+        double s2 = 1.0 - ax * ax;
+        double ext = hl * fabs(ax) + r * sqrt(s2 > 0.0 ? s2 : 0.0);
+        if (fabs(ca[a] - cb[a]) - (hb[a] + ext) > 0.0) sep = 1;
+      }
+      if (!sep) return 1;
+    } else if (orc_box_box_overlap(ca, R, P->boxes[k].h, cb, hb)) {
+      return 1;
+    }
   }
   return 0;
 }
@@ -545,6 +561,54 @@ void orc_params_quadx(orc_params* P) {
   P->start_pos[2] = 1.0;           /* quadx_base_env.py:23 */
   P->settle_steps = 10;
   P->angle_repr = 1;
+  orc_finalize(P);
+}
+
+/* QuadX with drone_model="primitive_drone" (quadx.py:29; used by examples/core/08_mixed_drones.py and
+ * the pole / ball-in-cup envs): models/vehicles/primitive_drone/primitive_drone.{urdf,yaml}. */
+void orc_params_primitive_drone(orc_params* P) {
+  orc_params_quadx(P);
+  /* primitive_drone.urdf:27-30 */
+  P->mass = 1.0;
+  P->I_own[0][0] = 0.01; P->I_own[1][1] = 0.01; P->I_own[2][2] = 0.016;
+  /* collision: base box 0.2 x 0.1 x 0.05 (:21-26) + four prop discs, cylinders r 0.12, length 0.01
+   * (:42-47,69-74,96-101,123-128) at the prop joints (:56,83,110,138) */
+  const double rx[4] = {0.16, -0.16, 0.16, -0.16}, ry[4] = {-0.16, 0.16, 0.16, -0.16};
+  P->n_boxes = 5;
+  memset(P->boxes, 0, sizeof(P->boxes));
+  P->boxes[0].h[0] = 0.1; P->boxes[0].h[1] = 0.05; P->boxes[0].h[2] = 0.025;
+  for (int i = 0; i < 4; ++i) {
+    P->boxes[1 + i].kind = 1;
+    P->boxes[1 + i].c[0] = rx[i]; P->boxes[1 + i].c[1] = ry[i];
+    P->boxes[1 + i].h[0] = 0.12; P->boxes[1 + i].h[1] = 0.12; P->boxes[1 + i].h[2] = 0.005;
+  }
+  /* primitive_drone.yaml:1-6 */
+  const double total_thrust = 40.0, thrust_coef = 3.0e-7, torque_coef = 3.0e-7, noise = 0.003, tau = 0.01;
+  const double tq[4] = {-1, -1, +1, +1};
+  for (int i = 0; i < 4; ++i) {
+    P->motor_r[i][0] = rx[i]; P->motor_r[i][1] = ry[i];
+    P->thrust_coef[i] = thrust_coef;
+    P->torque_coef[i] = tq[i] * torque_coef;
+    P->max_rpm[i] = sqrt(total_thrust / (4 * thrust_coef));
+    P->motor_tau[i] = tau;
+    P->noise_ratio[i] = noise;
+  }
+  for (int k = 0; k < 3; ++k) P->drag_const[k] = 0.5 * 1.225 * 2.0 * 0.08; /* primitive_drone.yaml:8-11 */
+  P->drag_coef_pqr = 1.0e-4;
+  { /* primitive_drone.yaml:13-54 */
+    const double kp0[3] = {1.5e-2, 1.5e-2, 5.0e-3}, ki0[3] = {1.0e-5, 1.0e-5, 2.0e-6}, kd0[3] = {1.2e-5, 1.2e-5, 1.2e-6}, l0[3] = {1, 1, 1};
+    const double kp1[3] = {2, 2, 2}, z3[3] = {0, 0, 0}, l1[3] = {6, 6, 6};
+    const double kp2[2] = {0.3, 0.3}, ki2[2] = {0.03, 0.03}, kd2[2] = {0.3, 0.3}, l2[2] = {1.0, 1.0};
+    const double kp3[2] = {1, 1}, l3[2] = {5, 5};
+    set_pid(&P->pid[0], 3, kp0, ki0, kd0, l0);
+    set_pid(&P->pid[1], 3, kp1, z3, z3, l1);
+    set_pid(&P->pid[2], 2, kp2, ki2, kd2, l2);
+    set_pid(&P->pid[3], 2, kp3, z3, z3, l3);
+    const double zvkp = 3.0, zvki = 0.8, zvkd = 0.2, zvl = 1.0;
+    const double zpkp = 1.0, zero = 0.0, zpl = 3.0;
+    set_pid(&P->zpid[0], 1, &zvkp, &zvki, &zvkd, &zvl);
+    set_pid(&P->zpid[1], 1, &zpkp, &zero, &zero, &zpl);
+  }
   orc_finalize(P);
 }
 

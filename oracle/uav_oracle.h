@@ -50,7 +50,8 @@ typedef struct {
 
 typedef struct {
   double c[3];  /* centre in base frame */
-  double h[3];  /* half extents */
+  double h[3];  /* box: half extents; cylinder (axis = link z): radius, radius, half length */
+  int kind;     /* 0 box, 1 cylinder (primitive_drone.urdf:42-47: the prop discs) */
 } orc_box;
 
 /* One lifting surface -- lifting_surfaces.py:141-239, fixedwing.yaml:8-71 */
@@ -168,6 +169,7 @@ typedef struct {
 /* ---------- parameter sets (numbers copied from the reference's YAML/URDF, cited in .c) ---------- */
 void orc_params_quadx(orc_params* P);
 void orc_params_fixedwing(orc_params* P);
+void orc_params_primitive_drone(orc_params* P);
 void orc_task_hover(orc_params* P);
 void orc_task_quadx_waypoints(orc_params* P);
 void orc_task_fixedwing_waypoints(orc_params* P);

@@ -25,7 +25,7 @@ class PfPid(C.Structure):
 
 
 class PfBox(C.Structure):
-    _fields_ = [("c", f3), ("h", f3)]
+    _fields_ = [("c", f3), ("h", f3), ("kind", C.c_int32)]
 
 
 class PfSurface(C.Structure):

@@ -4,6 +4,8 @@ that each live in their OWN world (independent lanes), stepped by the HIP kernel
 Same surface as the reference where it is on the hot path:
   Aviary(start_pos[N,3], start_orn[N,3], drone_type, drone_options=..., physics_hz=240,
          world_scale=1.0, seed=...)                           core/aviary.py:69-216
+         drone_options: control_hz, starting_velocity, drone_model ("cf2x" | "primitive_drone",
+         quadx.py:29), or any entry of the parameter tables in pyflyt_amd/params.py
   reset()                                                     :218-312
   set_mode(int) / set_setpoint(i, sp) / set_all_setpoints(sp) :440-478
   step()                                                      :480-531

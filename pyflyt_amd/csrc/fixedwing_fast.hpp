@@ -83,6 +83,8 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
   if (P.motor_r[0][0] != 0.f || P.motor_r[0][1] != 0.f || P.motor_r[0][2] != 0.f) return false;
   if (P.thrust_unit[0][0] != 1.f || P.thrust_unit[0][1] != 0.f || P.thrust_unit[0][2] != 0.f) return false;
   if (P.wp_yaw_penalty != 0.f) return false;
+  for (int k = 0; k < P.n_boxes; ++k)
+    if (P.boxes[k].kind != 0) return false;  // fw_floor_contact tests boxes only
   Bd.dt = P.dt; Bd.half_dt = 0.5f * P.dt; Bd.gravity_z = P.gravity_z; Bd.vmax = P.max_coord_vel; Bd.inv_mass = P.inv_mass;
   for (int k = 0; k < 6; ++k) { Bd.H[k] = P.I_pa[k] + (P.use_gyro_term ? P.I_own[k] : 0.f); Bd.iI[k] = P.I_inv[k]; }
   for (int k = 0; k < 3; ++k) Bd.com[k] = P.has_com_offset ? P.com[k] : 0.f;

@@ -62,7 +62,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   }
   if (!(P.motor_tmax[0] == P.motor_tmax[1] && P.motor_tmax[2] == P.motor_tmax[3] && P.motor_tmax[0] == -P.motor_tmax[2] &&
         P.motor_tmax[0] <= 0.f)) return false;
-  if (P.n_boxes != 1 || P.num_targets > 4) return false;
+  if (P.n_boxes != 1 || P.boxes[0].kind != 0 || P.num_targets > 4) return false;
   if (P.ticks_per_control != 2 || P.env_step_ratio > 4 || P.env_step_ratio < 1) return false;
   if ((P.settle_steps * 2) % 4 != 0 || P.settle_steps * 2 > 24) return false;
   K.dt = P.dt; K.half_dt = 0.5f * P.dt; K.gravity_z = P.gravity_z; K.vmax = P.max_coord_vel; K.inv_mass = P.inv_mass;

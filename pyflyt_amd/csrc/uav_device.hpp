@@ -222,6 +222,22 @@ PF_DEV bool box_overlaps_aabb(v3 ca, const m3& R, const float ha[3], v3 cb, cons
   return !sep;
 }
 
+// Cylinder (centre c, axis = third column of R, radius r, half length hl) against the world-aligned
+// ground box: separating-axis test on the box's face normals with the cylinder's exact support
+// extent; see oracle/uav_oracle.c:orc_contact_plane for the restated rule.
+PF_DEV bool cyl_overlaps_aabb(v3 c, const m3& R, float r, float hl, v3 cb, const float hb[3]) {
+  const float ax[3] = {R.m02, R.m12, R.m22};
+  const float t[3] = {c.x - cb.x, c.y - cb.y, c.z - cb.z};
+  bool sep = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float s2 = __builtin_fmaxf(1.0f - ax[k] * ax[k], 0.0f);
+    float ext = hl * __builtin_fabsf(ax[k]) + r * __builtin_sqrtf(s2);
+    sep |= (__builtin_fabsf(t[k]) - (hb[k] + ext) > 0.0f);
+  }
+  return !sep;
+}
+
 // ---------------------------------------------------------------- counter-based RNG
 // Philox4x32-10; integer stream bit-identical to oracle/uav_oracle.c:orc_philox4x32.
 struct u32x4 {

@@ -72,7 +72,8 @@ struct Body {
     for (int k = 0; k < PF_MAX_BOXES; ++k) {
       if (k < P.n_boxes) {
         v3 c = p + mul(R, v3{P.boxes[k].c[0], P.boxes[k].c[1], P.boxes[k].c[2]});
-        hit |= box_overlaps_aabb(c, R, P.boxes[k].h, cb, hb);
+        if (P.boxes[k].kind == 1) hit |= cyl_overlaps_aabb(c, R, P.boxes[k].h[0], P.boxes[k].h[2], cb, hb);
+        else hit |= box_overlaps_aabb(c, R, P.boxes[k].h, cb, hb);
       }
     }
     return hit;

@@ -41,6 +41,36 @@ CF2X: dict[str, Any] = {
     "control_hz": 120,  # drones/quadx.py:27
 }
 
+# QuadX(drone_model="primitive_drone") (drones/quadx.py:29; examples/core/08_mixed_drones.py, the pole and
+# ball-in-cup envs): same airframe code, another model folder.
+PRIMITIVE_DRONE: dict[str, Any] = {
+    # models/vehicles/primitive_drone/primitive_drone.urdf:27-30 (base link), :21-26 (collision box),
+    # :42-47,69-74,96-101,123-128 (prop discs: cylinders r 0.12, length 0.01), :56,83,110,138 (prop joints)
+    "mass": 1.0,
+    "inertia_diag": (0.01, 0.01, 0.016),
+    "collision_boxes": [((0.0, 0.0, 0.0), (0.2, 0.1, 0.05))],
+    "collision_cylinders": [((0.16, -0.16, 0.0), 0.12, 0.01), ((-0.16, 0.16, 0.0), 0.12, 0.01),
+                            ((0.16, 0.16, 0.0), 0.12, 0.01), ((-0.16, -0.16, 0.0), 0.12, 0.01)],
+    "motor_r": [(0.16, -0.16, 0.0), (-0.16, 0.16, 0.0), (0.16, 0.16, 0.0), (-0.16, -0.16, 0.0)],
+    # models/vehicles/primitive_drone/primitive_drone.yaml:1-6
+    "total_thrust": 40.0, "thrust_coef": 3.0e-7, "torque_coef": 3.0e-7, "noise_ratio": 0.003, "motor_tau": 0.01,
+    "torque_signs": (-1.0, -1.0, 1.0, 1.0),
+    "motor_map": [(-1.0, -1.0, -1.0, 1.0), (1.0, 1.0, -1.0, 1.0), (1.0, -1.0, 1.0, 1.0), (-1.0, 1.0, 1.0, 1.0)],
+    # primitive_drone.yaml:8-11
+    "drag_coef_xyz": 2.0, "drag_area_xyz": 0.08, "drag_coef_pqr": 1.0e-4,
+    # primitive_drone.yaml:13-54 (kp, ki, kd, lim)
+    "pid": {
+        "ang_vel": ([1.5e-2, 1.5e-2, 5.0e-3], [1.0e-5, 1.0e-5, 2.0e-6], [1.2e-5, 1.2e-5, 1.2e-6], [1.0, 1.0, 1.0]),
+        "ang_pos": ([2.0, 2.0, 2.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [6.0, 6.0, 6.0]),
+        "lin_vel": ([0.3, 0.3], [0.03, 0.03], [0.3, 0.3], [1.0, 1.0]),
+        "lin_pos": ([1.0, 1.0], [0.0, 0.0], [0.0, 0.0], [5.0, 5.0]),
+        "z_pos": ([1.0], [0.0], [0.0], [3.0]),
+        "z_vel": ([3.0], [0.8], [0.2], [1.0]),
+    },
+    "control_hz": 120,
+}
+QUADX_MODELS = {"cf2x": CF2X, "primitive_drone": PRIMITIVE_DRONE}
+
 _SURF_COMMON = dict(Cl_alpha_2D=6.283, flap_to_chord=0.3, eta=0.65, Cd_0=0.01, tau=0.05)
 FIXEDWING: dict[str, Any] = {
     # models/vehicles/fixedwing/fixedwing.urdf: (mass, link origin) -- all link inertias are zero
@@ -114,8 +144,9 @@ def _fill(arr, vals):
         arr[i] = v
 
 
-def _set_body(P, links, own_inertia, boxes):
-    """links: [(mass, r)], own_inertia: 3x3 sum of link inertias (base frame, about their own COMs)."""
+def _set_body(P, links, own_inertia, boxes, cylinders=()):
+    """links: [(mass, r)], own_inertia: 3x3 sum of link inertias (base frame, about their own COMs).
+    boxes: [(centre, size)]; cylinders: [(centre, radius, length)], axis = link z."""
     m = np.array([l[0] for l in links], dtype=np.float64)
     r = np.array([l[1] for l in links], dtype=np.float64)
     M = m.sum()
@@ -131,12 +162,16 @@ def _set_body(P, links, own_inertia, boxes):
     _fill(P.I_pa, _sym6(I_pa))
     _fill(P.I_inv, _sym6(I_inv))
     P.has_com_offset = int(np.abs(com).max() > 0.0)
-    P.n_boxes = len(boxes)
+    if len(boxes) + len(cylinders) > L.PF_MAX_BOXES:
+        raise ValueError(f"at most {L.PF_MAX_BOXES} collision shapes per vehicle")
+    P.n_boxes = len(boxes) + len(cylinders)
     rad = 0.0
-    for k, (c, size) in enumerate(boxes):
-        h = 0.5 * np.array(size, dtype=np.float64)
+    shapes = [(c, 0.5 * np.array(size, dtype=np.float64), 0) for c, size in boxes] + \
+             [(c, np.array([r, r, 0.5 * length], dtype=np.float64), 1) for c, r, length in cylinders]
+    for k, (c, h, kind) in enumerate(shapes):
         _fill(P.boxes[k].c, c)
         _fill(P.boxes[k].h, h)
+        P.boxes[k].kind = kind
         rad = max(rad, float(np.linalg.norm(np.abs(np.array(c)) + h)))
     # nudged up so that fp32 rounding can never make the early-out stricter than the exact test
     P.bound_radius = rad * (1.0 + 1e-6)
@@ -188,10 +223,15 @@ def build_params(
     P.settle_steps = 10  # gym_envs/quadx_envs/quadx_base_env.py:209
 
     if vehicle == "quadx":
-        V = copy.deepcopy(CF2X)
-        V.update(vehicle_options or {})
+        vo = dict(vehicle_options or {})
+        model = vo.pop("drone_model", "cf2x")  # drones/quadx.py:29
+        if model not in QUADX_MODELS:
+            raise ValueError(f"unknown QuadX drone_model {model!r}; available: {sorted(QUADX_MODELS)}")
+        V = copy.deepcopy(QUADX_MODELS[model])
+        V.update(vo)
         P.vehicle = L.QUADX
-        _set_body(P, [(V["mass"], (0.0, 0.0, 0.0))], np.diag(V["inertia_diag"]).astype(np.float64), V["collision_boxes"])
+        _set_body(P, [(V["mass"], (0.0, 0.0, 0.0))], np.diag(V["inertia_diag"]).astype(np.float64), V["collision_boxes"],
+                  V.get("collision_cylinders", ()))
         P.n_motors = 4
         max_rpm = math.sqrt(V["total_thrust"] / (4.0 * V["thrust_coef"]))  # drones/quadx.py:111-113
         for i in range(4):

@@ -220,6 +220,18 @@ def gen_aviary():
         save(f"aviary_fixedwing_mode{mode}".replace("-1", "m1"), **d)
 
 
+def gen_primitive():
+    # QuadX(drone_model="primitive_drone") (quadx.py:29): another parameter set + cylinder prop colliders
+    opts = dict(drone_model="primitive_drone")
+    for mode in (0, 6, 7):
+        d = run_aviary("quadx", mode, 150, seed=300 + mode, start_pos=[0.3, -0.2, 1.5], start_orn=[0.05, -0.08, 0.6],
+                       noise=True, drone_options=opts)
+        save(f"aviary_primitive_mode{mode}", **d)
+    # a tilted drop: a prop disc (cylinder) reaches the floor before the base box does
+    d = run_aviary("quadx", 0, 120, seed=5, start_pos=[0.0, 0.0, 0.30], start_orn=[0.5, 0.2, 0.0], noise=False, drone_options=opts)
+    save("aviary_primitive_drop", **d)
+
+
 def gen_wind():
     # wind hook (aviary.py:266-285,324-333; boring_bodies.py:93-96; lifting_surfaces.py:88-93)
     d = run_aviary("quadx", 6, 150, seed=41, start_pos=[0.3, -0.2, 1.5], start_orn=[0.05, -0.08, 0.6], noise=True, wind="register")
@@ -383,3 +395,4 @@ if __name__ == "__main__":
     gen_envs_crash()
     gen_ma_hover()
     gen_wind()
+    gen_primitive()

@@ -43,11 +43,12 @@ def sample_setpoint(rng, n, drone, mode):
     }[mode]()
 
 
-CASES = [("quadx", m) for m in range(-1, 8)] + [("fixedwing", 0), ("fixedwing", -1)]
+CASES = [("quadx", m, "cf2x") for m in range(-1, 8)] + [("fixedwing", 0, None), ("fixedwing", -1, None)] + \
+        [("quadx", m, "primitive_drone") for m in (0, 6, 7)]  # QuadX(drone_model="primitive_drone"), quadx.py:29
 
 
-@pytest.mark.parametrize("drone,mode", CASES)
-def test_aviary_parity(drone, mode):
+@pytest.mark.parametrize("drone,mode,model", CASES)
+def test_aviary_parity(drone, mode, model):
     from pyflyt_amd.core import Aviary
 
     n, steps, seed = 128, 120, 40 + mode
@@ -55,7 +56,8 @@ def test_aviary_parity(drone, mode):
     z0 = 1.5 if drone == "quadx" else 10.0
     start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(z0, z0 + 1.0, size=(n, 1))], axis=1)
     start_orn = rng.uniform(-0.15, 0.15, size=(n, 3)) * np.array([1, 1, 5.0])
-    env = Aviary(start_pos, start_orn, drone_type=drone, seed=seed)
+    primitive = model == "primitive_drone"
+    env = Aviary(start_pos, start_orn, drone_type=drone, seed=seed, drone_options=dict(drone_model=model) if primitive else None)
     env.set_mode(mode)
 
     lib = O.lib()
@@ -63,7 +65,7 @@ def test_aviary_parity(drone, mode):
     # the oracle sees the fp32-rounded spawn the device was given
     sp32 = start_pos.astype(np.float32).astype(np.float64)
     for i in range(n):
-        P = O.make_params(drone, noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=sp32[i], start_rpy=start_orn[i])
+        P = O.make_params("primitive_drone" if primitive else drone, noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=sp32[i], start_rpy=start_orn[i])
         L = O.Lane()
         lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
         lib.orc_set_mode(C.byref(P), C.byref(L), mode)
@@ -81,6 +83,13 @@ def test_aviary_parity(drone, mode):
     worst = 0.0
     ok = np.ones(n, dtype=bool)
     ok25 = None
+    # primitive_drone's z_vel PID has kd/T = 0.2 * 120 = 24 per control tick (primitive_drone.yaml:50-54, cf2x: 6):
+    # its cascaded modes chatter between the throttle limits and amplify fp32 rounding so fast that an
+    # fp32 build of the ORACLE is itself 1e-3 .. 3e-2 (median lane) away from the fp64 one after 120
+    # steps (`python tests/tools/fp32_sensitivity.py primitive_drone`: mode 6 86 %, mode 7 98 % of the
+    # lanes beyond 1e-4). So: every lane within 1e-4 over the first 8 steps, bounded drift after that;
+    # mode 0 (no z PIDs) holds the full criterion.
+    strict_steps = 8 if (primitive and mode > 0) else 25
     for k in range(steps):
         if k % 20 == 5:
             sp = sample_setpoint(rng, n, drone, mode).astype(np.float32)
@@ -100,15 +109,51 @@ def test_aviary_parity(drone, mode):
         contact = np.array([bool(L.contact_step) for L in Ls])
         ok &= (e < RTOL) & (env.contact_array.cpu().numpy() == contact)
         worst = max(worst, e[ok].max() if ok.any() else 0.0)
-        if k == 24:
+        if k == strict_steps - 1:
             ok25 = ok.copy()
     med = float(np.median(e))
-    print(f"aviary {drone} mode {mode}: worst rel err {worst:.2e}, dropped@25 {1 - ok25.mean():.4f}, dropped@{steps} {1 - ok.mean():.4f}, "
+    print(f"aviary {drone}{'/primitive' if primitive else ''} mode {mode}: worst rel err {worst:.2e}, dropped@{strict_steps} {1 - ok25.mean():.4f}, dropped@{steps} {1 - ok.mean():.4f}, "
           f"median lane err at end {med:.1e}")
     assert 1 - ok25.mean() <= 0.01
-    assert med < RTOL
+    assert med < (RTOL if not (primitive and mode > 0) else 0.1)
     if drone == "fixedwing" or mode in (-1, 0):
         assert 1 - ok.mean() <= 0.01
+    env.disconnect()
+
+
+def test_primitive_drone_prop_disc_contact():
+    """Tilted drops of the primitive drone: a prop disc (cylinder collider, primitive_drone.urdf:42-47)
+    reaches the floor before the base box; the contact flag must rise on the same Aviary step as in
+    the oracle for every lane."""
+    from pyflyt_amd.core import Aviary
+
+    n = 128
+    rng = np.random.default_rng(5)
+    start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(0.25, 0.5, size=(n, 1))], axis=1)
+    start_orn = np.concatenate([rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-3, 3, size=(n, 1))], axis=1)
+    env = Aviary(start_pos, start_orn, drone_type="quadx", seed=1, motor_noise=False, drone_options=dict(drone_model="primitive_drone"))
+    env.set_mode(0)
+    lib = O.lib()
+    sp32 = start_pos.astype(np.float32).astype(np.float64)
+    Ps, Ls = [], []
+    for i in range(n):
+        P = O.make_params("primitive_drone", noise_mode=O.NOISE_OFF, start_pos=sp32[i], start_rpy=start_orn[i])
+        L = O.Lane()
+        lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
+        lib.orc_set_mode(C.byref(P), C.byref(L), 0)
+        Ps.append(P); Ls.append(L)
+    first_g = np.full(n, -1); first_r = np.full(n, -1)
+    for k in range(80):
+        env.step()
+        cg = env.contact_array.cpu().numpy()
+        for i, (P, L) in enumerate(zip(Ps, Ls)):
+            lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+            if L.contact_step and first_r[i] < 0:
+                first_r[i] = k
+        first_g[(first_g < 0) & cg] = k
+    assert (first_r >= 0).all()
+    # a lane whose lowest point crosses z = 0 within fp32 rounding of a tick boundary may flip by one step
+    assert (np.abs(first_g - first_r) <= 1).all() and (first_g == first_r).mean() >= 0.97
     env.disconnect()
 
 

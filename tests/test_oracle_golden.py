@@ -88,7 +88,12 @@ def lane_state(L, fixedwing):
 
 
 AVIARY = [f"aviary_quadx_mode{m}" for m in ["m1", 0, 1, 2, 3, 4, 5, 6, 7, "7_nonoise"]] + \
-         ["aviary_fixedwing_mode0", "aviary_fixedwing_modem1"]
+         ["aviary_fixedwing_mode0", "aviary_fixedwing_modem1"] + \
+         [f"aviary_primitive_mode{m}" for m in (0, 6, 7)]  # QuadX(drone_model="primitive_drone")
+
+
+def model_of(name):
+    return "fixedwing" if "fixedwing" in name else ("primitive_drone" if "primitive" in name else "quadx")
 
 
 @pytest.mark.parametrize("name", AVIARY)
@@ -96,7 +101,7 @@ def test_aviary_trajectory(golden_dir, name):
     g = load(golden_dir, name)
     fw = "fixedwing" in name
     noise = bool(g["noise"])
-    P = O.make_params("fixedwing" if fw else "quadx", noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF,
+    P = O.make_params(model_of(name), noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF,
                       start_pos=g["start_pos"], start_rpy=g["start_orn"])
     L = O.Lane()
     lib = O.lib()
@@ -177,14 +182,14 @@ def test_aviary_wind_trajectory(golden_dir, name):
     assert np.abs(lane_state(L2, fw)[0] - g["states"][-1]).max() > 1e-3
 
 
-@pytest.mark.parametrize("name", ["aviary_quadx_drop", "aviary_fixedwing_drop"])
+@pytest.mark.parametrize("name", ["aviary_quadx_drop", "aviary_fixedwing_drop", "aviary_primitive_drop"])
 def test_aviary_drop_contact(golden_dir, name):
     """Fall onto the floor: the contact flag must rise on the same Aviary step as in the
     reference-on-fake-Bullet run (neither side restates a contact response)."""
     g = load(golden_dir, name)
     fw = "fixedwing" in name
     noise = bool(g["noise"])
-    P = O.make_params("fixedwing" if fw else "quadx", noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF,
+    P = O.make_params(model_of(name), noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF,
                       start_pos=g["start_pos"], start_rpy=g["start_orn"])
     L = O.Lane()
     lib = O.lib()

@@ -6,7 +6,7 @@ tests/test_gpu_aviary.py. It shows that the drift seen on the GPU in the cascade
 the z PIDs (cf2x.yaml:43-54: z_vel kd = 0.05 at 120 Hz is a derivative gain of 6 per tick) is a
 property of the reference's controller in fp32, not of the kernels. Results are quoted in DESIGN.md.
 
-usage: python tests/tools/fp32_sensitivity.py
+usage: python tests/tools/fp32_sensitivity.py [quadx|primitive_drone]
 """
 import ctypes as C
 import os
@@ -45,6 +45,8 @@ def build_f32():
 
 def main():
     O32 = build_f32()
+    model = sys.argv[1] if len(sys.argv) > 1 else "quadx"  # "quadx" (cf2x) | "primitive_drone"
+    print(f"model {model}")
     for mode in range(-1, 8):
         n, steps, seed = 64, 120, 40 + mode
         rng = np.random.default_rng(seed)
@@ -56,7 +58,7 @@ def main():
             lib = O.lib()
             Ps, Ls = [], []
             for i in range(n):
-                P = O.make_params("quadx", noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=start_pos[i], start_rpy=start_orn[i])
+                P = O.make_params(model, noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=start_pos[i], start_rpy=start_orn[i])
                 L = O.Lane()
                 lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
                 lib.orc_set_mode(C.byref(P), C.byref(L), mode)

@@ -753,6 +753,7 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
   hipStream_t s = (hipStream_t)stream;
   if (ctx->fast) {
     if (P.task == PF_TASK_HOVER) launch_fast<PF_TASK_HOVER>(ctx, b, op, mask, s);
+    else if (P.task == PF_TASK_MA_HOVER) launch_fast<PF_TASK_MA_HOVER>(ctx, b, op, mask, s);
     else launch_fast<PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
   } else if (ctx->fast_fw && ctx->tmpl) {
     launch_fast_fw(ctx, b, op, mask, s);

@@ -1,5 +1,5 @@
-// quadx_fast.hpp -- the hand-tuned hot kernel: QuadX, flight mode 0 (rate PID + thrust), Hover and
-// Waypoints tasks. This is the kernel BASELINE.json's metric is quoted on.
+// quadx_fast.hpp -- the hand-tuned hot kernel: QuadX, flight mode 0 (rate PID + thrust), Hover,
+// Waypoints and multi-agent Hover tasks. This is the kernel BASELINE.json's metric is quoted on.
 //
 // What makes it lean (measured with rocprofv3 PMC, profiles/):
 //   * a compact, vehicle-specific constant block (QuadK, ~60 dwords) instead of the generic
@@ -47,7 +47,7 @@ struct QuadK {
 // Fill QuadK from the ABI struct; returns false when the configuration needs the generic kernel.
 inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   if (P.vehicle != PF_QUADX || P.flight_mode != 0) return false;
-  if (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS) return false;
+  if (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS && P.task != PF_TASK_MA_HOVER) return false;
   if (P.has_com_offset) return false;
   if (P.I_own[1] != 0.f || P.I_own[2] != 0.f || P.I_own[4] != 0.f) return false;  // diagonal inertia only
   for (int k = 0; k < 6; ++k)
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     V.E[0] = g5.y; V.E[1] = g5.z; V.E[2] = g5.w;
     step_count = __float_as_int(gi.x); flags = __float_as_int(gi.y);
     n_left = __float_as_int(gi.w);
-    if (TASK == PF_TASK_WAYPOINTS) {
+    if (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER) {  // MA: spawn pos (3), spawn quat (4), current action (4)
       float4 a = Sin[12 * N + li], b = Sin[13 * N + li], c = Sin[14 * N + li];
       tgt[0][0] = a.x; tgt[0][1] = a.y; tgt[0][2] = a.z; tgt[1][0] = a.w;
       tgt[1][1] = b.x; tgt[1][2] = b.y; tgt[2][0] = b.z; tgt[2][1] = b.w;
@@ -258,6 +258,9 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     }
   }
   old_dist = new_dist;
+  // MA hover (ma_quadx_base_env.py:139-150,326-332): the action of the previous call, observed this call
+  float4 ma_past = float4{0.f, 0.f, 0.f, 0.f};
+  if (TASK == PF_TASK_MA_HOVER) ma_past = Sin[15 * N + li];
   V.contact_now = (flags & PF_F_CONTACT) != 0;
   V.contact_step = false;
   V.derive();
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   float reward = 0.0f;
   bool pop_pending = false;
   bool was_reset = false;
-  const int D = (K.angle_repr ? 13 : 12) + 8 + (TASK == PF_TASK_WAYPOINTS ? 3 * K.num_targets : 0);
+  const int D = (K.angle_repr ? 13 : 12) + 8 + (TASK == PF_TASK_WAYPOINTS ? 3 * K.num_targets : (TASK == PF_TASK_MA_HOVER ? 3 : 0));
   const int settle_ticks = K.settle_steps * 2;
 
   auto pop_target = [&]() {
@@ -329,7 +332,10 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   // skipped, :493 clip); equal thrusts cancel every torque exactly, so the settle ticks are a
   // vertical (z, vz, throttle) recurrence.
   auto reset_lane = [&]() {
-    float thr = 0.f, vz = 0.f, z = K.start_pos[2];
+    // MA hover: the agent's own spawn pose from the side block (level by quadk_from_params' contract:
+    // the host passes the least level / lowest agent as the parameter block's start pose)
+    const float sx = TASK == PF_TASK_MA_HOVER ? tgt[0][0] : K.start_pos[0], sy = TASK == PF_TASK_MA_HOVER ? tgt[0][1] : K.start_pos[1];
+    float thr = 0.f, vz = 0.f, z = TASK == PF_TASK_MA_HOVER ? tgt[0][2] : K.start_pos[2];
     auto settle_tick = [&](float xi) {
       float s = fmaf(xi, K.m_noise, 1.0f);
       thr = fmaf(K.m_a, 0.05f - thr, thr) * s;
@@ -347,8 +353,9 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       else x = float4{0.f, 0.f, 0.f, 0.f};
       settle_tick(x.x); settle_tick(x.y); settle_tick(x.z); settle_tick(x.w);
     }
-    V.p = v3{K.start_pos[0], K.start_pos[1], z};
-    V.q = quat{K.start_quat[0], K.start_quat[1], K.start_quat[2], K.start_quat[3]};
+    V.p = v3{sx, sy, z};
+    if (TASK == PF_TASK_MA_HOVER) V.q = quat{tgt[1][0], tgt[1][1], tgt[1][2], tgt[2][0]};
+    else V.q = quat{K.start_quat[0], K.start_quat[1], K.start_quat[2], K.start_quat[3]};
     V.v = v3{0.f, 0.f, vz}; V.w = v3{0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) { V.thr[k] = thr; V.pwm[k] = 0.05f; }
@@ -357,7 +364,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     V.contact_now = false; V.contact_step = false;
     V.derive();
     step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
-    act0 = act1 = act2 = act3 = 0.f;
+    act0 = act1 = act2 = act3 = 0.f;  // (MA hover: the action memories live in the side block and survive resets)
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = K.num_targets;
       n_left = nt;
@@ -429,8 +436,14 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     else { row[k++] = rpy.x; row[k++] = rpy.y; row[k++] = rpy.z; }
     row[k++] = V.vb.x; row[k++] = V.vb.y; row[k++] = V.vb.z;
     row[k++] = V.p.x; row[k++] = V.p.y; row[k++] = V.p.z;
-    row[k++] = act0; row[k++] = act1; row[k++] = act2; row[k++] = act3;
-    row[k++] = V.thr[0]; row[k++] = V.thr[1]; row[k++] = V.thr[2]; row[k++] = V.thr[3];
+    if (TASK == PF_TASK_MA_HOVER) {  // ma_quadx_hover_env.py:141-166: aux, past action, start_pos
+      row[k++] = V.thr[0]; row[k++] = V.thr[1]; row[k++] = V.thr[2]; row[k++] = V.thr[3];
+      row[k++] = ma_past.x; row[k++] = ma_past.y; row[k++] = ma_past.z; row[k++] = ma_past.w;
+      row[k++] = tgt[0][0]; row[k++] = tgt[0][1]; row[k++] = tgt[0][2];
+    } else {
+      row[k++] = act0; row[k++] = act1; row[k++] = act2; row[k++] = act3;
+      row[k++] = V.thr[0]; row[k++] = V.thr[1]; row[k++] = V.thr[2]; row[k++] = V.thr[3];
+    }
     if (TASK == PF_TASK_WAYPOINTS) {
       m3 Re = rot_from_quat(qe);
 #pragma unroll
@@ -482,6 +495,12 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
     sp0 = a.x; sp1 = a.y; sp2 = a.z; sp3 = a.w;
     reward = -0.1f;
+    if (TASK == PF_TASK_MA_HOVER) {  // past <- current, current <- action (ma_quadx_base_env.py:326-332)
+      ma_past = float4{tgt[2][1], tgt[2][2], tgt[3][0], tgt[3][1]};
+      tgt[2][1] = a.x; tgt[2][2] = a.y; tgt[3][0] = a.z; tgt[3][1] = a.w;
+      reward = 0.0f;
+      term = false; trunc = false;  // per-call flags (:336-337); no early exit from the inner loop (:342-361)
+    }
   }
   bool go = stepping && !(term || trunc);  // quadx_base_env.py:289-290
   for (int s = 0; s < K.env_step_ratio; ++s) {
@@ -504,8 +523,26 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
         new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
       }
       if (step_count > K.max_steps) trunc = true;                                          // quadx_base_env.py:254
+      if (TASK == PF_TASK_MA_HOVER) {  // ma_quadx_hover_env.py:168-205: additive penalties, no early exit
+        if (V.contact_step) { reward -= 100.0f; flags |= PF_F_INFO_COLLISION; term = true; }
+        if (dot(V.p, V.p) > K.dome2) { reward -= 100.0f; flags |= PF_F_INFO_OOB; term = true; }
+        if (!K.task_sparse) {
+          float dx = V.p.x - tgt[0][0], dy = V.p.y - tgt[0][1], dz = V.p.z - tgt[0][2];
+          float lin = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+          quat q = V.q;
+          float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+          float sarg = -2.0f * (q.x * q.z - q.w * q.y) * frcp(sqx + sqy + sqz + squ);
+          bool gim = __builtin_fabsf(sarg) >= 0.99999f;
+          float roll = gim ? 0.0f : fast_atan2(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+          float pitch = gim ? __builtin_copysignf(0.5f * kPi, sarg) : fast_asin(sarg);
+          float ang = fsqrt(fmaf(roll, roll, pitch * pitch));
+          reward -= fmaf(ang, 0.1f, lin);
+          reward += 1.0f;
+        }
+      } else {
       if (V.contact_step) { reward = -100.0f; flags |= PF_F_INFO_COLLISION; term = true; } // :258-261
       if (dot(V.p, V.p) > K.dome2) { reward = -100.0f; flags |= PF_F_INFO_OOB; term = true; } // :264-267
+      }
       if (TASK == PF_TASK_HOVER) {
         if (!K.task_sparse) {  // quadx_hover_env.py:120-138
           float dz = V.p.z - 1.0f;
@@ -522,7 +559,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
           reward -= lin + ang;
           reward += 1.0f;
         }
-      } else {
+      } else if (TASK == PF_TASK_WAYPOINTS) {
         if (!K.task_sparse) {  // quadx_waypoints_env.py:183-192
           float progress = (isinf(old_dist + new_dist)) ? 0.0f : old_dist - new_dist;
           reward += __builtin_fmaxf(3.0f * progress, 0.0f);
@@ -535,7 +572,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
           if (n_left - 1 == 0) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
         }
       }
-      go = !(term || trunc);
+      if (TASK != PF_TASK_MA_HOVER) go = !(term || trunc);
     }
   }
   const float out_reward = stepping ? reward : 0.0f;
@@ -570,7 +607,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     Sout[4 * N + li] = float4{V.thr[2], V.thr[3], V.I[0], V.I[1]};
     Sout[5 * N + li] = float4{V.I[2], V.E[0], V.E[1], V.E[2]};
     Sout[6 * N + li] = float4{__int_as_float(step_count), __int_as_float(flags), __int_as_float((int)rng_ctr), __int_as_float(n_left)};
-    if (TASK == PF_TASK_WAYPOINTS) {
+    if (TASK == PF_TASK_MA_HOVER) Sout[15 * N + li] = ma_past;
+    if (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER) {
       Sout[12 * N + li] = float4{tgt[0][0], tgt[0][1], tgt[0][2], tgt[1][0]};
       Sout[13 * N + li] = float4{tgt[1][1], tgt[1][2], tgt[2][0], tgt[2][1]};
       Sout[14 * N + li] = float4{tgt[2][2], tgt[3][0], tgt[3][1], tgt[3][2]};

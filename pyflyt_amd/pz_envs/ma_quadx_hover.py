@@ -60,7 +60,12 @@ class MAQuadXHoverEnv:
 
     def _build(self, seed):
         A, E = self.num_possible_agents, self.num_envs
-        P = build_params("quadx", "ma_hover", noise=self._noise, autoreset="off", seed=seed, **self._kw)
+        # The kernels take every agent's spawn from the state's side block; the parameter block's start
+        # pose only tells pf_ctx_create whether the specialised kernel's level-spawn settle applies
+        # (quadx_fast.hpp), so it carries the lowest position and the least level orientation of the team.
+        worst_orn = self.start_orn[np.argmax(np.abs(self.start_orn[:, :2]).sum(axis=1))]
+        P = build_params("quadx", "ma_hover", noise=self._noise, autoreset="off", seed=seed,
+                         start_pos=self.start_pos[np.argmin(self.start_pos[:, 2])], start_orn=worst_orn, **self._kw)
         self.engine = BatchEngine(P, A * E, device=self.device)
         # lane = env * A + agent; the per-lane spawn lives in the state's side block
         pose = np.concatenate([self.start_pos, np.stack([quat_from_euler(o) for o in self.start_orn])], axis=1)  # [A,7]

@@ -12,9 +12,14 @@ from oracle import oracle as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def test_ma_hover_parity_and_api():
+@pytest.mark.parametrize("kernel", ["specialised", "generic"])
+def test_ma_hover_parity_and_api(monkeypatch, kernel):
+    """Both device paths of the MA task: the specialised QuadX kernel (quadx_fast.hpp, level spawns) and
+    the generic env_kernel (forced with PF_DISABLE_FAST, also taken when a spawn is tilted)."""
     from pyflyt_amd.pz_envs import MAQuadXHoverEnv
 
+    if kernel == "generic":
+        monkeypatch.setenv("PF_DISABLE_FAST", "1")
     E, seed = 64, 4
     env = MAQuadXHoverEnv(num_envs=E, seed=seed, flight_dome_size=2.5, max_duration_seconds=1.0)
     A = env.num_possible_agents

@@ -30,6 +30,19 @@ json.dump(out, open(os.path.join(dst, "pmc_summary_hover65536.json"), "w"), inde
 json.dump({"env": "hover", "batch": 65536, "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
            "source": "profiles/r01/pmc_summary_hover65536.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per guide)"},
           open(os.path.join(R, "profiles", "pmc_latest.json"), "w"), indent=1)
+other = {}
+for env in ("fixedwing_waypoints", "quadx_waypoints"):
+    for f in glob.glob(os.path.join(src, "pmc_sq_" + env, "*", "*counter_collection.csv")):
+        agg = collections.defaultdict(list); name = ""
+        for r in csv.DictReader(open(f)):
+            if "env_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"])); name = r["Kernel_Name"]
+        w = sum(agg["SQ_WAVES"][10:]) / len(agg["SQ_WAVES"][10:])
+        other[env] = {"kernel": name.split("(")[0], "waves": w,
+                      "per_wave": {k[3:]: sum(v[10:]) / len(v[10:]) / w for k, v in agg.items() if k != "SQ_WAVES"}}
+if other:
+    json.dump(other, open(os.path.join(dst, "pmc_sq_other_kernels65536.json"), "w"), indent=1)
+    print(json.dumps(other, indent=1))
 for f in sorted(glob.glob(os.path.join(dst, "bench_*.json"))):
     d = json.load(open(f)); r = d["roofline"]
     print(os.path.basename(f), "value %.3e" % d["value"], "launch_us %.2f" % r["launch_us"], "achieved %.0f GB/s frac %.3f" % (r["achieved"], r["frac"]),

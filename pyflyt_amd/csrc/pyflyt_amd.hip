@@ -599,7 +599,6 @@ struct pf_ctx {
   pf::QuadK K;
   pf_params* P_dev;  // device copy of P for the rarely-taken floor-contact path
   float4* tmpl;      // settled spawn state for lane-independent resets (env_kernel), or null
-  int n_simd;
   // Fixedwing-Waypoints specialisation (fixedwing_fast.hpp)
   bool fast_fw;
   pf::FwK FK;
@@ -677,7 +676,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
-  c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr; c->n_simd = 1024;
+  c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr;
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
   pf::FwTable fsurf;
   c->fast_fw = pf::fwk_from_params(P, c->FK, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;
@@ -685,8 +684,6 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     int cur = -1;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_simd = prop.multiProcessorCount * 4;
     hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
     if (e == hipSuccess) e = hipMemcpy(c->P_dev, &P, sizeof(pf_params), hipMemcpyHostToDevice);
     if (e == hipSuccess && c->fast_fw) {

@@ -67,12 +67,20 @@ FW_LOW, FW_HIGH = -np.ones(4), np.ones(4)
 
 def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, high, seed=0, gentle=None, max_bad=0.005, **over):
     eng = _engine(vehicle, task, n, noise=noise, autoreset=autoreset, seed=seed,
-                  **{k: v for k, v in over.items() if k in ("goal_reach_distance", "max_duration_seconds", "angle_representation", "sparse_reward")})
+                  **{k: v for k, v in over.items() if k in ("goal_reach_distance", "max_duration_seconds", "angle_representation", "sparse_reward",
+                                                             "agent_hz", "num_targets", "flight_dome_size")})
     oover = {}
     if "goal_reach_distance" in over:
         oover["goal_reach_distance"] = over["goal_reach_distance"]
-    if "max_duration_seconds" in over:
-        oover["max_steps"] = int(over["max_duration_seconds"] * (40 if task == "hover" else 30))
+    hz = over.get("agent_hz", 40 if task == "hover" else 30)
+    if "max_duration_seconds" in over or "agent_hz" in over:
+        oover["max_steps"] = int(over.get("max_duration_seconds", 10.0 if task == "hover" else (10.0 if vehicle == "quadx" else 120.0)) * hz)
+    if "agent_hz" in over:
+        oover["env_step_ratio"] = 120 // hz
+    if "num_targets" in over:
+        oover["num_targets"] = over["num_targets"]
+    if "flight_dome_size" in over:
+        oover["dome"] = over["flight_dome_size"]
     if over.get("angle_representation") == "euler":
         oover["angle_repr"] = 0
     if over.get("sparse_reward"):
@@ -139,6 +147,23 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
           f"dropped lanes {frac_bad:.4f}, episodes ended {n_done}")
     assert frac_bad <= max_bad, frac_bad
     return worst, n_done
+
+
+@pytest.mark.parametrize("vehicle,task,env_name,over", [
+    ("quadx", "hover", "hover", dict(agent_hz=30)),                       # 4 Aviary steps per env step
+    ("quadx", "hover", "hover", dict(agent_hz=60, flight_dome_size=1.5)),  # 2, small dome: many OOB endings
+    ("quadx", "hover", "hover", dict(agent_hz=120, sparse_reward=True)),   # 1
+    ("quadx", "waypoints", "quadx_waypoints", dict(num_targets=1, goal_reach_distance=1.5)),
+    ("quadx", "waypoints", "quadx_waypoints", dict(num_targets=3, agent_hz=40, angle_representation="euler")),
+    ("fixedwing", "waypoints", "fixedwing_waypoints", dict(agent_hz=60, num_targets=2)),
+    ("fixedwing", "waypoints", "fixedwing_waypoints", dict(agent_hz=40, flight_dome_size=60.0, sparse_reward=True)),
+])
+def test_env_constructor_knobs(vehicle, task, env_name, over):
+    """The reference envs' constructor arguments that change the kernel's loop structure or observation
+    width (agent_hz -> Aviary steps per env step, num_targets -> observation width, dome, reward style)."""
+    low, high = (QUAD_LOW, QUAD_HIGH) if vehicle == "quadx" else (FW_LOW, FW_HIGH)
+    worst, n_done = run_env_parity(vehicle, task, env_name, 512, 100, "philox", "next_step", low, high, seed=41, **over)
+    assert worst < RTOL
 
 
 def test_smoke_entry():

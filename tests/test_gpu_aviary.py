@@ -186,3 +186,72 @@ def test_aviary_errors():
     env = Aviary(np.array([[0, 0, 1.0]]), np.zeros((1, 3)))
     with pytest.raises(ValueError):
         env.set_mode(8)
+
+
+@pytest.mark.parametrize("drone", ["quadx", "fixedwing"])
+@pytest.mark.parametrize("world", [
+    dict(physics_hz=480),                                   # 4 ticks per control step, dt = 1/480
+    dict(use_gyro_term=False),                              # the doubtful Bullet facts are parameters:
+    dict(max_coord_vel=6.0),                                #   a velocity clamp that actually bites
+    dict(gravity_z=-3.71, world_scale=2.0),
+])
+def test_world_options_reach_the_kernels(drone, world):
+    """Non-default world constants take the generic path end to end: same constants on both sides,
+    same trajectories. (These are exactly the named [BULLET-FROM-MEMORY] parameters, so a correction
+    from a real PyBullet run is a parameter change, not a code change.)"""
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    n, steps, seed = 96, 60, 90
+    rng = np.random.default_rng(seed)
+    z0 = 1.5 if drone == "quadx" else 10.0
+    start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(z0, z0 + 1.0, size=(n, 1))], axis=1).astype(np.float32)
+    start_orn = rng.uniform(-0.15, 0.15, size=(n, 3)) * np.array([1, 1, 5.0])
+    from pyflyt_amd.params import quat_from_euler
+
+    P = build_params(drone, "none", noise="philox", autoreset="off", seed=seed, world_options=world)
+    eng = BatchEngine(P, n, device="cuda:0")
+    pose = torch.tensor(np.concatenate([start_pos, np.stack([quat_from_euler(o) for o in start_orn])], axis=1), dtype=torch.float32, device="cuda:0").contiguous()
+    eng.aviary_reset(pose)
+    sp = torch.zeros(n, 4, device="cuda:0")
+    eng.aviary_set_mode(0, sp)
+    hz = world.get("physics_hz", 240)
+    over = dict(world_dt=1.0 / hz, world_ticks_per_control=hz // 120)
+    if "use_gyro_term" in world:
+        over["world_use_gyro_term"] = int(world["use_gyro_term"])
+    if "max_coord_vel" in world:
+        over["world_max_coord_vel"] = world["max_coord_vel"]
+    if "gravity_z" in world:
+        over["world_gravity_z"] = world["gravity_z"]
+    if "world_scale" in world:
+        over["world_plane_half_xy"] = 15.0 * world["world_scale"]
+        over["world_plane_half_z"] = 5.0 * world["world_scale"]
+    lib = O.lib()
+    Ps, Ls = [], []
+    for i in range(n):
+        Pi = O.make_params(drone, noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=start_pos[i].astype(np.float64), start_rpy=start_orn[i], **over)
+        L = O.Lane()
+        lib.orc_aviary_reset(C.byref(Pi), C.byref(L), i)
+        lib.orc_set_mode(C.byref(Pi), C.byref(L), 0)
+        Ps.append(Pi); Ls.append(L)
+    worst = 0.0
+    for k in range(steps):
+        if k % 15 == 3:
+            s = sample_setpoint(rng, n, drone, 0).astype(np.float32)
+            sp.copy_(torch.tensor(s))
+            for i, L in enumerate(Ls):
+                for j in range(4):
+                    L.setpoint[j] = float(s[i, j])
+        st_g, aux_g = eng.aviary_step(sp)
+        for Pi, L in zip(Ps, Ls):
+            lib.orc_aviary_step(C.byref(Pi), C.byref(L), None, 0, 0)
+            L.rng_ctr += 1
+        st = np.array([list(L.w_b) + list(L.rpy) + list(L.v_b) + list(L.p) for L in Ls]).reshape(n, 4, 3)
+        g = st_g.cpu().numpy().astype(np.float64).reshape(n, 4, 3)
+        scale = np.maximum(1.0, np.linalg.norm(st, axis=2, keepdims=True))
+        worst = max(worst, float((np.abs(g - st) / scale).max()))
+    print(f"world {world} {drone}: worst {worst:.2e}")
+    assert worst < RTOL
+    if "max_coord_vel" in world and drone == "fixedwing":
+        assert np.abs(np.array([list(L.v) for L in Ls])).max() <= world["max_coord_vel"] + 1e-9  # 20 m/s spawn, clamped
+    eng.close()

@@ -142,6 +142,10 @@ typedef struct pf_buffers {
    * links, lifting_surfaces.py:88-93) */
   const float* wind;       /* [n][K][3] world-frame wind velocity at those links as of the previous update_state, or NULL */
   float* out_link_pos;     /* [n][K][3] world positions of those links after the call, or NULL */
+  /* per-drone control rate (pf_aviary_step / pf_aviary_tick): physics ticks between controller updates of
+   * each drone, a divisor of ticks_per_control (= physics_hz / the SLOWEST drone's control_hz,
+   * aviary.py:288-289; drones given different `control_hz`, tests/test_core.py:34-62). NULL = uniform. */
+  const int32_t* ctrl_ratio; /* [n] */
 } pf_buffers;
 
 typedef struct pf_ctx pf_ctx;

@@ -64,7 +64,31 @@ class Aviary:
         self.drone_type = drone_type
         self.device = torch.device(device)
         self.physics_hz = int(physics_hz)
-        opts = dict(drone_options or {})
+        # drone_options: one dict for the whole batch, or one per drone (core/aviary.py:150-163). Per-drone
+        # dicts may differ in `control_hz` only (tests/test_core.py:34-62): the Aviary then steps at the
+        # slowest controller's rate (aviary.py:288-289) and every drone's controller fires at its own.
+        per_drone_hz = None
+        if isinstance(drone_options, (list, tuple)):
+            if len(drone_options) != self.num_drones:
+                raise AviaryInitException(f"drone_options must be a dict or a sequence of {self.num_drones} dicts")
+            dicts = [dict(d or {}) for d in drone_options]
+            if any("control_hz" in d for d in dicts):
+                per_drone_hz = [int(d.pop("control_hz", 120)) for d in dicts]
+            if any(d != dicts[0] for d in dicts):
+                raise AviaryInitException("per-drone drone_options may differ in `control_hz` only")
+            opts = dicts[0]
+            if per_drone_hz is not None and len(set(per_drone_hz)) > 1:
+                for hz in per_drone_hz:
+                    if self.physics_hz % hz != 0:  # base_drone.py:95-98
+                        raise ValueError(f"`physics_hz` ({self.physics_hz}) must be multiple of `control_hz` ({hz}).")
+                rates = sorted(set(per_drone_hz))
+                if any(b % a != 0 for a, b in zip(rates[:-1], rates[1:])):  # aviary.py:292-297
+                    raise AssertionError("Looprates must form common multiples of each other.")
+                opts["control_hz"] = min(per_drone_hz)
+            elif per_drone_hz is not None:
+                opts["control_hz"], per_drone_hz = per_drone_hz[0], None
+        else:
+            opts = dict(drone_options or {})
         vopts: dict[str, Any] = {}
         if "control_hz" in opts:
             vopts["control_hz"] = int(opts.pop("control_hz"))
@@ -78,6 +102,8 @@ class Aviary:
                          world_options={"physics_hz": self.physics_hz, "world_scale": float(world_scale)})
         self._seed = 0 if seed is None else int(seed)
         self.engine = BatchEngine(P, self.num_drones, device=self.device, lane_offset=lane_offset)
+        if per_drone_hz is not None:
+            self.engine.ctrl_ratio = torch.tensor([self.physics_hz // hz for hz in per_drone_hz], dtype=torch.int32, device=self.device)
         pose = np.concatenate([start_pos, np.stack([quat_from_euler(o) for o in start_orn])], axis=1)
         self._start_pose = torch.tensor(pose, dtype=torch.float32, device=self.device).contiguous()
         self.start_pos, self.start_orn = start_pos, start_orn

@@ -483,9 +483,22 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   for (int k = 0; k < 6; ++k)
     if (k < spn) sp[k] = B.setpoints[li * spn + k];
   bool contact = false;
+  const int ratio = B.ctrl_ratio ? B.ctrl_ratio[li] : 0;
   for (int s = 0; s < n_steps; ++s) {
     nz.begin_event(rng_ctr, 0u, B.xi ? B.xi + (size_t)s * P.ticks_per_control * N : nullptr);
-    V.template aviary_step<kRuntimeMode>(P, sp, nz, 0);
+    if (ratio > 0) {  // this drone's own control rate: controller every `ratio` ticks with period ratio * dt
+      V.b.contact_step = false;
+      for (int t = 0; t < P.ticks_per_control; ++t) {
+        if (t % ratio == 0) {
+          if (t > 0) V.b.rpy = euler_from_quat_fast(V.b.q);
+          V.template control<kRuntimeMode>(P, sp, ratio * P.dt);
+        }
+        V.tick(P, nz.get(t));
+      }
+      V.b.rpy = euler_from_quat_fast(V.b.q);
+    } else {
+      V.template aviary_step<kRuntimeMode>(P, sp, nz, 0);
+    }
     rng_ctr += 1;
     contact = V.b.contact_step;
   }
@@ -538,8 +551,9 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
 #pragma unroll
   for (int k = 0; k < 6; ++k)
     if (k < spn) sp[k] = B.setpoints[li * spn + k];
-  if (tick_index == 0 || !kQuad) {
-    V.template control<kRuntimeMode>(P, sp);  // Fixedwing: stateless mixing, recomputed every tick
+  const int ratio = B.ctrl_ratio ? B.ctrl_ratio[li] : P.ticks_per_control;
+  if (tick_index % ratio == 0 || !kQuad) {
+    V.template control<kRuntimeMode>(P, sp, B.ctrl_ratio ? ratio * P.dt : 0.0f);  // Fixedwing: stateless mixing, recomputed every tick
   } else {
     const float4 c = S[(size_t)kCmdGroup * N + li];
     V.set_cmd(c);

@@ -213,16 +213,19 @@ struct QuadX {
     sp[0] = sp[1] = sp[2] = sp[3] = 0.0f;
     zI[0] = zI[1] = zE[0] = zE[1] = 0.0f;
   }
-  PF_DEV void pid3(const pf_pid& g, const pf_params& P, float* I, float* E, v3 st, float a[3], int n) {
+  PF_DEV void pid3(const pf_pid& g, float T, float invT, float* I, float* E, v3 st, float a[3], int n) {
     const float s[3] = {st.x, st.y, st.z};
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-      if (k < n) a[k] = pid1(g.kp[k], g.ki[k], g.kd[k], g.lim[k], P.control_period, P.inv_control_period, I[k], E[k], s[k], a[k]);
+      if (k < n) a[k] = pid1(g.kp[k], g.ki[k], g.kd[k], g.lim[k], T, invT, I[k], E[k], s[k], a[k]);
   }
-  // update_control (quadx.py:401-493)
+  // update_control (quadx.py:401-493). period_over > 0: this drone's own control period (an Aviary
+  // whose drones run different control_hz, tests/test_core.py:34-62); otherwise the batch-wide one.
   template <int MODE_T>
-  PF_DEV void control(const pf_params& P, const float sp[6]) {
+  PF_DEV void control(const pf_params& P, const float sp[6], float period_over = 0.0f) {
     const int mode = (MODE_T == kRuntimeMode) ? P.flight_mode : MODE_T;
+    const float cT = period_over > 0.0f ? period_over : P.control_period;
+    const float cIT = period_over > 0.0f ? 1.0f / period_over : P.inv_control_period;
     float a[3] = {sp[0], sp[1], sp[2]};
     float z = sp[3];
     if (mode == -1) {
@@ -230,31 +233,29 @@ struct QuadX {
       return;
     }
     if (mode == 0 || mode == 2) {
-      pid3(P.pid[0], P, I0, E0, b.wb, a, 3);
+      pid3(P.pid[0], cT, cIT, I0, E0, b.wb, a, 3);
     } else if (mode == 1 || mode == 3) {
-      pid3(P.pid[1], P, I1, E1, b.rpy, a, 3);
-      pid3(P.pid[0], P, I0, E0, b.wb, a, 3);
+      pid3(P.pid[1], cT, cIT, I1, E1, b.rpy, a, 3);
+      pid3(P.pid[0], cT, cIT, I0, E0, b.wb, a, 3);
     } else {
-      if (mode == 7) pid3(P.pid[3], P, I3, E3, b.p, a, 2);
+      if (mode == 7) pid3(P.pid[3], cT, cIT, I3, E3, b.p, a, 2);
       if (mode == 6 || mode == 7) {  // quadx.py:448-451,460-463
         float s, c;
         sincosf(b.rpy.z, &s, &c);
         float a0 = c * a[0] + s * a[1], a1 = -s * a[0] + c * a[1];
         a[0] = a0; a[1] = a1;
       }
-      pid3(P.pid[2], P, I2, E2, b.vb, a, 2);
+      pid3(P.pid[2], cT, cIT, I2, E2, b.vb, a, 2);
       { float t0 = -a[1], t1 = a[0]; a[0] = t0; a[1] = t1; }
-      pid3(P.pid[1], P, I1, E1, b.rpy, a, mode == 7 ? 3 : 2);
-      pid3(P.pid[0], P, I0, E0, b.wb, a, 3);
+      pid3(P.pid[1], cT, cIT, I1, E1, b.rpy, a, mode == 7 ? 3 : 2);
+      pid3(P.pid[0], cT, cIT, I0, E0, b.wb, a, 3);
     }
     if (mode == 0) {
       z = clampf(z, 0.0f, 1.0f);
     } else {
       if (!(mode == 1 || mode == 5 || mode == 6))
-        z = pid1(P.zpid[1].kp[0], P.zpid[1].ki[0], P.zpid[1].kd[0], P.zpid[1].lim[0], P.control_period,
-                 P.inv_control_period, zI[1], zE[1], b.p.z, z);
-      z = pid1(P.zpid[0].kp[0], P.zpid[0].ki[0], P.zpid[0].kd[0], P.zpid[0].lim[0], P.control_period,
-               P.inv_control_period, zI[0], zE[0], b.vb.z, z);
+        z = pid1(P.zpid[1].kp[0], P.zpid[1].ki[0], P.zpid[1].kd[0], P.zpid[1].lim[0], cT, cIT, zI[1], zE[1], b.p.z, z);
+      z = pid1(P.zpid[0].kp[0], P.zpid[0].ki[0], P.zpid[0].kd[0], P.zpid[0].lim[0], cT, cIT, zI[0], zE[0], b.vb.z, z);
       z = clampf(z, 0.0f, 1.0f);
     }
     // mixing + saturation handling (quadx.py:482-493)
@@ -459,7 +460,7 @@ struct Fixedwing {
   }
   float cmd[6];
   template <int MODE_T>
-  PF_DEV void control(const pf_params& P, const float sp[6]) {  // fixedwing.py:229-259
+  PF_DEV void control(const pf_params& P, const float sp[6], float = 0.0f) {  // fixedwing.py:229-259 (stateless: no period)
     if (P.flight_mode == -1) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) cmd[k] = sp[k];

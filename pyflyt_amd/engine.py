@@ -51,6 +51,7 @@ class BatchEngine:
         self.out_state = None
         self.link_pos = None
         self.wind_links = 0
+        self.ctrl_ratio = None  # [n] int32: physics ticks per controller update of each drone, or None = uniform
         self.out_aux = None
         self.out_contact = None
         self._buf = L.PfBuffers()
@@ -71,6 +72,7 @@ class BatchEngine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _buffers(self, actions=None, xi=None, xi_reset=None, u_targets=None, setpoints=None, start_pose=None, wind=None):
+        # (ctrl_ratio: per-drone control rate, set once by the batched Aviary)
         b = self._buf
         b.state = _ptr(self.state)
         b.actions = _ptr(actions)
@@ -89,6 +91,7 @@ class BatchEngine:
         b.start_pose = _ptr(start_pose)
         b.wind = _ptr(wind)
         b.out_link_pos = _ptr(self.link_pos)
+        b.ctrl_ratio = _ptr(self.ctrl_ratio)
         return b
 
     def _check_f32(self, t, shape, name):

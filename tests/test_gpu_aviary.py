@@ -285,3 +285,54 @@ def test_default_control_reaches_setpoints():
         assert abs(st[1][2] - target[2]) < 0.05                            # yaw
         assert np.abs(np.array(list(L.p)) - st[3]).max() < 0.05            # and the oracle is at the same place
     env.disconnect()
+
+
+@pytest.mark.parametrize("mode,steps", [(0, 40), (1, 8), (7, 6)])
+def test_multi_spawn_different_control_rates(mode, steps):
+    """Mirror of the reference's tests/test_core.py:34-62 (`test_multi_spawn`): three drones in one Aviary
+    with control_hz 60 / 120 / 240. The Aviary steps at the slowest controller's rate (4 physics ticks,
+    aviary.py:288-289); each drone's controller fires at its own rate with its own PID period. Checked
+    against per-drone oracles stepped at their own rates (mode 7 as in the reference's test, over the
+    window in which its fp32-sensitive z PIDs still hold 1e-4; the rate and angle modes for longer)."""
+    from pyflyt_amd.core import Aviary
+
+    rates = [60, 120, 240] * 16
+    n = len(rates)
+    rng = np.random.default_rng(2)
+    start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(1.0, 2.0, size=(n, 1))], axis=1).astype(np.float32)
+    start_orn = np.zeros((n, 3))
+    env = Aviary(start_pos, start_orn, drone_type="quadx", seed=6, drone_options=[dict(control_hz=hz) for hz in rates])
+    assert env.updates_per_step == 4
+    env.set_mode(mode)
+    lib = O.lib()
+    Ps, Ls = [], []
+    for i, hz in enumerate(rates):
+        P = O.make_params("quadx", noise_mode=O.NOISE_OFF, start_pos=start_pos[i].astype(np.float64), control_period=1.0 / hz,
+                          world_ticks_per_control=240 // hz)
+        L = O.Lane()
+        lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
+        lib.orc_set_mode(C.byref(P), C.byref(L), mode)
+        Ps.append(P); Ls.append(L)
+    env.disconnect()
+    env = Aviary(start_pos, start_orn, drone_type="quadx", seed=6, motor_noise=False, drone_options=[dict(control_hz=hz) for hz in rates])
+    env.set_mode(mode)
+    sp = sample_setpoint(rng, n, "quadx", mode).astype(np.float32)
+    env.set_all_setpoints(sp)
+    for i, L in enumerate(Ls):
+        for j in range(4):
+            L.setpoint[j] = float(sp[i, j])
+    worst = 0.0
+    for k in range(steps):
+        env.step()
+        for P, L, hz in zip(Ps, Ls, rates):
+            for _ in range(hz // 60):  # an Aviary step of this world = 4 ticks = hz/60 of the drone's own control steps
+                lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+        st = np.array([list(L.w_b) + list(L.rpy) + list(L.v_b) + list(L.p) for L in Ls]).reshape(n, 4, 3)
+        g = env.all_states.cpu().numpy().astype(np.float64)
+        scale = np.maximum(1.0, np.linalg.norm(st, axis=2, keepdims=True))
+        worst = max(worst, float((np.abs(g - st) / scale).max()))
+    print(f"mixed control rates mode {mode}: worst {worst:.2e}")
+    assert worst < RTOL
+    with pytest.raises(AssertionError):  # aviary.py:292-297
+        Aviary(start_pos[:2], start_orn[:2], drone_type="quadx", drone_options=[dict(control_hz=80), dict(control_hz=120)])
+    env.disconnect()

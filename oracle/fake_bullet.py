@@ -85,6 +85,7 @@ class _Link:
         self.joint_origin = np.zeros(3)
         self.boxes = []  # (centre in link frame, half extents)
         self.cyls = []   # (centre in link frame, radius, half length), axis = link z
+        self.rot = np.eye(3)  # link frame -> base frame (joint rpy; only massless links may be rotated)
 
 
 class _Body:
@@ -116,8 +117,8 @@ class _Body:
         out = []
         for l in self.links:
             for c, h in l.boxes:
-                centre = self.p + R @ ((l.joint_origin + c) * self.scale)
-                out.append((centre, R, h * self.scale))
+                centre = self.p + R @ ((l.joint_origin + l.rot @ c) * self.scale)
+                out.append((centre, R @ l.rot, h * self.scale))
         return out
 
     def world_cyls(self):
@@ -125,8 +126,8 @@ class _Body:
         out = []
         for l in self.links:
             for c, rad, hl in l.cyls:
-                centre = self.p + R @ ((l.joint_origin + c) * self.scale)
-                out.append((centre, R[:, 2].copy(), rad * self.scale, hl * self.scale))
+                centre = self.p + R @ ((l.joint_origin + l.rot @ c) * self.scale)
+                out.append((centre, (R @ l.rot)[:, 2].copy(), rad * self.scale, hl * self.scale))
         return out
 
 
@@ -166,7 +167,9 @@ def _box_box_overlap(ca, Ra, ha, cb, hb):
 
 
 def parse_urdf(path):
-    root = ET.parse(path).getroot()
+    text = open(path).read()
+    end = text.find("</robot>")  # rocket.urdf closes <robot> twice; Bullet's parser stops at the first
+    root = ET.fromstring(text[: end + len("</robot>")] if end >= 0 else text)
     links = {}
     order = []
     for le in root.findall("link"):
@@ -204,7 +207,12 @@ def parse_urdf(path):
         child = je.find("child").get("link")
         o = je.find("origin")
         if o is not None:
-            assert np.allclose(_vec(o.get("rpy", "0 0 0")), 0.0)
+            rpy = _vec(o.get("rpy", "0 0 0"))
+            if not np.allclose(rpy, 0.0):
+                # rotated child frames are supported for massless links only (rocket.urdf legs): the
+                # rotation then matters for their collision shapes alone
+                assert links[child].mass == 0.0 and not links[child].inertia.any()
+                links[child].rot = matrix_from_quat(quat_from_euler(rpy))
             links[child].joint_origin = _vec(o.get("xyz", "0 0 0"))
         children.add(child)
         joint_children.append((parent, child))
@@ -247,9 +255,16 @@ class BulletClient:
         pass
 
     def changeDynamics(self, body, link, **kwargs):
-        # PyFlyt only zeroes the artificial damping (base_drone.py:301-304); the tick below has none
-        assert set(kwargs) <= {"linearDamping", "angularDamping"}
-        assert all(v == 0.0 for v in kwargs.values())
+        # PyFlyt zeroes the artificial damping (base_drone.py:301-304; the tick below has none) and, for
+        # fuel tanks, rewrites a link's mass and diagonal inertia every tick (boosters.py:193-198)
+        assert set(kwargs) <= {"linearDamping", "angularDamping", "mass", "localInertiaDiagonal"}
+        assert all(kwargs[k] == 0.0 for k in ("linearDamping", "angularDamping") if k in kwargs)
+        if "mass" in kwargs or "localInertiaDiagonal" in kwargs:
+            l = self._bodies[body].links[int(link) + 1]
+            if "mass" in kwargs:
+                l.mass = float(kwargs["mass"])
+            if "localInertiaDiagonal" in kwargs:
+                l.inertia = np.diag(np.asarray(kwargs["localInertiaDiagonal"], dtype=np.float64))
 
     # ------------------------------------------------------------ world
     def resetSimulation(self):

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libuav_oracle.so")
 
-MAX_TARGETS, MAX_BOXES, MAX_SURF = 8, 8, 5
+MAX_TARGETS, MAX_BOXES, MAX_SURF, MAX_LINKS = 8, 12, 5, 12
 QUADX, FIXEDWING = 0, 1
 TASK_NONE, TASK_HOVER, TASK_WAYPOINTS, TASK_MA_HOVER = 0, 1, 2, 3
 NOISE_OFF, NOISE_INJECT, NOISE_PHILOX = 0, 1, 2
@@ -35,7 +35,7 @@ class PidGains(C.Structure):
 
 
 class Box(C.Structure):
-    _fields_ = [("c", d3), ("h", d3), ("kind", C.c_int)]
+    _fields_ = [("c", d3), ("h", d3), ("kind", C.c_int), ("yaw", C.c_double)]
 
 
 class Surface(C.Structure):
@@ -70,6 +70,12 @@ class Params(C.Structure):
         ("throttle_remap", C.c_double), ("collide_any", C.c_int),
         ("wp_dist_reward", C.c_double), ("wp_yaw_penalty", C.c_double),
         ("noise_mode", C.c_int), ("seed", C.c_uint64),
+        ("n_links", C.c_int), ("link_mass", C.c_double * MAX_LINKS), ("link_r", d3 * MAX_LINKS), ("link_I", d3 * MAX_LINKS),
+        ("fueltank_link", C.c_int), ("booster_link", C.c_int),
+        ("total_fuel", C.c_double), ("max_fuel_rate", C.c_double), ("fuel_inertia", d3), ("min_thrust", C.c_double),
+        ("max_thrust", C.c_double), ("booster_tau", C.c_double), ("booster_noise", C.c_double), ("reignitable", C.c_int),
+        ("gimbal_tau", C.c_double), ("gimbal_range_rad", C.c_double), ("finlet_map", d3 * 4),
+        ("starting_fuel_ratio", C.c_double),
         ("wind_fn", C.c_void_p),
     ]
 
@@ -103,7 +109,8 @@ class Lane(C.Structure):
         ("p", d3), ("q", C.c_double * 4), ("v", d3), ("w", d3),
         ("w_b", d3), ("rpy", d3), ("v_b", d3), ("surf_v", d3 * MAX_SURF), ("drag_v_b", d3),
         ("throttle", C.c_double * 4), ("actuation", C.c_double * MAX_SURF),
-        ("pwm", C.c_double * 4), ("cmd", C.c_double * 6), ("setpoint", C.c_double * 6),
+        ("pwm", C.c_double * 4), ("cmd", C.c_double * 8), ("setpoint", C.c_double * 8),
+        ("fuel_ratio", C.c_double), ("ignition", C.c_int), ("gimbal", C.c_double * 2),
         ("pid_I", d3 * 4), ("pid_E", d3 * 4), ("zpid_I", C.c_double * 2), ("zpid_E", C.c_double * 2),
         ("mode", C.c_int), ("physics_steps", C.c_int), ("contact_now", C.c_int), ("contact_step", C.c_int),
         ("step_count", C.c_int), ("terminated", C.c_int), ("truncated", C.c_int),
@@ -165,7 +172,7 @@ def lib():
         L.orc_env_reset_batch.argtypes = [PP, LP, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_step_batch.argtypes = [PP, LP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        for f in ("orc_params_quadx", "orc_params_fixedwing", "orc_params_primitive_drone", "orc_task_hover", "orc_task_quadx_waypoints",
+        for f in ("orc_params_quadx", "orc_params_fixedwing", "orc_params_primitive_drone", "orc_params_rocket", "orc_task_hover", "orc_task_quadx_waypoints",
                   "orc_task_fixedwing_waypoints", "orc_task_ma_hover", "orc_finalize"):
             getattr(L, f).argtypes = [PP]
         _lib = L
@@ -186,6 +193,8 @@ def make_params(env: str, noise_mode: int = NOISE_OFF, seed: int = 0, **override
     P = Params()
     if env == "primitive_drone":
         L.orc_params_primitive_drone(C.byref(P))
+    elif env == "rocket":
+        L.orc_params_rocket(C.byref(P))
     elif env in ("quadx", "hover", "quadx_waypoints", "ma_hover"):
         L.orc_params_quadx(C.byref(P))
     else:

@@ -207,6 +207,15 @@ int orc_contact_plane(const orc_params* P, const double p[3], const double q[4])
         if (fabs(ca[a] - cb[a]) - (hb[a] + ext) > 0.0) sep = 1;
       }
       if (!sep) return 1;
+    } else if (P->boxes[k].yaw != 0.0) { /* a box on a yaw-rotated link: axes = R * Rz(yaw) */
+      const double cy = cos(P->boxes[k].yaw), sy = sin(P->boxes[k].yaw);
+      double Rr[3][3];
+      for (int a = 0; a < 3; ++a) {
+        Rr[a][0] = R[a][0] * cy + R[a][1] * sy;
+        Rr[a][1] = -R[a][0] * sy + R[a][1] * cy;
+        Rr[a][2] = R[a][2];
+      }
+      if (orc_box_box_overlap(ca, Rr, P->boxes[k].h, cb, hb)) return 1;
     } else if (orc_box_box_overlap(ca, R, P->boxes[k].h, cb, hb)) {
       return 1;
     }
@@ -220,9 +229,24 @@ int orc_contact_plane(const orc_params* P, const double p[3], const double q[4])
  * applyDeltaVeeMultiDof (per-coordinate clamp) -> stepPositionsMultiDof (exp-map quaternion).
  * F_b: net external force in the base frame (gravity excluded); tau_b: net external torque about
  * the BASE ORIGIN in the base frame. State (p, v) is that of the base origin, as Bullet keeps it. */
+typedef struct { /* the composite body the tick integrates; constant for QuadX / Fixedwing, rebuilt per tick for the Rocket */
+  double mass, com[3], I_own[3][3], I_pa[3][3], I_inv[3][3];
+} orc_body;
+static void rigid_tick_body(const orc_world* W, const orc_body* B, double p[3], double q[4], double v[3], double w[3],
+                            const double F_b[3], const double tau_b[3]);
 void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], double w[3],
                     const double F_b[3], const double tau_b[3]) {
-  const double dt = P->world.dt;
+  orc_body B;
+  B.mass = P->mass;
+  memcpy(B.com, P->com, sizeof(B.com));
+  memcpy(B.I_own, P->I_own, sizeof(B.I_own));
+  memcpy(B.I_pa, P->I_pa, sizeof(B.I_pa));
+  memcpy(B.I_inv, P->I_inv, sizeof(B.I_inv));
+  rigid_tick_body(&P->world, &B, p, q, v, w, F_b, tau_b);
+}
+static void rigid_tick_body(const orc_world* Wd, const orc_body* P, double p[3], double q[4], double v[3], double w[3],
+                            const double F_b[3], const double tau_b[3]) {
+  const double dt = Wd->dt;
   double R[3][3];
   orc_matrix_from_quat(q, R);
   double w_b[3];
@@ -236,7 +260,7 @@ void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], 
   double Iw[3], g1[3], g2[3] = {0, 0, 0};
   matvec(P->I_pa, w_b, Iw);
   cross3(w_b, Iw, g1);
-  if (P->world.use_gyro_term) {
+  if (Wd->use_gyro_term) {
     matvec(P->I_own, w_b, Iw);
     cross3(w_b, Iw, g2);
   }
@@ -247,7 +271,7 @@ void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], 
   /* linear acceleration of the COM, then of the base origin */
   double F_w[3], a[3];
   matvec(R, F_b, F_w);
-  a[0] = F_w[0] / P->mass; a[1] = F_w[1] / P->mass; a[2] = F_w[2] / P->mass + P->world.gravity_z;
+  a[0] = F_w[0] / P->mass; a[1] = F_w[1] / P->mass; a[2] = F_w[2] / P->mass + Wd->gravity_z;
   double c_w[3], t1[3], t2[3], t3[3];
   matvec(R, P->com, c_w);
   cross3(wdot, c_w, t1);
@@ -255,7 +279,7 @@ void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], 
   cross3(w, t2, t3);
   for (int i = 0; i < 3; ++i) a[i] = a[i] - t1[i] - t3[i];
   /* v += a dt with the per-coordinate clamp (order: omega then velocity) */
-  const double vmax = P->world.max_coord_vel;
+  const double vmax = Wd->max_coord_vel;
   for (int i = 0; i < 3; ++i) w[i] = clipd(w[i] + wdot[i] * dt, -vmax, vmax);
   for (int i = 0; i < 3; ++i) v[i] = clipd(v[i] + a[i] * dt, -vmax, vmax);
   /* x += v dt (semi-implicit Euler: new velocity) */
@@ -714,7 +738,7 @@ void orc_update_state(const orc_params* P, orc_lane* L) {
    * at the time of the previous tick's end: physics_steps / physics_hz with physics_steps not yet
    * incremented for this tick. */
   const double now = (double)L->physics_steps * P->world.dt;
-  if (P->vehicle == ORC_QUADX) { /* boring_bodies.py:78-111: one body, the centre-of-mass link at the base origin */
+  if (P->vehicle == ORC_QUADX || P->vehicle == ORC_ROCKET) { /* boring_bodies.py:78-111: one body at the base origin (QuadX centre-of-mass link; Rocket fuel tank link, rocket.py:97) */
     double lv[3] = {L->v[0], L->v[1], L->v[2]};
     if (P->wind_fn) {
       double wnd[3];
@@ -743,6 +767,7 @@ void orc_update_state(const orc_params* P, orc_lane* L) {
 /* quadx.py:233-373 ; fixedwing.py:206-227 */
 void orc_set_mode(const orc_params* P, orc_lane* L, int mode) {
   L->mode = mode;
+  if (P->vehicle == ORC_ROCKET) return; /* base_drone.py:243-259: only records the mode */
   if (P->vehicle == ORC_FIXEDWING) {
     for (int i = 0; i < 6; ++i) L->setpoint[i] = 0.0;
     return;
@@ -777,7 +802,8 @@ void orc_aviary_reset(const orc_params* P, orc_lane* L, uint64_t lane_id) {
   for (int k = 0; k < 3; ++k) { L->p[k] = P->start_pos[k]; L->v[k] = P->start_vel[k]; }
   orc_quat_from_euler(P->start_rpy, L->q); /* base_drone.py:115 */
   orc_set_mode(P, L, 0);
-  for (int i = 0; i < 6; ++i) L->setpoint[i] = 0.0; /* quadx.py:225 */
+  for (int i = 0; i < 8; ++i) L->setpoint[i] = 0.0; /* quadx.py:225, rocket.py:228-229 */
+  if (P->vehicle == ORC_ROCKET) L->fuel_ratio = P->starting_fuel_ratio; /* rocket.py:236, boosters.py:119-130 */
   memset(L->zpid_I, 0, sizeof(L->zpid_I));
   memset(L->zpid_E, 0, sizeof(L->zpid_E));
   orc_update_state(P, L);
@@ -791,6 +817,143 @@ static double tick_noise(const orc_params* P, const orc_lane* L, const double* x
   return (double)P->n_motors + lane_normal(P, L, flat, stream);
 }
 
+/* The composite of the Rocket's links with the fuel tank's current mass and inertia (the reference
+ * rewrites them every tick: boosters.py:193-198 -> changeDynamics). */
+static void rocket_composite(const orc_params* P, double fuel_ratio, orc_body* B) {
+  double M = 0.0, mc[3] = {0, 0, 0};
+  memset(B, 0, sizeof(*B));
+  for (int i = 0; i < P->n_links; ++i) {
+    const double m = (i == P->fueltank_link) ? fuel_ratio * P->total_fuel : P->link_mass[i];
+    M += m;
+    for (int k = 0; k < 3; ++k) mc[k] += m * P->link_r[i][k];
+  }
+  B->mass = M;
+  for (int k = 0; k < 3; ++k) B->com[k] = mc[k] / M;
+  for (int i = 0; i < P->n_links; ++i) {
+    const int tank = (i == P->fueltank_link);
+    const double m = tank ? fuel_ratio * P->total_fuel : P->link_mass[i];
+    double d[3];
+    for (int k = 0; k < 3; ++k) d[k] = P->link_r[i][k] - B->com[k];
+    const double dd = dot3(d, d);
+    for (int a = 0; a < 3; ++a) {
+      B->I_own[a][a] += tank ? fuel_ratio * P->fuel_inertia[a] : P->link_I[i][a];
+      for (int b = 0; b < 3; ++b) B->I_pa[a][b] += m * ((a == b ? dd : 0.0) - d[a] * d[b]);
+    }
+  }
+  double I[3][3];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) I[a][b] = B->I_own[a][b] + B->I_pa[a][b];
+  inv3(I, B->I_inv);
+}
+/* rocket.py:268-290 update_physics: body drag, grid fins, gimbal, booster (+ fuel tank mass properties) */
+static void rocket_physics(const orc_params* P, orc_lane* L, double noise, double F_b[3], double T_b[3], orc_body* body) {
+  const double dt = P->world.dt;
+  double Fd[3];
+  orc_body_drag(P, L->drag_v_b, Fd); /* rocket.py:271, the fuel tank link at the base origin */
+  for (int k = 0; k < 3; ++k) F_b[k] += Fd[k];
+  for (int i = 0; i < P->n_surf; ++i) { /* rocket.py:274, lifting_surfaces.py:266-324 */
+    const orc_surface* S = &P->surf[i];
+    L->actuation[i] += (dt / S->tau) * (L->cmd[i] - L->actuation[i]);
+    double F[3], T[3], rxf[3];
+    orc_surface_force(S, L->surf_v[i], L->actuation[i], F, T);
+    cross3(S->r, F, rxf);
+    for (int k = 0; k < 3; ++k) { F_b[k] += F[k]; T_b[k] += rxf[k] + T[k]; }
+  }
+  /* gimbals.py:151-217: first-order lag, then R = R_x(a1) R_y(a2) by Rodrigues' formula */
+  for (int k = 0; k < 2; ++k) L->gimbal[k] += (dt / P->gimbal_tau) * (L->cmd[6 + k] - L->gimbal[k]);
+  const double a1 = L->gimbal[0] * P->gimbal_range_rad, a2 = L->gimbal[1] * P->gimbal_range_rad;
+  const double s1 = sin(a1), c1 = 1.0 - 2.0 * sin(a1 / 2.0) * sin(a1 / 2.0);
+  const double s2 = sin(a2), c2 = 1.0 - 2.0 * sin(a2 / 2.0) * sin(a2 / 2.0);
+  const double dir[3] = {s2, -s1 * c2, c1 * c2}; /* R1 R2 (0,0,1) */
+  /* boosters.py:213-263 */
+  const double ratio_min = P->min_thrust / P->max_thrust;
+  L->ignition = ((!P->reignitable) && L->ignition) || (L->cmd[4] > 0.5);
+  const double target = L->ignition ? (L->cmd[5] * (1.0 - ratio_min) + ratio_min) : 0.0;
+  double thr = L->throttle[0];
+  thr += (dt / P->booster_tau) * (target - thr);
+  thr += noise * thr * P->booster_noise;
+  thr *= (L->fuel_ratio > 0.0) ? 1.0 : 0.0;
+  L->throttle[0] = thr;
+  L->fuel_ratio = clipd(L->fuel_ratio - thr * (P->max_fuel_rate / P->total_fuel) * dt, 0.0, 1.0);
+  const double thrust = thr * P->max_thrust;
+  double F[3] = {dir[0] * thrust, dir[1] * thrust, dir[2] * thrust}, rxf[3];
+  cross3(P->link_r[P->booster_link], F, rxf);
+  for (int k = 0; k < 3; ++k) { F_b[k] += F[k]; T_b[k] += rxf[k]; }
+  rocket_composite(P, L->fuel_ratio, body);
+}
+
+/* models/vehicles/rocket/rocket.{urdf,yaml}; drones/rocket.py:84-219 */
+void orc_params_rocket(orc_params* P) {
+  memset(P, 0, sizeof(*P));
+  P->vehicle = ORC_ROCKET;
+  world_defaults(&P->world);
+  /* rocket.urdf: base :37-38, fuel tank :58-59,69, booster :78-79,95, fins :104,121 :130,147 :156,173 :182,199,
+   * legs :208,225 :234,251 :260,277, flame :285,296 (massless links still listed: they carry collision shapes) */
+  const double lm[10] = {91.0, 410.9, 47.0, 0.05, 0.05, 0.05, 0.05, 0.0, 0.0, 0.0};
+  const double lr[10][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, -2}, {0.35, 0, 2.051}, {-0.35, 0, 2.051}, {0, 0.35, 2.051},
+                            {0, -0.35, 2.051}, {0.0, 0.35, -2.4}, {0.3031, -0.175, -2.4}, {-0.3031, -0.175, -2.4}};
+  const double li[10][3] = {{372.6, 372.6, 1.55}, {1678, 1678, 7.01}, {192.43, 192.43, 0.81}};
+  P->n_links = 10;
+  for (int i = 0; i < 10; ++i) {
+    P->link_mass[i] = lm[i];
+    for (int k = 0; k < 3; ++k) { P->link_r[i][k] = lr[i][k]; P->link_I[i][k] = li[i][k]; }
+  }
+  P->fueltank_link = 1; P->booster_link = 2;
+  /* collision shapes: base cylinder :43 (the fuel tank's :64 lies inside it), booster cylinder :84, fin boxes
+   * :110,136,162,188, leg boxes :214,240,266 with the legs' yaw :251,277 */
+  int k = 0;
+  P->boxes[k].kind = 1; P->boxes[k].h[0] = P->boxes[k].h[1] = 0.185; P->boxes[k].h[2] = 4.77 / 2; ++k;
+  P->boxes[k].kind = 1; P->boxes[k].c[2] = -2.0; P->boxes[k].h[0] = P->boxes[k].h[1] = 0.25; P->boxes[k].h[2] = 0.25; ++k;
+  for (int f = 0; f < 4; ++f, ++k) {
+    for (int a = 0; a < 3; ++a) P->boxes[k].c[a] = lr[3 + f][a];
+    P->boxes[k].h[0] = f < 2 ? 0.15 : 0.015; P->boxes[k].h[1] = f < 2 ? 0.015 : 0.15; P->boxes[k].h[2] = 0.15;
+  }
+  const double yaw[3] = {0.0, 4.188, -4.188};
+  for (int g = 0; g < 3; ++g, ++k) {
+    for (int a = 0; a < 3; ++a) P->boxes[k].c[a] = lr[7 + g][a];
+    P->boxes[k].h[0] = 0.025; P->boxes[k].h[1] = 0.25; P->boxes[k].h[2] = 0.025;
+    P->boxes[k].yaw = yaw[g];
+  }
+  P->n_boxes = k;
+  /* rocket.yaml:7-19 */
+  P->total_fuel = 410.9; P->max_fuel_rate = 1.451;
+  P->fuel_inertia[0] = 1678; P->fuel_inertia[1] = 1678; P->fuel_inertia[2] = 7.01;
+  P->min_thrust = 2966.7; P->max_thrust = 7607.0; P->reignitable = 1;
+  P->gimbal_range_rad = 5.0 * PI / 180.0; P->booster_tau = 0.01; P->gimbal_tau = 0.01; P->booster_noise = 0.01;
+  P->n_motors = 1; /* np_random.normal(*throttle.shape) with one booster: loc = 1 (boosters.py:236-240) */
+  /* rocket.yaml:21-32, rocket.py:114-142: "x fins" lift along y, "y fins" lift along x, all facing -z.
+   * The reference binds the four LiftingSurface objects to link ids 0..3 (surface_id=finlet_id), which
+   * in rocket.urdf's joint order are the fuel tank, the booster, fin_pos_x and fin_neg_x -- not the four
+   * fin links 2..5. That is where their velocities are sampled and their forces applied; reproduced. */
+  P->n_surf = 4;
+  for (int i = 0; i < 4; ++i) {
+    orc_surface* S = &P->surf[i];
+    for (int a = 0; a < 3; ++a) S->r[a] = lr[1 + i][a];
+    S->lift_unit[i < 2 ? 1 : 0] = 1.0;
+    S->drag_unit[2] = -1.0;
+    S->Cl_alpha_2D = 6.283; S->chord = 0.5; S->span = 0.5; S->flap_to_chord = 1.0; S->eta = 0.65;
+    S->alpha_0_base = 0.0; S->alpha_stall_P_base = 20.0 * PI / 180.0; S->alpha_stall_N_base = -20.0 * PI / 180.0;
+    S->Cd_0 = 0.01; S->deflection_limit = 45.0; S->tau = 0.05;
+  }
+  const double fm[4][3] = {{0, 1, 1}, {0, 1, -1}, {1, 0, -1}, {1, 0, 1}}; /* rocket.py:152-159 */
+  memcpy(P->finlet_map, fm, sizeof(fm));
+  /* rocket.yaml:34-40, boring_bodies.py:63 */
+  P->drag_const[0] = 0.5 * 1.225 * 1.16 * 1.7649; P->drag_const[1] = P->drag_const[0];
+  P->drag_const[2] = 0.5 * 1.225 * 2.0 * 0.1075;
+  P->control_period = 1.0 / 120.0; /* rocket.py:36 */
+  P->starting_fuel_ratio = 0.05;   /* rocket.py:47 */
+  P->start_pos[2] = 1.0;
+  P->angle_repr = 1;
+  /* mass / com / inertia of the full-tank composite, for orc_finalize()'s bookkeeping only */
+  orc_body B;
+  rocket_composite(P, 1.0, &B);
+  P->mass = B.mass;
+  memcpy(P->com, B.com, sizeof(B.com));
+  memcpy(P->I_own, B.I_own, sizeof(B.I_own));
+  memcpy(P->I_pa, B.I_pa, sizeof(B.I_pa));
+  orc_finalize(P);
+}
+
 /* aviary.py:480-531 */
 void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_t flat_base, uint32_t stream) {
   L->contact_step = 0; /* :507 */
@@ -799,6 +962,12 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
     if (L->physics_steps % P->world.ticks_per_control == 0) {
       if (P->vehicle == ORC_QUADX) {
         orc_quadx_control(P, L);
+      } else if (P->vehicle == ORC_ROCKET) { /* rocket.py:249-257 */
+        for (int i = 0; i < 4; ++i) {
+          double c = P->finlet_map[i][0] * L->setpoint[0] + P->finlet_map[i][1] * L->setpoint[1] + P->finlet_map[i][2] * L->setpoint[2];
+          L->cmd[i] = clipd(c, -1.0, 1.0);
+        }
+        for (int i = 0; i < 4; ++i) L->cmd[4 + i] = L->setpoint[3 + i];
       } else if (L->mode == -1) { /* fixedwing.py:241-243 */
         for (int i = 0; i < 6; ++i) L->cmd[i] = L->setpoint[i];
       } else { /* fixedwing.py:246-250 */
@@ -808,6 +977,7 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
     /* update_physics */
     double F_b[3] = {0, 0, 0}, T_b[3] = {0, 0, 0};
     double thrust[4][3], torque[4][3];
+    orc_body rocket_body;
     double noise = tick_noise(P, L, xi, t, flat_base + (uint32_t)t, stream);
     if (P->vehicle == ORC_QUADX) {
       double Fd[3];
@@ -822,6 +992,8 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
       if (!L->contact_now) { /* quadx.py:502-510 */
         for (int k = 0; k < 3; ++k) T_b[k] += -sgn(L->w_b[k]) * P->drag_coef_pqr * (L->w_b[k] * L->w_b[k]);
       }
+    } else if (P->vehicle == ORC_ROCKET) {
+      rocket_physics(P, L, noise, F_b, T_b, &rocket_body);
     } else {
       for (int i = 0; i < P->n_surf; ++i) { /* fixedwing.py:263, lifting_surfaces.py:266-324 */
         const orc_surface* S = &P->surf[i];
@@ -838,7 +1010,8 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
     }
     /* stepSimulation: collision detection at the pre-integration pose, then the free-body tick */
     L->contact_now = orc_contact_plane(P, L->p, L->q);
-    orc_rigid_tick(P, L->p, L->q, L->v, L->w, F_b, T_b);
+    if (P->vehicle == ORC_ROCKET) rigid_tick_body(&P->world, &rocket_body, L->p, L->q, L->v, L->w, F_b, T_b);
+    else orc_rigid_tick(P, L->p, L->q, L->v, L->w, F_b, T_b);
     orc_update_state(P, L);
     if (L->contact_now) L->contact_step = 1; /* :523-525 */
     L->physics_steps += 1;

@@ -26,10 +26,11 @@ extern "C" {
 #endif
 
 #define ORC_MAX_TARGETS 8
-#define ORC_MAX_BOXES 8
+#define ORC_MAX_LINKS 12
+#define ORC_MAX_BOXES 12
 #define ORC_MAX_SURF 5
 
-enum { ORC_QUADX = 0, ORC_FIXEDWING = 1 };
+enum { ORC_QUADX = 0, ORC_FIXEDWING = 1, ORC_ROCKET = 2 };
 enum { ORC_TASK_NONE = 0, ORC_TASK_HOVER = 1, ORC_TASK_WAYPOINTS = 2, ORC_TASK_MA_HOVER = 3 };
 enum { ORC_NOISE_OFF = 0, ORC_NOISE_INJECT = 1, ORC_NOISE_PHILOX = 2 };
 
@@ -52,6 +53,7 @@ typedef struct {
   double c[3];  /* centre in base frame */
   double h[3];  /* box: half extents; cylinder (axis = link z): radius, radius, half length */
   int kind;     /* 0 box, 1 cylinder (primitive_drone.urdf:42-47: the prop discs) */
+  double yaw;   /* rotation of the shape's link about the base z axis (rocket.urdf:251,277: the legs) */
 } orc_box;
 
 /* One lifting surface -- lifting_surfaces.py:141-239, fixedwing.yaml:8-71 */
@@ -121,6 +123,18 @@ typedef struct {
   int noise_mode;
   uint64_t seed;
 
+  /* rocket only (drones/rocket.py, abstractions/boosters.py, gimbals.py; models/vehicles/rocket/) */
+  int n_links;                           /* links[0] = base, then the URDF's child links in joint order */
+  double link_mass[ORC_MAX_LINKS];
+  double link_r[ORC_MAX_LINKS][3];       /* link COM in the base frame */
+  double link_I[ORC_MAX_LINKS][3];       /* diagonal own inertia (all massive links are axis-aligned) */
+  int fueltank_link, booster_link;       /* indices into links[] */
+  double total_fuel, max_fuel_rate, fuel_inertia[3], min_thrust, max_thrust, booster_tau, booster_noise;
+  int reignitable;
+  double gimbal_tau, gimbal_range_rad;
+  double finlet_map[4][3];               /* rocket.py:152-159 */
+  double starting_fuel_ratio;            /* rocket.py:47 */
+
   /* wind field (aviary.py:266-285,324-333; base_wind_field.py:10-69): called from update_state with
    * the Aviary's elapsed time and the world positions of the n links it is sampled at (QuadX: the
    * body link, boring_bodies.py:93-96; Fixedwing: the five surface links, lifting_surfaces.py:88-93);
@@ -139,8 +153,12 @@ typedef struct {
   double throttle[4];
   double actuation[ORC_MAX_SURF];
   double pwm[4];
-  double cmd[6];
-  double setpoint[6];
+  double cmd[8];
+  double setpoint[8];
+  /* rocket: boosters.py:119-130 (ignition, fuel ratio; the throttle lives in throttle[0]), gimbals.py:118-122 */
+  double fuel_ratio;
+  int ignition;
+  double gimbal[2];
   /* controllers */
   double pid_I[4][3], pid_E[4][3];
   double zpid_I[2], zpid_E[2];
@@ -170,6 +188,7 @@ typedef struct {
 void orc_params_quadx(orc_params* P);
 void orc_params_fixedwing(orc_params* P);
 void orc_params_primitive_drone(orc_params* P);
+void orc_params_rocket(orc_params* P);
 void orc_task_hover(orc_params* P);
 void orc_task_quadx_waypoints(orc_params* P);
 void orc_task_fixedwing_waypoints(orc_params* P);

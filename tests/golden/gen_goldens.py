@@ -165,7 +165,7 @@ def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True
         env.register_wind_field_function(wind_from_coef(WIND_COEF))
     env.set_mode(mode)
     rng = np.random.default_rng(seed + 1000)
-    sp_dim = 4 if not (drone_type == "fixedwing" and mode == -1) else 6
+    sp_dim = 7 if drone_type == "rocket" else (4 if not (drone_type == "fixedwing" and mode == -1) else 6)
     states, auxs, sps, xis, contacts = [], [], [], [], []
     init_state, init_aux, init_sp = env.state(0).copy(), env.aux_state(0).copy(), env.drones[0].setpoint.copy()
     sp = np.array(env.drones[0].setpoint, dtype=np.float64).copy()
@@ -188,6 +188,9 @@ def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True
                     sp = np.array([*rng.uniform(-1.0, 1.0, size=2), rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5)])
                 elif mode == 7:
                     sp = np.array([*rng.uniform(-2.0, 2.0, size=2), rng.uniform(-1.0, 1.0), rng.uniform(0.5, 2.5)])
+            elif drone_type == "rocket":  # rocket.py:230-236: fins x, y, yaw | ignition | throttle | gimbal 1, 2
+                sp = np.concatenate([rng.uniform(-0.6, 0.6, size=3), [float(rng.random() < 0.8)], rng.uniform(0.0, 1.0, size=1),
+                                     rng.uniform(-1.0, 1.0, size=2)])
             else:
                 sp = rng.uniform(-1.0, 1.0, size=sp_dim)
                 sp[-1] = rng.uniform(0.0, 1.0)
@@ -230,6 +233,21 @@ def gen_primitive():
     # a tilted drop: a prop disc (cylinder) reaches the floor before the base box does
     d = run_aviary("quadx", 0, 120, seed=5, start_pos=[0.0, 0.0, 0.30], start_orn=[0.5, 0.2, 0.0], noise=False, drone_options=opts)
     save("aviary_primitive_drop", **d)
+
+
+def gen_rocket():
+    # Rocket (drones/rocket.py, abstractions/boosters.py, gimbals.py): booster with fuel burn (variable mass
+    # and inertia through changeDynamics), 2-axis thrust gimbal, four grid fins, per-axis body drag
+    d = run_aviary("rocket", 0, 200, seed=500, start_pos=[0.0, 0.0, 80.0], start_orn=[0.05, 0.02, 0.3], noise=True)
+    save("aviary_rocket_default_fuel", **d)
+    # plenty of fuel, a burn long enough to move the composite centre of mass noticeably
+    d = run_aviary("rocket", 0, 300, seed=501, start_pos=[1.0, -2.0, 200.0], start_orn=[-0.1, 0.15, -1.0], noise=True,
+                   drone_options=dict(starting_fuel_ratio=0.6))
+    save("aviary_rocket_fuel60", **d)
+    # free fall with the engine off from low altitude, tilted: a leg / the booster reaches the floor
+    d = run_aviary("rocket", 0, 150, seed=502, start_pos=[0.0, 0.0, 4.0], start_orn=[0.4, 0.1, 0.0], noise=False,
+                   drone_options=dict(starting_fuel_ratio=0.0))
+    save("aviary_rocket_drop", **d)
 
 
 def gen_wind():
@@ -396,3 +414,4 @@ if __name__ == "__main__":
     gen_ma_hover()
     gen_wind()
     gen_primitive()
+    gen_rocket()

@@ -206,6 +206,44 @@ def test_aviary_drop_contact(golden_dir, name):
         np.testing.assert_allclose(st, g["states"][k], atol=TOL)
 
 
+@pytest.mark.parametrize("name,fuel", [("aviary_rocket_default_fuel", 0.05), ("aviary_rocket_fuel60", 0.6), ("aviary_rocket_drop", 0.0)])
+def test_rocket_trajectory(golden_dir, name, fuel):
+    """Rocket (drones/rocket.py + boosters.py + gimbals.py): grid fins, gimballed booster with fuel burn
+    (the composite mass / centre of mass / inertia are rebuilt every tick, as changeDynamics does in
+    the reference), per-axis body drag; the drop run ends with a leg / the booster on the floor."""
+    g = load(golden_dir, name)
+    noise = bool(g["noise"])
+    P = O.make_params("rocket", noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF, start_pos=g["start_pos"],
+                      start_rpy=g["start_orn"], starting_fuel_ratio=fuel)
+    L = O.Lane()
+    lib = O.lib()
+    lib.orc_aviary_reset(C.byref(P), C.byref(L), 0)
+    lib.orc_set_mode(C.byref(P), C.byref(L), 0)
+
+    def state():
+        st = np.array([list(L.w_b), list(L.rpy), list(L.v_b), list(L.p)])
+        aux = np.array(list(L.actuation)[:4] + [float(L.ignition), L.fuel_ratio, L.throttle[0]] + list(L.gimbal))
+        return st, aux
+
+    st, aux = state()
+    np.testing.assert_allclose(st, g["init_state"], atol=1e-14)
+    np.testing.assert_allclose(aux, g["init_aux"], atol=1e-14)
+    worst = 0.0
+    first_contact = int(np.argmax(g["contact"])) if g["contact"].any() else len(g["states"])
+    for k in range(len(g["states"])):
+        for i, x in enumerate(g["setpoints"][k]):
+            L.setpoint[i] = x
+        xi = np.ascontiguousarray(np.nan_to_num(g["xi"][k]))
+        lib.orc_aviary_step(C.byref(P), C.byref(L), dp(xi), 0, 0)
+        assert bool(L.contact_step) == bool(g["contact"][k]), k
+        st, aux = state()
+        scale = np.maximum(1.0, np.abs(g["states"][k]))
+        worst = max(worst, (np.abs(st - g["states"][k]) / scale).max(), np.abs(aux - g["aux"][k]).max())
+    assert worst < TOL, worst
+    if "drop" in name:
+        assert first_contact < len(g["states"]) and not g["contact"][0]
+
+
 # ------------------------------------------------------------------ env level
 ENVS = [
     ("env_hover_random", "hover", {}),

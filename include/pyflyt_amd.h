@@ -31,11 +31,11 @@ extern "C" {
 
 #define PF_ABI_VERSION 2
 #define PF_MAX_TARGETS 8
-#define PF_MAX_BOXES 8
+#define PF_MAX_BOXES 12
 #define PF_MAX_SURF 5
 
 enum pf_status { PF_OK = 0, PF_ERR_ARG = -1, PF_ERR_UNSUPPORTED = -2, PF_ERR_NO_DEVICE = -3 };
-enum pf_vehicle { PF_QUADX = 0, PF_FIXEDWING = 1 };
+enum pf_vehicle { PF_QUADX = 0, PF_FIXEDWING = 1, PF_ROCKET = 2 /* Aviary-level entry points only */ };
 enum pf_task { PF_TASK_NONE = 0, PF_TASK_HOVER = 1, PF_TASK_WAYPOINTS = 2, PF_TASK_MA_HOVER = 3 };
 enum pf_noise { PF_NOISE_OFF = 0, PF_NOISE_INJECT = 1, PF_NOISE_PHILOX = 2 };
 enum pf_autoreset { PF_AUTORESET_OFF = 0, PF_AUTORESET_NEXT_STEP = 1, PF_AUTORESET_SAME_STEP = 2 };
@@ -53,6 +53,7 @@ typedef struct pf_pid {
 typedef struct pf_box {
   float c[3], h[3]; /* centre in the base frame; box: half extents, cylinder: radius, radius, half length */
   int32_t kind;     /* 0 box, 1 cylinder along the link z axis (primitive_drone.urdf:42-47 prop discs) */
+  float yaw;        /* rotation of the shape's link about the base z axis (rocket.urdf:251,277 legs) */
 } pf_box;
 
 /* one lifting surface: abstractions/lifting_surfaces.py:141-239 (constants precomputed on host) */
@@ -68,6 +69,24 @@ typedef struct pf_surface {
 
 /* All constants of one batched simulation. Filled by the host from its own parameter tables
  * (pyflyt_amd/params.py; numbers from cf2x.yaml/.urdf and fixedwing.yaml/.urdf, cited there). */
+/* Rocket (drones/rocket.py, abstractions/boosters.py, gimbals.py, models/vehicles/rocket/): the fuel
+ * tank's mass and inertia change every tick (boosters.py:193-198), so the composite body is rebuilt per
+ * tick from these aggregates over the other ("dry") links. */
+typedef struct pf_rocket {
+  float dry_mass;              /* sum m_i */
+  float dry_mr[3];             /* sum m_i r_i */
+  float dry_S[6];              /* sum m_i ((r_i.r_i) 1 - r_i r_i^T), symmetric xx xy xz yy yz zz */
+  float dry_I[3];              /* sum of the links' own (diagonal) inertias */
+  float tank_r[3];             /* fuel tank link COM in the base frame */
+  float total_fuel, fuel_rate_ratio /* max_fuel_rate / total_fuel */, fuel_inertia[3];
+  float thrust_min_ratio /* min_thrust / max_thrust */, max_thrust, booster_dt_over_tau, booster_noise;
+  int32_t reignitable;
+  float booster_r[3];          /* booster link COM */
+  float gimbal_dt_over_tau, gimbal_range_rad;
+  float finlet_map[4][3];      /* rocket.py:152-159 */
+  float starting_fuel_ratio;   /* rocket.py:47 */
+} pf_rocket;
+
 typedef struct pf_params {
   int32_t vehicle;  /* pf_vehicle */
   int32_t task;     /* pf_task */
@@ -117,6 +136,7 @@ typedef struct pf_params {
   float dome, goal_reach_distance, min_height;
   float wp_dist_reward, wp_yaw_penalty;
   float action_low[4], action_high[4]; /* action space box (quadx_base_env.py:80-102) */
+  pf_rocket rocket;
 } pf_params;
 
 /* Device buffers of one call. state layout: float4 groups, [n_groups][n_lanes][4]. */
@@ -132,9 +152,9 @@ typedef struct pf_buffers {
   const float* xi_reset;   /* PF_NOISE_INJECT: [settle_steps*ticks_per_control][n] */
   const float* u_targets;  /* PF_NOISE_INJECT, waypoint tasks: [3*num_targets][n] theta|phi|dist draws */
   /* Aviary-level calls only */
-  const float* setpoints;  /* [n][4] (quadx, fixedwing mode 0) or [n][6] (fixedwing mode -1) */
+  const float* setpoints;  /* [n][4] (quadx, fixedwing mode 0), [n][6] (fixedwing mode -1) or [n][7] (rocket) */
   float* out_state;        /* [n][12]: ang_vel, ang_pos, lin_vel, lin_pos rows of Aviary.state(i) */
-  float* out_aux;          /* [n][4] quadx throttle | [n][6] fixedwing surfaces + throttle */
+  float* out_aux;          /* [n][4] quadx throttle | [n][6] fixedwing surfaces + throttle | [n][9] rocket fins, ignition, fuel, throttle, gimbal */
   uint8_t* out_contact;    /* [n] contact_array[planeId] after the step, or NULL */
   const float* start_pose; /* pf_aviary_reset: [n][7] per-lane spawn (pos xyz, quat xyzw) or NULL = pf_params */
   /* wind field (pf_aviary_tick / pf_aviary_reset; ABI 2). K = pf_wind_links(): the links the reference

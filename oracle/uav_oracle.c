@@ -523,6 +523,10 @@ void orc_finalize(orc_params* P) {
       double d = sqrt(x * x + y * y + z * z);
       if (d > m) m = d;
     }
+    if (P->boxes[k].yaw != 0.0) { /* rotated about z: bound by |c| + |h|, whatever the yaw */
+      const double* c = P->boxes[k].c; const double* h = P->boxes[k].h;
+      m = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) + sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+    }
     if (m > r) r = m;
   }
   P->bound_radius = r;

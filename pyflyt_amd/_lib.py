@@ -8,8 +8,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpyflyt_amd.so")
 
-PF_MAX_BOXES, PF_MAX_SURF = 8, 5
-QUADX, FIXEDWING = 0, 1
+PF_MAX_BOXES, PF_MAX_SURF = 12, 5
+QUADX, FIXEDWING, ROCKET = 0, 1, 2
 TASK_NONE, TASK_HOVER, TASK_WAYPOINTS, TASK_MA_HOVER = 0, 1, 2, 3
 NOISE_OFF, NOISE_INJECT, NOISE_PHILOX = 0, 1, 2
 AUTORESET_OFF, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
@@ -25,7 +25,7 @@ class PfPid(C.Structure):
 
 
 class PfBox(C.Structure):
-    _fields_ = [("c", f3), ("h", f3), ("kind", C.c_int32)]
+    _fields_ = [("c", f3), ("h", f3), ("kind", C.c_int32), ("yaw", C.c_float)]
 
 
 class PfSurface(C.Structure):
@@ -36,6 +36,17 @@ class PfSurface(C.Structure):
         ("alpha_0_base", C.c_float), ("alpha_stall_P_base", C.c_float), ("alpha_stall_N_base", C.c_float),
         ("Cd_0", C.c_float), ("deflection_limit_rad", C.c_float), ("dt_over_tau", C.c_float),
         ("half_rho_area", C.c_float), ("chord", C.c_float),
+    ]
+
+
+class PfRocket(C.Structure):
+    _fields_ = [
+        ("dry_mass", C.c_float), ("dry_mr", f3), ("dry_S", f6), ("dry_I", f3), ("tank_r", f3),
+        ("total_fuel", C.c_float), ("fuel_rate_ratio", C.c_float), ("fuel_inertia", f3),
+        ("thrust_min_ratio", C.c_float), ("max_thrust", C.c_float), ("booster_dt_over_tau", C.c_float),
+        ("booster_noise", C.c_float), ("reignitable", C.c_int32), ("booster_r", f3),
+        ("gimbal_dt_over_tau", C.c_float), ("gimbal_range_rad", C.c_float), ("finlet_map", f3 * 4),
+        ("starting_fuel_ratio", C.c_float),
     ]
 
 
@@ -61,6 +72,7 @@ class PfParams(C.Structure):
         ("dome", C.c_float), ("goal_reach_distance", C.c_float), ("min_height", C.c_float),
         ("wp_dist_reward", C.c_float), ("wp_yaw_penalty", C.c_float),
         ("action_low", f4), ("action_high", f4),
+        ("rocket", PfRocket),
     ]
 
 

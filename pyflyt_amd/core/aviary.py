@@ -4,8 +4,10 @@ that each live in their OWN world (independent lanes), stepped by the HIP kernel
 Same surface as the reference where it is on the hot path:
   Aviary(start_pos[N,3], start_orn[N,3], drone_type, drone_options=..., physics_hz=240,
          world_scale=1.0, seed=...)                           core/aviary.py:69-216
+         drone_type: "quadx" | "fixedwing" | "rocket" (one type per Aviary)
          drone_options: control_hz, starting_velocity, drone_model ("cf2x" | "primitive_drone",
-         quadx.py:29), or any entry of the parameter tables in pyflyt_amd/params.py
+         quadx.py:29), starting_fuel_ratio (rocket.py:47), or any entry of the parameter tables in
+         pyflyt_amd/params.py
   reset()                                                     :218-312
   set_mode(int) / set_setpoint(i, sp) / set_all_setpoints(sp) :440-478
   step()                                                      :480-531
@@ -50,8 +52,8 @@ class Aviary:
             if len(kinds) != 1:
                 raise AviaryInitException("the batched Aviary needs one drone type for the whole batch")
             drone_type = kinds.pop()
-        if drone_type not in ("quadx", "fixedwing"):
-            raise AviaryInitException(f"drone_type {drone_type!r} is not on the batched hot path (quadx, fixedwing)")
+        if drone_type not in ("quadx", "fixedwing", "rocket"):
+            raise AviaryInitException(f"drone_type {drone_type!r} is not on the batched path (quadx, fixedwing, rocket)")
         if render:
             raise AviaryInitException("rendering is out of scope for the batched GPU path")
         if wind_type is not None and not callable(wind_type):  # core/aviary.py:270-285
@@ -94,6 +96,8 @@ class Aviary:
             vopts["control_hz"] = int(opts.pop("control_hz"))
         if "starting_velocity" in opts:
             vopts["starting_velocity"] = tuple(opts.pop("starting_velocity"))
+        if "starting_fuel_ratio" in opts:  # rocket.py:47
+            vopts["starting_fuel_ratio"] = float(opts.pop("starting_fuel_ratio"))
         for k in ("use_camera", "use_gimbal", "camera_fps"):
             opts.pop(k, None)
         vopts.update(opts)
@@ -109,8 +113,8 @@ class Aviary:
         self.start_pos, self.start_orn = start_pos, start_orn
         self.updates_per_step = P.ticks_per_control  # core/aviary.py:288-289
         self.step_period = 1.0 / (self.physics_hz / P.ticks_per_control)
-        self._sp_dim = 4
-        self.setpoints = torch.zeros(self.num_drones, 4, dtype=torch.float32, device=self.device)
+        self._sp_dim = 7 if drone_type == "rocket" else 4  # rocket.py:228
+        self.setpoints = torch.zeros(self.num_drones, self._sp_dim, dtype=torch.float32, device=self.device)
         self.reset()
 
     # ------------------------------------------------------------------ core/aviary.py:218-312
@@ -121,7 +125,7 @@ class Aviary:
         self.engine.state.zero_()
         self.engine.aviary_reset(self._start_pose)
         self.mode = 0
-        self._set_sp_dim(4)
+        self._set_sp_dim(7 if self.drone_type == "rocket" else 4)
         self.setpoints.zero_()
         self._contact_acc = None
         # wind field given to the constructor (core/aviary.py:266-285): built per reset with the
@@ -167,10 +171,10 @@ class Aviary:
         if not isinstance(flight_modes, (int, np.integer)):
             raise NotImplementedError("per-drone flight modes are not supported: the mode is uniform over the batch")
         mode = int(flight_modes)
-        lo, hi = (-1, 7) if self.drone_type == "quadx" else (-1, 0)
+        lo, hi = {"quadx": (-1, 7), "fixedwing": (-1, 0), "rocket": (0, 0)}[self.drone_type]
         if mode < lo or mode > hi:
             raise ValueError(f"`mode` must be between {lo} and {hi}, got {mode}.")  # quadx.py:260-263
-        self._set_sp_dim(6 if (self.drone_type == "fixedwing" and mode == -1) else 4)
+        self._set_sp_dim(7 if self.drone_type == "rocket" else (6 if (self.drone_type == "fixedwing" and mode == -1) else 4))
         self.engine.aviary_set_mode(mode, self.setpoints)
         self.mode = mode
 

@@ -19,6 +19,7 @@
 #include "uav_vehicles.hpp"
 #include "quadx_fast.hpp"
 #include "fixedwing_fast.hpp"
+#include "rocket.hpp"
 
 namespace pf {
 
@@ -408,7 +409,7 @@ __global__ void __launch_bounds__(kWave) aviary_reset_kernel(const pf_params P, 
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   VEH V;
-  float sp[6];
+  float sp[8];
   V.reset(P, pose ? pose + (size_t)lane * 7 : nullptr, sp);
   float4* S = reinterpret_cast<float4*>(B.state);
   V.store(S, (size_t)n, (size_t)lane, /*mode=*/7, INFINITY, int4{0, 0, 0, 0});
@@ -443,14 +444,14 @@ __global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params 
   // load everything (old mode 7 == all groups), re-initialise the controllers, store everything
   V.load(reinterpret_cast<const float4*>(B.state), (size_t)n, (size_t)lane, 7, nd, ints);
   V.b.rpy = euler_from_quat(V.b.q);
-  float sp[6] = {0, 0, 0, 0, 0, 0};
+  float sp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (sp_out)
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 8; ++k)
       if (k < sp_dim) sp[k] = sp_out[(size_t)lane * sp_dim + k];
   V.set_mode(new_mode, sp);
   V.store(reinterpret_cast<float4*>(B.state), (size_t)n, (size_t)lane, 7, nd, ints);
   if (sp_out)
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 8; ++k)
       if (k < sp_dim) sp_out[(size_t)lane * sp_dim + k] = sp[k];
   (void)P;
 }
@@ -477,10 +478,10 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   nz.mode = P.noise_mode; nz.n = n; nz.lane = lane;
   nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
   nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
-  float sp[6] = {0, 0, 0, 0, 0, 0};
-  const int spn = (P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4;
+  float sp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int spn = P.vehicle == PF_ROCKET ? 7 : ((P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4);
 #pragma unroll
-  for (int k = 0; k < 6; ++k)
+  for (int k = 0; k < 8; ++k)
     if (k < spn) sp[k] = B.setpoints[li * spn + k];
   bool contact = false;
   const int ratio = B.ctrl_ratio ? B.ctrl_ratio[li] : 0;
@@ -546,10 +547,10 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
   nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
   nz.begin_event(rng_ctr, 0u, B.xi);
-  float sp[6] = {0, 0, 0, 0, 0, 0};
-  const int spn = (P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4;
+  float sp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int spn = P.vehicle == PF_ROCKET ? 7 : ((P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4);
 #pragma unroll
-  for (int k = 0; k < 6; ++k)
+  for (int k = 0; k < 8; ++k)
     if (k < spn) sp[k] = B.setpoints[li * spn + k];
   const int ratio = B.ctrl_ratio ? B.ctrl_ratio[li] : P.ticks_per_control;
   if (tick_index % ratio == 0 || !kQuad) {
@@ -675,7 +676,10 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     return fail(nullptr, PF_ERR_NO_DEVICE, "pf_ctx_create: no HIP device (this library has no CPU fallback)");
   if (device < 0 || device >= count) return fail(nullptr, PF_ERR_ARG, "pf_ctx_create: bad device index");
   const pf_params& P = *params;
-  if (P.vehicle != PF_QUADX && P.vehicle != PF_FIXEDWING) return fail(nullptr, PF_ERR_ARG, "unknown vehicle");
+  if (P.vehicle != PF_QUADX && P.vehicle != PF_FIXEDWING && P.vehicle != PF_ROCKET) return fail(nullptr, PF_ERR_ARG, "unknown vehicle");
+  if (P.vehicle == PF_ROCKET && P.task != PF_TASK_NONE)
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "the Rocket is available through the Aviary-level entry points only (Rocket-Landing needs a resting contact)");
+  if (P.vehicle == PF_ROCKET && P.flight_mode != 0) return fail(nullptr, PF_ERR_ARG, "rocket flight_mode must be 0");
   if (P.task == PF_TASK_WAYPOINTS && (P.num_targets < 1 || P.num_targets > 4))
     return fail(nullptr, PF_ERR_UNSUPPORTED, "num_targets must be in 1..4");
   if (P.vehicle == PF_QUADX && (P.flight_mode < -1 || P.flight_mode > 7)) return fail(nullptr, PF_ERR_ARG, "quadx flight_mode must be in -1..7");
@@ -735,7 +739,9 @@ void pf_ctx_destroy(pf_ctx* ctx) {
   if (ctx->surf_dev) hipFree(ctx->surf_dev);
   delete ctx;
 }
-int pf_state_groups(const pf_ctx* ctx) { return ctx->P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : pf::Fixedwing::GROUPS; }
+int pf_state_groups(const pf_ctx* ctx) {
+  return ctx->P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : (ctx->P.vehicle == PF_ROCKET ? pf::Rocket::GROUPS : pf::Fixedwing::GROUPS);
+}
 int pf_obs_dim(const pf_ctx* ctx) {
   const pf_params& P = ctx->P;
   int aux = P.vehicle == PF_QUADX ? 4 : 6;
@@ -792,6 +798,8 @@ int pf_aviary_reset(pf_ctx* ctx, const pf_buffers* b, void* stream) {
   const float* pose = b->start_pose;
   if (ctx->P.vehicle == PF_QUADX)
     hipLaunchKernelGGL(pf::aviary_reset_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, pose);
+  else if (ctx->P.vehicle == PF_ROCKET)
+    hipLaunchKernelGGL(pf::aviary_reset_kernel<pf::Rocket>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, pose);
   else
     hipLaunchKernelGGL(pf::aviary_reset_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, pose);
   ctx->P.flight_mode = 0;  // drone.reset() -> set_mode(0) (quadx.py:224, fixedwing.py:196)
@@ -802,13 +810,16 @@ int pf_aviary_set_mode(pf_ctx* ctx, const pf_buffers* b, int mode, float* setpoi
   if (!ctx || !b || !b->state) return fail(ctx, PF_ERR_ARG, "pf_aviary_set_mode: state buffer required");
   if (ctx->P.vehicle == PF_QUADX && (mode < -1 || mode > 7)) return fail(ctx, PF_ERR_ARG, "`mode` must be between -1 and 7");
   if (ctx->P.vehicle == PF_FIXEDWING && (mode < -1 || mode > 0)) return fail(ctx, PF_ERR_ARG, "`mode` must be between -1 and 0");
+  if (ctx->P.vehicle == PF_ROCKET && mode != 0) return fail(ctx, PF_ERR_ARG, "`mode` must be 0 (rocket.py:238-247)");
   int rc = ensure_device(ctx);
   if (rc) return rc;
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
   hipStream_t s = (hipStream_t)stream;
-  const int sp_dim = (ctx->P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4;  // fixedwing.py:221-224
+  const int sp_dim = ctx->P.vehicle == PF_ROCKET ? 7 : ((ctx->P.vehicle == PF_FIXEDWING && mode == -1) ? 6 : 4);  // fixedwing.py:221-224, rocket.py:228
   if (ctx->P.vehicle == PF_QUADX)
     hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, sp_dim, mode, setpoints_out);
+  else if (ctx->P.vehicle == PF_ROCKET)
+    hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::Rocket>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, sp_dim, mode, setpoints_out);
   else
     hipLaunchKernelGGL(pf::aviary_set_mode_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, sp_dim, mode, setpoints_out);
   ctx->P.flight_mode = mode;
@@ -825,6 +836,8 @@ int pf_aviary_step(pf_ctx* ctx, const pf_buffers* b, int n_steps, void* stream) 
   hipStream_t s = (hipStream_t)stream;
   if (ctx->P.vehicle == PF_QUADX)
     hipLaunchKernelGGL(pf::aviary_step_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps, ctx->P_dev);
+  else if (ctx->P.vehicle == PF_ROCKET)
+    hipLaunchKernelGGL(pf::aviary_step_kernel<pf::Rocket>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps, ctx->P_dev);
   else
     hipLaunchKernelGGL(pf::aviary_step_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, n_steps, ctx->P_dev);
   PF_HIP(ctx, hipGetLastError());
@@ -840,12 +853,16 @@ int pf_aviary_tick(pf_ctx* ctx, const pf_buffers* b, int tick_index, void* strea
   hipStream_t s = (hipStream_t)stream;
   if (ctx->P.vehicle == PF_QUADX)
     hipLaunchKernelGGL(pf::aviary_tick_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, tick_index, ctx->P_dev);
+  else if (ctx->P.vehicle == PF_ROCKET)
+    hipLaunchKernelGGL(pf::aviary_tick_kernel<pf::Rocket>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, tick_index, ctx->P_dev);
   else
     hipLaunchKernelGGL(pf::aviary_tick_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, tick_index, ctx->P_dev);
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;
 }
-int pf_wind_links(const pf_ctx* ctx) { return ctx->P.vehicle == PF_QUADX ? pf::QuadX::WIND_LINKS : pf::Fixedwing::WIND_LINKS; }
+int pf_wind_links(const pf_ctx* ctx) {
+  return ctx->P.vehicle == PF_QUADX ? pf::QuadX::WIND_LINKS : (ctx->P.vehicle == PF_ROCKET ? pf::Rocket::WIND_LINKS : pf::Fixedwing::WIND_LINKS);
+}
 int pf_sample_actions(pf_ctx* ctx, float* actions, uint32_t step_index, void* stream) {
   if (!ctx || !actions) return fail(ctx, PF_ERR_ARG, "pf_sample_actions: bad argument");
   int rc = ensure_device(ctx);

@@ -72,8 +72,17 @@ struct Body {
     for (int k = 0; k < PF_MAX_BOXES; ++k) {
       if (k < P.n_boxes) {
         v3 c = p + mul(R, v3{P.boxes[k].c[0], P.boxes[k].c[1], P.boxes[k].c[2]});
-        if (P.boxes[k].kind == 1) hit |= cyl_overlaps_aabb(c, R, P.boxes[k].h[0], P.boxes[k].h[2], cb, hb);
-        else hit |= box_overlaps_aabb(c, R, P.boxes[k].h, cb, hb);
+        if (P.boxes[k].kind == 1) {
+          hit |= cyl_overlaps_aabb(c, R, P.boxes[k].h[0], P.boxes[k].h[2], cb, hb);
+        } else if (P.boxes[k].yaw != 0.0f) {  // a box on a yaw-rotated link: axes = R * Rz(yaw)
+          float sy, cy;
+          sincosf(P.boxes[k].yaw, &sy, &cy);
+          m3 Rr{R.m00 * cy + R.m01 * sy, -R.m00 * sy + R.m01 * cy, R.m02, R.m10 * cy + R.m11 * sy, -R.m10 * sy + R.m11 * cy, R.m12,
+                R.m20 * cy + R.m21 * sy, -R.m20 * sy + R.m21 * cy, R.m22};
+          hit |= box_overlaps_aabb(c, Rr, P.boxes[k].h, cb, hb);
+        } else {
+          hit |= box_overlaps_aabb(c, R, P.boxes[k].h, cb, hb);
+        }
       }
     }
     return hit;
@@ -94,6 +103,26 @@ struct Body {
       v3 cw = mul(R, com);
       a = a - cross(wdot, cw) - cross(w, cross(w, cw));
     }
+    const float dt = P.dt, vm = P.max_coord_vel;
+    w = v3{clampf(fmaf(wdot.x, dt, w.x), -vm, vm), clampf(fmaf(wdot.y, dt, w.y), -vm, vm), clampf(fmaf(wdot.z, dt, w.z), -vm, vm)};
+    v = v3{clampf(fmaf(a.x, dt, v.x), -vm, vm), clampf(fmaf(a.y, dt, v.y), -vm, vm), clampf(fmaf(a.z, dt, v.z), -vm, vm)};
+    p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z)};
+    q = quat_integrate(q, w, 0.5f * dt);
+    derive();
+    contact_step |= contact_now;
+  }
+  // The same tick for a body whose mass properties change over time (Rocket): inverse mass, centre of
+  // mass, gyroscopic inertia H and inverse inertia (symmetric xx xy xz yy yz zz) are arguments.
+  PF_DEV void tick_var(const pf_params& P, v3 F, v3 tau, float inv_mass, v3 com, const float H[6], const float Iinv[6]) {
+    contact_now = detect_contact(P);
+    tau = tau - cross(com, F);
+    v3 h = symmul(H, wb);
+    v3 wdot_b = symmul(Iinv, tau - cross(wb, h));
+    v3 wdot = mul(R, wdot_b);
+    v3 a = inv_mass * mul(R, F);
+    a.z += P.gravity_z;
+    v3 cw = mul(R, com);
+    a = a - cross(wdot, cw) - cross(w, cross(w, cw));
     const float dt = P.dt, vm = P.max_coord_vel;
     w = v3{clampf(fmaf(wdot.x, dt, w.x), -vm, vm), clampf(fmaf(wdot.y, dt, w.y), -vm, vm), clampf(fmaf(wdot.z, dt, w.z), -vm, vm)};
     v = v3{clampf(fmaf(a.x, dt, v.x), -vm, vm), clampf(fmaf(a.y, dt, v.y), -vm, vm), clampf(fmaf(a.z, dt, v.z), -vm, vm)};
@@ -323,6 +352,72 @@ struct QuadX {
   PF_DEV void set_cmd(float4 c) { pwm[0] = c.x; pwm[1] = c.y; pwm[2] = c.z; pwm[3] = c.w; }
 };
 
+// lifting_surfaces.py:266-498 for one surface; returns force & torque in the (axis-aligned) link
+// frame. libm-free: (cos a, sin a) come from the velocity components, the effective angle of attack
+// a_eff = a - (a_0 + a_i) by the angle-difference identities with a small-angle polynomial for the
+// second operand (|a_0 + a_i| < 0.8 rad for any surface the model admits), a itself (needed for the
+// regime tests and CM) from the polynomial atan2.
+PF_DEV void lifting_surface(const pf_surface& S, v3 vloc, float a, v3& F, v3& T) {
+  v3 lift{S.lift[0], S.lift[1], S.lift[2]}, drag{S.drag[0], S.drag[1], S.drag[2]};
+  float V2 = dot(vloc, vloc);
+  float la = dot(vloc, lift), fa = dot(vloc, drag);
+  float h2 = fmaf(la, la, fa * fa);
+  float ih = frsq(h2);
+  const bool still = !(h2 > 0.0f);
+  float ca = still ? 1.0f : fa * ih, sa = still ? 0.0f : -la * ih;
+  float alpha = fast_atan2(-la, fa);  // :342-345
+  // :386-394
+  float defl = a * S.deflection_limit_rad;
+  float dCl = S.Cl_alpha_3D * S.aero_tau_eta * defl;
+  float dClmax = S.flap_to_chord * dCl;
+  float ClmaxP = fmaf(S.Cl_alpha_3D, S.alpha_stall_P_base - S.alpha_0_base, dClmax);
+  float ClmaxN = fmaf(S.Cl_alpha_3D, S.alpha_stall_N_base - S.alpha_0_base, dClmax);
+  float a0 = S.alpha_0_base - dCl * S.inv_Cl_alpha_3D;
+  float aP = fmaf(ClmaxP, S.inv_Cl_alpha_3D, a0), aN = fmaf(ClmaxN, S.inv_Cl_alpha_3D, a0);
+  const bool linear = (aN < alpha) && (alpha < aP);
+  // induced angle: linear regime :397-399, post-stall two-point np.interp :409-425
+  float Cl_lin = S.Cl_alpha_3D * (alpha - a0);
+  float ai;
+  if (linear) {
+    ai = Cl_lin * S.inv_pi_aspect;
+  } else if (alpha > 0.0f) {
+    float ai_stall = S.Cl_alpha_3D * (aP - a0) * S.inv_pi_aspect;
+    float x0 = aP, x1 = 0.5f * kPi;
+    ai = (alpha <= x0) ? ai_stall : (alpha >= x1 ? 0.0f : ai_stall - ai_stall * frcp(x1 - x0) * (alpha - x0));
+  } else {
+    float ai_stall = S.Cl_alpha_3D * (aN - a0) * S.inv_pi_aspect;
+    float x0 = -0.5f * kPi, x1 = aN;
+    ai = (alpha <= x0) ? 0.0f : (alpha >= x1 ? ai_stall : ai_stall * frcp(x1 - x0) * (alpha - x0));
+  }
+  const float x = a0 + ai;
+  const float ae = alpha - x;
+  float sx, cx;
+  sincos_small(x, sx, cx);
+  const float se = sa * cx - ca * sx, ce = fmaf(ca, cx, sa * sx);
+  float Cl, Cd, CM;
+  if (linear) {  // :397-406
+    Cl = Cl_lin;
+    float CT = S.Cd_0 * ce;
+    float CN = (Cl + CT * se) * frcp(ce);
+    Cd = CN * se + CT * ce;
+    CM = -CN * (0.25f - 0.175f * (1.0f - 2.0f * ae * (1.0f / kPi)));
+  } else {  // :427-448
+    float Cd90 = fmaf(-4.26e-2f, defl * defl, fmaf(2.1e-1f, defl, 1.98f));
+    float CN = Cd90 * se * (frcp(0.56f + 0.44f * __builtin_fabsf(se)) - S.exp_term);
+    float CT = 0.5f * S.Cd_0 * ce;
+    Cl = CN * ce - CT * se;
+    Cd = CN * se + CT * ce;
+    CM = -CN * (0.25f - 0.175f * (1.0f - 2.0f * __builtin_fabsf(ae) * (1.0f / kPi)));
+  }
+  // :485-498
+  float QA = S.half_rho_area * V2;
+  float L = Cl * QA, D = Cd * QA;
+  float fn = L * ca + D * sa, fp = L * sa - D * ca;
+  F = v3{lift.x * fn + drag.x * fp, lift.y * fn + drag.y * fp, lift.z * fn + drag.z * fp};
+  float tm = QA * CM * S.chord;
+  T = v3{tm * S.torque[0], tm * S.torque[1], tm * S.torque[2]};
+}
+
 // ------------------------------------------------------------------------------------------
 // Fixedwing: drones/fixedwing.py + abstractions/lifting_surfaces.py
 struct Fixedwing {
@@ -393,71 +488,6 @@ struct Fixedwing {
     thr = 0.0f;
     set_mode(0, sp);
   }
-  // lifting_surfaces.py:266-498 for one surface; returns force & torque in the (axis-aligned) link
-  // frame. libm-free: (cos a, sin a) come from the velocity components, the effective angle of attack
-  // a_eff = a - (a_0 + a_i) by the angle-difference identities with a small-angle polynomial for the
-  // second operand (|a_0 + a_i| < 0.8 rad for any surface the model admits), a itself (needed for the
-  // regime tests and CM) from the polynomial atan2.
-  PF_DEV void surface(const pf_surface& S, v3 vloc, float a, v3& F, v3& T) const {
-    v3 lift{S.lift[0], S.lift[1], S.lift[2]}, drag{S.drag[0], S.drag[1], S.drag[2]};
-    float V2 = dot(vloc, vloc);
-    float la = dot(vloc, lift), fa = dot(vloc, drag);
-    float h2 = fmaf(la, la, fa * fa);
-    float ih = frsq(h2);
-    const bool still = !(h2 > 0.0f);
-    float ca = still ? 1.0f : fa * ih, sa = still ? 0.0f : -la * ih;
-    float alpha = fast_atan2(-la, fa);  // :342-345
-    // :386-394
-    float defl = a * S.deflection_limit_rad;
-    float dCl = S.Cl_alpha_3D * S.aero_tau_eta * defl;
-    float dClmax = S.flap_to_chord * dCl;
-    float ClmaxP = fmaf(S.Cl_alpha_3D, S.alpha_stall_P_base - S.alpha_0_base, dClmax);
-    float ClmaxN = fmaf(S.Cl_alpha_3D, S.alpha_stall_N_base - S.alpha_0_base, dClmax);
-    float a0 = S.alpha_0_base - dCl * S.inv_Cl_alpha_3D;
-    float aP = fmaf(ClmaxP, S.inv_Cl_alpha_3D, a0), aN = fmaf(ClmaxN, S.inv_Cl_alpha_3D, a0);
-    const bool linear = (aN < alpha) && (alpha < aP);
-    // induced angle: linear regime :397-399, post-stall two-point np.interp :409-425
-    float Cl_lin = S.Cl_alpha_3D * (alpha - a0);
-    float ai;
-    if (linear) {
-      ai = Cl_lin * S.inv_pi_aspect;
-    } else if (alpha > 0.0f) {
-      float ai_stall = S.Cl_alpha_3D * (aP - a0) * S.inv_pi_aspect;
-      float x0 = aP, x1 = 0.5f * kPi;
-      ai = (alpha <= x0) ? ai_stall : (alpha >= x1 ? 0.0f : ai_stall - ai_stall * frcp(x1 - x0) * (alpha - x0));
-    } else {
-      float ai_stall = S.Cl_alpha_3D * (aN - a0) * S.inv_pi_aspect;
-      float x0 = -0.5f * kPi, x1 = aN;
-      ai = (alpha <= x0) ? 0.0f : (alpha >= x1 ? ai_stall : ai_stall * frcp(x1 - x0) * (alpha - x0));
-    }
-    const float x = a0 + ai;
-    const float ae = alpha - x;
-    float sx, cx;
-    sincos_small(x, sx, cx);
-    const float se = sa * cx - ca * sx, ce = fmaf(ca, cx, sa * sx);
-    float Cl, Cd, CM;
-    if (linear) {  // :397-406
-      Cl = Cl_lin;
-      float CT = S.Cd_0 * ce;
-      float CN = (Cl + CT * se) * frcp(ce);
-      Cd = CN * se + CT * ce;
-      CM = -CN * (0.25f - 0.175f * (1.0f - 2.0f * ae * (1.0f / kPi)));
-    } else {  // :427-448
-      float Cd90 = fmaf(-4.26e-2f, defl * defl, fmaf(2.1e-1f, defl, 1.98f));
-      float CN = Cd90 * se * (frcp(0.56f + 0.44f * __builtin_fabsf(se)) - S.exp_term);
-      float CT = 0.5f * S.Cd_0 * ce;
-      Cl = CN * ce - CT * se;
-      Cd = CN * se + CT * ce;
-      CM = -CN * (0.25f - 0.175f * (1.0f - 2.0f * __builtin_fabsf(ae) * (1.0f / kPi)));
-    }
-    // :485-498
-    float QA = S.half_rho_area * V2;
-    float L = Cl * QA, D = Cd * QA;
-    float fn = L * ca + D * sa, fp = L * sa - D * ca;
-    F = v3{lift.x * fn + drag.x * fp, lift.y * fn + drag.y * fp, lift.z * fn + drag.z * fp};
-    float tm = QA * CM * S.chord;
-    T = v3{tm * S.torque[0], tm * S.torque[1], tm * S.torque[2]};
-  }
   float cmd[6];
   template <int MODE_T>
   PF_DEV void control(const pf_params& P, const float sp[6], float = 0.0f) {  // fixedwing.py:229-259 (stateless: no period)
@@ -493,7 +523,7 @@ struct Fixedwing {
       v3 vloc = b.vb + cross(b.wb, r);  // lifting_surfaces.py:73-110
       if (wind) vloc = vloc - mulT(b.R, v3{wind[3 * i + 0], wind[3 * i + 1], wind[3 * i + 2]});
       v3 f, t;
-      surface(S, vloc, ai, f, t);
+      lifting_surface(S, vloc, ai, f, t);
       F = F + f;
       tau = tau + cross(r, f) + t;
     }

@@ -140,7 +140,7 @@ class BatchEngine:
     # ------------------------------------------------------------------ Aviary level
     def _aviary_outputs(self):
         if self.out_state is None:
-            aux = 4 if self.params.vehicle == L.QUADX else 6
+            aux = {L.QUADX: 4, L.FIXEDWING: 6, L.ROCKET: 9}[self.params.vehicle]
             self.out_state = torch.zeros(self.n, 12, dtype=torch.float32, device=self.device)
             self.out_aux = torch.zeros(self.n, aux, dtype=torch.float32, device=self.device)
             self.out_contact = torch.zeros(self.n, dtype=torch.bool, device=self.device)
@@ -185,7 +185,7 @@ class BatchEngine:
     # ------------------------------------------------------------------ state views
     def ints(self):
         """[n, 4] int32 view: step_count, flags, rng_ctr, n_targets_left."""
-        g = 6 if self.params.vehicle == L.QUADX else 5
+        g = 5 if self.params.vehicle == L.FIXEDWING else 6
         return self.state[g].view(torch.int32)
 
     def flags(self):

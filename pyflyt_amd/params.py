@@ -111,6 +111,44 @@ FIXEDWING: dict[str, Any] = {
     "control_hz": 120,                                  # drones/fixedwing.py:24
 }
 
+ROCKET: dict[str, Any] = {
+    # models/vehicles/rocket/rocket.urdf: (mass, link COM, own diagonal inertia) in joint order; index 0 = base.
+    # base :37-38 | fuel tank :58-59,69 | booster :78-79,95 | fins :104,121 :130,147 :156,173 :182,199 |
+    # legs :208,225 :234,251 :260,277 (massless; they carry collision boxes)
+    "links": [
+        (91.0, (0.0, 0.0, 0.0), (372.6, 372.6, 1.55)),
+        (410.9, (0.0, 0.0, 0.0), (1678.0, 1678.0, 7.01)),   # fuel tank: mass and inertia scale with the fuel left
+        (47.0, (0.0, 0.0, -2.0), (192.43, 192.43, 0.81)),
+        (0.05, (0.35, 0.0, 2.051), (0.0, 0.0, 0.0)), (0.05, (-0.35, 0.0, 2.051), (0.0, 0.0, 0.0)),
+        (0.05, (0.0, 0.35, 2.051), (0.0, 0.0, 0.0)), (0.05, (0.0, -0.35, 2.051), (0.0, 0.0, 0.0)),
+    ],
+    "fueltank_link": 1, "booster_link": 2,
+    # collision: base cylinder :43 (the fuel tank's :64 lies inside it), booster cylinder :84, fin boxes
+    # :110,136,162,188, leg boxes :214,240,266 on links yawed by :225,251,277
+    "collision_cylinders": [((0.0, 0.0, 0.0), 0.185, 4.77), ((0.0, 0.0, -2.0), 0.25, 0.5)],
+    "collision_boxes": [((0.35, 0.0, 2.051), (0.3, 0.03, 0.3)), ((-0.35, 0.0, 2.051), (0.3, 0.03, 0.3)),
+                        ((0.0, 0.35, 2.051), (0.03, 0.3, 0.3)), ((0.0, -0.35, 2.051), (0.03, 0.3, 0.3))],
+    "collision_boxes_yawed": [((0.0, 0.35, -2.4), (0.05, 0.5, 0.05), 0.0), ((0.3031, -0.175, -2.4), (0.05, 0.5, 0.05), 4.188),
+                              ((-0.3031, -0.175, -2.4), (0.05, 0.5, 0.05), -4.188)],
+    # models/vehicles/rocket/rocket.yaml:7-19
+    "total_fuel": 410.9, "max_fuel_rate": 1.451, "fuel_inertia": (1678.0, 1678.0, 7.01), "min_thrust": 2966.7,
+    "max_thrust": 7607.0, "reignitable": True, "gimbal_range_degrees": 5.0, "booster_tau": 0.01, "gimbal_tau": 0.01,
+    "noise_ratio": 0.01,
+    # rocket.yaml:21-32; drones/rocket.py:114-142: "x fins" lift along y, "y fins" along x, all facing -z. The reference
+    # binds the four LiftingSurface objects to link ids 0..3 = fuel tank, booster, fin_pos_x, fin_neg_x (surface_id=finlet_id),
+    # not to the four fin links: that is where they sample velocity and apply force, and what is reproduced here.
+    "finlet": dict(Cl_alpha_2D=6.283, chord=0.5, span=0.5, flap_to_chord=1.0, eta=0.65, alpha_0_base=0.0,
+                   alpha_stall_P_base=20.0, alpha_stall_N_base=-20.0, Cd_0=0.01, deflection_limit=45.0, tau=0.05),
+    "finlet_links": (1, 2, 3, 4),                   # indices into "links" (= link ids 0..3)
+    "finlet_lift": ((0, 1, 0), (0, 1, 0), (1, 0, 0), (1, 0, 0)),
+    "finlet_forward": (0, 0, -1),
+    "finlet_map": ((0.0, 1.0, 1.0), (0.0, 1.0, -1.0), (1.0, 0.0, -1.0), (1.0, 0.0, 1.0)),  # rocket.py:152-159
+    # rocket.yaml:34-40
+    "drag_coef": (1.16, 1.16, 2.0), "drag_area": (1.7649, 1.7649, 0.1075),
+    "starting_fuel_ratio": 0.05,                    # rocket.py:47
+    "control_hz": 120,                              # rocket.py:36
+}
+
 WORLD: dict[str, Any] = {
     "physics_hz": 240,         # core/aviary.py:79
     "gravity_z": -9.81,        # core/aviary.py:226
@@ -144,9 +182,9 @@ def _fill(arr, vals):
         arr[i] = v
 
 
-def _set_body(P, links, own_inertia, boxes, cylinders=()):
+def _set_body(P, links, own_inertia, boxes, cylinders=(), yawed_boxes=()):
     """links: [(mass, r)], own_inertia: 3x3 sum of link inertias (base frame, about their own COMs).
-    boxes: [(centre, size)]; cylinders: [(centre, radius, length)], axis = link z."""
+    boxes: [(centre, size)]; cylinders: [(centre, radius, length)], axis = link z; yawed_boxes: [(centre, size, yaw)]."""
     m = np.array([l[0] for l in links], dtype=np.float64)
     r = np.array([l[1] for l in links], dtype=np.float64)
     M = m.sum()
@@ -162,17 +200,20 @@ def _set_body(P, links, own_inertia, boxes, cylinders=()):
     _fill(P.I_pa, _sym6(I_pa))
     _fill(P.I_inv, _sym6(I_inv))
     P.has_com_offset = int(np.abs(com).max() > 0.0)
-    if len(boxes) + len(cylinders) > L.PF_MAX_BOXES:
+    if len(boxes) + len(cylinders) + len(yawed_boxes) > L.PF_MAX_BOXES:
         raise ValueError(f"at most {L.PF_MAX_BOXES} collision shapes per vehicle")
-    P.n_boxes = len(boxes) + len(cylinders)
+    P.n_boxes = len(boxes) + len(cylinders) + len(yawed_boxes)
     rad = 0.0
-    shapes = [(c, 0.5 * np.array(size, dtype=np.float64), 0) for c, size in boxes] + \
-             [(c, np.array([r, r, 0.5 * length], dtype=np.float64), 1) for c, r, length in cylinders]
-    for k, (c, h, kind) in enumerate(shapes):
+    shapes = [(c, 0.5 * np.array(size, dtype=np.float64), 0, 0.0) for c, size in boxes] + \
+             [(c, np.array([r, r, 0.5 * length], dtype=np.float64), 1, 0.0) for c, r, length in cylinders] + \
+             [(c, 0.5 * np.array(size, dtype=np.float64), 0, float(yaw)) for c, size, yaw in yawed_boxes]
+    for k, (c, h, kind, yaw) in enumerate(shapes):
         _fill(P.boxes[k].c, c)
         _fill(P.boxes[k].h, h)
         P.boxes[k].kind = kind
-        rad = max(rad, float(np.linalg.norm(np.abs(np.array(c)) + h)))
+        P.boxes[k].yaw = yaw
+        # (a yawed box's own bounding sphere: its half-diagonal, whatever the yaw)
+        rad = max(rad, float(np.linalg.norm(c) + np.linalg.norm(h)) if yaw else float(np.linalg.norm(np.abs(np.array(c)) + h)))
     # nudged up so that fp32 rounding can never make the early-out stricter than the exact test
     P.bound_radius = rad * (1.0 + 1e-6)
 
@@ -201,7 +242,7 @@ def build_params(
     vehicle_options: dict | None = None,
     world_options: dict | None = None,
 ) -> L.PfParams:
-    """vehicle in {'quadx','fixedwing'}; task in {'none','hover','waypoints','ma_hover'}."""
+    """vehicle in {'quadx','fixedwing','rocket'}; task in {'none','hover','waypoints','ma_hover'}."""
     W = dict(WORLD, **(world_options or {}))
     P = L.PfParams()
     P.noise_mode = {"off": L.NOISE_OFF, "inject": L.NOISE_INJECT, "philox": L.NOISE_PHILOX}[noise]
@@ -296,6 +337,55 @@ def build_params(
         _fill(P.assist_signs, V["assist_signs"])
         default_start, start_vel = (0.0, 0.0, 10.0), V["starting_velocity"]  # fixedwing_waypoints_env.py:63
         low, high = (-1.0,) * 4, (1.0,) * 4  # fixedwing_base_env.py:78-80
+    elif vehicle == "rocket":
+        if task != "none":
+            raise ValueError("the Rocket is available at the Aviary level only (Rocket-Landing needs a resting contact)")
+        V = copy.deepcopy(ROCKET)
+        V.update(vehicle_options or {})
+        P.vehicle = L.ROCKET
+        links = V["links"]
+        own = np.diag(np.sum([l[2] for l in links], axis=0)).astype(np.float64)
+        _set_body(P, [(l[0], l[1]) for l in links], own, V["collision_boxes"], V["collision_cylinders"], V["collision_boxes_yawed"])
+        P.n_motors = 1  # np_random.normal(*throttle.shape) with one booster: xi ~ N(1, 1) (boosters.py:236-240)
+        K = P.rocket
+        ft, bo = V["fueltank_link"], V["booster_link"]
+        dry = [l for i, l in enumerate(links) if i != ft]
+        m = np.array([l[0] for l in dry], dtype=np.float64); r = np.array([l[1] for l in dry], dtype=np.float64)
+        K.dry_mass = m.sum()
+        _fill(K.dry_mr, (m[:, None] * r).sum(0))
+        S = sum(mi * ((ri @ ri) * np.eye(3) - np.outer(ri, ri)) for mi, ri in zip(m, r))
+        _fill(K.dry_S, _sym6(S))
+        _fill(K.dry_I, np.sum([l[2] for l in dry], axis=0))
+        _fill(K.tank_r, links[ft][1]); _fill(K.booster_r, links[bo][1])
+        K.total_fuel = V["total_fuel"]; K.fuel_rate_ratio = V["max_fuel_rate"] / V["total_fuel"]
+        _fill(K.fuel_inertia, V["fuel_inertia"])
+        K.thrust_min_ratio = V["min_thrust"] / V["max_thrust"]; K.max_thrust = V["max_thrust"]
+        K.booster_dt_over_tau = dt / V["booster_tau"]; K.booster_noise = V["noise_ratio"]
+        K.reignitable = int(bool(V["reignitable"]))
+        K.gimbal_dt_over_tau = dt / V["gimbal_tau"]; K.gimbal_range_rad = math.radians(V["gimbal_range_degrees"])
+        for i in range(4):
+            _fill(K.finlet_map[i], V["finlet_map"][i])
+        K.starting_fuel_ratio = float(V["starting_fuel_ratio"])
+        P.n_surf = 4
+        f = V["finlet"]
+        for i in range(4):  # abstractions/lifting_surfaces.py:228-239
+            Sf = P.surf[i]
+            lift = np.array(V["finlet_lift"][i], dtype=np.float64); fwd = np.array(V["finlet_forward"], dtype=np.float64)
+            aspect = f["span"] / f["chord"]
+            Cl3D = f["Cl_alpha_2D"] * (aspect / (aspect + ((2.0 * (aspect + 4.0)) / (aspect + 2.0))))
+            theta_f = math.acos(2.0 * f["flap_to_chord"] - 1.0)
+            aero_tau = 1.0 - ((theta_f - math.sin(theta_f)) / math.pi)
+            _fill(Sf.r, links[V["finlet_links"][i]][1]); _fill(Sf.lift, lift); _fill(Sf.drag, fwd); _fill(Sf.torque, np.cross(lift, fwd))
+            Sf.Cl_alpha_3D = Cl3D; Sf.inv_Cl_alpha_3D = 1.0 / Cl3D; Sf.aero_tau_eta = aero_tau * f["eta"]
+            Sf.flap_to_chord = f["flap_to_chord"]; Sf.inv_pi_aspect = 1.0 / (math.pi * aspect)
+            Sf.exp_term = 0.41 * (1.0 - math.exp(-17.0 / aspect))
+            Sf.alpha_0_base = math.radians(f["alpha_0_base"]); Sf.alpha_stall_P_base = math.radians(f["alpha_stall_P_base"])
+            Sf.alpha_stall_N_base = math.radians(f["alpha_stall_N_base"]); Sf.Cd_0 = f["Cd_0"]
+            Sf.deflection_limit_rad = math.radians(f["deflection_limit"]); Sf.dt_over_tau = dt / f["tau"]
+            Sf.half_rho_area = 0.5 * 1.225 * f["chord"] * f["span"]; Sf.chord = f["chord"]
+        _fill(P.drag_const, [0.5 * 1.225 * c * a for c, a in zip(V["drag_coef"], V["drag_area"])])  # boring_bodies.py:63
+        default_start, start_vel = (0.0, 0.0, 1.0), (0.0, 0.0, 0.0)
+        low, high = (-1.0,) * 4, (1.0,) * 4
     else:
         raise ValueError(f"unknown vehicle {vehicle!r}")
 

@@ -182,10 +182,14 @@ def test_aviary_errors():
     with pytest.raises(AviaryInitException):
         Aviary(np.zeros((4, 2)), np.zeros((4, 2)))
     with pytest.raises(AviaryInitException):
-        Aviary(np.zeros((4, 3)), np.zeros((4, 3)), drone_type="rocket")
+        Aviary(np.zeros((4, 3)), np.zeros((4, 3)), drone_type="quadplane")
     env = Aviary(np.array([[0, 0, 1.0]]), np.zeros((1, 3)))
     with pytest.raises(ValueError):
         env.set_mode(8)
+    rk = Aviary(np.array([[0, 0, 50.0]]), np.zeros((1, 3)), drone_type="rocket")
+    with pytest.raises(ValueError):
+        rk.set_mode(1)  # rocket.py:238-247: mode 0 only
+    rk.disconnect()
 
 
 @pytest.mark.parametrize("drone", ["quadx", "fixedwing"])
@@ -335,4 +339,84 @@ def test_multi_spawn_different_control_rates(mode, steps):
     assert worst < RTOL
     with pytest.raises(AssertionError):  # aviary.py:292-297
         Aviary(start_pos[:2], start_orn[:2], drone_type="quadx", drone_options=[dict(control_hz=80), dict(control_hz=120)])
+    env.disconnect()
+
+
+@pytest.mark.parametrize("fuel", [0.05, 0.6])
+def test_rocket_aviary_parity(fuel):
+    """Rocket (drones/rocket.py) through the batched Aviary against the oracle (itself pinned on three
+    reference-generated trajectories): grid fins, gimballed booster, fuel burn with the composite mass /
+    centre of mass / inertia rebuilt every tick, per-axis body drag, Philox booster noise."""
+    from pyflyt_amd.core import Aviary
+
+    n, steps, seed = 128, 150, 77
+    rng = np.random.default_rng(seed)
+    start_pos = np.concatenate([rng.uniform(-5, 5, size=(n, 2)), rng.uniform(100.0, 200.0, size=(n, 1))], axis=1).astype(np.float32)
+    start_orn = rng.uniform(-0.2, 0.2, size=(n, 3)) * np.array([1, 1, 5.0])
+    env = Aviary(start_pos, start_orn, drone_type="rocket", seed=seed, drone_options=dict(starting_fuel_ratio=fuel))
+    env.set_mode(0)
+    assert env.setpoints.shape == (n, 7) and env.all_aux_states.shape == (n, 9)
+    lib = O.lib()
+    Ps, Ls = [], []
+    for i in range(n):
+        P = O.make_params("rocket", noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=start_pos[i].astype(np.float64),
+                          start_rpy=start_orn[i], starting_fuel_ratio=fuel)
+        L = O.Lane()
+        lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
+        lib.orc_set_mode(C.byref(P), C.byref(L), 0)
+        Ps.append(P); Ls.append(L)
+    worst = 0.0
+    for k in range(steps):
+        if k % 25 == 3:  # fins x, y, yaw | ignition | throttle | gimbal 1, 2 (rocket.py:230-236)
+            sp = np.concatenate([rng.uniform(-0.6, 0.6, size=(n, 3)), (rng.random((n, 1)) < 0.8).astype(np.float64),
+                                 rng.uniform(0, 1, size=(n, 1)), rng.uniform(-1, 1, size=(n, 2))], axis=1).astype(np.float32)
+            env.set_all_setpoints(sp)
+            for i, L in enumerate(Ls):
+                for j in range(7):
+                    L.setpoint[j] = float(sp[i, j])
+        env.step()
+        for P, L in zip(Ps, Ls):
+            lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+            L.rng_ctr += 1
+        st = np.array([list(L.w_b) + list(L.rpy) + list(L.v_b) + list(L.p) for L in Ls]).reshape(n, 4, 3)
+        aux = np.array([list(L.actuation)[:4] + [float(L.ignition), L.fuel_ratio, L.throttle[0]] + list(L.gimbal) for L in Ls])
+        g = env.all_states.cpu().numpy().astype(np.float64)
+        ga = env.all_aux_states.cpu().numpy().astype(np.float64)
+        scale = np.maximum(1.0, np.linalg.norm(st, axis=2, keepdims=True))
+        worst = max(worst, float((np.abs(g - st) / scale).max()), float(np.abs(ga - aux).max()))
+    print(f"rocket fuel {fuel}: worst {worst:.2e}")
+    assert worst < RTOL
+    assert (aux[:, 5] < fuel).any()  # fuel was burnt
+    env.disconnect()
+
+
+def test_rocket_drop_contact():
+    """Engine off, tilted, from a few metres: a leg (yaw-rotated box), the booster or the body cylinder
+    reaches the floor; the contact flag must rise with the oracle's (within one Aviary step at a rounding
+    boundary)."""
+    from pyflyt_amd.core import Aviary
+
+    n = 96
+    rng = np.random.default_rng(8)
+    start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(3.0, 5.0, size=(n, 1))], axis=1).astype(np.float32)
+    start_orn = np.concatenate([rng.uniform(-0.6, 0.6, size=(n, 2)), rng.uniform(-3, 3, size=(n, 1))], axis=1)
+    env = Aviary(start_pos, start_orn, drone_type="rocket", seed=1, motor_noise=False, drone_options=dict(starting_fuel_ratio=0.0))
+    lib = O.lib()
+    Ps, Ls = [], []
+    for i in range(n):
+        P = O.make_params("rocket", noise_mode=O.NOISE_OFF, start_pos=start_pos[i].astype(np.float64), start_rpy=start_orn[i], starting_fuel_ratio=0.0)
+        L = O.Lane()
+        lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
+        Ps.append(P); Ls.append(L)
+    first_g = np.full(n, -1); first_r = np.full(n, -1)
+    for k in range(120):
+        env.step()
+        cg = env.contact_array.cpu().numpy()
+        for i, (P, L) in enumerate(zip(Ps, Ls)):
+            lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+            if L.contact_step and first_r[i] < 0:
+                first_r[i] = k
+        first_g[(first_g < 0) & cg] = k
+    assert (first_r >= 0).all()
+    assert (np.abs(first_g - first_r) <= 1).all() and (first_g == first_r).mean() >= 0.97
     env.disconnect()

@@ -47,13 +47,14 @@ class WindField:  # the constructor protocol of core/aviary.py:277-283
 
 
 @pytest.mark.parametrize("drone,mode,kind", [("quadx", 6, "register"), ("quadx", 0, "ctor"), ("quadx", 7, "ctor"),
-                                             ("fixedwing", 0, "ctor"), ("fixedwing", 0, "register")])
+                                             ("fixedwing", 0, "ctor"), ("fixedwing", 0, "register"),
+                                             ("rocket", 0, "ctor"), ("rocket", 0, "register")])
 def test_aviary_wind_parity(drone, mode, kind):
     from pyflyt_amd.core import Aviary
 
     n, steps, seed = 96, 80, 70 + mode
     rng = np.random.default_rng(seed)
-    z0 = 1.5 if drone == "quadx" else 10.0
+    z0 = {"quadx": 1.5, "fixedwing": 10.0, "rocket": 120.0}[drone]
     start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(z0, z0 + 1.0, size=(n, 1))], axis=1)
     start_orn = rng.uniform(-0.15, 0.15, size=(n, 3)) * np.array([1, 1, 5.0])
     if kind == "ctor":
@@ -79,14 +80,21 @@ def test_aviary_wind_parity(drone, mode, kind):
 
     def ref_state():
         st = np.array([[list(L.w_b), list(L.rpy), list(L.v_b), list(L.p)] for L in Ls])
-        aux = np.array([list(L.actuation) + [L.throttle[0]] if drone == "fixedwing" else list(L.throttle) for L in Ls])
+        if drone == "rocket":
+            aux = np.array([list(L.actuation)[:4] + [float(L.ignition), L.fuel_ratio, L.throttle[0]] + list(L.gimbal) for L in Ls])
+        else:
+            aux = np.array([list(L.actuation) + [L.throttle[0]] if drone == "fixedwing" else list(L.throttle) for L in Ls])
         return st, aux
 
     ok = np.ones(n, dtype=bool)
     worst = 0.0
     for k in range(steps):
         if k % 20 == 5:
-            sp = sample_setpoint(rng, n, drone, mode).astype(np.float32)
+            if drone == "rocket":
+                sp = np.concatenate([rng.uniform(-0.6, 0.6, size=(n, 3)), (rng.random((n, 1)) < 0.8).astype(np.float64),
+                                     rng.uniform(0, 1, size=(n, 1)), rng.uniform(-1, 1, size=(n, 2))], axis=1).astype(np.float32)
+            else:
+                sp = sample_setpoint(rng, n, drone, mode).astype(np.float32)
             env.set_all_setpoints(sp)
             for i, L in enumerate(Ls):
                 for j in range(sp.shape[1]):
@@ -108,7 +116,7 @@ def test_aviary_wind_parity(drone, mode, kind):
     med = float(np.median(e))
     print(f"wind {drone} mode {mode} {kind}: worst {worst:.2e}, dropped {1 - ok.mean():.4f}, median at end {med:.1e}")
     assert med < RTOL
-    if drone == "fixedwing" or mode == 0:
+    if drone in ("fixedwing", "rocket") or mode == 0:
         assert ok.mean() >= 0.99
     assert env.elapsed_time == pytest.approx(steps * env.updates_per_step / env.physics_hz)
     env.disconnect()

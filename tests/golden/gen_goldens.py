@@ -260,6 +260,9 @@ def gen_wind():
     save("aviary_fixedwing_wind_ctor", **d)
     d = run_aviary("fixedwing", 0, 100, seed=44, start_pos=[0.0, 0.0, 10.0], start_orn=[0.0, 0.0, 0.0], noise=True, wind="register")
     save("aviary_fixedwing_wind_register", **d)
+    d = run_aviary("rocket", 0, 120, seed=45, start_pos=[1.0, -2.0, 150.0], start_orn=[-0.1, 0.15, -1.0], noise=True, wind="ctor",
+                   drone_options=dict(starting_fuel_ratio=0.3))
+    save("aviary_rocket_wind_ctor", **d)
 
 
 # --------------------------------------------------------------------------- env level

@@ -137,7 +137,7 @@ def wind_from_coef(c):
 
 
 @pytest.mark.parametrize("name", ["aviary_quadx_wind_register", "aviary_quadx_wind_ctor",
-                                  "aviary_fixedwing_wind_ctor", "aviary_fixedwing_wind_register"])
+                                  "aviary_fixedwing_wind_ctor", "aviary_fixedwing_wind_register", "aviary_rocket_wind_ctor"])
 def test_aviary_wind_trajectory(golden_dir, name):
     """Wind hook (aviary.py:266-285,324-333): sampled in update_state at the link positions with the
     Aviary's (lagging) elapsed time, subtracted from the link velocities that feed the body drag
@@ -146,11 +146,19 @@ def test_aviary_wind_trajectory(golden_dir, name):
     the constructor, sampled in reset()."""
     g = load(golden_dir, name)
     fw = "fixedwing" in name
-    P = O.make_params("fixedwing" if fw else "quadx", noise_mode=O.NOISE_INJECT,
-                      start_pos=g["start_pos"], start_rpy=g["start_orn"])
+    rocket = "rocket" in name
+    extra = dict(starting_fuel_ratio=0.3) if rocket else {}
+    P = O.make_params("rocket" if rocket else ("fixedwing" if fw else "quadx"), noise_mode=O.NOISE_INJECT,
+                      start_pos=g["start_pos"], start_rpy=g["start_orn"], **extra)
     L = O.Lane()
     lib = O.lib()
     fn = wind_from_coef(g["wind_coef"])
+    if rocket:
+        def lane_state(L, _fw):  # noqa: F811 -- rocket aux layout (rocket.py:320-326)
+            st = np.array([list(L.w_b), list(L.rpy), list(L.v_b), list(L.p)])
+            return st, np.array(list(L.actuation)[:4] + [float(L.ignition), L.fuel_ratio, L.throttle[0]] + list(L.gimbal))
+    else:
+        lane_state = globals()["lane_state"]
     keep = None
     if int(g["wind_kind"]) == 2:
         keep = O.set_wind(P, fn)
@@ -171,7 +179,8 @@ def test_aviary_wind_trajectory(golden_dir, name):
     assert keep is not None
     assert worst < TOL, worst
     # and the wind matters: the same run without it must differ visibly
-    P2 = O.make_params("fixedwing" if fw else "quadx", noise_mode=O.NOISE_INJECT, start_pos=g["start_pos"], start_rpy=g["start_orn"])
+    P2 = O.make_params("rocket" if rocket else ("fixedwing" if fw else "quadx"), noise_mode=O.NOISE_INJECT, start_pos=g["start_pos"],
+                       start_rpy=g["start_orn"], **extra)
     L2 = O.Lane()
     lib.orc_aviary_reset(C.byref(P2), C.byref(L2), 0)
     lib.orc_set_mode(C.byref(P2), C.byref(L2), int(g["mode"]))

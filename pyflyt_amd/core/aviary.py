@@ -18,8 +18,9 @@ Same surface as the reference where it is on the hot path:
                     function of (time, positions[M,3] device tensor) -> wind[M,3] device tensor,
                     sampled after every physics tick exactly where and when the reference samples
                     it (boring_bodies.py:93-96, lifting_surfaces.py:88-93)
+Several drone types in one Aviary are composed from one engine per type (core/mixed.py).
 Not carried over (out of scope): rendering/cameras, custom Python controllers,
-mixed drone types, partial arming, drone-drone contact.
+partial arming, drone-drone contact.
 """
 from __future__ import annotations
 
@@ -38,6 +39,14 @@ class AviaryInitException(Exception):
 
 
 class Aviary:
+    def __new__(cls, start_pos=None, start_orn=None, drone_type="quadx", *args, **kwargs):
+        # several drone types in one Aviary (core/aviary.py:139-175): one engine per type behind one surface
+        if cls is Aviary and not isinstance(drone_type, str) and len(set(drone_type)) > 1:
+            from .mixed import MixedAviary
+
+            return MixedAviary(start_pos, start_orn, drone_type, *args, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, start_pos, start_orn, drone_type: str | Sequence[str] = "quadx", drone_options: dict | None = None,
                  wind_type=None, wind_options=None, render: bool = False, physics_hz: int = 240, world_scale: float = 1.0,
                  seed: None | int = None, device="cuda:0", motor_noise: bool = True, lane_offset: int = 0):
@@ -48,10 +57,9 @@ class Aviary:
         if start_orn.shape != start_pos.shape:  # :129-136
             raise AviaryInitException(f"start_orn must be same shape as start_pos, currently {start_orn.shape}.")
         if not isinstance(drone_type, str):
-            kinds = set(drone_type)
-            if len(kinds) != 1:
-                raise AviaryInitException("the batched Aviary needs one drone type for the whole batch")
-            drone_type = kinds.pop()
+            if len(drone_type) != start_pos.shape[0]:  # core/aviary.py:139-143
+                raise AviaryInitException(f"If multiple `drone_types` are used, must have same number of `drone_types` ({len(drone_type)}) as number of drones ({start_pos.shape[0]}).")
+            drone_type = drone_type[0]  # (several distinct types are handled by MixedAviary, see __new__)
         if drone_type not in ("quadx", "fixedwing", "rocket"):
             raise AviaryInitException(f"drone_type {drone_type!r} is not on the batched path (quadx, fixedwing, rocket)")
         if render:

@@ -420,3 +420,43 @@ def test_rocket_drop_contact():
     assert (first_r >= 0).all()
     assert (np.abs(first_g - first_r) <= 1).all() and (first_g == first_r).mean() >= 0.97
     env.disconnect()
+
+
+def test_mixed_drones():
+    """Mirror of the reference's tests/test_core.py:228-259 (`test_mixed_drones`): a rocket, a quadx and a
+    fixedwing in one Aviary with per-drone options and per-drone flight modes. Each drone must fly exactly
+    as it does alone (same seed, same global lane), and the combined accessors keep the caller's order."""
+    from pyflyt_amd.core import Aviary, MixedAviary
+
+    start_pos = np.array([[0.0, 5.0, 5.0], [0.0, 0.0, 1.0], [5.0, 0.0, 1.0], [1.0, 1.0, 2.0]])
+    start_orn = np.zeros_like(start_pos)
+    start_orn[0, 0] = np.pi / 2
+    types = ["rocket", "quadx", "fixedwing", "quadx"]
+    options = [dict(), dict(use_camera=True), dict(starting_velocity=np.array([0.0, 0.0, 0.0])), dict(use_camera=True)]
+    env = Aviary(start_pos=start_pos, start_orn=start_orn, render=False, drone_type=types, drone_options=options, seed=11)
+    assert isinstance(env, MixedAviary) and env.num_drones == 4
+    env.set_mode([0, 7, 0, 7])
+    alone = [Aviary(start_pos[[i]], start_orn[[i]], drone_type=t, drone_options=options[i], seed=11, lane_offset={0: 0, 1: 1, 2: 2, 3: 2}[i])
+             for i, t in enumerate(types)]
+    # (the two quadx share one engine: lanes 1 and 2 of the global numbering -> offsets 1 and 1+1)
+    for a, m in zip(alone, [0, 7, 0, 7]):
+        a.set_mode(m)
+    env.set_setpoint(1, np.array([1.0, 0.0, 0.0, 2.0])); alone[1].set_setpoint(0, np.array([1.0, 0.0, 0.0, 2.0]))
+    env.set_setpoint(0, np.array([0.1, 0.0, 0.0, 1.0, 0.5, 0.2, -0.2])); alone[0].set_setpoint(0, np.array([0.1, 0.0, 0.0, 1.0, 0.5, 0.2, -0.2]))
+    for _ in range(100):
+        _ = env.all_states
+        env.step()
+        for a in alone:
+            a.step()
+    st = env.all_states
+    assert st.shape == (4, 4, 3)
+    for i, a in enumerate(alone):
+        assert torch.equal(st[i], a.state(0)), i
+        assert torch.equal(env.aux_state(i), a.aux_state(0))
+    assert [len(x) for x in env.all_aux_states] == [9, 4, 6, 4]
+    assert env.contact_array.shape == (4,)
+    with pytest.raises(NotImplementedError):
+        env.set_mode([0, 7, 0, 6])  # two quadx in different modes share one engine
+    env.disconnect()
+    for a in alone:
+        a.disconnect()

@@ -19,8 +19,8 @@ Same surface as the reference where it is on the hot path:
                     sampled after every physics tick exactly where and when the reference samples
                     it (boring_bodies.py:93-96, lifting_surfaces.py:88-93)
 Several drone types in one Aviary are composed from one engine per type (core/mixed.py).
-Not carried over (out of scope): rendering/cameras, custom Python controllers,
-partial arming, drone-drone contact.
+Custom controllers (register_controller) run batch-wide on device tensors.
+Not carried over (out of scope): rendering/cameras, partial arming, drone-drone contact.
 """
 from __future__ import annotations
 
@@ -36,6 +36,26 @@ from ..params import build_params, quat_from_euler
 
 class AviaryInitException(Exception):
     """Mirrors core/aviary.py:21-44."""
+
+
+class _DroneProxy:
+    def __init__(self, aviary, index):
+        self._aviary, self.index = aviary, index
+
+    def register_controller(self, controller_id: int, controller_constructor, base_mode: int) -> None:
+        self._aviary.register_controller(controller_id=controller_id, controller_constructor=controller_constructor, base_mode=base_mode)
+
+    @property
+    def state(self):
+        return self._aviary.state(self.index)
+
+    @property
+    def aux_state(self):
+        return self._aviary.aux_state(self.index)
+
+    @property
+    def setpoint(self):
+        return self._aviary.setpoints[self.index]
 
 
 class Aviary:
@@ -69,6 +89,8 @@ class Aviary:
                 raise AssertionError(f"Unknown wind field model {wind_type}.")
             raise LookupError("Invalid setting for wind field.")
         self.wind_type, self.wind_options = wind_type, dict(wind_options or {})
+        self._registered_controllers: dict[int, Any] = {}
+        self._registered_base_modes: dict[int, int] = {}
         self.wind_field = None
         self.num_drones = start_pos.shape[0]
         self.drone_type = drone_type
@@ -136,6 +158,8 @@ class Aviary:
         self._set_sp_dim(7 if self.drone_type == "rocket" else 4)
         self.setpoints.zero_()
         self._contact_acc = None
+        self._controller = None
+        self._base_sp_dim = self._sp_dim
         # wind field given to the constructor (core/aviary.py:266-285): built per reset with the
         # Aviary's generator and options, and sampled by the reset's update_state at time 0
         self.wind_field = None
@@ -174,17 +198,43 @@ class Aviary:
             self._sp_dim = d
             self.setpoints = torch.zeros(self.num_drones, d, dtype=torch.float32, device=self.device)
 
+    # ------------------------------------------------------------------ quadx.py:375-399, base_drone.py:261-283
+    def register_controller(self, controller_id: int, controller_constructor, base_mode: int) -> None:
+        """Custom controllers (tests/test_core.py:141-192): `controller_constructor()` must give an object
+        with `reset()` and `step(state, setpoint)`, here called ONCE PER CONTROL STEP FOR THE WHOLE BATCH with
+        device tensors -- state [N, 4, 3] (ang_vel, ang_pos, lin_vel, lin_pos rows), setpoint [N, k] -- and
+        returning the [N, k_base] setpoints of `base_mode`, which the kernels then run."""
+        lo, hi = {"quadx": (-1, 7), "fixedwing": (-1, 0), "rocket": (0, 0)}[self.drone_type]
+        assert controller_id < lo or controller_id > hi, f"`controller_id` must not be a default flight mode ({lo}..{hi}), got {controller_id}."
+        assert lo <= base_mode <= hi, f"`base_mode` must be a default flight mode ({lo}..{hi}), got {base_mode}."
+        if self.engine.ctrl_ratio is not None:
+            raise NotImplementedError("custom controllers with per-drone control rates")
+        self._registered_controllers[int(controller_id)] = controller_constructor
+        self._registered_base_modes[int(controller_id)] = int(base_mode)
+
+    @property
+    def drones(self):
+        """`env.drones[i].register_controller(...)` as in the reference: the registration is batch-wide."""
+        return [_DroneProxy(self, i) for i in range(self.num_drones)]
+
     # ------------------------------------------------------------------ :440-478
     def set_mode(self, flight_modes: int) -> None:
+        if isinstance(flight_modes, (list, tuple, np.ndarray)) and len(set(int(m) for m in flight_modes)) == 1:
+            flight_modes = int(flight_modes[0])
         if not isinstance(flight_modes, (int, np.integer)):
             raise NotImplementedError("per-drone flight modes are not supported: the mode is uniform over the batch")
         mode = int(flight_modes)
+        self._controller = None
+        if mode in self._registered_controllers:  # quadx.py:266-269: instantiate, then behave as the base mode
+            self._controller = self._registered_controllers[mode]()
+            mode = self._registered_base_modes[mode]
         lo, hi = {"quadx": (-1, 7), "fixedwing": (-1, 0), "rocket": (0, 0)}[self.drone_type]
         if mode < lo or mode > hi:
             raise ValueError(f"`mode` must be between {lo} and {hi}, got {mode}.")  # quadx.py:260-263
         self._set_sp_dim(7 if self.drone_type == "rocket" else (6 if (self.drone_type == "fixedwing" and mode == -1) else 4))
         self.engine.aviary_set_mode(mode, self.setpoints)
         self.mode = mode
+        self._base_sp_dim = self._sp_dim
 
     def set_setpoint(self, index: int, setpoint) -> None:
         self.setpoints[index] = torch.as_tensor(np.asarray(setpoint), dtype=torch.float32, device=self.device)
@@ -203,6 +253,16 @@ class Aviary:
         if self.wind_field is not None:
             return self._step_with_wind(n_steps)
         self._contact_acc = None
+        if self._controller is not None:  # quadx.py:417-429: the custom controller runs first, on the last update_state's state
+            for _ in range(n_steps):
+                sp = self._controller.step(self.all_states, self.setpoints)
+                sp = sp.to(device=self.device, dtype=torch.float32).reshape(self.num_drones, -1).contiguous()
+                assert sp.shape[1] == self._base_sp_dim, f"custom controller outputting wrong shape, expected (N, {self._base_sp_dim}) but got {tuple(sp.shape)}."
+                self.engine.aviary_step(sp, n_steps=1)
+            self.physics_steps += n_steps * self.updates_per_step
+            self.aviary_steps += n_steps
+            self.elapsed_time = self.physics_steps / self.physics_hz
+            return
         self.engine.aviary_step(self.setpoints, n_steps=n_steps)
         self.physics_steps += n_steps * self.updates_per_step
         self.aviary_steps += n_steps

@@ -460,3 +460,57 @@ def test_mixed_drones():
     env.disconnect()
     for a in alone:
         a.disconnect()
+
+
+def test_custom_controller():
+    """Mirror of the reference's tests/test_core.py:141-192 (`test_custom_controller`): controller id 8 on top
+    of base mode 6, steering to (1, 1, 1) with a constant yaw rate -- here batched over device tensors, and
+    checked against the oracle running mode 6 with the same law evaluated in numpy."""
+    from pyflyt_amd.core import Aviary
+
+    class CustomController:
+        def __init__(self):
+            self.calls = 0
+
+        def reset(self):
+            pass
+
+        def step(self, state, setpoint):  # state [N, 4, 3], setpoint [N, 4]
+            self.calls += 1
+            target_velocity = torch.tensor([1.0, 1.0, 1.0], device=state.device) - state[:, 3]
+            yaw_rate = torch.full_like(target_velocity[:, :1], 0.5)
+            return torch.cat([target_velocity[:, :2], yaw_rate, target_velocity[:, 2:]], dim=1)
+
+    n = 32
+    rng = np.random.default_rng(4)
+    start_pos = np.concatenate([rng.uniform(-0.5, 0.5, size=(n, 2)), rng.uniform(0.8, 1.2, size=(n, 1))], axis=1).astype(np.float32)
+    env = Aviary(start_pos, np.zeros((n, 3)), drone_type="quadx", seed=9, motor_noise=False)
+    env.drones[0].register_controller(controller_constructor=CustomController, controller_id=8, base_mode=6)
+    env.set_mode(8)
+    lib = O.lib()
+    Ps, Ls = [], []
+    for i in range(n):
+        P = O.make_params("quadx", noise_mode=O.NOISE_OFF, start_pos=start_pos[i].astype(np.float64))
+        L = O.Lane()
+        lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
+        lib.orc_set_mode(C.byref(P), C.byref(L), 6)
+        Ps.append(P); Ls.append(L)
+    worst = 0.0
+    for k in range(600):
+        env.step()
+        for P, L in zip(Ps, Ls):
+            tv = np.array([1.0, 1.0, 1.0]) - np.array(list(L.p))
+            for j, x in enumerate([tv[0], tv[1], 0.5, tv[2]]):
+                L.setpoint[j] = float(np.float32(x))
+            lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+        if k < 12:  # mode 6 is one of the fp32-sensitive cascades: point-wise parity over its strict window only
+            st = np.array([list(L.w_b) + list(L.rpy) + list(L.v_b) + list(L.p) for L in Ls]).reshape(n, 4, 3)
+            worst = max(worst, float(np.abs(env.all_states.cpu().numpy() - st).max()))
+    assert worst < 1e-3, worst
+    pos = env.all_states[:, 3].cpu().numpy()
+    assert np.abs(pos - 1.0).max() < 0.2, pos  # arriving at (1, 1, 1), as the oracle does:
+    assert np.abs(np.array([list(L.p) for L in Ls]) - 1.0).max() < 0.2
+    assert env._controller.calls == 600
+    with pytest.raises(AssertionError):
+        env.register_controller(controller_id=3, controller_constructor=CustomController, base_mode=6)  # a default mode id
+    env.disconnect()

@@ -124,13 +124,27 @@ def test_partial_reset_mask():
     env.close()
 
 
-def test_flatten_waypoints():
-    from pyflyt_amd.gym_envs import QuadXWaypointsVecEnv
+@pytest.mark.parametrize("env_id,att", [("PyFlyt/QuadX-Waypoints-v4", 21), ("PyFlyt/Fixedwing-Waypoints-v4", 23)])
+@pytest.mark.parametrize("context_length", [2, 8])
+def test_flatten_waypoints(env_id, att, context_length):
+    """tests/test_gym_envs.py:115-130 (FlattenWaypointEnv with context lengths 2 and 8): fixed width
+    attitude + 3 * context_length, the first min(ctx, remaining) target deltas, zero padding after."""
+    from pyflyt_amd.gym_envs import make_vec
 
-    env = QuadXWaypointsVecEnv(64, flatten=True, context_length=2, seed=1)
+    env = make_vec(env_id, 64, flatten=True, context_length=context_length, seed=1)
+    dict_env = make_vec(env_id, 64, flatten=False, seed=1)
     obs, _ = env.reset(seed=1)
-    assert obs.shape == (64, 21 + 6) == env.observation_space.shape
-    env.close()
+    dobs, _ = dict_env.reset(seed=1)
+    assert obs.shape == (64, att + 3 * context_length) == env.observation_space.shape
+    for k in range(5):
+        a = env.sample_actions(k)
+        obs = env.step(a)[0]
+        dobs = dict_env.step(a)[0]
+    have = min(context_length, 4)
+    assert torch.equal(obs[:, :att], dobs["attitude"])
+    assert torch.equal(obs[:, att:att + 3 * have], dobs["target_deltas"][:, :have].reshape(64, -1))
+    assert (obs[:, att + 3 * have:] == 0).all()
+    env.close(); dict_env.close()
 
 
 def test_shard_invariance():

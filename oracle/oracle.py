@@ -172,7 +172,7 @@ def lib():
         L.orc_env_reset_batch.argtypes = [PP, LP, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_step_batch.argtypes = [PP, LP, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        for f in ("orc_params_quadx", "orc_params_fixedwing", "orc_params_primitive_drone", "orc_params_rocket", "orc_task_hover", "orc_task_quadx_waypoints",
+        for f in ("orc_params_quadx", "orc_params_fixedwing", "orc_params_primitive_drone", "orc_params_rocket", "orc_params_acrowing", "orc_task_hover", "orc_task_quadx_waypoints",
                   "orc_task_fixedwing_waypoints", "orc_task_ma_hover", "orc_finalize"):
             getattr(L, f).argtypes = [PP]
         _lib = L
@@ -195,6 +195,8 @@ def make_params(env: str, noise_mode: int = NOISE_OFF, seed: int = 0, **override
         L.orc_params_primitive_drone(C.byref(P))
     elif env == "rocket":
         L.orc_params_rocket(C.byref(P))
+    elif env == "acrowing":
+        L.orc_params_acrowing(C.byref(P))
     elif env in ("quadx", "hover", "quadx_waypoints", "ma_hover"):
         L.orc_params_quadx(C.byref(P))
     else:

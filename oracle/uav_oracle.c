@@ -701,6 +701,45 @@ void orc_params_fixedwing(orc_params* P) {
   P->angle_repr = 1;
   orc_finalize(P);
 }
+/* Fixedwing with drone_model="acrowing" (ma_fixedwing_base_env.py:193-195): models/vehicles/acrowing/acrowing.{urdf,yaml} */
+void orc_params_acrowing(orc_params* P) {
+  orc_params_fixedwing(P);
+  /* acrowing.urdf: base :21, h-tail :44,61, v-tail :70,87, ailerons :96,113 :122,139, main wing :148,165, fuselage :174,191 */
+  const double m[7] = {0.3, 0.1, 0.05, 0.2, 0.2, 0.5, 1.0};
+  const double r[7][3] = {{0, 0, 0}, {-1.1, 0, 0}, {-1.1, 0, 0.25}, {-0.35, 0.95, 0}, {-0.35, -0.95, 0}, {-0.35, 0, 0}, {-0.45, 0, 0}};
+  double M = 0, c[3] = {0, 0, 0};
+  for (int i = 0; i < 7; ++i) { M += m[i]; for (int k = 0; k < 3; ++k) c[k] += m[i] * r[i][k]; }
+  for (int k = 0; k < 3; ++k) c[k] /= M;
+  P->mass = M;
+  memcpy(P->com, c, sizeof(c));
+  memset(P->I_pa, 0, sizeof(P->I_pa));
+  for (int i = 0; i < 7; ++i) {
+    double d[3] = {r[i][0] - c[0], r[i][1] - c[1], r[i][2] - c[2]};
+    double d2 = dot3(d, d);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) P->I_pa[a][b] += m[i] * ((a == b ? d2 : 0.0) - d[a] * d[b]);
+  }
+  /* collision boxes :50,76,102,128,154,180 */
+  const double bs[6][3] = {{0.3, 0.8, 0.05}, {0.4, 0.05, 0.5}, {0.31, 0.3, 0.06}, {0.31, 0.3, 0.06}, {0.3, 1.8, 0.05}, {1.4, 0.2, 0.2}};
+  for (int i = 0; i < 6; ++i)
+    for (int k = 0; k < 3; ++k) { P->boxes[i].c[k] = r[1 + i][k]; P->boxes[i].h[k] = 0.5 * bs[i][k]; }
+  P->max_rpm[0] = sqrt(30.0 / 3.16e-10); /* acrowing.yaml:2 */
+  /* acrowing.yaml:8-71, surface order of fixedwing.py:80-138 */
+  const int link_of[5] = {3, 4, 1, 2, 5};
+  const double chord[5] = {0.3, 0.3, 0.3, 0.4, 0.3}, span[5] = {0.3, 0.3, 0.8, 0.4, 1.6}, f2c[5] = {0.3, 0.3, 0.5, 0.4, 0.1};
+  const double a0[5] = {0, 0, 0, 0, -2}, asp[5] = {16, 16, 11, 11, 16}, asn[5] = {-12, -12, -11, -11, -10};
+  const double lim[5] = {30, 30, 20, 35, 15};
+  for (int i = 0; i < 5; ++i) {
+    orc_surface* S = &P->surf[i];
+    memcpy(S->r, r[link_of[i]], sizeof(S->r));
+    S->chord = chord[i]; S->span = span[i]; S->flap_to_chord = f2c[i];
+    S->alpha_0_base = a0[i] * (PI / 180.0);
+    S->alpha_stall_P_base = asp[i] * (PI / 180.0);
+    S->alpha_stall_N_base = asn[i] * (PI / 180.0);
+    S->deflection_limit = lim[i];
+  }
+  orc_finalize(P);
+}
 void orc_task_hover(orc_params* P) { /* quadx_hover_env.py:32-37 */
   P->task = ORC_TASK_HOVER;
   P->flight_mode = 0; P->dome = 3.0; P->max_steps = 400; P->env_step_ratio = 3;

@@ -189,6 +189,7 @@ void orc_params_quadx(orc_params* P);
 void orc_params_fixedwing(orc_params* P);
 void orc_params_primitive_drone(orc_params* P);
 void orc_params_rocket(orc_params* P);
+void orc_params_acrowing(orc_params* P);
 void orc_task_hover(orc_params* P);
 void orc_task_quadx_waypoints(orc_params* P);
 void orc_task_fixedwing_waypoints(orc_params* P);

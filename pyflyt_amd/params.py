@@ -149,6 +149,39 @@ ROCKET: dict[str, Any] = {
     "control_hz": 120,                              # rocket.py:36
 }
 
+# Fixedwing(drone_model="acrowing") (pz_envs/fixedwing_envs/ma_fixedwing_base_env.py:193-195): the aerobatic
+# airframe; same class, another model folder.
+ACROWING: dict[str, Any] = copy.deepcopy(FIXEDWING)
+ACROWING.update({
+    # models/vehicles/acrowing/acrowing.urdf: base :21, h-tail :44,61, v-tail :70,87, ailerons :96,113 :122,139,
+    # main wing :148,165, fuselage :174,191 (motor and gunsight links are massless)
+    "links": [
+        (0.3, (0.0, 0.0, 0.0)), (0.1, (-1.1, 0.0, 0.0)), (0.05, (-1.1, 0.0, 0.25)), (0.2, (-0.35, 0.95, 0.0)),
+        (0.2, (-0.35, -0.95, 0.0)), (0.5, (-0.35, 0.0, 0.0)), (1.0, (-0.45, 0.0, 0.0)),
+    ],
+    # collision boxes :50,76,102,128,154,180
+    "collision_boxes": [
+        ((-1.1, 0.0, 0.0), (0.3, 0.8, 0.05)), ((-1.1, 0.0, 0.25), (0.4, 0.05, 0.5)),
+        ((-0.35, 0.95, 0.0), (0.31, 0.3, 0.06)), ((-0.35, -0.95, 0.0), (0.31, 0.3, 0.06)),
+        ((-0.35, 0.0, 0.0), (0.3, 1.8, 0.05)), ((-0.45, 0.0, 0.0), (1.4, 0.2, 0.2)),
+    ],
+    "total_thrust": 30.0,  # acrowing.yaml:2
+    # acrowing.yaml:8-71 in the surface order of drones/fixedwing.py:80-138
+    "surfaces": [
+        dict(_SURF_COMMON, name="left_aileron", r=(-0.35, 0.95, 0.0), lift=(0, 0, 1), chord=0.3, span=0.3, flap_to_chord=0.3,
+             alpha_0_base=0.0, alpha_stall_P_base=16.0, alpha_stall_N_base=-12.0, deflection_limit=30.0),
+        dict(_SURF_COMMON, name="right_aileron", r=(-0.35, -0.95, 0.0), lift=(0, 0, 1), chord=0.3, span=0.3, flap_to_chord=0.3,
+             alpha_0_base=0.0, alpha_stall_P_base=16.0, alpha_stall_N_base=-12.0, deflection_limit=30.0),
+        dict(_SURF_COMMON, name="horizontal_tail", r=(-1.1, 0.0, 0.0), lift=(0, 0, 1), chord=0.3, span=0.8, flap_to_chord=0.5,
+             alpha_0_base=0.0, alpha_stall_P_base=11.0, alpha_stall_N_base=-11.0, deflection_limit=20.0),
+        dict(_SURF_COMMON, name="vertical_tail", r=(-1.1, 0.0, 0.25), lift=(0, 1, 0), chord=0.4, span=0.4, flap_to_chord=0.4,
+             alpha_0_base=0.0, alpha_stall_P_base=11.0, alpha_stall_N_base=-11.0, deflection_limit=35.0),
+        dict(_SURF_COMMON, name="main_wing", r=(-0.35, 0.0, 0.0), lift=(0, 0, 1), chord=0.3, span=1.6, flap_to_chord=0.1,
+             alpha_0_base=-2.0, alpha_stall_P_base=16.0, alpha_stall_N_base=-10.0, deflection_limit=15.0),
+    ],
+})
+FIXEDWING_MODELS = {"fixedwing": FIXEDWING, "acrowing": ACROWING}
+
 WORLD: dict[str, Any] = {
     "physics_hz": 240,         # core/aviary.py:79
     "gravity_z": -9.81,        # core/aviary.py:226
@@ -296,8 +329,12 @@ def build_params(
         else:
             low, high = (-xyz, -xyz, -xyz, 0.0), (xyz, xyz, xyz, thr)
     elif vehicle == "fixedwing":
-        V = copy.deepcopy(FIXEDWING)
-        V.update(vehicle_options or {})
+        vo = dict(vehicle_options or {})
+        model = vo.pop("drone_model", "fixedwing")  # drones/fixedwing.py:25
+        if model not in FIXEDWING_MODELS:
+            raise ValueError(f"unknown Fixedwing drone_model {model!r}; available: {sorted(FIXEDWING_MODELS)}")
+        V = copy.deepcopy(FIXEDWING_MODELS[model])
+        V.update(vo)
         P.vehicle = L.FIXEDWING
         _set_body(P, V["links"], np.zeros((3, 3)), V["collision_boxes"])
         P.n_motors = 1

@@ -235,6 +235,14 @@ def gen_primitive():
     save("aviary_primitive_drop", **d)
 
 
+def gen_acrowing():
+    # Fixedwing(drone_model="acrowing"): the aerobatic airframe of the dogfight env (ma_fixedwing_base_env.py:193-195)
+    for mode in (0, -1):
+        d = run_aviary("fixedwing", mode, 200, seed=600 + mode, start_pos=[0.0, 0.0, 30.0], start_orn=[0.02, 0.05, -0.3],
+                       noise=True, drone_options=dict(drone_model="acrowing"))
+        save(f"aviary_acrowing_mode{mode}".replace("-1", "m1"), **d)
+
+
 def gen_rocket():
     # Rocket (drones/rocket.py, abstractions/boosters.py, gimbals.py): booster with fuel burn (variable mass
     # and inertia through changeDynamics), 2-axis thrust gimbal, four grid fins, per-axis body drag
@@ -418,3 +426,4 @@ if __name__ == "__main__":
     gen_wind()
     gen_primitive()
     gen_rocket()
+    gen_acrowing()

@@ -44,7 +44,8 @@ def sample_setpoint(rng, n, drone, mode):
 
 
 CASES = [("quadx", m, "cf2x") for m in range(-1, 8)] + [("fixedwing", 0, None), ("fixedwing", -1, None)] + \
-        [("quadx", m, "primitive_drone") for m in (0, 6, 7)]  # QuadX(drone_model="primitive_drone"), quadx.py:29
+        [("quadx", m, "primitive_drone") for m in (0, 6, 7)] + \
+        [("fixedwing", 0, "acrowing"), ("fixedwing", -1, "acrowing")]  # drone_model=: quadx.py:29, ma_fixedwing_base_env.py:193-195
 
 
 @pytest.mark.parametrize("drone,mode,model", CASES)
@@ -57,7 +58,8 @@ def test_aviary_parity(drone, mode, model):
     start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(z0, z0 + 1.0, size=(n, 1))], axis=1)
     start_orn = rng.uniform(-0.15, 0.15, size=(n, 3)) * np.array([1, 1, 5.0])
     primitive = model == "primitive_drone"
-    env = Aviary(start_pos, start_orn, drone_type=drone, seed=seed, drone_options=dict(drone_model=model) if primitive else None)
+    env = Aviary(start_pos, start_orn, drone_type=drone, seed=seed,
+                 drone_options=dict(drone_model=model) if model in ("primitive_drone", "acrowing") else None)
     env.set_mode(mode)
 
     lib = O.lib()
@@ -65,7 +67,8 @@ def test_aviary_parity(drone, mode, model):
     # the oracle sees the fp32-rounded spawn the device was given
     sp32 = start_pos.astype(np.float32).astype(np.float64)
     for i in range(n):
-        P = O.make_params("primitive_drone" if primitive else drone, noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=sp32[i], start_rpy=start_orn[i])
+        P = O.make_params(model if model in ("primitive_drone", "acrowing") else drone, noise_mode=O.NOISE_PHILOX, seed=seed,
+                          start_pos=sp32[i], start_rpy=start_orn[i])
         L = O.Lane()
         lib.orc_aviary_reset(C.byref(P), C.byref(L), i)
         lib.orc_set_mode(C.byref(P), C.byref(L), mode)

@@ -89,17 +89,20 @@ def lane_state(L, fixedwing):
 
 AVIARY = [f"aviary_quadx_mode{m}" for m in ["m1", 0, 1, 2, 3, 4, 5, 6, 7, "7_nonoise"]] + \
          ["aviary_fixedwing_mode0", "aviary_fixedwing_modem1"] + \
-         [f"aviary_primitive_mode{m}" for m in (0, 6, 7)]  # QuadX(drone_model="primitive_drone")
+         [f"aviary_primitive_mode{m}" for m in (0, 6, 7)] + \
+         ["aviary_acrowing_mode0", "aviary_acrowing_modem1"]  # QuadX(drone_model="primitive_drone"), Fixedwing(drone_model="acrowing")
 
 
 def model_of(name):
+    if "acrowing" in name:
+        return "acrowing"
     return "fixedwing" if "fixedwing" in name else ("primitive_drone" if "primitive" in name else "quadx")
 
 
 @pytest.mark.parametrize("name", AVIARY)
 def test_aviary_trajectory(golden_dir, name):
     g = load(golden_dir, name)
-    fw = "fixedwing" in name
+    fw = "fixedwing" in name or "acrowing" in name
     noise = bool(g["noise"])
     P = O.make_params(model_of(name), noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF,
                       start_pos=g["start_pos"], start_rpy=g["start_orn"])

@@ -226,3 +226,48 @@ def test_large_batch_runs():
     assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
     assert int(env.engine.ints()[:, 2].min()) == 4  # 1 reset event + 3 step events on every lane
     env.close()
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary without Python on the calling side: tests/c_abi/abi_smoke.c (plain C + the HIP runtime
+    for device buffers) is compiled against include/pyflyt_amd.h, linked to libpyflyt_amd.so, and must
+    reproduce the Python path bit for bit from the same parameter block and seed."""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+
+    from pyflyt_amd import _lib, build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    gcc = shutil.which("gcc")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if gcc is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("gcc / ROCm headers not available on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    # a C compiler, the HIP runtime API for the device buffers, and the library: nothing else
+    subprocess.check_call([gcc, "-std=c11", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"),
+                           os.path.join(root, "tests", "c_abi", "abi_smoke.c"), "-o", str(exe),
+                           "-L" + libdir, "-lpyflyt_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(rocm, "lib")])
+    n, steps = 1000, 25
+    P = build_params("quadx", "waypoints", noise="philox", autoreset="next_step", seed=5)
+    (tmp_path / "params.bin").write_bytes(bytes(P))
+    subprocess.check_call([str(exe), str(tmp_path / "params.bin"), str(n), str(steps), str(tmp_path / "out.bin")])
+    eng = BatchEngine(P, n)
+    a = torch.empty(n, 4, device="cuda:0")
+    eng.env_reset()
+    for k in range(steps):
+        eng.sample_actions(a, k)
+        eng.env_step(a)
+    raw = np.frombuffer((tmp_path / "out.bin").read_bytes(), dtype=np.uint8)
+    D = eng.obs_dim
+    obs = raw[: 4 * D * n].view(np.float32).reshape(n, D)
+    rew = raw[4 * D * n: 4 * D * n + 4 * n].view(np.float32)
+    term = raw[4 * D * n + 4 * n: 4 * D * n + 5 * n].astype(bool)
+    trunc = raw[4 * D * n + 5 * n:].astype(bool)
+    assert np.array_equal(obs, eng.obs.cpu().numpy()) and np.array_equal(rew, eng.reward.cpu().numpy())
+    assert np.array_equal(term, eng.terminated.cpu().numpy()) and np.array_equal(trunc, eng.truncated.cpu().numpy())
+    eng.close()

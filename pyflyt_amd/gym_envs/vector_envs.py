@@ -215,3 +215,45 @@ def make_vec(env_id: str, num_envs: int, **kwargs):
     if env_id not in _REGISTRY:
         raise KeyError(f"{env_id!r} is not on the batched hot path; available: {sorted(_REGISTRY)}")
     return _REGISTRY[env_id](num_envs, **kwargs)
+
+
+class SingleEnv:
+    """One environment with the reference's single-env calling convention -- what
+    `gymnasium.make("PyFlyt/QuadX-Hover-v4")` hands back (numpy observations, Python scalars, no
+    auto-reset; quadx_base_env.py:128-301) -- on top of a 1-lane batch. For existing scripts and tests;
+    throughput comes from `make_vec`."""
+
+    def __init__(self, env_id: str, **kwargs):
+        kwargs.pop("autoreset_mode", None)
+        self.vec = make_vec(env_id, 1, autoreset_mode="disabled", **kwargs)
+        self.observation_space = self.vec.single_observation_space
+        self.action_space = self.vec.single_action_space
+        self.metadata = dict(self.vec.metadata)
+        self.unwrapped = self
+
+    @staticmethod
+    def _np(x):
+        if isinstance(x, dict):
+            return {k: SingleEnv._np(v) for k, v in x.items()}
+        return x[0].detach().cpu().numpy()
+
+    def _info(self, infos):
+        return {k: (SingleEnv._np(v) if torch.is_tensor(v) or isinstance(v, dict) else v) for k, v in infos.items()}
+
+    def reset(self, *, seed: int | None = None, options: dict | None = None):
+        obs, infos = self.vec.reset(seed=seed)
+        return self._np(obs), {k: (bool(v) if getattr(v, "dtype", None) == np.bool_ else v) for k, v in self._info(infos).items()}
+
+    def step(self, action):
+        a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(1, 4), device=self.vec.device)
+        obs, rew, term, trunc, infos = self.vec.step(a)
+        info = {k: (bool(v) if getattr(v, "dtype", None) == np.bool_ else v) for k, v in self._info(infos).items()}
+        return self._np(obs), float(rew[0]), bool(term[0]), bool(trunc[0]), info
+
+    def close(self):
+        self.vec.close()
+
+
+def make(env_id: str, **kwargs) -> SingleEnv:
+    """The counterpart of `gymnasium.make(id, **kwargs)` for the supported ids."""
+    return SingleEnv(env_id, **kwargs)

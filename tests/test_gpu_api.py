@@ -271,3 +271,33 @@ def test_c_abi_from_plain_c(tmp_path):
     assert np.array_equal(obs, eng.obs.cpu().numpy()) and np.array_equal(rew, eng.reward.cpu().numpy())
     assert np.array_equal(term, eng.terminated.cpu().numpy()) and np.array_equal(trunc, eng.truncated.cpu().numpy())
     eng.close()
+
+
+@pytest.mark.parametrize("env_id", IDS)
+def test_single_env_seeding_and_spaces(env_id):
+    """The reference's tests/test_gym_envs.py:92-112 (`test_seeding`) on the single-env adapter: two envs
+    with the same seed, 100 sampled actions, reset on termination/truncation -- identical observations,
+    rewards and flags; observations inside the observation space (what check_env verifies, :76-89)."""
+    from pyflyt_amd.gym_envs import make
+
+    kw = dict(flatten=True, context_length=2) if "Waypoints" in env_id else {}
+    env1, env2 = make(env_id, seed=42, **kw), make(env_id, seed=42, **kw)
+    rng = np.random.default_rng(0)
+    obs1, _ = env1.reset(seed=42)
+    obs2, _ = env2.reset(seed=42)
+    assert isinstance(obs1, np.ndarray) and obs1.shape == env1.observation_space.shape
+    assert np.array_equal(obs1, obs2)
+    n_eps = 0
+    for _ in range(100):
+        action = rng.uniform(env1.action_space.low, env1.action_space.high).astype(np.float32)
+        o1, r1, t1, u1, i1 = env1.step(action)
+        o2, r2, t2, u2, i2 = env2.step(action)
+        assert np.array_equal(o1, o2) and r1 == r2 and t1 == t2 and u1 == u2
+        assert isinstance(r1, float) and isinstance(t1, bool) and isinstance(u1, bool)
+        assert env1.observation_space.contains(o1.astype(np.float32))
+        if t1 or u1:
+            n_eps += 1
+            o1, _ = env1.reset(seed=42 + n_eps)
+            o2, _ = env2.reset(seed=42 + n_eps)
+            assert np.array_equal(o1, o2)
+    env1.close(); env2.close()

@@ -413,18 +413,17 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
   // observation row (fixedwing_base_env.py:75-92,213-224; fixedwing_waypoints_env.py:116-167)
   auto write_obs_row = [&]() {
     float* row = tile + tid * D;
-    quat q = V.q;
-    float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
-    float id = frcp(sqx + sqy + sqz + squ);
-    float sarg = -2.0f * (q.x * q.z - q.w * q.y) * id;
+    // (the Euler-angle arguments are entries of the rotation matrix derive() holds for the unit q:
+    //  -2(xz - wy) = -R20, 2(yz + wx) = R21, w2-x2-y2+z2 = R22, 2(xy + wz) = R10, w2+x2-y2-z2 = R00)
+    float sarg = -V.R.m20;
     quat qe;
     v3 rpy;
     if (__builtin_fabsf(sarg) >= 0.99999f) {  // gimbal-lock branch of pybullet, rare: library trig
-      rpy = euler_from_quat(q);
+      rpy = euler_from_quat(V.q);
       qe = quat_from_euler(rpy);
     } else {
-      float ar = 2.0f * (q.y * q.z + q.w * q.x), br = squ - sqx - sqy + sqz;
-      float ay = 2.0f * (q.x * q.y + q.w * q.z), by = squ + sqx - sqy - sqz;
+      float ar = V.R.m21, br = V.R.m22;
+      float ay = V.R.m10, by = V.R.m00;
       float hr = frsq(fmaf(ar, ar, br * br)), hy = frsq(fmaf(ay, ay, by * by));
       float cr, sr, cp, sp, cy, sy;
       half_angle(br * hr, ar * hr, cr, sr);

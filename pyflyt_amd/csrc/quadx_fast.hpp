@@ -408,18 +408,17 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   // getQuaternionFromEuler(getEulerFromQuaternion(q)) (quadx_base_env.py:243), computed without trig.
   auto write_obs_row = [&]() {
     float* row = tile + tid * D;
-    quat q = V.q;
-    float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
-    float id = frcp(sqx + sqy + sqz + squ);
-    float sarg = -2.0f * (q.x * q.z - q.w * q.y) * id;
+    // (the Euler-angle arguments are entries of the rotation matrix derive() holds for the unit q:
+    //  -2(xz - wy) = -R20, 2(yz + wx) = R21, w2-x2-y2+z2 = R22, 2(xy + wz) = R10, w2+x2-y2-z2 = R00)
+    float sarg = -V.R.m20;
     quat qe;
     v3 rpy;
     if (__builtin_fabsf(sarg) >= 0.99999f) {  // gimbal-lock branch of pybullet, rare: library trig
-      rpy = euler_from_quat(q);
+      rpy = euler_from_quat(V.q);
       qe = quat_from_euler(rpy);
     } else {
-      float ar = 2.0f * (q.y * q.z + q.w * q.x), br = squ - sqx - sqy + sqz;
-      float ay = 2.0f * (q.x * q.y + q.w * q.z), by = squ + sqx - sqy - sqz;
+      float ar = V.R.m21, br = V.R.m22;
+      float ay = V.R.m10, by = V.R.m00;
       float hr = frsq(fmaf(ar, ar, br * br)), hy = frsq(fmaf(ay, ay, by * by));
       float cr, sr, cp, sp, cy, sy;
       half_angle(br * hr, ar * hr, cr, sr);
@@ -529,11 +528,11 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
         if (!K.task_sparse) {
           float dx = V.p.x - tgt[0][0], dy = V.p.y - tgt[0][1], dz = V.p.z - tgt[0][2];
           float lin = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-          quat q = V.q;
-          float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
-          float sarg = -2.0f * (q.x * q.z - q.w * q.y) * frcp(sqx + sqy + sqz + squ);
+          // roll, pitch of getEulerFromQuaternion from the rotation matrix derive() just built (unit q):
+          // -2(xz - wy) = -R20, 2(yz + wx) = R21, w^2 - x^2 - y^2 + z^2 = R22
+          float sarg = -V.R.m20;
           bool gim = __builtin_fabsf(sarg) >= 0.99999f;
-          float roll = gim ? 0.0f : fast_atan2(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+          float roll = gim ? 0.0f : fast_atan2(V.R.m21, V.R.m22);
           float pitch = gim ? __builtin_copysignf(0.5f * kPi, sarg) : fast_asin(sarg);
           float ang = fsqrt(fmaf(roll, roll, pitch * pitch));
           reward -= fmaf(ang, 0.1f, lin);
@@ -548,11 +547,11 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
           float dz = V.p.z - 1.0f;
           float lin = fsqrt(fmaf(V.p.x, V.p.x, fmaf(V.p.y, V.p.y, dz * dz)));
           // roll, pitch of getEulerFromQuaternion (gimbal branch: roll = 0, |pitch| = pi/2)
-          quat q = V.q;
-          float sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
-          float sarg = -2.0f * (q.x * q.z - q.w * q.y) * frcp(sqx + sqy + sqz + squ);
+          // (from the rotation matrix derive() just built, unit q: -2(xz - wy) = -R20, 2(yz + wx) = R21,
+          //  w^2 - x^2 - y^2 + z^2 = R22)
+          float sarg = -V.R.m20;
           bool gim = __builtin_fabsf(sarg) >= 0.99999f;
-          float roll = gim ? 0.0f : fast_atan2(2.0f * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+          float roll = gim ? 0.0f : fast_atan2(V.R.m21, V.R.m22);
           float pitch = gim ? __builtin_copysignf(0.5f * kPi, sarg) : fast_asin(sarg);
           float ang = fsqrt(fmaf(roll, roll, pitch * pitch));
           reward -= 0.01f * (V.wb.z * V.wb.z);

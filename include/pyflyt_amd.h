@@ -166,6 +166,12 @@ typedef struct pf_buffers {
    * each drone, a divisor of ticks_per_control (= physics_hz / the SLOWEST drone's control_hz,
    * aviary.py:288-289; drones given different `control_hz`, tests/test_core.py:34-62). NULL = uniform. */
   const int32_t* ctrl_ratio; /* [n] */
+  /* per-drone flight modes (QuadX; Aviary.set_mode with a list, core/aviary.py:440-458): read by
+   * pf_aviary_set_mode / _step / _tick instead of the context's mode. NULL = one mode for all. */
+  const int32_t* modes;      /* [n] */
+  /* per-drone spawn velocity for pf_aviary_reset (drone_options[i]["starting_velocity"], fixedwing.py:35,
+   * ma_fixedwing_dogfight_env.py:218-222): world-frame linear velocity [n][3], NULL = pf_params.start_vel */
+  const float* start_vel;
 } pf_buffers;
 
 typedef struct pf_ctx pf_ctx;

@@ -100,14 +100,18 @@ class Aviary:
         # dicts may differ in `control_hz` only (tests/test_core.py:34-62): the Aviary then steps at the
         # slowest controller's rate (aviary.py:288-289) and every drone's controller fires at its own.
         per_drone_hz = None
+        per_drone_vel = None
         if isinstance(drone_options, (list, tuple)):
             if len(drone_options) != self.num_drones:
                 raise AviaryInitException(f"drone_options must be a dict or a sequence of {self.num_drones} dicts")
             dicts = [dict(d or {}) for d in drone_options]
             if any("control_hz" in d for d in dicts):
                 per_drone_hz = [int(d.pop("control_hz", 120)) for d in dicts]
+            if any("starting_velocity" in d for d in dicts):  # fixedwing.py:35, ma_fixedwing_dogfight_env.py:218-222
+                default_v = (20.0, 0.0, 0.0) if drone_type == "fixedwing" else (0.0, 0.0, 0.0)
+                per_drone_vel = np.array([np.asarray(d.pop("starting_velocity", default_v), dtype=np.float64) for d in dicts])
             if any(d != dicts[0] for d in dicts):
-                raise AviaryInitException("per-drone drone_options may differ in `control_hz` only")
+                raise AviaryInitException("per-drone drone_options may differ in `control_hz` and `starting_velocity` only")
             opts = dicts[0]
             if per_drone_hz is not None and len(set(per_drone_hz)) > 1:
                 for hz in per_drone_hz:
@@ -138,6 +142,9 @@ class Aviary:
         self.engine = BatchEngine(P, self.num_drones, device=self.device, lane_offset=lane_offset)
         if per_drone_hz is not None:
             self.engine.ctrl_ratio = torch.tensor([self.physics_hz // hz for hz in per_drone_hz], dtype=torch.int32, device=self.device)
+        if per_drone_vel is not None:
+            # world-frame linear velocity handed to resetBaseVelocity as is (fixedwing.py:201)
+            self.engine.start_vel = torch.tensor(per_drone_vel, dtype=torch.float32, device=self.device).contiguous()
         pose = np.concatenate([start_pos, np.stack([quat_from_euler(o) for o in start_orn])], axis=1)
         self._start_pose = torch.tensor(pose, dtype=torch.float32, device=self.device).contiguous()
         self.start_pos, self.start_orn = start_pos, start_orn
@@ -219,10 +226,13 @@ class Aviary:
 
     # ------------------------------------------------------------------ :440-478
     def set_mode(self, flight_modes: int) -> None:
-        if isinstance(flight_modes, (list, tuple, np.ndarray)) and len(set(int(m) for m in flight_modes)) == 1:
-            flight_modes = int(flight_modes[0])
-        if not isinstance(flight_modes, (int, np.integer)):
-            raise NotImplementedError("per-drone flight modes are not supported: the mode is uniform over the batch")
+        if isinstance(flight_modes, (list, tuple, np.ndarray)):
+            assert len(flight_modes) == self.num_drones, f"Expected {self.num_drones} flight_modes, got {len(flight_modes)}."
+            if len(set(int(m) for m in flight_modes)) == 1:
+                flight_modes = int(flight_modes[0])
+            else:
+                return self._set_modes_per_drone([int(m) for m in flight_modes])
+        self.engine.modes = None
         mode = int(flight_modes)
         self._controller = None
         if mode in self._registered_controllers:  # quadx.py:266-269: instantiate, then behave as the base mode
@@ -235,6 +245,23 @@ class Aviary:
         self.engine.aviary_set_mode(mode, self.setpoints)
         self.mode = mode
         self._base_sp_dim = self._sp_dim
+
+    def _set_modes_per_drone(self, modes) -> None:
+        """A different flight mode per drone (core/aviary.py:449-455): QuadX only -- every QuadX mode takes four
+        setpoint values; the modes live in a per-lane buffer the Aviary-level kernels read."""
+        if self.drone_type != "quadx":
+            raise NotImplementedError("per-drone flight modes are supported for QuadX (Fixedwing modes differ in setpoint width)")
+        if any(m in self._registered_controllers for m in modes):
+            raise NotImplementedError("custom controllers with per-drone flight modes")
+        for m in modes:
+            if m < -1 or m > 7:
+                raise ValueError(f"`mode` must be between -1 and 7, got {m}.")
+        self._controller = None
+        self._set_sp_dim(4)
+        self.engine.modes = torch.tensor(modes, dtype=torch.int32, device=self.device)
+        self.engine.aviary_set_mode(0, self.setpoints)
+        self.mode = list(modes)
+        self._base_sp_dim = 4
 
     def set_setpoint(self, index: int, setpoint) -> None:
         self.setpoints[index] = torch.as_tensor(np.asarray(setpoint), dtype=torch.float32, device=self.device)

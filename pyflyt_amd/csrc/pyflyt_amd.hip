@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(kWave) aviary_reset_kernel(const pf_params P, 
   if (lane >= n) return;
   VEH V;
   float sp[8];
-  V.reset(P, pose ? pose + (size_t)lane * 7 : nullptr, sp);
+  V.reset(P, pose ? pose + (size_t)lane * 7 : nullptr, sp, B.start_vel ? B.start_vel + (size_t)lane * 3 : nullptr);
   float4* S = reinterpret_cast<float4*>(B.state);
   V.store(S, (size_t)n, (size_t)lane, /*mode=*/7, INFINITY, int4{0, 0, 0, 0});
   if (B.out_state) {
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params 
   if (sp_out)
     for (int k = 0; k < 8; ++k)
       if (k < sp_dim) sp[k] = sp_out[(size_t)lane * sp_dim + k];
-  V.set_mode(new_mode, sp);
+  V.set_mode(B.modes ? B.modes[lane] : new_mode, sp);
   V.store(reinterpret_cast<float4*>(B.state), (size_t)n, (size_t)lane, 7, nd, ints);
   if (sp_out)
     for (int k = 0; k < 8; ++k)
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   V.bind(ktab);
   float nd;
   int4 ints;
-  const int mode = P.flight_mode;
+  const int mode = B.modes ? B.modes[li] : P.flight_mode;
   V.load(reinterpret_cast<const float4*>(B.state), N, li, mode, nd, ints);
   V.b.rpy = euler_from_quat_fast(V.b.q);
   uint32_t rng_ctr = (uint32_t)ints.z;
@@ -487,12 +487,13 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   const int ratio = B.ctrl_ratio ? B.ctrl_ratio[li] : 0;
   for (int s = 0; s < n_steps; ++s) {
     nz.begin_event(rng_ctr, 0u, B.xi ? B.xi + (size_t)s * P.ticks_per_control * N : nullptr);
-    if (ratio > 0) {  // this drone's own control rate: controller every `ratio` ticks with period ratio * dt
+    if (ratio > 0 || B.modes) {  // this drone's own control rate (period ratio * dt) and / or flight mode
+      const int rr = ratio > 0 ? ratio : P.ticks_per_control;
       V.b.contact_step = false;
       for (int t = 0; t < P.ticks_per_control; ++t) {
-        if (t % ratio == 0) {
+        if (t % rr == 0) {
           if (t > 0) V.b.rpy = euler_from_quat_fast(V.b.q);
-          V.template control<kRuntimeMode>(P, sp, ratio * P.dt);
+          V.template control<kRuntimeMode>(P, sp, ratio > 0 ? ratio * P.dt : 0.0f, B.modes ? mode : kNoModeOverride);
         }
         V.tick(P, nz.get(t));
       }
@@ -537,7 +538,7 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   V.bind(ktab);
   float nd;
   int4 ints;
-  const int mode = P.flight_mode;
+  const int mode = B.modes ? B.modes[li] : P.flight_mode;
   float4* S = reinterpret_cast<float4*>(B.state);
   V.load(S, N, li, mode, nd, ints);
   V.b.rpy = euler_from_quat_fast(V.b.q);
@@ -554,7 +555,7 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
     if (k < spn) sp[k] = B.setpoints[li * spn + k];
   const int ratio = B.ctrl_ratio ? B.ctrl_ratio[li] : P.ticks_per_control;
   if (tick_index % ratio == 0 || !kQuad) {
-    V.template control<kRuntimeMode>(P, sp, B.ctrl_ratio ? ratio * P.dt : 0.0f);  // Fixedwing: stateless mixing, recomputed every tick
+    V.template control<kRuntimeMode>(P, sp, B.ctrl_ratio ? ratio * P.dt : 0.0f, B.modes ? mode : kNoModeOverride);  // Fixedwing: stateless mixing, recomputed every tick
   } else {
     const float4 c = S[(size_t)kCmdGroup * N + li];
     V.set_cmd(c);
@@ -811,6 +812,7 @@ int pf_aviary_set_mode(pf_ctx* ctx, const pf_buffers* b, int mode, float* setpoi
   if (ctx->P.vehicle == PF_QUADX && (mode < -1 || mode > 7)) return fail(ctx, PF_ERR_ARG, "`mode` must be between -1 and 7");
   if (ctx->P.vehicle == PF_FIXEDWING && (mode < -1 || mode > 0)) return fail(ctx, PF_ERR_ARG, "`mode` must be between -1 and 0");
   if (ctx->P.vehicle == PF_ROCKET && mode != 0) return fail(ctx, PF_ERR_ARG, "`mode` must be 0 (rocket.py:238-247)");
+  if (b->modes && ctx->P.vehicle != PF_QUADX) return fail(ctx, PF_ERR_UNSUPPORTED, "per-drone flight modes are supported for QuadX only (Fixedwing modes differ in setpoint width)");
   int rc = ensure_device(ctx);
   if (rc) return rc;
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;

@@ -54,8 +54,8 @@ struct Rocket {
     S[6 * n + i] = float4{__int_as_float(ints.x), __int_as_float(ints.y), __int_as_float(ints.z), __int_as_float(ints.w)};
   }
   PF_DEV void set_mode(int, float*) {}  // base_drone.py:243-259: records the mode, setpoint untouched
-  PF_DEV void reset(const pf_params& P, const float* pose, float sp[8]) {  // rocket.py:222-236
-    b.spawn(P, pose);
+  PF_DEV void reset(const pf_params& P, const float* pose, float sp[8], const float* vel = nullptr) {  // rocket.py:222-236
+    b.spawn(P, pose, vel);
 #pragma unroll
     for (int k = 0; k < 4; ++k) act[k] = 0.0f;
     thr = 0.0f; ign = 0.0f; gim[0] = gim[1] = 0.0f;
@@ -64,7 +64,7 @@ struct Rocket {
     for (int k = 0; k < 8; ++k) { sp[k] = 0.0f; cmd[k] = 0.0f; }
   }
   template <int MODE_T>
-  PF_DEV void control(const pf_params& P, const float sp[8], float = 0.0f) {  // rocket.py:249-257
+  PF_DEV void control(const pf_params& P, const float sp[8], float = 0.0f, int = 0) {  // rocket.py:249-257
     const pf_rocket& K = P.rocket;
 #pragma unroll
     for (int i = 0; i < 4; ++i)

@@ -131,7 +131,7 @@ struct Body {
     derive();
     contact_step |= contact_now;
   }
-  PF_DEV void spawn(const pf_params& P, const float* pose /* [7] or null */) {
+  PF_DEV void spawn(const pf_params& P, const float* pose /* [7] or null */, const float* vel = nullptr /* [3] or null */) {
     if (pose) {
       p = v3{pose[0], pose[1], pose[2]};
       q = quat{pose[3], pose[4], pose[5], pose[6]};
@@ -139,7 +139,7 @@ struct Body {
       p = v3{P.start_pos[0], P.start_pos[1], P.start_pos[2]};
       q = quat{P.start_quat[0], P.start_quat[1], P.start_quat[2], P.start_quat[3]};
     }
-    v = v3{P.start_vel[0], P.start_vel[1], P.start_vel[2]};
+    v = vel ? v3{vel[0], vel[1], vel[2]} : v3{P.start_vel[0], P.start_vel[1], P.start_vel[2]};
     w = v3{0.0f, 0.0f, 0.0f};
     contact_now = false;
     contact_step = false;
@@ -152,6 +152,7 @@ struct Body {
 // QuadX: drones/quadx.py. MODE_T == kRuntimeMode selects the flight mode from pf_params at run
 // time; any other value folds the cascade at compile time (mode 0 is the env hot path).
 constexpr int kRuntimeMode = 100;
+constexpr int kNoModeOverride = -100;  // control(): no per-drone flight mode given
 
 struct QuadX {
   static constexpr int GROUPS = 16, G_INT = 6, G_TGT = 12, AUX = 4, SP = 4;  // g15: MA-hover past action
@@ -234,8 +235,8 @@ struct QuadX {
     else sp[3] = b.p.z;
   }
   // drone.reset() + update_state (quadx.py:222-231, aviary.py:310-311); setpoint -> zeros(4)
-  PF_DEV void reset(const pf_params& P, const float* pose, float sp[6]) {
-    b.spawn(P, pose);
+  PF_DEV void reset(const pf_params& P, const float* pose, float sp[6], const float* vel = nullptr) {
+    b.spawn(P, pose, vel);
 #pragma unroll
     for (int k = 0; k < 4; ++k) thr[k] = pwm[k] = 0.0f;
     set_mode(0, sp);
@@ -251,8 +252,8 @@ struct QuadX {
   // update_control (quadx.py:401-493). period_over > 0: this drone's own control period (an Aviary
   // whose drones run different control_hz, tests/test_core.py:34-62); otherwise the batch-wide one.
   template <int MODE_T>
-  PF_DEV void control(const pf_params& P, const float sp[6], float period_over = 0.0f) {
-    const int mode = (MODE_T == kRuntimeMode) ? P.flight_mode : MODE_T;
+  PF_DEV void control(const pf_params& P, const float sp[6], float period_over = 0.0f, int mode_over = kNoModeOverride) {
+    const int mode = mode_over != kNoModeOverride ? mode_over : ((MODE_T == kRuntimeMode) ? P.flight_mode : MODE_T);
     const float cT = period_over > 0.0f ? period_over : P.control_period;
     const float cIT = period_over > 0.0f ? 1.0f / period_over : P.inv_control_period;
     float a[3] = {sp[0], sp[1], sp[2]};
@@ -481,8 +482,8 @@ struct Fixedwing {
 #pragma unroll
     for (int k = 0; k < 6; ++k) sp[k] = 0.0f;
   }
-  PF_DEV void reset(const pf_params& P, const float* pose, float sp[6]) {  // fixedwing.py:194-204
-    b.spawn(P, pose);
+  PF_DEV void reset(const pf_params& P, const float* pose, float sp[6], const float* vel = nullptr) {  // fixedwing.py:194-204
+    b.spawn(P, pose, vel);
 #pragma unroll
     for (int k = 0; k < 5; ++k) act[k] = 0.0f;
     thr = 0.0f;
@@ -490,7 +491,7 @@ struct Fixedwing {
   }
   float cmd[6];
   template <int MODE_T>
-  PF_DEV void control(const pf_params& P, const float sp[6], float = 0.0f) {  // fixedwing.py:229-259 (stateless: no period)
+  PF_DEV void control(const pf_params& P, const float sp[6], float = 0.0f, int = 0) {  // fixedwing.py:229-259 (stateless: no period)
     if (P.flight_mode == -1) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) cmd[k] = sp[k];

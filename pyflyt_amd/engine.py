@@ -52,6 +52,8 @@ class BatchEngine:
         self.link_pos = None
         self.wind_links = 0
         self.ctrl_ratio = None  # [n] int32: physics ticks per controller update of each drone, or None = uniform
+        self.modes = None       # [n] int32: per-drone flight modes (QuadX), or None = the context's mode
+        self.start_vel = None   # [n, 3] float32: per-drone spawn velocity for aviary_reset, or None = params
         self.out_aux = None
         self.out_contact = None
         self._buf = L.PfBuffers()
@@ -92,6 +94,8 @@ class BatchEngine:
         b.wind = _ptr(wind)
         b.out_link_pos = _ptr(self.link_pos)
         b.ctrl_ratio = _ptr(self.ctrl_ratio)
+        b.modes = _ptr(self.modes)
+        b.start_vel = _ptr(self.start_vel)
         return b
 
     def _check_f32(self, t, shape, name):

@@ -517,3 +517,51 @@ def test_custom_controller():
     with pytest.raises(AssertionError):
         env.register_controller(controller_id=3, controller_constructor=CustomController, base_mode=6)  # a default mode id
     env.disconnect()
+
+
+def test_per_drone_flight_modes_and_spawn_velocities():
+    """`Aviary.set_mode([...])` with a different mode per QuadX (core/aviary.py:449-455) and per-drone
+    `starting_velocity` for Fixedwings (fixedwing.py:35,201; the dogfight env spawns every aircraft with its
+    own velocity, ma_fixedwing_dogfight_env.py:218-222): each drone must fly exactly as in a single-mode /
+    single-velocity Aviary of its own."""
+    from pyflyt_amd.core import Aviary
+
+    modes = [0, 7, 6, -1, 4, 7, 1, 0]
+    n = len(modes)
+    rng = np.random.default_rng(12)
+    pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(1.0, 2.0, size=(n, 1))], axis=1)
+    orn = rng.uniform(-0.1, 0.1, size=(n, 3))
+    env = Aviary(pos, orn, drone_type="quadx", seed=21)
+    env.set_mode(modes)
+    sps = [sample_setpoint(rng, 1, "quadx", m)[0].astype(np.float32) for m in modes]
+    alone = []
+    for i, m in enumerate(modes):
+        a = Aviary(pos[[i]], orn[[i]], drone_type="quadx", seed=21, lane_offset=i)
+        a.set_mode(m)
+        assert torch.allclose(a.setpoints[0], env.setpoints[i])  # the per-mode default setpoints (quadx.py:275-290)
+        a.set_setpoint(0, sps[i]); env.set_setpoint(i, sps[i])
+        alone.append(a)
+    for _ in range(40):
+        env.step()
+        for a in alone:
+            a.step()
+    for i, a in enumerate(alone):
+        assert torch.allclose(env.state(i), a.state(0), rtol=1e-5, atol=1e-6), (i, modes[i])
+        assert torch.allclose(env.aux_state(i), a.aux_state(0), rtol=1e-5, atol=1e-6)
+        a.disconnect()
+    env.disconnect()
+
+    vels = [np.array([20.0, 0.0, 0.0]), np.array([0.0, 15.0, 1.0]), np.array([-12.0, -12.0, 0.0])]
+    fpos = np.array([[0.0, 0.0, 30.0]] * 3); forn = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 1.57], [0.0, 0.1, -2.36]])
+    env = Aviary(fpos, forn, drone_type="fixedwing", seed=5, drone_options=[dict(starting_velocity=v) for v in vels])
+    for i, v in enumerate(vels):
+        a = Aviary(fpos[[i]], forn[[i]], drone_type="fixedwing", seed=5, lane_offset=i, drone_options=dict(starting_velocity=v))
+        for _ in range(30):
+            a.step()
+        alone.append(a)
+    for _ in range(30):
+        env.step()
+    for i in range(3):
+        assert torch.allclose(env.state(i), alone[n + i].state(0), rtol=1e-5, atol=1e-5), i
+        alone[n + i].disconnect()
+    env.disconnect()

@@ -65,10 +65,7 @@ class MixedAviary:
         if isinstance(flight_modes, (list, tuple, np.ndarray)):
             assert len(flight_modes) == self.num_drones, f"Expected {self.num_drones} flight_modes, got {len(flight_modes)}."
             for k, idx in self._idx.items():
-                modes = {int(flight_modes[i]) for i in idx}
-                if len(modes) != 1:
-                    raise NotImplementedError(f"drones of one type ({k}) share one flight mode on the batched path")
-                self.parts[k].set_mode(modes.pop())
+                self.parts[k].set_mode([int(flight_modes[i]) for i in idx])  # (per-drone modes within a type: QuadX only)
         else:
             for p in self.parts.values():
                 p.set_mode(int(flight_modes))

@@ -458,8 +458,8 @@ def test_mixed_drones():
         assert torch.equal(env.aux_state(i), a.aux_state(0))
     assert [len(x) for x in env.all_aux_states] == [9, 4, 6, 4]
     assert env.contact_array.shape == (4,)
-    with pytest.raises(NotImplementedError):
-        env.set_mode([0, 7, 0, 6])  # two quadx in different modes share one engine
+    env.set_mode([0, 7, 0, 6])  # the two quadx now in different modes: a per-lane mode buffer inside their engine
+    env.step()
     env.disconnect()
     for a in alone:
         a.disconnect()

@@ -172,6 +172,10 @@ typedef struct pf_buffers {
   /* per-drone spawn velocity for pf_aviary_reset (drone_options[i]["starting_velocity"], fixedwing.py:35,
    * ma_fixedwing_dogfight_env.py:218-222): world-frame linear velocity [n][3], NULL = pf_params.start_vel */
   const float* start_vel;
+  /* Aviary.set_armed (core/aviary.py:423-438,510-521): a disarmed drone gets no controller update, no motor /
+   * aerodynamic / drag forces and no state read-back -- PyBullet still integrates it under gravity, its
+   * out_state / out_aux rows keep their last values. [n] bytes, NULL = all armed. */
+  const uint8_t* armed;
 } pf_buffers;
 
 typedef struct pf_ctx pf_ctx;

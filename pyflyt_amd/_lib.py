@@ -83,7 +83,7 @@ class PfBuffers(C.Structure):
         ("xi", C.c_void_p), ("xi_reset", C.c_void_p), ("u_targets", C.c_void_p),
         ("setpoints", C.c_void_p), ("out_state", C.c_void_p), ("out_aux", C.c_void_p),
         ("out_contact", C.c_void_p), ("start_pose", C.c_void_p),
-        ("wind", C.c_void_p), ("out_link_pos", C.c_void_p), ("ctrl_ratio", C.c_void_p), ("modes", C.c_void_p), ("start_vel", C.c_void_p),
+        ("wind", C.c_void_p), ("out_link_pos", C.c_void_p), ("ctrl_ratio", C.c_void_p), ("modes", C.c_void_p), ("start_vel", C.c_void_p), ("armed", C.c_void_p),
     ]
 
 

@@ -20,7 +20,7 @@ Same surface as the reference where it is on the hot path:
                     it (boring_bodies.py:93-96, lifting_surfaces.py:88-93)
 Several drone types in one Aviary are composed from one engine per type (core/mixed.py).
 Custom controllers (register_controller) run batch-wide on device tensors.
-Not carried over (out of scope): rendering/cameras, partial arming, drone-drone contact.
+Not carried over (out of scope): rendering/cameras, drone-drone contact.
 """
 from __future__ import annotations
 
@@ -270,9 +270,15 @@ class Aviary:
         sp = setpoints if torch.is_tensor(setpoints) else torch.as_tensor(np.asarray(setpoints))
         self.setpoints.copy_(sp.to(device=self.device, dtype=torch.float32).reshape(self.num_drones, self._sp_dim))
 
-    def set_armed(self, settings) -> None:
-        if isinstance(settings, (list, tuple)) and not all(settings) or (not isinstance(settings, (list, tuple)) and not settings):
-            raise NotImplementedError("disarming drones is not part of the batched hot path")
+    def set_armed(self, settings) -> None:  # core/aviary.py:423-438
+        """Arm / disarm drones: a disarmed drone gets no controller update, no forces and no state read-back
+        (its `state` / `aux_state` keep their last values), but still falls under gravity."""
+        if isinstance(settings, (list, tuple, np.ndarray)):
+            assert len(settings) == self.num_drones, f"Expected {self.num_drones} settings, got {len(settings)}."
+            flags = [bool(x) for x in settings]
+        else:
+            flags = [bool(settings)] * self.num_drones
+        self.engine.armed = None if all(flags) else torch.tensor(flags, dtype=torch.bool, device=self.device)
 
     # ------------------------------------------------------------------ :480-531
     def step(self, n_steps: int = 1) -> None:

@@ -79,8 +79,8 @@ class MixedAviary:
             self.set_setpoint(i, setpoints[i])
 
     def set_armed(self, settings) -> None:
-        for p in self.parts.values():
-            p.set_armed(settings if not isinstance(settings, (list, tuple)) else True)
+        for k, idx in self._idx.items():
+            self.parts[k].set_armed([settings[i] for i in idx] if isinstance(settings, (list, tuple, np.ndarray)) else settings)
 
     def register_wind_field_function(self, wind_field) -> None:
         for p in self.parts.values():

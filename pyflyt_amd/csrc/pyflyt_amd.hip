@@ -485,9 +485,13 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
     if (k < spn) sp[k] = B.setpoints[li * spn + k];
   bool contact = false;
   const int ratio = B.ctrl_ratio ? B.ctrl_ratio[li] : 0;
+  const bool armed = !B.armed || B.armed[li] != 0;  // aviary.py:423-438
   for (int s = 0; s < n_steps; ++s) {
     nz.begin_event(rng_ctr, 0u, B.xi ? B.xi + (size_t)s * P.ticks_per_control * N : nullptr);
-    if (ratio > 0 || B.modes) {  // this drone's own control rate (period ratio * dt) and / or flight mode
+    if (!armed) {  // no control, no forces, no state read-back: gravity only (aviary.py:510-521 skip it, Bullet does not)
+      V.b.contact_step = false;
+      for (int t = 0; t < P.ticks_per_control; ++t) V.tick_unarmed(P);
+    } else if (ratio > 0 || B.modes) {  // this drone's own control rate (period ratio * dt) and / or flight mode
       const int rr = ratio > 0 ? ratio : P.ticks_per_control;
       V.b.contact_step = false;
       for (int t = 0; t < P.ticks_per_control; ++t) {
@@ -506,13 +510,13 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   }
   int flags = (ints.y & ~PF_F_CONTACT) | (V.b.contact_now ? PF_F_CONTACT : 0);
   V.store(reinterpret_cast<float4*>(B.state), N, li, mode, nd, int4{ints.x, flags, (int)rng_ctr, ints.w});
-  if (B.out_state) {
+  if (B.out_state && armed) {
     float4* o = reinterpret_cast<float4*>(B.out_state + li * 12);
     o[0] = float4{V.b.wb.x, V.b.wb.y, V.b.wb.z, V.b.rpy.x};
     o[1] = float4{V.b.rpy.y, V.b.rpy.z, V.b.vb.x, V.b.vb.y};
     o[2] = float4{V.b.vb.z, V.b.p.x, V.b.p.y, V.b.p.z};
   }
-  if (B.out_aux) {
+  if (B.out_aux && armed) {
     float aux[VEH::AUX];
     V.aux(aux);
     for (int k = 0; k < VEH::AUX; ++k) B.out_aux[li * VEH::AUX + k] = aux[k];
@@ -554,6 +558,10 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   for (int k = 0; k < 8; ++k)
     if (k < spn) sp[k] = B.setpoints[li * spn + k];
   const int ratio = B.ctrl_ratio ? B.ctrl_ratio[li] : P.ticks_per_control;
+  const bool armed = !B.armed || B.armed[li] != 0;
+  if (!armed) {
+    V.tick_unarmed(P);
+  } else {
   if (tick_index % ratio == 0 || !kQuad) {
     V.template control<kRuntimeMode>(P, sp, B.ctrl_ratio ? ratio * P.dt : 0.0f, B.modes ? mode : kNoModeOverride);  // Fixedwing: stateless mixing, recomputed every tick
   } else {
@@ -562,18 +570,19 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   }
   const float xi = nz.get(P.noise_mode == PF_NOISE_INJECT ? 0 : tick_index);
   V.tick(P, xi, B.wind ? B.wind + li * (size_t)(VEH::WIND_LINKS * 3) : nullptr);
+  }
   V.b.rpy = euler_from_quat_fast(V.b.q);
   if (tick_index == P.ticks_per_control - 1) rng_ctr += 1;
   int flags = (ints.y & ~PF_F_CONTACT) | (V.b.contact_now ? PF_F_CONTACT : 0);
   V.store(S, N, li, mode, nd, int4{ints.x, flags, (int)rng_ctr, ints.w});
   if (kQuad) S[(size_t)kCmdGroup * N + li] = V.get_cmd();
-  if (B.out_state) {
+  if (B.out_state && armed) {
     float4* o = reinterpret_cast<float4*>(B.out_state + li * 12);
     o[0] = float4{V.b.wb.x, V.b.wb.y, V.b.wb.z, V.b.rpy.x};
     o[1] = float4{V.b.rpy.y, V.b.rpy.z, V.b.vb.x, V.b.vb.y};
     o[2] = float4{V.b.vb.z, V.b.p.x, V.b.p.y, V.b.p.z};
   }
-  if (B.out_aux) {
+  if (B.out_aux && armed) {
     float aux[VEH::AUX];
     V.aux(aux);
     for (int k = 0; k < VEH::AUX; ++k) B.out_aux[li * VEH::AUX + k] = aux[k];

@@ -122,7 +122,12 @@ struct Rocket {
       F = F + f;
       tau = tau + cross(rb, f);
     }
-    // composite body with the current fuel mass / inertia (fuel tank at tank_r, diagonal inertia)
+    integrate(P, F, tau);
+  }
+  PF_DEV void tick_unarmed(const pf_params& P) { integrate(P, v3{0.f, 0.f, 0.f}, v3{0.f, 0.f, 0.f}); }
+  // stepSimulation on the composite body with the current fuel mass / inertia (fuel tank at tank_r, diagonal inertia)
+  PF_DEV void integrate(const pf_params& P, v3 F, v3 tau) {
+    const pf_rocket& K = P.rocket;
     const float mf = fuel * K.total_fuel;
     const float M = K.dry_mass + mf, iM = 1.0f / M;
     const v3 c{(K.dry_mr[0] + mf * K.tank_r[0]) * iM, (K.dry_mr[1] + mf * K.tank_r[1]) * iM, (K.dry_mr[2] + mf * K.tank_r[2]) * iM};

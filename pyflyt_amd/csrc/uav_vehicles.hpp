@@ -336,6 +336,7 @@ struct QuadX {
     }
     b.tick(P, F, tau);
   }
+  PF_DEV void tick_unarmed(const pf_params& P) { b.tick(P, v3{0.f, 0.f, 0.f}, v3{0.f, 0.f, 0.f}); }  // aviary.py:510-521
   // one Aviary.step (aviary.py:480-531): control on the first tick, pwm held afterwards
   template <int MODE_T>
   PF_DEV void aviary_step(const pf_params& P, const float sp[6], Noise& nz, int flat_base) {
@@ -541,6 +542,7 @@ struct Fixedwing {
     }
     b.tick(P, F, tau);
   }
+  PF_DEV void tick_unarmed(const pf_params& P) { b.tick(P, v3{0.f, 0.f, 0.f}, v3{0.f, 0.f, 0.f}); }
   template <int MODE_T>
   PF_DEV void aviary_step(const pf_params& P, const float sp[6], Noise& nz, int flat_base) {
     b.contact_step = false;

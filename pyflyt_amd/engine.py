@@ -54,6 +54,7 @@ class BatchEngine:
         self.ctrl_ratio = None  # [n] int32: physics ticks per controller update of each drone, or None = uniform
         self.modes = None       # [n] int32: per-drone flight modes (QuadX), or None = the context's mode
         self.start_vel = None   # [n, 3] float32: per-drone spawn velocity for aviary_reset, or None = params
+        self.armed = None       # [n] bool: Aviary.set_armed, or None = all armed
         self.out_aux = None
         self.out_contact = None
         self._buf = L.PfBuffers()
@@ -96,6 +97,7 @@ class BatchEngine:
         b.ctrl_ratio = _ptr(self.ctrl_ratio)
         b.modes = _ptr(self.modes)
         b.start_vel = _ptr(self.start_vel)
+        b.armed = _ptr(self.armed)
         return b
 
     def _check_f32(self, t, shape, name):

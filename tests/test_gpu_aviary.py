@@ -565,3 +565,26 @@ def test_per_drone_flight_modes_and_spawn_velocities():
         assert torch.allclose(env.state(i), alone[n + i].state(0), rtol=1e-5, atol=1e-5), i
         alone[n + i].disconnect()
     env.disconnect()
+
+
+def test_set_armed():
+    """core/aviary.py:423-438,510-521: a disarmed drone is skipped by control / physics / state updates --
+    it free-falls (Bullet still integrates it), its reported state stays frozen; re-arming resumes it."""
+    from pyflyt_amd.core import Aviary
+
+    pos = np.array([[0.0, 0.0, 3.0], [1.0, 0.0, 3.0], [2.0, 0.0, 3.0]])
+    env = Aviary(pos, np.zeros((3, 3)), drone_type="quadx", seed=2, motor_noise=False)
+    env.set_mode(7)
+    env.set_armed([True, False, True])
+    frozen = env.state(1).clone()
+    for _ in range(30):
+        env.step()
+    assert torch.equal(env.state(1), frozen)                       # no read-back
+    z = env.engine.state[0][:, 2].cpu().numpy()
+    t = 60 / 240.0
+    assert abs(z[1] - (3.0 - 0.5 * 9.81 * t * (t + 1 / 240.0))) < 1e-3   # semi-implicit free fall: z0 - g dt^2 n(n+1)/2
+    assert abs(z[0] - 3.0) < 0.05 and abs(z[2] - 3.0) < 0.05       # the armed ones hold position (mode 7)
+    env.set_armed(True)
+    env.step()
+    assert not torch.equal(env.state(1), frozen) and env.state(1)[2, 2] < -1.0   # now reported: falling at ~2.5 m/s
+    env.disconnect()

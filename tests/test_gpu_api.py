@@ -301,3 +301,15 @@ def test_single_env_seeding_and_spaces(env_id):
             o2, _ = env2.reset(seed=42 + n_eps)
             assert np.array_equal(o1, o2)
     env1.close(); env2.close()
+
+
+@pytest.mark.parametrize("script,args", [("01_vector_env.py", ["4096"]), ("02_aviary_position_control.py", []), ("03_wind_field.py", [])])
+def test_examples_run(script, args):
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip()

@@ -13,6 +13,10 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d 
 # instruction mix of the other two specialised kernels
 VEH=fixedwing TASK=waypoints rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/pmc_sq_fixedwing_waypoints -- python $R/scratch/prof_cfg.py > /dev/null 2>&1
 VEH=quadx TASK=waypoints rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/pmc_sq_quadx_waypoints -- python $R/scratch/prof_cfg.py > /dev/null 2>&1
+# kernel traces of the other two BASELINE configs
+for e in quadx_waypoints fixedwing_waypoints; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$e -- python $R/bench.py --env $e --steps 500 --warmup 100 --no-cpu-baseline > /dev/null 2>&1
+done
 # other envs / sizes, short
 for e in quadx_waypoints fixedwing_waypoints; do python $R/bench.py --env $e --steps 500 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$e.json; done
 python $R/bench.py --batch 4096 --steps 2000 --warmup 200 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_b4096.json

@@ -9,6 +9,9 @@ for f in glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "rocprofv3_kernel_stats_bench_hover65536.csv"))
 for f in glob.glob(os.path.join(src, "kt", "*", "*domain_stats.csv")):
     shutil.copy(f, os.path.join(dst, "rocprofv3_domain_stats_bench_hover65536.csv"))
+for env in ("quadx_waypoints", "fixedwing_waypoints"):
+    for f in glob.glob(os.path.join(src, "kt_" + env, "*", "*kernel_stats.csv")):
+        shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_bench_{env}65536.csv"))
 out = {}
 for d in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_sq", "pmc_tcc"):
     for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):

@@ -29,7 +29,6 @@ from typing import Any, Sequence
 import numpy as np
 import torch
 
-from .. import _lib as L
 from ..engine import BatchEngine
 from ..params import build_params, quat_from_euler
 

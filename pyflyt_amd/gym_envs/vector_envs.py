@@ -13,7 +13,6 @@ write in place: copy them if you need them after the next step().
 """
 from __future__ import annotations
 
-import math
 from typing import Any
 
 import numpy as np

@@ -159,6 +159,8 @@ class Aviary:
         self.aviary_steps = 0
         self.elapsed_time = 0.0
         self.engine.state.zero_()
+        self.engine.armed = None   # core/aviary.py:305-307: arm everything
+        self.engine.modes = None   # drone.reset() -> set_mode(0) on every drone
         self.engine.aviary_reset(self._start_pose)
         self.mode = 0
         self._set_sp_dim(7 if self.drone_type == "rocket" else 4)

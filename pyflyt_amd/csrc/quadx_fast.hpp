@@ -33,6 +33,12 @@ struct QuadK {
   float m_a, m_noise, fmax, tmax;
   float ryf[4], rxf[4];        // r_y*fmax, -r_x*fmax per motor (torque arms)
   float drag[3], pqr;          // boring_bodies.py:63, cf2x.yaml:11
+  // the same constants with the inverse inertia / inverse mass folded in (diagonal inertia, COM at the base
+  // origin): the tick computes angular and linear ACCELERATIONS directly
+  float ryfI[4], rxfI[4], tmaxI;   // ryf * iI.x, rxf * iI.y, tmax * iI.z
+  float pqI[3];                    // pqr * iI[k]
+  float gyI[3];                    // iI.x (I.z - I.y), iI.y (I.x - I.z), iI.z (I.y - I.x): -(w x I w) / I, 0 without the gyro term
+  float dragM[3], fmaxM;           // drag[k] * inv_mass, fmax * inv_mass
   // rate PID (cf2x.yaml:13-19): kp, ki*T, kd/T, lim
   float kp[3], kiT[3], kdT[3], lim[3];
   // env
@@ -79,6 +85,12 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
     K.start_pos[k] = P.start_pos[k];
   }
   K.pqr = P.drag_coef_pqr;
+  for (int i = 0; i < 4; ++i) { K.ryfI[i] = K.ryf[i] * K.iI[0]; K.rxfI[i] = K.rxf[i] * K.iI[1]; }
+  K.tmaxI = K.tmax * K.iI[2];
+  for (int k = 0; k < 3; ++k) { K.pqI[k] = K.pqr * K.iI[k]; K.dragM[k] = K.drag[k] * K.inv_mass; }
+  const float gy = P.use_gyro_term ? 1.f : 0.f;
+  K.gyI[0] = gy * K.iI[0] * (K.I[2] - K.I[1]); K.gyI[1] = gy * K.iI[1] * (K.I[0] - K.I[2]); K.gyI[2] = gy * K.iI[2] * (K.I[1] - K.I[0]);
+  K.fmaxM = K.fmax * K.inv_mass;
   for (int k = 0; k < 4; ++k) K.start_quat[k] = P.start_quat[k];
   K.dome2 = P.dome * P.dome; K.goal_reach = P.goal_reach_distance; K.min_height = P.min_height;
   K.dome09m1 = P.dome * 0.9f - 1.0f;
@@ -163,16 +175,21 @@ struct QuadHot {
       thr[i] = t;
       k[i] = t * __builtin_fabsf(t);
     }
-    float Fz = K.fmax * ((k[0] + k[1]) + (k[2] + k[3]));
-    v3 tau{fmaf(K.ryf[0], k[0], fmaf(K.ryf[1], k[1], fmaf(K.ryf[2], k[2], K.ryf[3] * k[3]))),
-           fmaf(K.rxf[0], k[0], fmaf(K.rxf[1], k[1], fmaf(K.rxf[2], k[2], K.rxf[3] * k[3]))),
-           K.tmax * ((k[2] + k[3]) - (k[0] + k[1]))};
-    v3 F{-K.drag[0] * (vb.x * __builtin_fabsf(vb.x)), -K.drag[1] * (vb.y * __builtin_fabsf(vb.y)),
-         fmaf(-K.drag[2], vb.z * __builtin_fabsf(vb.z), Fz)};
-    const float pq = contact_now ? 0.0f : K.pqr;
-    tau.x = fmaf(-pq, wb.x * __builtin_fabsf(wb.x), tau.x);
-    tau.y = fmaf(-pq, wb.y * __builtin_fabsf(wb.y), tau.y);
-    tau.z = fmaf(-pq, wb.z * __builtin_fabsf(wb.z), tau.z);
+    // body-frame angular acceleration (torque / inertia, constants pre-divided): motor arms and reaction torque,
+    // rotational drag gated on "no contact in the world" (quadx.py:502-510), gyroscopic term -(w x I w) / I
+    const float pqf = contact_now ? 0.0f : 1.0f;
+    v3 wdb{fmaf(K.ryfI[0], k[0], fmaf(K.ryfI[1], k[1], fmaf(K.ryfI[2], k[2], K.ryfI[3] * k[3]))),
+           fmaf(K.rxfI[0], k[0], fmaf(K.rxfI[1], k[1], fmaf(K.rxfI[2], k[2], K.rxfI[3] * k[3]))),
+           K.tmaxI * ((k[2] + k[3]) - (k[0] + k[1]))};
+    wdb.x = fmaf(-K.pqI[0], pqf * (wb.x * __builtin_fabsf(wb.x)), wdb.x);
+    wdb.y = fmaf(-K.pqI[1], pqf * (wb.y * __builtin_fabsf(wb.y)), wdb.y);
+    wdb.z = fmaf(-K.pqI[2], pqf * (wb.z * __builtin_fabsf(wb.z)), wdb.z);
+    wdb.x = fmaf(-K.gyI[0], wb.y * wb.z, wdb.x);
+    wdb.y = fmaf(-K.gyI[1], wb.z * wb.x, wdb.y);
+    wdb.z = fmaf(-K.gyI[2], wb.x * wb.y, wdb.z);
+    // body-frame specific force (force / mass): body drag (boring_bodies.py:113-119) + thrust along +z
+    v3 Fm{-K.dragM[0] * (vb.x * __builtin_fabsf(vb.x)), -K.dragM[1] * (vb.y * __builtin_fabsf(vb.y)),
+          fmaf(-K.dragM[2], vb.z * __builtin_fabsf(vb.z), K.fmaxM * ((k[0] + k[1]) + (k[2] + k[3])))};
     // collision detection at the pre-integration pose
     bool near = (p.z - K.bound_radius) <= 0.0f;
     contact_now = false;
@@ -181,13 +198,8 @@ struct QuadHot {
         contact_now = quad_floor_contact(p.x, p.y, p.z, q, Pfull->boxes[0].h[0], Pfull->boxes[0].h[1], Pfull->boxes[0].h[2],
                                          Pfull->plane_half_xy, Pfull->plane_half_z);
     }
-    // Newton-Euler in the body frame, diagonal inertia, COM at the base origin
-    v3 h{K.I[0] * wb.x, K.I[1] * wb.y, K.I[2] * wb.z};
-    v3 g = cross(wb, h);
-    if (K.use_gyro == 0.0f) g = v3{0.f, 0.f, 0.f};  // uniform branch
-    v3 wdb{K.iI[0] * (tau.x - g.x), K.iI[1] * (tau.y - g.y), K.iI[2] * (tau.z - g.z)};
     v3 wd = mul(R, wdb);
-    v3 a = mul(R, K.inv_mass * F);
+    v3 a = mul(R, Fm);
     a.z += K.gravity_z;
     w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
     v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};

@@ -174,6 +174,7 @@ def main():
     assert torch.isfinite(eng.obs).all(), "non-finite observation"
     assert int(ints[:, 2].min()) >= args.steps, "event counter did not advance"
 
+    line = None
     if rank == 0:
         total_lanes = n * world
         value = total_lanes * args.steps / wall_max
@@ -205,9 +206,19 @@ def main():
                 pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.env, args.noise, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if dist is not None:
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes its version banner to the C stdout; flush that first so that the JSON line is the LAST line of output
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

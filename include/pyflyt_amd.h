@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 2
+#define PF_ABI_VERSION 3
 #define PF_MAX_TARGETS 8
 #define PF_MAX_BOXES 12
 #define PF_MAX_SURF 5
@@ -43,7 +43,11 @@ enum pf_autoreset { PF_AUTORESET_OFF = 0, PF_AUTORESET_NEXT_STEP = 1, PF_AUTORES
 /* bits of the per-lane `flags` word (state group PF_G_INT, .y) */
 enum pf_flag {
   PF_F_TERMINATED = 1, PF_F_TRUNCATED = 2, PF_F_CONTACT = 4, /* contact after the last tick */
-  PF_F_INFO_COLLISION = 8, PF_F_INFO_OOB = 16, PF_F_INFO_COMPLETE = 32
+  PF_F_INFO_COLLISION = 8, PF_F_INFO_OOB = 16, PF_F_INFO_COMPLETE = 32,
+  /* a state word of the lane is NaN/Inf after an env step (the reference would carry the NaN on silently:
+   * e.g. 0 * inf in the mixer's saturation rescale, quadx.py:490-491, when hi == pmin). Sticky until the
+   * lane is reset; surfaced as infos["nonfinite"]; counted by bench.py. */
+  PF_F_NONFINITE = 64
 };
 
 typedef struct pf_pid {
@@ -176,6 +180,14 @@ typedef struct pf_buffers {
    * aerodynamic / drag forces and no state read-back -- PyBullet still integrates it under gravity, its
    * out_state / out_aux rows keep their last values. [n] bytes, NULL = all armed. */
   const uint8_t* armed;
+  /* ABI 3 */
+  /* SAME_STEP auto-reset: [n][2] int32 (flags word, targets left) of the finished episode as they were BEFORE the
+   * lane was re-initialised -- gymnasium's `final_info` next to `final_obs`; NULL = not reported */
+  int32_t* final_info;
+  /* pf_rollout only: the sampled / consumed action of every step, [k_steps][n][4], or NULL = not stored */
+  float* actions_out;
+  /* pf_body_tick only: [n][6] body-frame force (3) and torque (3) applied at the base link for every tick */
+  const float* wrench;
 } pf_buffers;
 
 typedef struct pf_ctx pf_ctx;
@@ -230,6 +242,27 @@ int pf_wind_links(const pf_ctx* ctx);
  * (the role of env.action_space.sample(), tests/test_gym_envs.py:104), keyed by
  * (seed, global lane, step_index). */
 int pf_sample_actions(pf_ctx* ctx, float* actions, uint32_t step_index, void* stream);
+
+/* k_steps consecutive env.step() calls (quadx_base_env.py:269-301 incl. auto-reset) in ONE launch with the
+ * per-lane state resident in registers between the steps: the synthetic random-action rollout of
+ * tests/test_gym_envs.py:100-110 (`env.step(env.action_space.sample())` in a loop) without the per-step
+ * round trip of the state through HBM. Nothing is skipped: every step writes its observation, reward and
+ * flags. Buffers are trajectories: b->obs [k_steps][n][obs_dim], b->reward / terminated / truncated
+ * [k_steps][n], b->final_obs / final_info (SAME_STEP) [k_steps][n][..]. Actions: b->actions == NULL samples
+ * step s of lane i exactly as pf_sample_actions(step_index0 + s) would (same Philox keys) and, if
+ * b->actions_out != NULL, stores it there; otherwise b->actions is a given open-loop sequence
+ * [k_steps][n][4]. Results are bit-identical to k_steps x (pf_sample_actions + pf_env_step).
+ * Supported where the specialised env kernels are (QuadX mode 0 Hover / Waypoints, PF_NOISE_OFF / PHILOX);
+ * PF_ERR_UNSUPPORTED otherwise. */
+int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_index0, void* stream);
+
+/* The reference's LOWER boundary for one drone: applyExternalForce / applyExternalTorque on the base link in
+ * LINK_FRAME followed by stepSimulation (core/drones/quadx.py:502-510, core/aviary.py:516), n_ticks times with
+ * the wrench b->wrench held: the free-body tick alone (collision detection, gyroscopic term, +-max_coord_vel
+ * clamp, exponential-map attitude update), no motors / drag / controller. Exists so that the integrator's
+ * analytic known-answer tests (free fall, constant torque, torque-free spin, clamp) run against the device
+ * code directly. Fills b->out_state / out_contact. */
+int pf_body_tick(pf_ctx* ctx, const pf_buffers* b, int n_ticks, void* stream);
 
 #ifdef __cplusplus
 }

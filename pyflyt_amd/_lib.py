@@ -4,94 +4,87 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpyflyt_amd.so")
 
-PF_MAX_BOXES, PF_MAX_SURF = 12, 5
 QUADX, FIXEDWING, ROCKET = 0, 1, 2
 TASK_NONE, TASK_HOVER, TASK_WAYPOINTS, TASK_MA_HOVER = 0, 1, 2, 3
 NOISE_OFF, NOISE_INJECT, NOISE_PHILOX = 0, 1, 2
 AUTORESET_OFF, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
-F_TERMINATED, F_TRUNCATED, F_CONTACT, F_INFO_COLLISION, F_INFO_OOB, F_INFO_COMPLETE = 1, 2, 4, 8, 16, 32
+F_TERMINATED, F_TRUNCATED, F_CONTACT, F_INFO_COLLISION, F_INFO_OOB, F_INFO_COMPLETE, F_NONFINITE = 1, 2, 4, 8, 16, 32, 64
 
-f3 = C.c_float * 3
-f4 = C.c_float * 4
-f6 = C.c_float * 6
-
-
-class PfPid(C.Structure):
-    _fields_ = [("kp", f3), ("ki", f3), ("kd", f3), ("lim", f3)]
-
-
-class PfBox(C.Structure):
-    _fields_ = [("c", f3), ("h", f3), ("kind", C.c_int32), ("yaw", C.c_float)]
+# --------------------------------------------------------------------------- structs from the header
+# The ctypes mirrors of pf_pid / pf_box / pf_surface / pf_rocket / pf_params / pf_buffers are GENERATED
+# from include/pyflyt_amd.h at import time (one source of truth: a reordered or retyped field cannot
+# drift between the header and this binding); the sizes are still cross-checked against the compiled
+# library in lib().
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "include", "pyflyt_amd.h"))
+_SCALARS = {"float": C.c_float, "int32_t": C.c_int32, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64,
+            "int64_t": C.c_int64, "uint8_t": C.c_uint8, "int": C.c_int, "double": C.c_double, "size_t": C.c_size_t}
 
 
-class PfSurface(C.Structure):
-    _fields_ = [
-        ("r", f3), ("lift", f3), ("drag", f3), ("torque", f3),
-        ("Cl_alpha_3D", C.c_float), ("inv_Cl_alpha_3D", C.c_float), ("aero_tau_eta", C.c_float),
-        ("flap_to_chord", C.c_float), ("inv_pi_aspect", C.c_float), ("exp_term", C.c_float),
-        ("alpha_0_base", C.c_float), ("alpha_stall_P_base", C.c_float), ("alpha_stall_N_base", C.c_float),
-        ("Cd_0", C.c_float), ("deflection_limit_rad", C.c_float), ("dt_over_tau", C.c_float),
-        ("half_rho_area", C.c_float), ("chord", C.c_float),
-    ]
+def _parse_header(path):
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    defines = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(PF_[A-Z_0-9]+)\s+(-?\d+)\b", text)}
+    enums = {}
+    for m in re.finditer(r"enum\s+\w+\s*\{(.*?)\}\s*;", text, flags=re.S):
+        nxt = 0
+        for item in m.group(1).split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                name, val = (s.strip() for s in item.split("="))
+                nxt = int(val, 0)
+            else:
+                name = item
+            enums[name] = nxt
+            nxt += 1
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            mm = re.match(r"^(const\s+)?(\w+)\s*(\*?)\s*(.*)$", decl)
+            base, ptr, rest = mm.group(2), mm.group(3), mm.group(4)
+            for item in rest.split(","):
+                item = item.strip()
+                is_ptr = bool(ptr) or item.startswith("*")
+                item = item.lstrip("* ")
+                nm = re.match(r"^(\w+)((?:\s*\[\s*\w+\s*\])*)$", item)
+                if not nm:
+                    raise ValueError(f"cannot parse field {item!r} of {m.group(3)} in {path}")
+                dims = [defines[d] if d in defines else int(d) for d in re.findall(r"\[\s*(\w+)\s*\]", nm.group(2))]
+                if is_ptr:
+                    ct = C.c_void_p
+                else:
+                    ct = _SCALARS.get(base) or structs[base]
+                    for d in reversed(dims):
+                        ct = ct * d
+                fields.append((nm.group(1), ct))
+        structs[m.group(3)] = type(m.group(3), (C.Structure,), {"_fields_": fields})
+    protos = sorted(set(re.findall(r"\b(pf_[a-z_0-9]+)\s*\(", text)))
+    return defines, enums, structs, protos
 
 
-class PfRocket(C.Structure):
-    _fields_ = [
-        ("dry_mass", C.c_float), ("dry_mr", f3), ("dry_S", f6), ("dry_I", f3), ("tank_r", f3),
-        ("total_fuel", C.c_float), ("fuel_rate_ratio", C.c_float), ("fuel_inertia", f3),
-        ("thrust_min_ratio", C.c_float), ("max_thrust", C.c_float), ("booster_dt_over_tau", C.c_float),
-        ("booster_noise", C.c_float), ("reignitable", C.c_int32), ("booster_r", f3),
-        ("gimbal_dt_over_tau", C.c_float), ("gimbal_range_rad", C.c_float), ("finlet_map", f3 * 4),
-        ("starting_fuel_ratio", C.c_float),
-    ]
+_DEFINES, _ENUMS, _STRUCTS, _PROTOS = _parse_header(HEADER_PATH)
+PF_ABI_VERSION = _DEFINES["PF_ABI_VERSION"]
+PfPid, PfBox, PfSurface, PfRocket = _STRUCTS["pf_pid"], _STRUCTS["pf_box"], _STRUCTS["pf_surface"], _STRUCTS["pf_rocket"]
+PfParams, PfBuffers = _STRUCTS["pf_params"], _STRUCTS["pf_buffers"]
+for _k, _v in _ENUMS.items():  # PF_F_TERMINATED -> F_TERMINATED etc. stay spelled out above; expose the rest as PF_*
+    globals().setdefault(_k, _v)
 
 
-class PfParams(C.Structure):
-    _fields_ = [
-        ("vehicle", C.c_int32), ("task", C.c_int32), ("flight_mode", C.c_int32), ("noise_mode", C.c_int32),
-        ("autoreset", C.c_int32), ("angle_repr", C.c_int32), ("sparse_reward", C.c_int32),
-        ("num_targets", C.c_int32), ("max_steps", C.c_int32), ("env_step_ratio", C.c_int32),
-        ("settle_steps", C.c_int32), ("ticks_per_control", C.c_int32), ("use_gyro_term", C.c_int32),
-        ("throttle_remap", C.c_int32), ("n_motors", C.c_int32), ("n_surf", C.c_int32), ("n_boxes", C.c_int32),
-        ("has_com_offset", C.c_int32), ("seed", C.c_uint64),
-        ("dt", C.c_float), ("gravity_z", C.c_float), ("max_coord_vel", C.c_float),
-        ("plane_half_xy", C.c_float), ("plane_half_z", C.c_float),
-        ("inv_mass", C.c_float), ("com", f3), ("I_own", f6), ("I_pa", f6), ("I_inv", f6),
-        ("bound_radius", C.c_float), ("boxes", PfBox * PF_MAX_BOXES),
-        ("motor_r", f3 * 4), ("thrust_unit", f3 * 4),
-        ("motor_dt_over_tau", f4), ("motor_fmax", f4), ("motor_tmax", f4), ("motor_noise", f4),
-        ("motor_map", f4 * 4), ("drag_const", f3), ("drag_coef_pqr", C.c_float),
-        ("pid", PfPid * 4), ("zpid", PfPid * 2),
-        ("control_period", C.c_float), ("inv_control_period", C.c_float),
-        ("surf", PfSurface * PF_MAX_SURF), ("assist_ids", C.c_int32 * 6), ("assist_signs", f6),
-        ("start_pos", f3), ("start_quat", f4), ("start_vel", f3),
-        ("dome", C.c_float), ("goal_reach_distance", C.c_float), ("min_height", C.c_float),
-        ("wp_dist_reward", C.c_float), ("wp_yaw_penalty", C.c_float),
-        ("action_low", f4), ("action_high", f4),
-        ("rocket", PfRocket),
-    ]
-
-
-class PfBuffers(C.Structure):
-    _fields_ = [
-        ("state", C.c_void_p), ("actions", C.c_void_p), ("obs", C.c_void_p), ("final_obs", C.c_void_p),
-        ("reward", C.c_void_p), ("terminated", C.c_void_p), ("truncated", C.c_void_p),
-        ("xi", C.c_void_p), ("xi_reset", C.c_void_p), ("u_targets", C.c_void_p),
-        ("setpoints", C.c_void_p), ("out_state", C.c_void_p), ("out_aux", C.c_void_p),
-        ("out_contact", C.c_void_p), ("start_pose", C.c_void_p),
-        ("wind", C.c_void_p), ("out_link_pos", C.c_void_p), ("ctrl_ratio", C.c_void_p), ("modes", C.c_void_p), ("start_vel", C.c_void_p), ("armed", C.c_void_p),
-    ]
-
-
-EXPORTS = (
-    "pf_abi_version", "pf_sizeof_params", "pf_sizeof_buffers", "pf_last_error", "pf_ctx_create", "pf_ctx_destroy", "pf_state_groups", "pf_obs_dim",
-    "pf_n_lanes", "pf_env_reset", "pf_env_step", "pf_aviary_reset", "pf_aviary_set_mode", "pf_aviary_step",
-    "pf_sample_actions", "pf_aviary_tick", "pf_wind_links",
-)
+EXPORTS = tuple(_PROTOS)  # every function the header declares
+PF_MAX_BOXES, PF_MAX_SURF, PF_MAX_TARGETS = _DEFINES["PF_MAX_BOXES"], _DEFINES["PF_MAX_SURF"], _DEFINES["PF_MAX_TARGETS"]
+assert (QUADX, FIXEDWING, ROCKET) == (_ENUMS["PF_QUADX"], _ENUMS["PF_FIXEDWING"], _ENUMS["PF_ROCKET"])
+assert (F_CONTACT, F_INFO_COMPLETE) == (_ENUMS["PF_F_CONTACT"], _ENUMS["PF_F_INFO_COMPLETE"])
 
 _lib = None
 
@@ -130,11 +123,13 @@ def lib():
     L.pf_sample_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.pf_aviary_tick.argtypes = [C.c_void_p, C.POINTER(PfBuffers), C.c_int, C.c_void_p]
     L.pf_wind_links.argtypes = [C.c_void_p]
+    L.pf_rollout.argtypes = [C.c_void_p, C.POINTER(PfBuffers), C.c_int, C.c_uint32, C.c_void_p]
+    L.pf_body_tick.argtypes = [C.c_void_p, C.POINTER(PfBuffers), C.c_int, C.c_void_p]
     L.pf_sizeof_params.restype = C.c_size_t
     L.pf_sizeof_buffers.restype = C.c_size_t
     if L.pf_sizeof_params() != C.sizeof(PfParams) or L.pf_sizeof_buffers() != C.sizeof(PfBuffers):
         raise PyFlytAmdError("struct layout mismatch between pyflyt_amd/_lib.py and include/pyflyt_amd.h")
-    if L.pf_abi_version() != 2:
+    if L.pf_abi_version() != PF_ABI_VERSION:
         raise PyFlytAmdError("ABI version mismatch between pyflyt_amd/_lib.py and libpyflyt_amd.so")
     _lib = L
     return L

@@ -527,7 +527,13 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
   }
   const float out_reward = stepping ? reward : 0.0f;
   const bool out_term = stepping && term, out_trunc = stepping && trunc;
-  if (stepping) { step_count += 1; rng_ctr += 1; }
+  if (stepping) {
+    step_count += 1; rng_ctr += 1;
+    // NaN / Inf guard: any non-finite state word poisons the sum (see quadx_fast.hpp)
+    const float chk = ((V.p.x + V.p.y) + (V.p.z + V.q.x)) + ((V.q.y + V.q.z) + (V.q.w + V.v.x)) + ((V.v.y + V.v.z) + (V.w.x + V.w.y)) +
+                      ((V.w.z + V.thr) + (V.act[0] + V.act[1])) + ((V.act[2] + V.act[3]) + V.act[4]);
+    if (!(__builtin_fabsf(chk) < INFINITY)) flags |= PF_F_NONFINITE;
+  }
 
   // ---------------------------------------------------------------- SAME_STEP auto-reset
   if (K.autoreset == PF_AUTORESET_SAME_STEP) {
@@ -536,6 +542,11 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
       if (B.final_obs != nullptr) {
         if (active) write_obs_row();
         flush_tile(B.final_obs);
+      }
+      if (B.final_info != nullptr && same) {  // gymnasium's final_info: the episode's flags / targets left, pre-reset
+        B.final_info[2 * li + 0] = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
+                                   (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
+        B.final_info[2 * li + 1] = n_left - (pop_pending ? 1 : 0);
       }
       if (same) reset_lane();
     }

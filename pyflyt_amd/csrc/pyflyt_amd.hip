@@ -335,7 +335,10 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   const bool stepped = active && !settling && op == OP_STEP;
   const float out_reward = stepped ? reward : 0.0f;
   const bool out_term = stepped && term, out_trunc = stepped && trunc;
-  if (stepped) { step_count += 1; rng_ctr += 1; }  // quadx_base_env.py:299
+  if (stepped) {
+    step_count += 1; rng_ctr += 1;  // quadx_base_env.py:299
+    if (V.nonfinite()) flags |= PF_F_NONFINITE;  // NaN / Inf guard (see quadx_fast.hpp)
+  }
 
   // ---------------------------------------------------------------- SAME_STEP auto-reset (rare path)
   if (P.autoreset == PF_AUTORESET_SAME_STEP) {
@@ -344,6 +347,11 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
       if (B.final_obs != nullptr) {  // terminal observation, before the state is re-initialised
         if (active) write_obs_row();
         flush_tile(B.final_obs);
+      }
+      if (B.final_info != nullptr && same) {  // gymnasium's final_info: the episode's flags / targets left, pre-reset
+        B.final_info[2 * li + 0] = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
+                                   (trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0);
+        B.final_info[2 * li + 1] = tg.n_left - (pop_pending ? 1 : 0);
       }
       if (same) {
         begin_reset();
@@ -598,6 +606,37 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   }
 }
 
+// applyExternalForce / applyExternalTorque on the base link (LINK_FRAME) + stepSimulation, n_ticks times
+// (pf_body_tick): the free-body tick by itself, for the integrator's known-answer tests.
+template <class VEH>
+__global__ void __launch_bounds__(kWave) body_tick_kernel(const pf_params P, const pf_buffers B, const int n, const int n_ticks) {
+  const int lane = blockIdx.x * kWave + threadIdx.x;
+  if (lane >= n) return;
+  const size_t li = lane, N = n;
+  VEH V;
+  float nd;
+  int4 ints;
+  float4* S = reinterpret_cast<float4*>(B.state);
+  V.load(S, N, li, 7, nd, ints);
+  const float* wr = B.wrench + li * 6;
+  const v3 F{wr[0], wr[1], wr[2]}, tau{wr[3], wr[4], wr[5]};
+  bool contact = false;
+  for (int t = 0; t < n_ticks; ++t) {
+    V.b.tick(P, F, tau);
+    contact |= V.b.contact_now;
+  }
+  V.b.rpy = euler_from_quat_fast(V.b.q);
+  int flags = (ints.y & ~PF_F_CONTACT) | (V.b.contact_now ? PF_F_CONTACT : 0);
+  V.store(S, N, li, 7, nd, int4{ints.x, flags, ints.z, ints.w});
+  if (B.out_state) {
+    float4* o = reinterpret_cast<float4*>(B.out_state + li * 12);
+    o[0] = float4{V.b.wb.x, V.b.wb.y, V.b.wb.z, V.b.rpy.x};
+    o[1] = float4{V.b.rpy.y, V.b.rpy.z, V.b.vb.x, V.b.vb.y};
+    o[2] = float4{V.b.vb.z, V.b.p.x, V.b.p.y, V.b.p.z};
+  }
+  if (B.out_contact) B.out_contact[li] = contact ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(256) sample_actions_kernel(const pf_params P, float* actions, const int n,
                                                              const uint64_t lane0, const uint32_t step_index) {
   const int lane = blockIdx.x * 256 + threadIdx.x;
@@ -650,11 +689,19 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
-#define PF_FAST(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask)
+#define PF_FAST(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, false>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
   if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
   else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
   else PF_FAST(PF_NOISE_OFF);
 #undef PF_FAST
+}
+template <int TASK>
+static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
+  const int grid = (ctx->n + 63) / 64;
+#define PF_ROLL(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, true>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+  if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX);
+  else PF_ROLL(PF_NOISE_OFF);
+#undef PF_ROLL
 }
 static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
@@ -879,6 +926,39 @@ int pf_sample_actions(pf_ctx* ctx, float* actions, uint32_t step_index, void* st
   int rc = ensure_device(ctx);
   if (rc) return rc;
   hipLaunchKernelGGL(pf::sample_actions_kernel, dim3((ctx->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->P, actions, ctx->n, ctx->lane0, step_index);
+  PF_HIP(ctx, hipGetLastError());
+  return PF_OK;
+}
+
+int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_index0, void* stream) {
+  if (!ctx || !b || !b->state || !b->obs || !b->reward || !b->terminated || !b->truncated)
+    return fail(ctx, PF_ERR_ARG, "pf_rollout: state, obs, reward, terminated and truncated buffers are required");
+  if (k_steps < 1) return fail(ctx, PF_ERR_ARG, "pf_rollout: k_steps must be >= 1");
+  const pf_params& P = ctx->P;
+  if (!ctx->fast || (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS))
+    return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: supported for the specialised QuadX mode-0 Hover / Waypoints kernels only");
+  if (P.noise_mode == PF_NOISE_INJECT) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: PF_NOISE_INJECT is a per-step protocol; use pf_env_step");
+  if (P.autoreset == PF_AUTORESET_OFF) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: needs an auto-reset mode (finished lanes would idle for the rest of the launch)");
+  int rc = ensure_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (P.task == PF_TASK_HOVER) launch_rollout<PF_TASK_HOVER>(ctx, b, k_steps, step_index0, s);
+  else launch_rollout<PF_TASK_WAYPOINTS>(ctx, b, k_steps, step_index0, s);
+  PF_HIP(ctx, hipGetLastError());
+  return PF_OK;
+}
+int pf_body_tick(pf_ctx* ctx, const pf_buffers* b, int n_ticks, void* stream) {
+  if (!ctx || !b || !b->state || !b->wrench) return fail(ctx, PF_ERR_ARG, "pf_body_tick: state and wrench buffers are required");
+  if (n_ticks < 1) return fail(ctx, PF_ERR_ARG, "pf_body_tick: n_ticks must be >= 1");
+  if (ctx->P.vehicle == PF_ROCKET) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_body_tick: the Rocket's mass properties change per tick; QuadX / Fixedwing only");
+  int rc = ensure_device(ctx);
+  if (rc) return rc;
+  const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
+  hipStream_t s = (hipStream_t)stream;
+  if (ctx->P.vehicle == PF_QUADX)
+    hipLaunchKernelGGL(pf::body_tick_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, n_ticks);
+  else
+    hipLaunchKernelGGL(pf::body_tick_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, n_ticks);
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;
 }

@@ -48,6 +48,7 @@ struct QuadK {
   int32_t task_sparse, angle_repr, num_targets, max_steps, env_step_ratio, settle_steps, tpc;
   int32_t noise_mode, autoreset, fast_settle;
   uint32_t seed_lo, seed_hi;
+  float act_lo[4], act_span[4];  // action box (quadx_base_env.py:80-102): low, high - low (pf_rollout's on-device sampling)
 };
 
 // Fill QuadK from the ABI struct; returns false when the configuration needs the generic kernel.
@@ -99,6 +100,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.env_step_ratio = P.env_step_ratio; K.settle_steps = P.settle_steps; K.tpc = P.ticks_per_control;
   K.noise_mode = P.noise_mode; K.autoreset = P.autoreset;
   K.seed_lo = (uint32_t)P.seed; K.seed_hi = (uint32_t)(P.seed >> 32);
+  for (int k = 0; k < 4; ++k) { K.act_lo[k] = P.action_low[k]; K.act_span[k] = P.action_high[k] - P.action_low[k]; }
   // level spawn at rest, far enough above the floor that the settle free-fall cannot touch it
   const float fall = 0.5f * 9.81f * (P.settle_steps * P.ticks_per_control * P.dt) * (P.settle_steps * P.ticks_per_control * P.dt);
   K.fast_settle = (P.start_quat[0] == 0.f && P.start_quat[1] == 0.f && P.start_vel[0] == 0.f && P.start_vel[1] == 0.f &&
@@ -218,10 +220,14 @@ struct QuadHot {
 // Specialised at compile time on the task and the noise source; requires (checked by
 // quadk_from_params) ticks_per_control == 2, env_step_ratio <= 4, a level spawn at rest and
 // settle_ticks a multiple of 4 and <= 24.
-template <int TASK, int NOISE, int LPW>
+// ROLLOUT: pf_rollout -- the same env step k_steps times in one launch with the lane's state resident in
+// registers (the loop below is then a real loop; for the one-launch-per-step instantiation it has a
+// compile-time trip count of one and disappears). Every step still writes its observation / reward /
+// flags, to trajectory buffers [k_steps][n][..]; the stores of step s drain while step s+1 computes.
+template <int TASK, int NOISE, int LPW, bool ROLLOUT>
 __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
-                                                             const uint8_t* __restrict__ mask) {
+                                                             const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
   constexpr int kMaxD = 13 + 4 + 4 + 12;
   constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
   __shared__ float tile[LPW * kMaxD];
@@ -278,16 +284,10 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   V.derive();
   bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
 
-  bool active, do_reset;
-  if (op == 1) {
-    do_reset = (mask == nullptr) || (mask[li] != 0);
-    active = do_reset;
-  } else {
-    do_reset = (K.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc);
-    active = true;
-  }
+  bool active;
+  if (op == 1) active = (mask == nullptr) || (mask[li] != 0);
+  else active = true;
   active = active && valid;
-  do_reset = do_reset && active;
 
   float act0 = 0.f, act1 = 0.f, act2 = 0.f, act3 = 0.f;
   float reward = 0.0f;
@@ -494,15 +494,42 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     lds_sync();
   };
 
+  const int KS = ROLLOUT ? k_steps : 1;
+  float4 a_nxt = float4{0.f, 0.f, 0.f, 0.f};
+  if (ROLLOUT && B.actions != nullptr) a_nxt = reinterpret_cast<const float4*>(B.actions)[li];
+  for (int it = 0; it < KS; ++it) {
+  const size_t toff = ROLLOUT ? (size_t)it * N : (size_t)0;  // this step's slot in the trajectory buffers (lanes)
   // ---------------------------------------------------------------- reset (NEXT_STEP / explicit)
+  bool do_reset;
+  if (op == 1) do_reset = active;
+  else do_reset = (K.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc) && active;
+  act0 = act1 = act2 = act3 = 0.f;
+  reward = 0.0f;
+  was_reset = false;
   prepare_settle_noise(do_reset);
   if (do_reset) reset_lane();
 
   // ---------------------------------------------------------------- the env step
   const bool stepping = active && !was_reset && op == 0;
   float sp0 = 0.f, sp1 = 0.f, sp2 = 0.f, sp3 = 0.f;
+  float4 a_roll = float4{0.f, 0.f, 0.f, 0.f};
+  if (ROLLOUT) {  // this step's action for every lane: given sequence (prefetched one step ahead) or sampled
+    if (B.actions != nullptr) {
+      a_roll = a_nxt;
+      if (it + 1 < KS) a_nxt = reinterpret_cast<const float4*>(B.actions)[toff + N + li];
+    } else {  // == sample_actions_kernel(step0 + it): same Philox key, same arithmetic
+      f4 u = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), step0 + (uint32_t)it, 0u, 3u));
+      a_roll = float4{fmaf(K.act_span[0], u.a, K.act_lo[0]), fmaf(K.act_span[1], u.b, K.act_lo[1]),
+                      fmaf(K.act_span[2], u.c, K.act_lo[2]), fmaf(K.act_span[3], u.d, K.act_lo[3])};
+    }
+    if (B.actions_out != nullptr && active) {
+      float* ao = B.actions_out + 4 * (toff + li);
+      __builtin_nontemporal_store(a_roll.x, ao + 0); __builtin_nontemporal_store(a_roll.y, ao + 1);
+      __builtin_nontemporal_store(a_roll.z, ao + 2); __builtin_nontemporal_store(a_roll.w, ao + 3);
+    }
+  }
   if (stepping) {
-    const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+    const float4 a = ROLLOUT ? a_roll : reinterpret_cast<const float4*>(B.actions)[li];
     act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
     sp0 = a.x; sp1 = a.y; sp2 = a.z; sp3 = a.w;
     reward = -0.1f;
@@ -588,7 +615,15 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   }
   const float out_reward = stepping ? reward : 0.0f;
   const bool out_term = stepping && term, out_trunc = stepping && trunc;
-  if (stepping) { step_count += 1; rng_ctr += 1; }  // quadx_base_env.py:299
+  if (stepping) {
+    step_count += 1; rng_ctr += 1;  // quadx_base_env.py:299
+    // NaN / Inf guard (the reference would carry a NaN on silently, e.g. 0 * inf in
+    // quadx.py:490-491 when the largest motor command equals the clipped minimum): any non-finite state
+    // word poisons the sum
+    const float chk = ((V.p.x + V.p.y) + (V.p.z + V.q.x)) + ((V.q.y + V.q.z) + (V.q.w + V.v.x)) + ((V.v.y + V.v.z) + (V.w.x + V.w.y)) +
+                      ((V.w.z + V.thr[0]) + (V.thr[1] + V.thr[2])) + ((V.thr[3] + V.I[0]) + (V.I[1] + V.I[2]));
+    if (!(__builtin_fabsf(chk) < INFINITY)) flags |= PF_F_NONFINITE;
+  }
 
   // ---------------------------------------------------------------- SAME_STEP auto-reset
   if (K.autoreset == PF_AUTORESET_SAME_STEP) {
@@ -596,7 +631,12 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     if (__any(same)) {
       if (B.final_obs != nullptr) {  // terminal observation, before the state is re-initialised
         if (active) write_obs_row();
-        flush_tile(B.final_obs);
+        flush_tile(B.final_obs + toff * D);
+      }
+      if (B.final_info != nullptr && same) {  // gymnasium's final_info: the episode's flags / targets left, pre-reset
+        B.final_info[2 * (toff + li) + 0] = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
+                                            (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
+        B.final_info[2 * (toff + li) + 1] = n_left - (pop_pending ? 1 : 0);
       }
       prepare_settle_noise(same);
       if (same) reset_lane();
@@ -606,11 +646,22 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   // ---------------------------------------------------------------- outputs
   // observation tile first, persistent state after it: nothing waits on the state stores
   if (active) write_obs_row();
-  flush_tile(B.obs);
+  flush_tile(B.obs + toff * D);
   if (active) {
     if (pop_pending) { pop_target(); pop_pending = false; }
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
             (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
+    if (op == 0) {  // a NEXT_STEP reset call reports (r=0, not done), gymnasium's convention
+      B.reward[toff + li] = out_reward;
+      B.terminated[toff + li] = out_term ? 1 : 0;
+      B.truncated[toff + li] = out_trunc ? 1 : 0;
+    }
+  }
+  // the next step's motor-noise normals (keyed by the event counter this step left behind)
+  if (ROLLOUT && NOISE == PF_NOISE_PHILOX && it + 1 < KS)
+    zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
+  }  // for it
+  if (active) {  // the persistent state goes back to HBM once per launch
     Sout[0 * N + li] = float4{V.p.x, V.p.y, V.p.z, new_dist};
     Sout[1 * N + li] = float4{V.q.x, V.q.y, V.q.z, V.q.w};
     Sout[2 * N + li] = float4{V.v.x, V.v.y, V.v.z, V.w.x};
@@ -623,11 +674,6 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       Sout[12 * N + li] = float4{tgt[0][0], tgt[0][1], tgt[0][2], tgt[1][0]};
       Sout[13 * N + li] = float4{tgt[1][1], tgt[1][2], tgt[2][0], tgt[2][1]};
       Sout[14 * N + li] = float4{tgt[2][2], tgt[3][0], tgt[3][1], tgt[3][2]};
-    }
-    if (op == 0) {  // a NEXT_STEP reset call reports (r=0, not done), gymnasium's convention
-      B.reward[li] = out_reward;
-      B.terminated[li] = out_term ? 1 : 0;
-      B.truncated[li] = out_trunc ? 1 : 0;
     }
   }
 }

@@ -131,6 +131,10 @@ struct Body {
     derive();
     contact_step |= contact_now;
   }
+  PF_DEV bool nonfinite() const {  // any NaN / Inf among the base state words poisons the sum
+    const float chk = ((p.x + p.y) + (p.z + q.x)) + ((q.y + q.z) + (q.w + v.x)) + ((v.y + v.z) + (w.x + w.y)) + w.z;
+    return !(__builtin_fabsf(chk) < INFINITY);
+  }
   PF_DEV void spawn(const pf_params& P, const float* pose /* [7] or null */, const float* vel = nullptr /* [3] or null */) {
     if (pose) {
       p = v3{pose[0], pose[1], pose[2]};
@@ -349,6 +353,7 @@ struct QuadX {
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = thr[k];
   }
+  PF_DEV bool nonfinite() const { return b.nonfinite() || !(__builtin_fabsf((thr[0] + thr[1]) + (thr[2] + thr[3])) < INFINITY); }
   // the motor commands held between the ticks of one Aviary step (pf_aviary_tick)
   PF_DEV float4 get_cmd() const { return float4{pwm[0], pwm[1], pwm[2], pwm[3]}; }
   PF_DEV void set_cmd(float4 c) { pwm[0] = c.x; pwm[1] = c.y; pwm[2] = c.z; pwm[3] = c.w; }
@@ -555,6 +560,7 @@ struct Fixedwing {
     for (int k = 0; k < 5; ++k) o[k] = act[k];
     o[5] = thr;
   }
+  PF_DEV bool nonfinite() const { return b.nonfinite() || !(__builtin_fabsf(((act[0] + act[1]) + (act[2] + act[3])) + (act[4] + thr)) < INFINITY); }
   PF_DEV float4 get_cmd() const { return float4{0.f, 0.f, 0.f, 0.f}; }  // stateless mixing: nothing to carry
   PF_DEV void set_cmd(float4) {}
 };

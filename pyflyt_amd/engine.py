@@ -45,6 +45,8 @@ class BatchEngine:
         self.state = torch.zeros(self.groups, self.n, 4, **f32)
         self.obs = torch.zeros(self.n, self.obs_dim, **f32)
         self.final_obs = torch.zeros(self.n, self.obs_dim, **f32) if params.autoreset == L.AUTORESET_SAME_STEP else None
+        # [n, 2] int32 (flags, targets left) of the episode that just ended, before the SAME_STEP re-initialisation
+        self.final_info = torch.zeros(self.n, 2, dtype=torch.int32, device=self.device) if params.autoreset == L.AUTORESET_SAME_STEP else None
         self.reward = torch.zeros(self.n, **f32)
         self.terminated = torch.zeros(self.n, dtype=torch.bool, device=self.device)
         self.truncated = torch.zeros(self.n, dtype=torch.bool, device=self.device)
@@ -74,7 +76,8 @@ class BatchEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _buffers(self, actions=None, xi=None, xi_reset=None, u_targets=None, setpoints=None, start_pose=None, wind=None):
+    def _buffers(self, actions=None, xi=None, xi_reset=None, u_targets=None, setpoints=None, start_pose=None, wind=None,
+                 wrench=None, actions_out=None):
         # (ctrl_ratio: per-drone control rate, set once by the batched Aviary)
         b = self._buf
         b.state = _ptr(self.state)
@@ -98,6 +101,9 @@ class BatchEngine:
         b.modes = _ptr(self.modes)
         b.start_vel = _ptr(self.start_vel)
         b.armed = _ptr(self.armed)
+        b.final_info = _ptr(self.final_info)
+        b.actions_out = _ptr(actions_out)
+        b.wrench = _ptr(wrench)
         return b
 
     def _check_f32(self, t, shape, name):
@@ -142,6 +148,39 @@ class BatchEngine:
         with torch.cuda.device(self.device):
             L.check(self.lib.pf_sample_actions(self._ctx, _ptr(out), int(step_index) & 0xFFFFFFFF, self._stream()), self._ctx)
         return out
+
+    def rollout(self, k_steps: int, step_index0: int = 0, actions=None, store_actions: bool = True):
+        """pf_rollout: `k_steps` env steps in one launch, state resident in registers. Returns the trajectory
+        tensors (obs [k, n, D], reward [k, n], terminated [k, n], truncated [k, n], actions [k, n, 4] or None);
+        bit-identical to k x (sample_actions(step_index0 + s) + env_step). `actions`: an open-loop sequence
+        [k, n, 4] instead of on-device sampling."""
+        k = int(k_steps)
+        t = getattr(self, "_traj", None)
+        if t is None or t["k"] != k:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            t = dict(k=k, obs=torch.empty(k, self.n, self.obs_dim, **f32), reward=torch.empty(k, self.n, **f32),
+                     terminated=torch.empty(k, self.n, dtype=torch.bool, device=self.device),
+                     truncated=torch.empty(k, self.n, dtype=torch.bool, device=self.device),
+                     actions=torch.empty(k, self.n, 4, **f32),
+                     final_obs=torch.zeros(k, self.n, self.obs_dim, **f32) if self.final_obs is not None else None,
+                     final_info=torch.zeros(k, self.n, 2, dtype=torch.int32, device=self.device) if self.final_info is not None else None)
+            self._traj = t
+        self._check_f32(actions, (k, self.n, 4), "actions")
+        b = self._buffers(actions=actions, actions_out=t["actions"] if (store_actions and actions is None) else None)
+        b.obs, b.reward, b.terminated, b.truncated = _ptr(t["obs"]), _ptr(t["reward"]), _ptr(t["terminated"]), _ptr(t["truncated"])
+        b.final_obs, b.final_info = _ptr(t["final_obs"]), _ptr(t["final_info"])
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_rollout(self._ctx, C.byref(b), k, int(step_index0) & 0xFFFFFFFF, self._stream()), self._ctx)
+        return t["obs"], t["reward"], t["terminated"], t["truncated"], (t["actions"] if actions is None and store_actions else actions)
+
+    def body_tick(self, wrench, n_ticks: int = 1):
+        """pf_body_tick: the free-body tick alone under a held body-frame wrench [n, 6] (force, torque)."""
+        self._aviary_outputs()
+        self._check_f32(wrench, (self.n, 6), "wrench")
+        b = self._buffers(wrench=wrench)
+        with torch.cuda.device(self.device):
+            L.check(self.lib.pf_body_tick(self._ctx, C.byref(b), int(n_ticks), self._stream()), self._ctx)
+        return self.out_state
 
     # ------------------------------------------------------------------ Aviary level
     def _aviary_outputs(self):

@@ -91,7 +91,11 @@ class _VecEnvBase:
         obs, rew, term, trunc = self.engine.env_step(actions)
         infos = self._infos()
         if self.engine.final_obs is not None:
+            # SAME_STEP (gymnasium.vector AutoresetMode.SAME_STEP): lanes that finished were re-initialised inside the
+            # step, so their terminal observation AND info travel in final_obs / final_info (rows of other lanes are stale)
             infos["final_obs"] = self._obs(self.engine.final_obs)
+            infos["final_info"] = self._infos(self.engine.final_info[:, 0], self.engine.final_info[:, 1])
+            infos["_final_info"] = term | trunc
         return self._obs(obs), rew, term, trunc, infos
 
     def close(self):
@@ -106,12 +110,13 @@ class _VecEnvBase:
     def _obs(self, buf):
         return buf
 
-    def _infos(self) -> dict[str, Any]:
-        f = self.engine.flags()
+    def _infos(self, flags=None, n_left=None) -> dict[str, Any]:
+        f = self.engine.flags() if flags is None else flags
         return {
             "out_of_bounds": (f & L.F_INFO_OOB) != 0,      # quadx_base_env.py:266
             "collision": (f & L.F_INFO_COLLISION) != 0,    # quadx_base_env.py:260
             "env_complete": (f & L.F_INFO_COMPLETE) != 0,  # quadx_waypoints_env.py:203
+            "nonfinite": (f & L.F_NONFINITE) != 0,         # NaN/Inf guard (not in the reference, which carries NaNs on silently)
         }
 
     @property
@@ -162,9 +167,10 @@ class _WaypointsMixin:
         # past the remaining targets are zero (flatten_waypoint_env.py:49-56 padding convention)
         return {"attitude": buf[:, :a], "target_deltas": buf[:, a:].view(-1, self.num_targets, 3)}
 
-    def _infos(self):
-        infos = super()._infos()
-        n_left = self.engine.ints()[:, 3]
+    def _infos(self, flags=None, n_left=None):
+        infos = super()._infos(flags)
+        if n_left is None:
+            n_left = self.engine.ints()[:, 3]
         infos["num_targets_reached"] = self.num_targets - n_left  # quadx_waypoints_env.py:204
         return infos
 

@@ -1,0 +1,101 @@
+"""pf_rollout (k env steps per launch, state resident in registers, actions sampled on device) must be
+BIT-IDENTICAL to k x (pf_sample_actions + pf_env_step): same Philox keys, same arithmetic, every step's
+observation / reward / flags written. Also against the fp64 oracle over the same action sequence."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(task, n, noise, autoreset, seed, lane_offset=0, **kw):
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    P = build_params("quadx", task, noise=noise, autoreset=autoreset, seed=seed, **kw)
+    return BatchEngine(P, n, device="cuda:0", lane_offset=lane_offset)
+
+
+@pytest.mark.parametrize("task", ["hover", "waypoints"])
+@pytest.mark.parametrize("noise,autoreset", [("philox", "next_step"), ("philox", "same_step"), ("off", "next_step")])
+def test_rollout_bit_identical_to_single_steps(task, noise, autoreset):
+    n, k, seed = 1000, 96, 21  # 1000: a ragged last wave
+    a = _engine(task, n, noise, autoreset, seed, lane_offset=4096)
+    b = _engine(task, n, noise, autoreset, seed, lane_offset=4096)
+    a.env_reset()
+    b.env_reset()
+    assert torch.equal(a.state, b.state)
+    # two launches of k/2 steps each: the state written back by the first must continue exactly
+    chunks = []
+    for c in range(2):
+        obs, rew, term, trunc, acts = a.rollout(k // 2, step_index0=c * (k // 2))
+        chunks.append([x.clone() for x in (obs, rew, term, trunc, acts)] +
+                      [a._traj["final_obs"].clone() if a.final_obs is not None else None,
+                       a._traj["final_info"].clone() if a.final_info is not None else None])
+    act = torch.empty(n, 4, device="cuda:0")
+    n_done = 0
+    for s in range(k):
+        c, j = divmod(s, k // 2)
+        b.sample_actions(act, s)
+        o, r, t, tr = b.env_step(act)
+        assert torch.equal(act, chunks[c][4][j]), f"step {s}: sampled action"
+        assert torch.equal(o, chunks[c][0][j]), f"step {s}: obs max diff {(o - chunks[c][0][j]).abs().max().item()}"
+        assert torch.equal(r, chunks[c][1][j]), f"step {s}: reward"
+        assert torch.equal(t, chunks[c][2][j]) and torch.equal(tr, chunks[c][3][j]), f"step {s}: flags"
+        done = t | tr
+        n_done += int(done.sum())
+        if autoreset == "same_step" and done.any():
+            assert torch.equal(b.final_obs[done], chunks[c][5][j][done]), f"step {s}: final_obs"
+            assert torch.equal(b.final_info[done], chunks[c][6][j][done]), f"step {s}: final_info"
+    assert torch.equal(a.state, b.state)
+    assert n_done > 200  # random actions end episodes quickly: the in-loop resets are exercised
+
+
+def test_rollout_given_action_sequence():
+    """An open-loop action sequence [k, n, 4] instead of on-device sampling."""
+    n, k = 320, 40
+    a = _engine("hover", n, "philox", "next_step", 5)
+    b = _engine("hover", n, "philox", "next_step", 5)
+    a.env_reset(); b.env_reset()
+    rng = np.random.default_rng(0)
+    seq = torch.tensor(rng.uniform([-3, -3, -3, 0], [3, 3, 3, 0.8], size=(k, n, 4)), dtype=torch.float32, device="cuda:0")
+    obs, rew, term, trunc, _ = a.rollout(k, actions=seq)
+    for s in range(k):
+        o, r, t, tr = b.env_step(seq[s].contiguous())
+        assert torch.equal(o, obs[s]) and torch.equal(r, rew[s]) and torch.equal(t, term[s]) and torch.equal(tr, trunc[s]), s
+    assert torch.equal(a.state, b.state)
+
+
+def test_rollout_against_oracle():
+    """The rollout's trajectory against the fp64 oracle fed the same (device-sampled) actions."""
+    n, k, seed = 512, 60, 9
+    a = _engine("hover", n, "philox", "next_step", seed)
+    a.env_reset()
+    obs, rew, term, trunc, acts = a.rollout(k)
+    orc = O.OracleBatch(O.make_params("hover", noise_mode=O.NOISE_PHILOX, seed=seed), n)
+    orc.reset()
+    ok = np.ones(n, dtype=bool)
+    worst = 0.0
+    for s in range(k):
+        ro, rr, rt, rtr, _ = orc.step(acts[s].cpu().numpy(), autoreset=1)
+        e = (np.abs(obs[s].cpu().numpy().astype(np.float64) - ro) / np.maximum(1.0, np.abs(ro))).max(axis=1)
+        ok &= (e < 1e-4) & (term[s].cpu().numpy() == rt) & (trunc[s].cpu().numpy() == rtr)
+        worst = max(worst, e[ok].max())
+    print(f"rollout vs oracle: worst {worst:.2e}, lanes compared to the end {ok.mean():.4f}")
+    assert ok.all() and worst < 1e-4
+
+
+def test_rollout_refusals():
+    from pyflyt_amd import PyFlytAmdError
+
+    e = _engine("hover", 64, "philox", "off", 1)
+    e.env_reset()
+    with pytest.raises(PyFlytAmdError):
+        e.rollout(4)  # no auto-reset mode
+    e = _engine("hover", 64, "philox", "next_step", 1, flight_mode=6)
+    e.env_reset()
+    with pytest.raises(PyFlytAmdError):
+        e.rollout(4)  # generic kernel configuration

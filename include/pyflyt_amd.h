@@ -207,6 +207,9 @@ void pf_ctx_destroy(pf_ctx* ctx);
 int pf_state_groups(const pf_ctx* ctx); /* float4 groups per lane in pf_buffers.state */
 int pf_obs_dim(const pf_ctx* ctx);
 int pf_n_lanes(const pf_ctx* ctx);
+/* which env kernel pf_env_step / pf_env_reset launch for this context: 0 the generic env_kernel, 1 the
+ * specialised QuadX mode-0 kernel (Hover / Waypoints / MA-Hover), 2 the specialised Fixedwing-Waypoints kernel */
+int pf_ctx_is_specialised(const pf_ctx* ctx);
 
 /* env.reset(): gym_envs/quadx_envs/quadx_base_env.py:149-212 (begin_reset + end_reset incl. the
  * 10 settle Aviary steps), quadx_hover_env.py:70-83, quadx_waypoints_env.py:112-125,

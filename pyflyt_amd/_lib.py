@@ -113,7 +113,7 @@ def lib():
     L.pf_ctx_create.argtypes = [C.POINTER(PfParams), C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]
     L.pf_ctx_destroy.argtypes = [C.c_void_p]
     L.pf_ctx_destroy.restype = None
-    for f in ("pf_state_groups", "pf_obs_dim", "pf_n_lanes"):
+    for f in ("pf_state_groups", "pf_obs_dim", "pf_n_lanes", "pf_ctx_is_specialised"):
         getattr(L, f).argtypes = [C.c_void_p]
     L.pf_env_reset.argtypes = [C.c_void_p, C.POINTER(PfBuffers), C.c_void_p, C.c_void_p]
     L.pf_env_step.argtypes = [C.c_void_p, C.POINTER(PfBuffers), C.c_void_p]

@@ -805,6 +805,7 @@ int pf_obs_dim(const pf_ctx* ctx) {
   return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? 3 * P.num_targets : (P.task == PF_TASK_MA_HOVER ? 3 : 0));
 }
 int pf_n_lanes(const pf_ctx* ctx) { return ctx->n; }
+int pf_ctx_is_specialised(const pf_ctx* ctx) { return ctx->fast ? 1 : ((ctx->fast_fw && ctx->tmpl) ? 2 : 0); }
 
 static int ensure_device(pf_ctx* ctx) {
   int cur = -1;

@@ -2,8 +2,8 @@
 Fixedwing modes, per-lane spawn poses, setpoints that change during the run, Philox motor noise.
 Compared per Aviary step against the fp64 oracle on `state(i)` (4,3) and `aux_state(i)`.
 
-Tolerance: 1e-4 relative (vector-normalised). Every mode must hold it for all lanes over the first
-25 Aviary steps (50 physics ticks). Over the full 120 steps it must hold for >= 99 % of the lanes in
+Tolerance: 1e-4 relative (vector-normalised). Every mode must hold it for EVERY lane over the first
+25 Aviary steps (50 physics ticks). Over the full 120 steps it must hold for every lane in
 the modes whose controller is well conditioned in fp32 (QuadX -1/0, Fixedwing); the cascaded QuadX
 modes that go through the z PIDs amplify fp32 rounding by themselves (z_vel: kd/T = 6 per control
 tick, cf2x.yaml:50-54) -- an fp32 build of the oracle drifts from the fp64 one just as far
@@ -117,10 +117,10 @@ def test_aviary_parity(drone, mode, model):
     med = float(np.median(e))
     print(f"aviary {drone}{'/primitive' if primitive else ''} mode {mode}: worst rel err {worst:.2e}, dropped@{strict_steps} {1 - ok25.mean():.4f}, dropped@{steps} {1 - ok.mean():.4f}, "
           f"median lane err at end {med:.1e}")
-    assert 1 - ok25.mean() <= 0.01
+    assert ok25.all(), f"lanes beyond 1e-4 within the first {strict_steps} Aviary steps: {np.nonzero(~ok25)[0][:8]}"
     assert med < (RTOL if not (primitive and mode > 0) else 0.1)
-    if drone == "fixedwing" or mode in (-1, 0):
-        assert 1 - ok.mean() <= 0.01
+    if drone == "fixedwing" or mode in (-1, 0):  # no z PIDs in the loop: every lane, all 120 steps
+        assert ok.all(), f"lanes beyond 1e-4 over {steps} Aviary steps: {np.nonzero(~ok)[0][:8]}"
     env.disconnect()
 
 

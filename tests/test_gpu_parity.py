@@ -4,12 +4,18 @@ states, action sequences and noise.
 Tolerance (fp32 kernel vs fp64 oracle, per north_star): |gpu - ref| <= RTOL * max(1, ||ref_vec||)
 with RTOL = 1e-4 for every observation element, every step, where ref_vec is the physical vector
 the element belongs to (angular velocity, attitude, velocity, position, action, actuators, each
-body-frame target delta). A lane is dropped from the comparison (and
-counted) from the first step at which it violates that bound or reports different
-terminated/truncated flags: this happens when fp32 rounding flips a discrete event -- the dome /
-floor / waypoint-reach thresholds or a lifting surface's stall branch -- by one inner step, after
-which the two trajectories are no longer comparable point-wise. The dropped fraction must stay
-below `max_bad` = 0.5 % (measured: 0 for every QuadX run, <= 0.2 % for the Fixedwing runs)."""
+body-frame target delta).
+
+Drop policy (strict):
+  * QuadX runs: NO lane may leave the comparison -- every lane must hold the bound and report identical
+    terminated / truncated flags at every step (`max_bad` = 0).
+  * Fixedwing runs (120 s episodes at 20 m/s towards 100 m domes: thousands of steps in which a waypoint-reach
+    or dome crossing can fall within fp32 rounding of a step boundary): a lane may leave the comparison ONLY
+    with a classified cause -- the two sides must show the same discrete event (episode end, target reached)
+    at DIFFERENT steps within +-1 step of the first violation, i.e. fp32 rounding moved a threshold crossing
+    over a step boundary, after which the trajectories are no longer comparable point-wise. A lane that
+    diverges without such an event flip (e.g. a wrong stall branch) fails the test. The classified fraction
+    must still stay below 0.5 %."""
 import numpy as np
 import pytest
 
@@ -65,7 +71,9 @@ QUAD_LOW, QUAD_HIGH = np.array([-np.pi] * 3 + [0.0]), np.array([np.pi] * 3 + [0.
 FW_LOW, FW_HIGH = -np.ones(4), np.ones(4)
 
 
-def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, high, seed=0, gentle=None, max_bad=0.005, **over):
+def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, high, seed=0, gentle=None, max_bad=None, **over):
+    if max_bad is None:
+        max_bad = 0.0 if vehicle == "quadx" else 0.005
     eng = _engine(vehicle, task, n, noise=noise, autoreset=autoreset, seed=seed,
                   **{k: v for k, v in over.items() if k in ("goal_reach_distance", "max_duration_seconds", "angle_representation", "sparse_reward",
                                                              "agent_hz", "num_targets", "flight_dome_size")})
@@ -108,6 +116,8 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
     obs_r = orc.reset(xi_reset=xr, u_targets=ut)
     assert relerr(obs_g, obs_r, G).max() < RTOL, relerr(obs_g, obs_r, G).max()
     ok = np.ones(n, dtype=bool)  # lanes still comparable point-wise
+    first_bad = np.full(n, -1)   # step of the first violation
+    ev_g, ev_r = [], []          # per step: (episode ended, targets left) on each side -- the discrete events
     worst = 0.0
     n_done = 0
     lane_steps = 0
@@ -122,7 +132,13 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
         orr, rr, tr, trr, fin = orc.step(a, xi=xi, xi_reset=xr, u_targets=ut, autoreset=amode)
         e = relerr(og, orr, G).max(axis=1)
         er = np.abs(rg - rr) / np.maximum(1.0, np.abs(rr))
-        ok &= (tg == tr) & (trg == trr) & (e < RTOL) & (er < 1e-3)
+        good = (tg == tr) & (trg == trr) & (e < RTOL) & (er < 1e-3)
+        first_bad[ok & ~good] = k
+        ok &= good
+        nl_g = eng.ints()[:, 3].cpu().numpy().copy() if nt else np.zeros(n, dtype=np.int32)
+        nl_r = orc.field("n_targets_left") if nt else np.zeros(n, dtype=np.int32)
+        ev_g.append(np.stack([(tg | trg).astype(np.int32), nl_g], axis=1))
+        ev_r.append(np.stack([(tr | trr).astype(np.int32), nl_r], axis=1))
         if ok.any():
             worst = max(worst, e[ok].max())
         lane_steps += int(ok.sum())
@@ -149,8 +165,18 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
                 if sel.any():
                     assert relerr(obs_g[sel], obs_r[sel], G).max() < RTOL
     frac_bad = 1.0 - ok.mean()
+    # classify every dropped lane: the same discrete event on both sides at different steps within +-1 step
+    ev_g, ev_r = np.stack(ev_g), np.stack(ev_r)  # [steps, n, 2]
+    unexplained = []
+    for i in np.nonzero(~ok)[0]:
+        k0 = int(first_bad[i])
+        lo, hi = max(0, k0 - 1), min(steps, k0 + 2)
+        flipped = (ev_g[lo:hi, i] != ev_r[lo:hi, i]).any()
+        if not flipped:
+            unexplained.append((int(i), k0))
     print(f"{vehicle}/{task} noise={noise} autoreset={autoreset}: worst rel err {worst:.2e} over {lane_steps} lane-steps, "
-          f"dropped lanes {frac_bad:.4f}, episodes ended {n_done}")
+          f"dropped lanes {frac_bad:.4f} ({int((~ok).sum())} of {n}; without an event flip: {len(unexplained)}), episodes ended {n_done}")
+    assert not unexplained, f"lanes left the comparison without a discrete-event flip: {unexplained[:8]}"
     assert frac_bad <= max_bad, frac_bad
     assert n_final_bad <= max(1, int(max_bad * n_final)), (n_final_bad, n_final)
     return worst, n_done

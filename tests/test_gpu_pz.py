@@ -33,7 +33,7 @@ def test_ma_hover_parity_and_api(monkeypatch, kernel):
             lib.orc_env_reset(C.byref(Ps[i]), C.byref(lanes[e][i]), e * A + i, None, None)
     ref = np.array([[np.frombuffer(lanes[e][i].obs, dtype=np.float64, count=24) for i in range(A)] for e in range(E)])
     got = np.stack([obs[a].cpu().numpy() for a in env.possible_agents], axis=1)
-    assert got.shape == (E, A, 24) and np.abs(got - ref).max() < 1e-4
+    assert got.shape == (E, A, 24) and np.abs(got - ref).max() < 1e-5
     rng = np.random.default_rng(0)
     worst, done_seen = 0.0, 0
     for k in range(45):
@@ -52,15 +52,20 @@ def test_ma_hover_parity_and_api(monkeypatch, kernel):
             ref_r = np.array([lanes[e][i].reward for e in range(E)])
             ref_t = np.array([bool(lanes[e][i].terminated) for e in range(E)])
             ref_u = np.array([bool(lanes[e][i].truncated) for e in range(E)])
-            same = (t[a].cpu().numpy() == ref_t) & (u[a].cpu().numpy() == ref_u)
-            assert same.mean() > 0.98
-            err = np.abs(o[a].cpu().numpy() - ref_o)[same].max()
+            # strict: identical flags for every copy of every agent at every step; observation within 1e-4 of
+            # each physical vector's magnitude; reward within 1e-4 relative (it carries -100 penalties)
+            assert (t[a].cpu().numpy() == ref_t).all() and (u[a].cpu().numpy() == ref_u).all(), (k, a)
+            got_o = o[a].cpu().numpy().astype(np.float64)
+            err = 0.0
+            for lo, hi in ((0, 3), (3, 7), (7, 10), (10, 13), (13, 17), (17, 21), (21, 24)):
+                scale = np.maximum(1.0, np.linalg.norm(ref_o[:, lo:hi], axis=1, keepdims=True))
+                err = max(err, float((np.abs(got_o[:, lo:hi] - ref_o[:, lo:hi]) / scale).max()))
             worst = max(worst, err)
-            assert np.abs(r[a].cpu().numpy() - ref_r)[same].max() < 2e-3
+            assert (np.abs(r[a].cpu().numpy() - ref_r) / np.maximum(1.0, np.abs(ref_r))).max() < 1e-4
             assert env.observation_space(a).shape == (24,) and torch.isfinite(o[a]).all()
             done_seen += int((ref_t | ref_u).sum())
     print(f"ma hover: worst obs err {worst:.2e}, episodes ended {done_seen}")
-    assert worst < 1e-3 and done_seen > 0
+    assert worst < 1e-4 and done_seen > 0
     env.close()
 
 

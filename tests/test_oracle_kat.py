@@ -1,0 +1,177 @@
+"""Analytic known-answer tests of the fp64 oracle's Bullet restatement (rows 10-12 of SURVEY.md 8(a)):
+closed forms from tests/kat.py, no second restatement in the loop. CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import kat
+from oracle import oracle as O
+
+
+def dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def tick(P, p, q, v, w, F=(0, 0, 0), tau=(0, 0, 0), n=1):
+    F, tau = np.array(F, dtype=np.float64), np.array(tau, dtype=np.float64)
+    for _ in range(n):
+        O.lib().orc_rigid_tick(C.byref(P), dp(p), dp(q), dp(v), dp(w), dp(F), dp(tau))
+
+
+def fresh(z=10.0):
+    return np.array([0.0, 0.0, z]), np.array([0.0, 0.0, 0.0, 1.0]), np.zeros(3), np.zeros(3)
+
+
+def test_free_fall_closed_form():
+    P = O.make_params("quadx")
+    p, q, v, w = fresh(50.0)
+    for n in range(1, 401):
+        tick(P, p, q, v, w)
+        z, vz = kat.free_fall_z(50.0, n)
+        assert abs(p[2] - z) < 1e-11 and abs(v[2] - vz) < 1e-12, n
+    assert p[0] == 0.0 and p[1] == 0.0 and np.array_equal(q, [0, 0, 0, 1]) and not w.any()
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_constant_principal_axis_torque(axis):
+    """w_n = n dt tau / I and the rotation angle dt^2 tau / I n (n + 1) / 2 about the same axis."""
+    P = O.make_params("quadx", world_gravity_z=0.0)
+    p, q, v, w = fresh()
+    tau = np.zeros(3)
+    tau[axis] = 2.0e-5
+    for n in range(1, 101):
+        tick(P, p, q, v, w, tau=tau)
+        wn, th = kat.const_torque_principal(2.0e-5, axis, n)
+        assert abs(w[axis] - wn) < 1e-10 * max(1.0, abs(wn)), n
+        assert abs(np.delete(w, axis)).max() < 1e-13
+        # q = (axis sin(th/2), cos(th/2))
+        assert abs(q[axis] - np.sin(th / 2)) < 1e-9 and abs(q[3] - np.cos(th / 2)) < 1e-9, (n, th)
+        assert abs(np.linalg.norm(q) - 1.0) < 1e-14
+    assert not p[:2].any() and p[2] == 10.0  # no force, no gravity: the body stays put
+
+
+@pytest.mark.parametrize("gyro", [1, 0])
+def test_torque_free_principal_spin_is_stationary(gyro):
+    """Torque-free spin about a principal axis: w x I w = 0, so w is constant with the gyroscopic term on and off."""
+    P = O.make_params("quadx", world_gravity_z=0.0, world_use_gyro_term=gyro)
+    for axis in range(3):
+        p, q, v, w = fresh()
+        w[axis] = 7.0
+        tick(P, p, q, v, w, n=500)
+        e = np.zeros(3)
+        e[axis] = 7.0
+        assert np.abs(w - e).max() < 1e-12
+        th = 7.0 * kat.DT * 500
+        assert abs(abs(q[3]) - abs(np.cos(th / 2))) < 1e-9
+
+
+def test_gyroscopic_term_conserves_angular_momentum_direction():
+    """A spin off the principal axes: with the term on, the world-frame angular momentum R I w_b keeps its
+    direction and magnitude to first order in dt (explicit Euler drift only); with it off, w_world is constant."""
+    on = O.make_params("quadx", world_gravity_z=0.0, world_use_gyro_term=1)
+    off = O.make_params("quadx", world_gravity_z=0.0, world_use_gyro_term=0)
+    w0 = np.array([3.0, -2.0, 5.0])
+    p, q, v, w = fresh()
+    w[:] = w0
+    L0 = kat.I_DIAG * w0  # R = 1 at the start
+    for _ in range(240):
+        tick(on, p, q, v, w)
+    R = np.zeros((3, 3))
+    O.lib().orc_matrix_from_quat(dp(q), dp(R))
+    L1 = R @ (kat.I_DIAG * (R.T @ w))
+    assert np.linalg.norm(L1 - L0) / np.linalg.norm(L0) < 2e-2
+    assert np.abs(w - w0).max() > 0.1  # the body axis precesses: w itself does change
+    p, q, v, w = fresh()
+    w[:] = w0
+    tick(off, p, q, v, w, n=240)
+    assert np.array_equal(w, w0)
+
+
+def test_velocity_clamp():
+    """+-100 per base-velocity coordinate (btMultiBody::m_maxCoordinateVelocity, applyDeltaVee)."""
+    P = O.make_params("quadx", world_gravity_z=0.0)
+    p, q, v, w = fresh()
+    tick(P, p, q, v, w, F=(1e3, -1e3, 2e3), tau=(1.0, -1.0, 0.5), n=5)
+    assert np.array_equal(np.abs(v), [kat.VMAX] * 3) and np.array_equal(np.abs(w), [kat.VMAX] * 3)
+    # positions move with the clamped velocity
+    p0 = p.copy()
+    tick(P, p, q, v, w, F=(1e3, -1e3, 2e3), tau=(1.0, -1.0, 0.5))
+    np.testing.assert_allclose(p - p0, kat.DT * v, atol=1e-12)
+    assert abs(np.linalg.norm(q) - 1.0) < 1e-14
+
+
+def test_euler_quat_round_trip_and_gimbal_branch():
+    rng = np.random.default_rng(0)
+    lib = O.lib()
+    for _ in range(200):  # away from the branch: exact round trip
+        rpy = rng.uniform([-3.1, -1.5, -3.1], [3.1, 1.5, 3.1])
+        q, back = np.zeros(4), np.zeros(3)
+        lib.orc_quat_from_euler(dp(rpy), dp(q))
+        assert abs(np.linalg.norm(q) - 1.0) < 1e-15
+        lib.orc_euler_from_quat(dp(q), dp(back))
+        np.testing.assert_allclose(back, rpy, atol=1e-12)
+    for sign in (1.0, -1.0):  # |sarg| >= 0.99999: roll = 0, pitch = +-pi/2, yaw = yaw -+ roll
+        for _ in range(50):
+            roll, yaw = rng.uniform(-1.5, 1.5, size=2)
+            for pitch in (sign * np.pi / 2, sign * (np.pi / 2 - 1e-3)):  # sin(pi/2 - 1e-3) = 0.9999995 >= 0.99999
+                rpy = np.array([roll, pitch, yaw])
+                q, back = np.zeros(4), np.zeros(3)
+                lib.orc_quat_from_euler(dp(rpy), dp(q))
+                lib.orc_euler_from_quat(dp(q), dp(back))
+                assert back[0] == 0.0 and back[1] == sign * np.pi / 2
+                assert abs(back[2] - kat.gimbal_yaw(roll, yaw, sign)) < 2.5e-3  # (1e-3 off the pole: yaw mixes in O(1e-3))
+        # just outside the branch the regular formulas apply
+        rpy = np.array([0.3, sign * (np.pi / 2 - 1e-2), -0.4])
+        q, back = np.zeros(4), np.zeros(3)
+        lib.orc_quat_from_euler(dp(rpy), dp(q))
+        lib.orc_euler_from_quat(dp(q), dp(back))
+        np.testing.assert_allclose(back, rpy, atol=1e-9)
+
+
+def test_matrix_from_denormalised_quaternion():
+    """btMatrix3x3::setRotation divides by |q|^2: a scaled quaternion gives the same rotation."""
+    rng = np.random.default_rng(1)
+    q = rng.normal(size=4)
+    R1, R2 = np.zeros((3, 3)), np.zeros((3, 3))
+    O.lib().orc_matrix_from_quat(dp(q / np.linalg.norm(q)), dp(R1))
+    O.lib().orc_matrix_from_quat(dp(q * 1.37), dp(R2))
+    np.testing.assert_allclose(R1, R2, atol=1e-14)
+    np.testing.assert_allclose(R1 @ R1.T, np.eye(3), atol=1e-14)
+
+
+def _lane(P, mode, pos=(0, 0, 5.0)):
+    L = O.Lane()
+    O.lib().orc_aviary_reset(C.byref(P), C.byref(L), 0)
+    O.lib().orc_set_mode(C.byref(P), C.byref(L), mode)
+    return L
+
+
+def test_motor_lag_closed_form():
+    """Mode -1 (raw pwm), noise off: throttle_n = p (1 - (1 - dt/tau)^n) tick by tick."""
+    P = O.make_params("quadx", noise_mode=O.NOISE_OFF, start_pos=[0, 0, 5.0])
+    L = _lane(P, -1)
+    pwm = [0.3, 0.5, 0.7, 0.9]
+    for i, x in enumerate(pwm):
+        L.setpoint[i] = x
+    for s in range(1, 21):
+        O.lib().orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+        np.testing.assert_allclose(list(L.throttle), kat.motor_lag(np.array(pwm), 2 * s), rtol=1e-13)
+
+
+def test_hover_equilibrium_throttle():
+    """throttle^2 = m g / total_thrust = 0.132435: thrust balances gravity (noise off, level)."""
+    assert abs(kat.HOVER_THROTTLE_SQ - 0.132435) < 1e-12
+    P = O.make_params("quadx", noise_mode=O.NOISE_OFF, start_pos=[0, 0, 5.0])
+    L = _lane(P, -1)
+    for i in range(4):
+        L.setpoint[i] = np.sqrt(kat.HOVER_THROTTLE_SQ)
+    for _ in range(40):  # the first-order lag converges: (1 - 0.41667)^80 ~ 2e-19
+        O.lib().orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+    vz = L.v[2]
+    for _ in range(60):
+        O.lib().orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
+    # only the body drag 7.35e-4 v^2 / m acts on the residual sink rate picked up during the spin-up
+    drag_acc = 7.35e-4 * vz * vz / kat.MASS
+    assert abs((L.v[2] - vz) - drag_acc * 120 * kat.DT) < 0.05 * drag_acc * 120 * kat.DT + 1e-12
+    assert abs(L.w[0]) + abs(L.w[1]) + abs(L.w[2]) < 1e-15 and abs(L.p[0]) + abs(L.p[1]) < 1e-15

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""capture_pybullet.py -- record Aviary-level trajectories from the REAL reference stack (PyFlyt + pybullet).
+
+RUN ON A MACHINE THAT HAS THE REFERENCE INSTALLED (`pip install PyFlyt pybullet`; neither exists in the
+build container or on the GPU boxes, which is why the Bullet boundary is "parity unpinned"):
+
+    python tests/golden/capture_pybullet.py            # writes tests/golden/pybullet/*.npz
+    python -m pytest tests/test_pybullet_capture.py    # oracle (CPU) and, with -m gpu, the HIP path against them
+
+What it records: for every case of tests/golden/gen_goldens.py's Aviary set (all 9 QuadX flight modes, both
+Fixedwing modes, primitive_drone, acrowing, Rocket, the three floor drops) the per-Aviary-step
+`state(0)` (4,3), `aux_state(0)`, the setpoints applied, and `contact_array.any()`, with the SAME spawn poses and
+the SAME setpoint schedule as the committed fixtures -- but on real Bullet and with the motor noise forced to
+zero (the generator's `normal()` returns 0), so that a difference can only come from the physics engine.
+Files have the layout of tests/golden/aviary_*.npz (`noise` = False), plus provenance (`pybullet_api`,
+`pyflyt_version`, `numpy_version`) and the Bullet facts our restatement had to assume (`bullet_facts`, JSON):
+the plane's collision shape, engine parameters, the dynamics info of the spawned bodies.
+
+This script only IMPORTS the installed reference packages and calls their public API; it contains none of
+their source. The files it writes are data (inputs + outputs)."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "pybullet")
+
+
+class ZeroNoiseRNG:
+    """np.random.Generator stand-in handed to Aviary(np_random=...): normal() -> 0 (no motor / booster noise,
+    motors.py:134-138, boosters.py:230-233), everything else from a seeded generator."""
+
+    def __init__(self, seed):
+        self._g = np.random.default_rng(seed)
+
+    def normal(self, *a, **k):
+        return 0.0
+
+    def __getattr__(self, name):
+        return getattr(self._g, name)
+
+
+def setpoint_schedule(drone_type, mode, rng, sp_dim):
+    """The setpoint drawn at steps k % 25 == 10 -- identical to gen_goldens.run_aviary."""
+    if drone_type == "quadx":
+        if mode == -1:
+            return rng.uniform(0.1, 0.6, size=4)
+        if mode == 0:
+            return np.array([*rng.uniform(-1.0, 1.0, size=3), rng.uniform(0.2, 0.6)])
+        if mode == 1:
+            return np.array([*rng.uniform(-0.4, 0.4, size=3), rng.uniform(-0.5, 0.5)])
+        if mode == 2:
+            return np.array([*rng.uniform(-0.5, 0.5, size=3), rng.uniform(0.5, 2.0)])
+        if mode == 3:
+            return np.array([*rng.uniform(-0.3, 0.3, size=3), rng.uniform(0.5, 2.0)])
+        if mode == 4:
+            return np.array([*rng.uniform(-1.0, 1.0, size=2), rng.uniform(-0.5, 0.5), rng.uniform(0.5, 2.0)])
+        if mode in (5, 6):
+            return np.array([*rng.uniform(-1.0, 1.0, size=2), rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5)])
+        return np.array([*rng.uniform(-2.0, 2.0, size=2), rng.uniform(-1.0, 1.0), rng.uniform(0.5, 2.5)])
+    if drone_type == "rocket":
+        return np.concatenate([rng.uniform(-0.6, 0.6, size=3), [float(rng.random() < 0.8)], rng.uniform(0.0, 1.0, size=1),
+                               rng.uniform(-1.0, 1.0, size=2)])
+    sp = rng.uniform(-1.0, 1.0, size=sp_dim)
+    sp[-1] = rng.uniform(0.0, 1.0)
+    return sp
+
+
+def bullet_facts(env):
+    """Everything about the Bullet world our restatement treats as a named parameter."""
+    facts = {}
+    try:
+        facts["engine"] = {k: (v if isinstance(v, (int, float, str)) else list(v)) for k, v in env.getPhysicsEngineParameters().items()}
+    except Exception as e:  # pragma: no cover
+        facts["engine_error"] = repr(e)
+    try:
+        plane = env.planeId
+        facts["plane_collision_shape"] = [list(map(lambda x: x if isinstance(x, (int, float, str, bytes)) else list(x), s))
+                                          for s in env.getCollisionShapeData(plane, -1)]
+        facts["plane_dynamics"] = list(map(lambda x: x if isinstance(x, (int, float)) else list(x), env.getDynamicsInfo(plane, -1)))
+    except Exception as e:  # pragma: no cover
+        facts["plane_error"] = repr(e)
+    try:
+        d = env.drones[0]
+        n_links = env.getNumJoints(d.Id)
+        facts["body_dynamics"] = {str(l): list(map(lambda x: x if isinstance(x, (int, float)) else list(x), env.getDynamicsInfo(d.Id, l)))
+                                  for l in range(-1, n_links)}
+    except Exception as e:  # pragma: no cover
+        facts["body_error"] = repr(e)
+    return json.dumps(facts, default=lambda o: o.decode() if isinstance(o, bytes) else str(o))
+
+
+def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, drone_options=None):
+    from PyFlyt.core import Aviary
+
+    env = Aviary(start_pos=np.array([start_pos], dtype=np.float64), start_orn=np.array([start_orn], dtype=np.float64),
+                 drone_type=drone_type, render=False, np_random=ZeroNoiseRNG(seed), drone_options=drone_options or {})
+    env.set_mode(mode)
+    rng = np.random.default_rng(seed + 1000)
+    sp_dim = 7 if drone_type == "rocket" else (4 if not (drone_type == "fixedwing" and mode == -1) else 6)
+    states, auxs, sps, contacts = [], [], [], []
+    init_state, init_aux, init_sp = env.state(0).copy(), env.aux_state(0).copy(), np.array(env.drones[0].setpoint, dtype=np.float64).copy()
+    facts = bullet_facts(env)
+    for k in range(n_steps):
+        if k % 25 == 10:
+            env.set_setpoint(0, setpoint_schedule(drone_type, mode, rng, sp_dim).copy())
+        env.step()
+        states.append(env.state(0).copy())
+        auxs.append(env.aux_state(0).copy())
+        sps.append(np.array(env.drones[0].setpoint, dtype=np.float64).copy())
+        contacts.append(bool(np.any(env.contact_array)))
+    env.disconnect()
+    return dict(states=np.array(states), aux=np.array(auxs), setpoints=np.array(sps), xi=np.full((n_steps, 2), np.nan),
+                contact=np.array(contacts), init_state=init_state, init_aux=init_aux, init_setpoint=init_sp, mode=mode,
+                start_pos=np.array(start_pos, dtype=np.float64), start_orn=np.array(start_orn, dtype=np.float64), noise=False,
+                bullet_facts=facts)
+
+
+# (file stem, drone_type, mode, steps, seed, start_pos, start_orn, drone_options) -- the cases of gen_goldens.py
+CASES = (
+    [(f"aviary_quadx_mode{m}".replace("-1", "m1"), "quadx", m, 200, 100 + m, [0.3, -0.2, 1.5], [0.05, -0.08, 0.6], None) for m in range(-1, 8)]
+    + [("aviary_quadx_drop", "quadx", 0, 150, 3, [0.0, 0.0, 0.15], [0.3, 0.2, 0.0], None)]
+    + [(f"aviary_fixedwing_mode{m}".replace("-1", "m1"), "fixedwing", m, 200, 200 + m, [0.0, 0.0, 10.0], [0.02, 0.05, -0.3], None) for m in (0, -1)]
+    + [(f"aviary_primitive_mode{m}", "quadx", m, 150, 300 + m, [0.3, -0.2, 1.5], [0.05, -0.08, 0.6], dict(drone_model="primitive_drone")) for m in (0, 6, 7)]
+    + [("aviary_primitive_drop", "quadx", 0, 120, 5, [0.0, 0.0, 0.30], [0.5, 0.2, 0.0], dict(drone_model="primitive_drone"))]
+    + [(f"aviary_acrowing_mode{m}".replace("-1", "m1"), "fixedwing", m, 200, 600 + m, [0.0, 0.0, 30.0], [0.02, 0.05, -0.3], dict(drone_model="acrowing")) for m in (0, -1)]
+    + [("aviary_rocket_default_fuel", "rocket", 0, 200, 500, [0.0, 0.0, 80.0], [0.05, 0.02, 0.3], None),
+       ("aviary_rocket_fuel60", "rocket", 0, 300, 501, [1.0, -2.0, 200.0], [-0.1, 0.15, -1.0], dict(starting_fuel_ratio=0.6)),
+       ("aviary_rocket_drop", "rocket", 0, 150, 502, [0.0, 0.0, 4.0], [0.4, 0.1, 0.0], dict(starting_fuel_ratio=0.0))]
+)
+
+
+def main():
+    try:
+        import pybullet
+        import PyFlyt
+    except ImportError as e:
+        sys.exit(f"capture_pybullet.py needs the real reference stack (pip install PyFlyt pybullet): {e}")
+    os.makedirs(OUT, exist_ok=True)
+    prov = dict(pybullet_api=int(pybullet.getAPIVersion()), pyflyt_version=str(getattr(PyFlyt, "__version__", "?")),
+                numpy_version=np.__version__)
+    for name, drone, mode, steps, seed, pos, orn, opts in CASES:
+        d = run_aviary(drone, mode, steps, seed, pos, orn, opts)
+        d.update(prov)
+        if drone == "rocket":
+            d["starting_fuel_ratio"] = float((opts or {}).get("starting_fuel_ratio", 0.05))
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
+        print(f"wrote {path}: {steps} Aviary steps, first contact at {int(np.argmax(d['contact'])) if d['contact'].any() else None}")
+
+
+if __name__ == "__main__":
+    main()

@@ -151,11 +151,11 @@ struct FwHot {
   bool contact_now, contact_step;
 
   PF_DEV void derive() {  // unit quaternion (quat_integrate / the settled template): scale 2
-    float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
-    float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
-    float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
-    float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
-    R = m3{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+    const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
+    const float xy = q.x * ys, xz = q.x * zs, yz = q.y * zs;
+    const float dx = fmaf(-q.x, xs, 1.0f), dy = fmaf(-q.y, ys, 1.0f);  // 1 - xx, 1 - yy
+    R = m3{fmaf(-q.z, zs, dy), fmaf(-q.w, zs, xy), fmaf(q.w, ys, xz), fmaf(q.w, zs, xy), fmaf(-q.z, zs, dx), fmaf(-q.w, xs, yz),
+           fmaf(-q.w, ys, xz), fmaf(q.w, xs, yz), fmaf(-q.y, ys, dx)};
     wb = mulT(R, w);
     vb = mulT(R, v);
   }
@@ -165,9 +165,9 @@ struct FwHot {
   // torque about the base origin).
   template <bool LIFT_Y>
   PF_DEV void surface(const FwSurf S, const float a, v3& F, v3& tau) const {
-    const float vx = vb.x + (wb.y * S.rz - wb.z * S.ry);
-    const float vy = vb.y + (wb.z * S.rx - wb.x * S.rz);
-    const float vz = vb.z + (wb.x * S.ry - wb.y * S.rx);
+    const float vx = fmaf(wb.y, S.rz, fmaf(-wb.z, S.ry, vb.x));
+    const float vy = fmaf(wb.z, S.rx, fmaf(-wb.x, S.rz, vb.y));
+    const float vz = fmaf(wb.x, S.ry, fmaf(-wb.y, S.rx, vb.z));
     const float V2 = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
     const float la = LIFT_Y ? vy : vz, fa = vx;
     const float h2 = fmaf(la, la, fa * fa);
@@ -197,38 +197,38 @@ struct FwHot {
     const float ae = alpha - x;
     float sx, cx;
     sincos_small(x, sx, cx);
-    const float se = sa * cx - ca * sx, ce = fmaf(ca, cx, sa * sx);
+    const float se = fmaf(sa, cx, -(ca * sx)), ce = fmaf(ca, cx, sa * sx);
     // :397-406
     float CT = S.cd0 * ce;
-    float CN = (Cl_lin + CT * se) * frcp(ce);
+    float CN = fmaf(CT, se, Cl_lin) * frcp(ce);
     float Cl = Cl_lin;
     float Cd = fmaf(CN, se, CT * ce);
-    float CM = -CN * (0.25f - 0.175f * (1.0f - (2.0f / kPi) * ae));
+    float CM = -CN * fmaf(0.175f * (2.0f / kPi), ae, 0.075f);  // 0.25 - 0.175 (1 - 2 ae / pi)
     if (any_stall) {  // :427-448
       const float Cd90 = fmaf(-4.26e-2f, defl * defl, fmaf(2.1e-1f, defl, 1.98f));
       const float CNs = Cd90 * se * (frcp(fmaf(0.44f, __builtin_fabsf(se), 0.56f)) - S.exp_term);
       const float CTs = 0.5f * S.cd0 * ce;
-      const float Cls = CNs * ce - CTs * se;
+      const float Cls = fmaf(CNs, ce, -(CTs * se));
       const float Cds = fmaf(CNs, se, CTs * ce);
-      const float CMs = -CNs * (0.25f - 0.175f * (1.0f - (2.0f / kPi) * __builtin_fabsf(ae)));
+      const float CMs = -CNs * fmaf(0.175f * (2.0f / kPi), __builtin_fabsf(ae), 0.075f);
       Cl = linear ? Cl : Cls; Cd = linear ? Cd : Cds; CM = linear ? CM : CMs;
     }
     // :485-498
     const float QA = S.hra * V2;
     const float L = Cl * QA, D = Cd * QA;
-    const float fn = fmaf(L, ca, D * sa), fp = L * sa - D * ca;  // along the lift unit / along +x
+    const float fn = fmaf(L, ca, D * sa), fp = fmaf(L, sa, -(D * ca));  // along the lift unit / along +x
     const float tm = QA * CM * S.chord;
     F.x += fp;
     if (LIFT_Y) {
       F.y += fn;
-      tau.x -= S.rz * fn;
-      tau.y += S.rz * fp;
-      tau.z += fmaf(S.rx, fn, -S.ry * fp) - tm;
+      tau.x = fmaf(-S.rz, fn, tau.x);
+      tau.y = fmaf(S.rz, fp, tau.y);
+      tau.z += fmaf(S.rx, fn, fmaf(-S.ry, fp, -tm));
     } else {
       F.z += fn;
-      tau.x += S.ry * fn;
-      tau.y += fmaf(S.rz, fp, -S.rx * fn) + tm;
-      tau.z -= S.ry * fp;
+      tau.x = fmaf(S.ry, fn, tau.x);
+      tau.y += fmaf(S.rz, fp, fmaf(-S.rx, fn, tm));
+      tau.z = fmaf(-S.ry, fp, tau.z);
     }
   }
   // one physics tick: update_physics (fixedwing.py:261-264) + stepSimulation + update_state (:266-291)
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
       half_angle(br * hr, ar * hr, cr, sr);
       half_angle(fsqrt((1.0f - sarg) * (1.0f + sarg)), sarg, cp, sp);
       half_angle(by * hy, ay * hy, cy, sy);
-      quat t{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+      quat t = quat_from_half_angles(cr, sr, cp, sp, cy, sy);
       float inv = frsq(fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w))));
       qe = quat{t.x * inv, t.y * inv, t.z * inv, t.w * inv};
       if (!K.angle_repr) rpy = v3{fast_atan2(ar, br), fast_asin(sarg), fast_atan2(ay, by)};
@@ -460,16 +460,7 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
       const int rows = min(64, n - wave_base);
       const int total = rows * D;
       float* g = out + (size_t)wave_base * D;
-      const int n4 = total >> 2;
-      const float4* t4 = reinterpret_cast<const float4*>(tile);
-      for (int i = tid; i < n4; i += 64) {
-        float4 t = t4[i];
-        __builtin_nontemporal_store(t.x, &g[4 * i + 0]);
-        __builtin_nontemporal_store(t.y, &g[4 * i + 1]);
-        __builtin_nontemporal_store(t.z, &g[4 * i + 2]);
-        __builtin_nontemporal_store(t.w, &g[4 * i + 3]);
-      }
-      for (int i = (n4 << 2) + tid; i < total; i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
+      stream_tile(tile, g, total, tid);
     } else if (active) {
       float* g = out + (size_t)lane * D;
       const float* row = tile + tid * D;

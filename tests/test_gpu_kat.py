@@ -217,7 +217,8 @@ def test_hover_equilibrium_throttle():
     # thrust balances gravity to fp32 rounding of 4 * 0.5 N * thr^2 / m vs 9.81 (~1e-6 m/s^2 -> 5e-7 m/s over 120 ticks)
     assert np.abs((vz1 - vz0) - drag_acc * 120 * kat.DT).max() < 2e-5
     s = env.engine.state
-    assert float(s[2, :, 3].abs().max() + s[3, :, :2].abs().max()) == 0.0 and float(s[0, :, :2].abs().max()) == 0.0
+    # (the four equal thrusts cancel every torque exactly in exact arithmetic; in fp32 the arm sum r_y f rounds to ~1e-7 relative)
+    assert float(s[2, :, 3].abs().max() + s[3, :, :2].abs().max()) < 1e-5 and float(s[0, :, :2].abs().max()) < 1e-5
     env.disconnect()
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 3
+#define PF_ABI_VERSION 4
 #define PF_MAX_TARGETS 8
 #define PF_MAX_BOXES 12
 #define PF_MAX_SURF 5
@@ -139,6 +139,11 @@ typedef struct pf_params {
   float start_pos[3], start_quat[4], start_vel[3];
   float dome, goal_reach_distance, min_height;
   float wp_dist_reward, wp_yaw_penalty;
+  /* QuadX-Waypoints yaw targets (quadx_waypoints_env.py:40-42, waypoint_handler.py:85-89,144-156,167-179): one more
+   * uniform per target at reset (drawn after all the positions), target deltas 4 wide (body-frame delta + wrapped
+   * yaw error), a target counts as reached only when the yaw error is under goal_reach_angle as well */
+  int32_t use_yaw_targets;
+  float goal_reach_angle;
   float action_low[4], action_high[4]; /* action space box (quadx_base_env.py:80-102) */
   pf_rocket rocket;
 } pf_params;
@@ -154,7 +159,7 @@ typedef struct pf_buffers {
   uint8_t* truncated;      /* [n] */
   const float* xi;         /* PF_NOISE_INJECT: [env_step_ratio*ticks_per_control][n] raw motor-noise draws */
   const float* xi_reset;   /* PF_NOISE_INJECT: [settle_steps*ticks_per_control][n] */
-  const float* u_targets;  /* PF_NOISE_INJECT, waypoint tasks: [3*num_targets][n] theta|phi|dist draws */
+  const float* u_targets;  /* PF_NOISE_INJECT, waypoint tasks: [3*num_targets][n] theta|phi|dist draws (+ [num_targets][n] yaw with use_yaw_targets) */
   /* Aviary-level calls only */
   const float* setpoints;  /* [n][4] (quadx, fixedwing mode 0), [n][6] (fixedwing mode -1) or [n][7] (rocket) */
   float* out_state;        /* [n][12]: ang_vel, ang_pos, lin_vel, lin_pos rows of Aviary.state(i) */

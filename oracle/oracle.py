@@ -69,6 +69,7 @@ class Params(C.Structure):
         ("num_targets", C.c_int), ("goal_reach_distance", C.c_double), ("min_height", C.c_double),
         ("throttle_remap", C.c_double), ("collide_any", C.c_int),
         ("wp_dist_reward", C.c_double), ("wp_yaw_penalty", C.c_double),
+        ("use_yaw_targets", C.c_int), ("goal_reach_angle", C.c_double),
         ("noise_mode", C.c_int), ("seed", C.c_uint64),
         ("n_links", C.c_int), ("link_mass", C.c_double * MAX_LINKS), ("link_r", d3 * MAX_LINKS), ("link_I", d3 * MAX_LINKS),
         ("fueltank_link", C.c_int), ("booster_link", C.c_int),
@@ -117,7 +118,8 @@ class Lane(C.Structure):
         ("info_oob", C.c_int), ("info_collision", C.c_int), ("info_complete", C.c_int),
         ("num_targets_reached", C.c_int),
         ("reward", C.c_double), ("action", C.c_double * 4), ("past_action", C.c_double * 4),
-        ("targets", d3 * MAX_TARGETS), ("n_targets_left", C.c_int),
+        ("targets", d3 * MAX_TARGETS), ("yaw_targets", C.c_double * MAX_TARGETS), ("yaw_error_scalar", C.c_double),
+        ("n_targets_left", C.c_int),
         ("new_dist", C.c_double), ("old_dist", C.c_double),
         ("obs", C.c_double * 48),
         ("rng_ctr", C.c_uint32), ("lane_id", C.c_uint64),

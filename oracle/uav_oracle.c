@@ -753,6 +753,7 @@ void orc_task_quadx_waypoints(orc_params* P) { /* quadx_waypoints_env.py:38-47,8
   P->sparse_reward = 0; P->angle_repr = 1; P->num_targets = 4; P->goal_reach_distance = 0.2;
   P->min_height = 0.1; P->collide_any = 0; P->throttle_remap = 0;
   P->wp_dist_reward = 0.1; P->wp_yaw_penalty = 0.01;
+  P->use_yaw_targets = 0; P->goal_reach_angle = 0.1; /* quadx_waypoints_env.py:40,42 */
 }
 void orc_task_fixedwing_waypoints(orc_params* P) { /* fixedwing_waypoints_env.py:36-45,63,81 */
   P->task = ORC_TASK_WAYPOINTS;
@@ -761,6 +762,7 @@ void orc_task_fixedwing_waypoints(orc_params* P) { /* fixedwing_waypoints_env.py
   P->sparse_reward = 0; P->angle_repr = 1; P->num_targets = 4; P->goal_reach_distance = 2.0;
   P->min_height = 0.5; P->collide_any = 1; P->throttle_remap = 1;
   P->wp_dist_reward = 1.0; P->wp_yaw_penalty = 0.0;
+  P->use_yaw_targets = 0; P->goal_reach_angle = INFINITY; /* fixedwing_waypoints_env.py:77-79 */
 }
 
 void orc_task_ma_hover(orc_params* P) { /* pz_envs/quadx_envs/ma_quadx_hover_env.py:36-52 */
@@ -1079,22 +1081,34 @@ static void sample_targets(const orc_params* P, orc_lane* L, const double* u_inj
     double x = dist * sin(phi) * cos(theta), y = dist * sin(phi) * sin(theta), z = fabs(dist * cos(phi));
     L->targets[i][0] = x; L->targets[i][1] = y; L->targets[i][2] = z > P->min_height ? z : P->min_height;
   }
+  if (P->use_yaw_targets) { /* waypoint_handler.py:85-89: drawn after all the positions */
+    for (int i = 0; i < n; ++i)
+      L->yaw_targets[i] = u_inj ? u_inj[3 * n + i] : -PI + (2.0 * PI) * lane_uniform(P, L, (uint32_t)(3 * n + i), 2);
+  }
+  L->yaw_error_scalar = 0.0;
 }
-/* waypoint_handler.py:117-158: distance_to_targets (no yaw targets) */
-static void compute_deltas(const orc_params* P, orc_lane* L, double deltas[][3]) {
+/* waypoint_handler.py:117-158: distance_to_targets; column 3 = yaw error when use_yaw_targets (:144-156) */
+static void compute_deltas(const orc_params* P, orc_lane* L, double deltas[][4]) {
   double qe[4], R[3][3];
   orc_quat_from_euler(L->rpy, qe); /* quadx_base_env.py:243 */
   orc_matrix_from_quat(qe, R);
   for (int i = 0; i < L->n_targets_left; ++i) {
     double d[3] = {L->targets[i][0] - L->p[0], L->targets[i][1] - L->p[1], L->targets[i][2] - L->p[2]};
     matTvec(R, d, deltas[i]); /* row-vector @ R */
+    deltas[i][3] = 0.0;
+    if (P->use_yaw_targets) {
+      double e = L->yaw_targets[i] - L->rpy[2];
+      if (e > PI) e -= 2.0 * PI;   /* rollover yaw, :147-149 */
+      if (e < -PI) e += 2.0 * PI;
+      deltas[i][3] = e;
+    }
   }
-  (void)P;
+  if (P->use_yaw_targets && L->n_targets_left > 0) L->yaw_error_scalar = fabs(deltas[0][3]);
 }
 int orc_obs_dim(const orc_params* P) {
   int att = (P->angle_repr ? 13 : 12) + 4 + (P->vehicle == ORC_QUADX ? 4 : 6);
   if (P->task == ORC_TASK_MA_HOVER) return att + 3;
-  return att + (P->task == ORC_TASK_WAYPOINTS ? 3 * P->num_targets : 0);
+  return att + (P->task == ORC_TASK_WAYPOINTS ? (P->use_yaw_targets ? 4 : 3) * P->num_targets : 0);
 }
 /* quadx_hover_env.py:85-115 ; quadx_waypoints_env.py:125-175 ; flatten_waypoint_env.py:42-62.
  * compute_state(): builds the observation (cached in the lane, as the reference caches
@@ -1126,10 +1140,11 @@ static void env_compute_state(const orc_params* P, orc_lane* L) {
     obs[k++] = L->throttle[0];
   }
   if (P->task == ORC_TASK_WAYPOINTS) {
-    double deltas[ORC_MAX_TARGETS][3];
+    double deltas[ORC_MAX_TARGETS][4];
     compute_deltas(P, L, deltas);
+    const int wcols = P->use_yaw_targets ? 4 : 3;
     for (int i = 0; i < P->num_targets; ++i)
-      for (int c = 0; c < 3; ++c) obs[k++] = (i < L->n_targets_left) ? deltas[i][c] : 0.0;
+      for (int c = 0; c < wcols; ++c) obs[k++] = (i < L->n_targets_left) ? deltas[i][c] : 0.0;
     L->old_dist = L->new_dist;
     L->new_dist = sqrt(dot3(deltas[0], deltas[0]));
   }
@@ -1175,9 +1190,13 @@ static void env_term_trunc_reward(const orc_params* P, orc_lane* L) {
         L->reward -= P->wp_yaw_penalty * (yaw_rate * yaw_rate);
       }
     }
-    if (L->new_dist < P->goal_reach_distance) { /* target_reached, waypoint_handler.py:167-179 */
+    if (L->new_dist < P->goal_reach_distance &&
+        (!P->use_yaw_targets || L->yaw_error_scalar < P->goal_reach_angle)) { /* target_reached, waypoint_handler.py:167-179 */
       L->reward = 100.0;
-      for (int i = 1; i < L->n_targets_left; ++i) memcpy(L->targets[i - 1], L->targets[i], sizeof(L->targets[0]));
+      for (int i = 1; i < L->n_targets_left; ++i) {
+        memcpy(L->targets[i - 1], L->targets[i], sizeof(L->targets[0]));
+        L->yaw_targets[i - 1] = L->yaw_targets[i];
+      }
       L->n_targets_left -= 1;
       int all = (L->n_targets_left == 0);
       if (all) L->truncated = 1;
@@ -1230,7 +1249,7 @@ void orc_env_step(const orc_params* P, orc_lane* L, const double action[4], cons
 /* ------------------------------------------------------------------ batch level */
 void orc_env_reset_batch(const orc_params* P, orc_lane* L, int n, uint64_t lane0, const uint8_t* mask,
                          const double* xi_reset, const double* u_targets) {
-  const int nr = P->settle_steps * P->world.ticks_per_control, nu = 3 * P->num_targets;
+  const int nr = P->settle_steps * P->world.ticks_per_control, nu = (P->use_yaw_targets ? 4 : 3) * P->num_targets;
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     if (mask && !mask[i]) continue;
@@ -1243,7 +1262,7 @@ void orc_env_step_batch(const orc_params* P, orc_lane* L, int n, const float* ac
                         double* reward, uint8_t* term, uint8_t* trunc, double* final_obs) {
   const int D = orc_obs_dim(P);
   const int ns = P->env_step_ratio * P->world.ticks_per_control;
-  const int nr = P->settle_steps * P->world.ticks_per_control, nu = 3 * P->num_targets;
+  const int nr = P->settle_steps * P->world.ticks_per_control, nu = (P->use_yaw_targets ? 4 : 3) * P->num_targets;
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     orc_lane* l = &L[i];

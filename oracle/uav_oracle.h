@@ -118,6 +118,8 @@ typedef struct {
   int collide_any;           /* fixedwing: any contact ; quadx: contact with plane (same thing here) */
   double wp_dist_reward;     /* 0.1 quadx, 1.0 fixedwing */
   double wp_yaw_penalty;     /* 0.01 quadx, 0 fixedwing */
+  int use_yaw_targets;       /* quadx_waypoints_env.py:40, waypoint_handler.py:85-89,144-156,167-179 */
+  double goal_reach_angle;   /* quadx_waypoints_env.py:42 (0.1 rad) */
 
   /* noise */
   int noise_mode;
@@ -173,6 +175,8 @@ typedef struct {
   double action[4];
   double past_action[4]; /* MA hover: self.past_actions (ma_quadx_base_env.py:326), survives resets */
   double targets[ORC_MAX_TARGETS][3];
+  double yaw_targets[ORC_MAX_TARGETS]; /* waypoint_handler.py:85-89 */
+  double yaw_error_scalar;             /* :156 */
   int n_targets_left;
   double new_dist, old_dist;
   /* observation as left by the last compute_state() (quadx_hover_env.py:85-115): the reference
@@ -232,7 +236,8 @@ void orc_aviary_reset(const orc_params* P, orc_lane* L, uint64_t lane_id);
 void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi,
                      uint32_t rng_call_base, uint32_t rng_stream);
 /* env.reset(): begin_reset + waypoint sampling + end_reset (quadx_base_env.py:149-212);
- * xi_reset: settle_steps*ticks_per_control normals, u_targets: 3*num_targets uniforms (inject mode) */
+ * xi_reset: settle_steps*ticks_per_control normals, u_targets: 3*num_targets uniforms (inject mode;
+ * 4*num_targets with use_yaw_targets: theta | phi | dist | yaw, the reference's draw order) */
 void orc_env_reset(const orc_params* P, orc_lane* L, uint64_t lane_id, const double* xi_reset,
                    const double* u_targets);
 /* env.step(action) (quadx_base_env.py:269-301); xi: env_step_ratio*ticks_per_control normals */

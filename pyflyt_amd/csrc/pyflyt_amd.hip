@@ -24,7 +24,7 @@
 namespace pf {
 
 constexpr int kWave = 64;
-constexpr int kMaxObs = 36;  // 13 + 4 + 6 + 3*4 = 35
+constexpr int kMaxObs = 40;  // 13 + 4 + 6 + 3*4 = 35 (Fixedwing), 13 + 4 + 4 + 4*4 = 37 (QuadX with yaw targets)
 
 enum { OP_STEP = 0, OP_RESET = 1 };
 
@@ -34,6 +34,7 @@ enum { OP_STEP = 0, OP_RESET = 1 };
 //   MA hover       : spawn position (3), spawn quaternion (4), the action of the previous call (4)
 struct SideBlock {
   float t[4][3];
+  float yaw[4];  // QuadX-Waypoints yaw targets (waypoint_handler.py:85-89), state group G_TGT + 3
   int n_left;
   PF_DEV void load(const float4* S, size_t n, size_t i, int g) {
     float4 a = S[(size_t)(g + 0) * n + i], b = S[(size_t)(g + 1) * n + i], c = S[(size_t)(g + 2) * n + i];
@@ -51,9 +52,14 @@ struct SideBlock {
     for (int k = 0; k < 3; ++k)
 #pragma unroll
       for (int c = 0; c < 3; ++c) t[k][c] = t[k + 1][c];
+    yaw[0] = yaw[1]; yaw[1] = yaw[2]; yaw[2] = yaw[3];
     n_left -= 1;
   }
 };
+PF_DEV float wrap_pi(float e) {  // waypoint_handler.py:147-149
+  e = e > kPi ? e - 2.0f * kPi : e;
+  return e < -kPi ? e + 2.0f * kPi : e;
+}
 
 // One Aviary.step out of line: used only by the rarely taken SAME_STEP settle loop so that the hot
 // loop below keeps the single inlined copy.
@@ -96,6 +102,10 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   int4 ints;
   V.load(Sin, N, li, mode, new_dist, ints);
   if (kSide) tg.load(Sin, N, li, VEH::G_TGT);
+  const bool kYaw = (TASK == PF_TASK_WAYPOINTS) && P.use_yaw_targets != 0;
+  tg.yaw[0] = tg.yaw[1] = tg.yaw[2] = tg.yaw[3] = 0.0f;
+  float yaw_err0 = 0.0f;  // waypoint_handler.py:156
+  if (kYaw) { float4 y = Sin[(size_t)(VEH::G_TGT + 3) * N + li]; tg.yaw[0] = y.x; tg.yaw[1] = y.y; tg.yaw[2] = y.z; tg.yaw[3] = y.w; }
   float4 ma_past = float4{0.f, 0.f, 0.f, 0.f};  // MA hover: self.past_actions (ma_quadx_base_env.py:326)
   if (TASK == PF_TASK_MA_HOVER) ma_past = Sin[(size_t)(VEH::G_TGT + 3) * N + li];
   int step_count = ints.x, flags = ints.y;
@@ -126,7 +136,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   bool pop_pending = false;
   bool rpy_valid = false;
   const int D = (P.angle_repr ? 13 : 12) + 4 + VEH::AUX +
-                (TASK == PF_TASK_WAYPOINTS ? 3 * P.num_targets : (TASK == PF_TASK_MA_HOVER ? 3 : 0));
+                (TASK == PF_TASK_WAYPOINTS ? (kYaw ? 4 : 3) * P.num_targets : (TASK == PF_TASK_MA_HOVER ? 3 : 0));
 
   // env.reset() up to (not including) the settle phase: quadx_base_env.py:149-206,
   // ma_quadx_base_env.py:206-241. Returns with `sp` = the mode's default setpoint.
@@ -172,6 +182,13 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
           tg.t[i][0] = dist * sph * ct; tg.t[i][1] = dist * sph * st; tg.t[i][2] = zz > P.min_height ? zz : P.min_height;
         }
       }
+      if (kYaw) {  // waypoint_handler.py:85-89: uniform(-pi, pi), drawn after all the positions
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nt)
+            tg.yaw[i] = (P.noise_mode == PF_NOISE_INJECT && B.u_targets != nullptr) ? B.u_targets[(size_t)(3 * nt + i) * N + li]
+                                                                                    : fmaf(2.0f * kPi, nz.uniform(3 * nt + i, 2u), -kPi);
+      }
     }
   };
   // compute_state's waypoint bookkeeping (waypoint_handler.py:135-142); ||R^T d|| = ||d||
@@ -181,6 +198,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     float dx = tg.t[0][0] - V.b.p.x, dy = tg.t[0][1] - V.b.p.y, dz = tg.t[0][2] - V.b.p.z;
     old_dist = new_dist;
     new_dist = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+    if (kYaw) yaw_err0 = __builtin_fabsf(wrap_pi(tg.yaw[0] - V.b.rpy.z));
   };
   // compute_term_trunc_reward: quadx_base_env.py:251-267, quadx_hover_env.py:117-138,
   // quadx_waypoints_env.py:177-204, fixedwing_waypoints_env.py:169-190, ma_quadx_hover_env.py:168-205
@@ -220,7 +238,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
           reward -= P.wp_yaw_penalty * (yaw_rate * yaw_rate);
         }
       }
-      if (new_dist < P.goal_reach_distance) {
+      if (new_dist < P.goal_reach_distance && (!kYaw || yaw_err0 < P.goal_reach_angle)) {  // waypoint_handler.py:167-179
         reward = 100.0f;
         pop_pending = true;  // the observation of this step still shows the reached target
         if ((tg.n_left - 1) == 0) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
@@ -258,6 +276,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
           v3 d = mulT(Re, v3{tg.t[i][0] - V.b.p.x, tg.t[i][1] - V.b.p.y, tg.t[i][2] - V.b.p.z});
           bool live = i < tg.n_left;
           row[k++] = live ? d.x : 0.0f; row[k++] = live ? d.y : 0.0f; row[k++] = live ? d.z : 0.0f;
+          if (kYaw) row[k++] = live ? wrap_pi(tg.yaw[i] - V.b.rpy.z) : 0.0f;  // waypoint_handler.py:144-153
         }
       }
     }
@@ -373,6 +392,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
             (trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0);
     V.store(Sout, N, li, mode, new_dist, int4{step_count, flags, (int)rng_ctr, tg.n_left});
     if (kSide) tg.store(Sout, N, li, VEH::G_TGT);
+    if (kYaw) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = float4{tg.yaw[0], tg.yaw[1], tg.yaw[2], tg.yaw[3]};
     if (TASK == PF_TASK_MA_HOVER) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = ma_past;
     if (op == OP_STEP) {  // a NEXT_STEP reset call reports (r=0, not done), gymnasium's convention
       B.reward[li] = out_reward;
@@ -738,6 +758,8 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   if (P.vehicle == PF_QUADX && (P.flight_mode < -1 || P.flight_mode > 7)) return fail(nullptr, PF_ERR_ARG, "quadx flight_mode must be in -1..7");
   if (P.vehicle == PF_FIXEDWING && (P.flight_mode < -1 || P.flight_mode > 0)) return fail(nullptr, PF_ERR_ARG, "fixedwing flight_mode must be -1 or 0");
   if (P.vehicle == PF_FIXEDWING && (P.task == PF_TASK_HOVER || P.task == PF_TASK_MA_HOVER)) return fail(nullptr, PF_ERR_UNSUPPORTED, "no fixedwing hover task in the reference");
+  if (P.use_yaw_targets && !(P.vehicle == PF_QUADX && P.task == PF_TASK_WAYPOINTS))
+    return fail(nullptr, PF_ERR_UNSUPPORTED, "use_yaw_targets exists for QuadX-Waypoints only (fixedwing_waypoints_env.py:77 hard-wires False)");
   if (P.task == PF_TASK_MA_HOVER && P.autoreset != PF_AUTORESET_OFF) return fail(nullptr, PF_ERR_ARG, "the multi-agent env has no auto-reset (PettingZoo parallel API)");
   if (P.task != PF_TASK_NONE && P.vehicle == PF_FIXEDWING && P.flight_mode != 0) return fail(nullptr, PF_ERR_UNSUPPORTED, "fixedwing env uses flight_mode 0");
   // quat_integrate()'s polynomial range: |w| dt / 2 <= pi/8 given the per-coordinate clamp
@@ -798,7 +820,7 @@ int pf_state_groups(const pf_ctx* ctx) {
 int pf_obs_dim(const pf_ctx* ctx) {
   const pf_params& P = ctx->P;
   int aux = P.vehicle == PF_QUADX ? 4 : 6;
-  return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? 3 * P.num_targets : (P.task == PF_TASK_MA_HOVER ? 3 : 0));
+  return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? (P.use_yaw_targets ? 4 : 3) * P.num_targets : (P.task == PF_TASK_MA_HOVER ? 3 : 0));
 }
 int pf_n_lanes(const pf_ctx* ctx) { return ctx->n; }
 int pf_ctx_is_specialised(const pf_ctx* ctx) { return ctx->fast ? 1 : ((ctx->fast_fw && ctx->tmpl) ? 2 : 0); }

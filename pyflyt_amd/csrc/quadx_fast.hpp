@@ -48,6 +48,8 @@ struct QuadK {
   int32_t task_sparse, angle_repr, num_targets, max_steps, env_step_ratio, settle_steps, tpc;
   int32_t noise_mode, autoreset, fast_settle;
   uint32_t seed_lo, seed_hi;
+  int32_t use_yaw;               // quadx_waypoints_env.py:40
+  float goal_angle;              // :42
   float act_lo[4], act_span[4];  // action box (quadx_base_env.py:80-102): low, high - low (pf_rollout's on-device sampling)
 };
 
@@ -105,6 +107,8 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.noise_mode = P.noise_mode; K.autoreset = P.autoreset;
   K.seed_lo = (uint32_t)P.seed; K.seed_hi = (uint32_t)(P.seed >> 32);
   for (int k = 0; k < 4; ++k) { K.act_lo[k] = P.action_low[k]; K.act_span[k] = P.action_high[k] - P.action_low[k]; }
+  K.use_yaw = (P.task == PF_TASK_WAYPOINTS && P.use_yaw_targets) ? 1 : 0;
+  K.goal_angle = P.goal_reach_angle;
   // level spawn at rest, far enough above the floor that the settle free-fall cannot touch it
   const float fall = 0.5f * 9.81f * (P.settle_steps * P.ticks_per_control * P.dt) * (P.settle_steps * P.ticks_per_control * P.dt);
   K.fast_settle = (P.start_quat[0] == 0.f && P.start_quat[1] == 0.f && P.start_vel[0] == 0.f && P.start_vel[1] == 0.f &&
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
                                                              const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
   constexpr bool ROLLOUT = ROLL != 0;
   constexpr bool GIVEN = ROLL == 2;
-  constexpr int kMaxD = 13 + 4 + 4 + 12;
+  constexpr int kMaxD = 13 + 4 + 4 + 16;  // attitude + 4 targets x (delta, yaw error)
   constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
   __shared__ float tile[LPW * kMaxD];
   __shared__ float sxi[64 * kSettleMax];
@@ -289,6 +293,20 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   // MA hover (ma_quadx_base_env.py:139-150,326-332): the action of the previous call, observed this call
   float4 ma_past = float4{0.f, 0.f, 0.f, 0.f};
   if (TASK == PF_TASK_MA_HOVER) ma_past = Sin[15 * N + li];
+  // waypoints with yaw targets (waypoint_handler.py:85-89): the four yaw targets ride in group 15
+  const bool kYaw = (TASK == PF_TASK_WAYPOINTS) && K.use_yaw != 0;
+  float ytg[4] = {0.f, 0.f, 0.f, 0.f};
+  float yaw_err0 = 0.0f;  // |yaw error| to the next target as of the last compute_state (waypoint_handler.py:156)
+  if (kYaw) { float4 y = Sin[15 * N + li]; ytg[0] = y.x; ytg[1] = y.y; ytg[2] = y.z; ytg[3] = y.w; }
+  // yaw of getEulerFromQuaternion from the rotation matrix derive() holds (gimbal branch: the library definition)
+  auto yaw_now = [&]() {
+    if (__builtin_fabsf(V.R.m20) >= 0.99999f) return euler_from_quat(V.q).z;
+    return fast_atan2(V.R.m10, V.R.m00);
+  };
+  auto wrap_pi = [](float e) {  // waypoint_handler.py:147-149
+    e = e > kPi ? e - 2.0f * kPi : e;
+    return e < -kPi ? e + 2.0f * kPi : e;
+  };
   V.contact_now = (flags & PF_F_CONTACT) != 0;
   V.contact_step = false;
   V.derive();
@@ -303,7 +321,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   float reward = 0.0f;
   bool pop_pending = false;
   bool was_reset = false;
-  const int D = (K.angle_repr ? 13 : 12) + 8 + (TASK == PF_TASK_WAYPOINTS ? 3 * K.num_targets : (TASK == PF_TASK_MA_HOVER ? 3 : 0));
+  const int D = (K.angle_repr ? 13 : 12) + 8 + (TASK == PF_TASK_WAYPOINTS ? (kYaw ? 4 : 3) * K.num_targets : (TASK == PF_TASK_MA_HOVER ? 3 : 0));
   const int settle_ticks = K.settle_steps * 2;
 
   auto pop_target = [&]() {
@@ -311,6 +329,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     for (int k = 0; k < 3; ++k)
 #pragma unroll
       for (int c = 0; c < 3; ++c) tgt[k][c] = tgt[k + 1][c];
+    ytg[0] = ytg[1]; ytg[1] = ytg[2]; ytg[2] = ytg[3];
     n_left -= 1;
   };
   // One wave per workgroup: LDS operations of a wave execute in issue order, so the row writes only
@@ -390,12 +409,19 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = K.num_targets;
       n_left = nt;
-      f4 u0, u1, u2;
+      f4 u0, u1, u2, u3 = f4{0.f, 0.f, 0.f, 0.f};
       const bool inj = (NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr);
       if (!inj) {
         u0 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 2u));
         u1 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 1u, 2u));
         u2 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 2u, 2u));
+        if (kYaw) u3 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 3u, 2u));
+      }
+      auto u = [&](int flat) { return pick4(flat < 4 ? u0 : (flat < 8 ? u1 : (flat < 12 ? u2 : u3)), (uint32_t)flat & 3u); };
+      if (kYaw) {  // waypoint_handler.py:85-89: uniform(-pi, pi), drawn after all the positions
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nt) ytg[i] = inj ? B.u_targets[(size_t)(3 * nt + i) * N + li] : fmaf(2.0f * kPi, u(3 * nt + i), -kPi);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -406,7 +432,6 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
             phi = B.u_targets[(size_t)(nt + i) * N + li] * (0.5f / kPi);
             dist = B.u_targets[(size_t)(2 * nt + i) * N + li];
           } else {
-            auto u = [&](int flat) { return pick4(flat < 4 ? u0 : (flat < 8 ? u1 : u2), (uint32_t)flat & 3u); };
             theta = u(i);
             phi = u(nt + i);
             dist = fmaf(K.dome09m1, u(2 * nt + i), 1.0f);
@@ -422,6 +447,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
       old_dist = INFINITY;
       new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+      if (kYaw) yaw_err0 = __builtin_fabsf(wrap_pi(ytg[0] - yaw_now()));
     }
     rng_ctr += 1;
     was_reset = true;
@@ -435,6 +461,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     float sarg = -V.R.m20;
     quat qe;
     v3 rpy;
+    const float obs_yaw = kYaw ? yaw_now() : 0.0f;
     if (__builtin_fabsf(sarg) >= 0.99999f) {  // gimbal-lock branch of pybullet, rare: library trig
       rpy = euler_from_quat(V.q);
       qe = quat_from_euler(rpy);
@@ -473,6 +500,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
           v3 d = mulT(Re, v3{tgt[i][0] - V.p.x, tgt[i][1] - V.p.y, tgt[i][2] - V.p.z});
           bool live = i < n_left;
           row[k++] = live ? d.x : 0.0f; row[k++] = live ? d.y : 0.0f; row[k++] = live ? d.z : 0.0f;
+          if (kYaw) row[k++] = live ? wrap_pi(ytg[i] - obs_yaw) : 0.0f;  // waypoint_handler.py:144-153
         }
       }
     }
@@ -558,6 +586,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
         float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
         old_dist = new_dist;
         new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+        if (kYaw) yaw_err0 = __builtin_fabsf(wrap_pi(ytg[0] - yaw_now()));
       }
       if (step_count > K.max_steps) trunc = true;                                          // quadx_base_env.py:254
       if (TASK == PF_TASK_MA_HOVER) {  // ma_quadx_hover_env.py:168-205: additive penalties, no early exit
@@ -603,7 +632,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
           reward = fmaf(K.wp_dist_reward, frcp(new_dist), reward);
           reward = fmaf(-K.wp_yaw_penalty * V.wb.z, V.wb.z, reward);
         }
-        if (new_dist < K.goal_reach) {  // :195-204; the observation of this step still shows the target
+        if (new_dist < K.goal_reach && (!kYaw || yaw_err0 < K.goal_angle)) {  // :195-204 (waypoint_handler.py:167-179); the observation of this step still shows the target
           reward = 100.0f;
           pop_pending = true;
           if (n_left - 1 == 0) { trunc = true; flags |= PF_F_INFO_COMPLETE; }
@@ -669,6 +698,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     Sout[5 * N + li] = float4{V.I[2], V.E[0], V.E[1], V.E[2]};
     Sout[6 * N + li] = float4{__int_as_float(step_count), __int_as_float(flags), __int_as_float((int)rng_ctr), __int_as_float(n_left)};
     if (TASK == PF_TASK_MA_HOVER) Sout[15 * N + li] = ma_past;
+    if (kYaw) Sout[15 * N + li] = float4{ytg[0], ytg[1], ytg[2], ytg[3]};
     if (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER) {
       Sout[12 * N + li] = float4{tgt[0][0], tgt[0][1], tgt[0][2], tgt[1][0]};
       Sout[13 * N + li] = float4{tgt[1][1], tgt[1][2], tgt[2][0], tgt[2][1]};

@@ -140,14 +140,15 @@ class _WaypointsMixin:
         nt = self.engine.params.num_targets
         dome = self.engine.params.dome
         self.num_targets = nt
+        tw = self.target_width = 4 if self.engine.params.use_yaw_targets else 3  # quadx_waypoints_env.py:99
         if self._flatten:
-            width = self.attitude_dim + 3 * self._context_length
+            width = self.attitude_dim + tw * self._context_length
             self.single_observation_space = Box(low=-np.inf, high=np.inf, shape=(width,), dtype=np.float32)
             self.observation_space = batch_box(self.single_observation_space, self.num_envs)
         else:
             self.single_observation_space = Dict({
                 "attitude": Box(low=-np.inf, high=np.inf, shape=(self.attitude_dim,), dtype=np.float32),
-                "target_deltas": Box(low=-2 * dome, high=2 * dome, shape=(nt, 3), dtype=np.float32),
+                "target_deltas": Box(low=-2 * dome, high=2 * dome, shape=(nt, tw), dtype=np.float32),
             })
             self.observation_space = Dict({
                 "attitude": batch_box(self.single_observation_space["attitude"], self.num_envs),
@@ -155,17 +156,17 @@ class _WaypointsMixin:
             })
 
     def _obs(self, buf):
-        a = self.attitude_dim
+        a, tw = self.attitude_dim, self.target_width
         if self._flatten:  # gym_envs/utils/flatten_waypoint_env.py:42-62
             ctx = self._context_length
             have = min(ctx, self.num_targets)
             if have == ctx:
-                return buf[:, : a + 3 * ctx]
-            pad = torch.zeros(buf.shape[0], 3 * (ctx - have), dtype=buf.dtype, device=buf.device)
-            return torch.cat([buf[:, : a + 3 * have], pad], dim=1)
+                return buf[:, : a + tw * ctx]
+            pad = torch.zeros(buf.shape[0], tw * (ctx - have), dtype=buf.dtype, device=buf.device)
+            return torch.cat([buf[:, : a + tw * have], pad], dim=1)
         # the reference's variable-length Sequence becomes a fixed [num_targets, 3] block whose rows
         # past the remaining targets are zero (flatten_waypoint_env.py:49-56 padding convention)
-        return {"attitude": buf[:, :a], "target_deltas": buf[:, a:].view(-1, self.num_targets, 3)}
+        return {"attitude": buf[:, :a], "target_deltas": buf[:, a:].view(-1, self.num_targets, tw)}
 
     def _infos(self, flags=None, n_left=None):
         infos = super()._infos(flags)
@@ -176,20 +177,18 @@ class _WaypointsMixin:
 
 
 class QuadXWaypointsVecEnv(_WaypointsMixin, _VecEnvBase):
-    """PyFlyt/QuadX-Waypoints-v4, batched. Keywords as quadx_waypoints_env.py:36-49 (yaw targets are
-    not supported). flatten=True returns FlattenWaypointEnv-style rows [attitude, ctx deltas]."""
+    """PyFlyt/QuadX-Waypoints-v4, batched. Keywords as quadx_waypoints_env.py:36-49, incl. `use_yaw_targets` /
+    `goal_reach_angle` (target deltas 4 wide: body-frame delta + wrapped yaw error; a waypoint counts only when
+    both gates hold). flatten=True returns FlattenWaypointEnv-style rows [attitude, ctx deltas]."""
     _vehicle, _task = "quadx", "waypoints"
 
     def __init__(self, num_envs: int, *, sparse_reward: bool = False, num_targets: int = 4, use_yaw_targets: bool = False,
                  goal_reach_distance: float = 0.2, goal_reach_angle: float = 0.1, flight_mode: int = 0,
                  flight_dome_size: float = 5.0, max_duration_seconds: float = 10.0, angle_representation: str = "quaternion",
                  agent_hz: int = 30, flatten: bool = False, context_length: int = 2, **kw):
-        if use_yaw_targets:
-            raise NotImplementedError("use_yaw_targets=True is not part of the batched hot path")
-        del goal_reach_angle
         self._flatten, self._context_length = bool(flatten), int(context_length)
         super().__init__(num_envs, sparse_reward=sparse_reward, num_targets=num_targets, goal_reach_distance=goal_reach_distance,
-                         flight_mode=flight_mode, flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds,
+                         use_yaw_targets=use_yaw_targets, goal_reach_angle=goal_reach_angle, flight_mode=flight_mode, flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds,
                          angle_representation=angle_representation, agent_hz=agent_hz, **kw)
 
 

@@ -270,6 +270,8 @@ def build_params(
     agent_hz: int | None = None,
     num_targets: int = 4,
     goal_reach_distance: float | None = None,
+    use_yaw_targets: bool = False,
+    goal_reach_angle: float = 0.1,
     start_pos=None,
     start_orn=None,
     vehicle_options: dict | None = None,
@@ -456,6 +458,10 @@ def build_params(
             P.min_height, P.wp_dist_reward, P.wp_yaw_penalty = 0.5, 1.0, 0.0
             P.throttle_remap = 1
         P.num_targets = int(num_targets)
+        if use_yaw_targets and vehicle != "quadx":
+            raise ValueError("use_yaw_targets exists for QuadX-Waypoints only (fixedwing_waypoints_env.py:77)")
+        P.use_yaw_targets = int(bool(use_yaw_targets))  # quadx_waypoints_env.py:40
+        P.goal_reach_angle = min(float(goal_reach_angle), 3.0e38)  # :42
     else:
         raise ValueError(f"unknown task {task!r}")
     hz = d_hz if agent_hz is None else int(agent_hz)

@@ -276,7 +276,7 @@ def gen_wind():
 # --------------------------------------------------------------------------- env level
 def flat_obs(env, obs, num_targets):
     if isinstance(obs, dict):
-        t = np.zeros((num_targets, 3))
+        t = np.zeros((num_targets, 4 if getattr(env.waypoints, "use_yaw_targets", False) else 3))
         n = obs["target_deltas"].shape[0]
         t[:n] = obs["target_deltas"]
         return np.concatenate([obs["attitude"], t.reshape(-1)])
@@ -362,6 +362,15 @@ def gen_envs():
     save("env_fixedwing_waypoints_gentle", **run_env(lambda: FixedwingWaypointsEnv(goal_reach_distance=40.0), 400, 6, gentle_fw_action, num_targets=4, ticks=8))
 
 
+def gen_envs_yaw():
+    # use_yaw_targets=True (quadx_waypoints_env.py:40, waypoint_handler.py:85-89,144-156,167-179): four more uniforms at
+    # reset (after the position draws), (remaining, 4) target deltas, reach = distance AND yaw error under goal_reach_angle
+    save("env_quadx_waypoints_yaw_random", **run_env(lambda: QuadXWaypointsEnv(use_yaw_targets=True), 300, 21, uniform_action, num_targets=4, ticks=8))
+    # wide distance gate, moderate angle gate, gentle flight: targets are reached, and some distance-only passes are refused
+    save("env_quadx_waypoints_yaw_reach", **run_env(lambda: QuadXWaypointsEnv(use_yaw_targets=True, goal_reach_distance=2.5, goal_reach_angle=1.2),
+                                                    400, 22, gentle_quad_action, num_targets=4, ticks=8))
+
+
 def gen_ma_hover():
     """pz_envs/quadx_envs/ma_quadx_hover_env.py driven through its PettingZoo dict API: 4 agents in one
     (fake-Bullet) world -- drone-drone contact is not restated, so agents are independent lanes. The
@@ -422,6 +431,7 @@ if __name__ == "__main__":
     gen_aviary()
     gen_envs()
     gen_envs_crash()
+    gen_envs_yaw()
     gen_ma_hover()
     gen_wind()
     gen_primitive()

@@ -42,9 +42,9 @@ def vec_err(got, ref, groups):
     return e
 
 
-def obs_groups(D, quat, aux, nt):
+def obs_groups(D, quat, aux, nt, tw=3):
     g, k = [], 0
-    for w in (3, 4 if quat else 3, 3, 3, 4, aux) + (3,) * nt:
+    for w in (3, 4 if quat else 3, 3, 3, 4, aux) + (tw,) * nt:
         g.append((k, k + w))
         k += w
     assert k == D, (k, D)
@@ -62,6 +62,8 @@ ENVS = [
     ("env_quadx_waypoints_reach", "quadx", "waypoints", dict(goal_reach_distance=2.5)),
     ("env_fixedwing_waypoints_random", "fixedwing", "waypoints", {}),
     ("env_fixedwing_waypoints_gentle", "fixedwing", "waypoints", dict(goal_reach_distance=40.0)),
+    ("env_quadx_waypoints_yaw_random", "quadx", "waypoints", dict(use_yaw_targets=True)),
+    ("env_quadx_waypoints_yaw_reach", "quadx", "waypoints", dict(use_yaw_targets=True, goal_reach_distance=2.5, goal_reach_angle=1.2)),
 ]
 
 
@@ -81,7 +83,7 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
     D = eng.obs_dim
     assert D == g["obs"].shape[1]
     nt = P.num_targets if task == "waypoints" else 0
-    G = obs_groups(D, bool(P.angle_repr), 4 if vehicle == "quadx" else 6, nt)
+    G = obs_groups(D, bool(P.angle_repr), 4 if vehicle == "quadx" else 6, nt, 4 if P.use_yaw_targets else 3)
     resets = set(int(k) for k in g["reset_before"])
     ri = 0
     worst = 0.0

@@ -45,10 +45,11 @@ def _oracle(env, n, noise, seed=0, **over):
     return O.OracleBatch(O.make_params(env, noise_mode=mode, seed=seed, **over), n)
 
 
-def obs_groups(D, quat, aux, nt):
-    """Index groups of the flattened observation: each physical vector is one group."""
+def obs_groups(D, quat, aux, nt, tw=3):
+    """Index groups of the flattened observation: each physical vector is one group (a target delta with its
+    yaw error, tw = 4, is one group: the yaw error is then held to 1e-4 * max(1, distance) rad)."""
     g, k = [], 0
-    for w in (3, 4 if quat else 3, 3, 3, 4, aux) + (3,) * nt:
+    for w in (3, 4 if quat else 3, 3, 3, 4, aux) + (tw,) * nt:
         g.append((k, k + w))
         k += w
     assert k == D, (k, D)
@@ -80,7 +81,7 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
         max_bad = 0.0 if vehicle == "quadx" else 0.005
     eng = _engine(vehicle, task, n, noise=noise, autoreset=autoreset, seed=seed,
                   **{k: v for k, v in over.items() if k in ("goal_reach_distance", "max_duration_seconds", "angle_representation", "sparse_reward",
-                                                             "agent_hz", "num_targets", "flight_dome_size")})
+                                                             "agent_hz", "num_targets", "flight_dome_size", "use_yaw_targets", "goal_reach_angle")})
     oover = {}
     if "goal_reach_distance" in over:
         oover["goal_reach_distance"] = over["goal_reach_distance"]
@@ -97,6 +98,10 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
         oover["angle_repr"] = 0
     if over.get("sparse_reward"):
         oover["sparse_reward"] = 1
+    if over.get("use_yaw_targets"):
+        oover["use_yaw_targets"] = 1
+        oover["goal_reach_angle"] = over.get("goal_reach_angle", 0.1)
+    yaw = bool(over.get("use_yaw_targets"))
     orc = _oracle(env_name, n, noise, seed=seed, **oover)
     rng = np.random.default_rng(seed + 1)
     T, TR = eng.ticks_per_step, eng.settle_ticks
@@ -108,13 +113,14 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
             return None, None, None, None, None, None
         xi = rng.normal(nm, 1.0, size=(n, T))
         xr = rng.normal(nm, 1.0, size=(n, TR))
-        ut = np.concatenate([rng.uniform(0, 2 * np.pi, size=(n, 2 * nt)), rng.uniform(1.0, eng.params.dome * 0.9, size=(n, nt))], axis=1) if nt else None
+        ut = np.concatenate([rng.uniform(0, 2 * np.pi, size=(n, 2 * nt)), rng.uniform(1.0, eng.params.dome * 0.9, size=(n, nt))] +
+                            ([rng.uniform(-np.pi, np.pi, size=(n, nt))] if yaw else []), axis=1) if nt else None
         dev = lambda a: None if a is None else torch.tensor(np.ascontiguousarray(a.T), dtype=torch.float32, device="cuda:0")  # noqa: E731
         # the oracle sees exactly the fp32-rounded draws the device sees
         f = lambda a: None if a is None else np.ascontiguousarray(a.astype(np.float32).astype(np.float64))  # noqa: E731
         return f(xi), f(xr), f(ut), dev(xi), dev(xr), dev(ut)
 
-    G = obs_groups(eng.obs_dim, bool(eng.params.angle_repr), 4 if vehicle == "quadx" else 6, nt)
+    G = obs_groups(eng.obs_dim, bool(eng.params.angle_repr), 4 if vehicle == "quadx" else 6, nt, 4 if yaw else 3)
     xi, xr, ut, dxi, dxr, dut = draws()
     obs_g = eng.env_reset(xi_reset=dxr, u_targets=dut).cpu().numpy().astype(np.float64)
     obs_r = orc.reset(xi_reset=xr, u_targets=ut)
@@ -252,6 +258,23 @@ def test_quadx_waypoints_reach():
 
     run_env_parity("quadx", "waypoints", "quadx_waypoints", 512, 150, "philox", "next_step", QUAD_LOW, QUAD_HIGH, seed=13,
                    gentle=gentle, goal_reach_distance=2.5)
+
+
+@pytest.mark.parametrize("kernel", ["specialised", "generic"])
+@pytest.mark.parametrize("noise,autoreset", [("inject", "off"), ("philox", "next_step"), ("philox", "same_step")])
+def test_quadx_waypoints_yaw_targets_parity(monkeypatch, noise, autoreset, kernel):
+    """use_yaw_targets=True (quadx_waypoints_env.py:40-42; waypoint_handler.py:85-89,144-156,167-179): 4-wide target
+    deltas, the extra reset draws, the reach gate on the yaw error. Gentle flight with wide gates so that targets are
+    reached (and refused on the yaw gate alone)."""
+    if kernel == "generic":
+        monkeypatch.setenv("PF_DISABLE_FAST", "1")
+
+    def gentle(rng, n):
+        return np.concatenate([rng.uniform(-0.3, 0.3, size=(n, 2)), rng.uniform(-1.5, 1.5, size=(n, 1)), rng.uniform(0.33, 0.40, size=(n, 1))], axis=1).astype(np.float32)
+
+    run_env_parity("quadx", "waypoints", "quadx_waypoints", 512, 150, noise, autoreset, QUAD_LOW, QUAD_HIGH, seed=29, gentle=gentle,
+                   use_yaw_targets=True, goal_reach_distance=2.5, goal_reach_angle=1.2)
+    run_env_parity("quadx", "waypoints", "quadx_waypoints", 512, 60, noise, autoreset, QUAD_LOW, QUAD_HIGH, seed=31, use_yaw_targets=True)
 
 
 @pytest.mark.parametrize("noise,autoreset", [("inject", "off"), ("philox", "next_step"), ("philox", "same_step")])

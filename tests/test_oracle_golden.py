@@ -266,6 +266,8 @@ ENVS = [
     ("env_quadx_waypoints_reach", "quadx_waypoints", {"goal_reach_distance": 2.5}),
     ("env_fixedwing_waypoints_random", "fixedwing_waypoints", {}),
     ("env_fixedwing_waypoints_gentle", "fixedwing_waypoints", {"goal_reach_distance": 40.0}),
+    ("env_quadx_waypoints_yaw_random", "quadx_waypoints", {"use_yaw_targets": 1}),
+    ("env_quadx_waypoints_yaw_reach", "quadx_waypoints", {"use_yaw_targets": 1, "goal_reach_distance": 2.5, "goal_reach_angle": 1.2}),
 ]
 
 

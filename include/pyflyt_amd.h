@@ -29,10 +29,11 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 4
+#define PF_ABI_VERSION 5
 #define PF_MAX_TARGETS 8
 #define PF_MAX_BOXES 12
 #define PF_MAX_SURF 5
+#define PF_MAX_CONTACTS 48 /* contact vertices solved per body per tick (first in collider / vertex order) */
 
 enum pf_status { PF_OK = 0, PF_ERR_ARG = -1, PF_ERR_UNSUPPORTED = -2, PF_ERR_NO_DEVICE = -3 };
 enum pf_vehicle { PF_QUADX = 0, PF_FIXEDWING = 1, PF_ROCKET = 2 /* Aviary-level entry points only */ };
@@ -113,6 +114,21 @@ typedef struct pf_params {
   /* world / integrator: aviary.py:79,226 + Bullet defaults */
   float dt, gravity_z, max_coord_vel;
   float plane_half_xy, plane_half_z;
+  /* Contact RESPONSE against the ground slab -- what stepSimulation (core/aviary.py:516) does after collision
+   * detection. [BULLET-FROM-MEMORY], a named-parameter model (NOT btMultiBodyConstraintSolver digit for digit):
+   * contact points = the collider vertices (box corners; 8 rim points on either end disc of a cylinder) at or below the
+   * slab's top face at the pre-integration pose; contact_iters projected Gauss-Seidel sweeps over them in collider /
+   * vertex order at the velocity level (normal impulse >= 0 towards contact_restitution x approach speed, or towards
+ * -gap / dt for a vertex still above the face; two
+   * world-axis friction directions clamped to contact_friction x normal impulse); after the position update a
+   * translation of contact_erp x deepest penetration along +z. 0 = detection only (bodies fall through the floor). */
+  int32_t contact_response, contact_iters;
+  float contact_restitution, contact_friction, contact_erp;
+  /* speculative margin: vertices up to this far ABOVE the face are in the contact set as well, with the constraint
+   * "do not close more than the gap in this tick" (normal velocity >= -gap / dt): binds only when the vertex would
+   * otherwise penetrate within the tick, and keeps a resting body's vertices in the active set (Bullet's contact
+   * breaking threshold, 0.02 m, plays this role) */
+  float contact_margin;
   /* composite body */
   float inv_mass;
   float com[3];

@@ -121,6 +121,25 @@ class _Body:
                 out.append((centre, R @ l.rot, h * self.scale))
         return out
 
+    def contact_vertices(self):
+        """Body-frame positions (relative to the base origin) of the contact vertices, in URDF link order, each link's
+        boxes (8 corners: x sign fastest) then cylinders (end disc -z then +z, 8 rim points at 45 degree steps from the
+        link x axis) -- the order the contact sweep runs in."""
+        out = []
+        c45 = [math.cos(j * math.pi / 4.0) for j in range(8)]
+        s45 = [math.sin(j * math.pi / 4.0) for j in range(8)]
+        for l in self.links:
+            for c, h in l.boxes:
+                for i in range(8):
+                    loc = np.array([h[0] if i & 1 else -h[0], h[1] if i & 2 else -h[1], h[2] if i & 4 else -h[2]])
+                    out.append((l.joint_origin + l.rot @ (c + loc)) * self.scale)
+            for c, rad, hl in l.cyls:
+                for e in (-1.0, 1.0):
+                    for j in range(8):
+                        loc = np.array([rad * c45[j], rad * s45[j], e * hl])
+                        out.append((l.joint_origin + l.rot @ (c + loc)) * self.scale)
+        return out
+
     def world_cyls(self):
         R = matrix_from_quat(self.q)
         out = []
@@ -240,6 +259,10 @@ class BulletClient:
         self._contacts = []
         self._search = ""
         self.use_gyro_term = True
+        # contact response against fixed bodies' top faces (the ground slab): see _solve_contacts
+        self.contact_response = True
+        self.contact_restitution, self.contact_friction, self.contact_erp, self.contact_iters = 0.0, 0.5, 0.2, 10
+        self.contact_margin = 0.02
 
     # ------------------------------------------------------------ no-ops
     def setAdditionalSearchPath(self, path):
@@ -364,6 +387,52 @@ class BulletClient:
     def getContactPoints(self, *args, **kwargs):
         return list(self._contacts)
 
+    def _solve_contacts(self, b, I6, R):
+        """Contact response of free body `b` against the ground slab, the SAME named-parameter model as
+        oracle/uav_oracle.c:contact_solve but formulated independently: impulses act on the base twist (body frame,
+        [angular; linear] at the base ORIGIN) through the 6x6 spatial inertia the tick already assembled -- no centre of
+        mass, no 3x3 inertia. Returns the deepest penetration."""
+        slabs = [bx for f in self._bodies.values() if f.fixed for bx in f.world_boxes()]
+        pts = []
+        for rb in b.contact_vertices():
+            if len(pts) >= 48:  # the device code's PF_MAX_CONTACTS: vertices past it are ignored
+                break
+            x = b.p + R @ rb
+            for cb, Rb, hb in slabs:
+                if x[2] <= cb[2] + hb[2] + self.contact_margin and x[2] >= cb[2] - hb[2] and abs(x[0] - cb[0]) <= hb[0] and abs(x[1] - cb[1]) <= hb[1]:
+                    pts.append((rb, (cb[2] + hb[2]) - x[2]))
+                    break
+        if not pts:
+            return 0.0
+        I6inv = np.linalg.inv(I6)
+        tw = np.concatenate([R.T @ b.w, R.T @ b.v])  # body-frame twist
+        dirs = [R.T @ np.array(d) for d in ((0.0, 0.0, 1.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0))]
+        lam = np.zeros((len(pts), 3))
+        jac = [[np.concatenate([np.cross(rb, d), d]) for d in dirs] for rb, _ in pts]
+        vn0 = [float(j[0] @ tw) for j in jac]
+        for _ in range(self.contact_iters):
+            for c in range(len(pts)):
+                for d in range(3):
+                    j = jac[c][d]
+                    resp = I6inv @ j
+                    k = float(j @ resp)
+                    target = 0.0
+                    if d == 0:
+                        depth = pts[c][1]
+                        target = depth / self._dt if depth < 0.0 else (-self.contact_restitution * vn0[c] if vn0[c] < 0.0 else 0.0)
+                    dl = (target - float(j @ tw)) / k
+                    if d == 0:
+                        new = max(lam[c, 0] + dl, 0.0)
+                    else:
+                        lim = self.contact_friction * lam[c, 0]
+                        new = min(max(lam[c, d] + dl, -lim), lim)
+                    dl = new - lam[c, d]
+                    lam[c, d] = new
+                    tw = tw + dl * resp
+        b.w = R @ tw[:3]
+        b.v = R @ tw[3:]
+        return max(0.0, max(d for _, d in pts))
+
     # ------------------------------------------------------------ the tick
     def stepSimulation(self):
         dt = self._dt
@@ -429,7 +498,9 @@ class BulletClient:
             vm = b.max_coord_vel
             b.w = np.clip(b.w + wdot * dt, -vm, vm)
             b.v = np.clip(b.v + vdot * dt, -vm, vm)
+            deepest = self._solve_contacts(b, I6, R) if self.contact_response else 0.0
             b.p = b.p + dt * b.v
+            b.p[2] += self.contact_erp * deepest
             # exponential-map quaternion update with world-frame omega
             fAngle = math.sqrt(float(b.w @ b.w))
             if fAngle * dt > 0.25 * math.pi:

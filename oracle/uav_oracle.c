@@ -232,7 +232,7 @@ int orc_contact_plane(const orc_params* P, const double p[3], const double q[4])
 typedef struct { /* the composite body the tick integrates; constant for QuadX / Fixedwing, rebuilt per tick for the Rocket */
   double mass, com[3], I_own[3][3], I_pa[3][3], I_inv[3][3];
 } orc_body;
-static void rigid_tick_body(const orc_world* W, const orc_body* B, double p[3], double q[4], double v[3], double w[3],
+static void rigid_tick_body(const orc_params* PP, const orc_body* B, double p[3], double q[4], double v[3], double w[3],
                             const double F_b[3], const double tau_b[3]);
 void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], double w[3],
                     const double F_b[3], const double tau_b[3]) {
@@ -242,10 +242,105 @@ void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], 
   memcpy(B.I_own, P->I_own, sizeof(B.I_own));
   memcpy(B.I_pa, P->I_pa, sizeof(B.I_pa));
   memcpy(B.I_inv, P->I_inv, sizeof(B.I_inv));
-  rigid_tick_body(&P->world, &B, p, q, v, w, F_b, tau_b);
+  rigid_tick_body(P, &B, p, q, v, w, F_b, tau_b);
 }
-static void rigid_tick_body(const orc_world* Wd, const orc_body* P, double p[3], double q[4], double v[3], double w[3],
+
+/* ---- contact response against the ground slab (see orc_world in the header for the model) ---- */
+int orc_contact_points(const orc_params* P, const double p[3], const double q[4], double pts[][3], double depth[]) {
+  int n = 0;
+  if (p[2] - P->bound_radius > P->world.contact_margin) return 0;
+  double R[3][3];
+  orc_matrix_from_quat(q, R);
+  const double hxy = P->world.plane_half_xy, hz2 = 2.0 * P->world.plane_half_z;
+  for (int k = 0; k < P->n_boxes; ++k) {
+    const orc_box* b = &P->boxes[k];
+    const double cy = cos(b->yaw), sy = sin(b->yaw);
+    const int nv = b->kind == 1 ? 16 : 8;
+    for (int i = 0; i < nv; ++i) {
+      double l[3];
+      if (b->kind == 1) { /* end disc e = -1, +1; rim point j at j * 45 degrees from the link x axis */
+        const int e = i >> 3, j = i & 7;
+        const double c45[8] = {1.0, 0.70710678118654752, 0.0, -0.70710678118654752, -1.0, -0.70710678118654752, 0.0, 0.70710678118654752};
+        l[0] = b->h[0] * c45[j]; l[1] = b->h[0] * c45[(j + 6) & 7]; l[2] = (e ? 1.0 : -1.0) * b->h[2];
+      } else {
+        l[0] = (i & 1) ? b->h[0] : -b->h[0]; l[1] = (i & 2) ? b->h[1] : -b->h[1]; l[2] = (i & 4) ? b->h[2] : -b->h[2];
+      }
+      /* link frame (yawed about the base z axis) -> base frame -> world */
+      double bl[3] = {b->c[0] + cy * l[0] - sy * l[1], b->c[1] + sy * l[0] + cy * l[1], b->c[2] + l[2]};
+      double wpt[3];
+      matvec(R, bl, wpt);
+      wpt[0] += p[0]; wpt[1] += p[1]; wpt[2] += p[2];
+      if (n < ORC_MAX_CONTACTS && wpt[2] <= P->world.contact_margin && wpt[2] >= -hz2 && fabs(wpt[0]) <= hxy && fabs(wpt[1]) <= hxy) {
+        memcpy(pts[n], wpt, sizeof(wpt));
+        depth[n] = -wpt[2];
+        ++n;
+      }
+    }
+  }
+  return n;
+}
+/* projected Gauss-Seidel on the base twist (v at the base origin, w; world frame). Returns the deepest penetration. */
+static double contact_solve(const orc_params* PP, const orc_body* B, const double p[3], const double q[4], double v[3], double w[3]) {
+  const orc_world* W = &PP->world;
+  double pts[ORC_MAX_CONTACTS][3], depth[ORC_MAX_CONTACTS];
+  const int n = orc_contact_points(PP, p, q, pts, depth);
+  if (n == 0) return 0.0;
+  double R[3][3], Iw[3][3], tmp[3][3];
+  orc_matrix_from_quat(q, R);
+  for (int i = 0; i < 3; ++i) /* R I^-1 R^T */
+    for (int j = 0; j < 3; ++j) { tmp[i][j] = 0; for (int k = 0; k < 3; ++k) tmp[i][j] += R[i][k] * B->I_inv[k][j]; }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { Iw[i][j] = 0; for (int k = 0; k < 3; ++k) Iw[i][j] += tmp[i][k] * R[j][k]; }
+  double cw[3], vc[3], t[3];
+  matvec(R, B->com, cw);
+  cross3(w, cw, t);
+  for (int i = 0; i < 3; ++i) vc[i] = v[i] + t[i]; /* COM velocity */
+  const double im = 1.0 / B->mass;
+  double lam[ORC_MAX_CONTACTS][3], vn0[ORC_MAX_CONTACTS], arm[ORC_MAX_CONTACTS][3], dmax = 0.0;
+  for (int c = 0; c < n; ++c) {
+    for (int i = 0; i < 3; ++i) { arm[c][i] = pts[c][i] - (p[i] + cw[i]); lam[c][i] = 0.0; }
+    cross3(w, arm[c], t);
+    vn0[c] = vc[2] + t[2];
+    if (depth[c] > dmax) dmax = depth[c];
+  }
+  static const double dir[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}}; /* normal, friction x, friction y */
+  for (int it = 0; it < W->contact_iters; ++it) {
+    for (int c = 0; c < n; ++c) {
+      for (int d = 0; d < 3; ++d) {
+        double rxd[3], ang[3], axr[3], u[3];
+        cross3(arm[c], dir[d], rxd);
+        matvec(Iw, rxd, ang);
+        cross3(ang, arm[c], axr);
+        const double k = im + dot3(dir[d], axr);
+        cross3(w, arm[c], t);
+        for (int i = 0; i < 3; ++i) u[i] = vc[i] + t[i];
+        double target = 0.0;
+        if (d == 0) target = depth[c] < 0.0 ? depth[c] / W->dt /* speculative: may close the gap, no more */
+                                            : (vn0[c] < 0.0 ? -W->contact_restitution * vn0[c] : 0.0);
+        double dl = (target - dot3(u, dir[d])) / k, nl;
+        if (d == 0) {
+          nl = lam[c][0] + dl;
+          if (nl < 0.0) nl = 0.0;
+        } else {
+          const double lim = W->contact_friction * lam[c][0];
+          nl = lam[c][d] + dl;
+          if (nl > lim) nl = lim;
+          if (nl < -lim) nl = -lim;
+        }
+        dl = nl - lam[c][d];
+        lam[c][d] = nl;
+        for (int i = 0; i < 3; ++i) { vc[i] += im * dl * dir[d][i]; w[i] += dl * ang[i]; }
+      }
+    }
+  }
+  cross3(w, cw, t);
+  for (int i = 0; i < 3; ++i) v[i] = vc[i] - t[i];
+  return dmax;
+}
+
+static void rigid_tick_body(const orc_params* PP, const orc_body* P, double p[3], double q[4], double v[3], double w[3],
                             const double F_b[3], const double tau_b[3]) {
+  const orc_world* Wd = &PP->world;
   const double dt = Wd->dt;
   double R[3][3];
   orc_matrix_from_quat(q, R);
@@ -282,8 +377,11 @@ static void rigid_tick_body(const orc_world* Wd, const orc_body* P, double p[3],
   const double vmax = Wd->max_coord_vel;
   for (int i = 0; i < 3; ++i) w[i] = clipd(w[i] + wdot[i] * dt, -vmax, vmax);
   for (int i = 0; i < 3; ++i) v[i] = clipd(v[i] + a[i] * dt, -vmax, vmax);
+  /* constraint solve: contacts found at the pre-integration pose act on the new velocities */
+  const double deepest = Wd->contact_response ? contact_solve(PP, P, p, q, v, w) : 0.0;
   /* x += v dt (semi-implicit Euler: new velocity) */
   for (int i = 0; i < 3; ++i) p[i] += dt * v[i];
+  if (deepest > 0.0) p[2] += Wd->contact_erp * deepest; /* penetration recovery, position level */
   /* q <- exp(w dt / 2) * q with world-frame w, then normalise */
   double fAngle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   if (fAngle * dt > 0.25 * PI) fAngle = 0.25 * PI / dt; /* ANGULAR_MOTION_THRESHOLD */
@@ -500,6 +598,7 @@ static void world_defaults(orc_world* W) {
   W->gravity_z = -9.81;      /* aviary.py:226 */
   W->use_gyro_term = 1;      /* [BULLET-FROM-MEMORY] */
   W->max_coord_vel = 100.0;  /* [BULLET-FROM-MEMORY] */
+  W->contact_response = 1; W->contact_restitution = 0.0; W->contact_friction = 0.5; W->contact_erp = 0.2; W->contact_iters = 10; W->contact_margin = 0.02; /* [BULLET-FROM-MEMORY] defaults */
   W->plane_half_xy = 15.0;   /* [BULLET-FROM-MEMORY] pybullet_data plane.urdf */
   W->plane_half_z = 5.0;
   W->ticks_per_control = 2;  /* 240/120, quadx.py:27-28 */
@@ -1055,7 +1154,7 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
     }
     /* stepSimulation: collision detection at the pre-integration pose, then the free-body tick */
     L->contact_now = orc_contact_plane(P, L->p, L->q);
-    if (P->vehicle == ORC_ROCKET) rigid_tick_body(&P->world, &rocket_body, L->p, L->q, L->v, L->w, F_b, T_b);
+    if (P->vehicle == ORC_ROCKET) rigid_tick_body(P, &rocket_body, L->p, L->q, L->v, L->w, F_b, T_b);
     else orc_rigid_tick(P, L->p, L->q, L->v, L->w, F_b, T_b);
     orc_update_state(P, L);
     if (L->contact_now) L->contact_step = 1; /* :523-525 */

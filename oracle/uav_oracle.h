@@ -43,6 +43,22 @@ typedef struct {
   double plane_half_xy;      /* plane.urdf collision box 30x30x10 -> 15 * world_scale */
   double plane_half_z;       /* 5 * world_scale; box centre at z = -plane_half_z */
   int ticks_per_control;     /* physics_hz / control_hz = 2, base_drone.py:102 */
+  /* Contact RESPONSE against the ground slab (aviary.py:516 stepSimulation, the part after collision detection).
+   * [BULLET-FROM-MEMORY], a named-parameter model, NOT Bullet's btMultiBodyConstraintSolver digit for digit:
+   * contact points = the collider vertices (box corners; 8 rim points on either end disc of a cylinder) found at
+   * or below the slab's top face at the pre-integration pose; projected Gauss-Seidel over them at the velocity level
+   * (normal impulse >= 0 towards restitution * approach speed, two world-axis friction directions clamped to
+   * friction * normal impulse), contact_iters sweeps in collider / vertex order; then, after the position update, a
+   * translation of contact_erp * (deepest penetration) along +z (Bullet's split-impulse style recovery: no energy
+   * is injected). Bullet's defaults: restitution 0, lateral friction 0.5 (body) x 1.0 (plane.urdf), erp 0.2. */
+  int contact_response;      /* 1: solve contacts (default); 0: detection only, bodies pass through the floor */
+  double contact_restitution, contact_friction, contact_erp;
+  int contact_iters;
+  /* speculative margin: vertices up to this far ABOVE the face are in the contact set too, with the constraint
+   * "do not close more than the gap in this tick" (normal velocity >= -gap / dt). It binds only when the vertex would
+   * otherwise penetrate within the tick, and it keeps the vertices of a resting body in the active set instead of
+   * letting them drop in and out of it (Bullet's contact breaking threshold plays this role: 0.02 m). */
+  double contact_margin;
 } orc_world;
 
 typedef struct {
@@ -220,6 +236,11 @@ int orc_box_box_overlap(const double ca[3], const double Ra[3][3], const double 
                         const double cb[3], const double hb[3]);
 void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], double w[3],
                     const double F_b[3], const double tau_b[3]);
+/* contact vertices of the body at pose (p, q) that lie at or below the slab's top face: world positions and
+ * penetration depths (negative = gap of a speculative contact), in collider / vertex order; returns their number
+ * (<= ORC_MAX_CONTACTS) */
+#define ORC_MAX_CONTACTS 48 /* same cap as the device code (PF_MAX_CONTACTS): vertices past it are ignored */
+int orc_contact_points(const orc_params* P, const double p[3], const double q[4], double pts[][3], double depth[]);
 
 /* ---------- RNG (same integer stream as the device) ---------- */
 void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);

@@ -23,6 +23,7 @@
 #pragma once
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
+#include "uav_vehicles.hpp"  // contact_solve_dev
 
 namespace pf {
 
@@ -88,7 +89,7 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
   Bd.dt = P.dt; Bd.half_dt = 0.5f * P.dt; Bd.gravity_z = P.gravity_z; Bd.vmax = P.max_coord_vel; Bd.inv_mass = P.inv_mass;
   for (int k = 0; k < 6; ++k) { Bd.H[k] = P.I_pa[k] + (P.use_gyro_term ? P.I_own[k] : 0.f); Bd.iI[k] = P.I_inv[k]; }
   for (int k = 0; k < 3; ++k) Bd.com[k] = P.has_com_offset ? P.com[k] : 0.f;
-  Bd.bound_radius = P.bound_radius;
+  Bd.bound_radius = P.bound_radius + (P.contact_response ? P.contact_margin : 0.0f);  // floor-code gate incl. the speculative contact margin
   Bd.m_a = P.motor_dt_over_tau[0]; Bd.m_noise = P.motor_noise[0]; Bd.fmax = P.motor_fmax[0]; Bd.tmax = P.motor_tmax[0];
   for (int k = 0; k < 7; ++k) Bd.pad[k] = 0.f;
   K.dome2 = P.dome * P.dome; K.goal_reach = P.goal_reach_distance; K.min_height = P.min_height;
@@ -275,7 +276,16 @@ struct FwHot {
     a = a - cross(wd, cw) - cross(w, cross(w, cw));
     w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
     v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
-    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z)};
+    float lift = 0.0f;  // contact response (see quadx_fast.hpp / uav_vehicles.hpp:contact_solve_dev)
+    if (__any(near)) {
+      if (near && Pfull->contact_response) {
+        const ContactOut o = contact_solve_dev(Pfull, p, q, v, w, Pfull->inv_mass, com, Pfull->I_inv[0], Pfull->I_inv[1], Pfull->I_inv[2],
+                                               Pfull->I_inv[3], Pfull->I_inv[4], Pfull->I_inv[5]);
+        v = o.v; w = o.w;
+        lift = Pfull->contact_erp * o.deepest;
+      }
+    }
+    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, K.half_dt);
     derive();
     contact_step |= contact_now;

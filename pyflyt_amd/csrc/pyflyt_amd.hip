@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   constexpr bool kSide = (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER);
 
   VEH V;
+  V.b.pdev = Pdev;
   V.bind(ktab);
   SideBlock tg;
   float new_dist;
@@ -410,6 +411,7 @@ __global__ void settle_template_kernel(const pf_params P, float4* tmpl, const pf
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   VEH V;
+  V.b.pdev = Pdev;
   V.bind(ktab);
   float sp[6] = {0, 0, 0, 0, 0, 0};
   V.reset(P, nullptr, sp);
@@ -428,6 +430,7 @@ __global__ void __launch_bounds__(kWave) aviary_reset_kernel(const pf_params P, 
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   VEH V;
+  V.b.pdev = nullptr;  // (no tick in this kernel)
   float sp[8];
   V.reset(P, pose ? pose + (size_t)lane * 7 : nullptr, sp, B.start_vel ? B.start_vel + (size_t)lane * 3 : nullptr);
   float4* S = reinterpret_cast<float4*>(B.state);
@@ -458,6 +461,7 @@ __global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params 
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   VEH V;
+  V.b.pdev = nullptr;  // (no tick in this kernel)
   float nd;
   int4 ints;
   // load everything (old mode 7 == all groups), re-initialise the controllers, store everything
@@ -486,6 +490,7 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   if (lane >= n) return;
   const size_t li = lane, N = n;
   VEH V;
+  V.b.pdev = Pdev;
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -558,6 +563,7 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   constexpr bool kQuad = VEH::AUX == 4;
   constexpr int kCmdGroup = 12;
   VEH V;
+  V.b.pdev = Pdev;
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -620,11 +626,13 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
 // applyExternalForce / applyExternalTorque on the base link (LINK_FRAME) + stepSimulation, n_ticks times
 // (pf_body_tick): the free-body tick by itself, for the integrator's known-answer tests.
 template <class VEH>
-__global__ void __launch_bounds__(kWave) body_tick_kernel(const pf_params P, const pf_buffers B, const int n, const int n_ticks) {
+__global__ void __launch_bounds__(kWave) body_tick_kernel(const pf_params P, const pf_buffers B, const int n, const int n_ticks,
+                                                          const pf_params* __restrict__ Pdev) {
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   const size_t li = lane, N = n;
   VEH V;
+  V.b.pdev = Pdev;
   float nd;
   int4 ints;
   float4* S = reinterpret_cast<float4*>(B.state);
@@ -975,9 +983,9 @@ int pf_body_tick(pf_ctx* ctx, const pf_buffers* b, int n_ticks, void* stream) {
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
   hipStream_t s = (hipStream_t)stream;
   if (ctx->P.vehicle == PF_QUADX)
-    hipLaunchKernelGGL(pf::body_tick_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, n_ticks);
+    hipLaunchKernelGGL(pf::body_tick_kernel<pf::QuadX>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, n_ticks, ctx->P_dev);
   else
-    hipLaunchKernelGGL(pf::body_tick_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, n_ticks);
+    hipLaunchKernelGGL(pf::body_tick_kernel<pf::Fixedwing>, dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, n_ticks, ctx->P_dev);
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;
 }

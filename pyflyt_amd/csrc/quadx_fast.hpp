@@ -20,6 +20,7 @@
 
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
+#include "uav_vehicles.hpp"  // contact_solve_dev
 
 namespace pf {
 
@@ -82,7 +83,8 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.I[0] = P.I_own[0]; K.I[1] = P.I_own[3]; K.I[2] = P.I_own[5];
   K.iI[0] = P.I_inv[0]; K.iI[1] = P.I_inv[3]; K.iI[2] = P.I_inv[5];
   K.use_gyro = P.use_gyro_term ? 1.f : 0.f;
-  K.bound_radius = P.bound_radius;
+  // gate of the out-of-line floor code: within one bounding radius of the floor, widened by the speculative contact margin
+  K.bound_radius = P.bound_radius + (P.contact_response ? P.contact_margin : 0.0f);
   K.m_a = P.motor_dt_over_tau[0]; K.m_noise = P.motor_noise[0]; K.fmax = P.motor_fmax[0]; K.tmax = P.motor_tmax[2];
   for (int i = 0; i < 4; ++i) { K.ryf[i] = P.motor_r[i][1] * P.motor_fmax[0]; K.rxf[i] = -P.motor_r[i][0] * P.motor_fmax[0]; }
   for (int k = 0; k < 3; ++k) {
@@ -112,7 +114,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   // level spawn at rest, far enough above the floor that the settle free-fall cannot touch it
   const float fall = 0.5f * 9.81f * (P.settle_steps * P.ticks_per_control * P.dt) * (P.settle_steps * P.ticks_per_control * P.dt);
   K.fast_settle = (P.start_quat[0] == 0.f && P.start_quat[1] == 0.f && P.start_vel[0] == 0.f && P.start_vel[1] == 0.f &&
-                   P.start_vel[2] == 0.f && P.start_pos[2] - 2.0f * fall - 0.05f > P.bound_radius && P.gravity_z < 0.f)
+                   P.start_vel[2] == 0.f && P.start_pos[2] - 2.0f * fall - 0.05f > K.bound_radius && P.gravity_z < 0.f)
                       ? 1 : 0;
   return K.fast_settle != 0;  // the hot kernel only implements the level-spawn settle recurrence
 }
@@ -213,7 +215,18 @@ struct QuadHot {
          fmaf(R.m20, Fm.x, fmaf(R.m21, Fm.y, fmaf(R.m22, Fm.z, K.gravity_z)))};
     w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
     v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
-    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z)};
+    // contact response (the constraint solve of stepSimulation) for lanes within one bounding radius of the floor:
+    // out of line, with its constants read from the device parameter block inside the rare path
+    float lift = 0.0f;
+    if (__any(near)) {
+      if (near && Pfull->contact_response) {
+        const ContactOut o = contact_solve_dev(Pfull, p, q, v, w, Pfull->inv_mass, v3{0.f, 0.f, 0.f}, Pfull->I_inv[0], Pfull->I_inv[1],
+                                               Pfull->I_inv[2], Pfull->I_inv[3], Pfull->I_inv[4], Pfull->I_inv[5]);
+        v = o.v; w = o.w;
+        lift = Pfull->contact_erp * o.deepest;
+      }
+    }
+    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, K.half_dt);
     derive();
     contact_step |= contact_now;

@@ -47,6 +47,101 @@ PF_DEV float pid1(float kp, float ki, float kd, float lim, float T, float invT, 
   return clampf(kp * e + I + d, -lim, lim);
 }
 
+// ------------------------------------------------------------------------------------------
+// Contact response against the ground slab: what stepSimulation does after collision detection, as the
+// named-parameter model documented at pf_params.contact_response (oracle/uav_oracle.c:contact_solve is the fp64
+// restatement, oracle/fake_bullet.py:_solve_contacts the independent second one). Contact vertices at or below
+// the slab's top face at the pre-integration pose (p, q); contact_iters projected Gauss-Seidel sweeps on the COM
+// velocity / angular velocity (world frame); returns the new base twist and the deepest penetration.
+// Out of line on purpose: it runs only for lanes within one bounding radius of the floor, its per-contact arrays
+// are dynamically indexed (scratch memory), and that frame must not leak into the callers' register allocation.
+struct ContactOut {
+  v3 v, w;
+  float deepest;
+};
+__device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict__ P, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
+                                                     float i0, float i1, float i2, float i3, float i4, float i5) {
+  float armx[PF_MAX_CONTACTS], army[PF_MAX_CONTACTS], armz[PF_MAX_CONTACTS];
+  float ln[PF_MAX_CONTACTS], lx[PF_MAX_CONTACTS], ly[PF_MAX_CONTACTS], vn0[PF_MAX_CONTACTS], dep[PF_MAX_CONTACTS];
+  const m3 R = rot_from_quat(q);
+  const v3 cw = mul(R, com);
+  const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin;
+  const float inv_dt = 1.0f / P->dt;
+  int n = 0;
+  float deepest = 0.0f;
+  for (int k = 0; k < P->n_boxes; ++k) {
+    const pf_box b = P->boxes[k];
+    float sy = 0.0f, cy = 1.0f;
+    if (b.yaw != 0.0f) sincosf(b.yaw, &sy, &cy);
+    const int nv = b.kind == 1 ? 16 : 8;
+    for (int i = 0; i < nv; ++i) {
+      float l0, l1, l2;
+      if (b.kind == 1) {  // end disc -z then +z, rim point j at j * 45 degrees from the link x axis
+        const int j = i & 7;
+        const float c45 = (j == 0) ? 1.0f : ((j == 4) ? -1.0f : ((j == 2 || j == 6) ? 0.0f : ((j == 1 || j == 7) ? 0.70710678f : -0.70710678f)));
+        const int js = (j + 6) & 7;
+        const float s45 = (js == 0) ? 1.0f : ((js == 4) ? -1.0f : ((js == 2 || js == 6) ? 0.0f : ((js == 1 || js == 7) ? 0.70710678f : -0.70710678f)));
+        l0 = b.h[0] * c45; l1 = b.h[0] * s45; l2 = (i >> 3) ? b.h[2] : -b.h[2];
+      } else {
+        l0 = (i & 1) ? b.h[0] : -b.h[0]; l1 = (i & 2) ? b.h[1] : -b.h[1]; l2 = (i & 4) ? b.h[2] : -b.h[2];
+      }
+      const v3 bl{b.c[0] + cy * l0 - sy * l1, b.c[1] + sy * l0 + cy * l1, b.c[2] + l2};
+      const v3 off = mul(R, bl);
+      const v3 x = p + off;
+      if (n < PF_MAX_CONTACTS && x.z <= margin && x.z >= -hz2 && __builtin_fabsf(x.x) <= hxy && __builtin_fabsf(x.y) <= hxy) {
+        const v3 a = off - cw;
+        armx[n] = a.x; army[n] = a.y; armz[n] = a.z;
+        ln[n] = lx[n] = ly[n] = 0.0f;
+        dep[n] = -x.z;
+        deepest = __builtin_fmaxf(deepest, -x.z);
+        ++n;
+      }
+    }
+  }
+  ContactOut out{v, w, deepest};
+  if (n == 0) return out;
+  // world-frame inverse inertia R I^-1 R^T (symmetric)
+  const float Ii[6] = {i0, i1, i2, i3, i4, i5};
+  const v3 c0 = symmul(Ii, v3{R.m00, R.m01, R.m02}), c1 = symmul(Ii, v3{R.m10, R.m11, R.m12}), c2 = symmul(Ii, v3{R.m20, R.m21, R.m22});
+  // rows of R dotted with the columns above: Iw[a][b] = row_a(R) . (I^-1 row_b(R)^T)
+  const float w00 = dot(v3{R.m00, R.m01, R.m02}, c0), w01 = dot(v3{R.m00, R.m01, R.m02}, c1), w02 = dot(v3{R.m00, R.m01, R.m02}, c2);
+  const float w11 = dot(v3{R.m10, R.m11, R.m12}, c1), w12 = dot(v3{R.m10, R.m11, R.m12}, c2), w22 = dot(v3{R.m20, R.m21, R.m22}, c2);
+  const float Iw[6] = {w00, w01, w02, w11, w12, w22};
+  v3 vc = v + cross(w, cw);
+  for (int c = 0; c < n; ++c) vn0[c] = vc.z + cross(w, v3{armx[c], army[c], armz[c]}).z;
+  const float mu = P->contact_friction, rest = P->contact_restitution;
+  for (int it = 0; it < P->contact_iters; ++it) {
+    for (int c = 0; c < n; ++c) {
+      const v3 a{armx[c], army[c], armz[c]};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {  // normal +z, friction +x, friction +y
+        const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
+        const v3 ang = symmul(Iw, cross(a, dir));
+        const float kk = inv_mass + dot(dir, cross(ang, a));
+        const v3 u = vc + cross(w, a);
+        float target = 0.0f;
+        if (d == 0) target = dep[c] < 0.0f ? dep[c] * inv_dt  // speculative: may close the gap, no more
+                                           : (vn0[c] < 0.0f ? -rest * vn0[c] : 0.0f);
+        float dl = (target - dot(u, dir)) / kk, nl;
+        float* acc = d == 0 ? &ln[c] : (d == 1 ? &lx[c] : &ly[c]);
+        if (d == 0) {
+          nl = __builtin_fmaxf(*acc + dl, 0.0f);
+        } else {
+          const float lim = mu * ln[c];
+          nl = __builtin_fminf(__builtin_fmaxf(*acc + dl, -lim), lim);
+        }
+        dl = nl - *acc;
+        *acc = nl;
+        vc = vc + (inv_mass * dl) * dir;
+        w = w + dl * ang;
+      }
+    }
+  }
+  out.w = w;
+  out.v = vc - cross(w, cw);
+  return out;
+}
+
 // Rigid body shared by both vehicles: the Bullet base state + what update_state derives from it.
 struct Body {
   v3 p;
@@ -106,10 +201,21 @@ struct Body {
     const float dt = P.dt, vm = P.max_coord_vel;
     w = v3{clampf(fmaf(wdot.x, dt, w.x), -vm, vm), clampf(fmaf(wdot.y, dt, w.y), -vm, vm), clampf(fmaf(wdot.z, dt, w.z), -vm, vm)};
     v = v3{clampf(fmaf(a.x, dt, v.x), -vm, vm), clampf(fmaf(a.y, dt, v.y), -vm, vm), clampf(fmaf(a.z, dt, v.z), -vm, vm)};
-    p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z)};
+    const float lift = respond(Pdev_of(P), P.inv_mass, P.has_com_offset ? com : v3{0.f, 0.f, 0.f}, P.I_inv);
+    p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, 0.5f * dt);
     derive();
     contact_step |= contact_now;
+  }
+  // constraint solve of stepSimulation: contacts found at the pre-integration pose act on the new velocities; returns the
+  // position-level penetration recovery (contact_erp x deepest penetration) to add to z after the position update
+  const pf_params* pdev;  // device copy of the parameter block (the out-of-line contact solver reads the colliders from it)
+  PF_DEV const pf_params* Pdev_of(const pf_params&) const { return pdev; }
+  PF_DEV float respond(const pf_params* Pd, float inv_mass, v3 com, const float Iinv[6]) {
+    if (Pd == nullptr || !Pd->contact_response || (p.z - Pd->bound_radius) > Pd->contact_margin) return 0.0f;
+    const ContactOut o = contact_solve_dev(Pd, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
+    v = o.v; w = o.w;
+    return Pd->contact_erp * o.deepest;
   }
   // The same tick for a body whose mass properties change over time (Rocket): inverse mass, centre of
   // mass, gyroscopic inertia H and inverse inertia (symmetric xx xy xz yy yz zz) are arguments.
@@ -126,7 +232,8 @@ struct Body {
     const float dt = P.dt, vm = P.max_coord_vel;
     w = v3{clampf(fmaf(wdot.x, dt, w.x), -vm, vm), clampf(fmaf(wdot.y, dt, w.y), -vm, vm), clampf(fmaf(wdot.z, dt, w.z), -vm, vm)};
     v = v3{clampf(fmaf(a.x, dt, v.x), -vm, vm), clampf(fmaf(a.y, dt, v.y), -vm, vm), clampf(fmaf(a.z, dt, v.z), -vm, vm)};
-    p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z)};
+    const float lift = respond(pdev, inv_mass, com, Iinv);
+    p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, 0.5f * dt);
     derive();
     contact_step |= contact_now;

@@ -191,6 +191,15 @@ WORLD: dict[str, Any] = {
     "max_coord_vel": 100.0,    # btMultiBody::m_maxCoordinateVelocity
     "plane_half_xy": 15.0,     # pybullet_data plane.urdf collision box 30 x 30 x 10, centre z = -5
     "plane_half_z": 5.0,
+    # contact response against that slab: a named-parameter model of what stepSimulation does after collision detection
+    # (vertex contacts, projected Gauss-Seidel at the velocity level, position-level penetration recovery; DESIGN.md
+    # section 3), with Bullet's defaults: restitution 0, lateral friction 0.5 (body) x 1.0 (plane.urdf), erp 0.2
+    "contact_response": True,
+    "contact_restitution": 0.0,
+    "contact_friction": 0.5,
+    "contact_erp": 0.2,
+    "contact_iters": 10,
+    "contact_margin": 0.02,    # speculative contacts (Bullet's contact breaking threshold)
 }
 
 
@@ -215,9 +224,12 @@ def _fill(arr, vals):
         arr[i] = v
 
 
-def _set_body(P, links, own_inertia, boxes, cylinders=(), yawed_boxes=()):
+def _set_body(P, links, own_inertia, boxes, cylinders=(), yawed_boxes=(), cylinders_first=False):
     """links: [(mass, r)], own_inertia: 3x3 sum of link inertias (base frame, about their own COMs).
-    boxes: [(centre, size)]; cylinders: [(centre, radius, length)], axis = link z; yawed_boxes: [(centre, size, yaw)]."""
+    boxes: [(centre, size)]; cylinders: [(centre, radius, length)], axis = link z; yawed_boxes: [(centre, size, yaw)].
+    The shapes are stored in the URDF's link order (the contact solver sweeps its contact vertices in that order, and a
+    Gauss-Seidel sweep is order dependent): boxes then cylinders (primitive_drone.urdf: base box, four prop discs), or
+    cylinders first (rocket.urdf: body and booster cylinders, then the fin boxes, then the legs)."""
     m = np.array([l[0] for l in links], dtype=np.float64)
     r = np.array([l[1] for l in links], dtype=np.float64)
     M = m.sum()
@@ -237,8 +249,9 @@ def _set_body(P, links, own_inertia, boxes, cylinders=(), yawed_boxes=()):
         raise ValueError(f"at most {L.PF_MAX_BOXES} collision shapes per vehicle")
     P.n_boxes = len(boxes) + len(cylinders) + len(yawed_boxes)
     rad = 0.0
-    shapes = [(c, 0.5 * np.array(size, dtype=np.float64), 0, 0.0) for c, size in boxes] + \
-             [(c, np.array([r, r, 0.5 * length], dtype=np.float64), 1, 0.0) for c, r, length in cylinders] + \
+    sb = [(c, 0.5 * np.array(size, dtype=np.float64), 0, 0.0) for c, size in boxes]
+    sc = [(c, np.array([r, r, 0.5 * length], dtype=np.float64), 1, 0.0) for c, r, length in cylinders]
+    shapes = (sc + sb if cylinders_first else sb + sc) + \
              [(c, 0.5 * np.array(size, dtype=np.float64), 0, float(yaw)) for c, size, yaw in yawed_boxes]
     for k, (c, h, kind, yaw) in enumerate(shapes):
         _fill(P.boxes[k].c, c)
@@ -296,6 +309,11 @@ def build_params(
     P.use_gyro_term = int(bool(W["use_gyro_term"]))
     P.plane_half_xy = W["plane_half_xy"] * W["world_scale"]
     P.plane_half_z = W["plane_half_z"] * W["world_scale"]
+    # contact response against the ground slab (named-parameter model; Bullet's defaults)
+    P.contact_response = int(bool(W["contact_response"]))
+    P.contact_restitution, P.contact_friction, P.contact_erp = W["contact_restitution"], W["contact_friction"], W["contact_erp"]
+    P.contact_iters = int(W["contact_iters"])
+    P.contact_margin = W["contact_margin"] * W["world_scale"]
     P.settle_steps = 10  # gym_envs/quadx_envs/quadx_base_env.py:209
 
     if vehicle == "quadx":
@@ -384,7 +402,8 @@ def build_params(
         P.vehicle = L.ROCKET
         links = V["links"]
         own = np.diag(np.sum([l[2] for l in links], axis=0)).astype(np.float64)
-        _set_body(P, [(l[0], l[1]) for l in links], own, V["collision_boxes"], V["collision_cylinders"], V["collision_boxes_yawed"])
+        _set_body(P, [(l[0], l[1]) for l in links], own, V["collision_boxes"], V["collision_cylinders"], V["collision_boxes_yawed"],
+                  cylinders_first=True)
         P.n_motors = 1  # np_random.normal(*throttle.shape) with one booster: xi ~ N(1, 1) (boosters.py:236-240)
         K = P.rocket
         ft, bo = V["fueltank_link"], V["booster_link"]

@@ -142,7 +142,7 @@ def wind_from_coef(c):
     return wind
 
 
-def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True, drone_options=None, wind=None):
+def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True, drone_options=None, wind=None, hold_setpoint=None):
     """wind: None | "register" (Aviary.register_wind_field_function after construction, as
     tests/test_core.py:266-296 does: the first tick still sees wind-free velocities) | "ctor"
     (wind_type=<class>, as tests/test_core.py:299-340: the wind is sampled in reset())."""
@@ -169,8 +169,11 @@ def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True
     states, auxs, sps, xis, contacts = [], [], [], [], []
     init_state, init_aux, init_sp = env.state(0).copy(), env.aux_state(0).copy(), env.drones[0].setpoint.copy()
     sp = np.array(env.drones[0].setpoint, dtype=np.float64).copy()
+    if hold_setpoint is not None:
+        sp = np.array(hold_setpoint, dtype=np.float64)
+        env.set_setpoint(0, sp.copy())
     for k in range(n_steps):
-        if k % 25 == 10:
+        if k % 25 == 10 and hold_setpoint is None:
             if drone_type == "quadx":
                 if mode == -1:
                     sp = rng.uniform(0.1, 0.6, size=4)
@@ -256,6 +259,19 @@ def gen_rocket():
     d = run_aviary("rocket", 0, 150, seed=502, start_pos=[0.0, 0.0, 4.0], start_orn=[0.4, 0.1, 0.0], noise=False,
                    drone_options=dict(starting_fuel_ratio=0.0))
     save("aviary_rocket_drop", **d)
+
+
+def gen_landing():
+    # landings with the motors off: the contact RESPONSE (impulses, friction, penetration recovery) from first touch to rest
+    d = run_aviary("quadx", -1, 250, seed=31, start_pos=[0.1, -0.1, 0.2], start_orn=[0.2, -0.1, 0.5], noise=False, hold_setpoint=[0, 0, 0, 0])
+    save("aviary_quadx_land", **d)
+    d = run_aviary("quadx", -1, 300, seed=32, start_pos=[0.0, 0.0, 0.4], start_orn=[0.6, 0.3, 0.0], noise=False,
+                   drone_options=dict(drone_model="primitive_drone"), hold_setpoint=[0, 0, 0, 0])
+    save("aviary_primitive_land", **d)
+    # the Rocket settling on its three legs (rocket.urdf:208-277), engine off, tank empty
+    d = run_aviary("rocket", 0, 450, seed=33, start_pos=[0.0, 0.0, 2.8], start_orn=[0.03, -0.02, 0.4], noise=False,
+                   drone_options=dict(starting_fuel_ratio=0.0), hold_setpoint=[0, 0, 0, 0, 0, 0, 0])
+    save("aviary_rocket_land", **d)
 
 
 def gen_wind():
@@ -432,6 +448,7 @@ if __name__ == "__main__":
     gen_envs()
     gen_envs_crash()
     gen_envs_yaw()
+    gen_landing()
     gen_ma_hover()
     gen_wind()
     gen_primitive()

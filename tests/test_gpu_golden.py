@@ -195,8 +195,12 @@ AVIARY = {
     "aviary_acrowing_mode0": None, "aviary_acrowing_modem1": None,
     "aviary_quadx_drop": None, "aviary_fixedwing_drop": None, "aviary_primitive_drop": None,
     "aviary_rocket_default_fuel": None, "aviary_rocket_fuel60": None, "aviary_rocket_drop": None,
+    # landings with the motors off, first touch to rest: the contact response (vertex contacts, Gauss-Seidel sweeps,
+    # friction, penetration recovery) in fp32 against the reference-on-fake-Bullet recording
+    "aviary_quadx_land": None, "aviary_primitive_land": None, "aviary_rocket_land": None,
 }
-ROCKET_FUEL = {"aviary_rocket_default_fuel": 0.05, "aviary_rocket_fuel60": 0.6, "aviary_rocket_drop": 0.0, "aviary_rocket_wind_ctor": 0.3}
+ROCKET_FUEL = {"aviary_rocket_default_fuel": 0.05, "aviary_rocket_fuel60": 0.6, "aviary_rocket_drop": 0.0, "aviary_rocket_wind_ctor": 0.3,
+               "aviary_rocket_land": 0.0}
 
 
 def aviary_engine(name, g):

@@ -256,3 +256,73 @@ def test_hot_kernel_integrator_free_fall_and_clamp():
     for k in range(20):
         obs, *_ = e.env_step(a)
     assert (obs[:, 9] == -kat.VMAX).all()  # body-frame vz of a level drone == world vz, clamped
+
+
+# ------------------------------------------------------------------ contact response (the same known answers as the oracle's)
+def test_contact_drop_comes_to_rest_at_half_height():
+    """tests/test_oracle_kat.py::test_contact_drop_comes_to_rest_at_half_height on the device: level and tilted quads
+    dropped with the motors off end ON the floor, z = half the collision box's height (0.01), at rest, never below it."""
+    from pyflyt_amd.core import Aviary
+
+    n = 128
+    rng = np.random.default_rng(3)
+    pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(0.15, 0.4, size=(n, 1))], axis=1)
+    orn = np.concatenate([rng.uniform(-0.6, 0.6, size=(n, 2)), rng.uniform(-3, 3, size=(n, 1))], axis=1)
+    orn[:16] = 0.0  # level drops
+    env = Aviary(pos, orn, "quadx", motor_noise=False)
+    env.set_mode(-1)
+    env.set_all_setpoints(np.zeros((n, 4)))
+    zmin = np.full(n, np.inf)
+    touched = np.zeros(n, dtype=bool)
+    for k in range(360):
+        env.step()
+        z = env.engine.state[0, :, 2].cpu().numpy()
+        touched |= env.contact_array.cpu().numpy()
+        zmin = np.minimum(zmin, z)
+    st = env.all_states.double().cpu().numpy()
+    assert touched.all()
+    assert np.abs(st[:, 3, 2] - 0.01).max() < 2e-5, np.abs(st[:, 3, 2] - 0.01).max()      # rests at half-height
+    assert zmin.min() > 0.0099, zmin.min()                                                 # never below the floor
+    assert np.abs(st[:, 1, :2]).max() < 1e-3 and np.abs(st[:, 0]).max() < 1e-2 and np.abs(st[:, 2]).max() < 1e-3  # flat, at rest
+    assert np.abs(st[:16, 3, :2] - pos[:16, :2]).max() < 1e-4  # the level drops did not move sideways
+    env.disconnect()
+
+
+def test_rocket_settles_on_its_legs():
+    from pyflyt_amd.core import Aviary
+
+    n = 64
+    rng = np.random.default_rng(4)
+    pos = np.concatenate([rng.uniform(-2, 2, size=(n, 2)), rng.uniform(2.6, 3.0, size=(n, 1))], axis=1)
+    orn = np.concatenate([rng.uniform(-0.03, 0.03, size=(n, 2)), rng.uniform(-3, 3, size=(n, 1))], axis=1)
+    env = Aviary(pos, orn, "rocket", motor_noise=False, drone_options=dict(starting_fuel_ratio=0.0))
+    env.set_mode(0)
+    env.step(n_steps=1500)
+    st = env.all_states.double().cpu().numpy()
+    assert np.abs(st[:, 3, 2] - 2.425).max() < 1e-3 and np.abs(st[:, 1, :2]).max() < 2e-3  # standing on the legs (rocket.urdf:208-277), upright
+    assert np.abs(st[:, 2]).max() < 2e-2 and np.abs(st[:, 0]).max() < 2e-2
+    env.disconnect()
+
+
+def test_contact_friction_stops_a_slide():
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    n = 64
+    out = {}
+    for mu in (0.5, 0.0):
+        P = build_params("quadx", "none", noise="off", autoreset="off", world_options=dict(contact_friction=mu))
+        eng = BatchEngine(P, n, device=DEV)
+        eng.start_vel = torch.tensor(np.tile([[1.0, 0.0, 0.0]], (n, 1)), dtype=torch.float32, device=DEV)
+        pose = torch.zeros(n, 7, device=DEV)
+        pose[:, 2] = 0.0101
+        pose[:, 6] = 1.0
+        eng.aviary_reset(pose.contiguous())
+        sp = torch.zeros(n, 4, device=DEV)
+        eng.aviary_set_mode(-1, sp)
+        sp.zero_()
+        eng.aviary_step(sp, 120)
+        out[mu] = (eng.state[0, :, 0].double().cpu().numpy(), eng.state[2, :, 0].double().cpu().numpy())
+    x, vx = out[0.5]
+    assert np.abs(x - 1.0 / (2 * 0.5 * kat.G)).max() < 0.1 * 0.102 and np.abs(vx).max() < 1e-3  # stops after v^2 / (2 mu g)
+    assert np.abs(out[0.0][1] - (1.0 - 7.35e-4 / kat.MASS)).max() < 2e-3  # frictionless: only the body drag slows it

@@ -90,7 +90,8 @@ def lane_state(L, fixedwing):
 AVIARY = [f"aviary_quadx_mode{m}" for m in ["m1", 0, 1, 2, 3, 4, 5, 6, 7, "7_nonoise"]] + \
          ["aviary_fixedwing_mode0", "aviary_fixedwing_modem1"] + \
          [f"aviary_primitive_mode{m}" for m in (0, 6, 7)] + \
-         ["aviary_acrowing_mode0", "aviary_acrowing_modem1"]  # QuadX(drone_model="primitive_drone"), Fixedwing(drone_model="acrowing")
+         ["aviary_acrowing_mode0", "aviary_acrowing_modem1"] + \
+         ["aviary_quadx_land", "aviary_primitive_land"]  # motors off, from first touch to rest: the contact response
 
 
 def model_of(name):
@@ -124,7 +125,9 @@ def test_aviary_trajectory(golden_dir, name):
         err = max(np.abs(st - g["states"][k]).max(), np.abs(aux - g["aux"][k]).max())
         worst = max(worst, err)
         assert bool(L.contact_step) == bool(g["contact"][k])
-    assert worst < TOL, worst
+    # trajectories that touch the floor go through the contact solver's Gauss-Seidel sweeps, where the two independent
+    # formulations (COM-based 3x3 here, 6x6 spatial inertia at the base origin in fake_bullet) round differently
+    assert worst < (1e-8 if g["contact"].any() else TOL), worst
 
 
 def wind_from_coef(c):
@@ -196,8 +199,9 @@ def test_aviary_wind_trajectory(golden_dir, name):
 
 @pytest.mark.parametrize("name", ["aviary_quadx_drop", "aviary_fixedwing_drop", "aviary_primitive_drop"])
 def test_aviary_drop_contact(golden_dir, name):
-    """Fall onto the floor: the contact flag must rise on the same Aviary step as in the
-    reference-on-fake-Bullet run (neither side restates a contact response)."""
+    """Fall onto the floor: the contact flag must rise on the same Aviary step as in the reference-on-fake-Bullet run,
+    and the landing itself -- impulses, friction, penetration recovery, coming to rest -- must match: the contact
+    response is implemented twice, independently (oracle: COM-based; fake_bullet: spatial inertia at the base origin)."""
     g = load(golden_dir, name)
     fw = "fixedwing" in name
     noise = bool(g["noise"])
@@ -218,7 +222,8 @@ def test_aviary_drop_contact(golden_dir, name):
         np.testing.assert_allclose(st, g["states"][k], atol=TOL)
 
 
-@pytest.mark.parametrize("name,fuel", [("aviary_rocket_default_fuel", 0.05), ("aviary_rocket_fuel60", 0.6), ("aviary_rocket_drop", 0.0)])
+@pytest.mark.parametrize("name,fuel", [("aviary_rocket_default_fuel", 0.05), ("aviary_rocket_fuel60", 0.6), ("aviary_rocket_drop", 0.0),
+                                       ("aviary_rocket_land", 0.0)])
 def test_rocket_trajectory(golden_dir, name, fuel):
     """Rocket (drones/rocket.py + boosters.py + gimbals.py): grid fins, gimballed booster with fuel burn
     (the composite mass / centre of mass / inertia are rebuilt every tick, as changeDynamics does in
@@ -251,7 +256,7 @@ def test_rocket_trajectory(golden_dir, name, fuel):
         st, aux = state()
         scale = np.maximum(1.0, np.abs(g["states"][k]))
         worst = max(worst, (np.abs(st - g["states"][k]) / scale).max(), np.abs(aux - g["aux"][k]).max())
-    assert worst < TOL, worst
+    assert worst < (1e-8 if g["contact"].any() else TOL), worst  # (contact solver: see test_aviary_trajectory)
     if "drop" in name:
         assert first_contact < len(g["states"]) and not g["contact"][0]
 

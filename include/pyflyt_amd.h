@@ -129,6 +129,10 @@ typedef struct pf_params {
    * otherwise penetrate within the tick, and keeps a resting body's vertices in the active set (Bullet's contact
    * breaking threshold, 0.02 m, plays this role) */
   float contact_margin;
+  /* allowed penetration: the constraints let a vertex sink contact_slop below the face and the recovery only acts on what
+   * is deeper, so a body at rest overlaps the slab by exactly this much and its contact REPORT (penetration >= 0) stays
+   * true and stable instead of flickering at a zero gap */
+  float contact_slop;
   /* composite body */
   float inv_mass;
   float com[3];
@@ -222,7 +226,9 @@ const char* pf_last_error(const pf_ctx* ctx);
 
 /* Replaces constructing `Aviary(...)` + the drone objects (core/aviary.py:69-216,
  * core/drones/quadx.py:22-220, fixedwing.py:18-192): binds the parameter block to a device.
- * lane_offset = global index of lane 0 (multi-GPU sharding; keys the counter-based RNG). */
+ * lane_offset = global index of lane 0 (multi-GPU sharding; keys the counter-based RNG).
+ * The context owns two device allocations: a copy of the parameter block and, when contact_response is on, the contact
+ * solver's workspace (PF_MAX_CONTACTS x 8 floats per lane = 1.5 KB/lane; touched only by lanes near the floor). */
 int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lane_offset, pf_ctx** out);
 void pf_ctx_destroy(pf_ctx* ctx);
 int pf_state_groups(const pf_ctx* ctx); /* float4 groups per lane in pf_buffers.state */

@@ -262,7 +262,7 @@ class BulletClient:
         # contact response against fixed bodies' top faces (the ground slab): see _solve_contacts
         self.contact_response = True
         self.contact_restitution, self.contact_friction, self.contact_erp, self.contact_iters = 0.0, 0.5, 0.2, 10
-        self.contact_margin = 0.02
+        self.contact_margin, self.contact_slop = 0.02, 0.001
 
     # ------------------------------------------------------------ no-ops
     def setAdditionalSearchPath(self, path):
@@ -419,7 +419,8 @@ class BulletClient:
                     target = 0.0
                     if d == 0:
                         depth = pts[c][1]
-                        target = depth / self._dt if depth < 0.0 else (-self.contact_restitution * vn0[c] if vn0[c] < 0.0 else 0.0)
+                        target = ((depth - self.contact_slop) / self._dt if depth < self.contact_slop
+                                  else (-self.contact_restitution * vn0[c] if vn0[c] < 0.0 else 0.0))
                     dl = (target - float(j @ tw)) / k
                     if d == 0:
                         new = max(lam[c, 0] + dl, 0.0)
@@ -431,7 +432,7 @@ class BulletClient:
                     tw = tw + dl * resp
         b.w = R @ tw[:3]
         b.v = R @ tw[3:]
-        return max(0.0, max(d for _, d in pts))
+        return max(0.0, max(d for _, d in pts) - self.contact_slop)
 
     # ------------------------------------------------------------ the tick
     def stepSimulation(self):

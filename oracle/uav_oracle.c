@@ -315,8 +315,8 @@ static double contact_solve(const orc_params* PP, const orc_body* B, const doubl
         cross3(w, arm[c], t);
         for (int i = 0; i < 3; ++i) u[i] = vc[i] + t[i];
         double target = 0.0;
-        if (d == 0) target = depth[c] < 0.0 ? depth[c] / W->dt /* speculative: may close the gap, no more */
-                                            : (vn0[c] < 0.0 ? -W->contact_restitution * vn0[c] : 0.0);
+        if (d == 0) target = depth[c] < W->contact_slop ? (depth[c] - W->contact_slop) / W->dt /* may close the gap down to the slop, no more */
+                                                        : (vn0[c] < 0.0 ? -W->contact_restitution * vn0[c] : 0.0);
         double dl = (target - dot3(u, dir[d])) / k, nl;
         if (d == 0) {
           nl = lam[c][0] + dl;
@@ -381,7 +381,7 @@ static void rigid_tick_body(const orc_params* PP, const orc_body* P, double p[3]
   const double deepest = Wd->contact_response ? contact_solve(PP, P, p, q, v, w) : 0.0;
   /* x += v dt (semi-implicit Euler: new velocity) */
   for (int i = 0; i < 3; ++i) p[i] += dt * v[i];
-  if (deepest > 0.0) p[2] += Wd->contact_erp * deepest; /* penetration recovery, position level */
+  if (deepest > Wd->contact_slop) p[2] += Wd->contact_erp * (deepest - Wd->contact_slop); /* penetration recovery, position level */
   /* q <- exp(w dt / 2) * q with world-frame w, then normalise */
   double fAngle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   if (fAngle * dt > 0.25 * PI) fAngle = 0.25 * PI / dt; /* ANGULAR_MOTION_THRESHOLD */
@@ -598,7 +598,7 @@ static void world_defaults(orc_world* W) {
   W->gravity_z = -9.81;      /* aviary.py:226 */
   W->use_gyro_term = 1;      /* [BULLET-FROM-MEMORY] */
   W->max_coord_vel = 100.0;  /* [BULLET-FROM-MEMORY] */
-  W->contact_response = 1; W->contact_restitution = 0.0; W->contact_friction = 0.5; W->contact_erp = 0.2; W->contact_iters = 10; W->contact_margin = 0.02; /* [BULLET-FROM-MEMORY] defaults */
+  W->contact_response = 1; W->contact_restitution = 0.0; W->contact_friction = 0.5; W->contact_erp = 0.2; W->contact_iters = 10; W->contact_margin = 0.02; W->contact_slop = 0.001; /* [BULLET-FROM-MEMORY] defaults */
   W->plane_half_xy = 15.0;   /* [BULLET-FROM-MEMORY] pybullet_data plane.urdf */
   W->plane_half_z = 5.0;
   W->ticks_per_control = 2;  /* 240/120, quadx.py:27-28 */

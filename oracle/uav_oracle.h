@@ -59,6 +59,10 @@ typedef struct {
    * otherwise penetrate within the tick, and it keeps the vertices of a resting body in the active set instead of
    * letting them drop in and out of it (Bullet's contact breaking threshold plays this role: 0.02 m). */
   double contact_margin;
+  /* allowed penetration: the constraints let a vertex sink contact_slop below the face and the recovery only acts on
+   * what is deeper, so a body at rest overlaps the slab by exactly this much -- which keeps the contact REPORT
+   * (penetration >= 0, orc_contact_plane) true and stable while it rests, instead of flickering at a zero gap */
+  double contact_slop;
 } orc_world;
 
 typedef struct {

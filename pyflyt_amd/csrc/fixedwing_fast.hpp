@@ -150,6 +150,7 @@ struct FwHot {
   float cmd[6];
   m3 R; v3 wb, vb;
   bool contact_now, contact_step;
+  int lane_idx;  // this lane's slot in the contact solver's workspace
 
   PF_DEV void derive() {  // unit quaternion (quat_integrate / the settled template): scale 2
     const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
@@ -279,10 +280,9 @@ struct FwHot {
     float lift = 0.0f;  // contact response (see quadx_fast.hpp / uav_vehicles.hpp:contact_solve_dev)
     if (__any(near)) {
       if (near && Pfull->contact_response) {
-        const ContactOut o = contact_solve_dev(Pfull, p, q, v, w, Pfull->inv_mass, com, Pfull->I_inv[0], Pfull->I_inv[1], Pfull->I_inv[2],
-                                               Pfull->I_inv[3], Pfull->I_inv[4], Pfull->I_inv[5]);
+        const ContactOut o = contact_solve_dev(Pfull, lane_idx, p, q, v, w);
         v = o.v; w = o.w;
-        lift = Pfull->contact_erp * o.deepest;
+        lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
       }
     }
     p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
@@ -313,6 +313,7 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
   fw_surf_cptr surf = (fw_surf_cptr)(uintptr_t)table_g;
 
   FwHot V;
+  V.lane_idx = (int)li;
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;

@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
 
   VEH V;
   V.b.pdev = Pdev;
+  V.b.lane_idx = min((int)(blockIdx.x * kWave + threadIdx.x), n - 1);
   V.bind(ktab);
   SideBlock tg;
   float new_dist;
@@ -412,6 +413,7 @@ __global__ void settle_template_kernel(const pf_params P, float4* tmpl, const pf
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   VEH V;
   V.b.pdev = Pdev;
+  V.b.lane_idx = 0;  // (runs once at context creation, before any lane exists: lane 0's workspace slot is free)
   V.bind(ktab);
   float sp[6] = {0, 0, 0, 0, 0, 0};
   V.reset(P, nullptr, sp);
@@ -431,6 +433,7 @@ __global__ void __launch_bounds__(kWave) aviary_reset_kernel(const pf_params P, 
   if (lane >= n) return;
   VEH V;
   V.b.pdev = nullptr;  // (no tick in this kernel)
+  V.b.lane_idx = 0;
   float sp[8];
   V.reset(P, pose ? pose + (size_t)lane * 7 : nullptr, sp, B.start_vel ? B.start_vel + (size_t)lane * 3 : nullptr);
   float4* S = reinterpret_cast<float4*>(B.state);
@@ -462,6 +465,7 @@ __global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params 
   if (lane >= n) return;
   VEH V;
   V.b.pdev = nullptr;  // (no tick in this kernel)
+  V.b.lane_idx = 0;
   float nd;
   int4 ints;
   // load everything (old mode 7 == all groups), re-initialise the controllers, store everything
@@ -491,6 +495,7 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   const size_t li = lane, N = n;
   VEH V;
   V.b.pdev = Pdev;
+  V.b.lane_idx = min((int)(blockIdx.x * kWave + threadIdx.x), n - 1);
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -564,6 +569,7 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   constexpr int kCmdGroup = 12;
   VEH V;
   V.b.pdev = Pdev;
+  V.b.lane_idx = min((int)(blockIdx.x * kWave + threadIdx.x), n - 1);
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -633,6 +639,7 @@ __global__ void __launch_bounds__(kWave) body_tick_kernel(const pf_params P, con
   const size_t li = lane, N = n;
   VEH V;
   V.b.pdev = Pdev;
+  V.b.lane_idx = lane;
   float nd;
   int4 ints;
   float4* S = reinterpret_cast<float4*>(B.state);
@@ -680,7 +687,8 @@ struct pf_ctx {
   // hot-path specialisation (quadx_fast.hpp)
   bool fast;
   pf::QuadK K;
-  pf_params* P_dev;  // device copy of P for the rarely-taken floor-contact path
+  pf_params* P_dev;  // device copy of P (a pf::pf_dev_block: the block + the contact workspace pointer) for the rarely-taken floor paths
+  float* contact_ws; // contact solver workspace, [PF_MAX_CONTACTS][8][n] floats, or null (contact_response off)
   float4* tmpl;      // settled spawn state for lane-independent resets (env_kernel), or null
   // Fixedwing-Waypoints specialisation (fixedwing_fast.hpp)
   bool fast_fw;
@@ -777,7 +785,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
-  c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr;
+  c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr; c->contact_ws = nullptr;
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
   pf::FwTable fsurf;
   c->fast_fw = pf::fwk_from_params(P, c->FK, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;
@@ -785,14 +793,21 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     int cur = -1;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
-    hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
-    if (e == hipSuccess) e = hipMemcpy(c->P_dev, &P, sizeof(pf_params), hipMemcpyHostToDevice);
+    pf::pf_dev_block blk;
+    blk.P = P; blk.contact_ws = nullptr; blk.n_lanes = n_lanes;
+    hipError_t e = hipSuccess;
+    if (P.contact_response) {
+      e = hipMalloc((void**)&c->contact_ws, sizeof(float) * (size_t)PF_MAX_CONTACTS * 8 * (size_t)n_lanes);
+      blk.contact_ws = c->contact_ws;
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&c->P_dev, sizeof(pf::pf_dev_block));
+    if (e == hipSuccess) e = hipMemcpy(c->P_dev, &blk, sizeof(blk), hipMemcpyHostToDevice);
     if (e == hipSuccess && c->fast_fw) {
       e = hipMalloc((void**)&c->surf_dev, sizeof(fsurf));
       if (e == hipSuccess) e = hipMemcpy(c->surf_dev, &fsurf, sizeof(fsurf), hipMemcpyHostToDevice);
     }
     if (cur >= 0) (void)hipSetDevice(cur);
-    if (e != hipSuccess) { delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
+    if (e != hipSuccess) { if (c->contact_ws) hipFree(c->contact_ws); if (c->P_dev) hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
   }
   if (!c->fast && (P.task == PF_TASK_HOVER || P.task == PF_TASK_WAYPOINTS) &&
       (P.vehicle == PF_FIXEDWING || P.noise_mode == PF_NOISE_OFF)) {
@@ -810,7 +825,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
       e = hipDeviceSynchronize();
     }
     if (cur >= 0) hipSetDevice(cur);
-    if (e != hipSuccess) { if (c->tmpl) hipFree(c->tmpl); if (c->surf_dev) hipFree(c->surf_dev); hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: settle template"); }
+    if (e != hipSuccess) { if (c->tmpl) hipFree(c->tmpl); if (c->surf_dev) hipFree(c->surf_dev); if (c->contact_ws) hipFree(c->contact_ws); hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: settle template"); }
   }
   *out = c;
   return PF_OK;
@@ -818,6 +833,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
 void pf_ctx_destroy(pf_ctx* ctx) {
   if (!ctx) return;
   if (ctx->P_dev) hipFree(ctx->P_dev);
+  if (ctx->contact_ws) hipFree(ctx->contact_ws);
   if (ctx->tmpl) hipFree(ctx->tmpl);
   if (ctx->surf_dev) hipFree(ctx->surf_dev);
   delete ctx;

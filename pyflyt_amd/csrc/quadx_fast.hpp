@@ -136,6 +136,7 @@ struct QuadHot {
   m3 R; v3 wb, vb;
   float pwm[4];
   bool contact_now, contact_step;
+  int lane_idx;  // this lane's slot in the contact solver's workspace
 
   PF_DEV void derive() {
     // btMatrix3x3::setRotation scales by 2/|q|^2; q leaves quat_integrate()/the spawn normalised to
@@ -220,10 +221,9 @@ struct QuadHot {
     float lift = 0.0f;
     if (__any(near)) {
       if (near && Pfull->contact_response) {
-        const ContactOut o = contact_solve_dev(Pfull, p, q, v, w, Pfull->inv_mass, v3{0.f, 0.f, 0.f}, Pfull->I_inv[0], Pfull->I_inv[1],
-                                               Pfull->I_inv[2], Pfull->I_inv[3], Pfull->I_inv[4], Pfull->I_inv[5]);
+        const ContactOut o = contact_solve_dev(Pfull, lane_idx, p, q, v, w);
         v = o.v; w = o.w;
-        lift = Pfull->contact_erp * o.deepest;
+        lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
       }
     }
     p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   float4* Sout = reinterpret_cast<float4*>(B.state);
 
   QuadHot V;
+  V.lane_idx = (int)li;
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;

@@ -59,13 +59,26 @@ struct ContactOut {
   v3 v, w;
   float deepest;
 };
-__device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict__ P, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
-                                                     float i0, float i1, float i2, float i3, float i4, float i5) {
-  float armx[PF_MAX_CONTACTS], army[PF_MAX_CONTACTS], armz[PF_MAX_CONTACTS];
-  float ln[PF_MAX_CONTACTS], lx[PF_MAX_CONTACTS], ly[PF_MAX_CONTACTS], vn0[PF_MAX_CONTACTS], dep[PF_MAX_CONTACTS];
+// What the context keeps on the device: the parameter block and, behind it, the contact solver's workspace
+// ([PF_MAX_CONTACTS][8][n_lanes] floats: arm (3), accumulated impulses (3), initial normal velocity, depth; lane-minor so
+// that the lanes of a wave that are in contact touch consecutive addresses). Global memory on purpose: the per-contact
+// arrays are dynamically indexed, and as private (scratch) arrays they gave every kernel that can reach the solver a
+// 1.4 KB/lane private segment -- measured 1.5x slower env steps although the solver itself almost never runs.
+struct pf_dev_block {
+  pf_params P;
+  float* contact_ws;
+  int32_t n_lanes;
+};
+// (inlined into the two out-of-line entry points below)
+PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
+                                     float i0, float i1, float i2, float i3, float i4, float i5) {
+  const pf_dev_block* D = reinterpret_cast<const pf_dev_block*>(P);
+  float* ws = D->contact_ws + lane;
+  const size_t st = (size_t)D->n_lanes;
+  auto W = [&](int c, int f) -> float& { return ws[(size_t)(c * 8 + f) * st]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth
   const m3 R = rot_from_quat(q);
   const v3 cw = mul(R, com);
-  const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin;
+  const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin, slop = P->contact_slop;
   const float inv_dt = 1.0f / P->dt;
   int n = 0;
   float deepest = 0.0f;
@@ -90,29 +103,29 @@ __device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict
       const v3 x = p + off;
       if (n < PF_MAX_CONTACTS && x.z <= margin && x.z >= -hz2 && __builtin_fabsf(x.x) <= hxy && __builtin_fabsf(x.y) <= hxy) {
         const v3 a = off - cw;
-        armx[n] = a.x; army[n] = a.y; armz[n] = a.z;
-        ln[n] = lx[n] = ly[n] = 0.0f;
-        dep[n] = -x.z;
+        W(n, 0) = a.x; W(n, 1) = a.y; W(n, 2) = a.z;
+        W(n, 3) = 0.0f; W(n, 4) = 0.0f; W(n, 5) = 0.0f;
+        W(n, 7) = -x.z;
         deepest = __builtin_fmaxf(deepest, -x.z);
         ++n;
       }
     }
   }
-  ContactOut out{v, w, deepest};
+  ContactOut out{v, w, __builtin_fmaxf(deepest - slop, 0.0f)};
   if (n == 0) return out;
   // world-frame inverse inertia R I^-1 R^T (symmetric)
   const float Ii[6] = {i0, i1, i2, i3, i4, i5};
-  const v3 c0 = symmul(Ii, v3{R.m00, R.m01, R.m02}), c1 = symmul(Ii, v3{R.m10, R.m11, R.m12}), c2 = symmul(Ii, v3{R.m20, R.m21, R.m22});
-  // rows of R dotted with the columns above: Iw[a][b] = row_a(R) . (I^-1 row_b(R)^T)
-  const float w00 = dot(v3{R.m00, R.m01, R.m02}, c0), w01 = dot(v3{R.m00, R.m01, R.m02}, c1), w02 = dot(v3{R.m00, R.m01, R.m02}, c2);
-  const float w11 = dot(v3{R.m10, R.m11, R.m12}, c1), w12 = dot(v3{R.m10, R.m11, R.m12}, c2), w22 = dot(v3{R.m20, R.m21, R.m22}, c2);
-  const float Iw[6] = {w00, w01, w02, w11, w12, w22};
+  const v3 r0{R.m00, R.m01, R.m02}, r1{R.m10, R.m11, R.m12}, r2{R.m20, R.m21, R.m22};
+  const v3 c0 = symmul(Ii, r0), c1 = symmul(Ii, r1), c2 = symmul(Ii, r2);
+  const float Iw[6] = {dot(r0, c0), dot(r0, c1), dot(r0, c2), dot(r1, c1), dot(r1, c2), dot(r2, c2)};
   v3 vc = v + cross(w, cw);
-  for (int c = 0; c < n; ++c) vn0[c] = vc.z + cross(w, v3{armx[c], army[c], armz[c]}).z;
+  for (int c = 0; c < n; ++c) W(c, 6) = vc.z + cross(w, v3{W(c, 0), W(c, 1), W(c, 2)}).z;
   const float mu = P->contact_friction, rest = P->contact_restitution;
   for (int it = 0; it < P->contact_iters; ++it) {
     for (int c = 0; c < n; ++c) {
-      const v3 a{armx[c], army[c], armz[c]};
+      const v3 a{W(c, 0), W(c, 1), W(c, 2)};
+      const float vn0 = W(c, 6), dep = W(c, 7);
+      float lam[3] = {W(c, 3), W(c, 4), W(c, 5)};
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // normal +z, friction +x, friction +y
         const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
@@ -120,26 +133,38 @@ __device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict
         const float kk = inv_mass + dot(dir, cross(ang, a));
         const v3 u = vc + cross(w, a);
         float target = 0.0f;
-        if (d == 0) target = dep[c] < 0.0f ? dep[c] * inv_dt  // speculative: may close the gap, no more
-                                           : (vn0[c] < 0.0f ? -rest * vn0[c] : 0.0f);
+        if (d == 0) target = dep < slop ? (dep - slop) * inv_dt  // may close the gap down to the slop, no more
+                                        : (vn0 < 0.0f ? -rest * vn0 : 0.0f);
         float dl = (target - dot(u, dir)) / kk, nl;
-        float* acc = d == 0 ? &ln[c] : (d == 1 ? &lx[c] : &ly[c]);
         if (d == 0) {
-          nl = __builtin_fmaxf(*acc + dl, 0.0f);
+          nl = __builtin_fmaxf(lam[0] + dl, 0.0f);
         } else {
-          const float lim = mu * ln[c];
-          nl = __builtin_fminf(__builtin_fmaxf(*acc + dl, -lim), lim);
+          const float lim = mu * lam[0];
+          nl = __builtin_fminf(__builtin_fmaxf(lam[d] + dl, -lim), lim);
         }
-        dl = nl - *acc;
-        *acc = nl;
+        dl = nl - lam[d];
+        lam[d] = nl;
         vc = vc + (inv_mass * dl) * dir;
         w = w + dl * ang;
       }
+      W(c, 3) = lam[0]; W(c, 4) = lam[1]; W(c, 5) = lam[2];
     }
   }
   out.w = w;
   out.v = vc - cross(w, cw);
   return out;
+}
+// Constant mass properties (QuadX, Fixedwing): read from the parameter block inside the call, so that the call passes 16
+// dwords -- all in registers; with the ten mass-property words as arguments the last three went over the stack and gave
+// every caller a private segment.
+__device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict__ P, int lane, v3 p, quat q, v3 v, v3 w) {
+  const v3 com = P->has_com_offset ? v3{P->com[0], P->com[1], P->com[2]} : v3{0.f, 0.f, 0.f};
+  return contact_solve_impl(P, lane, p, q, v, w, P->inv_mass, com, P->I_inv[0], P->I_inv[1], P->I_inv[2], P->I_inv[3], P->I_inv[4], P->I_inv[5]);
+}
+// Mass properties that change per tick (Rocket): passed by value.
+__device__ __noinline__ ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, int lane, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
+                                                         float i0, float i1, float i2, float i3, float i4, float i5) {
+  return contact_solve_impl(P, lane, p, q, v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
 }
 
 // Rigid body shared by both vehicles: the Bullet base state + what update_state derives from it.
@@ -201,7 +226,7 @@ struct Body {
     const float dt = P.dt, vm = P.max_coord_vel;
     w = v3{clampf(fmaf(wdot.x, dt, w.x), -vm, vm), clampf(fmaf(wdot.y, dt, w.y), -vm, vm), clampf(fmaf(wdot.z, dt, w.z), -vm, vm)};
     v = v3{clampf(fmaf(a.x, dt, v.x), -vm, vm), clampf(fmaf(a.y, dt, v.y), -vm, vm), clampf(fmaf(a.z, dt, v.z), -vm, vm)};
-    const float lift = respond(Pdev_of(P), P.inv_mass, P.has_com_offset ? com : v3{0.f, 0.f, 0.f}, P.I_inv);
+    const float lift = respond(pdev);
     p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, 0.5f * dt);
     derive();
@@ -210,10 +235,16 @@ struct Body {
   // constraint solve of stepSimulation: contacts found at the pre-integration pose act on the new velocities; returns the
   // position-level penetration recovery (contact_erp x deepest penetration) to add to z after the position update
   const pf_params* pdev;  // device copy of the parameter block (the out-of-line contact solver reads the colliders from it)
-  PF_DEV const pf_params* Pdev_of(const pf_params&) const { return pdev; }
-  PF_DEV float respond(const pf_params* Pd, float inv_mass, v3 com, const float Iinv[6]) {
+  int lane_idx;           // this lane's slot in the contact solver's workspace
+  PF_DEV float respond(const pf_params* Pd) {
     if (Pd == nullptr || !Pd->contact_response || (p.z - Pd->bound_radius) > Pd->contact_margin) return 0.0f;
-    const ContactOut o = contact_solve_dev(Pd, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
+    const ContactOut o = contact_solve_dev(Pd, lane_idx, p, q, v, w);
+    v = o.v; w = o.w;
+    return Pd->contact_erp * o.deepest;  // (deepest: already net of the slop)
+  }
+  PF_DEV float respond_var(const pf_params* Pd, float inv_mass, v3 com, const float Iinv[6]) {
+    if (Pd == nullptr || !Pd->contact_response || (p.z - Pd->bound_radius) > Pd->contact_margin) return 0.0f;
+    const ContactOut o = contact_solve_var_dev(Pd, lane_idx, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
     v = o.v; w = o.w;
     return Pd->contact_erp * o.deepest;
   }
@@ -232,7 +263,7 @@ struct Body {
     const float dt = P.dt, vm = P.max_coord_vel;
     w = v3{clampf(fmaf(wdot.x, dt, w.x), -vm, vm), clampf(fmaf(wdot.y, dt, w.y), -vm, vm), clampf(fmaf(wdot.z, dt, w.z), -vm, vm)};
     v = v3{clampf(fmaf(a.x, dt, v.x), -vm, vm), clampf(fmaf(a.y, dt, v.y), -vm, vm), clampf(fmaf(a.z, dt, v.z), -vm, vm)};
-    const float lift = respond(pdev, inv_mass, com, Iinv);
+    const float lift = respond_var(pdev, inv_mass, com, Iinv);
     p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, 0.5f * dt);
     derive();

@@ -200,6 +200,7 @@ WORLD: dict[str, Any] = {
     "contact_erp": 0.2,
     "contact_iters": 10,
     "contact_margin": 0.02,    # speculative contacts (Bullet's contact breaking threshold)
+    "contact_slop": 0.001,     # allowed penetration: what a resting body overlaps the floor by
 }
 
 
@@ -314,6 +315,7 @@ def build_params(
     P.contact_restitution, P.contact_friction, P.contact_erp = W["contact_restitution"], W["contact_friction"], W["contact_erp"]
     P.contact_iters = int(W["contact_iters"])
     P.contact_margin = W["contact_margin"] * W["world_scale"]
+    P.contact_slop = W["contact_slop"] * W["world_scale"]
     P.settle_steps = 10  # gym_envs/quadx_envs/quadx_base_env.py:209
 
     if vehicle == "quadx":

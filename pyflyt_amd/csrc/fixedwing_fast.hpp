@@ -278,8 +278,14 @@ struct FwHot {
     w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
     v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
     float lift = 0.0f;  // contact response (see quadx_fast.hpp / uav_vehicles.hpp:contact_solve_dev)
-    if (__any(near)) {
-      if (near && Pfull->contact_response) {
+    bool act = false;  // can a contact constraint act at all this tick? (Body::contact_may_act)
+    if (near) {
+      const float r0 = Pfull->bound_radius, slop = Pfull->contact_slop;
+      const float low = p.z - r0, vlow = v.z - fsqrt(dot(w, w)) * r0;
+      act = (fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop);
+    }
+    if (__any(act)) {
+      if (act && Pfull->contact_response) {
         const ContactOut o = contact_solve_dev(Pfull, lane_idx, p, q, v, w);
         v = o.v; w = o.w;
         lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)

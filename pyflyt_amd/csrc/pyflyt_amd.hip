@@ -688,7 +688,7 @@ struct pf_ctx {
   bool fast;
   pf::QuadK K;
   pf_params* P_dev;  // device copy of P (a pf::pf_dev_block: the block + the contact workspace pointer) for the rarely-taken floor paths
-  float* contact_ws; // contact solver workspace, [PF_MAX_CONTACTS][8][n] floats, or null (contact_response off)
+  float* contact_ws; // contact solver workspace, [PF_MAX_CONTACTS][kContactWords][n] floats, or null (contact_response off)
   float4* tmpl;      // settled spawn state for lane-independent resets (env_kernel), or null
   // Fixedwing-Waypoints specialisation (fixedwing_fast.hpp)
   bool fast_fw;
@@ -797,7 +797,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     blk.P = P; blk.contact_ws = nullptr; blk.n_lanes = n_lanes;
     hipError_t e = hipSuccess;
     if (P.contact_response) {
-      e = hipMalloc((void**)&c->contact_ws, sizeof(float) * (size_t)PF_MAX_CONTACTS * 8 * (size_t)n_lanes);
+      e = hipMalloc((void**)&c->contact_ws, sizeof(float) * (size_t)PF_MAX_CONTACTS * pf::kContactWords * (size_t)n_lanes);
       blk.contact_ws = c->contact_ws;
     }
     if (e == hipSuccess) e = hipMalloc((void**)&c->P_dev, sizeof(pf::pf_dev_block));

@@ -29,7 +29,8 @@ struct QuadK {
   float dt, half_dt, gravity_z, vmax, inv_mass;
   float I[3], iI[3];           // diagonal inertia and its inverse (cf2x.urdf:14)
   float use_gyro;              // 1.0 / 0.0
-  float bound_radius;
+  float bound_radius;          // gate of the out-of-line floor code (incl. the speculative contact margin)
+  float bound_radius0, slop;   // the bare bounding radius and the allowed overlap: "can a contact constraint act this tick?"
   // motors (identical): motors.py:131-138,182-193
   float m_a, m_noise, fmax, tmax;
   float ryf[4], rxf[4];        // r_y*fmax, -r_x*fmax per motor (torque arms)
@@ -85,6 +86,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.use_gyro = P.use_gyro_term ? 1.f : 0.f;
   // gate of the out-of-line floor code: within one bounding radius of the floor, widened by the speculative contact margin
   K.bound_radius = P.bound_radius + (P.contact_response ? P.contact_margin : 0.0f);
+  K.bound_radius0 = P.bound_radius; K.slop = P.contact_slop;
   K.m_a = P.motor_dt_over_tau[0]; K.m_noise = P.motor_noise[0]; K.fmax = P.motor_fmax[0]; K.tmax = P.motor_tmax[2];
   for (int i = 0; i < 4; ++i) { K.ryf[i] = P.motor_r[i][1] * P.motor_fmax[0]; K.rxf[i] = -P.motor_r[i][0] * P.motor_fmax[0]; }
   for (int k = 0; k < 3; ++k) {
@@ -218,9 +220,16 @@ struct QuadHot {
     v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
     // contact response (the constraint solve of stepSimulation) for lanes within one bounding radius of the floor:
     // out of line, with its constants read from the device parameter block inside the rare path
+    // (can a constraint act at all this tick? conservative bound on the lowest vertex's height after the tick; when it stays
+    //  above the allowed overlap every constraint is slack, the solve would return the velocities unchanged: Body::contact_may_act)
     float lift = 0.0f;
-    if (__any(near)) {
-      if (near && Pfull->contact_response) {
+    bool act = false;
+    if (near) {
+      const float low = p.z - K.bound_radius0, vlow = v.z - fsqrt(dot(w, w)) * K.bound_radius0;
+      act = (fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop);
+    }
+    if (__any(act)) {
+      if (act && Pfull->contact_response) {
         const ContactOut o = contact_solve_dev(Pfull, lane_idx, p, q, v, w);
         v = o.v; w = o.w;
         lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)

@@ -60,10 +60,12 @@ struct ContactOut {
   float deepest;
 };
 // What the context keeps on the device: the parameter block and, behind it, the contact solver's workspace
-// ([PF_MAX_CONTACTS][8][n_lanes] floats: arm (3), accumulated impulses (3), initial normal velocity, depth; lane-minor so
+// ([PF_MAX_CONTACTS][12][n_lanes] floats: arm (3), accumulated impulses (3), initial normal velocity, depth, the three
+// inverse effective masses; lane-minor so
 // that the lanes of a wave that are in contact touch consecutive addresses). Global memory on purpose: the per-contact
 // arrays are dynamically indexed, and as private (scratch) arrays they gave every kernel that can reach the solver a
 // 1.4 KB/lane private segment -- measured 1.5x slower env steps although the solver itself almost never runs.
+constexpr int kContactWords = 12;
 struct pf_dev_block {
   pf_params P;
   float* contact_ws;
@@ -75,7 +77,7 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
   const pf_dev_block* D = reinterpret_cast<const pf_dev_block*>(P);
   float* ws = D->contact_ws + lane;
   const size_t st = (size_t)D->n_lanes;
-  auto W = [&](int c, int f) -> float& { return ws[(size_t)(c * 8 + f) * st]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth
+  auto W = [&](int c, int f) -> float& { return ws[(size_t)(c * kContactWords + f) * st]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth, 8-10 1/k
   const m3 R = rot_from_quat(q);
   const v3 cw = mul(R, com);
   const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin, slop = P->contact_slop;
@@ -119,23 +121,34 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
   const v3 c0 = symmul(Ii, r0), c1 = symmul(Ii, r1), c2 = symmul(Ii, r2);
   const float Iw[6] = {dot(r0, c0), dot(r0, c1), dot(r0, c2), dot(r1, c1), dot(r1, c2), dot(r2, c2)};
   v3 vc = v + cross(w, cw);
-  for (int c = 0; c < n; ++c) W(c, 6) = vc.z + cross(w, v3{W(c, 0), W(c, 1), W(c, 2)}).z;
+  // per contact, once: the normal velocity the sweeps start from and the three inverse effective masses
+  // 1 / (1/m + dir . ((I_w^-1 (a x dir)) x a)) -- iteration invariant, and a division each
+  for (int c = 0; c < n; ++c) {
+    const v3 a{W(c, 0), W(c, 1), W(c, 2)};
+    W(c, 6) = vc.z + cross(w, a).z;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
+      W(c, 8 + d) = 1.0f / (inv_mass + dot(dir, cross(symmul(Iw, cross(a, dir)), a)));
+    }
+  }
   const float mu = P->contact_friction, rest = P->contact_restitution;
   for (int it = 0; it < P->contact_iters; ++it) {
+    bool changed = false;
     for (int c = 0; c < n; ++c) {
       const v3 a{W(c, 0), W(c, 1), W(c, 2)};
       const float vn0 = W(c, 6), dep = W(c, 7);
       float lam[3] = {W(c, 3), W(c, 4), W(c, 5)};
+      const float kinv[3] = {W(c, 8), W(c, 9), W(c, 10)};
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // normal +z, friction +x, friction +y
         const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
         const v3 ang = symmul(Iw, cross(a, dir));
-        const float kk = inv_mass + dot(dir, cross(ang, a));
         const v3 u = vc + cross(w, a);
         float target = 0.0f;
         if (d == 0) target = dep < slop ? (dep - slop) * inv_dt  // may close the gap down to the slop, no more
                                         : (vn0 < 0.0f ? -rest * vn0 : 0.0f);
-        float dl = (target - dot(u, dir)) / kk, nl;
+        float dl = (target - dot(u, dir)) * kinv[d], nl;
         if (d == 0) {
           nl = __builtin_fmaxf(lam[0] + dl, 0.0f);
         } else {
@@ -144,11 +157,13 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
         }
         dl = nl - lam[d];
         lam[d] = nl;
+        changed |= dl != 0.0f;
         vc = vc + (inv_mass * dl) * dir;
         w = w + dl * ang;
       }
       W(c, 3) = lam[0]; W(c, 4) = lam[1]; W(c, 5) = lam[2];
     }
+    if (!changed) break;  // a sweep that moved nothing: every further sweep would repeat it exactly
   }
   out.w = w;
   out.v = vc - cross(w, cw);
@@ -236,14 +251,24 @@ struct Body {
   // position-level penetration recovery (contact_erp x deepest penetration) to add to z after the position update
   const pf_params* pdev;  // device copy of the parameter block (the out-of-line contact solver reads the colliders from it)
   int lane_idx;           // this lane's slot in the contact solver's workspace
+  // Can any contact constraint act this tick? Every vertex lies within bound_radius of the base origin, so its height is
+  // >= low = p.z - bound_radius and its normal velocity >= v.z - |w| bound_radius: if even that worst case ends the tick
+  // above the allowed overlap (and nothing is deeper than it now), every constraint of the solve is slack -- all impulses
+  // exactly zero, no recovery -- and the call is skipped without changing the result.
+  PF_DEV bool contact_may_act(const pf_params* Pd) const {
+    const float low = p.z - Pd->bound_radius;
+    if (low > Pd->contact_margin) return false;
+    const float vlow = v.z - __builtin_sqrtf(dot(w, w)) * Pd->bound_radius;
+    return (low + Pd->contact_slop + Pd->dt * vlow < 0.0f) || (low < -Pd->contact_slop);
+  }
   PF_DEV float respond(const pf_params* Pd) {
-    if (Pd == nullptr || !Pd->contact_response || (p.z - Pd->bound_radius) > Pd->contact_margin) return 0.0f;
+    if (Pd == nullptr || !Pd->contact_response || !contact_may_act(Pd)) return 0.0f;
     const ContactOut o = contact_solve_dev(Pd, lane_idx, p, q, v, w);
     v = o.v; w = o.w;
     return Pd->contact_erp * o.deepest;  // (deepest: already net of the slop)
   }
   PF_DEV float respond_var(const pf_params* Pd, float inv_mass, v3 com, const float Iinv[6]) {
-    if (Pd == nullptr || !Pd->contact_response || (p.z - Pd->bound_radius) > Pd->contact_margin) return 0.0f;
+    if (Pd == nullptr || !Pd->contact_response || !contact_may_act(Pd)) return 0.0f;
     const ContactOut o = contact_solve_var_dev(Pd, lane_idx, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
     v = o.v; w = o.w;
     return Pd->contact_erp * o.deepest;

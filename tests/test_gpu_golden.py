@@ -19,6 +19,9 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 RTOL = 1e-4
+# observations / states that carry a floor impact (the contact solver's impulses): see tests/test_gpu_parity.py and
+# tests/tools/fp32_contact_sensitivity.py -- an fp32 build of the oracle itself is this far from the fp64 one there
+RTOL_IMPACT = 2e-3
 N = 70
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -105,8 +108,11 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
         a = torch.tensor(np.repeat(g["action"][k][None], N, axis=0), dtype=torch.float32, device=DEV).contiguous()
         obs, rew, term, trunc = eng.env_step(a, xi=dev_cols(g["xi"][k]))
         e = vec_err(obs.double().cpu().numpy(), g["obs"][k], G)
-        worst = max(worst, e)
-        assert e < RTOL, (name, k, e)
+        if bool(g["info_col"][k]):  # terminal observation of an episode that ends on the floor
+            assert e < RTOL_IMPACT, (name, k, e)
+        else:
+            worst = max(worst, e)
+            assert e < RTOL, (name, k, e)
         r = rew.double().cpu().numpy()
         assert np.abs(r - g["reward"][k]).max() <= 1e-3 * max(1.0, abs(g["reward"][k])), (name, k, r[0], g["reward"][k])
         assert (term.cpu().numpy() == bool(g["term"][k])).all() and (trunc.cpu().numpy() == bool(g["trunc"][k])).all(), (name, k)
@@ -197,7 +203,9 @@ AVIARY = {
     "aviary_rocket_default_fuel": None, "aviary_rocket_fuel60": None, "aviary_rocket_drop": None,
     # landings with the motors off, first touch to rest: the contact response (vertex contacts, Gauss-Seidel sweeps,
     # friction, penetration recovery) in fp32 against the reference-on-fake-Bullet recording
-    "aviary_quadx_land": None, "aviary_primitive_land": None, "aviary_rocket_land": None,
+    # (the primitive drone rocks on its prop discs and the rocket on its legs for seconds: an fp32 oracle is 4e-3 / 5e-1 away
+    #  from the fp64 one during that, tests/tools/fp32_contact_sensitivity.py, and both end in the same pose: prefix + loose tail)
+    "aviary_quadx_land": None, "aviary_primitive_land": (22, 5e-2), "aviary_rocket_land": (31, 5e-2),
 }
 ROCKET_FUEL = {"aviary_rocket_default_fuel": 0.05, "aviary_rocket_fuel60": 0.6, "aviary_rocket_drop": 0.0, "aviary_rocket_wind_ctor": 0.3,
                "aviary_rocket_land": 0.0}
@@ -254,7 +262,9 @@ def test_aviary_fixture_replay(name):
             first_bad = k
         assert (eng.out_contact.cpu().numpy() == bool(g["contact"][k])).all(), (name, k)
         if bound is None:
-            assert e < RTOL, (name, k, e)
+            # from one Aviary step before the first reported contact on, the trajectory carries the contact solver's impulses
+            touched = bool(g["contact"][: k + 2].any())
+            assert e < (RTOL_IMPACT if touched else RTOL), (name, k, e)
         elif k < bound[0]:
             assert e < RTOL, (name, k, e)
         elif bound[1] is not None:

@@ -295,8 +295,9 @@ def test_rocket_settles_on_its_legs():
 
     n = 64
     rng = np.random.default_rng(4)
-    pos = np.concatenate([rng.uniform(-2, 2, size=(n, 2)), rng.uniform(2.6, 3.0, size=(n, 1))], axis=1)
-    orn = np.concatenate([rng.uniform(-0.03, 0.03, size=(n, 2)), rng.uniform(-3, 3, size=(n, 1))], axis=1)
+    # (gentle: dropped half a metre with a 3 degree tilt the 9.5 m body topples -- in the oracle as well)
+    pos = np.concatenate([rng.uniform(-2, 2, size=(n, 2)), rng.uniform(2.45, 2.55, size=(n, 1))], axis=1)
+    orn = np.concatenate([rng.uniform(-0.01, 0.01, size=(n, 2)), rng.uniform(-3, 3, size=(n, 1))], axis=1)
     env = Aviary(pos, orn, "rocket", motor_noise=False, drone_options=dict(starting_fuel_ratio=0.0))
     env.set_mode(0)
     env.step(n_steps=1500)

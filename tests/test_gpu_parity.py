@@ -30,6 +30,11 @@ from oracle import oracle as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
+# The terminal observation of an episode that ends ON THE FLOOR carries the impact impulse of the contact solver (10
+# Gauss-Seidel sweeps with clamps at zero normal impulse and at the friction cone): a float32 build of the ORACLE is up to
+# 4e-4 (quad) away from the fp64 one on that one observation and back to 4e-6 a few steps later
+# (tests/tools/fp32_contact_sensitivity.py) -- a property of the non-smooth model in fp32, not of the kernels.
+RTOL_IMPACT = 2e-3
 
 
 def _engine(vehicle, task, n, **kw):
@@ -143,7 +148,13 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
         orr, rr, tr, trr, fin = orc.step(a, xi=xi, xi_reset=xr, u_targets=ut, autoreset=amode)
         e = relerr(og, orr, G).max(axis=1)
         er = np.abs(rg - rr) / np.maximum(1.0, np.abs(rr))
-        good = (tg == tr) & (trg == trr) & (e < RTOL) & (er < 1e-3)
+        from pyflyt_amd import _lib as PL
+
+        impact = ((eng.flags().cpu().numpy() & PL.F_INFO_COLLISION) != 0) & (orc.field("info_collision") != 0) & tg & tr
+        if autoreset == "same_step":
+            impact = np.zeros(n, dtype=bool)  # (the lane was re-initialised inside the step; its terminal observation is checked through final_obs below)
+        good = (tg == tr) & (trg == trr) & (e < np.where(impact, RTOL_IMPACT, RTOL)) & (er < 1e-3)
+        e = np.where(impact, 0.0, e)  # (held to RTOL_IMPACT above, not part of `worst`)
         # Both sides END the episode in this env step with identical flags, but at different INNER Aviary steps
         # (quadx_base_env.py:289-290 breaks out of the inner loop once terminated): fp32 rounding moved a dome / floor /
         # reach crossing over an inner-step boundary. Only this terminal observation (and its reward) shows it; both
@@ -169,8 +180,9 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
                 # over an inner-step boundary: flags and the (reset) observation still agree, only this
                 # vector shows it. Counted like the dropped lanes (same bound), not tolerated silently.
                 ef = relerr(eng.final_obs.cpu().numpy().astype(np.float64)[d], fin[d], G).max(axis=1)
+                hit = (eng.final_info[:, 0].cpu().numpy()[d] & PL.F_INFO_COLLISION) != 0  # floor impact: RTOL_IMPACT (see the top of the file)
                 n_final += int(d.sum())
-                n_final_bad += int((ef >= RTOL).sum())
+                n_final_bad += int((ef >= np.where(hit, RTOL_IMPACT, RTOL)).sum())
         if autoreset == "off":
             # finished lanes are reset together on both sides
             done = (tr | trr | tg | trg)

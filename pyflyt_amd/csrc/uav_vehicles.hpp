@@ -60,12 +60,12 @@ struct ContactOut {
   float deepest;
 };
 // What the context keeps on the device: the parameter block and, behind it, the contact solver's workspace
-// ([PF_MAX_CONTACTS][12][n_lanes] floats: arm (3), accumulated impulses (3), initial normal velocity, depth, the three
-// inverse effective masses; lane-minor so
+// ([PF_MAX_CONTACTS][20][n_lanes] floats: arm (3), accumulated impulses (3), initial normal velocity, depth, and per
+// direction the inverse effective mass and the angular response I_w^-1 (a x dir) (3 + 9); lane-minor so
 // that the lanes of a wave that are in contact touch consecutive addresses). Global memory on purpose: the per-contact
 // arrays are dynamically indexed, and as private (scratch) arrays they gave every kernel that can reach the solver a
 // 1.4 KB/lane private segment -- measured 1.5x slower env steps although the solver itself almost never runs.
-constexpr int kContactWords = 12;
+constexpr int kContactWords = 20;
 struct pf_dev_block {
   pf_params P;
   float* contact_ws;
@@ -77,7 +77,7 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
   const pf_dev_block* D = reinterpret_cast<const pf_dev_block*>(P);
   float* ws = D->contact_ws + lane;
   const size_t st = (size_t)D->n_lanes;
-  auto W = [&](int c, int f) -> float& { return ws[(size_t)(c * kContactWords + f) * st]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth, 8-10 1/k
+  auto W = [&](int c, int f) -> float& { return ws[(size_t)(c * kContactWords + f) * st]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth, 8-10 1/k, 11-19 angular responses
   const m3 R = rot_from_quat(q);
   const v3 cw = mul(R, com);
   const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin, slop = P->contact_slop;
@@ -129,7 +129,9 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
-      W(c, 8 + d) = 1.0f / (inv_mass + dot(dir, cross(symmul(Iw, cross(a, dir)), a)));
+      const v3 ang = symmul(Iw, cross(a, dir));
+      W(c, 8 + d) = 1.0f / (inv_mass + dot(dir, cross(ang, a)));
+      W(c, 11 + 3 * d) = ang.x; W(c, 12 + 3 * d) = ang.y; W(c, 13 + 3 * d) = ang.z;
     }
   }
   const float mu = P->contact_friction, rest = P->contact_restitution;
@@ -143,7 +145,7 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // normal +z, friction +x, friction +y
         const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
-        const v3 ang = symmul(Iw, cross(a, dir));
+        const v3 ang{W(c, 11 + 3 * d), W(c, 12 + 3 * d), W(c, 13 + 3 * d)};
         const v3 u = vc + cross(w, a);
         float target = 0.0f;
         if (d == 0) target = dep < slop ? (dep - slop) * inv_dt  // may close the gap down to the slop, no more

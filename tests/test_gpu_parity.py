@@ -150,7 +150,10 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
         er = np.abs(rg - rr) / np.maximum(1.0, np.abs(rr))
         from pyflyt_amd import _lib as PL
 
-        impact = ((eng.flags().cpu().numpy() & PL.F_INFO_COLLISION) != 0) & (orc.field("info_collision") != 0) & tg & tr
+        # an observation that carries the floor's impulses: the step that reports the collision on both sides, or a lane
+        # within reach of the floor (the speculative contact constraint stops the fall one tick before the report)
+        zlow = orc.field("p")[:, 2] - float(orc.P.bound_radius)
+        impact = (((eng.flags().cpu().numpy() & PL.F_INFO_COLLISION) != 0) & (orc.field("info_collision") != 0) & tg & tr) | (zlow < 0.05)
         if autoreset == "same_step":
             impact = np.zeros(n, dtype=bool)  # (the lane was re-initialised inside the step; its terminal observation is checked through final_obs below)
         good = (tg == tr) & (trg == trr) & (e < np.where(impact, RTOL_IMPACT, RTOL)) & (er < 1e-3)

@@ -227,8 +227,7 @@ const char* pf_last_error(const pf_ctx* ctx);
 /* Replaces constructing `Aviary(...)` + the drone objects (core/aviary.py:69-216,
  * core/drones/quadx.py:22-220, fixedwing.py:18-192): binds the parameter block to a device.
  * lane_offset = global index of lane 0 (multi-GPU sharding; keys the counter-based RNG).
- * The context owns two device allocations: a copy of the parameter block and, when contact_response is on, the contact
- * solver's workspace (PF_MAX_CONTACTS x 20 floats per lane = 3.8 KB/lane; touched only by lanes whose contacts act). */
+ * The context owns one device allocation: a copy of the parameter block (read by the rarely-taken floor paths). */
 int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lane_offset, pf_ctx** out);
 void pf_ctx_destroy(pf_ctx* ctx);
 int pf_state_groups(const pf_ctx* ctx); /* float4 groups per lane in pf_buffers.state */

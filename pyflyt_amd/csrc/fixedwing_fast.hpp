@@ -150,7 +150,7 @@ struct FwHot {
   float cmd[6];
   m3 R; v3 wb, vb;
   bool contact_now, contact_step;
-  int lane_idx;  // this lane's slot in the contact solver's workspace
+  lds_fptr cws;  // the wave's LDS regions for the contact solver (aliased onto the observation tile, idle during the ticks)
 
   PF_DEV void derive() {  // unit quaternion (quat_integrate / the settled template): scale 2
     const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
@@ -285,11 +285,11 @@ struct FwHot {
       act = (fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop);
     }
     if (__any(act)) {
-      if (act && Pfull->contact_response) {
-        const ContactOut o = contact_solve_dev(Pfull, lane_idx, p, q, v, w);
+      contact_rounds(act && Pfull->contact_response, cws, [&](lds_fptr slot) {
+        const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
         v = o.v; w = o.w;
         lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
-      }
+      });
     }
     p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, K.half_dt);
@@ -319,7 +319,8 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
   fw_surf_cptr surf = (fw_surf_cptr)(uintptr_t)table_g;
 
   FwHot V;
-  V.lane_idx = (int)li;
+  static_assert(64 * kMaxD >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
+  V.cws = (lds_fptr)tile;
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;

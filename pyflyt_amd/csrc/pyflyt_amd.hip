@@ -95,9 +95,10 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   const int mode = (MODE_T == kRuntimeMode) ? P.flight_mode : MODE_T;
   constexpr bool kSide = (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER);
 
+  static_assert(kWave * kMaxObs >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
   VEH V;
   V.b.pdev = Pdev;
-  V.b.lane_idx = min((int)(blockIdx.x * kWave + threadIdx.x), n - 1);
+  V.b.cws = (lds_fptr)tile;  // (idle during the physics ticks)
   V.bind(ktab);
   SideBlock tg;
   float new_dist;
@@ -411,9 +412,10 @@ __global__ void settle_template_kernel(const pf_params P, float4* tmpl, const pf
   VEH::fill_table(ktab, Pdev, threadIdx.x);
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __shared__ float cws[kContactSlots * kContactSlotFloats];
   VEH V;
   V.b.pdev = Pdev;
-  V.b.lane_idx = 0;  // (runs once at context creation, before any lane exists: lane 0's workspace slot is free)
+  V.b.cws = (lds_fptr)cws;
   V.bind(ktab);
   float sp[6] = {0, 0, 0, 0, 0, 0};
   V.reset(P, nullptr, sp);
@@ -433,7 +435,7 @@ __global__ void __launch_bounds__(kWave) aviary_reset_kernel(const pf_params P, 
   if (lane >= n) return;
   VEH V;
   V.b.pdev = nullptr;  // (no tick in this kernel)
-  V.b.lane_idx = 0;
+  V.b.cws = nullptr;
   float sp[8];
   V.reset(P, pose ? pose + (size_t)lane * 7 : nullptr, sp, B.start_vel ? B.start_vel + (size_t)lane * 3 : nullptr);
   float4* S = reinterpret_cast<float4*>(B.state);
@@ -465,7 +467,7 @@ __global__ void __launch_bounds__(kWave) aviary_set_mode_kernel(const pf_params 
   if (lane >= n) return;
   VEH V;
   V.b.pdev = nullptr;  // (no tick in this kernel)
-  V.b.lane_idx = 0;
+  V.b.cws = nullptr;
   float nd;
   int4 ints;
   // load everything (old mode 7 == all groups), re-initialise the controllers, store everything
@@ -493,9 +495,10 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   const size_t li = lane, N = n;
+  __shared__ float cws[kContactSlots * kContactSlotFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
   VEH V;
   V.b.pdev = Pdev;
-  V.b.lane_idx = min((int)(blockIdx.x * kWave + threadIdx.x), n - 1);
+  V.b.cws = (lds_fptr)cws;
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -567,9 +570,10 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   const size_t li = lane, N = n;
   constexpr bool kQuad = VEH::AUX == 4;
   constexpr int kCmdGroup = 12;
+  __shared__ float cws[kContactSlots * kContactSlotFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
   VEH V;
   V.b.pdev = Pdev;
-  V.b.lane_idx = min((int)(blockIdx.x * kWave + threadIdx.x), n - 1);
+  V.b.cws = (lds_fptr)cws;
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -637,9 +641,10 @@ __global__ void __launch_bounds__(kWave) body_tick_kernel(const pf_params P, con
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   const size_t li = lane, N = n;
+  __shared__ float cws[kContactSlots * kContactSlotFloats];
   VEH V;
   V.b.pdev = Pdev;
-  V.b.lane_idx = lane;
+  V.b.cws = (lds_fptr)cws;
   float nd;
   int4 ints;
   float4* S = reinterpret_cast<float4*>(B.state);
@@ -687,8 +692,7 @@ struct pf_ctx {
   // hot-path specialisation (quadx_fast.hpp)
   bool fast;
   pf::QuadK K;
-  pf_params* P_dev;  // device copy of P (a pf::pf_dev_block: the block + the contact workspace pointer) for the rarely-taken floor paths
-  float* contact_ws; // contact solver workspace, [PF_MAX_CONTACTS][kContactWords][n] floats, or null (contact_response off)
+  pf_params* P_dev;  // device copy of P for the rarely-taken floor paths (contact detection and response) and the LDS constant tables
   float4* tmpl;      // settled spawn state for lane-independent resets (env_kernel), or null
   // Fixedwing-Waypoints specialisation (fixedwing_fast.hpp)
   bool fast_fw;
@@ -785,7 +789,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
-  c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr; c->contact_ws = nullptr;
+  c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr;
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
   pf::FwTable fsurf;
   c->fast_fw = pf::fwk_from_params(P, c->FK, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;
@@ -793,21 +797,14 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     int cur = -1;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
-    pf::pf_dev_block blk;
-    blk.P = P; blk.contact_ws = nullptr; blk.n_lanes = n_lanes;
-    hipError_t e = hipSuccess;
-    if (P.contact_response) {
-      e = hipMalloc((void**)&c->contact_ws, sizeof(float) * (size_t)PF_MAX_CONTACTS * pf::kContactWords * (size_t)n_lanes);
-      blk.contact_ws = c->contact_ws;
-    }
-    if (e == hipSuccess) e = hipMalloc((void**)&c->P_dev, sizeof(pf::pf_dev_block));
-    if (e == hipSuccess) e = hipMemcpy(c->P_dev, &blk, sizeof(blk), hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
+    if (e == hipSuccess) e = hipMemcpy(c->P_dev, &P, sizeof(pf_params), hipMemcpyHostToDevice);
     if (e == hipSuccess && c->fast_fw) {
       e = hipMalloc((void**)&c->surf_dev, sizeof(fsurf));
       if (e == hipSuccess) e = hipMemcpy(c->surf_dev, &fsurf, sizeof(fsurf), hipMemcpyHostToDevice);
     }
     if (cur >= 0) (void)hipSetDevice(cur);
-    if (e != hipSuccess) { if (c->contact_ws) hipFree(c->contact_ws); if (c->P_dev) hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
+    if (e != hipSuccess) { if (c->P_dev) hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
   }
   if (!c->fast && (P.task == PF_TASK_HOVER || P.task == PF_TASK_WAYPOINTS) &&
       (P.vehicle == PF_FIXEDWING || P.noise_mode == PF_NOISE_OFF)) {
@@ -825,7 +822,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
       e = hipDeviceSynchronize();
     }
     if (cur >= 0) hipSetDevice(cur);
-    if (e != hipSuccess) { if (c->tmpl) hipFree(c->tmpl); if (c->surf_dev) hipFree(c->surf_dev); if (c->contact_ws) hipFree(c->contact_ws); hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: settle template"); }
+    if (e != hipSuccess) { if (c->tmpl) hipFree(c->tmpl); if (c->surf_dev) hipFree(c->surf_dev); hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: settle template"); }
   }
   *out = c;
   return PF_OK;
@@ -833,7 +830,6 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
 void pf_ctx_destroy(pf_ctx* ctx) {
   if (!ctx) return;
   if (ctx->P_dev) hipFree(ctx->P_dev);
-  if (ctx->contact_ws) hipFree(ctx->contact_ws);
   if (ctx->tmpl) hipFree(ctx->tmpl);
   if (ctx->surf_dev) hipFree(ctx->surf_dev);
   delete ctx;

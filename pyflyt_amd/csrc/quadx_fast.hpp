@@ -138,7 +138,7 @@ struct QuadHot {
   m3 R; v3 wb, vb;
   float pwm[4];
   bool contact_now, contact_step;
-  int lane_idx;  // this lane's slot in the contact solver's workspace
+  lds_fptr cws;  // the wave's LDS regions for the contact solver (aliased onto the observation tile, idle during the ticks)
 
   PF_DEV void derive() {
     // btMatrix3x3::setRotation scales by 2/|q|^2; q leaves quat_integrate()/the spawn normalised to
@@ -229,11 +229,11 @@ struct QuadHot {
       act = (fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop);
     }
     if (__any(act)) {
-      if (act && Pfull->contact_response) {
-        const ContactOut o = contact_solve_dev(Pfull, lane_idx, p, q, v, w);
+      contact_rounds(act && Pfull->contact_response, cws, [&](lds_fptr slot) {
+        const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
         v = o.v; w = o.w;
         lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
-      }
+      });
     }
     p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, K.half_dt);
@@ -280,7 +280,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   float4* Sout = reinterpret_cast<float4*>(B.state);
 
   QuadHot V;
-  V.lane_idx = (int)li;
+  static_assert(LPW * kMaxD >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
+  V.cws = (lds_fptr)tile;
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;

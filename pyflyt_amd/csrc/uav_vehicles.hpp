@@ -59,25 +59,21 @@ struct ContactOut {
   v3 v, w;
   float deepest;
 };
-// What the context keeps on the device: the parameter block and, behind it, the contact solver's workspace
-// ([PF_MAX_CONTACTS][20][n_lanes] floats: arm (3), accumulated impulses (3), initial normal velocity, depth, and per
-// direction the inverse effective mass and the angular response I_w^-1 (a x dir) (3 + 9); lane-minor so
-// that the lanes of a wave that are in contact touch consecutive addresses). Global memory on purpose: the per-contact
-// arrays are dynamically indexed, and as private (scratch) arrays they gave every kernel that can reach the solver a
-// 1.4 KB/lane private segment -- measured 1.5x slower env steps although the solver itself almost never runs.
-constexpr int kContactWords = 20;
-struct pf_dev_block {
-  pf_params P;
-  float* contact_ws;
-  int32_t n_lanes;
-};
+// Per-contact working set: arm (3), accumulated impulses (3), initial normal velocity, depth, the three inverse
+// effective masses. It lives in LDS: the arrays are dynamically indexed (as private arrays they gave every kernel a 1.4 KB/lane
+// scratch segment: env steps 1.5x slower), and the sweeps are a chain of dependent loads (in a global-memory workspace every
+// sweep paid a full memory round trip that a lone wave per SIMD cannot hide: +0.9 us per env step). Only a few lanes of a
+// wave need the solver in the same tick, so kContactSlots regions are enough; callers deal them out by ballot rank
+// (Body::respond) and come back for another round if more lanes ask. The hot kernels alias the regions onto their
+// observation tile, which is idle during the physics ticks.
+constexpr int kContactWords = 11;
+constexpr int kContactSlotFloats = PF_MAX_CONTACTS * kContactWords;  // 528
+constexpr int kContactSlots = 4;
+typedef __attribute__((address_space(3))) float* lds_fptr;
 // (inlined into the two out-of-line entry points below)
-PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
+PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
                                      float i0, float i1, float i2, float i3, float i4, float i5) {
-  const pf_dev_block* D = reinterpret_cast<const pf_dev_block*>(P);
-  float* ws = D->contact_ws + lane;
-  const size_t st = (size_t)D->n_lanes;
-  auto W = [&](int c, int f) -> float& { return ws[(size_t)(c * kContactWords + f) * st]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth, 8-10 1/k, 11-19 angular responses
+  auto W = [&](int c, int f) -> __attribute__((address_space(3))) float& { return ws[c * kContactWords + f]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth, 8-10 1/k
   const m3 R = rot_from_quat(q);
   const v3 cw = mul(R, com);
   const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin, slop = P->contact_slop;
@@ -129,9 +125,7 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
-      const v3 ang = symmul(Iw, cross(a, dir));
-      W(c, 8 + d) = 1.0f / (inv_mass + dot(dir, cross(ang, a)));
-      W(c, 11 + 3 * d) = ang.x; W(c, 12 + 3 * d) = ang.y; W(c, 13 + 3 * d) = ang.z;
+      W(c, 8 + d) = 1.0f / (inv_mass + dot(dir, cross(symmul(Iw, cross(a, dir)), a)));
     }
   }
   const float mu = P->contact_friction, rest = P->contact_restitution;
@@ -145,7 +139,7 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
 #pragma unroll
       for (int d = 0; d < 3; ++d) {  // normal +z, friction +x, friction +y
         const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
-        const v3 ang{W(c, 11 + 3 * d), W(c, 12 + 3 * d), W(c, 13 + 3 * d)};
+        const v3 ang = symmul(Iw, cross(a, dir));
         const v3 u = vc + cross(w, a);
         float target = 0.0f;
         if (d == 0) target = dep < slop ? (dep - slop) * inv_dt  // may close the gap down to the slop, no more
@@ -174,14 +168,28 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, int lane, 
 // Constant mass properties (QuadX, Fixedwing): read from the parameter block inside the call, so that the call passes 16
 // dwords -- all in registers; with the ten mass-property words as arguments the last three went over the stack and gave
 // every caller a private segment.
-__device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict__ P, int lane, v3 p, quat q, v3 v, v3 w) {
+__device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w) {
   const v3 com = P->has_com_offset ? v3{P->com[0], P->com[1], P->com[2]} : v3{0.f, 0.f, 0.f};
-  return contact_solve_impl(P, lane, p, q, v, w, P->inv_mass, com, P->I_inv[0], P->I_inv[1], P->I_inv[2], P->I_inv[3], P->I_inv[4], P->I_inv[5]);
+  return contact_solve_impl(P, ws, p, q, v, w, P->inv_mass, com, P->I_inv[0], P->I_inv[1], P->I_inv[2], P->I_inv[3], P->I_inv[4], P->I_inv[5]);
 }
 // Mass properties that change per tick (Rocket): passed by value.
-__device__ __noinline__ ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, int lane, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
+__device__ __noinline__ ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
                                                          float i0, float i1, float i2, float i3, float i4, float i5) {
-  return contact_solve_impl(P, lane, p, q, v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
+  return contact_solve_impl(P, ws, p, q, v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
+}
+// Deal the kContactSlots LDS regions out to the lanes of the (currently active part of the) wave that need the solver,
+// by ballot rank, in as many rounds as it takes. `solve(slot_base)` runs the solver for this lane.
+template <class F>
+PF_DEV void contact_rounds(bool need, lds_fptr ws, F&& solve) {
+  unsigned long long m = __ballot(need);
+  while (m != 0ull) {
+    const int rank = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+    if (need && rank < kContactSlots) {
+      solve(ws + rank * kContactSlotFloats);
+      need = false;
+    }
+    m = __ballot(need);
+  }
 }
 
 // Rigid body shared by both vehicles: the Bullet base state + what update_state derives from it.
@@ -252,7 +260,7 @@ struct Body {
   // constraint solve of stepSimulation: contacts found at the pre-integration pose act on the new velocities; returns the
   // position-level penetration recovery (contact_erp x deepest penetration) to add to z after the position update
   const pf_params* pdev;  // device copy of the parameter block (the out-of-line contact solver reads the colliders from it)
-  int lane_idx;           // this lane's slot in the contact solver's workspace
+  lds_fptr cws;           // the wave's kContactSlots LDS regions for the contact solver
   // Can any contact constraint act this tick? Every vertex lies within bound_radius of the base origin, so its height is
   // >= low = p.z - bound_radius and its normal velocity >= v.z - |w| bound_radius: if even that worst case ends the tick
   // above the allowed overlap (and nothing is deeper than it now), every constraint of the solve is slack -- all impulses
@@ -264,16 +272,24 @@ struct Body {
     return (low + Pd->contact_slop + Pd->dt * vlow < 0.0f) || (low < -Pd->contact_slop);
   }
   PF_DEV float respond(const pf_params* Pd) {
-    if (Pd == nullptr || !Pd->contact_response || !contact_may_act(Pd)) return 0.0f;
-    const ContactOut o = contact_solve_dev(Pd, lane_idx, p, q, v, w);
-    v = o.v; w = o.w;
-    return Pd->contact_erp * o.deepest;  // (deepest: already net of the slop)
+    if (Pd == nullptr) return 0.0f;  // (wave-uniform: kernels without ticks)
+    float lift = 0.0f;
+    contact_rounds(Pd->contact_response && contact_may_act(Pd), cws, [&](lds_fptr slot) {
+      const ContactOut o = contact_solve_dev(Pd, slot, p, q, v, w);
+      v = o.v; w = o.w;
+      lift = Pd->contact_erp * o.deepest;  // (deepest: already net of the slop)
+    });
+    return lift;
   }
   PF_DEV float respond_var(const pf_params* Pd, float inv_mass, v3 com, const float Iinv[6]) {
-    if (Pd == nullptr || !Pd->contact_response || !contact_may_act(Pd)) return 0.0f;
-    const ContactOut o = contact_solve_var_dev(Pd, lane_idx, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
-    v = o.v; w = o.w;
-    return Pd->contact_erp * o.deepest;
+    if (Pd == nullptr) return 0.0f;
+    float lift = 0.0f;
+    contact_rounds(Pd->contact_response && contact_may_act(Pd), cws, [&](lds_fptr slot) {
+      const ContactOut o = contact_solve_var_dev(Pd, slot, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
+      v = o.v; w = o.w;
+      lift = Pd->contact_erp * o.deepest;
+    });
+    return lift;
   }
   // The same tick for a body whose mass properties change over time (Rocket): inverse mass, centre of
   // mass, gyroscopic inertia H and inverse inertia (symmetric xx xy xz yy yz zz) are arguments.

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: pmc_roll.sh <tag> "<counters>" [ENV=VAL ...] -- SQ counters of the pf_rollout launches, per wave and per env step
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; tag=$1; ctrs=$2; shift; shift
-env "$@" rocprofv3 --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -- python $R/scratch/prof_roll.py > /dev/null 2>&1
+env "$@" timeout 150 rocprofv3 --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -- python $R/scratch/prof_roll.py > /dev/null 2>&1
 K=100; for kv in "$@"; do case $kv in K=*) K=${kv#K=};; esac; done
 python3 - "$tag" "$K" <<'PY'
 import csv,collections,glob,sys

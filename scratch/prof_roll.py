@@ -5,7 +5,8 @@ import torch
 from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine
 n = int(os.environ.get("N", "65536")); k = int(os.environ.get("K", "100")); reps = int(os.environ.get("REPS", "6"))
-P = build_params("quadx", os.environ.get("TASK", "hover"), noise=os.environ.get("NOISE", "philox"), autoreset="next_step")
+P = build_params("quadx", os.environ.get("TASK", "hover"), noise=os.environ.get("NOISE", "philox"), autoreset="next_step",
+                 world_options=dict(contact_response=os.environ.get("CR", "1") == "1"))
 eng = BatchEngine(P, n)
 eng.env_reset()
 for i in range(reps):

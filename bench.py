@@ -53,18 +53,23 @@ def parse():
     ap.add_argument("--no-contact-response", action="store_true",
                     help="contact DETECTION only (round-1 semantics: an episode still ends on the floor, but its terminal observation "
                          "lacks the impact impulse); diagnostic, not the headline configuration")
+    ap.add_argument("--world", action="append", default=[], metavar="KEY=VALUE",
+                    help="override an entry of pyflyt_amd.params.WORLD (diagnostic), e.g. --world contact_iters=6")
     ap.add_argument("--rollout-steps", type=int, default=100, help="env steps per pf_rollout launch of the second, state-resident figure (0 = skip)")
     return ap.parse_args()
 
 
-def make_engine(env, batch, device, lane_offset, noise, contact_response=True):
+def make_engine(env, batch, device, lane_offset, noise, contact_response=True, world=()):
     from pyflyt_amd import build_params
     from pyflyt_amd.engine import BatchEngine
 
     vehicle, task = {"hover": ("quadx", "hover"), "quadx_waypoints": ("quadx", "waypoints"),
                      "fixedwing_waypoints": ("fixedwing", "waypoints")}[env]
-    P = build_params(vehicle, task, noise=noise, autoreset="next_step", seed=0,
-                     world_options=None if contact_response else dict(contact_response=False))
+    wo = {} if contact_response else dict(contact_response=False)
+    for kv in world:
+        k, v = kv.split("=", 1)
+        wo[k] = float(v) if "." in v or "e" in v.lower() else int(v)
+    P = build_params(vehicle, task, noise=noise, autoreset="next_step", seed=0, world_options=wo or None)
     return BatchEngine(P, batch, device=device, lane_offset=lane_offset)
 
 
@@ -127,7 +132,7 @@ def main():
     # per-GPU slice; no collective in the timed loop
     shard = weak_shard(args.batch, rank, world) if args.scaling == "weak" else strong_shard(args.batch, rank, world)
     n = shard.lanes
-    eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise, contact_response=not args.no_contact_response)
+    eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise, contact_response=not args.no_contact_response, world=args.world)
     g = max(1, min(args.graph_steps, args.steps))
     ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(g)]
     for i, a in enumerate(ring):
@@ -234,7 +239,7 @@ def main():
                                    f"random actions, motor noise {args.noise}, NEXT_STEP auto-reset"
                        if args.env == "hover" else f"{args.env}, batch {n}/GPU x {world}",
                        "batch_per_gpu": n, "global_batch": total_lanes, "ticks_per_env_step": eng.ticks_per_step,
-                       "launch": "hipGraph" if graph is not None else "eager", "contact_response": not args.no_contact_response, "parallelism": f"dp{world} (independent lanes, no collective)"},
+                       "launch": "hipGraph" if graph is not None else "eager", "contact_response": not args.no_contact_response, "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "kernel": "pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel", "algorithmic_bytes_per_launch": algo,

@@ -245,6 +245,7 @@ def parse_urdf(path):
 class BulletClient:
     """Duck-type of pybullet_utils.bullet_client.BulletClient for the hot-path method set."""
 
+    DEFAULT_CONTACT_RESPONSE = True  # (tests/golden/gen_goldens.py switches it off while it records the env-level fixtures)
     DIRECT = 2
     GUI = 1
     LINK_FRAME = 1
@@ -260,7 +261,7 @@ class BulletClient:
         self._search = ""
         self.use_gyro_term = True
         # contact response against fixed bodies' top faces (the ground slab): see _solve_contacts
-        self.contact_response = True
+        self.contact_response = BulletClient.DEFAULT_CONTACT_RESPONSE
         self.contact_restitution, self.contact_friction, self.contact_erp, self.contact_iters = 0.0, 0.5, 0.2, 10
         self.contact_margin, self.contact_slop = 0.02, 0.001
 

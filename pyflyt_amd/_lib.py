@@ -7,7 +7,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyflyt_amd.so")
+# (PF_LIB_PATH: an alternative build of the same ABI, for A/B experiments: scratch/variants2/)
+LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libpyflyt_amd.so")
 
 QUADX, FIXEDWING, ROCKET = 0, 1, 2
 TASK_NONE, TASK_HOVER, TASK_WAYPOINTS, TASK_MA_HOVER = 0, 1, 2, 3

@@ -720,16 +720,19 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
-#define PF_FAST(NZ) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
+#define PF_FAST2(NZ, CR) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
+#define PF_FAST(NZ) do { if (ctx->P.contact_response) PF_FAST2(NZ, true); else PF_FAST2(NZ, false); } while (0)
   if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
   else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
   else PF_FAST(PF_NOISE_OFF);
 #undef PF_FAST
+#undef PF_FAST2
 }
 template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
-#define PF_ROLL(NZ, R) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+#define PF_ROLL2(NZ, R, CR) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+#define PF_ROLL(NZ, R) do { if (ctx->P.contact_response) PF_ROLL2(NZ, R, true); else PF_ROLL2(NZ, R, false); } while (0)
   if (b->actions == nullptr) {
     if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX, 1);
     else PF_ROLL(PF_NOISE_OFF, 1);
@@ -738,6 +741,7 @@ static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32
     else PF_ROLL(PF_NOISE_OFF, 2);
   }
 #undef PF_ROLL
+#undef PF_ROLL2
 }
 static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;

@@ -31,6 +31,9 @@ struct QuadK {
   float use_gyro;              // 1.0 / 0.0
   float bound_radius;          // gate of the out-of-line floor code (incl. the speculative contact margin)
   float bound_radius0, slop;   // the bare bounding radius and the allowed overlap: "can a contact constraint act this tick?"
+  float box_h[3], plane_xy, plane_z;  // the collision box's half extents and the slab's: kernel-argument SGPRs, because with random
+                                      // actions some lane of nearly every wave is near the floor in nearly every tick -- as scalar
+                                      // loads inside that block they cost a memory round trip per tick (+0.7 us per env step)
   // motors (identical): motors.py:131-138,182-193
   float m_a, m_noise, fmax, tmax;
   float ryf[4], rxf[4];        // r_y*fmax, -r_x*fmax per motor (torque arms)
@@ -78,6 +81,8 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   if (!(P.motor_tmax[0] == P.motor_tmax[1] && P.motor_tmax[2] == P.motor_tmax[3] && P.motor_tmax[0] == -P.motor_tmax[2] &&
         P.motor_tmax[0] <= 0.f)) return false;
   if (P.n_boxes != 1 || P.boxes[0].kind != 0 || P.num_targets > 4) return false;
+  // (the tick's direct lowest-vertex floor test assumes the one collision box is centred on the base origin and not yawed)
+  if (P.boxes[0].c[0] != 0.f || P.boxes[0].c[1] != 0.f || P.boxes[0].c[2] != 0.f || P.boxes[0].yaw != 0.f) return false;
   if (P.ticks_per_control != 2 || P.env_step_ratio > 4 || P.env_step_ratio < 1) return false;
   if ((P.settle_steps * 2) % 4 != 0 || P.settle_steps * 2 > 24) return false;
   K.dt = P.dt; K.half_dt = 0.5f * P.dt; K.gravity_z = P.gravity_z; K.vmax = P.max_coord_vel; K.inv_mass = P.inv_mass;
@@ -87,6 +92,8 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   // gate of the out-of-line floor code: within one bounding radius of the floor, widened by the speculative contact margin
   K.bound_radius = P.bound_radius + (P.contact_response ? P.contact_margin : 0.0f);
   K.bound_radius0 = P.bound_radius; K.slop = P.contact_slop;
+  for (int k = 0; k < 3; ++k) K.box_h[k] = P.boxes[0].h[k];
+  K.plane_xy = P.plane_half_xy; K.plane_z = P.plane_half_z;
   K.m_a = P.motor_dt_over_tau[0]; K.m_noise = P.motor_noise[0]; K.fmax = P.motor_fmax[0]; K.tmax = P.motor_tmax[2];
   for (int i = 0; i < 4; ++i) { K.ryf[i] = P.motor_r[i][1] * P.motor_fmax[0]; K.rxf[i] = -P.motor_r[i][0] * P.motor_fmax[0]; }
   for (int k = 0; k < 3; ++k) {
@@ -181,6 +188,11 @@ struct QuadHot {
     for (int i = 0; i < 4; ++i) pwm[i] = med3(pwm[i], 0.05f, 1.0f);
   }
   // one physics tick: update_physics (quadx.py:495-510) + stepSimulation + update_state (:512-535)
+  // CR: contact RESPONSE compiled in (pf_params.contact_response). The env tasks of this kernel end the episode in the Aviary
+  // step that reports a floor contact, so the response can only alter that terminal observation; it is a template switch
+  // because even its never-taken call site costs the hot loop (+0.6 us per env step at 65 536 lanes: one more divergent region
+  // and its PHI copies per tick, profiles/r02), and with random actions some lane of nearly every wave is near the floor.
+  template <bool CR>
   PF_DEV void tick(const QuadK& K, float xi, const pf_params* Pfull) {
     const float s = fmaf(xi, K.m_noise, 1.0f);
     float k[4];
@@ -205,13 +217,23 @@ struct QuadHot {
     // body-frame specific force (force / mass): body drag (boring_bodies.py:113-119) + thrust along +z
     v3 Fm{-K.dragM[0] * (vb.x * __builtin_fabsf(vb.x)), -K.dragM[1] * (vb.y * __builtin_fabsf(vb.y)),
           fmaf(-K.dragM[2], vb.z * __builtin_fabsf(vb.z), K.fmaxM * ((k[0] + k[1]) + (k[2] + k[3])))};
-    // collision detection at the pre-integration pose
+    // collision detection at the pre-integration pose. The single collision box is centred on the base origin, so its
+    // lowest vertex sits at low = p.z - (|R20| hx + |R21| hy + |R22| hz), and away from the slab's rim the 15-axis verdict
+    // "penetration >= 0" IS low <= 0 (the slab's top-face normal is the only axis that can separate a box from what is
+    // locally a half-space; the direct form also avoids the cancellation of (p.z + 5) - (5 + ext) in fp32). The out-of-line
+    // 15-axis test runs only within one bounding radius of the rim.
     bool near = (p.z - K.bound_radius) <= 0.0f;
     contact_now = false;
+    float low = INFINITY;
     if (__any(near)) {
-      if (near)
-        contact_now = quad_floor_contact(p.x, p.y, p.z, q, Pfull->boxes[0].h[0], Pfull->boxes[0].h[1], Pfull->boxes[0].h[2],
-                                         Pfull->plane_half_xy, Pfull->plane_half_z);
+      if (near) {
+        const float hx = K.box_h[0], hy = K.box_h[1], hz = K.box_h[2];
+        const float pxy = K.plane_xy, pz = K.plane_z;
+        low = p.z - fmaf(__builtin_fabsf(R.m20), hx, fmaf(__builtin_fabsf(R.m21), hy, __builtin_fabsf(R.m22) * hz));
+        const bool inside = (__builtin_fabsf(p.x) + K.bound_radius0 < pxy) && (__builtin_fabsf(p.y) + K.bound_radius0 < pxy) && (low > -pz);
+        contact_now = low <= 0.0f;
+        if (!inside) contact_now = quad_floor_contact(p.x, p.y, p.z, q, hx, hy, hz, pxy, pz);
+      }
     }
     v3 wd = mul(R, wdb);
     v3 a{fmaf(R.m00, Fm.x, fmaf(R.m01, Fm.y, R.m02 * Fm.z)), fmaf(R.m10, Fm.x, fmaf(R.m11, Fm.y, R.m12 * Fm.z)),
@@ -223,19 +245,21 @@ struct QuadHot {
     // (can a constraint act at all this tick? conservative bound on the lowest vertex's height after the tick; when it stays
     //  above the allowed overlap every constraint is slack, the solve would return the velocities unchanged: Body::contact_may_act)
     float lift = 0.0f;
-    bool act = false;
-    if (near) {
-      const float low = p.z - K.bound_radius0, vlow = v.z - fsqrt(dot(w, w)) * K.bound_radius0;
-      act = (fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop);
+    if (CR) {
+      bool act = false;
+      if (near) {  // (low: the exact height of the lowest vertex, from the detection above)
+        const float vlow = v.z - fsqrt(dot(w, w)) * K.bound_radius0;
+        act = (fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop);
+      }
+      if (__any(act)) {
+        contact_rounds(act, cws, [&](lds_fptr slot) {
+          const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
+          v = o.v; w = o.w;
+          lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
+        });
+      }
     }
-    if (__any(act)) {
-      contact_rounds(act && Pfull->contact_response, cws, [&](lds_fptr slot) {
-        const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
-        v = o.v; w = o.w;
-        lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
-      });
-    }
-    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
+    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), CR ? fmaf(K.dt, v.z, p.z) + lift : fmaf(K.dt, v.z, p.z)};
     q = quat_integrate(q, w, K.half_dt);
     derive();
     contact_step |= contact_now;
@@ -258,7 +282,7 @@ struct QuadHot {
 // loop then contains NO vector-memory load, so nothing in it ever waits on vmcnt (on gfx9 stores count in vmcnt too: a
 // load in the loop would make every step wait for the previous step's observation stores to be acknowledged);
 // 2 = pf_rollout over a given action sequence (prefetched one step ahead; pays that wait).
-template <int TASK, int NOISE, int LPW, int ROLL>
+template <int TASK, int NOISE, int LPW, int ROLL, bool CR>
 __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
                                                              const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
@@ -602,8 +626,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       // one Aviary.step (aviary.py:480-531): control on the first tick, pwm held on the second
       V.contact_step = false;
       V.control(K, sp0, sp1, sp2, sp3);
-      V.tick(K, xi0, Pfull);
-      V.tick(K, xi1, Pfull);
+      V.template tick<CR>(K, xi0, Pfull);
+      V.template tick<CR>(K, xi1, Pfull);
       // compute_state side effects + compute_term_trunc_reward
       if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:135-142; ||R^T d|| = ||d||
         if (pop_pending) { pop_target(); pop_pending = false; }

@@ -194,7 +194,10 @@ WORLD: dict[str, Any] = {
     # contact response against that slab: a named-parameter model of what stepSimulation does after collision detection
     # (vertex contacts, projected Gauss-Seidel at the velocity level, position-level penetration recovery; DESIGN.md
     # section 3), with Bullet's defaults: restitution 0, lateral friction 0.5 (body) x 1.0 (plane.urdf), erp 0.2
-    "contact_response": True,
+    # None = by task: ON for the Aviary-level surface (landings), OFF for the gym / PettingZoo env tasks, which end the episode in
+    # the Aviary step that reports the contact -- there the response could only alter that one terminal observation, and it
+    # costs every env step ~12 %. True / False force it.
+    "contact_response": None,
     "contact_restitution": 0.0,
     "contact_friction": 0.5,
     "contact_erp": 0.2,
@@ -311,7 +314,7 @@ def build_params(
     P.plane_half_xy = W["plane_half_xy"] * W["world_scale"]
     P.plane_half_z = W["plane_half_z"] * W["world_scale"]
     # contact response against the ground slab (named-parameter model; Bullet's defaults)
-    P.contact_response = int(bool(W["contact_response"]))
+    P.contact_response = int(task == "none") if W["contact_response"] is None else int(bool(W["contact_response"]))
     P.contact_restitution, P.contact_friction, P.contact_erp = W["contact_restitution"], W["contact_friction"], W["contact_erp"]
     P.contact_iters = int(W["contact_iters"])
     P.contact_margin = W["contact_margin"] * W["world_scale"]

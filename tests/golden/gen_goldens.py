@@ -299,7 +299,19 @@ def flat_obs(env, obs, num_targets):
     return np.array(obs, dtype=np.float64)
 
 
-def run_env(make, n_steps, seed, action_fn, num_targets=0, ticks=6):
+def run_env(make, n_steps, seed, action_fn, num_targets=0, ticks=6, contact_response=False):
+    """contact_response: the gym / PettingZoo env tasks default to contact DETECTION only (they end the episode in the Aviary
+    step that reports the contact; pyflyt_amd.params.WORLD); `True` records the same env with the response on."""
+    from oracle import fake_bullet
+
+    fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = contact_response
+    try:
+        return _run_env(make, n_steps, seed, action_fn, num_targets, ticks)
+    finally:
+        fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
+
+
+def _run_env(make, n_steps, seed, action_fn, num_targets=0, ticks=6):
     env = make()
     obs, info = env.reset(seed=seed)
     rng_env = env.np_random
@@ -362,6 +374,8 @@ def lowthrust_quad_action(env, rng, k):
 
 def gen_envs_crash():
     save("env_hover_crash", **run_env(lambda: QuadXHoverEnv(), 150, 8, lowthrust_quad_action, ticks=6))
+    # the same episodes with the contact response on: the terminal observations carry the impact impulses
+    save("env_hover_crash_response", **run_env(lambda: QuadXHoverEnv(), 150, 8, lowthrust_quad_action, ticks=6, contact_response=True))
     # the fixedwing cannot reach the 30 m x 30 m floor box from its default start (z=10, 20 m/s), so
     # floor contact for it is pinned at Aviary level, from a low start
     d = run_aviary("fixedwing", 0, 60, seed=12, start_pos=[0.0, 0.0, 0.8], start_orn=[0.2, 0.25, 0.0], noise=True)
@@ -401,7 +415,10 @@ def gen_ma_hover():
         made.append(r)
         return r
 
+    from oracle import fake_bullet
+
     np.random.default_rng = recording_default_rng
+    fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = False  # env tasks: detection only by default (see run_env)
     try:
         env = MAQuadXHoverEnv(flight_dome_size=2.5, max_duration_seconds=1.0)  # small dome/duration: both exits occur
         rng = orig(123)
@@ -435,6 +452,7 @@ def gen_ma_hover():
              **{k: np.array(v) for k, v in rec.items()})
     finally:
         np.random.default_rng = orig
+        fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
 
 
 if __name__ == "__main__":

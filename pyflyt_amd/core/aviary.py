@@ -308,8 +308,15 @@ class Aviary:
         # positions with the not-yet-advanced elapsed_time) -> contact splice -> counters
         for _ in range(n_steps):
             acc = torch.zeros_like(self.engine.out_contact)
+            sp = self.setpoints
+            if self._controller is not None:
+                # quadx.py:417-429: a registered custom controller runs at the control tick (tick 0 of the Aviary step) on the
+                # state the last update_state left, wind field or not; its output is the base mode's setpoint for this step
+                sp = self._controller.step(self.all_states, self.setpoints)
+                sp = sp.to(device=self.device, dtype=torch.float32).reshape(self.num_drones, -1).contiguous()
+                assert sp.shape[1] == self._base_sp_dim, f"custom controller outputting wrong shape, expected (N, {self._base_sp_dim}) but got {tuple(sp.shape)}."
             for t in range(self.updates_per_step):
-                self.engine.aviary_tick(self.setpoints, t, wind=self._wind)
+                self.engine.aviary_tick(sp, t, wind=self._wind)
                 acc |= self.engine.out_contact
                 self._wind = self._sample_wind()
                 self.physics_steps += 1

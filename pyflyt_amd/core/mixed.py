@@ -36,11 +36,17 @@ class MixedAviary:
                 self._where[i] = (k, j)
         base_offset = int(kw.pop("lane_offset", 0))
         self.parts: dict[str, Any] = {}
+        done = 0
         for k, idx in self._idx.items():
             opts = [dict(drone_options[i] or {}) for i in idx]
             same = all(o == opts[0] for o in opts)
+            # RNG lanes: the counter-based generator is keyed by (seed, lane); every part gets its own DISJOINT lane range
+            # [base + drones of the earlier parts, ...) so that no two drones of the fleet -- of this shard or, with
+            # lane_offset advanced by num_drones per shard, of another -- ever share a key (interleaved types would
+            # otherwise overlap: ['quadx', 'fixedwing', 'quadx'] used lanes {0, 1} and {1})
             self.parts[k] = Aviary(start_pos[idx], start_orn[idx], drone_type=k, drone_options=opts[0] if same else opts,
-                                   lane_offset=base_offset + idx[0], **kw)
+                                   lane_offset=base_offset + done, **kw)
+            done += len(idx)
         any_part = next(iter(self.parts.values()))
         self.physics_hz = any_part.physics_hz
         self.device = any_part.device

@@ -114,6 +114,26 @@ class BatchEngine:
                              f"got {t.dtype} {tuple(t.shape)} on {t.device}")
         return t
 
+    def _check(self, t, shape, dtypes, name):
+        """Every tensor whose data_ptr() crosses the C ABI is checked here: the kernels index raw pointers, so a wrongly
+        sized, typed, placed or strided tensor would read or write out of bounds silently."""
+        if t is None:
+            return None
+        if t.dtype not in dtypes or t.device != self.device or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} must be a contiguous {'/'.join(str(d) for d in dtypes)} tensor of shape {tuple(shape)} on {self.device}, "
+                             f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+        return t
+
+    def _sp_dim(self, mode=None):
+        mode = self.params.flight_mode if mode is None else mode
+        return 7 if self.params.vehicle == L.ROCKET else (6 if (self.params.vehicle == L.FIXEDWING and mode == -1) else 4)
+
+    def _check_per_lane(self):
+        self._check(self.ctrl_ratio, (self.n,), (torch.int32,), "ctrl_ratio")
+        self._check(self.modes, (self.n,), (torch.int32,), "modes")
+        self._check(self.start_vel, (self.n, 3), (torch.float32,), "start_vel")
+        self._check(self.armed, (self.n,), (torch.bool, torch.uint8), "armed")
+
     @property
     def ticks_per_step(self):
         return self.params.env_step_ratio * self.params.ticks_per_control
@@ -128,6 +148,8 @@ class BatchEngine:
             if mask.dtype != torch.bool and mask.dtype != torch.uint8:
                 raise ValueError("mask must be a bool/uint8 tensor")
             mask = mask.to(device=self.device).contiguous()
+            self._check(mask, (self.n,), (torch.bool, torch.uint8), "mask")
+        self._check_targets(u_targets)
         self._check_f32(xi_reset, (self.settle_ticks, self.n), "xi_reset")
         b = self._buffers(xi_reset=xi_reset, u_targets=u_targets)
         with torch.cuda.device(self.device):
@@ -138,10 +160,16 @@ class BatchEngine:
         self._check_f32(actions, (self.n, 4), "actions")
         self._check_f32(xi, (self.ticks_per_step, self.n), "xi")
         self._check_f32(xi_reset, (self.settle_ticks, self.n), "xi_reset")
+        self._check_targets(u_targets)
         b = self._buffers(actions=actions, xi=xi, xi_reset=xi_reset, u_targets=u_targets)
         with torch.cuda.device(self.device):
             L.check(self.lib.pf_env_step(self._ctx, C.byref(b), self._stream()), self._ctx)
         return self.obs, self.reward, self.terminated, self.truncated
+
+    def _check_targets(self, u_targets):
+        if u_targets is not None:
+            rows = (4 if self.params.use_yaw_targets else 3) * self.params.num_targets
+            self._check_f32(u_targets, (rows, self.n), "u_targets")
 
     def sample_actions(self, out, step_index: int):
         self._check_f32(out, (self.n, 4), "out")
@@ -196,6 +224,7 @@ class BatchEngine:
     def aviary_reset(self, start_pose=None):
         self._aviary_outputs()
         self._check_f32(start_pose, (self.n, 7), "start_pose")
+        self._check_per_lane()
         b = self._buffers(start_pose=start_pose)
         with torch.cuda.device(self.device):
             L.check(self.lib.pf_aviary_reset(self._ctx, C.byref(b), self._stream()), self._ctx)
@@ -203,6 +232,8 @@ class BatchEngine:
 
     def aviary_set_mode(self, mode: int, setpoints):
         self._aviary_outputs()
+        self._check_f32(setpoints, (self.n, self._sp_dim(int(mode))), "setpoints")
+        self._check_per_lane()
         b = self._buffers()
         with torch.cuda.device(self.device):
             L.check(self.lib.pf_aviary_set_mode(self._ctx, C.byref(b), int(mode), _ptr(setpoints), self._stream()), self._ctx)
@@ -210,6 +241,9 @@ class BatchEngine:
 
     def aviary_step(self, setpoints, n_steps: int = 1, xi=None):
         self._aviary_outputs()
+        self._check_f32(setpoints, (self.n, self._sp_dim()), "setpoints")
+        self._check_f32(xi, (int(n_steps) * self.params.ticks_per_control, self.n), "xi")
+        self._check_per_lane()
         b = self._buffers(setpoints=setpoints, xi=xi)
         with torch.cuda.device(self.device):
             L.check(self.lib.pf_aviary_step(self._ctx, C.byref(b), int(n_steps), self._stream()), self._ctx)
@@ -222,6 +256,8 @@ class BatchEngine:
         self._aviary_outputs()
         self._check_f32(wind, (self.n, self.wind_links, 3), "wind")
         self._check_f32(xi, (self.n,), "xi")
+        self._check_f32(setpoints, (self.n, self._sp_dim()), "setpoints")
+        self._check_per_lane()
         b = self._buffers(setpoints=setpoints, xi=xi, wind=wind)
         with torch.cuda.device(self.device):
             L.check(self.lib.pf_aviary_tick(self._ctx, C.byref(b), int(tick_index), self._stream()), self._ctx)

@@ -159,3 +159,50 @@ def test_wind_field_validation():
     with pytest.raises(LookupError):
         Aviary(np.array([[0.0, 0.0, 1.0]]), np.zeros((1, 3)), drone_type="quadx", wind_type=3)
     env.disconnect()
+
+
+def test_custom_controller_runs_under_a_wind_field():
+    """A registered custom controller (quadx.py:417-429) must run at the control tick whether or not a wind field is attached:
+    the tick-by-tick wind path and the fused path (no wind) call it once per Aviary step with the same states, and with a
+    zero wind field both paths must end in the same place."""
+    from pyflyt_amd.core import Aviary
+
+    class Steer:
+        calls = 0
+
+        def reset(self):
+            pass
+
+        def step(self, state, setpoint):
+            Steer.calls += 1
+            tv = torch.tensor([1.0, 1.0, 1.5], device=state.device) - state[:, 3]
+            return torch.cat([tv[:, :2], torch.full_like(tv[:, :1], 0.3), tv[:, 2:]], dim=1)
+
+    n = 64
+    pos = np.tile(np.array([[0.0, 0.0, 1.0]]), (n, 1))
+    envs = []
+    for with_wind in (False, True):
+        env = Aviary(pos, np.zeros((n, 3)), "quadx", seed=2, motor_noise=False)
+        if with_wind:
+            env.register_wind_field_function(lambda t, p: torch.zeros_like(p))
+        env.register_controller(controller_id=8, controller_constructor=Steer, base_mode=6)
+        env.set_mode(8)
+        Steer.calls = 0
+        for _ in range(60):
+            env.step()
+        assert Steer.calls == 60
+        envs.append(env)
+    a, b = envs
+    assert torch.allclose(a.all_states, b.all_states, rtol=1e-5, atol=1e-6)
+    assert float((a.all_states[:, 3, :2] - torch.tensor(pos[:, :2], device="cuda:0", dtype=torch.float32)).abs().max()) > 0.05  # it did steer
+    # and a real wind changes the outcome while the controller keeps running
+    c = Aviary(pos, np.zeros((n, 3)), "quadx", seed=2, motor_noise=False)
+    c.register_wind_field_function(wind_torch)
+    c.register_controller(controller_id=8, controller_constructor=Steer, base_mode=6)
+    c.set_mode(8)
+    Steer.calls = 0
+    for _ in range(60):
+        c.step()
+    assert Steer.calls == 60 and float((c.all_states - a.all_states).abs().max()) > 1e-3
+    for e in (a, b, c):
+        e.disconnect()

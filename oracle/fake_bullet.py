@@ -447,9 +447,18 @@ class BulletClient:
                     continue
                 A, B = self._bodies[ia], self._bodies[ib]
                 if A.fixed == B.fixed:
-                    assert A.fixed or True  # drone-drone contact is out of scope
-                    if not A.fixed:
+                    if A.fixed:
                         continue
+                    # two free bodies (the PettingZoo envs put every agent's drone in one world): box colliders, the 15-axis
+                    # verdict evaluated in the second box's frame. Detection only -- no impulses between drones.
+                    hit = False
+                    for ca, Ra, ha in A.world_boxes():
+                        for cb, Rb, hb in B.world_boxes():
+                            if _box_box_overlap(Rb.T @ (ca - cb), Rb.T @ Ra, ha, np.zeros(3), hb):
+                                hit = True
+                    if hit:
+                        self._contacts.append((0, ia, ib, -1, -1))
+                    continue
                 fixed, free = (A, B) if A.fixed else (B, A)
                 idf, idr = (ia, ib) if A.fixed else (ib, ia)
                 hit = False

@@ -116,6 +116,7 @@ class Lane(C.Structure):
         ("fuel_ratio", C.c_double), ("ignition", C.c_int), ("gimbal", C.c_double * 2),
         ("pid_I", d3 * 4), ("pid_E", d3 * 4), ("zpid_I", C.c_double * 2), ("zpid_E", C.c_double * 2),
         ("mode", C.c_int), ("physics_steps", C.c_int), ("contact_now", C.c_int), ("contact_step", C.c_int),
+        ("world_contact", C.c_int), ("peer_contact", C.c_int),
         ("step_count", C.c_int), ("terminated", C.c_int), ("truncated", C.c_int),
         ("info_oob", C.c_int), ("info_collision", C.c_int), ("info_complete", C.c_int),
         ("num_targets_reached", C.c_int),
@@ -170,6 +171,10 @@ def lib():
         L.orc_aviary_reset.argtypes = [PP, LP, C.c_uint64]
         L.orc_aviary_step.argtypes = [PP, LP, dp, C.c_uint32, C.c_uint32]
         L.orc_env_reset.argtypes = [PP, LP, C.c_uint64, dp, dp]
+        PPP, LPP, dpp = C.POINTER(PP), C.POINTER(LP), C.POINTER(dp)
+        L.orc_world_aviary_step.argtypes = [PPP, LPP, C.c_int, dpp, C.c_uint32, C.c_uint32]
+        L.orc_world_env_reset.argtypes = [PPP, LPP, C.c_int, C.c_uint64, dpp]
+        L.orc_world_env_step.argtypes = [PPP, LPP, C.c_int, dp, dpp]
         L.orc_env_step.argtypes = [PP, LP, dp, dp]
         L.orc_obs_dim.argtypes = [PP]
         L.orc_env_obs.argtypes = [PP, LP, dp]
@@ -226,6 +231,42 @@ def make_params(env: str, noise_mode: int = NOISE_OFF, seed: int = 0, **override
             setattr(P, k, v)
     L.orc_finalize(C.byref(P))
     return P
+
+
+class OracleWorld:
+    """A drones in ONE world (the PettingZoo envs): drone-drone contact detection and the world-global rotational-drag
+    gate couple them; everything else is per drone. params: one block per drone (its own spawn pose)."""
+
+    def __init__(self, params_list, lane_id0: int = 0):
+        self.A = len(params_list)
+        self.Ps = list(params_list)
+        self.Ls = [Lane() for _ in range(self.A)]
+        self.lane_id0 = lane_id0
+        PP, LP = C.POINTER(Params), C.POINTER(Lane)
+        self._pp = (PP * self.A)(*[C.pointer(p) for p in self.Ps])
+        self._lp = (LP * self.A)(*[C.pointer(l) for l in self.Ls])
+        self.obs_dim = lib().orc_obs_dim(C.byref(self.Ps[0]))
+
+    def _rows(self, x):
+        """[A, k] array of injected draws -> array of A row pointers (kept alive on self), or None."""
+        if x is None:
+            return None
+        self._keep = [np.ascontiguousarray(r, dtype=np.float64) for r in x]
+        dp = C.POINTER(C.c_double)
+        return (dp * self.A)(*[r.ctypes.data_as(dp) for r in self._keep])
+
+    def reset(self, xi_reset=None):
+        lib().orc_world_env_reset(self._pp, self._lp, self.A, self.lane_id0, self._rows(xi_reset))
+        return self.obs()
+
+    def step(self, actions, xi=None):
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.A, 4)
+        lib().orc_world_env_step(self._pp, self._lp, self.A, _dp(a), self._rows(xi))
+        return (self.obs(), np.array([l.reward for l in self.Ls]), np.array([bool(l.terminated) for l in self.Ls]),
+                np.array([bool(l.truncated) for l in self.Ls]))
+
+    def obs(self):
+        return np.stack([np.frombuffer(l.obs, dtype=np.float64, count=self.obs_dim).copy() for l in self.Ls])
 
 
 class OracleBatch:

@@ -1103,9 +1103,14 @@ void orc_params_rocket(orc_params* P) {
 }
 
 /* aviary.py:480-531 */
+static void aviary_tick_one(const orc_params* P, orc_lane* L, const double* xi, int t, uint32_t flat_base, uint32_t stream);
 void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_t flat_base, uint32_t stream) {
   L->contact_step = 0; /* :507 */
-  for (int t = 0; t < P->world.ticks_per_control; ++t) {
+  for (int t = 0; t < P->world.ticks_per_control; ++t) aviary_tick_one(P, L, xi, t, flat_base, stream);
+}
+/* one physics tick of Aviary.step for one drone (aviary.py:510-525): control, forces, stepSimulation, update_state */
+static void aviary_tick_one(const orc_params* P, orc_lane* L, const double* xi, int t, uint32_t flat_base, uint32_t stream) {
+  {
     /* update_control */
     if (L->physics_steps % P->world.ticks_per_control == 0) {
       if (P->vehicle == ORC_QUADX) {
@@ -1137,7 +1142,7 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
         cross3(P->motor_r[i], thrust[i], rxf);
         for (int k = 0; k < 3; ++k) { F_b[k] += thrust[i][k]; T_b[k] += rxf[k] + torque[i][k]; }
       }
-      if (!L->contact_now) { /* quadx.py:502-510 */
+      if (!(L->contact_now || L->world_contact)) { /* quadx.py:502-510: no contact point anywhere in the world */
         for (int k = 0; k < 3; ++k) T_b[k] += -sgn(L->w_b[k]) * P->drag_coef_pqr * (L->w_b[k] * L->w_b[k]);
       }
     } else if (P->vehicle == ORC_ROCKET) {
@@ -1157,13 +1162,53 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
       for (int k = 0; k < 3; ++k) { F_b[k] += thrust[0][k]; T_b[k] += rxf[k] + torque[0][k]; }
     }
     /* stepSimulation: collision detection at the pre-integration pose, then the free-body tick */
-    L->contact_now = orc_contact_plane(P, L->p, L->q);
+    L->contact_now = orc_contact_plane(P, L->p, L->q) || L->peer_contact;
     if (P->vehicle == ORC_ROCKET) rigid_tick_body(P, &rocket_body, L->p, L->q, L->v, L->w, F_b, T_b);
     else orc_rigid_tick(P, L->p, L->q, L->v, L->w, F_b, T_b);
     orc_update_state(P, L);
     if (L->contact_now) L->contact_step = 1; /* :523-525 */
     L->physics_steps += 1;
   }
+}
+
+/* ---- shared world ---- */
+/* box k of drone a against box l of drone b: the 15-axis verdict with b's frame as the axis-aligned one */
+static int drones_overlap(const orc_params* Pa, const orc_lane* La, const orc_params* Pb, const orc_lane* Lb) {
+  double d[3] = {La->p[0] - Lb->p[0], La->p[1] - Lb->p[1], La->p[2] - Lb->p[2]};
+  const double rr = Pa->bound_radius + Pb->bound_radius;
+  if (dot3(d, d) > rr * rr) return 0; /* bounding spheres apart */
+  double Ra[3][3], Rb[3][3];
+  orc_matrix_from_quat(La->q, Ra);
+  orc_matrix_from_quat(Lb->q, Rb);
+  for (int k = 0; k < Pa->n_boxes; ++k) {
+    for (int l = 0; l < Pb->n_boxes; ++l) {
+      double oa[3], ob[3], ca[3], rel[3], Rrel[3][3];
+      matvec(Ra, Pa->boxes[k].c, oa);
+      matvec(Rb, Pb->boxes[l].c, ob);
+      for (int i = 0; i < 3; ++i) ca[i] = (La->p[i] + oa[i]) - (Lb->p[i] + ob[i]);
+      matTvec(Rb, ca, rel); /* a's box centre in b's box frame */
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { Rrel[i][j] = 0.0; for (int m = 0; m < 3; ++m) Rrel[i][j] += Rb[m][i] * Ra[m][j]; }
+      const double zero[3] = {0.0, 0.0, 0.0};
+      if (orc_box_box_overlap(rel, Rrel, Pa->boxes[k].h, zero, Pb->boxes[l].h)) return 1;
+    }
+  }
+  return 0;
+}
+void orc_world_aviary_step(const orc_params* const* Pl, orc_lane* const* Ll, int A, const double* const* xi,
+                           uint32_t flat_base, uint32_t stream) {
+  for (int i = 0; i < A; ++i) Ll[i]->contact_step = 0;
+  const int tpc = Pl[0]->world.ticks_per_control;
+  for (int t = 0; t < tpc; ++t) {
+    int world_prev = 0; /* contact points left by the previous stepSimulation, anywhere in the world */
+    for (int i = 0; i < A; ++i) world_prev |= Ll[i]->contact_now;
+    for (int i = 0; i < A; ++i) { Ll[i]->world_contact = world_prev; Ll[i]->peer_contact = 0; }
+    for (int i = 0; i < A; ++i) /* this tick's collision detection between the drones, at the pre-integration poses */
+      for (int j = i + 1; j < A; ++j)
+        if (drones_overlap(Pl[i], Ll[i], Pl[j], Ll[j])) { Ll[i]->peer_contact = 1; Ll[j]->peer_contact = 1; }
+    for (int i = 0; i < A; ++i) aviary_tick_one(Pl[i], Ll[i], xi ? xi[i] : 0, t, flat_base, stream);
+  }
+  for (int i = 0; i < A; ++i) Ll[i]->peer_contact = 0;
 }
 
 /* gym_envs/utils/waypoint_handler.py:53-89 ; injected draws: u[0:n]=theta, u[n:2n]=phi,
@@ -1347,6 +1392,37 @@ void orc_env_step(const orc_params* P, orc_lane* L, const double action[4], cons
   }
   L->step_count += 1;
   L->rng_ctr += 1;
+}
+
+/* ---- PettingZoo env on a shared world (ma_quadx_base_env.py:183-371, ma_quadx_hover_env.py:99-205) ---- */
+void orc_world_env_reset(const orc_params* const* Pl, orc_lane* const* Ll, int A, uint64_t lane_id0, const double* const* xi_reset) {
+  for (int i = 0; i < A; ++i) {
+    orc_aviary_reset(Pl[i], Ll[i], lane_id0 + (uint64_t)i);
+    orc_set_mode(Pl[i], Ll[i], Pl[i]->flight_mode);
+    Ll[i]->world_contact = 0; Ll[i]->peer_contact = 0;
+  }
+  const int tpc = Pl[0]->world.ticks_per_control;
+  const double* xs[64];
+  for (int s = 0; s < Pl[0]->settle_steps; ++s) {
+    for (int i = 0; i < A; ++i) xs[i] = (xi_reset && xi_reset[i]) ? xi_reset[i] + s * tpc : 0;
+    orc_world_aviary_step(Pl, Ll, A, xi_reset ? xs : 0, (uint32_t)(s * tpc), 1);
+  }
+  for (int i = 0; i < A; ++i) { env_compute_state(Pl[i], Ll[i]); Ll[i]->rng_ctr += 1; }
+}
+void orc_world_env_step(const orc_params* const* Pl, orc_lane* const* Ll, int A, const double* actions, const double* const* xi) {
+  for (int i = 0; i < A; ++i) {
+    orc_lane* L = Ll[i];
+    for (int k = 0; k < 4; ++k) { L->past_action[k] = L->action[k]; L->action[k] = actions[4 * i + k]; L->setpoint[k] = actions[4 * i + k]; }
+    L->reward = 0.0; L->terminated = 0; L->truncated = 0;
+  }
+  const int tpc = Pl[0]->world.ticks_per_control;
+  const double* xs[64];
+  for (int s = 0; s < Pl[0]->env_step_ratio; ++s) { /* no early exit (:342-361) */
+    for (int i = 0; i < A; ++i) xs[i] = (xi && xi[i]) ? xi[i] + s * tpc : 0;
+    orc_world_aviary_step(Pl, Ll, A, xi ? xs : 0, (uint32_t)(s * tpc), 0);
+    for (int i = 0; i < A; ++i) { env_term_trunc_reward(Pl[i], Ll[i]); env_compute_state(Pl[i], Ll[i]); }
+  }
+  for (int i = 0; i < A; ++i) { Ll[i]->step_count += 1; Ll[i]->rng_ctr += 1; }
 }
 
 /* ------------------------------------------------------------------ batch level */

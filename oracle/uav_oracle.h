@@ -186,8 +186,12 @@ typedef struct {
   double zpid_I[2], zpid_E[2];
   int mode;
   int physics_steps;
-  int contact_now;    /* len(getContactPoints())>0 after the last stepSimulation */
-  int contact_step;   /* contact_array after the last Aviary.step */
+  int contact_now;    /* this body has contact points after the last stepSimulation (floor, or another drone of its world) */
+  int contact_step;   /* contact_array[drone.Id].any() after the last Aviary.step */
+  /* shared world (pz_envs: all agents of an env live in ONE Bullet world, ma_quadx_base_env.py:206-241); both stay 0
+   * for a drone that is alone in its world */
+  int world_contact;  /* len(getContactPoints()) > 0 for the WHOLE world after the last stepSimulation: quadx.py:509 gates every drone's rotational drag on it */
+  int peer_contact;   /* this tick's drone-drone verdict for this body, set by orc_world_aviary_step before the tick */
   /* env */
   int step_count, terminated, truncated;
   int info_oob, info_collision, info_complete, num_targets_reached;
@@ -260,6 +264,16 @@ void orc_aviary_reset(const orc_params* P, orc_lane* L, uint64_t lane_id);
 /* one Aviary.step (aviary.py:480-531); xi: ticks_per_control normals (ORC_NOISE_INJECT) or NULL */
 void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi,
                      uint32_t rng_call_base, uint32_t rng_stream);
+/* ---------- shared world: A drones in ONE world (PettingZoo envs) ----------
+ * drone-drone hits enter contact_array[drone.Id] (ma_quadx_hover_env.py:181: any contact of the agent's body ends its
+ * episode) and the rotational-drag gate of EVERY drone looks at the contact points of the whole world (quadx.py:509).
+ * Detection only between drones (box colliders, 15-axis test in the other box's frame): no drone-drone impulses.
+ * Pl / Ll: arrays of A pointers (each drone has its own parameter block: spawn pose); xi: A pointers or NULL. */
+void orc_world_aviary_step(const orc_params* const* Pl, orc_lane* const* Ll, int A, const double* const* xi,
+                           uint32_t rng_call_base, uint32_t rng_stream);
+void orc_world_env_reset(const orc_params* const* Pl, orc_lane* const* Ll, int A, uint64_t lane_id0, const double* const* xi_reset);
+void orc_world_env_step(const orc_params* const* Pl, orc_lane* const* Ll, int A, const double* actions /* [A][4] */,
+                        const double* const* xi);
 /* env.reset(): begin_reset + waypoint sampling + end_reset (quadx_base_env.py:149-212);
  * xi_reset: settle_steps*ticks_per_control normals, u_targets: 3*num_targets uniforms (inject mode;
  * 4*num_targets with use_yaw_targets: theta | phi | dist | yaw, the reference's draw order) */

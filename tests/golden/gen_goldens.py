@@ -455,6 +455,71 @@ def gen_ma_hover():
         fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
 
 
+def gen_ma_hover_shared():
+    """The same PettingZoo env with what makes its world SHARED visible: agents spawned 10 cm apart in height so that the
+    pairs collide while they drift (drone-drone hits enter contact_array[drone.Id], ma_quadx_hover_env.py:181), the contact
+    response on so that a dead drone comes to rest on the floor -- and from then on switches off the rotational drag of
+    every drone in the world (quadx.py:509 looks at the contact points of the whole world)."""
+    from oracle import fake_bullet
+    from PyFlyt.pz_envs.quadx_envs.ma_quadx_hover_env import MAQuadXHoverEnv
+
+    made = []
+    orig = np.random.default_rng
+
+    def recording_default_rng(seed=None):
+        r = ref_stubs.RecordingRNG(orig(seed))
+        made.append(r)
+        return r
+
+    np.random.default_rng = recording_default_rng
+    fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
+    try:
+        start_pos = np.array([[-0.1, 0.0, 1.0], [0.1, 0.0, 1.01], [0.0, 1.0, 1.0], [0.0, -1.0, 0.5]])
+        env = MAQuadXHoverEnv(start_pos=start_pos, start_orn=np.zeros((4, 3)), flight_dome_size=3.0, max_duration_seconds=2.0)
+        rng = orig(321)
+        rec = dict(action=[], obs=[], reward=[], term=[], trunc=[], xi=[], alive=[], reset_before=[], reset_obs=[], reset_xi=[],
+                   world_contact=[], drone_contact=[])
+
+        def do_reset(seed):
+            obs, infos = env.reset(seed=seed)
+            r = made[-1]
+            rec["reset_obs"].append(np.stack([obs[a] for a in env.possible_agents]))
+            rec["reset_xi"].append(r.drain("normal").reshape(-1, 4))
+            return r
+
+        r = do_reset(0)
+        n_ag = len(env.possible_agents)
+        for k in range(140):
+            if len(env.agents) == 0:
+                rec["reset_before"].append(k)
+                r = do_reset(k)
+            alive = [a in env.agents for a in env.possible_agents]
+            # agents 0 and 1 steer towards each other (roll-rate commands of opposite sign), the others hover / sink
+            acts = {}
+            for a in env.agents:
+                i = env.agent_name_mapping[a]
+                base = {0: [0.0, 0.6, 0.0, 0.36], 1: [0.0, -0.6, 0.0, 0.36], 2: [0.0, 0.0, 0.3, 0.37], 3: [0.0, 0.0, 0.0, 0.05]}[i]
+                acts[a] = np.array(base) + np.array([*rng.uniform(-0.05, 0.05, size=3), rng.uniform(-0.01, 0.01)])
+            obs, rew, term, trunc, infos = env.step(acts)
+            A = np.zeros((n_ag, 4)); O = np.full((n_ag, 24), np.nan); R = np.full(n_ag, np.nan)
+            T = np.zeros(n_ag, bool); U = np.zeros(n_ag, bool)
+            for i, a in enumerate(env.possible_agents):
+                if a in acts:
+                    A[i] = acts[a]; O[i] = obs[a]; R[i] = rew[a]; T[i] = term[a]; U[i] = trunc[a]
+            rec["action"].append(A); rec["obs"].append(O); rec["reward"].append(R); rec["term"].append(T); rec["trunc"].append(U)
+            rec["alive"].append(alive)
+            rec["xi"].append(r.drain("normal").reshape(-1, 4))
+            ca = env.aviary.contact_array
+            ids = [d.Id for d in env.aviary.drones]
+            rec["world_contact"].append(bool(np.any(ca)))
+            rec["drone_contact"].append([bool(np.any(ca[i][ids])) for i in ids])
+        save("env_ma_quadx_hover_shared", start_pos=env.start_pos, start_orn=env.start_orn, dome=3.0, max_steps=env.max_steps,
+             **{k: np.array(v) for k, v in rec.items()})
+    finally:
+        np.random.default_rng = orig
+        fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected groups only: python gen_goldens.py wind
         for name in sys.argv[1:]:
@@ -468,6 +533,7 @@ if __name__ == "__main__":
     gen_envs_yaw()
     gen_landing()
     gen_ma_hover()
+    gen_ma_hover_shared()
     gen_wind()
     gen_primitive()
     gen_rocket()

@@ -359,3 +359,46 @@ def test_ma_quadx_hover_trajectory(golden_dir):
                 assert bool(Ls[i].terminated) == bool(g["term"][k][i]) and bool(Ls[i].truncated) == bool(g["trunc"][k][i])
                 seen_term += int(g["term"][k][i])
     assert seen_term >= 4 and ri == len(g["reset_obs"])
+
+
+def test_ma_quadx_hover_shared_world_trajectory(golden_dir):
+    """The PettingZoo env with everything its SHARED world adds: two agents fly into each other -- the hit
+    enters contact_array[drone.Id] and ends both episodes (ma_quadx_hover_env.py:181) -- and a dead drone on the floor
+    switches off the rotational drag of every drone in the world (quadx.py:509). Recorded from the reference's env on
+    fake_bullet (drone-drone detection, contact response on), replayed through the oracle's world-level step."""
+    g = load(golden_dir, "env_ma_quadx_hover_shared")
+    A = g["start_pos"].shape[0]
+    Ps = [O.make_params("ma_hover", noise_mode=O.NOISE_INJECT, start_pos=g["start_pos"][i], start_rpy=g["start_orn"][i], dome=float(g["dome"]),
+                        max_steps=int(g["max_steps"]), world_contact_response=1) for i in range(A)]
+    W = O.OracleWorld(Ps)
+    resets = set(int(k) for k in g["reset_before"])
+    ri = 0
+
+    def do_reset():
+        nonlocal ri
+        obs = W.reset(xi_reset=g["reset_xi"][ri].T)
+        np.testing.assert_allclose(obs, g["reset_obs"][ri], atol=TOL)
+        ri += 1
+
+    do_reset()
+    hits = 0
+    for k in range(len(g["action"])):
+        if k in resets:
+            do_reset()
+        obs, rew, term, trunc = W.step(g["action"][k], xi=g["xi"][k].T)
+        for i in range(A):
+            if g["alive"][k][i]:
+                np.testing.assert_allclose(obs[i], g["obs"][k][i], atol=1e-8, err_msg=f"step {k} agent {i}")
+                assert abs(rew[i] - g["reward"][k][i]) < 1e-8
+                assert bool(term[i]) == bool(g["term"][k][i]) and bool(trunc[i]) == bool(g["trunc"][k][i]), (k, i)
+        assert bool(any(L.contact_now for L in W.Ls)) == bool(g["world_contact"][k]), k
+        hits += int(g["drone_contact"][k].any())
+    assert hits > 0 and ri == len(g["reset_obs"])
+    # the same actions with every agent alone in its own world: no hit, different outcome
+    Ws = [O.OracleWorld([p]) for p in Ps]
+    for i, w in enumerate(Ws):
+        w.reset(xi_reset=g["reset_xi"][0].T[i:i + 1])
+    k_hit = int(np.argmax(g["drone_contact"].any(1)))
+    for k in range(k_hit + 1):
+        outs = [w.step(g["action"][k][i:i + 1], xi=g["xi"][k].T[i:i + 1]) for i, w in enumerate(Ws)]
+    assert not outs[0][2][0] and not outs[1][2][0]  # alone, agents 0 and 1 do not terminate at the step of the hit

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 5
+#define PF_ABI_VERSION 6
 #define PF_MAX_TARGETS 8
 #define PF_MAX_BOXES 12
 #define PF_MAX_SURF 5
@@ -165,6 +165,12 @@ typedef struct pf_params {
   int32_t use_yaw_targets;
   float goal_reach_angle;
   float action_low[4], action_high[4]; /* action space box (quadx_base_env.py:80-102) */
+  /* PF_TASK_MA_HOVER: agents per SHARED world (pz_envs put every agent's drone in one Bullet world,
+   * ma_quadx_base_env.py:206-241). 0 / 1 = every lane alone in its world. A > 1: lanes [w A, (w+1) A) are one world -- a hit
+   * between two of its drones enters both contact arrays and ends both episodes (ma_quadx_hover_env.py:181), and a contact
+   * point anywhere in the world switches off every drone's rotational drag (quadx.py:509). Detection only between drones
+   * (box colliders; no drone-drone impulses). A must divide 64 and the lane count. */
+  int32_t agents_per_world;
   pf_rocket rocket;
 } pf_params;
 

@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
                                                     const float4* __restrict__ tmpl, const pf_params* __restrict__ Pdev) {
   __shared__ float tile[kWave * kMaxObs];
   __shared__ float ktab[VEH::TABLE_FLOATS];
+  __shared__ float wpose[kWave * 8];  // shared worlds: each lane's pose and contact bit, exchanged once per tick
   const int tid = threadIdx.x;
   VEH::fill_table(ktab, Pdev, tid);
   __syncthreads();
@@ -331,10 +332,53 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     nz.begin_event(rng_ctr, 0u, B.xi);
   }
 
+  // Shared world (pz_envs: every agent's drone in ONE Bullet world): the A lanes of a world sit next to each other in the
+  // wave; before every tick they exchange pose and contact bit through LDS, test their collision boxes against each other
+  // (15 axes, in the peer's frame, behind a bounding-sphere test) and OR the world's contact bits into the gate of the
+  // rotational drag. One Aviary.step = control + ticks_per_control x (exchange, tick).
+  const int A = (TASK == PF_TASK_MA_HOVER && P.agents_per_world > 1) ? P.agents_per_world : 1;
+  auto world_aviary_step = [&](int flat_base) {
+    V.b.contact_step = false;
+    V.template control<MODE_T>(P, sp);
+    const int wbase = (tid / A) * A, wlocal = tid - wbase;
+    for (int t = 0; t < P.ticks_per_control; ++t) {
+      float* me = wpose + tid * 8;
+      me[0] = V.b.p.x; me[1] = V.b.p.y; me[2] = V.b.p.z; me[3] = V.b.q.x; me[4] = V.b.q.y; me[5] = V.b.q.z; me[6] = V.b.q.w;
+      me[7] = V.b.contact_now ? 1.0f : 0.0f;
+      lds_sync();
+      bool world = false, peer = false;
+      for (int j = 1; j < A; ++j) {
+        const float* o = wpose + (wbase + (wlocal + j) % A) * 8;
+        world |= o[7] != 0.0f;
+        const v3 d{V.b.p.x - o[0], V.b.p.y - o[1], V.b.p.z - o[2]};
+        const float rr = 2.0f * P.bound_radius;
+        if (dot(d, d) <= rr * rr) {  // bounding spheres touch: the box tests, this drone's boxes in the peer's box frames
+          const m3 Rb = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
+          const m3& Ra = V.b.R;
+          const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
+                        Rb.m01 * Ra.m00 + Rb.m11 * Ra.m10 + Rb.m21 * Ra.m20, Rb.m01 * Ra.m01 + Rb.m11 * Ra.m11 + Rb.m21 * Ra.m21, Rb.m01 * Ra.m02 + Rb.m11 * Ra.m12 + Rb.m21 * Ra.m22,
+                        Rb.m02 * Ra.m00 + Rb.m12 * Ra.m10 + Rb.m22 * Ra.m20, Rb.m02 * Ra.m01 + Rb.m12 * Ra.m11 + Rb.m22 * Ra.m21, Rb.m02 * Ra.m02 + Rb.m12 * Ra.m12 + Rb.m22 * Ra.m22};
+          for (int k = 0; k < P.n_boxes; ++k) {
+            for (int l = 0; l < P.n_boxes; ++l) {
+              const v3 ca = d + mul(Ra, v3{P.boxes[k].c[0], P.boxes[k].c[1], P.boxes[k].c[2]}) - mul(Rb, v3{P.boxes[l].c[0], P.boxes[l].c[1], P.boxes[l].c[2]});
+              peer |= box_overlaps_aabb(mulT(Rb, ca), Rrel, P.boxes[k].h, v3{0.f, 0.f, 0.f}, P.boxes[l].h);
+            }
+          }
+        }
+      }
+      V.b.world_contact = world;
+      V.b.peer_contact = peer;
+      lds_sync();
+      V.tick(P, nz.get(flat_base + t));
+    }
+    V.b.peer_contact = false;
+    V.b.rpy = euler_from_quat_fast(V.b.q);
+  };
   int it = 0;
   while (__any(my_its > 0)) {
     if (my_its > 0) {
-      V.template aviary_step<MODE_T>(P, sp, nz, it * P.ticks_per_control);
+      if (A > 1) world_aviary_step(it * P.ticks_per_control);
+      else V.template aviary_step<MODE_T>(P, sp, nz, it * P.ticks_per_control);
       rpy_valid = true;
       my_its -= 1;
       if (!settling) {
@@ -782,6 +826,15 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   if (P.vehicle == PF_QUADX && (P.flight_mode < -1 || P.flight_mode > 7)) return fail(nullptr, PF_ERR_ARG, "quadx flight_mode must be in -1..7");
   if (P.vehicle == PF_FIXEDWING && (P.flight_mode < -1 || P.flight_mode > 0)) return fail(nullptr, PF_ERR_ARG, "fixedwing flight_mode must be -1 or 0");
   if (P.vehicle == PF_FIXEDWING && (P.task == PF_TASK_HOVER || P.task == PF_TASK_MA_HOVER)) return fail(nullptr, PF_ERR_UNSUPPORTED, "no fixedwing hover task in the reference");
+  if (P.agents_per_world > 1) {
+    if (!(P.vehicle == PF_QUADX && P.task == PF_TASK_MA_HOVER))
+      return fail(nullptr, PF_ERR_UNSUPPORTED, "agents_per_world > 1 (a shared world) exists for the PettingZoo QuadX hover task only");
+    if (64 % P.agents_per_world != 0 || n_lanes % P.agents_per_world != 0)
+      return fail(nullptr, PF_ERR_ARG, "agents_per_world must divide 64 (the lanes of a world share a wavefront) and the lane count");
+    for (int k = 0; k < P.n_boxes; ++k)
+      if (P.boxes[k].kind != 0 || P.boxes[k].yaw != 0.0f)
+        return fail(nullptr, PF_ERR_UNSUPPORTED, "shared worlds test plain box colliders against each other (cf2x); this airframe has cylinders / yawed boxes");
+  }
   if (P.use_yaw_targets && !(P.vehicle == PF_QUADX && P.task == PF_TASK_WAYPOINTS))
     return fail(nullptr, PF_ERR_UNSUPPORTED, "use_yaw_targets exists for QuadX-Waypoints only (fixedwing_waypoints_env.py:77 hard-wires False)");
   if (P.task == PF_TASK_MA_HOVER && P.autoreset != PF_AUTORESET_OFF) return fail(nullptr, PF_ERR_ARG, "the multi-agent env has no auto-reset (PettingZoo parallel API)");

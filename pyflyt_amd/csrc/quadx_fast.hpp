@@ -63,6 +63,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   if (P.vehicle != PF_QUADX || P.flight_mode != 0) return false;
   if (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS && P.task != PF_TASK_MA_HOVER) return false;
   if (P.has_com_offset) return false;
+  if (P.agents_per_world > 1) return false;  // shared worlds: the generic kernel exchanges poses between the lanes of a world
   {  // QuadHot::derive() builds the rotation with scale 2 instead of btMatrix3x3::setRotation's 2/|q|^2: unit spawn quaternion only
     const float q2 = P.start_quat[0] * P.start_quat[0] + P.start_quat[1] * P.start_quat[1] + P.start_quat[2] * P.start_quat[2] + P.start_quat[3] * P.start_quat[3];
     if (!(q2 > 1.0f - 1e-6f && q2 < 1.0f + 1e-6f)) return false;

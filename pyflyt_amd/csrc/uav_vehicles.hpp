@@ -201,6 +201,9 @@ struct Body {
   v3 wb, vb;    // quadx.py:522-523
   v3 rpy;       // quadx.py:526 (refreshed once per Aviary step)
   bool contact_now, contact_step;
+  // shared world (PF_TASK_MA_HOVER with agents_per_world > 1); both false for a drone that is alone in its world
+  bool world_contact = false;  // a contact point anywhere in the world after the previous tick (quadx.py:509)
+  bool peer_contact = false;   // this tick's drone-drone verdict for this body
 
   PF_DEV void derive() {
     R = rot_from_quat(q);
@@ -235,7 +238,7 @@ struct Body {
   // stepSimulation (aviary.py:516): collision detection at the pre-integration pose, then the
   // semi-implicit Euler free-body tick. F, tau: body frame; tau about the base origin.
   PF_DEV void tick(const pf_params& P, v3 F, v3 tau) {
-    contact_now = detect_contact(P);
+    contact_now = detect_contact(P) || peer_contact;
     v3 com{P.com[0], P.com[1], P.com[2]};
     if (P.has_com_offset) tau = tau - cross(com, F);
     v3 h = symmul(P.I_pa, wb);
@@ -514,7 +517,7 @@ struct QuadX {
       tau.y = fmaf(-P.motor_r[i][0], f, tau.y);
       tau.z = fmaf(k, P.motor_tmax[i], tau.z);
     }
-    if (!b.contact_now) {  // quadx.py:502-510
+    if (!(b.contact_now || b.world_contact)) {  // quadx.py:502-510: no contact point anywhere in the world
       tau.x = fmaf(-P.drag_coef_pqr, sq_signed(b.wb.x), tau.x);
       tau.y = fmaf(-P.drag_coef_pqr, sq_signed(b.wb.y), tau.y);
       tau.z = fmaf(-P.drag_coef_pqr, sq_signed(b.wb.z), tau.z);

@@ -289,6 +289,7 @@ def build_params(
     goal_reach_distance: float | None = None,
     use_yaw_targets: bool = False,
     goal_reach_angle: float = 0.1,
+    agents_per_world: int = 0,
     start_pos=None,
     start_orn=None,
     vehicle_options: dict | None = None,
@@ -471,6 +472,7 @@ def build_params(
         d_dome, d_dur, d_hz, d_reach = 3.0, 10.0, 40, 0.2
     elif task == "ma_hover":  # pz_envs/quadx_envs/ma_quadx_hover_env.py:36-52
         P.task = L.TASK_MA_HOVER
+        P.agents_per_world = int(agents_per_world)  # > 1: the agents of an env share one world (ma_quadx_base_env.py:206-241)
         d_dome, d_dur, d_hz, d_reach = 10.0, 30.0, 40, 0.2
     elif task == "waypoints":
         P.task = L.TASK_WAYPOINTS

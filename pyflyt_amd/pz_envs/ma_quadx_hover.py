@@ -3,9 +3,15 @@
 
 Same constructor keywords, agent naming ("uav_i"), dict-in/dict-out `reset()` / `step()`, observation
 layout [ang_vel, quat|rpy, lin_vel, lin_pos, throttle(4), past action(4), start_pos(3)], additive
--100 penalties, per-call term/trunc flags, culling of finished agents. One difference, by scope
-(SURVEY.md section 8(a) row 22, 8(f)-2): the reference puts all agents in ONE Bullet world so they can
-collide with each other; here every agent is an independent lane (no drone-drone contact).
+-100 penalties, per-call term/trunc flags, culling of finished agents.
+
+`shared_world`: the reference puts all agents of an env in ONE Bullet world (ma_quadx_base_env.py:206-241). With
+shared_world=True so does this env: the agents of a copy are adjacent lanes of one wavefront, a hit between two drones
+enters both contact arrays and ends both episodes (ma_quadx_hover_env.py:181), and a contact point anywhere in the world --
+e.g. a finished drone lying on the floor -- switches off the rotational drag of every drone (quadx.py:509). The contact
+response is then on (a finished drone must come to rest on the floor, not fall through it); between drones there is detection
+only (no impulses). The number of agents must divide 64. Default False: every agent an independent lane (round 1 semantics,
+and the specialised kernel).
 
 `num_envs` independent copies of the whole multi-agent env are stepped at once: dict values are
 tensors of shape [num_envs, ...] (squeezed to the reference's per-agent vectors when num_envs == 1).
@@ -29,7 +35,8 @@ class MAQuadXHoverEnv:
     def __init__(self, start_pos=np.array([[-1.0, -1.0, 1.0], [1.0, -1.0, 1.0], [-1.0, 1.0, 1.0], [1.0, 1.0, 1.0]]),
                  start_orn=np.zeros((4, 3)), sparse_reward: bool = False, flight_mode: int = 0, flight_dome_size: float = 10.0,
                  max_duration_seconds: float = 30.0, angle_representation: str = "quaternion", agent_hz: int = 40,
-                 render_mode=None, num_envs: int = 1, device="cuda:0", seed: int = 0, motor_noise: bool = True):
+                 render_mode=None, num_envs: int = 1, device="cuda:0", seed: int = 0, motor_noise: bool = True,
+                 shared_world: bool = False):
         if render_mode is not None:
             raise ValueError("rendering is out of scope for the batched GPU path")
         start_pos, start_orn = np.asarray(start_pos, dtype=np.float64), np.asarray(start_orn, dtype=np.float64)
@@ -49,6 +56,11 @@ class MAQuadXHoverEnv:
                         angle_representation=angle_representation, agent_hz=agent_hz, sparse_reward=sparse_reward)
         self._noise = "philox" if motor_noise else "off"
         self._seed = int(seed)
+        self.shared_world = bool(shared_world)
+        if self.shared_world:
+            if 64 % self.num_possible_agents != 0:
+                raise ValueError("shared_world=True needs a number of agents that divides 64 (the agents of a world share a wavefront)")
+            self._kw.update(agents_per_world=self.num_possible_agents, world_options=dict(contact_response=True))
         self._build(self._seed)
         att = 13 if angle_representation == "quaternion" else 12
         xyz, thr = np.pi, 0.8

@@ -83,3 +83,123 @@ def test_ma_hover_single_env_shapes_and_culling():
         assert set(o) == set(acts) and all(isinstance(float(r[a]), float) for a in r)
     assert env.agents == []  # all culled
     env.close()
+
+
+def _vec_err(got, ref):
+    e = 0.0
+    for lo, hi in ((0, 3), (3, 7), (7, 10), (10, 13), (13, 17), (17, 21), (21, 24)):
+        scale = max(1.0, float(np.linalg.norm(ref[lo:hi])))
+        e = max(e, float(np.abs(got[lo:hi] - ref[lo:hi]).max()) / scale)
+    return e
+
+
+def test_shared_world_fixture_replay(golden_dir):
+    """tests/golden/env_ma_quadx_hover_shared.npz -- the reference's PettingZoo env on a world where two agents fly into
+    each other and a dead drone ends up on the floor -- replayed through the HIP path (agents_per_world = 4: the four lanes
+    of a world exchange poses through LDS every tick)."""
+    import os
+
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+    from pyflyt_amd.params import quat_from_euler
+
+    g = np.load(os.path.join(golden_dir, "env_ma_quadx_hover_shared.npz"))
+    A = g["start_pos"].shape[0]
+    P = build_params("quadx", "ma_hover", noise="inject", autoreset="off", start_pos=g["start_pos"][np.argmin(g["start_pos"][:, 2])],
+                     start_orn=g["start_orn"][0], flight_dome_size=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 40.0,
+                     agents_per_world=A, world_options=dict(contact_response=True))
+    eng = BatchEngine(P, A, device="cuda:0")
+    assert eng.lib.pf_ctx_is_specialised(eng._ctx) == 0
+    pose = np.concatenate([g["start_pos"], np.stack([quat_from_euler(o) for o in g["start_orn"]])], axis=1)
+    side = np.zeros((A, 12), dtype=np.float32)
+    side[:, :7] = pose
+    eng.state[12:15] = torch.tensor(side, device="cuda:0").view(A, 3, 4).permute(1, 0, 2)
+    t32 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda:0")  # noqa: E731
+    resets = set(int(k) for k in g["reset_before"])
+    ri = 0
+
+    def do_reset():
+        nonlocal ri
+        obs = eng.env_reset(xi_reset=t32(g["reset_xi"][ri])).double().cpu().numpy()
+        for i in range(A):
+            assert _vec_err(obs[i], g["reset_obs"][ri][i]) < 1e-4
+        ri += 1
+
+    do_reset()
+    worst, hits = 0.0, 0
+    for k in range(len(g["action"])):
+        if k in resets:
+            do_reset()
+        obs, rew, term, trunc = eng.env_step(t32(g["action"][k]), xi=t32(g["xi"][k]))
+        o = obs.double().cpu().numpy()
+        for i in range(A):
+            if g["alive"][k][i]:
+                e = _vec_err(o[i], g["obs"][k][i])
+                near_floor = g["obs"][k][i][12] < 0.12  # (within reach of the floor: the contact solver's impulses, RTOL_IMPACT)
+                worst = max(worst, 0.0 if near_floor else e)
+                assert e < (5e-3 if near_floor else 1e-4), (k, i, e)
+                assert bool(term[i]) == bool(g["term"][k][i]) and bool(trunc[i]) == bool(g["trunc"][k][i]), (k, i)
+                assert abs(float(rew[i]) - g["reward"][k][i]) <= 1e-3 * max(1.0, abs(g["reward"][k][i]))
+        hits += int(g["drone_contact"][k].any())
+    print(f"shared-world fixture: worst {worst:.2e}, steps with a drone-drone hit {hits}")
+    assert hits > 0 and ri == len(g["reset_obs"])
+
+
+def test_shared_world_parity_and_effect():
+    """MAQuadXHoverEnv(shared_world=True) against the oracle's world-level step (Philox noise, 32 copies of a 4-agent env whose
+    agents 0 and 1 steer into each other), and against the same env with independent lanes: the hit must end both episodes
+    in the shared world and not in the independent one."""
+    from pyflyt_amd.pz_envs import MAQuadXHoverEnv
+
+    E, seed = 32, 11
+    start_pos = np.array([[-0.15, 0.0, 1.0], [0.15, 0.0, 1.01], [0.0, 1.0, 1.0], [0.0, -1.0, 1.2]])
+    kw = dict(start_pos=start_pos, start_orn=np.zeros((4, 3)), num_envs=E, seed=seed, flight_dome_size=3.0, max_duration_seconds=2.0)
+    env = MAQuadXHoverEnv(shared_world=True, **kw)
+    ind = MAQuadXHoverEnv(shared_world=False, **kw)
+    A = env.num_possible_agents
+    worlds = []
+    for e in range(E):
+        Ps = [O.make_params("ma_hover", noise_mode=O.NOISE_PHILOX, seed=seed, start_pos=start_pos[i], dome=3.0, max_steps=80, world_contact_response=1)
+              for i in range(A)]
+        worlds.append(O.OracleWorld(Ps, lane_id0=e * A))
+    obs, _ = env.reset(seed=seed)
+    ind.reset(seed=seed)
+    ref0 = np.stack([w.reset() for w in worlds])  # [E, A, 24]
+    got0 = np.stack([obs[a].cpu().numpy() for a in env.possible_agents], axis=1)
+    assert np.abs(got0 - ref0).max() < 1e-5
+    rng = np.random.default_rng(2)
+    alive = np.ones((E, A), dtype=bool)      # per copy (the façade culls an agent once it is done in EVERY copy)
+    hit_shared = np.zeros(E, dtype=bool)
+    worst = 0.0
+    for k in range(60):
+        base = np.array([[0.0, 0.7, 0.0, 0.36], [0.0, -0.7, 0.0, 0.36], [0.0, 0.0, 0.3, 0.37], [0.0, 0.0, 0.0, 0.33]])
+        acts_np = base[None] + rng.uniform(-0.05, 0.05, size=(E, A, 4)) * np.array([1, 1, 1, 0.2])
+        acts = {a: torch.tensor(acts_np[:, i].astype(np.float32), device="cuda:0") for i, a in enumerate(env.possible_agents) if a in env.agents}
+        if not acts:
+            break
+        o, r, t, u, info = env.step(acts)
+        acts_i = {a: torch.tensor(acts_np[:, i].astype(np.float32), device="cuda:0") for i, a in enumerate(ind.possible_agents) if a in ind.agents}
+        if acts_i:
+            ind.step(acts_i)
+        step_acts = np.zeros((E, A, 4))
+        for i, a in enumerate(env.possible_agents):
+            if a in acts:
+                step_acts[:, i] = acts_np[:, i].astype(np.float32)
+        for e, w in enumerate(worlds):
+            ro, rr, rt, ru = w.step(step_acts[e])
+            for i, a in enumerate(env.possible_agents):
+                if a in o and alive[e, i]:
+                    got = o[a][e].cpu().numpy().astype(np.float64)
+                    near_floor = ro[i][12] < 0.12
+                    err = _vec_err(got, ro[i])
+                    worst = max(worst, 0.0 if near_floor else err)
+                    assert err < (5e-3 if near_floor else 1e-4), (k, e, a, err)
+                    assert bool(t[a][e]) == bool(rt[i]) and bool(u[a][e]) == bool(ru[i]), (k, e, a)
+                    if rt[i] or ru[i]:
+                        alive[e, i] = False
+            hit_shared[e] |= bool(w.Ls[0].contact_step and w.Ls[1].contact_step and w.Ls[0].p[2] > 0.3)
+    print(f"shared world parity: worst {worst:.2e}; copies with a mid-air hit between agents 0 and 1: {int(hit_shared.sum())}/{E}")
+    assert hit_shared.mean() > 0.5
+    # the independent-lane env flies the same commands without that hit: agents 0 and 1 survive the step of the hit
+    assert "uav_0" in ind.agents or ind.step_count >= 40
+    env.close(); ind.close()

@@ -223,7 +223,7 @@ struct QuadHot {
     // "penetration >= 0" IS low <= 0 (the slab's top-face normal is the only axis that can separate a box from what is
     // locally a half-space; the direct form also avoids the cancellation of (p.z + 5) - (5 + ext) in fp32). The out-of-line
     // 15-axis test runs only within one bounding radius of the rim.
-    bool near = (p.z - K.bound_radius) <= 0.0f;
+    bool near = ((p.z - K.bound_radius) <= 0.0f) && ((p.z + K.bound_radius) >= -2.0f * K.plane_z);  // (not once it has fallen through, contact_response off)
     contact_now = false;
     float low = INFINITY;
     if (__any(near)) {

@@ -211,8 +211,14 @@ struct Body {
     vb = mulT(R, v);
   }
   // collision detection at the current pose against the ground box (aviary.py:240-242,523-525)
+  // (can the body reach the ground slab at all? within one bounding radius of its top face, not below its bottom face, not
+  //  beyond its rim: an aircraft that has flown off the 30 m slab and keeps falling is "under the floor" for seconds)
+  PF_DEV bool slab_in_reach(const pf_params& P, float extra) const {
+    const float r = P.bound_radius + extra;
+    return (p.z - r <= 0.0f) && (p.z + r >= -2.0f * P.plane_half_z) && (__builtin_fabsf(p.x) - r <= P.plane_half_xy) && (__builtin_fabsf(p.y) - r <= P.plane_half_xy);
+  }
   PF_DEV bool detect_contact(const pf_params& P) const {
-    if (p.z - P.bound_radius > 0.0f) return false;
+    if (!slab_in_reach(P, 0.0f)) return false;
     const float hb[3] = {P.plane_half_xy, P.plane_half_xy, P.plane_half_z};
     v3 cb{0.0f, 0.0f, -P.plane_half_z};
     bool hit = false;
@@ -270,7 +276,7 @@ struct Body {
   // exactly zero, no recovery -- and the call is skipped without changing the result.
   PF_DEV bool contact_may_act(const pf_params* Pd) const {
     const float low = p.z - Pd->bound_radius;
-    if (low > Pd->contact_margin) return false;
+    if (!slab_in_reach(*Pd, Pd->contact_margin)) return false;
     const float vlow = v.z - __builtin_sqrtf(dot(w, w)) * Pd->bound_radius;
     return (low + Pd->contact_slop + Pd->dt * vlow < 0.0f) || (low < -Pd->contact_slop);
   }

@@ -6,7 +6,7 @@ from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine
 n = int(os.environ.get("N", "65536")); steps = int(os.environ.get("STEPS", "60"))
 P = build_params(os.environ.get("VEH","quadx"), os.environ.get("TASK","hover"), noise=os.environ.get("NOISE","philox"), autoreset="next_step",
-                 world_options=dict(contact_response=os.environ.get("CR", "1") == "1"))
+                 world_options=(dict(contact_response=os.environ["CR"] == "1") if "CR" in os.environ else None))
 if "SETTLE" in os.environ: P.settle_steps = int(os.environ["SETTLE"])
 eng = BatchEngine(P, n)
 ring = [torch.empty(n,4,device="cuda") for _ in range(16)]

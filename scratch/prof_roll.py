@@ -6,7 +6,7 @@ from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine
 n = int(os.environ.get("N", "65536")); k = int(os.environ.get("K", "100")); reps = int(os.environ.get("REPS", "6"))
 P = build_params("quadx", os.environ.get("TASK", "hover"), noise=os.environ.get("NOISE", "philox"), autoreset="next_step",
-                 world_options=dict(contact_response=os.environ.get("CR", "1") == "1"))
+                 world_options=(dict(contact_response=os.environ["CR"] == "1") if "CR" in os.environ else None))
 eng = BatchEngine(P, n)
 eng.env_reset()
 for i in range(reps):

@@ -195,7 +195,7 @@ def main():
     # actions sampled on device with pf_sample_actions' keys, every step's obs / action / reward / flags written
     # to trajectory buffers). Timed with HIP events on the launch stream; same barrier / max-over-ranks rule.
     roll = None
-    if args.rollout_steps > 0 and args.env != "fixedwing_waypoints":
+    if args.rollout_steps > 0:
         kk = args.rollout_steps
         reps = max(1, args.steps // kk)
         with torch.cuda.stream(stream):
@@ -239,7 +239,7 @@ def main():
                                    f"random actions, motor noise {args.noise}, NEXT_STEP auto-reset"
                        if args.env == "hover" else f"{args.env}, batch {n}/GPU x {world}",
                        "batch_per_gpu": n, "global_batch": total_lanes, "ticks_per_env_step": eng.ticks_per_step,
-                       "launch": "hipGraph" if graph is not None else "eager", "contact_response": not args.no_contact_response, "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
+                       "launch": "hipGraph" if graph is not None else "eager", "contact_response": bool(eng.params.contact_response), "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "kernel": "pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel", "algorithmic_bytes_per_launch": algo,
@@ -270,7 +270,7 @@ def main():
                 "frac": ALGO_BYTES[args.env] * n / per_step / 1e9 / HBM_PEAK_GBS,
                 # and against what this launch shape actually has to move
                 "bytes_per_step_moved": moved, "frac_moved": moved * n / per_step / 1e9 / HBM_PEAK_GBS,
-                "kernel": "pf::quadx_m0_env_kernel<..., ROLLOUT>", "launch_us": rev / reps * 1e6,
+                "kernel": ("pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel") + "<..., ROLL=1>", "launch_us": rev / reps * 1e6,
                 "note": "k env steps per launch, state in registers, on-device action sampling (pf_sample_actions keys); bit-identical to k x pf_env_step (tests/test_gpu_rollout.py)",
             }
         if not args.no_cpu_baseline and world == 1:

@@ -287,7 +287,7 @@ int pf_sample_actions(pf_ctx* ctx, float* actions, uint32_t step_index, void* st
  * step s of lane i exactly as pf_sample_actions(step_index0 + s) would (same Philox keys) and, if
  * b->actions_out != NULL, stores it there; otherwise b->actions is a given open-loop sequence
  * [k_steps][n][4]. Results are bit-identical to k_steps x (pf_sample_actions + pf_env_step).
- * Supported where the specialised env kernels are (QuadX mode 0 Hover / Waypoints, PF_NOISE_OFF / PHILOX);
+ * Supported where the specialised env kernels are (QuadX mode 0 Hover / Waypoints, Fixedwing-Waypoints; PF_NOISE_OFF / PHILOX);
  * PF_ERR_UNSUPPORTED otherwise. */
 int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_index0, void* stream);
 

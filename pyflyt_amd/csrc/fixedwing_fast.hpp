@@ -16,6 +16,11 @@
 //     1.9 KB/lane, the second staged them through an LDS table);
 //   * the post-stall branches (lifting_surfaces.py:409-448) run only in waves where some lane is
 //     stalled (wave-uniform test), side-symmetric so one interpolation serves both signs;
+//   * the four lift-+z surfaces are evaluated two at a time in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 /
+//     v_pk_add_f32: two IEEE operations per issue slot, and at one wave per SIMD every instruction is
+//     one slot): ailerons together, h-tail with the main wing. The element-wise arithmetic and the
+//     order the five surfaces accumulate in are those of the one-at-a-time evaluation, so results are
+//     bit-identical to it; the transcendental and select steps have no packed form and stay scalar;
 //   * one gyroscopic inertia (I_pa + I_own) instead of two products, rotation scale 2 for the unit
 //     quaternion, Euler angles only in the epilogue;
 //   * resets copy the context's settled spawn state (the settle throttle command is 0, so the motor
@@ -41,7 +46,15 @@ struct FwSurf {  // 16 floats, one s_load_dwordx16 per surface per tick
   float chord;
 };
 
-struct FwBody {  // 32 floats behind the five FwSurf rows, two s_load_dwordx16 per tick
+typedef float f2 __attribute__((ext_vector_type(2)));
+PF_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
+PF_DEV f2 sp2(float x) { return f2{x, x}; }                                       // op_sel splat, no instruction
+
+struct FwSurf2 {  // two lift-+z surfaces side by side, every field a (first, second) pair: two s_load_dwordx16 per tick
+  f2 rx, ry, rz, cl3d, a0b, aPb, aNb, tau_eta, c1, ipa, exp_term, cd0, defl_lim, dt_tau, hra, chord;
+};
+
+struct FwBody {  // 32 floats behind the surface rows, two s_load_dwordx16 per tick
   float dt, half_dt, gravity_z, vmax, inv_mass;
   float H[6], iI[6];       // gyroscopic inertia I_pa (+ I_own if use_gyro) and inverse inertia, symmetric 6
   float com[3];
@@ -51,21 +64,23 @@ struct FwBody {  // 32 floats behind the five FwSurf rows, two s_load_dwordx16 p
   float pad[5];
 };
 struct FwTable {
-  FwSurf surf[5];
+  FwSurf2 pair[2];  // (left aileron, right aileron), (horizontal tail, main wing): fixedwing.py:80-141 ids (0,1), (2,4)
+  FwSurf vtail;     // id 3, lift unit +y
   FwBody body;
 };
-static_assert(sizeof(FwSurf) == 64 && sizeof(FwBody) == 128, "constant table rows are whole s_load_dwordx16 units");
+static_assert(sizeof(FwSurf) == 64 && sizeof(FwSurf2) == 128 && sizeof(FwBody) == 128, "constant table rows are whole s_load_dwordx16 units");
 
 struct FwK {  // what stays in kernel-argument SGPRs for the whole kernel: env constants only
   float dome2, goal_reach, min_height, dome09m1, wp_dist_reward;
   int32_t task_sparse, angle_repr, num_targets, max_steps, env_step_ratio, throttle_remap;
   int32_t noise_mode, autoreset;
   uint32_t seed_lo, seed_hi;
+  float act_lo[4], act_span[4];  // action box (fixedwing_base_env.py:78-80): low, high - low (pf_rollout's on-device sampling)
 };
 
 // Fill FwK / FwTable from the ABI struct; false -> the configuration needs the generic kernel.
 inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
-  FwSurf* S = T.surf;
+  FwSurf S[5];
   FwBody& Bd = T.body;
   if (P.vehicle != PF_FIXEDWING || P.flight_mode != 0 || P.task != PF_TASK_WAYPOINTS) return false;
   if (P.n_surf != 5 || P.n_motors != 1 || P.ticks_per_control != 2) return false;
@@ -100,6 +115,7 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
   K.env_step_ratio = P.env_step_ratio; K.throttle_remap = P.throttle_remap;
   K.noise_mode = P.noise_mode; K.autoreset = P.autoreset;
   K.seed_lo = (uint32_t)P.seed; K.seed_hi = (uint32_t)(P.seed >> 32);
+  for (int k = 0; k < 4; ++k) { K.act_lo[k] = P.action_low[k]; K.act_span[k] = P.action_high[k] - P.action_low[k]; }
   for (int i = 0; i < 5; ++i) {
     const pf_surface& s = P.surf[i];
     FwSurf& o = S[i];
@@ -109,6 +125,16 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
     o.ipa = s.inv_pi_aspect; o.exp_term = s.exp_term; o.cd0 = s.Cd_0; o.defl_lim = s.deflection_limit_rad;
     o.dt_tau = s.dt_over_tau; o.hra = s.half_rho_area; o.chord = s.chord;
   }
+  const int pa[2] = {0, 2}, pb[2] = {1, 4};
+  for (int k = 0; k < 2; ++k) {
+    const FwSurf &a = S[pa[k]], &b = S[pb[k]];
+    FwSurf2& o = T.pair[k];
+    o.rx = f2{a.rx, b.rx}; o.ry = f2{a.ry, b.ry}; o.rz = f2{a.rz, b.rz}; o.cl3d = f2{a.cl3d, b.cl3d};
+    o.a0b = f2{a.a0b, b.a0b}; o.aPb = f2{a.aPb, b.aPb}; o.aNb = f2{a.aNb, b.aNb}; o.tau_eta = f2{a.tau_eta, b.tau_eta};
+    o.c1 = f2{a.c1, b.c1}; o.ipa = f2{a.ipa, b.ipa}; o.exp_term = f2{a.exp_term, b.exp_term}; o.cd0 = f2{a.cd0, b.cd0};
+    o.defl_lim = f2{a.defl_lim, b.defl_lim}; o.dt_tau = f2{a.dt_tau, b.dt_tau}; o.hra = f2{a.hra, b.hra}; o.chord = f2{a.chord, b.chord};
+  }
+  T.vtail = S[3];
   return true;
 }
 
@@ -125,7 +151,9 @@ __device__ __noinline__ bool fw_floor_contact(float px, float py, float pz, m3 R
   return hit;
 }
 
+typedef const FwTable __attribute__((address_space(4))) * fw_tab_cptr;
 typedef const FwSurf __attribute__((address_space(4))) * fw_surf_cptr;
+typedef const FwSurf2 __attribute__((address_space(4))) * fw_surf2_cptr;
 typedef const FwBody __attribute__((address_space(4))) * fw_body_cptr;
 PF_DEV FwBody fw_load_body(fw_body_cptr p) {
   FwBody b;
@@ -145,6 +173,45 @@ PF_DEV FwSurf fw_load_surf(fw_surf_cptr p) {  // uniform address in the constant
   S.defl_lim = p->defl_lim; S.dt_tau = p->dt_tau; S.hra = p->hra; S.chord = p->chord;
   return S;
 }
+
+PF_DEV FwSurf2 fw_load_surf2(fw_surf2_cptr p) {  // two s_load_dwordx16, every field an aligned SGPR pair
+  FwSurf2 S;
+  S.rx = p->rx; S.ry = p->ry; S.rz = p->rz; S.cl3d = p->cl3d; S.a0b = p->a0b; S.aPb = p->aPb; S.aNb = p->aNb;
+  S.tau_eta = p->tau_eta; S.c1 = p->c1; S.ipa = p->ipa; S.exp_term = p->exp_term; S.cd0 = p->cd0;
+  S.defl_lim = p->defl_lim; S.dt_tau = p->dt_tau; S.hra = p->hra; S.chord = p->chord;
+  return S;
+}
+// fast_atan2 (uav_device.hpp) on two arguments at once: the same operations element by element, the
+// polynomial and the products packed
+PF_DEV f2 fast_atan2_pair(f2 y, f2 x) {
+  const float ax0 = __builtin_fabsf(x.x), ay0 = __builtin_fabsf(y.x), ax1 = __builtin_fabsf(x.y), ay1 = __builtin_fabsf(y.y);
+  const float mx0 = __builtin_fmaxf(ax0, ay0), mn0 = __builtin_fminf(ax0, ay0);
+  const float mx1 = __builtin_fmaxf(ax1, ay1), mn1 = __builtin_fminf(ax1, ay1);
+  f2 t = f2{mn0, mn1} * f2{frcp(mx0), frcp(mx1)};
+  t = f2{(mx0 == 0.0f) ? 0.0f : t.x, (mx1 == 0.0f) ? 0.0f : t.y};
+  const f2 s = t * t;
+  f2 p = fma2(s, sp2(0.0029035410843789577f), sp2(-0.016282962635159492f));
+  p = fma2(s, p, sp2(0.04303929582238197f));
+  p = fma2(s, p, sp2(-0.07533670216798782f));
+  p = fma2(s, p, sp2(0.10654674470424652f));
+  p = fma2(s, p, sp2(-0.14207133650779724f));
+  p = fma2(s, p, sp2(0.19993053376674652f));
+  p = fma2(s, p, sp2(-0.3333309292793274f));
+  p = fma2(s, p, sp2(1.0f));
+  f2 r = p * t;
+  const f2 rq = sp2(0.5f * kPi) - r;
+  r = f2{(ay0 > ax0) ? rq.x : r.x, (ay1 > ax1) ? rq.y : r.y};
+  const f2 rh = sp2(kPi) - r;
+  r = f2{(x.x < 0.0f) ? rh.x : r.x, (x.y < 0.0f) ? rh.y : r.y};
+  return f2{__builtin_copysignf(r.x, y.x), __builtin_copysignf(r.y, y.y)};
+}
+PF_DEV void sincos_small_pair(f2 x, f2& sn, f2& cs) {  // sincos_small (uav_device.hpp), packed
+  const f2 t = x * x;
+  sn = x * fma2(t, fma2(t, fma2(t, fma2(t, fma2(t, sp2(-2.5052108e-8f), sp2(2.7557319e-6f)), sp2(-1.9841270e-4f)), sp2(8.3333333e-3f)), sp2(-1.6666667e-1f)), sp2(1.0f));
+  cs = fma2(t, fma2(t, fma2(t, fma2(t, fma2(t, fma2(t, sp2(2.0876757e-9f), sp2(-2.7557319e-7f)), sp2(2.4801587e-5f)), sp2(-1.3888889e-3f)), sp2(4.1666667e-2f)), sp2(-0.5f)), sp2(1.0f));
+}
+
+struct FwPairOut { f2 fp, fn, ty; };  // per surface: force along +x, along the lift unit (+z), and the r x f + moment part of tau.y
 
 struct FwHot {
   v3 p; quat q; v3 v, w;
@@ -236,24 +303,117 @@ struct FwHot {
       tau.z = fmaf(-S.ry, fp, tau.z);
     }
   }
+  // Two lift-+z surfaces at once: surface<false> element by element (same operations, same order), the
+  // multiply-add chains in packed fp32.
+  PF_DEV FwPairOut surface_pair(const FwSurf2 S, const f2 a) const {
+    const f2 wbx = sp2(wb.x), wby = sp2(wb.y), wbz = sp2(wb.z);
+    const f2 vx = fma2(wby, S.rz, fma2(-wbz, S.ry, sp2(vb.x)));
+    const f2 vy = fma2(wbz, S.rx, fma2(-wbx, S.rz, sp2(vb.y)));
+    const f2 vz = fma2(wbx, S.ry, fma2(-wby, S.rx, sp2(vb.z)));
+    const f2 V2 = fma2(vx, vx, fma2(vy, vy, vz * vz));
+    const f2 la = vz, fa = vx;
+    const f2 h2 = fma2(la, la, fa * fa);
+    const f2 ih = f2{frsq(h2.x), frsq(h2.y)};
+    const f2 cu = fa * ih, su = -la * ih;
+    const bool still0 = !(h2.x > 0.0f), still1 = !(h2.y > 0.0f);
+    const f2 ca = f2{still0 ? 1.0f : cu.x, still1 ? 1.0f : cu.y};
+    const f2 sa = f2{still0 ? 0.0f : su.x, still1 ? 0.0f : su.y};
+    const f2 alpha = fast_atan2_pair(-la, fa);
+    const f2 defl = a * S.defl_lim;
+    const f2 a0 = fma2(-S.tau_eta, defl, S.a0b);
+    const f2 aP = fma2(S.c1, defl, S.aPb), aN = fma2(S.c1, defl, S.aNb);
+    const bool lin0 = (aN.x < alpha.x) && (alpha.x < aP.x), lin1 = (aN.y < alpha.y) && (alpha.y < aP.y);
+    const f2 Cl_lin = S.cl3d * (alpha - a0);
+    f2 ai = Cl_lin * S.ipa;
+    const bool any_stall = __any(!(lin0 && lin1));
+    if (any_stall) {
+      const bool pos0 = alpha.x > 0.0f, pos1 = alpha.y > 0.0f;
+      const f2 as = f2{pos0 ? aP.x : aN.x, pos1 ? aP.y : aN.y};
+      const f2 ai_stall = S.cl3d * (as - a0) * S.ipa;
+      const f2 edge = f2{pos0 ? 0.5f * kPi : -0.5f * kPi, pos1 ? 0.5f * kPi : -0.5f * kPi};
+      const f2 den = edge - as;
+      const f2 tt = (edge - alpha) * f2{frcp(den.x), frcp(den.y)};
+      const f2 ais = ai_stall * f2{med3(tt.x, 0.0f, 1.0f), med3(tt.y, 0.0f, 1.0f)};
+      ai = f2{lin0 ? ai.x : ais.x, lin1 ? ai.y : ais.y};
+    }
+    const f2 x = a0 + ai;
+    const f2 ae = alpha - x;
+    f2 sx, cx;
+    sincos_small_pair(x, sx, cx);
+    const f2 se = fma2(sa, cx, -(ca * sx)), ce = fma2(ca, cx, sa * sx);
+    const f2 CT = S.cd0 * ce;
+    const f2 CN = fma2(CT, se, Cl_lin) * f2{frcp(ce.x), frcp(ce.y)};
+    f2 Cl = Cl_lin;
+    f2 Cd = fma2(CN, se, CT * ce);
+    f2 CM = -CN * fma2(sp2(0.175f * (2.0f / kPi)), ae, sp2(0.075f));
+    if (any_stall) {
+      const f2 Cd90 = fma2(sp2(-4.26e-2f), defl * defl, fma2(sp2(2.1e-1f), defl, sp2(1.98f)));
+      const f2 dn = fma2(sp2(0.44f), f2{__builtin_fabsf(se.x), __builtin_fabsf(se.y)}, sp2(0.56f));
+      const f2 CNs = Cd90 * se * (f2{frcp(dn.x), frcp(dn.y)} - S.exp_term);
+      const f2 CTs = sp2(0.5f) * S.cd0 * ce;
+      const f2 Cls = fma2(CNs, ce, -(CTs * se));
+      const f2 Cds = fma2(CNs, se, CTs * ce);
+      const f2 CMs = -CNs * fma2(sp2(0.175f * (2.0f / kPi)), f2{__builtin_fabsf(ae.x), __builtin_fabsf(ae.y)}, sp2(0.075f));
+      Cl = f2{lin0 ? Cl.x : Cls.x, lin1 ? Cl.y : Cls.y};
+      Cd = f2{lin0 ? Cd.x : Cds.x, lin1 ? Cd.y : Cds.y};
+      CM = f2{lin0 ? CM.x : CMs.x, lin1 ? CM.y : CMs.y};
+    }
+    const f2 QA = S.hra * V2;
+    const f2 L = Cl * QA, D = Cd * QA;
+    FwPairOut o;
+    o.fn = fma2(L, ca, D * sa);
+    o.fp = fma2(L, sa, -(D * ca));
+    const f2 tm = QA * CM * S.chord;
+    o.ty = fma2(S.rz, o.fp, fma2(-S.rx, o.fn, tm));
+    return o;
+  }
+  // one lift-+z surface's force and torque into the body totals (the tail of surface<false>)
+  PF_DEV static void accumulate(const float ry, const float fp, const float fn, const float ty, v3& F, v3& tau) {
+    F.x += fp;
+    F.z += fn;
+    tau.x = fmaf(ry, fn, tau.x);
+    tau.y += ty;
+    tau.z = fmaf(-ry, fp, tau.z);
+  }
   // one physics tick: update_physics (fixedwing.py:261-264) + stepSimulation + update_state (:266-291)
-  PF_DEV void tick(fw_surf_cptr surf, const float xi, const pf_params* Pfull) {
+  PF_DEV void tick(fw_tab_cptr tab, const float xi, const pf_params* Pfull) {
     v3 F{0.f, 0.f, 0.f}, tau{0.f, 0.f, 0.f};
     // An opaque zero offset per tick keeps the per-surface constant loads inside the tick (16 SGPRs at
     // a time, see the file header) instead of hoisted and spilled; the scheduling barriers keep the
     // five surface bodies from being interleaved (which cost 255 VGPRs and scratch).
     uint32_t zoff;
     asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
-    fw_surf_cptr sk = surf + zoff;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const FwSurf S = fw_load_surf(sk + i);
-      act[i] = fmaf(S.dt_tau, cmd[i] - act[i], act[i]);  // lifting_surfaces.py:277
-      if (i == 3) surface<true>(S, act[i], F, tau);
-      else surface<false>(S, act[i], F, tau);
-      __builtin_amdgcn_sched_barrier(0);
+    fw_tab_cptr tk = tab + zoff;
+    FwPairOut tw;  // (h-tail, main wing): evaluated together, accumulated as surfaces 2 and 4 around the v-tail
+    float ry4;
+    {  // ailerons
+      const FwSurf2 S = fw_load_surf2(&tk->pair[0]);
+      f2 a = f2{act[0], act[1]};
+      a = fma2(S.dt_tau, f2{cmd[0], cmd[1]} - a, a);  // lifting_surfaces.py:277
+      act[0] = a.x; act[1] = a.y;
+      const FwPairOut o = surface_pair(S, a);
+      accumulate(S.ry.x, o.fp.x, o.fn.x, o.ty.x, F, tau);
+      accumulate(S.ry.y, o.fp.y, o.fn.y, o.ty.y, F, tau);
     }
-    const FwBody K = fw_load_body((fw_body_cptr)(sk + 5));
+    __builtin_amdgcn_sched_barrier(0);
+    {  // horizontal tail + main wing
+      const FwSurf2 S = fw_load_surf2(&tk->pair[1]);
+      f2 a = f2{act[2], act[4]};
+      a = fma2(S.dt_tau, f2{cmd[2], cmd[4]} - a, a);
+      act[2] = a.x; act[4] = a.y;
+      tw = surface_pair(S, a);
+      accumulate(S.ry.x, tw.fp.x, tw.fn.x, tw.ty.x, F, tau);
+      ry4 = S.ry.y;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {  // vertical tail
+      const FwSurf S = fw_load_surf(&tk->vtail);
+      act[3] = fmaf(S.dt_tau, cmd[3] - act[3], act[3]);
+      surface<true>(S, act[3], F, tau);
+    }
+    accumulate(ry4, tw.fp.y, tw.fn.y, tw.ty.y, F, tau);
+    __builtin_amdgcn_sched_barrier(0);
+    const FwBody K = fw_load_body(&tk->body);
     {  // motor (motors.py:110-195), at the base origin along +x
       float t = fmaf(K.m_a, cmd[5] - thr, thr);
       t = fmaf(xi * t, K.m_noise, t);
@@ -308,11 +468,15 @@ struct FwHot {
 // Same flat shape as quadx_m0_env_kernel (quadx_fast.hpp): prologue, one loop over the env step's
 // Aviary steps with a single per-lane predicate, epilogue. State groups: g0 p+dist, g1 q, g2 v+w.x,
 // g3 w.yz+act0,1, g4 act2..4+throttle, g5 ints, g6..8 the 4x3 targets (Fixedwing::load/store layout).
-template <int NOISE>
+// ROLL: as in quadx_m0_env_kernel -- 0 one env step per launch, 1 pf_rollout with on-device action sampling (no vector-memory
+// load in the loop), 2 pf_rollout over a given action sequence.
+template <int NOISE, int ROLL>
 __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, const FwTable* table_g, const pf_buffers B,
                                                                  const pf_params* __restrict__ Pfull, const float4* __restrict__ tmpl,
                                                                  const int n, const uint64_t lane0, const int op,
-                                                                 const uint8_t* __restrict__ mask) {
+                                                                 const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
+  constexpr bool ROLLOUT = ROLL != 0;
+  constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 6 + 12;
   __shared__ float tile[64 * kMaxD];
   const int tid = threadIdx.x;
@@ -323,7 +487,7 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
   const size_t N = (size_t)n;
   const float4* Sin = reinterpret_cast<const float4*>(B.state);
   float4* Sout = reinterpret_cast<float4*>(B.state);
-  fw_surf_cptr surf = (fw_surf_cptr)(uintptr_t)table_g;
+  fw_tab_cptr surf = (fw_tab_cptr)(uintptr_t)table_g;
 
   FwHot V;
   static_assert(64 * kMaxD >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
@@ -357,16 +521,10 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
   V.derive();
   bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
 
-  bool active, do_reset;
-  if (op == 1) {
-    do_reset = (mask == nullptr) || (mask[li] != 0);
-    active = do_reset;
-  } else {
-    do_reset = (K.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc);
-    active = true;
-  }
+  bool active;
+  if (op == 1) active = (mask == nullptr) || (mask[li] != 0);
+  else active = true;
   active = active && valid;
-  do_reset = do_reset && active;
 
   float act0 = 0.f, act1 = 0.f, act2 = 0.f, act3 = 0.f;
   float reward = 0.0f;
@@ -494,15 +652,42 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
     lds_sync();
   };
 
+  const int KS = ROLLOUT ? k_steps : 1;
+  float4 a_nxt = float4{0.f, 0.f, 0.f, 0.f};
+  if (GIVEN) a_nxt = reinterpret_cast<const float4*>(B.actions)[li];
+  for (int it = 0; it < KS; ++it) {
+  const size_t toff = ROLLOUT ? (size_t)it * N : (size_t)0;  // this step's slot in the trajectory buffers (lanes)
   // ---------------------------------------------------------------- reset (NEXT_STEP / explicit)
+  bool do_reset;
+  if (op == 1) do_reset = active;
+  else do_reset = (K.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc) && active;
+  act0 = act1 = act2 = act3 = 0.f;
+  reward = 0.0f;
+  was_reset = false;
   if (do_reset) reset_lane();
 
   // ---------------------------------------------------------------- the env step
   const bool stepping = active && !was_reset && op == 0;
 #pragma unroll
   for (int k = 0; k < 6; ++k) V.cmd[k] = 0.f;
+  float4 a_roll = float4{0.f, 0.f, 0.f, 0.f};
+  if (ROLLOUT) {  // this step's action for every lane: given sequence (prefetched one step ahead) or sampled
+    if (GIVEN) {
+      a_roll = a_nxt;
+      if (it + 1 < KS) a_nxt = reinterpret_cast<const float4*>(B.actions)[toff + N + li];
+    } else {  // == sample_actions_kernel(step0 + it): same Philox key, same arithmetic
+      f4 u = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), step0 + (uint32_t)it, 0u, 3u));
+      a_roll = float4{fmaf(K.act_span[0], u.a, K.act_lo[0]), fmaf(K.act_span[1], u.b, K.act_lo[1]),
+                      fmaf(K.act_span[2], u.c, K.act_lo[2]), fmaf(K.act_span[3], u.d, K.act_lo[3])};
+    }
+    if (!GIVEN && B.actions_out != nullptr && active) {
+      float* ao = B.actions_out + 4 * (toff + li);
+      __builtin_nontemporal_store(a_roll.x, ao + 0); __builtin_nontemporal_store(a_roll.y, ao + 1);
+      __builtin_nontemporal_store(a_roll.z, ao + 2); __builtin_nontemporal_store(a_roll.w, ao + 3);
+    }
+  }
   if (stepping) {
-    const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+    const float4 a = ROLLOUT ? a_roll : reinterpret_cast<const float4*>(B.actions)[li];
     act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
     const float thr_sp = K.throttle_remap ? fmaf(a.w, 0.5f, 0.5f) : a.w;  // fixedwing_base_env.py:260
     // update_control, mode 0 (fixedwing.py:143-144,246-250): constant over the env step
@@ -531,7 +716,7 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
       if (!K.task_sparse) {  // fixedwing_waypoints_env.py:174-178
         float progress = (isinf(old_dist + new_dist)) ? 0.0f : old_dist - new_dist;
         reward += __builtin_fmaxf(3.0f * progress, 0.0f);
-        reward += K.wp_dist_reward * frcp(new_dist);
+        reward = fmaf(K.wp_dist_reward, frcp(new_dist), reward);
       }
       if (new_dist < K.goal_reach) {  // :181-190
         reward = 100.0f;
@@ -557,12 +742,12 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
     if (__any(same)) {
       if (B.final_obs != nullptr) {
         if (active) write_obs_row();
-        flush_tile(B.final_obs);
+        flush_tile(B.final_obs + toff * D);
       }
       if (B.final_info != nullptr && same) {  // gymnasium's final_info: the episode's flags / targets left, pre-reset
-        B.final_info[2 * li + 0] = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
-                                   (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
-        B.final_info[2 * li + 1] = n_left - (pop_pending ? 1 : 0);
+        B.final_info[2 * (toff + li) + 0] = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
+                                            (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
+        B.final_info[2 * (toff + li) + 1] = n_left - (pop_pending ? 1 : 0);
       }
       if (same) reset_lane();
     }
@@ -570,11 +755,22 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
 
   // ---------------------------------------------------------------- outputs
   if (active) write_obs_row();
-  flush_tile(B.obs);
+  flush_tile(B.obs + toff * D);
   if (active) {
     if (pop_pending) { pop_target(); pop_pending = false; }
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
             (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
+    if (op == 0) {
+      B.reward[toff + li] = out_reward;
+      B.terminated[toff + li] = out_term ? 1 : 0;
+      B.truncated[toff + li] = out_trunc ? 1 : 0;
+    }
+  }
+  // the next step's motor-noise normals (keyed by the event counter this step left behind)
+  if (ROLLOUT && NOISE == PF_NOISE_PHILOX && it + 1 < KS)
+    zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
+  }  // for it
+  if (active) {  // the persistent state goes back to HBM once per launch
     Sout[0 * N + li] = float4{V.p.x, V.p.y, V.p.z, new_dist};
     Sout[1 * N + li] = float4{V.q.x, V.q.y, V.q.z, V.q.w};
     Sout[2 * N + li] = float4{V.v.x, V.v.y, V.v.z, V.w.x};
@@ -584,11 +780,6 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
     Sout[6 * N + li] = float4{tgt[0][0], tgt[0][1], tgt[0][2], tgt[1][0]};
     Sout[7 * N + li] = float4{tgt[1][1], tgt[1][2], tgt[2][0], tgt[2][1]};
     Sout[8 * N + li] = float4{tgt[2][2], tgt[3][0], tgt[3][1], tgt[3][2]};
-    if (op == 0) {
-      B.reward[li] = out_reward;
-      B.terminated[li] = out_term ? 1 : 0;
-      B.truncated[li] = out_trunc ? 1 : 0;
-    }
   }
 }
 

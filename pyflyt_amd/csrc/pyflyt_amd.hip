@@ -789,11 +789,23 @@ static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32
 }
 static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
-#define PF_FAST(NZ) hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, op, mask)
+#define PF_FAST(NZ) hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ, 0>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, op, mask, 1, 0u)
   if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
   else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
   else PF_FAST(PF_NOISE_OFF);
 #undef PF_FAST
+}
+static void launch_rollout_fw(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
+  const int grid = (ctx->n + 63) / 64;
+#define PF_ROLL(NZ, R) hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ, R>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+  if (b->actions == nullptr) {
+    if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX, 1);
+    else PF_ROLL(PF_NOISE_OFF, 1);
+  } else {
+    if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX, 2);
+    else PF_ROLL(PF_NOISE_OFF, 2);
+  }
+#undef PF_ROLL
 }
 template <class VEH, int TASK>
 static void launch_env_t(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
@@ -1031,14 +1043,16 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
     return fail(ctx, PF_ERR_ARG, "pf_rollout: state, obs, reward, terminated and truncated buffers are required");
   if (k_steps < 1) return fail(ctx, PF_ERR_ARG, "pf_rollout: k_steps must be >= 1");
   const pf_params& P = ctx->P;
-  if (!ctx->fast || (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS))
-    return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: supported for the specialised QuadX mode-0 Hover / Waypoints kernels only");
+  const bool fw = ctx->fast_fw && ctx->tmpl;
+  if (!fw && (!ctx->fast || (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS)))
+    return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: supported for the specialised kernels only (QuadX mode-0 Hover / Waypoints, Fixedwing-Waypoints)");
   if (P.noise_mode == PF_NOISE_INJECT) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: PF_NOISE_INJECT is a per-step protocol; use pf_env_step");
   if (P.autoreset == PF_AUTORESET_OFF) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: needs an auto-reset mode (finished lanes would idle for the rest of the launch)");
   int rc = ensure_device(ctx);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (P.task == PF_TASK_HOVER) launch_rollout<PF_TASK_HOVER>(ctx, b, k_steps, step_index0, s);
+  if (fw) launch_rollout_fw(ctx, b, k_steps, step_index0, s);
+  else if (P.task == PF_TASK_HOVER) launch_rollout<PF_TASK_HOVER>(ctx, b, k_steps, step_index0, s);
   else launch_rollout<PF_TASK_WAYPOINTS>(ctx, b, k_steps, step_index0, s);
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;

@@ -15,14 +15,19 @@ def _engine(task, n, noise, autoreset, seed, lane_offset=0, **kw):
     from pyflyt_amd import build_params
     from pyflyt_amd.engine import BatchEngine
 
-    P = build_params("quadx", task, noise=noise, autoreset=autoreset, seed=seed, **kw)
+    vehicle = "quadx"
+    if task.startswith("fixedwing_"):
+        vehicle, task = "fixedwing", task[len("fixedwing_"):]
+    P = build_params(vehicle, task, noise=noise, autoreset=autoreset, seed=seed, **kw)
     return BatchEngine(P, n, device="cuda:0", lane_offset=lane_offset)
 
 
-@pytest.mark.parametrize("task", ["hover", "waypoints"])
+@pytest.mark.parametrize("task", ["hover", "waypoints", "fixedwing_waypoints"])
 @pytest.mark.parametrize("noise,autoreset", [("philox", "next_step"), ("philox", "same_step"), ("off", "next_step")])
 def test_rollout_bit_identical_to_single_steps(task, noise, autoreset):
     n, k, seed = 1000, 96, 21  # 1000: a ragged last wave
+    if task == "fixedwing_waypoints":
+        k = 300  # the plane's episodes are longer: enough steps for a few hundred of them to end inside the rollouts
     a = _engine(task, n, noise, autoreset, seed, lane_offset=4096)
     b = _engine(task, n, noise, autoreset, seed, lane_offset=4096)
     a.env_reset()
@@ -51,6 +56,7 @@ def test_rollout_bit_identical_to_single_steps(task, noise, autoreset):
             assert torch.equal(b.final_obs[done], chunks[c][5][j][done]), f"step {s}: final_obs"
             assert torch.equal(b.final_info[done], chunks[c][6][j][done]), f"step {s}: final_info"
     assert torch.equal(a.state, b.state)
+    print(f"{task}: {n_done} episode ends inside the rollouts")
     assert n_done > 200  # random actions end episodes quickly: the in-loop resets are exercised
 
 
@@ -62,6 +68,20 @@ def test_rollout_given_action_sequence():
     a.env_reset(); b.env_reset()
     rng = np.random.default_rng(0)
     seq = torch.tensor(rng.uniform([-3, -3, -3, 0], [3, 3, 3, 0.8], size=(k, n, 4)), dtype=torch.float32, device="cuda:0")
+    obs, rew, term, trunc, _ = a.rollout(k, actions=seq)
+    for s in range(k):
+        o, r, t, tr = b.env_step(seq[s].contiguous())
+        assert torch.equal(o, obs[s]) and torch.equal(r, rew[s]) and torch.equal(t, term[s]) and torch.equal(tr, trunc[s]), s
+    assert torch.equal(a.state, b.state)
+
+
+def test_rollout_given_action_sequence_fixedwing():
+    n, k = 320, 60
+    a = _engine("fixedwing_waypoints", n, "philox", "next_step", 5)
+    b = _engine("fixedwing_waypoints", n, "philox", "next_step", 5)
+    a.env_reset(); b.env_reset()
+    rng = np.random.default_rng(0)
+    seq = torch.tensor(rng.uniform([-1, -1, -1, 0], [1, 1, 1, 1], size=(k, n, 4)), dtype=torch.float32, device="cuda:0")
     obs, rew, term, trunc, _ = a.rollout(k, actions=seq)
     for s in range(k):
         o, r, t, tr = b.env_step(seq[s].contiguous())

@@ -303,68 +303,149 @@ struct FwHot {
       tau.z = fmaf(-S.ry, fp, tau.z);
     }
   }
-  // Two lift-+z surfaces at once: surface<false> element by element (same operations, same order), the
-  // multiply-add chains in packed fp32.
-  PF_DEV FwPairOut surface_pair(const FwSurf2 S, const f2 a) const {
+  // Two lift-+z surfaces at once: surface<false> element by element (same operations on each element),
+  // the multiply-add chains in packed fp32. The statement ORDER is the schedule (the build runs with the
+  // machine scheduler off): a packed result read by the very next VALU instruction costs a wait state
+  // (s_nop) and a compare needs two instructions before the select that reads its mask (gfx940 hazards),
+  // so independent work is placed into every such gap by hand -- the Horner chains of atan2 and of
+  // sin / cos are interleaved with the actuator lag, the stall angles and the selects.
+  PF_DEV FwPairOut surface_pair(const FwSurf2 S, f2& a, const f2 cmd2) const {
     const f2 wbx = sp2(wb.x), wby = sp2(wb.y), wbz = sp2(wb.z);
-    const f2 vx = fma2(wby, S.rz, fma2(-wbz, S.ry, sp2(vb.x)));
-    const f2 vy = fma2(wbz, S.rx, fma2(-wbx, S.rz, sp2(vb.y)));
-    const f2 vz = fma2(wbx, S.ry, fma2(-wby, S.rx, sp2(vb.z)));
-    const f2 V2 = fma2(vx, vx, fma2(vy, vy, vz * vz));
+    const f2 da = cmd2 - a;
+    const f2 t1 = fma2(-wbz, S.ry, sp2(vb.x));
+    const f2 t2 = fma2(-wbx, S.rz, sp2(vb.y));
+    const f2 t3 = fma2(-wby, S.rx, sp2(vb.z));
+    a = fma2(S.dt_tau, da, a);  // lifting_surfaces.py:277
+    const f2 vx = fma2(wby, S.rz, t1);
+    const f2 vy = fma2(wbz, S.rx, t2);
+    const f2 vz = fma2(wbx, S.ry, t3);
     const f2 la = vz, fa = vx;
-    const f2 h2 = fma2(la, la, fa * fa);
-    const f2 ih = f2{frsq(h2.x), frsq(h2.y)};
-    const f2 cu = fa * ih, su = -la * ih;
-    const bool still0 = !(h2.x > 0.0f), still1 = !(h2.y > 0.0f);
-    const f2 ca = f2{still0 ? 1.0f : cu.x, still1 ? 1.0f : cu.y};
-    const f2 sa = f2{still0 ? 0.0f : su.x, still1 ? 0.0f : su.y};
-    const f2 alpha = fast_atan2_pair(-la, fa);
     const f2 defl = a * S.defl_lim;
+    const f2 fa2 = fa * fa;
+    const f2 vz2 = vz * vz;
+    const f2 h2 = fma2(la, la, fa2);
+    const f2 V2t = fma2(vy, vy, vz2);
     const f2 a0 = fma2(-S.tau_eta, defl, S.a0b);
-    const f2 aP = fma2(S.c1, defl, S.aPb), aN = fma2(S.c1, defl, S.aNb);
+    const f2 V2 = fma2(vx, vx, V2t);
+    // fast_atan2_pair(-la, fa), inlined so its chain can be interleaved
+    const f2 y = -la;
+    const float ax0 = __builtin_fabsf(fa.x), ay0 = __builtin_fabsf(y.x), ax1 = __builtin_fabsf(fa.y), ay1 = __builtin_fabsf(y.y);
+    const float mx0 = __builtin_fmaxf(ax0, ay0), mx1 = __builtin_fmaxf(ax1, ay1);
+    const float ih0 = frsq(h2.x), ih1 = frsq(h2.y);
+    const float rc0 = frcp(mx0), rc1 = frcp(mx1);
+    const float mn0 = __builtin_fminf(ax0, ay0), mn1 = __builtin_fminf(ax1, ay1);
+    const bool zero0 = mx0 == 0.0f, zero1 = mx1 == 0.0f;
+    const bool still0 = !(h2.x > 0.0f), still1 = !(h2.y > 0.0f);
+    const bool steep0 = ay0 > ax0, steep1 = ay1 > ax1;
+    const bool back0 = fa.x < 0.0f, back1 = fa.y < 0.0f;
+    const f2 ih = f2{ih0, ih1};
+    f2 t = f2{mn0, mn1} * f2{rc0, rc1};
+    const f2 cu = fa * ih, su = y * ih;
+    const f2 aP = fma2(S.c1, defl, S.aPb);
+    t = f2{zero0 ? 0.0f : t.x, zero1 ? 0.0f : t.y};
+    const f2 aN = fma2(S.c1, defl, S.aNb);
+    const f2 s = t * t;
+    const f2 QA = S.hra * V2;
+    f2 p = fma2(s, sp2(0.0029035410843789577f), sp2(-0.016282962635159492f));
+    const float ca0 = still0 ? 1.0f : cu.x;
+    p = fma2(s, p, sp2(0.04303929582238197f));
+    const float ca1 = still1 ? 1.0f : cu.y;
+    p = fma2(s, p, sp2(-0.07533670216798782f));
+    const float sa0 = still0 ? 0.0f : su.x;
+    p = fma2(s, p, sp2(0.10654674470424652f));
+    const float sa1 = still1 ? 0.0f : su.y;
+    p = fma2(s, p, sp2(-0.14207133650779724f));
+    const f2 ca = f2{ca0, ca1};
+    const f2 sa = f2{sa0, sa1};
+    const f2 dd = defl * defl;
+    p = fma2(s, p, sp2(0.19993053376674652f));
+    const f2 c9a = fma2(sp2(2.1e-1f), defl, sp2(1.98f));
+    p = fma2(s, p, sp2(-0.3333309292793274f));
+    const f2 Cd90 = fma2(sp2(-4.26e-2f), dd, c9a);  // (used by the post-stall branch only)
+    p = fma2(s, p, sp2(1.0f));
+    const f2 hcd = sp2(0.5f) * S.cd0;
+    f2 r = p * t;
+    const f2 nte = -S.tau_eta;  // filler-free: folded into the modifiers
+    const f2 rq = sp2(0.5f * kPi) - r;
+    r = f2{steep0 ? rq.x : r.x, steep1 ? rq.y : r.y};
+    const f2 rh = sp2(kPi) - r;
+    r = f2{back0 ? rh.x : r.x, back1 ? rh.y : r.y};
+    const f2 alpha = f2{__builtin_copysignf(r.x, y.x), __builtin_copysignf(r.y, y.y)};
+    (void)nte;
     const bool lin0 = (aN.x < alpha.x) && (alpha.x < aP.x), lin1 = (aN.y < alpha.y) && (alpha.y < aP.y);
-    const f2 Cl_lin = S.cl3d * (alpha - a0);
-    f2 ai = Cl_lin * S.ipa;
+    const f2 am = alpha - a0;
     const bool any_stall = __any(!(lin0 && lin1));
-    if (any_stall) {
+    const f2 Cl_lin = S.cl3d * am;
+    f2 ai = Cl_lin * S.ipa;
+    if (any_stall) {  // :409-425 (see surface<>)
       const bool pos0 = alpha.x > 0.0f, pos1 = alpha.y > 0.0f;
       const f2 as = f2{pos0 ? aP.x : aN.x, pos1 ? aP.y : aN.y};
-      const f2 ai_stall = S.cl3d * (as - a0) * S.ipa;
       const f2 edge = f2{pos0 ? 0.5f * kPi : -0.5f * kPi, pos1 ? 0.5f * kPi : -0.5f * kPi};
+      const f2 asm0 = as - a0;
       const f2 den = edge - as;
-      const f2 tt = (edge - alpha) * f2{frcp(den.x), frcp(den.y)};
+      const f2 num = edge - alpha;
+      const f2 aist = S.cl3d * asm0;
+      const f2 rden = f2{frcp(den.x), frcp(den.y)};
+      const f2 ai_stall = aist * S.ipa;
+      const f2 tt = num * rden;
       const f2 ais = ai_stall * f2{med3(tt.x, 0.0f, 1.0f), med3(tt.y, 0.0f, 1.0f)};
       ai = f2{lin0 ? ai.x : ais.x, lin1 ? ai.y : ais.y};
     }
     const f2 x = a0 + ai;
+    // sincos_small(x): the two Horner chains side by side
+    const f2 tq = x * x;
     const f2 ae = alpha - x;
-    f2 sx, cx;
-    sincos_small_pair(x, sx, cx);
-    const f2 se = fma2(sa, cx, -(ca * sx)), ce = fma2(ca, cx, sa * sx);
+    f2 ps = fma2(tq, sp2(-2.5052108e-8f), sp2(2.7557319e-6f));
+    f2 pc = fma2(tq, sp2(2.0876757e-9f), sp2(-2.7557319e-7f));
+    ps = fma2(tq, ps, sp2(-1.9841270e-4f));
+    pc = fma2(tq, pc, sp2(2.4801587e-5f));
+    ps = fma2(tq, ps, sp2(8.3333333e-3f));
+    pc = fma2(tq, pc, sp2(-1.3888889e-3f));
+    ps = fma2(tq, ps, sp2(-1.6666667e-1f));
+    pc = fma2(tq, pc, sp2(4.1666667e-2f));
+    ps = fma2(tq, ps, sp2(1.0f));
+    pc = fma2(tq, pc, sp2(-0.5f));
+    const f2 cmk = fma2(sp2(0.175f * (2.0f / kPi)), ae, sp2(0.075f));
+    const f2 cx = fma2(tq, pc, sp2(1.0f));
+    const f2 sx = x * ps;
+    const f2 cas = ca * sx;
+    const f2 sas = sa * sx;
+    const f2 se = fma2(sa, cx, -cas), ce = fma2(ca, cx, sas);
+    // :397-406
+    const float rce0 = frcp(ce.x), rce1 = frcp(ce.y);
     const f2 CT = S.cd0 * ce;
-    const f2 CN = fma2(CT, se, Cl_lin) * f2{frcp(ce.x), frcp(ce.y)};
+    const f2 CTc = CT * ce;
+    const f2 cnn = fma2(CT, se, Cl_lin);
+    const f2 CN = cnn * f2{rce0, rce1};
     f2 Cl = Cl_lin;
-    f2 Cd = fma2(CN, se, CT * ce);
-    f2 CM = -CN * fma2(sp2(0.175f * (2.0f / kPi)), ae, sp2(0.075f));
-    if (any_stall) {
-      const f2 Cd90 = fma2(sp2(-4.26e-2f), defl * defl, fma2(sp2(2.1e-1f), defl, sp2(1.98f)));
+    f2 Cd = fma2(CN, se, CTc);
+    f2 CM = -CN * cmk;
+    if (any_stall) {  // :427-448
       const f2 dn = fma2(sp2(0.44f), f2{__builtin_fabsf(se.x), __builtin_fabsf(se.y)}, sp2(0.56f));
-      const f2 CNs = Cd90 * se * (f2{frcp(dn.x), frcp(dn.y)} - S.exp_term);
-      const f2 CTs = sp2(0.5f) * S.cd0 * ce;
-      const f2 Cls = fma2(CNs, ce, -(CTs * se));
-      const f2 Cds = fma2(CNs, se, CTs * ce);
-      const f2 CMs = -CNs * fma2(sp2(0.175f * (2.0f / kPi)), f2{__builtin_fabsf(ae.x), __builtin_fabsf(ae.y)}, sp2(0.075f));
+      const f2 c9s = Cd90 * se;
+      const f2 CTs = hcd * ce;
+      const f2 cms = fma2(sp2(0.175f * (2.0f / kPi)), f2{__builtin_fabsf(ae.x), __builtin_fabsf(ae.y)}, sp2(0.075f));
+      const f2 rdn = f2{frcp(dn.x), frcp(dn.y)};
+      const f2 cts = CTs * se;
+      const f2 ctc = CTs * ce;
+      const f2 CNs = c9s * (rdn - S.exp_term);
+      const f2 Cls = fma2(CNs, ce, -cts);
+      const f2 Cds = fma2(CNs, se, ctc);
+      const f2 CMs = -CNs * cms;
       Cl = f2{lin0 ? Cl.x : Cls.x, lin1 ? Cl.y : Cls.y};
       Cd = f2{lin0 ? Cd.x : Cds.x, lin1 ? Cd.y : Cds.y};
       CM = f2{lin0 ? CM.x : CMs.x, lin1 ? CM.y : CMs.y};
     }
-    const f2 QA = S.hra * V2;
+    // :485-498
     const f2 L = Cl * QA, D = Cd * QA;
+    const f2 qc = QA * CM;
+    const f2 dsa = D * sa, dca = D * ca;
+    const f2 tm = qc * S.chord;
     FwPairOut o;
-    o.fn = fma2(L, ca, D * sa);
-    o.fp = fma2(L, sa, -(D * ca));
-    const f2 tm = QA * CM * S.chord;
-    o.ty = fma2(S.rz, o.fp, fma2(-S.rx, o.fn, tm));
+    o.fn = fma2(L, ca, dsa);
+    o.fp = fma2(L, sa, -dca);
+    const f2 ty0 = fma2(-S.rx, o.fn, tm);
+    o.ty = fma2(S.rz, o.fp, ty0);
     return o;
   }
   // one lift-+z surface's force and torque into the body totals (the tail of surface<false>)
@@ -389,9 +470,8 @@ struct FwHot {
     {  // ailerons
       const FwSurf2 S = fw_load_surf2(&tk->pair[0]);
       f2 a = f2{act[0], act[1]};
-      a = fma2(S.dt_tau, f2{cmd[0], cmd[1]} - a, a);  // lifting_surfaces.py:277
+      const FwPairOut o = surface_pair(S, a, f2{cmd[0], cmd[1]});
       act[0] = a.x; act[1] = a.y;
-      const FwPairOut o = surface_pair(S, a);
       accumulate(S.ry.x, o.fp.x, o.fn.x, o.ty.x, F, tau);
       accumulate(S.ry.y, o.fp.y, o.fn.y, o.ty.y, F, tau);
     }
@@ -399,9 +479,8 @@ struct FwHot {
     {  // horizontal tail + main wing
       const FwSurf2 S = fw_load_surf2(&tk->pair[1]);
       f2 a = f2{act[2], act[4]};
-      a = fma2(S.dt_tau, f2{cmd[2], cmd[4]} - a, a);
+      tw = surface_pair(S, a, f2{cmd[2], cmd[4]});
       act[2] = a.x; act[4] = a.y;
-      tw = surface_pair(S, a);
       accumulate(S.ry.x, tw.fp.x, tw.fn.x, tw.ty.x, F, tau);
       ry4 = S.ry.y;
     }

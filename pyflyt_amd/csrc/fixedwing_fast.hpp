@@ -46,10 +46,6 @@ struct FwSurf {  // 16 floats, one s_load_dwordx16 per surface per tick
   float chord;
 };
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-PF_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
-PF_DEV f2 sp2(float x) { return f2{x, x}; }                                       // op_sel splat, no instruction
-
 struct FwSurf2 {  // two lift-+z surfaces side by side, every field a (first, second) pair: two s_load_dwordx16 per tick
   f2 rx, ry, rz, cl3d, a0b, aPb, aNb, tau_eta, c1, ipa, exp_term, cd0, defl_lim, dt_tau, hra, chord;
 };

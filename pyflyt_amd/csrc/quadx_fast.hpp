@@ -140,24 +140,42 @@ __device__ __noinline__ bool quad_floor_contact(float px, float py, float pz, qu
 }
 
 struct QuadHot {
-  v3 p; quat q; v3 v, w;
-  float thr[4];
+  v3 p; quat q;
+  // angular / linear velocity as (w, v) element pairs, motor throttle and pwm as (0, 1), (2, 3) pairs: the operands of the
+  // packed-fp32 chains below live in aligned register pairs for the whole kernel (members of vector type, not pairs
+  // assembled from scalar members: those turned into overlapping vector loads that kept part of this struct in scratch)
+  f2 wvx, wvy, wvz;
+  f2 t01, t23;
   float I[3], E[3];
   m3 R; v3 wb, vb;
-  float pwm[4];
+  f2 pw01, pw23;
+  PF_DEV v3 w() const { return v3{wvx.x, wvy.x, wvz.x}; }
+  PF_DEV v3 v() const { return v3{wvx.y, wvy.y, wvz.y}; }
+  PF_DEV void set_wv(v3 w_, v3 v_) { wvx = f2{w_.x, v_.x}; wvy = f2{w_.y, v_.y}; wvz = f2{w_.z, v_.z}; }
+  PF_DEV float thr(int i) const { return i == 0 ? t01.x : i == 1 ? t01.y : i == 2 ? t23.x : t23.y; }
   bool contact_now, contact_step;
   lds_fptr cws;  // the wave's LDS regions for the contact solver (aliased onto the observation tile, idle during the ticks)
 
   PF_DEV void derive() {
     // btMatrix3x3::setRotation scales by 2/|q|^2; q leaves quat_integrate()/the spawn normalised to
-    // 1 ulp, so the factor is 2 to fp32 rounding and the reciprocal (a quarter-rate op) is skipped
+    // 1 ulp, so the factor is 2 to fp32 rounding and the reciprocal (a quarter-rate op) is skipped.
+    // Packed fp32 where two results share a shape (uav_device.hpp: f2): the off-diagonal entries come in
+    // +- pairs, and R^T w / R^T v are the same three-term chains on (w, v) element pairs.
     const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
     const float xy = q.x * ys, xz = q.x * zs, yz = q.y * zs;
     const float dx = fmaf(-q.x, xs, 1.0f), dy = fmaf(-q.y, ys, 1.0f);  // 1 - xx, 1 - yy
-    R = m3{fmaf(-q.z, zs, dy), fmaf(-q.w, zs, xy), fmaf(q.w, ys, xz), fmaf(q.w, zs, xy), fmaf(-q.z, zs, dx), fmaf(-q.w, xs, yz),
-           fmaf(-q.w, ys, xz), fmaf(q.w, xs, yz), fmaf(-q.y, ys, dx)};
-    wb = mulT(R, w);
-    vb = mulT(R, v);
+    const f2 qw = f2{-q.w, q.w};
+    const f2 r0011 = fma2(sp2(-q.z), sp2(zs), f2{dy, dx});  // (m00, m11)
+    const f2 r0110 = fma2(qw, sp2(zs), sp2(xy));            // (m01, m10)
+    const f2 r2002 = fma2(qw, sp2(ys), sp2(xz));            // (m20, m02)
+    const f2 r1221 = fma2(qw, sp2(xs), sp2(yz));            // (m12, m21)
+    const float m22 = fmaf(-q.y, ys, dx);
+    R = m3{r0011.x, r0110.x, r2002.y, r0110.y, r0011.y, r1221.x, r2002.x, r1221.y, m22};
+    f2 bx = sp2(R.m20) * wvz, by = sp2(R.m21) * wvz, bz = sp2(R.m22) * wvz;
+    bx = fma2(sp2(R.m10), wvy, bx); by = fma2(sp2(R.m11), wvy, by); bz = fma2(sp2(R.m12), wvy, bz);
+    bx = fma2(sp2(R.m00), wvx, bx); by = fma2(sp2(R.m01), wvx, by); bz = fma2(sp2(R.m02), wvx, bz);
+    wb = v3{bx.x, by.x, bz.x};  // mulT(R, w)
+    vb = v3{bx.y, by.y, bz.y};  // mulT(R, v)
   }
   // update_control, mode 0 (quadx.py:437-438,472,482-493)
   PF_DEV void control(const QuadK& K, float s0, float s1, float s2, float s3) {
@@ -173,20 +191,24 @@ struct QuadHot {
       a[k] = med3(fmaf(K.kdT[k], de, fmaf(K.kp[k], e, I[k])), -K.lim[k], K.lim[k]);
     }
     float z = med3(s3, 0.0f, 1.0f);
-    pwm[0] = z - a[0] - a[1] - a[2];
-    pwm[1] = z + a[0] + a[1] - a[2];
-    pwm[2] = z + a[0] - a[1] + a[2];
-    pwm[3] = z - a[0] + a[1] + a[2];
-    float hi = __builtin_fmaxf(__builtin_fmaxf(pwm[0], pwm[1]), __builtin_fmaxf(pwm[2], pwm[3]));
-    float lo = __builtin_fminf(__builtin_fminf(pwm[0], pwm[1]), __builtin_fminf(pwm[2], pwm[3]));
+    // motor mixing (quadx.py:96-105): ((z -+ a0) -+ a1) -+ a2, motors (0, 1) and (2, 3) as packed pairs
+    const f2 a0 = f2{-a[0], a[0]}, a1 = f2{-a[1], a[1]};
+    f2 p01 = sp2(z) + a0, p23 = sp2(z) - a0;
+    p01 = p01 + a1; p23 = p23 + a1;
+    p01 = p01 - sp2(a[2]); p23 = p23 + sp2(a[2]);
+    float hi = __builtin_fmaxf(__builtin_fmaxf(p01.x, p01.y), __builtin_fmaxf(p23.x, p23.y));
+    float lo = __builtin_fminf(__builtin_fminf(p01.x, p01.y), __builtin_fminf(p23.x, p23.y));
     if (hi != lo) {
       float pmax = __builtin_fminf(hi, 1.0f), pmin = __builtin_fmaxf(lo, 0.05f);
       float ka = (pmin - lo) * frcp(pmax - lo), ks = (hi - pmax) * frcp(hi - pmin);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pwm[i] = fmaf(ka, pmax - pwm[i], fmaf(-ks, pwm[i] - pmin, pwm[i]));
+      // pwm = fma(ka, pmax - pwm, fma(-ks, pwm - pmin, pwm))
+      const f2 u01 = p01 - sp2(pmin), u23 = p23 - sp2(pmin);
+      const f2 d01 = sp2(pmax) - p01, d23 = sp2(pmax) - p23;
+      const f2 g01 = fma2(sp2(-ks), u01, p01), g23 = fma2(sp2(-ks), u23, p23);
+      p01 = fma2(sp2(ka), d01, g01); p23 = fma2(sp2(ka), d23, g23);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pwm[i] = med3(pwm[i], 0.05f, 1.0f);
+    pw01 = f2{med3(p01.x, 0.05f, 1.0f), med3(p01.y, 0.05f, 1.0f)};
+    pw23 = f2{med3(p23.x, 0.05f, 1.0f), med3(p23.y, 0.05f, 1.0f)};
   }
   // one physics tick: update_physics (quadx.py:495-510) + stepSimulation + update_state (:512-535)
   // CR: contact RESPONSE compiled in (pf_params.contact_response). The env tasks of this kernel end the episode in the Aviary
@@ -197,11 +219,12 @@ struct QuadHot {
   PF_DEV void tick(const QuadK& K, float xi, const pf_params* Pfull) {
     const float s = fmaf(xi, K.m_noise, 1.0f);
     float k[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float t = fmaf(K.m_a, pwm[i] - thr[i], thr[i]) * s;
-      thr[i] = t;
-      k[i] = t * __builtin_fabsf(t);
+    {  // motors.py:110-195, t = fma(a, pwm - thr, thr) * noise; motors (0, 1) and (2, 3) as packed pairs
+      const f2 d01 = pw01 - t01, d23 = pw23 - t23;
+      t01 = fma2(sp2(K.m_a), d01, t01); t23 = fma2(sp2(K.m_a), d23, t23);
+      t01 = t01 * sp2(s); t23 = t23 * sp2(s);
+      k[0] = t01.x * __builtin_fabsf(t01.x); k[1] = t01.y * __builtin_fabsf(t01.y);
+      k[2] = t23.x * __builtin_fabsf(t23.x); k[3] = t23.y * __builtin_fabsf(t23.y);
     }
     // body-frame angular acceleration (torque / inertia, constants pre-divided): motor arms and reaction torque,
     // rotational drag gated on "no contact in the world" (quadx.py:502-510), gyroscopic term -(w x I w) / I
@@ -236,11 +259,19 @@ struct QuadHot {
         if (!inside) contact_now = quad_floor_contact(p.x, p.y, p.z, q, hx, hy, hz, pxy, pz);
       }
     }
-    v3 wd = mul(R, wdb);
-    v3 a{fmaf(R.m00, Fm.x, fmaf(R.m01, Fm.y, R.m02 * Fm.z)), fmaf(R.m10, Fm.x, fmaf(R.m11, Fm.y, R.m12 * Fm.z)),
-         fmaf(R.m20, Fm.x, fmaf(R.m21, Fm.y, fmaf(R.m22, Fm.z, K.gravity_z)))};
-    w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
-    v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
+    // world-frame angular and linear acceleration, R wdb and R Fm + g, row by row on (wdb, Fm) element pairs; then the
+    // semi-implicit velocity update on (w, v) pairs. (fma(x, y, -0) == x * y for every x, y: the angular half of the last
+    // row has no gravity term.)
+    {
+      const f2 X = f2{wdb.x, Fm.x}, Y = f2{wdb.y, Fm.y}, Z = f2{wdb.z, Fm.z};
+      f2 u0 = sp2(R.m02) * Z, u1 = sp2(R.m12) * Z, u2 = fma2(sp2(R.m22), Z, f2{-0.0f, K.gravity_z});
+      u0 = fma2(sp2(R.m01), Y, u0); u1 = fma2(sp2(R.m11), Y, u1); u2 = fma2(sp2(R.m21), Y, u2);
+      u0 = fma2(sp2(R.m00), X, u0); u1 = fma2(sp2(R.m10), X, u1); u2 = fma2(sp2(R.m20), X, u2);
+      const f2 nx = fma2(u0, sp2(K.dt), wvx), ny = fma2(u1, sp2(K.dt), wvy), nz = fma2(u2, sp2(K.dt), wvz);
+      wvx = f2{med3(nx.x, -K.vmax, K.vmax), med3(nx.y, -K.vmax, K.vmax)};
+      wvy = f2{med3(ny.x, -K.vmax, K.vmax), med3(ny.y, -K.vmax, K.vmax)};
+      wvz = f2{med3(nz.x, -K.vmax, K.vmax), med3(nz.y, -K.vmax, K.vmax)};
+    }
     // contact response (the constraint solve of stepSimulation) for lanes within one bounding radius of the floor:
     // out of line, with its constants read from the device parameter block inside the rare path
     // (can a constraint act at all this tick? conservative bound on the lowest vertex's height after the tick; when it stays
@@ -249,19 +280,19 @@ struct QuadHot {
     if (CR) {
       bool act = false;
       if (near) {  // (low: the exact height of the lowest vertex, from the detection above)
-        const float vlow = v.z - fsqrt(dot(w, w)) * K.bound_radius0;
+        const float vlow = wvz.y - fsqrt(dot(w(), w())) * K.bound_radius0;
         act = (fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop);
       }
       if (__any(act)) {
         contact_rounds(act, cws, [&](lds_fptr slot) {
-          const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
-          v = o.v; w = o.w;
+          const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v(), w());
+          set_wv(o.w, o.v);
           lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
         });
       }
     }
-    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), CR ? fmaf(K.dt, v.z, p.z) + lift : fmaf(K.dt, v.z, p.z)};
-    q = quat_integrate(q, w, K.half_dt);
+    p = v3{fmaf(K.dt, wvx.y, p.x), fmaf(K.dt, wvy.y, p.y), CR ? fmaf(K.dt, wvz.y, p.z) + lift : fmaf(K.dt, wvz.y, p.z)};
+    q = quat_integrate(q, w(), K.half_dt);
     derive();
     contact_step |= contact_now;
   }
@@ -324,9 +355,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     }
     V.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
     V.q = quat{g1.x, g1.y, g1.z, g1.w};
-    V.v = v3{g2.x, g2.y, g2.z};
-    V.w = v3{g2.w, g3.x, g3.y};
-    V.thr[0] = g3.z; V.thr[1] = g3.w; V.thr[2] = g4.x; V.thr[3] = g4.y;
+    V.set_wv(v3{g2.w, g3.x, g3.y}, v3{g2.x, g2.y, g2.z});
+    V.t01 = f2{g3.z, g3.w}; V.t23 = f2{g4.x, g4.y};
     V.I[0] = g4.z; V.I[1] = g4.w; V.I[2] = g5.x;
     V.E[0] = g5.y; V.E[1] = g5.z; V.E[2] = g5.w;
     step_count = __float_as_int(gi.x); flags = __float_as_int(gi.y);
@@ -446,9 +476,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     V.p = v3{sx, sy, z};
     if (TASK == PF_TASK_MA_HOVER) V.q = quat{tgt[1][0], tgt[1][1], tgt[1][2], tgt[2][0]};
     else V.q = quat{K.start_quat[0], K.start_quat[1], K.start_quat[2], K.start_quat[3]};
-    V.v = v3{0.f, 0.f, vz}; V.w = v3{0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { V.thr[k] = thr; V.pwm[k] = 0.05f; }
+    V.set_wv(v3{0.f, 0.f, 0.f}, v3{0.f, 0.f, vz});
+    V.t01 = V.t23 = sp2(thr); V.pw01 = V.pw23 = sp2(0.05f);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { V.I[k] = 0.f; V.E[k] = 0.f; }
     V.contact_now = false; V.contact_step = false;
@@ -534,12 +563,12 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     row[k++] = V.vb.x; row[k++] = V.vb.y; row[k++] = V.vb.z;
     row[k++] = V.p.x; row[k++] = V.p.y; row[k++] = V.p.z;
     if (TASK == PF_TASK_MA_HOVER) {  // ma_quadx_hover_env.py:141-166: aux, past action, start_pos
-      row[k++] = V.thr[0]; row[k++] = V.thr[1]; row[k++] = V.thr[2]; row[k++] = V.thr[3];
+      row[k++] = V.t01.x; row[k++] = V.t01.y; row[k++] = V.t23.x; row[k++] = V.t23.y;
       row[k++] = ma_past.x; row[k++] = ma_past.y; row[k++] = ma_past.z; row[k++] = ma_past.w;
       row[k++] = tgt[0][0]; row[k++] = tgt[0][1]; row[k++] = tgt[0][2];
     } else {
       row[k++] = act0; row[k++] = act1; row[k++] = act2; row[k++] = act3;
-      row[k++] = V.thr[0]; row[k++] = V.thr[1]; row[k++] = V.thr[2]; row[k++] = V.thr[3];
+      row[k++] = V.t01.x; row[k++] = V.t01.y; row[k++] = V.t23.x; row[k++] = V.t23.y;
     }
     if (TASK == PF_TASK_WAYPOINTS) {
       m3 Re = rot_from_quat(qe);
@@ -697,8 +726,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     // NaN / Inf guard (the reference would carry a NaN on silently, e.g. 0 * inf in
     // quadx.py:490-491 when the largest motor command equals the clipped minimum): any non-finite state
     // word poisons the sum
-    const float chk = ((V.p.x + V.p.y) + (V.p.z + V.q.x)) + ((V.q.y + V.q.z) + (V.q.w + V.v.x)) + ((V.v.y + V.v.z) + (V.w.x + V.w.y)) +
-                      ((V.w.z + V.thr[0]) + (V.thr[1] + V.thr[2])) + ((V.thr[3] + V.I[0]) + (V.I[1] + V.I[2]));
+    const float chk = ((V.p.x + V.p.y) + (V.p.z + V.q.x)) + ((V.q.y + V.q.z) + (V.q.w + V.wvx.y)) + ((V.wvy.y + V.wvz.y) + (V.wvx.x + V.wvy.x)) +
+                      ((V.wvz.x + V.t01.x) + (V.t01.y + V.t23.x)) + ((V.t23.y + V.I[0]) + (V.I[1] + V.I[2]));
     if (!(__builtin_fabsf(chk) < INFINITY)) flags |= PF_F_NONFINITE;
   }
 
@@ -741,9 +770,9 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   if (active) {  // the persistent state goes back to HBM once per launch
     Sout[0 * N + li] = float4{V.p.x, V.p.y, V.p.z, new_dist};
     Sout[1 * N + li] = float4{V.q.x, V.q.y, V.q.z, V.q.w};
-    Sout[2 * N + li] = float4{V.v.x, V.v.y, V.v.z, V.w.x};
-    Sout[3 * N + li] = float4{V.w.y, V.w.z, V.thr[0], V.thr[1]};
-    Sout[4 * N + li] = float4{V.thr[2], V.thr[3], V.I[0], V.I[1]};
+    Sout[2 * N + li] = float4{V.wvx.y, V.wvy.y, V.wvz.y, V.wvx.x};
+    Sout[3 * N + li] = float4{V.wvy.x, V.wvz.x, V.t01.x, V.t01.y};
+    Sout[4 * N + li] = float4{V.t23.x, V.t23.y, V.I[0], V.I[1]};
     Sout[5 * N + li] = float4{V.I[2], V.E[0], V.E[1], V.E[2]};
     Sout[6 * N + li] = float4{__int_as_float(step_count), __int_as_float(flags), __int_as_float((int)rng_ctr), __int_as_float(n_left)};
     if (TASK == PF_TASK_MA_HOVER) Sout[15 * N + li] = ma_past;

@@ -83,6 +83,13 @@ PF_DEV quat quat_from_euler(v3 e) {
 }
 
 // ---------------------------------------------------------------- lean math for the hot kernels
+// Packed fp32 (gfx940+: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): two IEEE single operations per issue slot, each
+// element rounded exactly as the scalar instruction would. A packed result read by the very next VALU instruction costs
+// a wait state, so callers interleave independent work (the build runs with the machine scheduler off: statement order
+// is the schedule). A splat operand (sp2) is an op_sel on any VGPR / SGPR, not an instruction.
+typedef float f2 __attribute__((ext_vector_type(2)));
+PF_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+PF_DEV f2 sp2(float x) { return f2{x, x}; }
 PF_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 PF_DEV float frsq(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
 PF_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); } // v_sqrt_f32, 1 ulp

@@ -21,6 +21,10 @@
 //     one slot): ailerons together, h-tail with the main wing. The element-wise arithmetic and the
 //     order the five surfaces accumulate in are those of the one-at-a-time evaluation, so results are
 //     bit-identical to it; the transcendental and select steps have no packed form and stay scalar;
+//     (the kernel sits exactly at the 256-VGPR limit of two waves per SIMD: packing the body integration as well, or moving
+//     the packed chains' constants from SGPR pairs into VGPRs, each saved ~100 instructions per tick on paper and LOST 8 % in
+//     the rollout measurement -- the first spill inside the tick loop is a scratch load, and on gfx9 its vmcnt wait also waits
+//     for every observation store in flight; profiles/README.md, round 2)
 //   * one gyroscopic inertia (I_pa + I_own) instead of two products, rotation scale 2 for the unit
 //     quaternion, Euler angles only in the epilogue;
 //   * resets copy the context's settled spawn state (the settle throttle command is 0, so the motor
@@ -177,36 +181,6 @@ PF_DEV FwSurf2 fw_load_surf2(fw_surf2_cptr p) {  // two s_load_dwordx16, every f
   S.defl_lim = p->defl_lim; S.dt_tau = p->dt_tau; S.hra = p->hra; S.chord = p->chord;
   return S;
 }
-// fast_atan2 (uav_device.hpp) on two arguments at once: the same operations element by element, the
-// polynomial and the products packed
-PF_DEV f2 fast_atan2_pair(f2 y, f2 x) {
-  const float ax0 = __builtin_fabsf(x.x), ay0 = __builtin_fabsf(y.x), ax1 = __builtin_fabsf(x.y), ay1 = __builtin_fabsf(y.y);
-  const float mx0 = __builtin_fmaxf(ax0, ay0), mn0 = __builtin_fminf(ax0, ay0);
-  const float mx1 = __builtin_fmaxf(ax1, ay1), mn1 = __builtin_fminf(ax1, ay1);
-  f2 t = f2{mn0, mn1} * f2{frcp(mx0), frcp(mx1)};
-  t = f2{(mx0 == 0.0f) ? 0.0f : t.x, (mx1 == 0.0f) ? 0.0f : t.y};
-  const f2 s = t * t;
-  f2 p = fma2(s, sp2(0.0029035410843789577f), sp2(-0.016282962635159492f));
-  p = fma2(s, p, sp2(0.04303929582238197f));
-  p = fma2(s, p, sp2(-0.07533670216798782f));
-  p = fma2(s, p, sp2(0.10654674470424652f));
-  p = fma2(s, p, sp2(-0.14207133650779724f));
-  p = fma2(s, p, sp2(0.19993053376674652f));
-  p = fma2(s, p, sp2(-0.3333309292793274f));
-  p = fma2(s, p, sp2(1.0f));
-  f2 r = p * t;
-  const f2 rq = sp2(0.5f * kPi) - r;
-  r = f2{(ay0 > ax0) ? rq.x : r.x, (ay1 > ax1) ? rq.y : r.y};
-  const f2 rh = sp2(kPi) - r;
-  r = f2{(x.x < 0.0f) ? rh.x : r.x, (x.y < 0.0f) ? rh.y : r.y};
-  return f2{__builtin_copysignf(r.x, y.x), __builtin_copysignf(r.y, y.y)};
-}
-PF_DEV void sincos_small_pair(f2 x, f2& sn, f2& cs) {  // sincos_small (uav_device.hpp), packed
-  const f2 t = x * x;
-  sn = x * fma2(t, fma2(t, fma2(t, fma2(t, fma2(t, sp2(-2.5052108e-8f), sp2(2.7557319e-6f)), sp2(-1.9841270e-4f)), sp2(8.3333333e-3f)), sp2(-1.6666667e-1f)), sp2(1.0f));
-  cs = fma2(t, fma2(t, fma2(t, fma2(t, fma2(t, fma2(t, sp2(2.0876757e-9f), sp2(-2.7557319e-7f)), sp2(2.4801587e-5f)), sp2(-1.3888889e-3f)), sp2(4.1666667e-2f)), sp2(-0.5f)), sp2(1.0f));
-}
-
 struct FwPairOut { f2 fp, fn, ty; };  // per surface: force along +x, along the lift unit (+z), and the r x f + moment part of tau.y
 
 struct FwHot {
@@ -361,13 +335,11 @@ struct FwHot {
     p = fma2(s, p, sp2(1.0f));
     const f2 hcd = sp2(0.5f) * S.cd0;
     f2 r = p * t;
-    const f2 nte = -S.tau_eta;  // filler-free: folded into the modifiers
     const f2 rq = sp2(0.5f * kPi) - r;
     r = f2{steep0 ? rq.x : r.x, steep1 ? rq.y : r.y};
     const f2 rh = sp2(kPi) - r;
     r = f2{back0 ? rh.x : r.x, back1 ? rh.y : r.y};
     const f2 alpha = f2{__builtin_copysignf(r.x, y.x), __builtin_copysignf(r.y, y.y)};
-    (void)nte;
     const bool lin0 = (aN.x < alpha.x) && (alpha.x < aP.x), lin1 = (aN.y < alpha.y) && (alpha.y < aP.y);
     const f2 am = alpha - a0;
     const bool any_stall = __any(!(lin0 && lin1));

@@ -129,6 +129,31 @@ class Lane(C.Structure):
     ]
 
 
+DF_MAX = 8
+_dfm = (C.c_double * DF_MAX) * DF_MAX
+_ifm = (C.c_int * DF_MAX) * DF_MAX
+
+
+class Dogfight(C.Structure):
+    """orc_dogfight (uav_oracle.h): env-level state of one MAFixedwingDogfightEnv world."""
+    _fields_ = [
+        ("A", C.c_int), ("team_size", C.c_int),
+        ("damage_per_hit", C.c_double), ("lethal_distance", C.c_double), ("lethal_angle", C.c_double),
+        ("aggressiveness", C.c_double), ("cooperativeness", C.c_double), ("sparse_reward", C.c_int),
+        ("dome", C.c_double), ("max_steps", C.c_int), ("env_step_ratio", C.c_int),
+        ("step_count", C.c_int), ("alive", C.c_int * DF_MAX), ("health", C.c_double * DF_MAX),
+        ("received_hits", C.c_int * DF_MAX), ("inactive", C.c_int * DF_MAX),
+        ("cur_dist", _dfm), ("cur_ang", _dfm), ("prev_dist", _dfm), ("prev_ang", _dfm),
+        ("cur_hit", _ifm), ("in_range", _ifm), ("chasing", _ifm),
+        ("other_att", ((C.c_double * 12) * DF_MAX) * DF_MAX),
+        ("acc_reward", C.c_double * DF_MAX), ("acc_term", C.c_int * DF_MAX), ("acc_trunc", C.c_int * DF_MAX),
+        ("info_bits", C.c_int * DF_MAX),
+        ("action", (C.c_double * 4) * DF_MAX), ("past_action", (C.c_double * 4) * DF_MAX),
+        ("obs", (C.c_double * (23 + (DF_MAX - 1) * 14)) * DF_MAX),
+        ("reward", C.c_double * DF_MAX), ("terminated", C.c_int * DF_MAX), ("truncated", C.c_int * DF_MAX),
+    ]
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
     src = os.path.join(_HERE, "uav_oracle.c")
@@ -175,6 +200,11 @@ def lib():
         L.orc_world_aviary_step.argtypes = [PPP, LPP, C.c_int, dpp, C.c_uint32, C.c_uint32]
         L.orc_world_env_reset.argtypes = [PPP, LPP, C.c_int, C.c_uint64, dpp]
         L.orc_world_env_step.argtypes = [PPP, LPP, C.c_int, dp, dpp]
+        assert L.orc_sizeof_dogfight() == C.sizeof(Dogfight), (L.orc_sizeof_dogfight(), C.sizeof(Dogfight))
+        DP = C.POINTER(Dogfight)
+        L.orc_dogfight_spawn.argtypes = [C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
+        L.orc_dogfight_reset.argtypes = [PPP, LPP, DP, C.c_uint64, dpp]
+        L.orc_dogfight_step.argtypes = [PPP, LPP, DP, dp, dpp]
         L.orc_env_step.argtypes = [PP, LP, dp, dp]
         L.orc_obs_dim.argtypes = [PP]
         L.orc_env_obs.argtypes = [PP, LP, dp]
@@ -267,6 +297,76 @@ class OracleWorld:
 
     def obs(self):
         return np.stack([np.frombuffer(l.obs, dtype=np.float64, count=self.obs_dim).copy() for l in self.Ls])
+
+
+DOGFIGHT_DEFAULTS = dict(team_size=2, spawn_min_radius=10.0, spawn_max_radius=50.0, damage_per_hit=0.003, lethal_distance=20.0,
+                         lethal_angle=0.07, aggressiveness=0.5, cooperativeness=0.5, sparse_reward=False, dome=800.0,
+                         max_duration_seconds=60.0, agent_hz=30)  # ma_fixedwing_dogfight_env.py:42-60
+
+
+def dogfight_spawn(team_size, min_radius, max_radius, u):
+    """_get_start_pos_orn (:176-213) + reset()'s 20 m/s forward velocity (:216-222) from 1 + 6 team_size uniforms."""
+    A = 2 * team_size
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    assert u.shape == (1 + 3 * A,)
+    pos, rpy, vel = np.zeros((A, 3)), np.zeros((A, 3)), np.zeros((A, 3))
+    lib().orc_dogfight_spawn(team_size, min_radius, max_radius, _dp(u), _dp(pos), _dp(rpy), _dp(vel))
+    return pos, rpy, vel
+
+
+class OracleDogfight:
+    """One world of MAFixedwingDogfightEnv on the fp64 oracle: A = 2 team_size Acrowing aircraft (their own orc_params blocks,
+    spawn pose / velocity per aircraft) stepped by orc_world_aviary_step, the env on top restated in orc_dogfight_*."""
+
+    def __init__(self, start_pos, start_rpy, start_vel=None, noise_mode=NOISE_OFF, seed=0, lane_id0=0, **kw):
+        cfg = dict(DOGFIGHT_DEFAULTS, **kw)
+        self.A = 2 * cfg["team_size"]
+        start_pos, start_rpy = np.asarray(start_pos, dtype=np.float64), np.asarray(start_rpy, dtype=np.float64)
+        assert start_pos.shape == (self.A, 3) and start_rpy.shape == (self.A, 3)
+        if start_vel is None:  # reset(): compute_rotation_forward(start_orn)[1] * 20
+            cr, cp = np.cos(start_rpy), None
+            start_vel = 20.0 * np.stack([np.cos(start_rpy[:, 2]) * np.cos(start_rpy[:, 1]), np.sin(start_rpy[:, 2]) * np.cos(start_rpy[:, 1]),
+                                         -np.sin(start_rpy[:, 1])], axis=1)
+        self.env_step_ratio = int(120 / cfg["agent_hz"])
+        self.max_steps = int(cfg["agent_hz"] * cfg["max_duration_seconds"])
+        # Aviary(world_scale=5.0, drone_type="fixedwing", drone_model="acrowing") (ma_fixedwing_base_env.py:193-210)
+        self.Ps = [make_params("acrowing", noise_mode=noise_mode, seed=seed, start_pos=start_pos[i], start_rpy=start_rpy[i], start_vel=start_vel[i],
+                               flight_mode=0, world_plane_half_xy=15.0 * 5.0, world_plane_half_z=5.0 * 5.0,
+                               world_contact_response=1, **cfg.get("param_overrides", {})) for i in range(self.A)]
+        self.Ls = [Lane() for _ in range(self.A)]
+        self.lane_id0 = lane_id0
+        PP, LP = C.POINTER(Params), C.POINTER(Lane)
+        self._pp = (PP * self.A)(*[C.pointer(p) for p in self.Ps])
+        self._lp = (LP * self.A)(*[C.pointer(l) for l in self.Ls])
+        D = self.D = Dogfight()
+        D.A, D.team_size = self.A, cfg["team_size"]
+        D.damage_per_hit, D.lethal_distance, D.lethal_angle = cfg["damage_per_hit"], cfg["lethal_distance"], cfg["lethal_angle"]
+        D.aggressiveness, D.cooperativeness, D.sparse_reward = cfg["aggressiveness"], cfg["cooperativeness"], int(cfg["sparse_reward"])
+        D.dome, D.max_steps, D.env_step_ratio = cfg["dome"], self.max_steps, self.env_step_ratio
+        self.obs_dim = 23 + (self.A - 1) * 14
+
+    _rows = OracleWorld._rows
+
+    def reset(self, xi_reset=None):
+        lib().orc_dogfight_reset(self._pp, self._lp, C.byref(self.D), self.lane_id0, self._rows(xi_reset))
+        return self.obs()
+
+    def step(self, actions, xi=None):
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.A, 4)
+        lib().orc_dogfight_step(self._pp, self._lp, C.byref(self.D), _dp(a), self._rows(xi))
+        D = self.D
+        return (self.obs(), np.array(D.reward[:self.A]), np.array(D.terminated[:self.A], dtype=bool), np.array(D.truncated[:self.A], dtype=bool))
+
+    def obs(self):
+        return np.stack([np.frombuffer(self.D.obs[i], dtype=np.float64, count=self.obs_dim).copy() for i in range(self.A)])
+
+    @property
+    def alive(self):
+        return np.array(self.D.alive[:self.A], dtype=bool)
+
+    @property
+    def health(self):
+        return np.array(self.D.health[:self.A])
 
 
 class OracleBatch:

@@ -1425,6 +1425,209 @@ void orc_world_env_step(const orc_params* const* Pl, orc_lane* const* Ll, int A,
   for (int i = 0; i < A; ++i) { Ll[i]->step_count += 1; Ll[i]->rng_ctr += 1; }
 }
 
+/* ---- MAFixedwingDogfightEnv (pz_envs/fixedwing_envs/ma_fixedwing_dogfight_env.py, ma_fixedwing_base_env.py) ----
+ * A = 2 * team_size Acrowing aircraft in one world; agents [0, team_size) are one team, the rest the other
+ * (:108-126 team_flag, friendly_fire_mask). Per-agent spawn pose / velocity come in through each agent's orc_params
+ * (start_pos, start_rpy, start_vel): orc_dogfight_spawn() restates _get_start_pos_orn (:176-213) and reset()'s 20 m/s
+ * forward velocity (:216-222) from a vector of uniforms. */
+void orc_dogfight_spawn(int team_size, double min_radius, double max_radius, const double* u /* [1 + 6 team_size] */,
+                        double* pos /* [A][3] */, double* rpy /* [A][3] */, double* vel /* [A][3] */) {
+  const int A = 2 * team_size;
+  const double phase = u[0] * 2.0 * PI; /* np_random.uniform(0, 2 pi) */
+  for (int i = 0; i < A; ++i) {
+    const double rad = PI / team_size * i + phase;                              /* :189-191 */
+    const double radius = min_radius + (max_radius - min_radius) * u[1 + i];       /* :192-196 */
+    const double height = min_radius + (max_radius - min_radius) * u[1 + A + i];   /* :197-201: spawn_min/max_RADIUS, sic */
+    pos[3 * i + 0] = radius * cos(rad); pos[3 * i + 1] = radius * sin(rad); pos[3 * i + 2] = height;
+    rpy[3 * i + 0] = 0.0; rpy[3 * i + 1] = 0.0;
+    rpy[3 * i + 2] = rad + u[1 + 2 * A + i] * PI / 8.0;                          /* :210-212 */
+    /* compute_rotation_forward(start_orn)[1] * 20 (ma_fixedwing_base_env.py:403-405 with roll = pitch = 0) */
+    vel[3 * i + 0] = 20.0 * cos(rpy[3 * i + 2]); vel[3 * i + 1] = 20.0 * sin(rpy[3 * i + 2]); vel[3 * i + 2] = -0.0 * 20.0;
+  }
+}
+
+static int df_team(const orc_dogfight* D, int i) { return i >= D->team_size; }
+
+/* update_states() = _compute_observation() (:466-549) + _compute_term_trunc_rew_info() (:651-722) */
+static void dogfight_update_states(const orc_params* const* Pl, orc_lane* const* Ll, orc_dogfight* D) {
+  const int A = D->A;
+  double att[ORC_DF_MAX][12], R[ORC_DF_MAX][9], fwd[ORC_DF_MAX][3], gv[ORC_DF_MAX][3];
+  (void)Pl;
+  memcpy(D->prev_dist, D->cur_dist, sizeof(D->cur_dist));
+  memcpy(D->prev_ang, D->cur_ang, sizeof(D->cur_ang));
+  for (int i = 0; i < A; ++i) {
+    const orc_lane* L = Ll[i];
+    for (int k = 0; k < 3; ++k) { att[i][k] = L->w_b[k]; att[i][3 + k] = L->rpy[k]; att[i][6 + k] = L->v_b[k]; att[i][9 + k] = L->p[k]; }
+    /* compute_rotation_forward (ma_fixedwing_base_env.py:336-405): rz @ ry @ rx and the nose direction */
+    const double cr = cos(L->rpy[0]), sr = sin(L->rpy[0]), cp = cos(L->rpy[1]), sp = sin(L->rpy[1]), cy = cos(L->rpy[2]), sy = sin(L->rpy[2]);
+    double* r = R[i];
+    r[0] = cy * cp; r[1] = cy * sp * sr - sy * cr; r[2] = cy * sp * cr + sy * sr;
+    r[3] = sy * cp; r[4] = sy * sp * sr + cy * cr; r[5] = sy * sp * cr - cy * sr;
+    r[6] = -sp;     r[7] = cp * sr;                r[8] = cp * cr;
+    fwd[i][0] = cy * cp; fwd[i][1] = sy * cp; fwd[i][2] = -sp;
+    for (int k = 0; k < 3; ++k) att[i][9 + k] -= fwd[i][k] * 0.35; /* :318: the state is the nose's, shift to the body centre */
+    for (int k = 0; k < 3; ++k) gv[i][k] = r[3 * k] * att[i][6] + r[3 * k + 1] * att[i][7] + r[3 * k + 2] * att[i][8]; /* :365 */
+  }
+  int hits[ORC_DF_MAX][ORC_DF_MAX];
+  for (int i = 0; i < A; ++i) {
+    for (int j = 0; j < A; ++j) {
+      double sep[3], dist = 0.0, dotf = 0.0;
+      for (int k = 0; k < 3; ++k) { sep[k] = att[j][9 + k] - att[i][9 + k]; dist += sep[k] * sep[k]; dotf += sep[k] * fwd[i][k]; }
+      dist = sqrt(dist);
+      const double ang = acos(dotf / dist); /* NaN on the diagonal, as in the reference (:327-333) */
+      D->cur_dist[i][j] = dist; D->cur_ang[i][j] = ang;
+      D->in_range[i][j] = dist < D->lethal_distance;
+      D->chasing[i][j] = fabs(ang) < PI / 2.0;
+      const int ff = df_team(D, i) != df_team(D, j);
+      hits[i][j] = (ang < D->lethal_angle) && D->in_range[i][j] && D->chasing[i][j] && ff; /* :339-344, :496 */
+      D->cur_hit[i][j] = hits[i][j];
+      /* the other aircraft as seen from this one (:350-378) */
+      double* o = D->other_att[i][j];
+      for (int k = 0; k < 3; ++k) { o[k] = att[j][k]; o[3 + k] = att[j][3 + k] - att[i][3 + k]; }
+      for (int k = 0; k < 3; ++k) { /* gv[j] @ R[i] (row vector times matrix) minus the own body velocity; sep @ R[i] */
+        o[6 + k] = gv[j][0] * R[i][k] + gv[j][1] * R[i][3 + k] + gv[j][2] * R[i][6 + k] - att[i][6 + k];
+        o[9 + k] = sep[0] * R[i][k] + sep[1] * R[i][3 + k] + sep[2] * R[i][6 + k];
+      }
+    }
+  }
+  for (int j = 0; j < A; ++j) { /* :499-503; healths is a float32 array */
+    int rec = 0;
+    for (int i = 0; i < A; ++i) rec += hits[i][j];
+    D->received_hits[j] += rec;
+    D->health[j] = (double)(float)(D->health[j] - D->damage_per_hit * rec);
+    if (D->health[j] < 0.0) D->health[j] = 0.0;
+  }
+  double dist_origin[ORC_DF_MAX];
+  for (int i = 0; i < A; ++i) {
+    const double sp2 = att[i][6] * att[i][6] + att[i][7] * att[i][7] + att[i][8] * att[i][8];
+    D->inactive[i] = (D->health[i] <= 0.0) && (att[i][11] < 2.0) && (sqrt(sp2) < 0.1); /* :505-510 */
+    dist_origin[i] = sqrt(att[i][9] * att[i][9] + att[i][10] * att[i][10] + att[i][11] * att[i][11]);
+  }
+  const int Dobs = 23 + (A - 1) * 14;
+  for (int i = 0; i < A; ++i) { /* :519-549, pop_obs_by_id :724-752 (flattened, zero padded) */
+    double* o = D->obs[i];
+    int k = 0;
+    memset(o, 0, sizeof(double) * (size_t)Dobs);
+    for (int c = 0; c < 12; ++c) o[k++] = att[i][c];
+    for (int c = 0; c < 5; ++c) o[k++] = Ll[i]->actuation[c]; /* aviary.aux_state(i): fixedwing.py:289-291 */
+    o[k++] = Ll[i]->throttle[0];
+    o[k++] = D->health[i];
+    for (int c = 0; c < 4; ++c) o[k++] = D->past_action[i][c];
+    for (int j = 0; j < A; ++j) {
+      if (j == i || D->inactive[j]) continue;
+      for (int c = 0; c < 12; ++c) o[k++] = D->other_att[i][j][c];
+      o[k++] = D->health[j];
+      o[k++] = df_team(D, j) == df_team(D, i) ? 1.0 : 0.0;
+    }
+  }
+  /* ---- _compute_engagement_rewards (:551-620), _compute_boundary_rewards (:622-649) */
+  int team_hits[2] = {0, 0};
+  for (int i = 0; i < A; ++i)
+    for (int j = 0; j < A; ++j) team_hits[df_team(D, i)] += hits[i][j];
+  for (int i = 0; i < A; ++i) {
+    double e = 0.0;
+    for (int j = 0; j < A; ++j) {
+      if (j == i) continue; /* fill_diagonal(0) */
+      const int ff = df_team(D, i) != df_team(D, j);
+      if (!D->sparse_reward) {
+        double dd = D->prev_dist[i][j] - D->cur_dist[i][j];
+        if (dd < 0.0) dd = 0.0;
+        e += 4.0 * dd * ((!D->in_range[i][j]) && D->chasing[i][j] && ff);
+        double da = (D->prev_ang[i][j] - D->cur_ang[i][j]) * (D->in_range[i][j] && ff);
+        if (da < 0.0) da *= D->aggressiveness;
+        e += 30.0 * da;
+        const double iaa_ij = (1.0 / (D->cur_ang[i][j] + 0.1)) * (ff && D->in_range[i][j] && D->chasing[i][j]);
+        const double iaa_ji = (1.0 / (D->cur_ang[j][i] + 0.1)) * (ff && D->in_range[j][i] && D->chasing[j][i]);
+        e += 3.0 * (iaa_ij - (1.0 - D->aggressiveness) * iaa_ji);
+      }
+      e += 20.0 * (hits[i][j] - (1.0 - D->aggressiveness) * hits[j][i]);
+    }
+    e += D->cooperativeness * team_hits[df_team(D, i)]; /* :609-617 */
+    double b = 0.0;
+    if (!D->sparse_reward) {
+      b += tanh(0.1 * att[i][11] - 1.0);
+      b -= tanh(0.0025 * dist_origin[i] - 1.0);
+      for (int j = 0; j < A; ++j)
+        if (j != i && D->cur_dist[i][j] < 5.0) b -= 10.0 * (5.0 - D->cur_dist[i][j]);
+    }
+    D->acc_reward[i] += e + b;
+    if (D->step_count > D->max_steps) D->acc_trunc[i] = 1;
+  }
+  for (int i = 0; i < A; ++i) { /* :665-680 */
+    if (D->health[i] <= 1e-3) { D->acc_term[i] = 1; D->info_bits[i] |= 1; }
+    if (Ll[i]->contact_step) { D->acc_term[i] = 1; D->acc_reward[i] = -1000.0; D->health[i] = 0.0; D->info_bits[i] |= 2; }
+    if (dist_origin[i] > D->dome) { D->acc_term[i] = 1; D->acc_reward[i] = -1000.0; D->health[i] = 0.0; D->info_bits[i] |= 4; }
+  }
+  /* :682-690 team_wins[team] = (healths[other team] <= 0) & any(healths[team] > 0): an ELEMENT-WISE assignment -- member k of
+   * a team "wins" when member k of the other team is out and someone of its own team is still up */
+  int any_up[2] = {0, 0};
+  for (int i = 0; i < A; ++i) any_up[df_team(D, i)] |= D->health[i] > 0.0;
+  for (int i = 0; i < A; ++i) {
+    const int t = df_team(D, i), k = i - t * D->team_size, opp = (1 - t) * D->team_size + k;
+    if (D->health[opp] <= 0.0 && any_up[t]) { D->acc_term[i] = 1; D->acc_reward[i] = 300.0; D->info_bits[i] |= 8; }
+  }
+}
+
+int orc_sizeof_dogfight(void) { return (int)sizeof(orc_dogfight); }
+
+void orc_dogfight_reset(const orc_params* const* Pl, orc_lane* const* Ll, orc_dogfight* D, uint64_t lane_id0, const double* const* xi_reset) {
+  const int A = D->A;
+  for (int i = 0; i < A; ++i) {
+    const uint32_t ctr = Ll[i]->rng_ctr;
+    orc_aviary_reset(Pl[i], Ll[i], lane_id0 + (uint64_t)i);
+    Ll[i]->rng_ctr = ctr;
+    orc_set_mode(Pl[i], Ll[i], Pl[i]->flight_mode); /* end_reset: set_mode(0) (ma_fixedwing_base_env.py:229) */
+    Ll[i]->world_contact = 0; Ll[i]->peer_contact = 0;
+  }
+  D->step_count = 0;
+  memset(D->cur_dist, 0, sizeof(D->cur_dist)); memset(D->cur_ang, 0, sizeof(D->cur_ang));
+  memset(D->prev_dist, 0, sizeof(D->prev_dist)); memset(D->prev_ang, 0, sizeof(D->prev_ang));
+  memset(D->cur_hit, 0, sizeof(D->cur_hit)); memset(D->in_range, 0, sizeof(D->in_range)); memset(D->chasing, 0, sizeof(D->chasing));
+  for (int i = 0; i < A; ++i) {
+    D->alive[i] = 1; D->health[i] = 1.0; D->received_hits[i] = 0; D->inactive[i] = 0;
+    D->acc_reward[i] = 0.0; D->acc_term[i] = 0; D->acc_trunc[i] = 0; D->info_bits[i] = 0;
+    D->reward[i] = 0.0; D->terminated[i] = 0; D->truncated[i] = 0;
+    /* current_actions / past_actions are created in __init__ and survive resets (ma_fixedwing_base_env.py:131-146) */
+  }
+  const int tpc = Pl[0]->world.ticks_per_control;
+  const double* xs[ORC_DF_MAX];
+  for (int s = 0; s < Pl[0]->settle_steps; ++s) { /* :232-233 */
+    for (int i = 0; i < A; ++i) xs[i] = (xi_reset && xi_reset[i]) ? xi_reset[i] + s * tpc : 0;
+    orc_world_aviary_step(Pl, Ll, A, xi_reset ? xs : 0, (uint32_t)(s * tpc), 1);
+  }
+  dogfight_update_states(Pl, Ll, D); /* :234; whatever it accumulates is popped by the first step */
+  for (int i = 0; i < A; ++i) Ll[i]->rng_ctr += 1;
+}
+
+void orc_dogfight_step(const orc_params* const* Pl, orc_lane* const* Ll, orc_dogfight* D, const double* actions, const double* const* xi) {
+  const int A = D->A;
+  for (int i = 0; i < A; ++i) { /* ma_fixedwing_base_env.py:289-302 */
+    for (int k = 0; k < 4; ++k) {
+      D->past_action[i][k] = D->action[i][k];
+      D->action[i][k] = D->alive[i] ? actions[4 * i + k] : 0.0;
+      Ll[i]->setpoint[k] = D->action[i][k];
+    }
+    Ll[i]->setpoint[3] = D->action[i][3] / 2.0 + 0.5;
+  }
+  const int tpc = Pl[0]->world.ticks_per_control;
+  const double* xs[ORC_DF_MAX];
+  for (int s = 0; s < D->env_step_ratio; ++s) { /* :305-307 */
+    for (int i = 0; i < A; ++i) xs[i] = (xi && xi[i]) ? xi[i] + s * tpc : 0;
+    orc_world_aviary_step(Pl, Ll, A, xi ? xs : 0, (uint32_t)(s * tpc), 0);
+    dogfight_update_states(Pl, Ll, D);
+  }
+  for (int i = 0; i < A; ++i) { /* :316-330, pop_term_trunc_rew_info_by_id (dogfight :754-771) */
+    D->reward[i] = 0.0; D->terminated[i] = 0; D->truncated[i] = 0;
+    if (D->alive[i]) {
+      D->reward[i] = D->acc_reward[i]; D->acc_reward[i] = 0.0;
+      D->terminated[i] = D->acc_term[i]; D->truncated[i] = D->acc_trunc[i];
+      if (D->terminated[i] || D->truncated[i]) D->alive[i] = 0;
+    }
+    Ll[i]->rng_ctr += 1;
+  }
+  D->step_count += 1;
+}
+
 /* ------------------------------------------------------------------ batch level */
 void orc_env_reset_batch(const orc_params* P, orc_lane* L, int n, uint64_t lane0, const uint8_t* mask,
                          const double* xi_reset, const double* u_targets) {

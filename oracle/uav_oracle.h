@@ -218,6 +218,40 @@ void orc_params_fixedwing(orc_params* P);
 void orc_params_primitive_drone(orc_params* P);
 void orc_params_rocket(orc_params* P);
 void orc_params_acrowing(orc_params* P);
+/* MAFixedwingDogfightEnv (pz_envs/fixedwing_envs/ma_fixedwing_dogfight_env.py): env-level state of ONE world of A = 2 team_size
+ * aircraft; the aircraft themselves are A orc_lane (stepped together by orc_world_aviary_step). */
+#define ORC_DF_MAX 8
+typedef struct {
+  /* constants (:42-60) */
+  int A, team_size;
+  double damage_per_hit, lethal_distance, lethal_angle, aggressiveness, cooperativeness;
+  int sparse_reward;
+  double dome;
+  int max_steps, env_step_ratio;
+  /* state */
+  int step_count;
+  int alive[ORC_DF_MAX];          /* still in self.agents */
+  double health[ORC_DF_MAX];      /* float32 in the reference */
+  int received_hits[ORC_DF_MAX];
+  int inactive[ORC_DF_MAX];       /* dead, on the ground and at rest: dropped from the others' observations (:505-510) */
+  double cur_dist[ORC_DF_MAX][ORC_DF_MAX], cur_ang[ORC_DF_MAX][ORC_DF_MAX];
+  double prev_dist[ORC_DF_MAX][ORC_DF_MAX], prev_ang[ORC_DF_MAX][ORC_DF_MAX];
+  int cur_hit[ORC_DF_MAX][ORC_DF_MAX], in_range[ORC_DF_MAX][ORC_DF_MAX], chasing[ORC_DF_MAX][ORC_DF_MAX];
+  double other_att[ORC_DF_MAX][ORC_DF_MAX][12];
+  double acc_reward[ORC_DF_MAX];  /* accumulated_rewards / _terminations / _truncations / infos (:651-722) */
+  int acc_term[ORC_DF_MAX], acc_trunc[ORC_DF_MAX];
+  int info_bits[ORC_DF_MAX];      /* 1 dead, 2 collision, 4 out_of_bounds, 8 team_win (sticky over the episode) */
+  double action[ORC_DF_MAX][4], past_action[ORC_DF_MAX][4];
+  double obs[ORC_DF_MAX][23 + (ORC_DF_MAX - 1) * 14];
+  /* popped by the last step for the agents that were alive */
+  double reward[ORC_DF_MAX];
+  int terminated[ORC_DF_MAX], truncated[ORC_DF_MAX];
+} orc_dogfight;
+int orc_sizeof_dogfight(void);
+void orc_dogfight_spawn(int team_size, double min_radius, double max_radius, const double* u, double* pos, double* rpy, double* vel);
+void orc_dogfight_reset(const orc_params* const* Pl, orc_lane* const* Ll, orc_dogfight* D, uint64_t lane_id0, const double* const* xi_reset);
+void orc_dogfight_step(const orc_params* const* Pl, orc_lane* const* Ll, orc_dogfight* D, const double* actions, const double* const* xi);
+
 void orc_task_hover(orc_params* P);
 void orc_task_quadx_waypoints(orc_params* P);
 void orc_task_fixedwing_waypoints(orc_params* P);

@@ -318,8 +318,8 @@ def build_params(
     P.contact_response = int(task == "none") if W["contact_response"] is None else int(bool(W["contact_response"]))
     P.contact_restitution, P.contact_friction, P.contact_erp = W["contact_restitution"], W["contact_friction"], W["contact_erp"]
     P.contact_iters = int(W["contact_iters"])
-    P.contact_margin = W["contact_margin"] * W["world_scale"]
-    P.contact_slop = W["contact_slop"] * W["world_scale"]
+    P.contact_margin = W["contact_margin"]  # (lengths of the contact model itself: not scaled with the world, as in
+    P.contact_slop = W["contact_slop"]      #  oracle/fake_bullet.py -- globalScaling scales the plane's geometry only)
     P.settle_steps = 10  # gym_envs/quadx_envs/quadx_base_env.py:209
 
     if vehicle == "quadx":

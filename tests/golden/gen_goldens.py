@@ -520,6 +520,110 @@ def gen_ma_hover_shared():
         fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
 
 
+def gen_dogfight():
+    """MAFixedwingDogfightEnv (pz_envs/fixedwing_envs/ma_fixedwing_dogfight_env.py, ma_fixedwing_base_env.py): two teams of
+    Acrowing aircraft in ONE world (world_scale 5), spawned on a circle flying outwards at 20 m/s, observing each other in
+    their own body frames, scoring hits inside a cone of fire. Two recordings of the reference's env on fake_bullet:
+      * `env_dogfight_default`: the default parameters, random actions (no one gets a shot in: observation layout, the
+        closing / boundary rewards, the accumulate-then-pop reward protocol, truncation);
+      * `env_dogfight_engage`: a wide cone of fire, long range and heavy damage with spawn poses that put every aircraft in
+        an opponent's sights (hits, health, deaths, the element-wise team-win override, culling of finished agents);
+      * `env_dogfight_crash`: a small flight dome and one aircraft diving from low altitude: the collision and out-of-bounds
+        overrides (-1000, health 0), aircraft that keep flying with zero commands after they were culled, and the `inactive`
+        filter of the observation (a dead aircraft at rest on the ground disappears from the others' observations).
+    Start poses of the last two are injected through `_get_start_pos_orn`."""
+    from oracle import fake_bullet
+    from PyFlyt.pz_envs.fixedwing_envs.ma_fixedwing_dogfight_env import MAFixedwingDogfightEnv
+
+    made = []
+    orig = np.random.default_rng
+
+    def recording_default_rng(seed=None):
+        r = ref_stubs.RecordingRNG(orig(seed))
+        made.append(r)
+        return r
+
+    np.random.default_rng = recording_default_rng
+    fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
+    try:
+        def run(name, n_steps, policy, seed, spawn=None, **kw):
+            env = MAFixedwingDogfightEnv(**kw)
+            if spawn is not None:
+                env._get_start_pos_orn = lambda seed_: (spawn[0].copy(), spawn[1].copy())
+            A = env.num_possible_agents
+            D = env.observation_space(None).shape[0]
+            n0 = len(made)
+            obs, infos = env.reset(seed=seed)
+            rngs = made[n0:]  # the Aviary's Generator, shared by its drones (aviary.py:258-262)
+            rec = dict(action=[], obs=[], reward=[], term=[], trunc=[], alive=[], health=[], received_hits=[], xi=[], info_bits=[])
+
+            def drain():
+                # motor noise: one N(0,1) per aircraft per physics tick (motors.py:188, one motor), drawn drone by drone
+                # inside each tick (aviary.py:505-508) -> [ticks, A]
+                cols = [c for c in (r.drain("normal") for r in rngs) if c.size]
+                assert len(cols) == 1, [c.size for c in cols]
+                return cols[0].reshape(-1, A)
+
+            reset_xi = drain()
+            reset_obs = np.stack([obs[a] for a in env.possible_agents])
+            prng = orig(seed + 1000)
+            for k in range(n_steps):
+                if len(env.agents) == 0:
+                    break
+                alive = np.array([a in env.agents for a in env.possible_agents])
+                acts = {a: policy(k, env.agent_name_mapping[a], prng) for a in env.agents}
+                obs, rew, term, trunc, infos = env.step(acts)
+                Aa = np.zeros((A, 4)); Oo = np.full((A, D), np.nan); R = np.full(A, np.nan)
+                T = np.zeros(A, bool); U = np.zeros(A, bool); B = np.zeros(A, np.int32)
+                for i, a in enumerate(env.possible_agents):
+                    if a in acts:
+                        Aa[i] = acts[a]; Oo[i] = obs[a]; R[i] = rew[a]; T[i] = term[a]; U[i] = trunc[a]
+                        inf = infos[a]
+                        B[i] = (1 * bool(inf.get("dead"))) | (2 * bool(inf.get("collision"))) | (4 * bool(inf.get("out_of_bounds"))) | (8 * bool(inf.get("team_win")))
+                rec["action"].append(Aa); rec["obs"].append(Oo); rec["reward"].append(R); rec["term"].append(T); rec["trunc"].append(U)
+                rec["alive"].append(alive); rec["health"].append(env.healths.copy()); rec["received_hits"].append(env.received_hits.copy())
+                rec["info_bits"].append(B)
+                rec["xi"].append(drain())
+            save(name, start_pos=env.start_pos, start_orn=env.start_orn, reset_obs=reset_obs, reset_xi=reset_xi,
+                 team_size=env.team_size, max_steps=env.max_steps, env_step_ratio=env.env_step_ratio, dome=env.flight_dome_size,
+                 damage_per_hit=env.damage_per_hit, lethal_distance=env.lethal_distance, lethal_angle=env.lethal_angle,
+                 aggressiveness=env.aggressiveness, cooperativeness=env.cooperativeness, sparse_reward=env.sparse_reward,
+                 **{k: np.array(v) for k, v in rec.items()})
+            return rec
+
+        run("env_dogfight_default", 80, lambda k, i, g: g.uniform(-1.0, 1.0, size=4), seed=3, max_duration_seconds=2.5)
+
+        # four aircraft 40 m up: 0 chases 2 from behind, 3 chases 1; a gentle random wobble on top of level flight
+        pos = np.array([[0.0, 0.0, 40.0], [60.0, 35.0, 42.0], [25.0, 1.0, 40.5], [35.0, 34.0, 41.5]])
+        orn = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.02], [0.0, 0.0, 0.03]])
+
+        def chase(k, i, g):
+            a = np.array([0.0, 0.0, 0.0, 0.6]) + g.uniform(-0.05, 0.05, size=4)
+            if i == 1 and k > 25:
+                a[1] = -1.0  # full pitch down: into the ground
+            return a
+
+        rec = run("env_dogfight_engage", 200, chase, seed=5, spawn=(pos, orn), damage_per_hit=0.02, lethal_distance=40.0,
+                  lethal_angle_radians=0.25, max_duration_seconds=20.0)
+        print("engage: hits", np.array(rec["received_hits"])[-1], "health", np.array(rec["health"])[-1], "bits", np.bitwise_or.reduce(np.array(rec["info_bits"]), axis=0))
+
+        pos = np.array([[10.0, 0.0, 30.0], [0.0, 20.0, 3.0], [-30.0, 0.0, 35.0], [0.0, -370.0, 30.0]])
+        orn = np.array([[0.0, 0.0, 0.0], [0.0, 0.6, np.pi / 2], [0.0, 0.0, np.pi], [0.0, 0.0, -np.pi / 2]])
+
+        def crash(k, i, g):
+            a = np.array([0.0, 0.02, 0.0, 0.5]) + g.uniform(-0.1, 0.1, size=4)
+            if i == 1:
+                a[1], a[3] = -1.0, -1.0  # nose down, throttle closed
+            return a
+
+        rec = run("env_dogfight_crash", 260, crash, seed=7, spawn=(pos, orn), flight_dome_size=400.0, max_duration_seconds=8.0)
+        print("crash: steps", len(rec["action"]), "health", np.array(rec["health"])[-1], "bits", np.bitwise_or.reduce(np.array(rec["info_bits"]), axis=0),
+              "others rows seen", sorted(set(int((~np.isnan(o) & (o != 0)).sum()) for o in np.array(rec["obs"]).reshape(-1, 65))))
+    finally:
+        np.random.default_rng = orig
+        fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected groups only: python gen_goldens.py wind
         for name in sys.argv[1:]:
@@ -534,6 +638,7 @@ if __name__ == "__main__":
     gen_landing()
     gen_ma_hover()
     gen_ma_hover_shared()
+    gen_dogfight()
     gen_wind()
     gen_primitive()
     gen_rocket()

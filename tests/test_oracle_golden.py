@@ -402,3 +402,56 @@ def test_ma_quadx_hover_shared_world_trajectory(golden_dir):
     for k in range(k_hit + 1):
         outs = [w.step(g["action"][k][i:i + 1], xi=g["xi"][k].T[i:i + 1]) for i, w in enumerate(Ws)]
     assert not outs[0][2][0] and not outs[1][2][0]  # alone, agents 0 and 1 do not terminate at the step of the hit
+
+
+@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash"])
+def test_dogfight_trajectory(golden_dir, name):
+    """MAFixedwingDogfightEnv (ma_fixedwing_dogfight_env.py) recorded from the reference's env on fake_bullet, replayed through
+    orc_dogfight_*: observation (self + the others in the own body frame, inactive aircraft dropped, zero padded), the
+    accumulate-then-pop rewards (fp32 in the reference: 1e-6 relative), health / hits, the collision / out-of-bounds / element-wise
+    team-win overrides, culling, aircraft that fly on with zero commands after they were culled."""
+    g = load(golden_dir, name)
+    W = O.OracleDogfight(g["start_pos"], g["start_orn"], noise_mode=O.NOISE_INJECT, team_size=int(g["team_size"]),
+                         damage_per_hit=float(g["damage_per_hit"]), lethal_distance=float(g["lethal_distance"]), lethal_angle=float(g["lethal_angle"]),
+                         aggressiveness=float(g["aggressiveness"]), cooperativeness=float(g["cooperativeness"]), sparse_reward=bool(g["sparse_reward"]),
+                         dome=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0)
+    np.testing.assert_allclose(W.reset(xi_reset=g["reset_xi"].T), g["reset_obs"], atol=TOL)
+    bits = np.zeros(W.A, dtype=int)
+    for k in range(len(g["action"])):
+        alive = g["alive"][k]
+        assert (W.alive == alive).all(), k
+        obs, rew, term, trunc = W.step(g["action"][k], xi=g["xi"][k].T)
+        for i in range(W.A):
+            if alive[i]:
+                np.testing.assert_allclose(obs[i], g["obs"][k][i], atol=1e-8, err_msg=f"step {k} agent {i}")
+                assert abs(rew[i] - g["reward"][k][i]) <= 1e-6 * max(1.0, abs(g["reward"][k][i])), (k, i, rew[i], g["reward"][k][i])
+                assert bool(term[i]) == bool(g["term"][k][i]) and bool(trunc[i]) == bool(g["trunc"][k][i]), (k, i)
+                assert (int(W.D.info_bits[i]) & int(g["info_bits"][k][i])) == int(g["info_bits"][k][i]), (k, i)
+                bits[i] |= int(g["info_bits"][k][i])
+        np.testing.assert_allclose(W.health, g["health"][k], atol=1e-6)
+        assert (np.array(W.D.received_hits[:W.A]) == g["received_hits"][k]).all()
+    if name == "env_dogfight_engage":
+        assert g["received_hits"][-1].sum() > 50 and (bits & 1).any() and (bits & 8).any()  # hits, deaths, team wins
+    if name == "env_dogfight_crash":
+        assert (bits & 4).any() and g["trunc"].any()  # out of bounds, truncation
+        assert any(W.D.inactive[:W.A])  # a dead aircraft at rest on the ground has dropped out of the observations
+
+
+def test_dogfight_spawn_restatement():
+    """orc_dogfight_spawn against the reference's _get_start_pos_orn arithmetic (ma_fixedwing_dogfight_env.py:176-213), fed the
+    draws of the same np.random.RandomState."""
+    team, lo, hi, seed = 2, 10.0, 50.0, 11
+    rs = np.random.RandomState(seed=seed)
+    u0 = rs.uniform(0.0, 2 * np.pi) / (2 * np.pi)
+    ur = (rs.uniform(low=lo, high=hi, size=(2 * team,)) - lo) / (hi - lo)
+    uh = (rs.uniform(low=lo, high=hi, size=(2 * team,)) - lo) / (hi - lo)
+    uy = rs.random(2 * team)
+    pos, rpy, vel = O.dogfight_spawn(team, lo, hi, np.concatenate([[u0], ur, uh, uy]))
+    rs = np.random.RandomState(seed=seed)  # the reference's lines, verbatim arithmetic
+    start_radian = np.pi / team * np.arange(team * 2) + rs.uniform(0.0, 2 * np.pi)
+    start_radius = rs.uniform(low=lo, high=hi, size=(team * 2,))
+    start_height = rs.uniform(low=lo, high=hi, size=(team * 2,))
+    yaw = start_radian + rs.random(2 * team) * np.pi / 8.0
+    np.testing.assert_allclose(pos, np.stack([start_radius * np.cos(start_radian), start_radius * np.sin(start_radian), start_height], axis=1), atol=1e-12)
+    np.testing.assert_allclose(rpy[:, 2], yaw, atol=1e-12)
+    np.testing.assert_allclose(vel, 20.0 * np.stack([np.cos(yaw), np.sin(yaw), 0 * yaw], axis=1), atol=1e-12)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 6
+#define PF_ABI_VERSION 7
 #define PF_MAX_TARGETS 8
 #define PF_MAX_BOXES 12
 #define PF_MAX_SURF 5
@@ -37,7 +37,8 @@ extern "C" {
 
 enum pf_status { PF_OK = 0, PF_ERR_ARG = -1, PF_ERR_UNSUPPORTED = -2, PF_ERR_NO_DEVICE = -3 };
 enum pf_vehicle { PF_QUADX = 0, PF_FIXEDWING = 1, PF_ROCKET = 2 /* Aviary-level entry points only */ };
-enum pf_task { PF_TASK_NONE = 0, PF_TASK_HOVER = 1, PF_TASK_WAYPOINTS = 2, PF_TASK_MA_HOVER = 3 };
+enum pf_task { PF_TASK_NONE = 0, PF_TASK_HOVER = 1, PF_TASK_WAYPOINTS = 2, PF_TASK_MA_HOVER = 3,
+               PF_TASK_DOGFIGHT = 4 /* MAFixedwingDogfightEnv (pz_envs/fixedwing_envs/ma_fixedwing_dogfight_env.py), fixedwing only */ };
 enum pf_noise { PF_NOISE_OFF = 0, PF_NOISE_INJECT = 1, PF_NOISE_PHILOX = 2 };
 enum pf_autoreset { PF_AUTORESET_OFF = 0, PF_AUTORESET_NEXT_STEP = 1, PF_AUTORESET_SAME_STEP = 2 };
 
@@ -171,6 +172,18 @@ typedef struct pf_params {
    * point anywhere in the world switches off every drone's rotational drag (quadx.py:509). Detection only between drones
    * (box colliders; no drone-drone impulses). A must divide 64 and the lane count. */
   int32_t agents_per_world;
+  /* PF_TASK_DOGFIGHT (ma_fixedwing_dogfight_env.py:42-60): two teams of df_team_size aircraft in one shared world,
+   * agents_per_world = 2 df_team_size <= 8 adjacent lanes, lanes [0, team) of a world one team, the rest the other.
+   * df_sample_spawn: 1 = every reset draws the world's spawn circle (_get_start_pos_orn :176-213) from the counter RNG keyed
+   * by the world's first lane; 0 = the spawn pose is read from the state's spawn groups (pos, rpy). The
+   * spawn velocity is 20 m/s along the nose (:216-222). Observation = [attitude 12, surfaces + throttle 6, health, past
+   * action 4] + 14 per other ACTIVE aircraft in index order (its attitude in the own body frame 12, its health, same-team
+   * flag), zero padded to 23 + 14 (A - 1) (:519-549, :724-752). pf_env_step pops reward / terminated / truncated for the
+   * agents still in the episode (PettingZoo parallel API: finished agents are culled, their aircraft fly on with zero
+   * commands, ma_fixedwing_base_env.py:289-330); pf_params.autoreset must be PF_AUTORESET_OFF. */
+  int32_t df_team_size, df_sample_spawn;
+  float df_spawn_min_radius, df_spawn_max_radius;
+  float df_damage_per_hit, df_lethal_distance, df_lethal_angle, df_aggressiveness, df_cooperativeness;
   pf_rocket rocket;
 } pf_params;
 

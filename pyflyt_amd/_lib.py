@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PF_LIB_PATH") or os.path.join(_HERE, "libpyflyt_amd.so")
 
 QUADX, FIXEDWING, ROCKET = 0, 1, 2
-TASK_NONE, TASK_HOVER, TASK_WAYPOINTS, TASK_MA_HOVER = 0, 1, 2, 3
+TASK_NONE, TASK_HOVER, TASK_WAYPOINTS, TASK_MA_HOVER, TASK_DOGFIGHT = 0, 1, 2, 3, 4
 NOISE_OFF, NOISE_INJECT, NOISE_PHILOX = 0, 1, 2
 AUTORESET_OFF, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
 F_TERMINATED, F_TRUNCATED, F_CONTACT, F_INFO_COLLISION, F_INFO_OOB, F_INFO_COMPLETE, F_NONFINITE = 1, 2, 4, 8, 16, 32, 64

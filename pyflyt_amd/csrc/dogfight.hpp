@@ -1,0 +1,379 @@
+// dogfight.hpp -- MAFixedwingDogfightEnv (pz_envs/fixedwing_envs/ma_fixedwing_dogfight_env.py,
+// ma_fixedwing_base_env.py) as one fused launch per env step.
+//
+// One lane = one Acrowing aircraft (the generic Fixedwing vehicle of uav_vehicles.hpp with the acrowing parameter block);
+// the A = 2 team_size <= 8 aircraft of a world are adjacent lanes of one wavefront, so everything the reference couples
+// them through goes through LDS:
+//   * physics: pose + contact bit before every tick (drone-drone box tests, the world-global contact gate -- world_exchange,
+//     shared with the PettingZoo QuadX task);
+//   * the env's update_states() after every Aviary step (:305-307 of the base env): each lane publishes its attitude (nose
+//     position shifted to the body centre, :318), computes ITS ROW of the n x n engagement matrices (distance, angle, in
+//     range / chasing / hit), publishes the row so that the others can read their column (hits received, the transposed
+//     reward terms), then its health, then -- after the collision / out-of-bounds overrides -- its health again for the
+//     element-wise team-win rule (:682-690).
+// Arithmetic differences from the reference, both inside the fp32 tolerance of the parity tests: the engagement angle is
+// atan2(|sep x fwd|, sep . fwd) instead of arccos(sep . fwd / |sep|) (the same angle, but arccos loses half the digits near
+// 0 -- exactly where the cone of fire is); the diagonal of the matrices is never formed (the reference fills it with NaN
+// and zeroes it afterwards).
+//
+// State groups (float4 each, [group][lane]): 0-5 the Fixedwing vehicle's (body, surfaces, ints); 6 (health, accumulated
+// reward, received hits, dogfight flags); 7 current action; 8 past action; 9-10 this lane's row of current_distances;
+// 11-12 its row of current_angles; 13 (spawn x, y, z, roll); 14 (spawn pitch, yaw, -, -).
+#pragma once
+#include "../../include/pyflyt_amd.h"
+#include "uav_device.hpp"
+#include "uav_vehicles.hpp"
+
+namespace pf {
+
+constexpr int kDfMaxAgents = 8;
+constexpr int kDfMaxObs = 23 + (kDfMaxAgents - 1) * 14;  // 121
+constexpr int kDfGroups = 15;
+enum {  // group 6, word 3
+  DF_ALIVE = 1,      // still in self.agents
+  DF_ACC_TERM = 2,   // accumulated_terminations / _truncations (sticky over the episode)
+  DF_ACC_TRUNC = 4,
+  DF_INACTIVE = 8,   // dead, on the ground and at rest (:505-510)
+  DF_INFO_DEAD = 16, DF_INFO_COLLISION = 32, DF_INFO_OOB = 64, DF_INFO_TEAM_WIN = 128
+};
+
+PF_DEV void lds_sync_wave() {  // one wave per workgroup: LDS traffic ordered, no s_barrier needed
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Shared world, before a physics tick: the A lanes of a world exchange pose and contact bit, test their collision boxes
+// against each other (15 axes, in the peer's frame, behind a bounding-sphere test) and OR the world's contact bits into the
+// gate of the rotational drag (quadx.py:509). wpose: 8 floats per lane of the wave.
+PF_DEV void world_exchange(Body& b, float* wpose, const int tid, const int A, const pf_params& P) {
+  const int wbase = (tid / A) * A, wlocal = tid - wbase;
+  float* me = wpose + tid * 8;
+  me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
+  me[7] = b.contact_now ? 1.0f : 0.0f;
+  lds_sync_wave();
+  bool world = false, peer = false;
+  for (int j = 1; j < A; ++j) {
+    const float* o = wpose + (wbase + (wlocal + j) % A) * 8;
+    world |= o[7] != 0.0f;
+    const v3 d{b.p.x - o[0], b.p.y - o[1], b.p.z - o[2]};
+    const float rr = 2.0f * P.bound_radius;
+    if (dot(d, d) <= rr * rr) {  // bounding spheres touch: the box tests, this drone's boxes in the peer's box frames
+      const m3 Rb = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
+      const m3& Ra = b.R;
+      const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
+                    Rb.m01 * Ra.m00 + Rb.m11 * Ra.m10 + Rb.m21 * Ra.m20, Rb.m01 * Ra.m01 + Rb.m11 * Ra.m11 + Rb.m21 * Ra.m21, Rb.m01 * Ra.m02 + Rb.m11 * Ra.m12 + Rb.m21 * Ra.m22,
+                    Rb.m02 * Ra.m00 + Rb.m12 * Ra.m10 + Rb.m22 * Ra.m20, Rb.m02 * Ra.m01 + Rb.m12 * Ra.m11 + Rb.m22 * Ra.m21, Rb.m02 * Ra.m02 + Rb.m12 * Ra.m12 + Rb.m22 * Ra.m22};
+      for (int k = 0; k < P.n_boxes; ++k) {
+        for (int l = 0; l < P.n_boxes; ++l) {
+          const v3 ca = d + mul(Ra, v3{P.boxes[k].c[0], P.boxes[k].c[1], P.boxes[k].c[2]}) - mul(Rb, v3{P.boxes[l].c[0], P.boxes[l].c[1], P.boxes[l].c[2]});
+          peer |= box_overlaps_aabb(mulT(Rb, ca), Rrel, P.boxes[k].h, v3{0.f, 0.f, 0.f}, P.boxes[l].h);
+        }
+      }
+    }
+  }
+  b.world_contact = world;
+  b.peer_contact = peer;
+  lds_sync_wave();
+}
+
+// per-lane exchange record of update_states(): 0-2 w_b, 3-5 rpy, 6-8 v_b, 9-11 body-centre position, 12-14 ground velocity,
+// 15 health after this update's hits, 16 inactive, 17 health after the overrides, 18 hit bits of this lane's row (as int),
+// 19 unused, 20-27 this lane's row of the masked 1 / (angle + 0.1)
+constexpr int kDfRec = 28;
+
+__global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, const pf_buffers B, const int n, const uint64_t lane0,
+                                                          const int op, const uint8_t* mask, const pf_params* __restrict__ Pdev) {
+  __shared__ float tile[64 * kDfMaxObs];
+  __shared__ float ktab[Fixedwing::TABLE_FLOATS];
+  __shared__ float wpose[64 * 8];
+  __shared__ float rec[64 * kDfRec];
+  static_assert(64 * kDfMaxObs >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
+  const int tid = threadIdx.x;
+  Fixedwing::fill_table(ktab, Pdev, tid);
+  __syncthreads();
+  const int wave_base = blockIdx.x * 64;
+  const int lane = wave_base + tid;
+  const bool valid = lane < n;
+  const size_t li = valid ? lane : n - 1;
+  const size_t N = (size_t)n;
+  const float4* Sin = reinterpret_cast<const float4*>(B.state);
+  float4* Sout = reinterpret_cast<float4*>(B.state);
+  const int A = P.agents_per_world, T = P.df_team_size;
+  const int wbase = (tid / A) * A, wlocal = tid - wbase;
+  const int my_team = wlocal >= T ? 1 : 0;
+  const int D = 23 + (A - 1) * 14;
+
+  Fixedwing V;
+  V.b.pdev = Pdev;
+  V.b.cws = (lds_fptr)tile;
+  V.bind(ktab);
+  float nd_unused;
+  int4 ints;
+  V.load(Sin, N, li, 0, nd_unused, ints);
+  int step_count = ints.x, flags = ints.y;
+  uint32_t rng_ctr = (uint32_t)ints.z;
+  const float4 g6 = Sin[6 * N + li];
+  float health = g6.x, acc = g6.y;
+  int received_hits = __float_as_int(g6.z), df = __float_as_int(g6.w);
+  float4 cur_a4 = Sin[7 * N + li], past_a4 = Sin[8 * N + li];
+  float cur_d[kDfMaxAgents], cur_ang[kDfMaxAgents];
+  {
+    const float4 a = Sin[9 * N + li], b = Sin[10 * N + li], c = Sin[11 * N + li], d = Sin[12 * N + li];
+    cur_d[0] = a.x; cur_d[1] = a.y; cur_d[2] = a.z; cur_d[3] = a.w; cur_d[4] = b.x; cur_d[5] = b.y; cur_d[6] = b.z; cur_d[7] = b.w;
+    cur_ang[0] = c.x; cur_ang[1] = c.y; cur_ang[2] = c.z; cur_ang[3] = c.w; cur_ang[4] = d.x; cur_ang[5] = d.y; cur_ang[6] = d.z; cur_ang[7] = d.w;
+  }
+  float4 sp_a = Sin[13 * N + li], sp_b = Sin[14 * N + li];
+
+  Noise nz;
+  nz.mode = P.noise_mode; nz.n = n; nz.lane = (int)li;
+  nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
+  nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
+
+  const bool do_reset = op == 1 && ((mask == nullptr) || (mask[li] != 0));
+  const bool active = valid && (op == 0 || do_reset);
+  float sp[6] = {0, 0, 0, 0, 0, 0};
+
+  // One Aviary.step of the shared world: control + ticks_per_control x (exchange, tick)
+  auto world_aviary_step = [&](int flat_base) {
+    V.b.contact_step = false;
+    V.template control<0>(P, sp);
+    for (int t = 0; t < P.ticks_per_control; ++t) {
+      world_exchange(V.b, wpose, tid, A, P);
+      V.tick(P, nz.get(flat_base + t));
+    }
+    V.b.peer_contact = false;
+    V.b.rpy = euler_from_quat_fast(V.b.q);
+  };
+
+  // update_states(): _compute_observation (:466-549) + _compute_term_trunc_rew_info (:651-722)
+  auto update_states = [&](const bool write_obs) {
+    float* me = rec + tid * kDfRec;
+    // ---- own attitude, rotation (rz ry rx) and nose direction (ma_fixedwing_base_env.py:336-405)
+    float sr, cr, spp, cp, sy, cy;
+    sincosf(V.b.rpy.x, &sr, &cr); sincosf(V.b.rpy.y, &spp, &cp); sincosf(V.b.rpy.z, &sy, &cy);
+    const float R00 = cy * cp, R01 = cy * spp * sr - sy * cr, R02 = cy * spp * cr + sy * sr;
+    const float R10 = sy * cp, R11 = sy * spp * sr + cy * cr, R12 = sy * spp * cr - cy * sr;
+    const float R20 = -spp, R21 = cp * sr, R22 = cp * cr;
+    const v3 fwd{cy * cp, sy * cp, -spp};
+    const v3 pc{fmaf(-0.35f, fwd.x, V.b.p.x), fmaf(-0.35f, fwd.y, V.b.p.y), fmaf(-0.35f, fwd.z, V.b.p.z)};  // :318
+    const v3 vb = V.b.vb, wb = V.b.wb;
+    const v3 gv{R00 * vb.x + R01 * vb.y + R02 * vb.z, R10 * vb.x + R11 * vb.y + R12 * vb.z, R20 * vb.x + R21 * vb.y + R22 * vb.z};  // :365
+    me[0] = wb.x; me[1] = wb.y; me[2] = wb.z; me[3] = V.b.rpy.x; me[4] = V.b.rpy.y; me[5] = V.b.rpy.z;
+    me[6] = vb.x; me[7] = vb.y; me[8] = vb.z; me[9] = pc.x; me[10] = pc.y; me[11] = pc.z; me[12] = gv.x; me[13] = gv.y; me[14] = gv.z;
+    lds_sync_wave();
+    // ---- this lane's row of the engagement matrices (:313-344)
+    float prev_d[kDfMaxAgents], prev_ang[kDfMaxAgents], iaa[kDfMaxAgents];
+    int hit_bits = 0, inr_bits = 0, chase_bits = 0;
+#pragma unroll
+    for (int j = 0; j < kDfMaxAgents; ++j) {
+      prev_d[j] = cur_d[j]; prev_ang[j] = cur_ang[j]; iaa[j] = 0.0f;
+      if (j < A && j != wlocal) {
+        const float* o = rec + (wbase + j) * kDfRec;
+        const v3 sep{o[9] - pc.x, o[10] - pc.y, o[11] - pc.z};
+        const float dist = sqrtf(dot(sep, sep));
+        const v3 cx = cross(sep, fwd);
+        const float ang = atan2f(sqrtf(dot(cx, cx)), dot(sep, fwd));  // == arccos(sep . fwd / |sep|), well conditioned near 0
+        const bool in_range = dist < P.df_lethal_distance, chasing = ang < 0.5f * kPi;
+        const bool ff = (j >= T ? 1 : 0) != my_team;
+        cur_d[j] = dist; cur_ang[j] = ang;
+        if (in_range) inr_bits |= 1 << j;
+        if (chasing) chase_bits |= 1 << j;
+        if ((ang < P.df_lethal_angle) && in_range && chasing && ff) hit_bits |= 1 << j;
+        if (ff && in_range && chasing) iaa[j] = 1.0f / (ang + 0.1f);
+      } else if (j < A) {
+        cur_d[j] = 0.0f; cur_ang[j] = 0.0f;
+      }
+    }
+    me[18] = __int_as_float(hit_bits);
+#pragma unroll
+    for (int j = 0; j < kDfMaxAgents; ++j) me[20 + j] = iaa[j];
+    lds_sync_wave();
+    // ---- hits received, health (:499-503), inactive (:505-510)
+    int rec_hits = 0, team_hits = 0;
+    for (int j = 0; j < A; ++j) {
+      const int hb = __float_as_int(rec[(wbase + j) * kDfRec + 18]);
+      rec_hits += (hb >> wlocal) & 1;
+      if ((j >= T ? 1 : 0) == my_team) team_hits += __builtin_popcount(hb);
+    }
+    received_hits += rec_hits;
+    health = __builtin_fmaxf(fmaf(-P.df_damage_per_hit, (float)rec_hits, health), 0.0f);
+    const bool inactive = (health <= 0.0f) && (pc.z < 2.0f) && (sqrtf(dot(vb, vb)) < 0.1f);
+    df = inactive ? (df | DF_INACTIVE) : (df & ~DF_INACTIVE);
+    me[15] = health; me[16] = inactive ? 1.0f : 0.0f;
+    lds_sync_wave();
+    // ---- observation (:519-549, pop_obs_by_id :724-752): written on the last update of the call only
+    if (write_obs) {
+      float* row = tile + tid * D;
+      int k = 0;
+      row[k++] = wb.x; row[k++] = wb.y; row[k++] = wb.z;
+      row[k++] = V.b.rpy.x; row[k++] = V.b.rpy.y; row[k++] = V.b.rpy.z;
+      row[k++] = vb.x; row[k++] = vb.y; row[k++] = vb.z;
+      row[k++] = pc.x; row[k++] = pc.y; row[k++] = pc.z;
+      float aux[6];
+      V.aux(aux);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) row[k++] = aux[a];
+      row[k++] = health;
+      row[k++] = past_a4.x; row[k++] = past_a4.y; row[k++] = past_a4.z; row[k++] = past_a4.w;
+      for (int j = 0; j < A; ++j) {
+        if (j == wlocal) continue;
+        const float* o = rec + (wbase + j) * kDfRec;
+        if (o[16] != 0.0f) continue;  // inactive aircraft are dropped, the rest moves up (:523-526)
+        row[k++] = o[0]; row[k++] = o[1]; row[k++] = o[2];
+        row[k++] = o[3] - V.b.rpy.x; row[k++] = o[4] - V.b.rpy.y; row[k++] = o[5] - V.b.rpy.z;  // :357-359
+        // the other's ground velocity in the own body frame (gv_j @ R_i) minus the own body velocity (:368-375)
+        row[k++] = o[12] * R00 + o[13] * R10 + o[14] * R20 - vb.x;
+        row[k++] = o[12] * R01 + o[13] * R11 + o[14] * R21 - vb.y;
+        row[k++] = o[12] * R02 + o[13] * R12 + o[14] * R22 - vb.z;
+        const v3 sep{o[9] - pc.x, o[10] - pc.y, o[11] - pc.z};  // sep @ R_i (:378)
+        row[k++] = sep.x * R00 + sep.y * R10 + sep.z * R20;
+        row[k++] = sep.x * R01 + sep.y * R11 + sep.z * R21;
+        row[k++] = sep.x * R02 + sep.y * R12 + sep.z * R22;
+        row[k++] = o[15];
+        row[k++] = ((j >= T ? 1 : 0) == my_team) ? 1.0f : 0.0f;
+      }
+      for (; k < D; ++k) row[k] = 0.0f;
+    }
+    // ---- rewards (:551-649)
+    float e = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kDfMaxAgents; ++j) {
+      if (j < A && j != wlocal) {
+        const bool ff = (j >= T ? 1 : 0) != my_team;
+        const bool in_range = (inr_bits >> j) & 1, chasing = (chase_bits >> j) & 1;
+        const float* o = rec + (wbase + j) * kDfRec;
+        const int hb_j = __float_as_int(o[18]);
+        const float hit_ij = (float)((hit_bits >> j) & 1), hit_ji = (float)((hb_j >> wlocal) & 1);
+        if (!P.sparse_reward) {
+          const float dd = __builtin_fmaxf(prev_d[j] - cur_d[j], 0.0f);
+          if (!in_range && chasing && ff) e = fmaf(4.0f, dd, e);
+          float da = (in_range && ff) ? prev_ang[j] - cur_ang[j] : 0.0f;
+          da = da < 0.0f ? da * P.df_aggressiveness : da;
+          e = fmaf(30.0f, da, e);
+          e = fmaf(3.0f, iaa[j] - (1.0f - P.df_aggressiveness) * o[20 + wlocal], e);
+        }
+        e = fmaf(20.0f, hit_ij - (1.0f - P.df_aggressiveness) * hit_ji, e);
+      }
+    }
+    e = fmaf(P.df_cooperativeness, (float)team_hits, e);  // :609-617
+    const float dist_origin = sqrtf(dot(pc, pc));
+    float bnd = 0.0f;
+    if (!P.sparse_reward) {
+      bnd += tanhf(fmaf(0.1f, pc.z, -1.0f));
+      bnd -= tanhf(fmaf(0.0025f, dist_origin, -1.0f));
+#pragma unroll
+      for (int j = 0; j < kDfMaxAgents; ++j)
+        if (j < A && j != wlocal && cur_d[j] < 5.0f) bnd -= 10.0f * (5.0f - cur_d[j]);
+    }
+    acc += e + bnd;
+    if (step_count > P.max_steps) df |= DF_ACC_TRUNC;
+    if (health <= 1e-3f) df |= DF_ACC_TERM | DF_INFO_DEAD;
+    if (V.b.contact_step) { df |= DF_ACC_TERM | DF_INFO_COLLISION; acc = -1000.0f; health = 0.0f; }
+    if (dist_origin > P.dome) { df |= DF_ACC_TERM | DF_INFO_OOB; acc = -1000.0f; health = 0.0f; }
+    me[17] = health;
+    lds_sync_wave();
+    // ---- team wins (:682-690): element-wise -- member k of a team wins when member k of the other team is out and
+    // someone of its own team is still up
+    bool any_up = false;
+    for (int j = 0; j < A; ++j)
+      if ((j >= T ? 1 : 0) == my_team) any_up |= rec[(wbase + j) * kDfRec + 17] > 0.0f;
+    const int opp = (1 - my_team) * T + (wlocal - my_team * T);
+    if (rec[(wbase + opp) * kDfRec + 17] <= 0.0f && any_up) { df |= DF_ACC_TERM | DF_INFO_TEAM_WIN; acc = 300.0f; }
+    lds_sync_wave();
+  };
+
+  float out_reward = 0.0f;
+  bool out_term = false, out_trunc = false;
+  if (op == 1) {
+    // ---------------------------------------------------------------- reset (dogfight :215-322, base env :160-234)
+    if (do_reset) {
+      if (P.df_sample_spawn) {  // _get_start_pos_orn (:176-213): the world's draws, keyed by its first lane
+        Noise wz = nz;
+        wz.c0 = (uint32_t)(lane0 + li - (size_t)wlocal);
+        wz.begin_event(rng_ctr, 2u, nullptr);
+        const float u0 = wz.uniform(0, 2u), ur = wz.uniform(1 + wlocal, 2u), uh = wz.uniform(1 + A + wlocal, 2u), uy = wz.uniform(1 + 2 * A + wlocal, 2u);
+        const float rad = fmaf(kPi / (float)T, (float)wlocal, 2.0f * kPi * u0);
+        const float radius = fmaf(P.df_spawn_max_radius - P.df_spawn_min_radius, ur, P.df_spawn_min_radius);
+        const float height = fmaf(P.df_spawn_max_radius - P.df_spawn_min_radius, uh, P.df_spawn_min_radius);  // (sic: the radius bounds, :197-201)
+        float s, c;
+        sincosf(rad, &s, &c);
+        sp_a = float4{radius * c, radius * s, height, 0.0f};
+        sp_b = float4{0.0f, fmaf(uy, kPi / 8.0f, rad), 0.0f, 0.0f};
+      }
+      const v3 rpy0{sp_a.w, sp_b.x, sp_b.y};
+      const quat q0 = quat_from_euler(rpy0);
+      float sr, cr, spp, cp, sy, cy;
+      sincosf(rpy0.x, &sr, &cr); sincosf(rpy0.y, &spp, &cp); sincosf(rpy0.z, &sy, &cy);
+      const float pose[7] = {sp_a.x, sp_a.y, sp_a.z, q0.x, q0.y, q0.z, q0.w};
+      const float vel[3] = {20.0f * cy * cp, 20.0f * sy * cp, -20.0f * spp};  // :216-222
+      V.reset(P, pose, sp, vel);
+      step_count = 0; flags = 0;
+      health = 1.0f; acc = 0.0f; received_hits = 0; df = DF_ALIVE;
+#pragma unroll
+      for (int j = 0; j < kDfMaxAgents; ++j) { cur_d[j] = 0.0f; cur_ang[j] = 0.0f; }
+      nz.begin_event(rng_ctr, 1u, B.xi_reset);
+    }
+    // (whole worlds reset together -- checked by the host side -- so the lanes that exchange data through LDS always take this
+    //  branch together; there is one wave per workgroup and no s_barrier, lanes that are not being reset simply idle)
+    if (do_reset) {
+      for (int s = 0; s < P.settle_steps; ++s) world_aviary_step(s * P.ticks_per_control);  // ma_fixedwing_base_env.py:232-233
+      update_states(true);  // :234; whatever it accumulates is popped by the first step
+      rng_ctr += 1;
+    }
+  } else {
+    // ---------------------------------------------------------------- step (ma_fixedwing_base_env.py:272-334)
+    const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+    past_a4 = cur_a4;
+    cur_a4 = (df & DF_ALIVE) ? a : float4{0.f, 0.f, 0.f, 0.f};  // culled agents: zero commands (:293-297)
+    sp[0] = cur_a4.x; sp[1] = cur_a4.y; sp[2] = cur_a4.z; sp[3] = fmaf(cur_a4.w, 0.5f, 0.5f);  // :300-301
+    nz.begin_event(rng_ctr, 0u, B.xi);
+    for (int s = 0; s < P.env_step_ratio; ++s) {
+      world_aviary_step(s * P.ticks_per_control);
+      update_states(s == P.env_step_ratio - 1);
+    }
+    if (df & DF_ALIVE) {  // pop (:316-330; dogfight :754-771)
+      out_reward = acc; acc = 0.0f;
+      out_term = (df & DF_ACC_TERM) != 0; out_trunc = (df & DF_ACC_TRUNC) != 0;
+      if (out_term || out_trunc) df &= ~DF_ALIVE;
+    }
+    step_count += 1; rng_ctr += 1;
+    if (V.nonfinite() || !(__builtin_fabsf(health + acc) < INFINITY)) flags |= PF_F_NONFINITE;
+  }
+
+  // ---------------------------------------------------------------- outputs: obs tile first, state after
+  lds_sync_wave();
+  {
+    const bool wave_all = __all(active || !valid);
+    if (wave_all) {
+      const int rows = min(64, n - wave_base);
+      stream_tile(tile, B.obs + (size_t)wave_base * D, rows * D, tid);
+    } else if (active) {
+      float* g = B.obs + (size_t)lane * D;
+      const float* row = tile + tid * D;
+      for (int k = 0; k < D; ++k) g[k] = row[k];
+    }
+  }
+  if (active) {
+    flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT | PF_F_INFO_COLLISION | PF_F_INFO_OOB)) | (out_term ? PF_F_TERMINATED : 0) |
+            (out_trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0) | ((df & DF_INFO_COLLISION) ? PF_F_INFO_COLLISION : 0) |
+            ((df & DF_INFO_OOB) ? PF_F_INFO_OOB : 0);
+    V.store(Sout, N, li, 0, 0.0f, int4{step_count, flags, (int)rng_ctr, 0});
+    Sout[6 * N + li] = float4{health, acc, __int_as_float(received_hits), __int_as_float(df)};
+    Sout[7 * N + li] = cur_a4;
+    Sout[8 * N + li] = past_a4;
+    Sout[9 * N + li] = float4{cur_d[0], cur_d[1], cur_d[2], cur_d[3]};
+    Sout[10 * N + li] = float4{cur_d[4], cur_d[5], cur_d[6], cur_d[7]};
+    Sout[11 * N + li] = float4{cur_ang[0], cur_ang[1], cur_ang[2], cur_ang[3]};
+    Sout[12 * N + li] = float4{cur_ang[4], cur_ang[5], cur_ang[6], cur_ang[7]};
+    Sout[13 * N + li] = sp_a;
+    Sout[14 * N + li] = sp_b;
+    if (op == 0) {
+      B.reward[li] = out_reward;
+      B.terminated[li] = out_term ? 1 : 0;
+      B.truncated[li] = out_trunc ? 1 : 0;
+    }
+  }
+}
+
+}  // namespace pf

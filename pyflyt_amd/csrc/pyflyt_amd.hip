@@ -19,6 +19,7 @@
 #include "uav_vehicles.hpp"
 #include "quadx_fast.hpp"
 #include "fixedwing_fast.hpp"
+#include "dogfight.hpp"
 #include "rocket.hpp"
 
 namespace pf {
@@ -340,35 +341,8 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   auto world_aviary_step = [&](int flat_base) {
     V.b.contact_step = false;
     V.template control<MODE_T>(P, sp);
-    const int wbase = (tid / A) * A, wlocal = tid - wbase;
     for (int t = 0; t < P.ticks_per_control; ++t) {
-      float* me = wpose + tid * 8;
-      me[0] = V.b.p.x; me[1] = V.b.p.y; me[2] = V.b.p.z; me[3] = V.b.q.x; me[4] = V.b.q.y; me[5] = V.b.q.z; me[6] = V.b.q.w;
-      me[7] = V.b.contact_now ? 1.0f : 0.0f;
-      lds_sync();
-      bool world = false, peer = false;
-      for (int j = 1; j < A; ++j) {
-        const float* o = wpose + (wbase + (wlocal + j) % A) * 8;
-        world |= o[7] != 0.0f;
-        const v3 d{V.b.p.x - o[0], V.b.p.y - o[1], V.b.p.z - o[2]};
-        const float rr = 2.0f * P.bound_radius;
-        if (dot(d, d) <= rr * rr) {  // bounding spheres touch: the box tests, this drone's boxes in the peer's box frames
-          const m3 Rb = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
-          const m3& Ra = V.b.R;
-          const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
-                        Rb.m01 * Ra.m00 + Rb.m11 * Ra.m10 + Rb.m21 * Ra.m20, Rb.m01 * Ra.m01 + Rb.m11 * Ra.m11 + Rb.m21 * Ra.m21, Rb.m01 * Ra.m02 + Rb.m11 * Ra.m12 + Rb.m21 * Ra.m22,
-                        Rb.m02 * Ra.m00 + Rb.m12 * Ra.m10 + Rb.m22 * Ra.m20, Rb.m02 * Ra.m01 + Rb.m12 * Ra.m11 + Rb.m22 * Ra.m21, Rb.m02 * Ra.m02 + Rb.m12 * Ra.m12 + Rb.m22 * Ra.m22};
-          for (int k = 0; k < P.n_boxes; ++k) {
-            for (int l = 0; l < P.n_boxes; ++l) {
-              const v3 ca = d + mul(Ra, v3{P.boxes[k].c[0], P.boxes[k].c[1], P.boxes[k].c[2]}) - mul(Rb, v3{P.boxes[l].c[0], P.boxes[l].c[1], P.boxes[l].c[2]});
-              peer |= box_overlaps_aabb(mulT(Rb, ca), Rrel, P.boxes[k].h, v3{0.f, 0.f, 0.f}, P.boxes[l].h);
-            }
-          }
-        }
-      }
-      V.b.world_contact = world;
-      V.b.peer_contact = peer;
-      lds_sync();
+      world_exchange(V.b, wpose, tid, A, P);  // (dogfight.hpp)
       V.tick(P, nz.get(flat_base + t));
     }
     V.b.peer_contact = false;
@@ -838,9 +812,17 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   if (P.vehicle == PF_QUADX && (P.flight_mode < -1 || P.flight_mode > 7)) return fail(nullptr, PF_ERR_ARG, "quadx flight_mode must be in -1..7");
   if (P.vehicle == PF_FIXEDWING && (P.flight_mode < -1 || P.flight_mode > 0)) return fail(nullptr, PF_ERR_ARG, "fixedwing flight_mode must be -1 or 0");
   if (P.vehicle == PF_FIXEDWING && (P.task == PF_TASK_HOVER || P.task == PF_TASK_MA_HOVER)) return fail(nullptr, PF_ERR_UNSUPPORTED, "no fixedwing hover task in the reference");
+  if (P.task == PF_TASK_DOGFIGHT) {  // ma_fixedwing_dogfight_env.py
+    if (P.vehicle != PF_FIXEDWING) return fail(nullptr, PF_ERR_UNSUPPORTED, "the dogfight task flies fixedwing aircraft (ma_fixedwing_base_env.py:201)");
+    if (P.df_team_size < 1 || 2 * P.df_team_size > pf::kDfMaxAgents || P.agents_per_world != 2 * P.df_team_size)
+      return fail(nullptr, PF_ERR_ARG, "dogfight: agents_per_world must be 2 * df_team_size, at most 8");
+    if (P.autoreset != PF_AUTORESET_OFF) return fail(nullptr, PF_ERR_ARG, "the multi-agent env has no auto-reset (PettingZoo parallel API)");
+    if (P.angle_repr != 0) return fail(nullptr, PF_ERR_UNSUPPORTED, "the dogfight env observes Euler angles (ma_fixedwing_dogfight_env.py:92)");
+    if (P.n_surf != PF_MAX_SURF || P.n_motors != 1) return fail(nullptr, PF_ERR_ARG, "dogfight: a five-surface, one-motor airframe");
+  }
   if (P.agents_per_world > 1) {
-    if (!(P.vehicle == PF_QUADX && P.task == PF_TASK_MA_HOVER))
-      return fail(nullptr, PF_ERR_UNSUPPORTED, "agents_per_world > 1 (a shared world) exists for the PettingZoo QuadX hover task only");
+    if (!((P.vehicle == PF_QUADX && P.task == PF_TASK_MA_HOVER) || P.task == PF_TASK_DOGFIGHT))
+      return fail(nullptr, PF_ERR_UNSUPPORTED, "agents_per_world > 1 (a shared world) exists for the PettingZoo tasks only (QuadX hover, fixedwing dogfight)");
     if (64 % P.agents_per_world != 0 || n_lanes % P.agents_per_world != 0)
       return fail(nullptr, PF_ERR_ARG, "agents_per_world must divide 64 (the lanes of a world share a wavefront) and the lane count");
     for (int k = 0; k < P.n_boxes; ++k)
@@ -904,10 +886,12 @@ void pf_ctx_destroy(pf_ctx* ctx) {
   delete ctx;
 }
 int pf_state_groups(const pf_ctx* ctx) {
+  if (ctx->P.task == PF_TASK_DOGFIGHT) return pf::kDfGroups;
   return ctx->P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : (ctx->P.vehicle == PF_ROCKET ? pf::Rocket::GROUPS : pf::Fixedwing::GROUPS);
 }
 int pf_obs_dim(const pf_ctx* ctx) {
   const pf_params& P = ctx->P;
+  if (P.task == PF_TASK_DOGFIGHT) return 23 + (P.agents_per_world - 1) * 14;  // ma_fixedwing_dogfight_env.py:128-160
   int aux = P.vehicle == PF_QUADX ? 4 : 6;
   return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? (P.use_yaw_targets ? 4 : 3) * P.num_targets : (P.task == PF_TASK_MA_HOVER ? 3 : 0));
 }
@@ -933,7 +917,9 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
   int rc = ensure_device(ctx);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (ctx->fast) {
+  if (P.task == PF_TASK_DOGFIGHT) {
+    hipLaunchKernelGGL(pf::dogfight_env_kernel, dim3((ctx->n + 63) / 64), dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->P_dev);
+  } else if (ctx->fast) {
     if (P.task == PF_TASK_HOVER) launch_fast<PF_TASK_HOVER>(ctx, b, op, mask, s);
     else if (P.task == PF_TASK_MA_HOVER) launch_fast<PF_TASK_MA_HOVER>(ctx, b, op, mask, s);
     else launch_fast<PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);

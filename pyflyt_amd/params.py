@@ -182,6 +182,13 @@ ACROWING.update({
 })
 FIXEDWING_MODELS = {"fixedwing": FIXEDWING, "acrowing": ACROWING}
 
+# MAFixedwingDogfightEnv's constructor defaults (pz_envs/fixedwing_envs/ma_fixedwing_dogfight_env.py:42-60); sample_spawn: draw
+# the spawn circle at every reset (the reference's behaviour) or fly from the poses stored in the state's spawn groups
+DOGFIGHT = {
+    "team_size": 2, "spawn_min_radius": 10.0, "spawn_max_radius": 50.0, "damage_per_hit": 0.003, "lethal_distance": 20.0,
+    "lethal_angle": 0.07, "aggressiveness": 0.5, "cooperativeness": 0.5, "sample_spawn": True,
+}
+
 WORLD: dict[str, Any] = {
     "physics_hz": 240,         # core/aviary.py:79
     "gravity_z": -9.81,        # core/aviary.py:226
@@ -290,12 +297,15 @@ def build_params(
     use_yaw_targets: bool = False,
     goal_reach_angle: float = 0.1,
     agents_per_world: int = 0,
+    dogfight: dict | None = None,
     start_pos=None,
     start_orn=None,
     vehicle_options: dict | None = None,
     world_options: dict | None = None,
 ) -> L.PfParams:
-    """vehicle in {'quadx','fixedwing','rocket'}; task in {'none','hover','waypoints','ma_hover'}."""
+    """vehicle in {'quadx','fixedwing','rocket'}; task in {'none','hover','waypoints','ma_hover','dogfight'}.
+    dogfight: overrides of DOGFIGHT (team_size, spawn radii, damage_per_hit, lethal_distance, lethal_angle, aggressiveness,
+    cooperativeness, sample_spawn)."""
     W = dict(WORLD, **(world_options or {}))
     P = L.PfParams()
     P.noise_mode = {"off": L.NOISE_OFF, "inject": L.NOISE_INJECT, "philox": L.NOISE_PHILOX}[noise]
@@ -315,7 +325,7 @@ def build_params(
     P.plane_half_xy = W["plane_half_xy"] * W["world_scale"]
     P.plane_half_z = W["plane_half_z"] * W["world_scale"]
     # contact response against the ground slab (named-parameter model; Bullet's defaults)
-    P.contact_response = int(task == "none") if W["contact_response"] is None else int(bool(W["contact_response"]))
+    P.contact_response = int(task in ("none", "dogfight")) if W["contact_response"] is None else int(bool(W["contact_response"]))
     P.contact_restitution, P.contact_friction, P.contact_erp = W["contact_restitution"], W["contact_friction"], W["contact_erp"]
     P.contact_iters = int(W["contact_iters"])
     P.contact_margin = W["contact_margin"]  # (lengths of the contact model itself: not scaled with the world, as in
@@ -474,6 +484,19 @@ def build_params(
         P.task = L.TASK_MA_HOVER
         P.agents_per_world = int(agents_per_world)  # > 1: the agents of an env share one world (ma_quadx_base_env.py:206-241)
         d_dome, d_dur, d_hz, d_reach = 10.0, 30.0, 40, 0.2
+    elif task == "dogfight":  # pz_envs/fixedwing_envs/ma_fixedwing_dogfight_env.py:42-60
+        if vehicle != "fixedwing":
+            raise ValueError("the dogfight task flies fixedwing aircraft (drone_model 'acrowing' in the reference)")
+        DF = dict(DOGFIGHT, **(dogfight or {}))
+        P.task = L.TASK_DOGFIGHT
+        P.df_team_size = int(DF["team_size"])
+        P.agents_per_world = 2 * P.df_team_size
+        P.df_sample_spawn = int(bool(DF["sample_spawn"]))
+        P.df_spawn_min_radius, P.df_spawn_max_radius = float(DF["spawn_min_radius"]), float(DF["spawn_max_radius"])
+        P.df_damage_per_hit, P.df_lethal_distance, P.df_lethal_angle = float(DF["damage_per_hit"]), float(DF["lethal_distance"]), float(DF["lethal_angle"])
+        P.df_aggressiveness, P.df_cooperativeness = float(DF["aggressiveness"]), float(DF["cooperativeness"])
+        P.throttle_remap = 1  # ma_fixedwing_base_env.py:300-301
+        d_dome, d_dur, d_hz, d_reach = 800.0, 60.0, 30, 0.0
     elif task == "waypoints":
         P.task = L.TASK_WAYPOINTS
         if vehicle == "quadx":  # quadx_waypoints_env.py:38-47,87

@@ -608,7 +608,7 @@ def gen_dogfight():
         print("engage: hits", np.array(rec["received_hits"])[-1], "health", np.array(rec["health"])[-1], "bits", np.bitwise_or.reduce(np.array(rec["info_bits"]), axis=0))
 
         pos = np.array([[10.0, 0.0, 30.0], [0.0, 20.0, 3.0], [-30.0, 0.0, 35.0], [0.0, -370.0, 30.0]])
-        orn = np.array([[0.0, 0.0, 0.0], [0.0, 0.6, np.pi / 2], [0.0, 0.0, np.pi], [0.0, 0.0, -np.pi / 2]])
+        orn = np.array([[0.0, 0.0, 0.0], [0.0, 0.6, np.pi / 2], [0.0, 0.0, 3.0], [0.0, 0.0, -np.pi / 2]])  # (yaw 3.0, not pi: the Euler branch cut)
 
         def crash(k, i, g):
             a = np.array([0.0, 0.02, 0.0, 0.5]) + g.uniform(-0.1, 0.1, size=4)

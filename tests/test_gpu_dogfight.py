@@ -1,0 +1,225 @@
+"""MAFixedwingDogfightEnv on the device (pyflyt_amd/csrc/dogfight.hpp) against
+  * the three trajectories recorded from the reference's own env (tests/golden/env_dogfight_*.npz, the reference's motor
+    noise and spawn poses injected), and
+  * the fp64 oracle (oracle/uav_oracle.c:orc_dogfight_*) over many worlds with the counter RNG on both sides: spawn circle,
+    motor noise, random actions.
+fp32 device, fp64 checker: observations to 2e-4 relative (positions of aircraft that have flown ~100 m), rewards to
+2e-3 (+1e-3 relative); a threshold event (cone of fire, range, a death) may fall on different sides in fp32 -- such worlds
+are counted and bounded, not compared further."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RTOL_IMPACT = 5e-3  # after a ground impact in the world (see test_gpu_golden.py / test_gpu_parity.py)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _engine(n_worlds, noise, seed=0, sample_spawn=False, lane_offset=0, **kw):
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    df = dict(sample_spawn=sample_spawn)
+    for k in ("team_size", "damage_per_hit", "lethal_distance", "lethal_angle", "aggressiveness", "cooperativeness", "spawn_min_radius", "spawn_max_radius"):
+        if k in kw:
+            df[k] = kw.pop(k)
+    P = build_params("fixedwing", "dogfight", noise=noise, autoreset="off", seed=seed, angle_representation="euler",
+                     vehicle_options=dict(drone_model="acrowing"), world_options=dict(world_scale=5.0), dogfight=df, **kw)
+    A = 2 * df.get("team_size", 2)
+    return BatchEngine(P, n_worlds * A, device="cuda:0", lane_offset=lane_offset), A
+
+
+def _set_spawn(eng, pos, rpy):
+    """state groups 13 / 14: (x, y, z, roll), (pitch, yaw, -, -) per lane."""
+    n = eng.n
+    g = torch.zeros(2, n, 4, dtype=torch.float32, device="cuda:0")
+    g[0, :, :3] = torch.tensor(pos, dtype=torch.float32)
+    g[0, :, 3] = torch.tensor(rpy[:, 0], dtype=torch.float32)
+    g[1, :, 0] = torch.tensor(rpy[:, 1], dtype=torch.float32)
+    g[1, :, 1] = torch.tensor(rpy[:, 2], dtype=torch.float32)
+    eng.state[13:15] = g
+
+
+def _rel(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash"])
+def test_dogfight_golden_replay(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    E = 16  # copies of the recorded world side by side (one wave)
+    eng, A = _engine(E, "inject", team_size=int(g["team_size"]), damage_per_hit=float(g["damage_per_hit"]), lethal_distance=float(g["lethal_distance"]),
+                     lethal_angle=float(g["lethal_angle"]), aggressiveness=float(g["aggressiveness"]), cooperativeness=float(g["cooperativeness"]),
+                     sparse_reward=bool(g["sparse_reward"]), flight_dome_size=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0)
+    assert eng.obs_dim == g["reset_obs"].shape[1] and int(eng.params.max_steps) == int(g["max_steps"])
+    _set_spawn(eng, np.tile(g["start_pos"], (E, 1)), np.tile(g["start_orn"], (E, 1)))
+    tile = lambda x: torch.tensor(np.tile(x, (1, E)), dtype=torch.float32, device="cuda:0").contiguous()  # [ticks, A] -> [ticks, n]
+    eng.env_reset(xi_reset=tile(g["reset_xi"]))
+    obs = eng.obs.cpu().numpy().astype(np.float64).reshape(E, A, -1)
+    assert _rel(obs, g["reset_obs"][None]).max() < 1e-4
+    assert np.abs(obs - obs[0:1]).max() == 0.0  # identical worlds stay bit-identical
+    worst_o = worst_r = worst_impact = 0.0
+    crashed, touched = set(), False  # an aircraft of the world has hit the ground: from then on its tumbling shows the fp32 sensitivity of
+    # impacts (tests/tools/fp32_contact_sensitivity.py) in everybody's observation of it -> the impact tolerance
+    for k in range(len(g["action"])):
+        act = torch.tensor(np.tile(g["action"][k], (E, 1)), dtype=torch.float32, device="cuda:0")
+        o, r, t, u = eng.env_step(act, xi=tile(g["xi"][k]))
+        from pyflyt_amd import _lib as PL
+        crashed |= set(np.nonzero((eng.flags()[:A] & PL.F_CONTACT).cpu().numpy())[0].tolist())
+        touched = len(crashed) > 0
+        o = o.cpu().numpy().astype(np.float64).reshape(E, A, -1)[0]
+        r, t, u = r.cpu().numpy().reshape(E, A)[0], t.cpu().numpy().reshape(E, A)[0], u.cpu().numpy().reshape(E, A)[0]
+        st = eng.state[6].cpu().numpy().reshape(E, A, 4)[0]
+        health, hits = st[:, 0], st[:, 2].view(np.int32)
+        for i in range(A):
+            if g["alive"][k][i]:
+                eo = _rel(o[i], g["obs"][k][i]).max()
+                er = abs(r[i] - g["reward"][k][i]) / max(1.0, abs(g["reward"][k][i]))
+                if touched:
+                    # the crashed aircraft tumbles over the ground: chaotic in fp32 vs fp64 within a few bounces (and the step at
+                    # which it comes to rest and drops out of the others' rows may differ by one). From the impact on: everybody's
+                    # OWN block to the flight tolerance, the rows of the others to the impact tolerance while the layouts agree
+                    eo = _rel(o[i][:23], g["obs"][k][i][:23]).max()
+                    worst_o = max(worst_o, eo)
+                    assert eo < 5e-4, (name, k, i, eo)
+                    rows_d, rows_g = o[i][23:].reshape(A - 1, 14), g["obs"][k][i][23:].reshape(A - 1, 14)
+                    nz_d, nz_g = np.abs(rows_d).sum(1) > 0, np.abs(rows_g).sum(1) > 0
+                    if (nz_d == nz_g).all():
+                        others = [j for j in range(A) if j != i]
+                        if nz_g.sum() < len(others):  # a row has dropped out: the aircraft at rest on the ground
+                            others = [j for j in others if j not in crashed]
+                        flying = np.array([j not in crashed for j in others] + [False] * (A - 1 - len(others)))
+                        if flying.any():
+                            worst_impact = max(worst_impact, _rel(rows_d[flying], rows_g[flying]).max())
+                            assert _rel(rows_d[flying], rows_g[flying]).max() < RTOL_IMPACT, (name, k, i)
+                else:
+                    worst_o = max(worst_o, eo)
+                    assert eo < 5e-4, (name, k, i, eo, int(_rel(o[i], g["obs"][k][i]).argmax()))
+                worst_r = max(worst_r, er)
+                assert er < 3e-3, (name, k, i, r[i], g["reward"][k][i])
+                assert bool(t[i]) == bool(g["term"][k][i]) and bool(u[i]) == bool(g["trunc"][k][i]), (name, k, i)
+            else:
+                assert r[i] == 0.0 and not t[i] and not u[i]  # culled agents report nothing
+        np.testing.assert_allclose(health, g["health"][k], atol=2e-5)
+        assert (hits == g["received_hits"][k]).all(), (name, k, hits, g["received_hits"][k])
+    if name == "env_dogfight_crash":  # the dead aircraft at rest has dropped out of the survivors' observations on both sides
+        assert (np.abs(o[0][23:].reshape(A - 1, 14)).sum(1) > 0).sum() == (np.abs(g["obs"][-1][0][23:].reshape(A - 1, 14)).sum(1) > 0).sum() == 2
+    print(f"{name}: worst obs {worst_o:.2e} (after a ground impact {worst_impact:.2e}) reward {worst_r:.2e} over {len(g['action'])} steps")
+
+
+def _uniforms(seed, lane_id, ctr, count, stream):
+    """The device's reset-time uniforms for a world (Noise::uniform): Philox4x32-10 keyed (seed, first lane of the world, event
+    counter, flat >> 2, stream), through the oracle's generator."""
+    import ctypes as C
+    u, buf = np.zeros(count), (C.c_double * 4)()
+    for call in range((count + 3) // 4):
+        O.lib().orc_uniform4(seed, lane_id, ctr, call, stream, buf)
+        for j in range(4):
+            if 4 * call + j < count:
+                u[4 * call + j] = buf[j]
+    return u
+
+
+def _run_vs_oracle(eng, A, worlds, steps, act_fn, label):
+    Wn, n = len(worlds), len(worlds) * A
+    ro = np.stack([w.reset() for w in worlds])
+    do = eng.obs.cpu().numpy().astype(np.float64).reshape(Wn, A, -1)
+    assert _rel(do, ro).max() < 2e-4, _rel(do, ro).max()
+    ok = np.ones(Wn, dtype=bool)
+    worst_o = worst_r = 0.0
+    events = dict(hits=0, dead=0, win=0, oob=0, trunc=0, collision=0)
+    for k in range(steps):
+        act = act_fn(k).astype(np.float32)
+        o, r, t, u = eng.env_step(torch.tensor(act.reshape(n, 4), device="cuda:0"))
+        o = o.cpu().numpy().astype(np.float64).reshape(Wn, A, -1)
+        r, t, u = r.cpu().numpy().reshape(Wn, A), t.cpu().numpy().reshape(Wn, A), u.cpu().numpy().reshape(Wn, A)
+        st = eng.state[6].cpu().numpy().reshape(Wn, A, 4)
+        for w, W in enumerate(worlds):
+            if not ok[w]:
+                continue
+            alive = W.alive.copy()
+            oo, rr, tt, uu = W.step(act[w].astype(np.float64))
+            if (t[w][alive] != tt[alive]).any() or (u[w][alive] != uu[alive]).any() or (st[w, :, 2].view(np.int32) != np.array(W.D.received_hits[:A])).any():
+                ok[w] = False  # a threshold event (cone of fire, range, death) fell on the other side in fp32: stop comparing this world
+                continue
+            if any(L.contact_step for L in W.Ls):
+                events["collision"] += 1
+                ok[w] = False  # ground impacts are compared in the golden replay; the tumbling afterwards is chaotic
+                continue
+            eo = max((_rel(o[w][i], oo[i]).max() for i in range(A) if alive[i]), default=0.0)
+            er = max((abs(r[w][i] - rr[i]) / max(1.0, abs(rr[i])) for i in range(A) if alive[i]), default=0.0)
+            worst_o, worst_r = max(worst_o, eo), max(worst_r, er)
+            bits = np.array(W.D.info_bits[:A])
+            events["hits"] += int(np.array(W.D.cur_hit).sum()); events["dead"] += int(((bits & 1) != 0).any())
+            events["win"] += int(((bits & 8) != 0).any()); events["oob"] += int(((bits & 4) != 0).any()); events["trunc"] += int(uu.any())
+    frac = (ok.sum() + events["collision"]) / Wn
+    print(f"{label}: worlds compared to the end (or to a ground impact) {frac:.3f}, worst obs {worst_o:.2e} reward {worst_r:.2e}, events {events}")
+    return frac, worst_o, worst_r, events
+
+
+def test_dogfight_sampled_spawn_vs_oracle():
+    """The world's spawn circle from the counter RNG (_get_start_pos_orn, :176-213) against the oracle's restatement fed the same
+    uniforms, then 40 steps of random actions with Philox motor noise on both sides."""
+    Wn, seed, lane_offset = 32, 13, 4096
+    kw = dict(flight_dome_size=75.0, max_duration_seconds=1.0)
+    eng, A = _engine(Wn, "philox", seed=seed, sample_spawn=True, lane_offset=lane_offset, **kw)
+    eng.env_reset()
+    sp = eng.state[13:15].cpu().numpy()
+    dev_pos, dev_yaw = sp[0, :, :3].reshape(Wn, A, 3), sp[1, :, 1].reshape(Wn, A)
+    worlds = []
+    for w in range(Wn):
+        pos, rpy, vel = O.dogfight_spawn(2, 10.0, 50.0, _uniforms(seed, lane_offset + w * A, 0, 1 + 3 * A, 2))
+        assert np.abs(pos - dev_pos[w]).max() < 2e-4 and np.abs(rpy[:, 2] - dev_yaw[w]).max() < 2e-6, w
+        worlds.append(O.OracleDogfight(pos, rpy, start_vel=vel, noise_mode=O.NOISE_PHILOX, seed=seed, lane_id0=lane_offset + w * A,
+                                       dome=kw["flight_dome_size"], max_duration_seconds=kw["max_duration_seconds"]))
+    assert np.abs(dev_pos[0] - dev_pos[1]).max() > 1.0  # every world draws its own circle
+    rng = np.random.default_rng(5)
+    frac, wo, wr, ev = _run_vs_oracle(eng, A, worlds, 40, lambda k: rng.uniform(-1.0, 1.0, size=(Wn, A, 4)), "dogfight, sampled spawn")
+    assert frac >= 0.9 and wo < 5e-4 and wr < 5e-3
+    assert ev["trunc"] > 0 and ev["oob"] > 0  # 1 s episodes; spawned up to 70 m out at 20 m/s inside a 75 m dome
+
+
+def test_dogfight_engagements_vs_oracle():
+    """Worlds set up for a fight: every aircraft of team 1 flies 15-40 m ahead of one of team 0, roughly on its heading, inside a
+    generous cone of fire -- hits from the first step, health running out, deaths, (element-wise) team wins, culled aircraft
+    flying on. Every world against its own fp64 oracle world; Philox motor noise, gentle random actions."""
+    Wn, seed, lane_offset = 48, 21, 640
+    kw = dict(damage_per_hit=0.006, lethal_distance=45.0, lethal_angle=0.3, flight_dome_size=500.0, max_duration_seconds=1.5)
+    eng, A = _engine(Wn, "philox", seed=seed, sample_spawn=False, lane_offset=lane_offset, **kw)
+    rng = np.random.default_rng(3)
+    pos, rpy = np.zeros((Wn, A, 3)), np.zeros((Wn, A, 3))
+    for w in range(Wn):
+        for i in range(2):  # team 0
+            pos[w, i] = [rng.uniform(-60, 60), rng.uniform(-60, 60) + 150.0 * i, rng.uniform(40, 60)]
+            rpy[w, i, 2] = rng.uniform(-np.pi + 0.2, np.pi - 0.2)
+            j = 2 + i      # its quarry
+            d = rng.uniform(15, 40)
+            off = rng.uniform(-0.15, 0.15)
+            pos[w, j] = pos[w, i] + d * np.array([np.cos(rpy[w, i, 2] + off), np.sin(rpy[w, i, 2] + off), rng.uniform(-0.05, 0.05)])
+            rpy[w, j, 2] = rpy[w, i, 2] + rng.uniform(-0.1, 0.1)
+    _set_spawn(eng, pos.reshape(-1, 3), rpy.reshape(-1, 3))
+    eng.env_reset()
+    worlds = [O.OracleDogfight(pos[w], rpy[w], noise_mode=O.NOISE_PHILOX, seed=seed, lane_id0=lane_offset + w * A,
+                               damage_per_hit=kw["damage_per_hit"], lethal_distance=kw["lethal_distance"], lethal_angle=kw["lethal_angle"],
+                               dome=kw["flight_dome_size"], max_duration_seconds=kw["max_duration_seconds"]) for w in range(Wn)]
+    base = np.array([0.0, 0.0, 0.0, 0.4])
+    frac, wo, wr, ev = _run_vs_oracle(eng, A, worlds, 50, lambda k: base + rng.uniform(-0.15, 0.15, size=(Wn, A, 4)), "dogfight, engagements")
+    assert frac >= 0.8 and wo < 5e-4 and wr < 5e-3
+    assert ev["hits"] > 500 and ev["dead"] > 0 and ev["win"] > 0 and ev["trunc"] > 0
+
+
+def test_dogfight_refusals():
+    from pyflyt_amd import PyFlytAmdError, build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    P = build_params("fixedwing", "dogfight", autoreset="off", angle_representation="euler", vehicle_options=dict(drone_model="acrowing"))
+    with pytest.raises(PyFlytAmdError):
+        BatchEngine(P, 6, device="cuda:0")  # not a whole number of worlds
+    P = build_params("fixedwing", "dogfight", autoreset="next_step", angle_representation="euler", vehicle_options=dict(drone_model="acrowing"))
+    with pytest.raises(PyFlytAmdError):
+        BatchEngine(P, 8, device="cuda:0")  # PettingZoo envs have no auto-reset

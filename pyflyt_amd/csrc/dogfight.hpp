@@ -92,14 +92,17 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   const int tid = threadIdx.x;
   Fixedwing::fill_table(ktab, Pdev, tid);
   __syncthreads();
-  const int wave_base = blockIdx.x * 64;
+  // a wave holds floor(64 / A) whole worlds (A = 6: ten worlds, four idle lanes): worlds never straddle a wave
+  const int A = P.agents_per_world, T = P.df_team_size;
+  const int LPW = (64 / A) * A;
+  if (tid >= LPW) return;  // (one wave per workgroup and no barrier below: the idle lanes simply leave)
+  const int wave_base = blockIdx.x * LPW;
   const int lane = wave_base + tid;
   const bool valid = lane < n;
   const size_t li = valid ? lane : n - 1;
   const size_t N = (size_t)n;
   const float4* Sin = reinterpret_cast<const float4*>(B.state);
   float4* Sout = reinterpret_cast<float4*>(B.state);
-  const int A = P.agents_per_world, T = P.df_team_size;
   const int wbase = (tid / A) * A, wlocal = tid - wbase;
   const int my_team = wlocal >= T ? 1 : 0;
   const int D = 23 + (A - 1) * 14;
@@ -346,8 +349,8 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   {
     const bool wave_all = __all(active || !valid);
     if (wave_all) {
-      const int rows = min(64, n - wave_base);
-      stream_tile(tile, B.obs + (size_t)wave_base * D, rows * D, tid);
+      const int rows = min(LPW, n - wave_base);
+      stream_tile(tile, B.obs + (size_t)wave_base * D, rows * D, tid, LPW);
     } else if (active) {
       float* g = B.obs + (size_t)lane * D;
       const float* row = tile + tid * D;

@@ -823,7 +823,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   if (P.agents_per_world > 1) {
     if (!((P.vehicle == PF_QUADX && P.task == PF_TASK_MA_HOVER) || P.task == PF_TASK_DOGFIGHT))
       return fail(nullptr, PF_ERR_UNSUPPORTED, "agents_per_world > 1 (a shared world) exists for the PettingZoo tasks only (QuadX hover, fixedwing dogfight)");
-    if (64 % P.agents_per_world != 0 || n_lanes % P.agents_per_world != 0)
+    if ((P.task != PF_TASK_DOGFIGHT && 64 % P.agents_per_world != 0) || n_lanes % P.agents_per_world != 0)
       return fail(nullptr, PF_ERR_ARG, "agents_per_world must divide 64 (the lanes of a world share a wavefront) and the lane count");
     for (int k = 0; k < P.n_boxes; ++k)
       if (P.boxes[k].kind != 0 || P.boxes[k].yaw != 0.0f)
@@ -918,7 +918,8 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (P.task == PF_TASK_DOGFIGHT) {
-    hipLaunchKernelGGL(pf::dogfight_env_kernel, dim3((ctx->n + 63) / 64), dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->P_dev);
+    const int lpw = (64 / P.agents_per_world) * P.agents_per_world;  // whole worlds per wave
+    hipLaunchKernelGGL(pf::dogfight_env_kernel, dim3((ctx->n + lpw - 1) / lpw), dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->P_dev);
   } else if (ctx->fast) {
     if (P.task == PF_TASK_HOVER) launch_fast<PF_TASK_HOVER>(ctx, b, op, mask, s);
     else if (P.task == PF_TASK_MA_HOVER) launch_fast<PF_TASK_MA_HOVER>(ctx, b, op, mask, s);

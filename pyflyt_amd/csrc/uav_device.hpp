@@ -205,16 +205,16 @@ PF_DEV quat quat_integrate(quat q, v3 w, float half_dt) {
 // `g` is wave-uniform; when it is not 16-byte aligned (a trajectory slot [step][n][D] with n * D odd) the copy
 // falls back to dword stores.
 typedef float pf_f4v __attribute__((ext_vector_type(4)));
-PF_DEV void stream_tile(const float* tile, float* g, int total, int tid) {
+PF_DEV void stream_tile(const float* tile, float* g, int total, int tid, int lanes = 64) {  // lanes: how many lanes of the wave take part
   const int n4 = total >> 2;
   if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {
     const pf_f4v* t4 = reinterpret_cast<const pf_f4v*>(tile);
     pf_f4v* g4 = reinterpret_cast<pf_f4v*>(g);
-    for (int i = tid; i < n4; i += 64) __builtin_nontemporal_store(t4[i], &g4[i]);
+    for (int i = tid; i < n4; i += lanes) __builtin_nontemporal_store(t4[i], &g4[i]);
   } else {
-    for (int i = tid; i < (n4 << 2); i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
+    for (int i = tid; i < (n4 << 2); i += lanes) __builtin_nontemporal_store(tile[i], &g[i]);
   }
-  for (int i = (n4 << 2) + tid; i < total; i += 64) __builtin_nontemporal_store(tile[i], &g[i]);
+  for (int i = (n4 << 2) + tid; i < total; i += lanes) __builtin_nontemporal_store(tile[i], &g[i]);
 }
 
 // ---------------------------------------------------------------- contact reporting

@@ -223,3 +223,44 @@ def test_dogfight_refusals():
     P = build_params("fixedwing", "dogfight", autoreset="next_step", angle_representation="euler", vehicle_options=dict(drone_model="acrowing"))
     with pytest.raises(PyFlytAmdError):
         BatchEngine(P, 8, device="cuda:0")  # PettingZoo envs have no auto-reset
+
+
+@pytest.mark.parametrize("team_size", [1, 2, 3, 4])
+def test_dogfight_pz_api(team_size):
+    """The PettingZoo-shaped façade: agent naming, spaces, dict in / dict out, culling, infos; world sizes that do not divide the
+    wavefront (team_size 3: six aircraft per world, ten worlds per wave); the same seed draws the same spawn circle."""
+    from pyflyt_amd.pz_envs import MAFixedwingDogfightEnv
+
+    A, E = 2 * team_size, 11
+    env = MAFixedwingDogfightEnv(team_size=team_size, num_envs=E, seed=4, max_duration_seconds=1.0, flight_dome_size=90.0,
+                                 lethal_distance=80.0, lethal_angle_radians=0.6, damage_per_hit=0.02)
+    assert env.possible_agents == [f"uav_{i}" for i in range(A)]
+    assert env.observation_space("uav_0").shape == (23 + (A - 1) * 14,) and env.action_space("uav_0").shape == (4,)
+    obs, infos = env.reset(seed=4)
+    assert set(obs) == set(env.possible_agents) and all(o.shape == (E, 23 + (A - 1) * 14) for o in obs.values())
+    spawn0 = env.start_pos.clone()
+    assert torch.isfinite(torch.stack(list(obs.values()))).all()
+    # aircraft spawn on a circle of radius 10..50 around the origin, 10..50 m up, health 1
+    r = spawn0[..., :2].norm(dim=-1)
+    assert (r >= 10 - 1e-3).all() and (r <= 50 + 1e-3).all() and (spawn0[..., 2] >= 10 - 1e-3).all() and (env.healths == 1.0).all()
+    g = torch.Generator().manual_seed(0)
+    seen_done, k = set(), 0
+    while env.agents:
+        acts = {a: torch.rand(E, 4, generator=g) * 2 - 1 for a in env.agents}
+        obs, rew, term, trunc, infos = env.step(acts)
+        assert set(obs) == set(acts) == set(rew) == set(term) == set(trunc) == set(infos)
+        for a in acts:
+            assert obs[a].shape == (E, 23 + (A - 1) * 14) and rew[a].shape == (E,) and torch.isfinite(obs[a]).all() and torch.isfinite(rew[a]).all()
+            assert set(infos[a]) == {"health", "received_hits", "dead", "collision", "out_of_bounds", "team_win"}
+            if bool((term[a] | trunc[a]).all()):
+                seen_done.add(a)
+        k += 1
+        assert k <= 40
+    assert seen_done == set(env.possible_agents)  # 1 s episodes: everybody is truncated at the latest
+    from pyflyt_amd import _lib as PL
+    assert not (env.engine.flags() & PL.F_NONFINITE).any()
+    obs2, _ = env.reset(seed=4)
+    assert torch.equal(env.start_pos, spawn0)  # same seed, same circle
+    env.reset(seed=5)
+    assert not torch.equal(env.start_pos, spawn0)
+    env.close()

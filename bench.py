@@ -32,7 +32,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # algorithmic HBM bytes per env step per lane:
 #   reads  128 B = 7 state float4 groups (112) + action float4 (16)
 #   writes 202 B = 7 state groups (112) + obs 21 f32 (84) + reward (4) + terminated (1) + truncated (1)
-ALGO_BYTES = {"hover": 330, "quadx_waypoints": 442, "fixedwing_waypoints": 418}
+ALGO_BYTES = {"hover": 330, "quadx_waypoints": 442, "fixedwing_waypoints": 418,
+              # dogfight (team_size 2): 15 state groups read + written (480), action (16), obs 65 f32 (260), reward + flags (6)
+              "dogfight": 762}
 
 
 def parse():
@@ -41,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=65536, help="lanes per GPU")
-    ap.add_argument("--env", default="hover", choices=["hover", "quadx_waypoints", "fixedwing_waypoints"])
+    ap.add_argument("--env", default="hover", choices=["hover", "quadx_waypoints", "fixedwing_waypoints", "dogfight"])
     ap.add_argument("--noise", default="philox", choices=["philox", "off"])
     ap.add_argument("--graph-steps", type=int, default=100, help="env steps captured per HIP graph")
     ap.add_argument("--no-graph", action="store_true")
@@ -63,6 +65,11 @@ def make_engine(env, batch, device, lane_offset, noise, contact_response=True, w
     from pyflyt_amd import build_params
     from pyflyt_amd.engine import BatchEngine
 
+    if env == "dogfight":  # MAFixedwingDogfightEnv defaults: 2 v 2 Acrowing per world (4 adjacent lanes), world_scale 5; no auto-reset
+        # in the PettingZoo API -- finished agents are culled and their aircraft fly on, the per-step work does not change
+        P = build_params("fixedwing", "dogfight", noise=noise, autoreset="off", seed=0, angle_representation="euler",
+                         vehicle_options=dict(drone_model="acrowing"), world_options=dict(world_scale=5.0))
+        return BatchEngine(P, batch, device=device, lane_offset=lane_offset)
     vehicle, task = {"hover": ("quadx", "hover"), "quadx_waypoints": ("quadx", "waypoints"),
                      "fixedwing_waypoints": ("fixedwing", "waypoints")}[env]
     wo = {} if contact_response else dict(contact_response=False)
@@ -137,6 +144,12 @@ def main():
     ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(g)]
     for i, a in enumerate(ring):
         eng.sample_actions(a, i)
+        if args.env == "dogfight":
+            # uniform actions over the whole box fly every aircraft into the ground within seconds, and a world of wrecks at rest
+            # on the floor (contact solve every tick for every lane) is not the regime a policy trains in: gentle commands
+            # around level flight instead (stick +-0.15, throttle command 0.25..0.55)
+            a.mul_(0.15)
+            a[:, 3] += 0.4
     eng.env_reset()
     torch.cuda.synchronize()
 
@@ -195,7 +208,7 @@ def main():
     # actions sampled on device with pf_sample_actions' keys, every step's obs / action / reward / flags written
     # to trajectory buffers). Timed with HIP events on the launch stream; same barrier / max-over-ranks rule.
     roll = None
-    if args.rollout_steps > 0:
+    if args.rollout_steps > 0 and args.env != "dogfight":
         kk = args.rollout_steps
         reps = max(1, args.steps // kk)
         with torch.cuda.stream(stream):
@@ -242,7 +255,8 @@ def main():
                        "launch": "hipGraph" if graph is not None else "eager", "contact_response": bool(eng.params.contact_response), "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                         "kernel": "pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel", "algorithmic_bytes_per_launch": algo,
+                         "kernel": {"fixedwing_waypoints": "pf::fixedwing_wp_env_kernel", "dogfight": "pf::dogfight_env_kernel"}.get(args.env, "pf::quadx_m0_env_kernel"),
+                         "algorithmic_bytes_per_launch": algo,
                          "launch_us": per_launch_s * 1e6},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -273,7 +287,7 @@ def main():
                 "kernel": ("pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel") + "<..., ROLL=1>", "launch_us": rev / reps * 1e6,
                 "note": "k env steps per launch, state in registers, on-device action sampling (pf_sample_actions keys); bit-identical to k x pf_env_step (tests/test_gpu_rollout.py)",
             }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.env != "dogfight":
             out["cpu_baseline"] = cpu_baseline(args.env, args.noise, args.cpu_seconds)
         line = json.dumps(out)
     if dist is not None:

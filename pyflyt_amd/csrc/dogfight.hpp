@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   Fixedwing V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)tile;
+  V.b.cslots = (64 * kDfMaxObs) / kContactSlotFloats;  // 14 solver regions fit the idle observation tile
   V.bind(ktab);
   float nd_unused;
   int4 ints;
@@ -141,10 +142,16 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   auto world_aviary_step = [&](int flat_base) {
     V.b.contact_step = false;
     V.template control<0>(P, sp);
+    // A wreck -- dead, on the ground and at rest: the reference's own `inactive` (:505-510), which drops it from everybody's
+    // observation -- is not integrated any further (the reference keeps stepping it in Bullet; nothing observable depends on
+    // that, and a world of wrecks would otherwise run the contact solve on every lane in every tick). It keeps its resting
+    // contact: the collision verdict of :667-670 stays up.
+    const bool wreck = (df & DF_INACTIVE) != 0;
     for (int t = 0; t < P.ticks_per_control; ++t) {
       world_exchange(V.b, wpose, tid, A, P);
-      V.tick(P, nz.get(flat_base + t));
+      if (!wreck) V.tick(P, nz.get(flat_base + t));
     }
+    if (wreck) V.b.contact_step = V.b.contact_now;
     V.b.peer_contact = false;
     V.b.rpy = euler_from_quat_fast(V.b.q);
   };

@@ -46,7 +46,9 @@ PF_DEV void lds_sync_wave() {  // one wave per workgroup: LDS traffic ordered, n
 // Shared world, before a physics tick: the A lanes of a world exchange pose and contact bit, test their collision boxes
 // against each other (15 axes, in the peer's frame, behind a bounding-sphere test) and OR the world's contact bits into the
 // gate of the rotational drag (quadx.py:509). wpose: 8 floats per lane of the wave.
-PF_DEV void world_exchange(Body& b, float* wpose, const int tid, const int A, const pf_params& P) {
+// Pd: the device copy of the parameter block -- the collision boxes are indexed dynamically, which for the by-value kernel
+// argument would mean a private copy in scratch memory.
+PF_DEV void world_exchange(Body& b, float* wpose, const int tid, const int A, const float bound_radius, const pf_params* __restrict__ Pd) {
   const int wbase = (tid / A) * A, wlocal = tid - wbase;
   float* me = wpose + tid * 8;
   me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
@@ -57,17 +59,19 @@ PF_DEV void world_exchange(Body& b, float* wpose, const int tid, const int A, co
     const float* o = wpose + (wbase + (wlocal + j) % A) * 8;
     world |= o[7] != 0.0f;
     const v3 d{b.p.x - o[0], b.p.y - o[1], b.p.z - o[2]};
-    const float rr = 2.0f * P.bound_radius;
+    const float rr = 2.0f * bound_radius;
     if (dot(d, d) <= rr * rr) {  // bounding spheres touch: the box tests, this drone's boxes in the peer's box frames
       const m3 Rb = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
       const m3& Ra = b.R;
       const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
                     Rb.m01 * Ra.m00 + Rb.m11 * Ra.m10 + Rb.m21 * Ra.m20, Rb.m01 * Ra.m01 + Rb.m11 * Ra.m11 + Rb.m21 * Ra.m21, Rb.m01 * Ra.m02 + Rb.m11 * Ra.m12 + Rb.m21 * Ra.m22,
                     Rb.m02 * Ra.m00 + Rb.m12 * Ra.m10 + Rb.m22 * Ra.m20, Rb.m02 * Ra.m01 + Rb.m12 * Ra.m11 + Rb.m22 * Ra.m21, Rb.m02 * Ra.m02 + Rb.m12 * Ra.m12 + Rb.m22 * Ra.m22};
-      for (int k = 0; k < P.n_boxes; ++k) {
-        for (int l = 0; l < P.n_boxes; ++l) {
-          const v3 ca = d + mul(Ra, v3{P.boxes[k].c[0], P.boxes[k].c[1], P.boxes[k].c[2]}) - mul(Rb, v3{P.boxes[l].c[0], P.boxes[l].c[1], P.boxes[l].c[2]});
-          peer |= box_overlaps_aabb(mulT(Rb, ca), Rrel, P.boxes[k].h, v3{0.f, 0.f, 0.f}, P.boxes[l].h);
+      const int nb = Pd->n_boxes;
+      for (int k = 0; k < nb; ++k) {
+        for (int l = 0; l < nb; ++l) {
+          const pf_box bk = Pd->boxes[k], bl = Pd->boxes[l];
+          const v3 ca = d + mul(Ra, v3{bk.c[0], bk.c[1], bk.c[2]}) - mul(Rb, v3{bl.c[0], bl.c[1], bl.c[2]});
+          peer |= box_overlaps_aabb(mulT(Rb, ca), Rrel, bk.h, v3{0.f, 0.f, 0.f}, bl.h);
         }
       }
     }
@@ -77,24 +81,37 @@ PF_DEV void world_exchange(Body& b, float* wpose, const int tid, const int A, co
   lds_sync_wave();
 }
 
+// sin / cos of an angle in [-pi, pi] (Euler angles): sincos_turns' exact quadrant reduction, abs error < 1e-7
+PF_DEV void sincos_angle(float a, float& s, float& c) {
+  const float u = a * (0.5f / kPi);
+  sincos_turns(u - __builtin_floorf(u), s, c);
+}
+// tanh(x) = 1 - 2 / (exp(2x) + 1): v_exp_f32 + v_rcp_f32, abs error ~1e-7 (saturates cleanly: exp -> inf gives 1, -> 0 gives -1)
+PF_DEV float fast_tanh(float x) { return 1.0f - 2.0f * frcp(__builtin_amdgcn_exp2f(x * 2.885390081777927f) + 1.0f); }
+
 // per-lane exchange record of update_states(): 0-2 w_b, 3-5 rpy, 6-8 v_b, 9-11 body-centre position, 12-14 ground velocity,
 // 15 health after this update's hits, 16 inactive, 17 health after the overrides, 18 hit bits of this lane's row (as int),
 // 19 unused, 20-27 this lane's row of the masked 1 / (angle + 0.1)
 constexpr int kDfRec = 28;
 
+// A: aircraft per world (2 team_size), a template parameter so that the per-row loops and register arrays have their exact size
+// and the observation tile (the biggest LDS user: 64 x (23 + 14 (A - 1)) floats) does not limit the workgroups per CU for the
+// common 2 v 2 case.
+template <int A>
 __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, const pf_buffers B, const int n, const uint64_t lane0,
                                                           const int op, const uint8_t* mask, const pf_params* __restrict__ Pdev) {
-  __shared__ float tile[64 * kDfMaxObs];
+  constexpr int D = 23 + (A - 1) * 14;
+  constexpr int kTile = 64 * D > kContactSlots * kContactSlotFloats ? 64 * D : kContactSlots * kContactSlotFloats;
+  __shared__ float tile[kTile];
   __shared__ float ktab[Fixedwing::TABLE_FLOATS];
   __shared__ float wpose[64 * 8];
   __shared__ float rec[64 * kDfRec];
-  static_assert(64 * kDfMaxObs >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
   const int tid = threadIdx.x;
   Fixedwing::fill_table(ktab, Pdev, tid);
   __syncthreads();
   // a wave holds floor(64 / A) whole worlds (A = 6: ten worlds, four idle lanes): worlds never straddle a wave
-  const int A = P.agents_per_world, T = P.df_team_size;
-  const int LPW = (64 / A) * A;
+  constexpr int T = A / 2;
+  constexpr int LPW = (64 / A) * A;
   if (tid >= LPW) return;  // (one wave per workgroup and no barrier below: the idle lanes simply leave)
   const int wave_base = blockIdx.x * LPW;
   const int lane = wave_base + tid;
@@ -105,12 +122,11 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   float4* Sout = reinterpret_cast<float4*>(B.state);
   const int wbase = (tid / A) * A, wlocal = tid - wbase;
   const int my_team = wlocal >= T ? 1 : 0;
-  const int D = 23 + (A - 1) * 14;
 
   Fixedwing V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)tile;
-  V.b.cslots = (64 * kDfMaxObs) / kContactSlotFloats;  // 14 solver regions fit the idle observation tile
+  V.b.cslots = kTile / kContactSlotFloats;  // as many solver regions as fit the idle observation tile
   V.bind(ktab);
   float nd_unused;
   int4 ints;
@@ -121,11 +137,12 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   float health = g6.x, acc = g6.y;
   int received_hits = __float_as_int(g6.z), df = __float_as_int(g6.w);
   float4 cur_a4 = Sin[7 * N + li], past_a4 = Sin[8 * N + li];
-  float cur_d[kDfMaxAgents], cur_ang[kDfMaxAgents];
+  float cur_d[A], cur_ang[A];
   {
     const float4 a = Sin[9 * N + li], b = Sin[10 * N + li], c = Sin[11 * N + li], d = Sin[12 * N + li];
-    cur_d[0] = a.x; cur_d[1] = a.y; cur_d[2] = a.z; cur_d[3] = a.w; cur_d[4] = b.x; cur_d[5] = b.y; cur_d[6] = b.z; cur_d[7] = b.w;
-    cur_ang[0] = c.x; cur_ang[1] = c.y; cur_ang[2] = c.z; cur_ang[3] = c.w; cur_ang[4] = d.x; cur_ang[5] = d.y; cur_ang[6] = d.z; cur_ang[7] = d.w;
+    const float rd[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, ra[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int j = 0; j < A; ++j) { cur_d[j] = rd[j]; cur_ang[j] = ra[j]; }
   }
   float4 sp_a = Sin[13 * N + li], sp_b = Sin[14 * N + li];
 
@@ -148,7 +165,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     // contact: the collision verdict of :667-670 stays up.
     const bool wreck = (df & DF_INACTIVE) != 0;
     for (int t = 0; t < P.ticks_per_control; ++t) {
-      world_exchange(V.b, wpose, tid, A, P);
+      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev);
       if (!wreck) V.tick(P, nz.get(flat_base + t));
     }
     if (wreck) V.b.contact_step = V.b.contact_now;
@@ -161,7 +178,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     float* me = rec + tid * kDfRec;
     // ---- own attitude, rotation (rz ry rx) and nose direction (ma_fixedwing_base_env.py:336-405)
     float sr, cr, spp, cp, sy, cy;
-    sincosf(V.b.rpy.x, &sr, &cr); sincosf(V.b.rpy.y, &spp, &cp); sincosf(V.b.rpy.z, &sy, &cy);
+    sincos_angle(V.b.rpy.x, sr, cr); sincos_angle(V.b.rpy.y, spp, cp); sincos_angle(V.b.rpy.z, sy, cy);
     const float R00 = cy * cp, R01 = cy * spp * sr - sy * cr, R02 = cy * spp * cr + sy * sr;
     const float R10 = sy * cp, R11 = sy * spp * sr + cy * cr, R12 = sy * spp * cr - cy * sr;
     const float R20 = -spp, R21 = cp * sr, R22 = cp * cr;
@@ -173,17 +190,17 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     me[6] = vb.x; me[7] = vb.y; me[8] = vb.z; me[9] = pc.x; me[10] = pc.y; me[11] = pc.z; me[12] = gv.x; me[13] = gv.y; me[14] = gv.z;
     lds_sync_wave();
     // ---- this lane's row of the engagement matrices (:313-344)
-    float prev_d[kDfMaxAgents], prev_ang[kDfMaxAgents], iaa[kDfMaxAgents];
+    float prev_d[A], prev_ang[A], iaa[A];
     int hit_bits = 0, inr_bits = 0, chase_bits = 0;
 #pragma unroll
-    for (int j = 0; j < kDfMaxAgents; ++j) {
+    for (int j = 0; j < A; ++j) {
       prev_d[j] = cur_d[j]; prev_ang[j] = cur_ang[j]; iaa[j] = 0.0f;
       if (j < A && j != wlocal) {
         const float* o = rec + (wbase + j) * kDfRec;
         const v3 sep{o[9] - pc.x, o[10] - pc.y, o[11] - pc.z};
-        const float dist = sqrtf(dot(sep, sep));
+        const float dist = fsqrt(dot(sep, sep));
         const v3 cx = cross(sep, fwd);
-        const float ang = atan2f(sqrtf(dot(cx, cx)), dot(sep, fwd));  // == arccos(sep . fwd / |sep|), well conditioned near 0
+        const float ang = fast_atan2(fsqrt(dot(cx, cx)), dot(sep, fwd));  // == arccos(sep . fwd / |sep|), well conditioned near 0
         const bool in_range = dist < P.df_lethal_distance, chasing = ang < 0.5f * kPi;
         const bool ff = (j >= T ? 1 : 0) != my_team;
         cur_d[j] = dist; cur_ang[j] = ang;
@@ -197,7 +214,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     }
     me[18] = __int_as_float(hit_bits);
 #pragma unroll
-    for (int j = 0; j < kDfMaxAgents; ++j) me[20 + j] = iaa[j];
+    for (int j = 0; j < A; ++j) me[20 + j] = iaa[j];
     lds_sync_wave();
     // ---- hits received, health (:499-503), inactive (:505-510)
     int rec_hits = 0, team_hits = 0;
@@ -208,7 +225,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     }
     received_hits += rec_hits;
     health = __builtin_fmaxf(fmaf(-P.df_damage_per_hit, (float)rec_hits, health), 0.0f);
-    const bool inactive = (health <= 0.0f) && (pc.z < 2.0f) && (sqrtf(dot(vb, vb)) < 0.1f);
+    const bool inactive = (health <= 0.0f) && (pc.z < 2.0f) && (dot(vb, vb) < 0.01f);
     df = inactive ? (df | DF_INACTIVE) : (df & ~DF_INACTIVE);
     me[15] = health; me[16] = inactive ? 1.0f : 0.0f;
     lds_sync_wave();
@@ -248,7 +265,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     // ---- rewards (:551-649)
     float e = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kDfMaxAgents; ++j) {
+    for (int j = 0; j < A; ++j) {
       if (j < A && j != wlocal) {
         const bool ff = (j >= T ? 1 : 0) != my_team;
         const bool in_range = (inr_bits >> j) & 1, chasing = (chase_bits >> j) & 1;
@@ -267,13 +284,13 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
       }
     }
     e = fmaf(P.df_cooperativeness, (float)team_hits, e);  // :609-617
-    const float dist_origin = sqrtf(dot(pc, pc));
+    const float dist_origin = fsqrt(dot(pc, pc));
     float bnd = 0.0f;
     if (!P.sparse_reward) {
-      bnd += tanhf(fmaf(0.1f, pc.z, -1.0f));
-      bnd -= tanhf(fmaf(0.0025f, dist_origin, -1.0f));
+      bnd += fast_tanh(fmaf(0.1f, pc.z, -1.0f));
+      bnd -= fast_tanh(fmaf(0.0025f, dist_origin, -1.0f));
 #pragma unroll
-      for (int j = 0; j < kDfMaxAgents; ++j)
+      for (int j = 0; j < A; ++j)
         if (j < A && j != wlocal && cur_d[j] < 5.0f) bnd -= 10.0f * (5.0f - cur_d[j]);
     }
     acc += e + bnd;
@@ -321,7 +338,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
       step_count = 0; flags = 0;
       health = 1.0f; acc = 0.0f; received_hits = 0; df = DF_ALIVE;
 #pragma unroll
-      for (int j = 0; j < kDfMaxAgents; ++j) { cur_d[j] = 0.0f; cur_ang[j] = 0.0f; }
+      for (int j = 0; j < A; ++j) { cur_d[j] = 0.0f; cur_ang[j] = 0.0f; }
       nz.begin_event(rng_ctr, 1u, B.xi_reset);
     }
     // (whole worlds reset together -- checked by the host side -- so the lanes that exchange data through LDS always take this
@@ -372,10 +389,13 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     Sout[6 * N + li] = float4{health, acc, __int_as_float(received_hits), __int_as_float(df)};
     Sout[7 * N + li] = cur_a4;
     Sout[8 * N + li] = past_a4;
-    Sout[9 * N + li] = float4{cur_d[0], cur_d[1], cur_d[2], cur_d[3]};
-    Sout[10 * N + li] = float4{cur_d[4], cur_d[5], cur_d[6], cur_d[7]};
-    Sout[11 * N + li] = float4{cur_ang[0], cur_ang[1], cur_ang[2], cur_ang[3]};
-    Sout[12 * N + li] = float4{cur_ang[4], cur_ang[5], cur_ang[6], cur_ang[7]};
+    float rd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < A; ++j) { rd[j] = cur_d[j]; ra[j] = cur_ang[j]; }
+    Sout[9 * N + li] = float4{rd[0], rd[1], rd[2], rd[3]};
+    Sout[10 * N + li] = float4{rd[4], rd[5], rd[6], rd[7]};
+    Sout[11 * N + li] = float4{ra[0], ra[1], ra[2], ra[3]};
+    Sout[12 * N + li] = float4{ra[4], ra[5], ra[6], ra[7]};
     Sout[13 * N + li] = sp_a;
     Sout[14 * N + li] = sp_b;
     if (op == 0) {

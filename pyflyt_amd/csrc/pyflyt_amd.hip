@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     V.b.contact_step = false;
     V.template control<MODE_T>(P, sp);
     for (int t = 0; t < P.ticks_per_control; ++t) {
-      world_exchange(V.b, wpose, tid, A, P);  // (dogfight.hpp)
+      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev);  // (dogfight.hpp)
       V.tick(P, nz.get(flat_base + t));
     }
     V.b.peer_contact = false;
@@ -919,7 +919,15 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
   hipStream_t s = (hipStream_t)stream;
   if (P.task == PF_TASK_DOGFIGHT) {
     const int lpw = (64 / P.agents_per_world) * P.agents_per_world;  // whole worlds per wave
-    hipLaunchKernelGGL(pf::dogfight_env_kernel, dim3((ctx->n + lpw - 1) / lpw), dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->P_dev);
+    const dim3 grid((ctx->n + lpw - 1) / lpw);
+#define PF_DF(AA) hipLaunchKernelGGL(pf::dogfight_env_kernel<AA>, grid, dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->P_dev)
+    switch (P.agents_per_world) {
+      case 2: PF_DF(2); break;
+      case 4: PF_DF(4); break;
+      case 6: PF_DF(6); break;
+      default: PF_DF(8); break;
+    }
+#undef PF_DF
   } else if (ctx->fast) {
     if (P.task == PF_TASK_HOVER) launch_fast<PF_TASK_HOVER>(ctx, b, op, mask, s);
     else if (P.task == PF_TASK_MA_HOVER) launch_fast<PF_TASK_MA_HOVER>(ctx, b, op, mask, s);

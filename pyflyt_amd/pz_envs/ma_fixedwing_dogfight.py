@@ -13,9 +13,12 @@ Differences from the reference, by construction of the batched path:
     [num_envs, ...] (squeezed to the reference's per-agent vectors when num_envs == 1);
   * the spawn circle of every copy is drawn from the counter-based RNG (Philox keyed by seed and the copy's first lane), not
     from `np.random.RandomState(seed)`: the same distribution (:176-213), a different stream;
-  * `flatten_observation=False` (a Dict of a fixed part and a variable-length Sequence) is not offered: the device writes
-    the flattened, zero-padded vector, which is what the reference's default returns;
-  * `assisted_flight=False` (six raw actuator commands) is not offered.
+  * `flatten_observation=False`: the device always writes the flattened, zero-padded vector; the Dict form is a host-side
+    view of it -- {"self": [23], "others": [k, 14]} with the k active others exactly as in the reference when num_envs == 1,
+    and {"self": [E, 23], "others": [E, A - 1, 14] zero padded, "others_mask": [E, A - 1]} for num_envs > 1 (a Sequence
+    space has no batched form);
+  * `assisted_flight=False` is not offered. (In the reference it only widens the action to six numbers: the Aviary stays in
+    mode 0 (ma_fixedwing_base_env.py:229), which reads setpoint[0:4]; the thrust remap then lands on the unused sixth entry.)
 """
 from __future__ import annotations
 
@@ -45,8 +48,7 @@ class MAFixedwingDogfightEnv:
             raise ValueError("rendering is out of scope for the batched GPU path")
         if not assisted_flight:
             raise NotImplementedError("assisted_flight=False (raw actuator commands) is not available on the batched path")
-        if not flatten_observation:
-            raise NotImplementedError("flatten_observation=False (Dict + variable-length Sequence) is not available on the batched path")
+        self.flatten_observation = bool(flatten_observation)
         if 120 % agent_hz != 0:  # ma_fixedwing_base_env.py:52-57
             lowest, highest = int(120 / (int(120 / agent_hz) + 1)), int(120 / int(120 / agent_hz))
             raise AssertionError(f"`agent_hz` must be round denominator of 120, try {lowest} or {highest}.")
@@ -96,6 +98,17 @@ class MAFixedwingDogfightEnv:
         t = t.view(E, A, *t.shape[1:])
         return [t[:, i].squeeze(0) if E == 1 else t[:, i] for i in range(A)]
 
+    def _obs_out(self, o):
+        """The observation of one agent in the form `flatten_observation` asks for (pop_obs_by_id, :724-752)."""
+        if self.flatten_observation:
+            return o
+        A = self.num_possible_agents
+        if self.num_envs == 1:
+            rows = o[23:].view(A - 1, 14)
+            return {"self": o[:23], "others": rows[rows.abs().sum(dim=1) > 0]}  # active others only, in index order (:523-541)
+        rows = o[:, 23:].view(self.num_envs, A - 1, 14)
+        return {"self": o[:, :23], "others": rows, "others_mask": rows.abs().sum(dim=2) > 0}
+
     @property
     def healths(self):
         """[num_envs, agents] float32 (self.healths of the reference)."""
@@ -122,7 +135,7 @@ class MAFixedwingDogfightEnv:
         self.agents = self.possible_agents[:]
         self.engine.env_reset()
         obs = self._split(self.engine.obs)
-        return {ag: obs[i] for i, ag in enumerate(self.possible_agents)}, {ag: dict() for ag in self.agents}
+        return {ag: self._obs_out(obs[i]) for i, ag in enumerate(self.possible_agents)}, {ag: dict() for ag in self.agents}
 
     # ------------------------------------------------------------------ ma_fixedwing_base_env.py:272-334
     def step(self, actions: dict):
@@ -138,7 +151,7 @@ class MAFixedwingDogfightEnv:
         observations, rewards, terminations, truncations, infos = {}, {}, {}, {}, {}
         for ag in self.agents:
             i = self.agent_name_mapping[ag]
-            observations[ag], rewards[ag], terminations[ag], truncations[ag] = o[i], r[i], t[i], u[i]
+            observations[ag], rewards[ag], terminations[ag], truncations[ag] = self._obs_out(o[i]), r[i], t[i], u[i]
             infos[ag] = {"health": health[i], "received_hits": hits[i], "dead": (bits[i] & _DF_DEAD) != 0,
                          "collision": (bits[i] & _DF_COLLISION) != 0, "out_of_bounds": (bits[i] & _DF_OOB) != 0,
                          "team_win": (bits[i] & _DF_TEAM_WIN) != 0}

@@ -264,3 +264,23 @@ def test_dogfight_pz_api(team_size):
     env.reset(seed=5)
     assert not torch.equal(env.start_pos, spawn0)
     env.close()
+
+
+def test_dogfight_pz_dict_observation():
+    """flatten_observation=False: the reference's Dict form as a view of the flattened vector."""
+    from pyflyt_amd.pz_envs import MAFixedwingDogfightEnv
+
+    env = MAFixedwingDogfightEnv(team_size=2, flatten_observation=False, seed=2)
+    flat = MAFixedwingDogfightEnv(team_size=2, flatten_observation=True, seed=2)
+    o1, _ = env.reset(seed=2)
+    o2, _ = flat.reset(seed=2)
+    for a in env.possible_agents:
+        assert o1[a]["self"].shape == (23,) and o1[a]["others"].shape == (3, 14)
+        assert torch.equal(torch.cat([o1[a]["self"], o1[a]["others"].flatten()]), o2[a])
+    env.close(); flat.close()
+    env = MAFixedwingDogfightEnv(team_size=1, flatten_observation=False, num_envs=5, seed=2)
+    o, _ = env.reset()
+    assert o["uav_0"]["self"].shape == (5, 23) and o["uav_0"]["others"].shape == (5, 1, 14) and o["uav_0"]["others_mask"].all()
+    env.close()
+    with pytest.raises(NotImplementedError):
+        MAFixedwingDogfightEnv(assisted_flight=False)

@@ -28,5 +28,9 @@ timeout 100 python $R/bench.py --batch 4096 --steps 2000 --warmup 200 --no-cpu-b
 timeout 100 python $R/bench.py --batch 524288 --steps 300 --warmup 50 --no-cpu-baseline --rollout-steps 50 2>/dev/null | tail -1 > $O/bench_b524288.json
 timeout 100 python $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --world contact_response=1 2>/dev/null | tail -1 > $O/bench_contact_response_on.json
 timeout 100 python $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline --scaling strong 2>/dev/null | tail -1 > $O/bench_strong_n1.json
+# the dogfight task (auxiliary figure): bench line + kernel trace, and step time against the population's state
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dogfight -- python $R/bench.py --env dogfight --steps 150 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
+timeout 100 python $R/bench.py --env dogfight --steps 150 --warmup 20 2>/dev/null | tail -1 > $O/bench_dogfight.json
+timeout 200 python $R/scratch/dog_diag.py 2>/dev/null | grep "^steps" > $O/dogfight_step_time_vs_population.txt
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O; ls $O

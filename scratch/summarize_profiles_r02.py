@@ -11,7 +11,8 @@ src, dst = os.path.join(R, "gpurun_out", "r02"), os.path.join(R, "profiles", "r0
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "bench_*.json")):
     shutil.copy(f, dst)
-for tag, name in (("kt", "hover65536"), ("kt_quadx_waypoints", "quadx_waypoints65536"), ("kt_fixedwing_waypoints", "fixedwing_waypoints65536")):
+for tag, name in (("kt", "hover65536"), ("kt_quadx_waypoints", "quadx_waypoints65536"), ("kt_fixedwing_waypoints", "fixedwing_waypoints65536"),
+                  ("kt_dogfight", "dogfight65536")):
     for f in glob.glob(os.path.join(src, tag, "*", "*kernel_stats.csv")):
         shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_bench_{name}.csv"))
     for f in glob.glob(os.path.join(src, tag, "*", "*domain_stats.csv")):
@@ -59,6 +60,8 @@ json.dump(summary, open(os.path.join(dst, "pmc_summary_hover65536.json"), "w"), 
 json.dump({"env": "hover", "batch": 65536, "hbm_bytes_per_launch": summary["step"]["hbm_bytes_per_env_step"],
            "source": "profiles/r02/pmc_summary_hover65536.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per guide)"},
           open(os.path.join(R, "profiles", "pmc_latest.json"), "w"), indent=1)
+if os.path.exists(os.path.join(src, "dogfight_step_time_vs_population.txt")):
+    shutil.copy(os.path.join(src, "dogfight_step_time_vs_population.txt"), dst)
 for f in sorted(glob.glob(os.path.join(dst, "bench_*.json"))):
     d = json.load(open(f)); r = d["roofline"]; ro = d.get("rollout")
     print(os.path.basename(f), "value %.3e" % d["value"], "launch_us %.2f frac %.3f" % (r["launch_us"], r["frac"]),

@@ -181,6 +181,10 @@ typedef struct pf_params {
    * flag), zero padded to 23 + 14 (A - 1) (:519-549, :724-752). pf_env_step pops reward / terminated / truncated for the
    * agents still in the episode (PettingZoo parallel API: finished agents are culled, their aircraft fly on with zero
    * commands, ma_fixedwing_base_env.py:289-330); pf_params.autoreset must be PF_AUTORESET_OFF. */
+  /* Filled in by pf_ctx_create (callers leave it 0): the most contact points the contact solve can see for this airframe --
+   * its collider vertices (8 per box, 16 per cylinder), at most PF_MAX_CONTACTS. Sizes the solver's LDS regions, i.e. how many
+   * lanes of a wave can be solved side by side. */
+  int32_t contact_max_points;
   int32_t df_team_size, df_sample_spawn;
   float df_spawn_min_radius, df_spawn_max_radius;
   float df_damage_per_hit, df_lethal_distance, df_lethal_angle, df_aggressiveness, df_cooperativeness;

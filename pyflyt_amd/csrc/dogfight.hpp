@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   Fixedwing V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)tile;
-  V.b.cslots = kTile / kContactSlotFloats;  // as many solver regions as fit the idle observation tile
+  V.b.contact_regions(P, kTile);  // as many solver regions as fit the idle observation tile
   V.bind(ktab);
   float nd_unused;
   int4 ints;

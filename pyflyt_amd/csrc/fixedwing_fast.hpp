@@ -499,11 +499,12 @@ struct FwHot {
       act = (fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop);
     }
     if (__any(act)) {
+      const int stride = Pfull->contact_max_points * kContactWords;
       contact_rounds(act && Pfull->contact_response, cws, [&](lds_fptr slot) {
         const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
         v = o.v; w = o.w;
         lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
-      });
+      }, min(64, (64 * 35) / stride), stride);
     }
     p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, K.half_dt);

@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)tile;  // (idle during the physics ticks)
+  V.b.contact_regions(P, kWave * kMaxObs);
   V.bind(ktab);
   SideBlock tg;
   float new_dist;
@@ -434,6 +435,7 @@ __global__ void settle_template_kernel(const pf_params P, float4* tmpl, const pf
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
+  V.b.contact_regions(P, kContactSlots * kContactSlotFloats);
   V.bind(ktab);
   float sp[6] = {0, 0, 0, 0, 0, 0};
   V.reset(P, nullptr, sp);
@@ -517,6 +519,7 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
+  V.b.contact_regions(P, kContactSlots * kContactSlotFloats);
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -592,6 +595,7 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
+  V.b.contact_regions(P, kContactSlots * kContactSlotFloats);
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -663,6 +667,7 @@ __global__ void __launch_bounds__(kWave) body_tick_kernel(const pf_params P, con
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
+  V.b.contact_regions(P, kContactSlots * kContactSlotFloats);
   float nd;
   int4 ints;
   float4* S = reinterpret_cast<float4*>(B.state);
@@ -840,6 +845,11 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
+  {  // the airframe's worst-case contact count (collider vertices), see pf_params.contact_max_points
+    int pts = 0;
+    for (int k = 0; k < P.n_boxes; ++k) pts += P.boxes[k].kind == 1 ? 16 : 8;
+    c->P.contact_max_points = pts < 1 ? 1 : (pts > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : pts);
+  }
   c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr;
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
   pf::FwTable fsurf;
@@ -849,7 +859,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
     hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
-    if (e == hipSuccess) e = hipMemcpy(c->P_dev, &P, sizeof(pf_params), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->P_dev, &c->P, sizeof(pf_params), hipMemcpyHostToDevice);
     if (e == hipSuccess && c->fast_fw) {
       e = hipMalloc((void**)&c->surf_dev, sizeof(fsurf));
       if (e == hipSuccess) e = hipMemcpy(c->surf_dev, &fsurf, sizeof(fsurf), hipMemcpyHostToDevice);
@@ -868,8 +878,8 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     hipError_t e = hipMalloc((void**)&c->tmpl, sizeof(float4) * groups);
     if (e == hipSuccess) e = hipMemset(c->tmpl, 0, sizeof(float4) * groups);
     if (e == hipSuccess) {
-      if (P.vehicle == PF_QUADX) hipLaunchKernelGGL(pf::settle_template_kernel<pf::QuadX>, dim3(1), dim3(64), 0, 0, P, c->tmpl, c->P_dev);
-      else hipLaunchKernelGGL(pf::settle_template_kernel<pf::Fixedwing>, dim3(1), dim3(64), 0, 0, P, c->tmpl, c->P_dev);
+      if (P.vehicle == PF_QUADX) hipLaunchKernelGGL(pf::settle_template_kernel<pf::QuadX>, dim3(1), dim3(64), 0, 0, c->P, c->tmpl, c->P_dev);
+      else hipLaunchKernelGGL(pf::settle_template_kernel<pf::Fixedwing>, dim3(1), dim3(64), 0, 0, c->P, c->tmpl, c->P_dev);
       e = hipDeviceSynchronize();
     }
     if (cur >= 0) hipSetDevice(cur);

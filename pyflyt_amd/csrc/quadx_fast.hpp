@@ -155,6 +155,7 @@ struct QuadHot {
   PF_DEV float thr(int i) const { return i == 0 ? t01.x : i == 1 ? t01.y : i == 2 ? t23.x : t23.y; }
   bool contact_now, contact_step;
   lds_fptr cws;  // the wave's LDS regions for the contact solver (aliased onto the observation tile, idle during the ticks)
+  int cws_floats;
 
   PF_DEV void derive() {
     // btMatrix3x3::setRotation scales by 2/|q|^2; q leaves quat_integrate()/the spawn normalised to
@@ -284,11 +285,14 @@ struct QuadHot {
         act = (fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop);
       }
       if (__any(act)) {
+        // regions sized for this airframe's own contact count: the single box needs 8 x 11 floats, 26 lanes per round
+        const int stride = Pfull->contact_max_points * kContactWords;
+        const int slots = min(64, cws_floats / stride);
         contact_rounds(act, cws, [&](lds_fptr slot) {
           const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v(), w());
           set_wv(o.w, o.v);
           lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
-        });
+        }, slots, stride);
       }
     }
     p = v3{fmaf(K.dt, wvx.y, p.x), fmaf(K.dt, wvy.y, p.y), CR ? fmaf(K.dt, wvz.y, p.z) + lift : fmaf(K.dt, wvz.y, p.z)};
@@ -338,6 +342,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   QuadHot V;
   static_assert(LPW * kMaxD >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
   V.cws = (lds_fptr)tile;
+  V.cws_floats = LPW * kMaxD;
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;

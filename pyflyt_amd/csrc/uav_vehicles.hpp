@@ -179,13 +179,15 @@ __device__ __noinline__ ContactOut contact_solve_var_dev(const pf_params* __rest
 }
 // Deal the kContactSlots LDS regions out to the lanes of the (currently active part of the) wave that need the solver,
 // by ballot rank, in as many rounds as it takes. `solve(slot_base)` runs the solver for this lane.
+// slots x stride floats behind `ws`: the callers size the regions for the airframe's own contact count (pf_params.contact_max_points:
+// a quadrotor's single box needs 8 x 11 floats, so 29 lanes fit where the worst case fits 4).
 template <class F>
-PF_DEV void contact_rounds(bool need, lds_fptr ws, F&& solve, const int slots = kContactSlots) {
+PF_DEV void contact_rounds(bool need, lds_fptr ws, F&& solve, const int slots = kContactSlots, const int stride = kContactSlotFloats) {
   unsigned long long m = __ballot(need);
   while (m != 0ull) {
     const int rank = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
     if (need && rank < slots) {
-      solve(ws + rank * kContactSlotFloats);
+      solve(ws + rank * stride);
       need = false;
     }
     m = __ballot(need);
@@ -202,7 +204,14 @@ struct Body {
   v3 rpy;       // quadx.py:526 (refreshed once per Aviary step)
   bool contact_now, contact_step;
   // shared world (PF_TASK_MA_HOVER with agents_per_world > 1); both false for a drone that is alone in its world
-  int cslots = kContactSlots;  // LDS regions behind `cws` (kernels with a larger idle tile hand out more per round)
+  int cslots = kContactSlots, cstride = kContactSlotFloats;  // LDS regions behind `cws`: how many, how far apart (contact_regions)
+  // `floats` of LDS behind cws, cut into regions of this airframe's own worst-case contact count
+  PF_DEV void contact_regions(const pf_params& P, int floats) {
+    const int pts = (P.contact_max_points > 0 && P.contact_max_points <= PF_MAX_CONTACTS) ? P.contact_max_points : PF_MAX_CONTACTS;
+    cstride = pts * kContactWords;
+    cslots = floats / cstride;
+    cslots = cslots > 64 ? 64 : cslots;
+  }
   bool world_contact = false;  // a contact point anywhere in the world after the previous tick (quadx.py:509)
   bool peer_contact = false;   // this tick's drone-drone verdict for this body
 
@@ -288,7 +297,7 @@ struct Body {
       const ContactOut o = contact_solve_dev(Pd, slot, p, q, v, w);
       v = o.v; w = o.w;
       lift = Pd->contact_erp * o.deepest;  // (deepest: already net of the slop)
-    }, cslots);
+    }, cslots, cstride);
     return lift;
   }
   PF_DEV float respond_var(const pf_params* Pd, float inv_mass, v3 com, const float Iinv[6]) {
@@ -298,7 +307,7 @@ struct Body {
       const ContactOut o = contact_solve_var_dev(Pd, slot, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
       v = o.v; w = o.w;
       lift = Pd->contact_erp * o.deepest;
-    }, cslots);
+    }, cslots, cstride);
     return lift;
   }
   // The same tick for a body whose mass properties change over time (Rocket): inverse mass, centre of

@@ -185,7 +185,11 @@ typedef struct pf_params {
    * its collider vertices (8 per box, 16 per cylinder), at most PF_MAX_CONTACTS. Sizes the solver's LDS regions, i.e. how many
    * lanes of a wave can be solved side by side. */
   int32_t contact_max_points;
-  int32_t df_team_size, df_sample_spawn;
+  /* df_freeze_wrecks (default 0 = the reference's behaviour: a crashed aircraft keeps tumbling in the physics until it comes
+   * to rest): 1 = an aircraft stops where it hits the ground -- velocities zeroed, not integrated any further, `inactive` from
+   * the next update on. Nothing an agent is rewarded for depends on a wreck's tumbling; it spares the contact solve, which
+   * otherwise dominates the step time of every wave that has an aircraft on the ground. */
+  int32_t df_team_size, df_sample_spawn, df_freeze_wrecks;
   float df_spawn_min_radius, df_spawn_max_radius;
   float df_damage_per_hit, df_lethal_distance, df_lethal_angle, df_aggressiveness, df_cooperativeness;
   pf_rocket rocket;

@@ -34,7 +34,8 @@ enum {  // group 6, word 3
   DF_ACC_TERM = 2,   // accumulated_terminations / _truncations (sticky over the episode)
   DF_ACC_TRUNC = 4,
   DF_INACTIVE = 8,   // dead, on the ground and at rest (:505-510)
-  DF_INFO_DEAD = 16, DF_INFO_COLLISION = 32, DF_INFO_OOB = 64, DF_INFO_TEAM_WIN = 128
+  DF_INFO_DEAD = 16, DF_INFO_COLLISION = 32, DF_INFO_OOB = 64, DF_INFO_TEAM_WIN = 128,
+  DF_FROZEN = 256    // df_freeze_wrecks: stopped where it hit the ground
 };
 
 PF_DEV void lds_sync_wave() {  // one wave per workgroup: LDS traffic ordered, no s_barrier needed
@@ -163,12 +164,17 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     // observation -- is not integrated any further (the reference keeps stepping it in Bullet; nothing observable depends on
     // that, and a world of wrecks would otherwise run the contact solve on every lane in every tick). It keeps its resting
     // contact: the collision verdict of :667-670 stays up.
-    const bool wreck = (df & DF_INACTIVE) != 0;
+    const bool wreck = (df & (DF_INACTIVE | DF_FROZEN)) != 0;
     for (int t = 0; t < P.ticks_per_control; ++t) {
       world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev);
       if (!wreck) V.tick(P, nz.get(flat_base + t));
     }
     if (wreck) V.b.contact_step = V.b.contact_now;
+    if (P.df_freeze_wrecks && V.b.contact_step && V.b.p.z < P.bound_radius + P.contact_margin) {  // (opt-in) stops where it hits the ground
+      V.b.v = v3{0.f, 0.f, 0.f}; V.b.w = v3{0.f, 0.f, 0.f};
+      V.b.derive();
+      df |= DF_FROZEN;  // no further integration; update_states() finds it inactive (dead, low, at rest) one update later
+    }
     V.b.peer_contact = false;
     V.b.rpy = euler_from_quat_fast(V.b.q);
   };
@@ -336,7 +342,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
       const float vel[3] = {20.0f * cy * cp, 20.0f * sy * cp, -20.0f * spp};  // :216-222
       V.reset(P, pose, sp, vel);
       step_count = 0; flags = 0;
-      health = 1.0f; acc = 0.0f; received_hits = 0; df = DF_ALIVE;
+      health = 1.0f; acc = 0.0f; received_hits = 0; df = DF_ALIVE;  // (clears DF_FROZEN too)
 #pragma unroll
       for (int j = 0; j < A; ++j) { cur_d[j] = 0.0f; cur_ang[j] = 0.0f; }
       nz.begin_event(rng_ctr, 1u, B.xi_reset);

@@ -17,6 +17,9 @@ Differences from the reference, by construction of the batched path:
     view of it -- {"self": [23], "others": [k, 14]} with the k active others exactly as in the reference when num_envs == 1,
     and {"self": [E, 23], "others": [E, A - 1, 14] zero padded, "others_mask": [E, A - 1]} for num_envs > 1 (a Sequence
     space has no batched form);
+  * `freeze_wrecks=True` (default False = the reference's behaviour) stops an aircraft where it hits the ground instead of
+    letting it tumble to rest: it leaves the others' observations one update later, and the step time of a world with
+    wrecks stays that of a world in flight (the contact solve of a tumbling airframe is the most expensive thing here);
   * `assisted_flight=False` is not offered. (In the reference it only widens the action to six numbers: the Aviary stays in
     mode 0 (ma_fixedwing_base_env.py:229), which reads setpoint[0:4]; the thrust remap then lands on the unused sixth entry.)
 """
@@ -43,7 +46,8 @@ class MAFixedwingDogfightEnv:
                  lethal_distance: float = 20.0, lethal_angle_radians: float = 0.07, assisted_flight: bool = True,
                  aggressiveness: float = 0.5, cooperativeness: float = 0.5, sparse_reward: bool = False,
                  flatten_observation: bool = True, flight_dome_size: float = 800.0, max_duration_seconds: float = 60.0,
-                 agent_hz: int = 30, render_mode=None, num_envs: int = 1, device="cuda:0", seed: int = 0, motor_noise: bool = True):
+                 agent_hz: int = 30, render_mode=None, num_envs: int = 1, device="cuda:0", seed: int = 0, motor_noise: bool = True,
+                 freeze_wrecks: bool = False):
         if render_mode is not None:
             raise ValueError("rendering is out of scope for the batched GPU path")
         if not assisted_flight:
@@ -66,7 +70,8 @@ class MAFixedwingDogfightEnv:
         self.device = torch.device(device)
         self._df = dict(team_size=self.team_size, spawn_min_radius=spawn_min_radius, spawn_max_radius=spawn_max_radius,
                         damage_per_hit=damage_per_hit, lethal_distance=lethal_distance, lethal_angle=lethal_angle_radians,
-                        aggressiveness=aggressiveness, cooperativeness=cooperativeness, sample_spawn=True)
+                        aggressiveness=aggressiveness, cooperativeness=cooperativeness, sample_spawn=True,
+                        freeze_wrecks=bool(freeze_wrecks))
         self._kw = dict(flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds, agent_hz=agent_hz,
                         sparse_reward=sparse_reward)
         self._noise = "philox" if motor_noise else "off"

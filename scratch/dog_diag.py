@@ -5,7 +5,13 @@ import torch
 import bench
 from pyflyt_amd import _lib as PL
 n = int(os.environ.get("N", "65536"))
-eng = bench.make_engine("dogfight", n, torch.device("cuda:0"), 0, "philox")
+if os.environ.get("FREEZE"):
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+    eng = BatchEngine(build_params("fixedwing", "dogfight", noise="philox", autoreset="off", seed=0, angle_representation="euler", vehicle_options=dict(drone_model="acrowing"),
+                                   world_options=dict(world_scale=5.0), dogfight=dict(freeze_wrecks=True)), n, device="cuda:0")
+else:
+    eng = bench.make_engine("dogfight", n, torch.device("cuda:0"), 0, "philox")
 ring = [torch.empty(n, 4, device="cuda:0") for _ in range(50)]
 for i, a in enumerate(ring):
     eng.sample_actions(a, i); a.mul_(float(os.environ.get("AMP", "0.15"))); a[:, 3] += 0.4

@@ -284,3 +284,41 @@ def test_dogfight_pz_dict_observation():
     env.close()
     with pytest.raises(NotImplementedError):
         MAFixedwingDogfightEnv(assisted_flight=False)
+
+
+def test_dogfight_freeze_wrecks():
+    """dogfight=dict(freeze_wrecks=True): an aircraft stops where it hits the ground and leaves the others' observations within
+    two updates; until the impact the trajectory is the default one bit for bit; nobody else is affected afterwards."""
+    g = np.load(os.path.join(GOLD, "env_dogfight_crash.npz"))
+    kw = dict(flight_dome_size=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0)
+    a, A = _engine(1, "inject", **kw)
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+    P = build_params("fixedwing", "dogfight", noise="inject", autoreset="off", angle_representation="euler", vehicle_options=dict(drone_model="acrowing"),
+                     world_options=dict(world_scale=5.0), dogfight=dict(sample_spawn=False, freeze_wrecks=True), **kw)
+    b = BatchEngine(P, A, device="cuda:0")
+    for e in (a, b):
+        _set_spawn(e, g["start_pos"], g["start_orn"])
+        e.env_reset(xi_reset=torch.tensor(g["reset_xi"], dtype=torch.float32, device="cuda:0").contiguous())
+    hit = None
+    for k in range(len(g["action"])):
+        act = torch.tensor(g["action"][k], dtype=torch.float32, device="cuda:0")
+        xi = torch.tensor(g["xi"][k], dtype=torch.float32, device="cuda:0").contiguous()
+        oa = a.env_step(act, xi=xi)[0].clone()
+        ob = b.env_step(act, xi=xi)[0].clone()
+        from pyflyt_amd import _lib as PL
+        if hit is None:
+            assert torch.equal(a.state[:6], b.state[:6]) or bool((b.flags() & PL.F_CONTACT).any()), k
+            if bool((b.flags() & PL.F_CONTACT).any()):
+                hit = k
+        else:
+            # the aircraft that never touched the ground fly on identically (drone-drone coupling aside: none here)
+            fly = [i for i in range(A) if not bool(b.flags()[i] & PL.F_CONTACT)]
+            assert torch.equal(a.state[:5, fly], b.state[:5, fly]), k
+            if k >= hit + 2:
+                wreck = [i for i in range(A) if i not in fly]
+                assert (b.state[6, wreck, 3].view(torch.int32) & 8).ne(0).all()          # inactive
+                assert (b.state[2, wreck, :3].abs().max() == 0)                           # at rest where it hit
+                rows = ob[fly[0]][23:].view(A - 1, 14)
+                assert int((rows.abs().sum(1) > 0).sum()) == A - 1 - len(wreck)           # gone from the survivors' observations
+    assert hit is not None and hit > 50

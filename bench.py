@@ -137,7 +137,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     # per-GPU slice; no collective in the timed loop
-    shard = weak_shard(args.batch, rank, world) if args.scaling == "weak" else strong_shard(args.batch, rank, world)
+    shard = weak_shard(args.batch, rank, world) if args.scaling == "weak" else strong_shard(args.batch, rank, world, unit=4 if args.env == "dogfight" else 1)
     n = shard.lanes
     eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise, contact_response=not args.no_contact_response, world=args.world)
     g = max(1, min(args.graph_steps, args.steps))

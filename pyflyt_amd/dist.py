@@ -26,16 +26,18 @@ def weak_shard(lanes_per_rank: int, rank: int, world: int) -> Shard:
     """Weak scaling: every rank owns `lanes_per_rank` lanes (BASELINE config 5: 65 536 per GPU)."""
     if not (0 <= rank < world) or lanes_per_rank <= 0:
         raise ValueError("bad shard arguments")
+    # (a shared world never straddles ranks as long as lanes_per_rank is a multiple of agents_per_world: pf_ctx_create checks it)
     return Shard(rank, world, lanes_per_rank, rank * lanes_per_rank, world * lanes_per_rank)
 
 
-def strong_shard(global_lanes: int, rank: int, world: int) -> Shard:
-    """Strong scaling: a fixed global batch cut into contiguous, near-equal slices."""
-    if not (0 <= rank < world) or global_lanes < world:
+def strong_shard(global_lanes: int, rank: int, world: int, unit: int = 1) -> Shard:
+    """Strong scaling: a fixed global batch cut into contiguous, near-equal slices. `unit`: lanes that must stay together
+    (the agents of a shared world: pf_params.agents_per_world) -- slices are whole multiples of it."""
+    if not (0 <= rank < world) or unit < 1 or global_lanes % unit != 0 or global_lanes // unit < world:
         raise ValueError("bad shard arguments")
-    base, rem = divmod(global_lanes, world)
-    lanes = base + (1 if rank < rem else 0)
-    off = rank * base + min(rank, rem)
+    base, rem = divmod(global_lanes // unit, world)
+    lanes = (base + (1 if rank < rem else 0)) * unit
+    off = (rank * base + min(rank, rem)) * unit
     return Shard(rank, world, lanes, off, global_lanes)
 
 

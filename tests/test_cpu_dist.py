@@ -19,6 +19,11 @@ from pyflyt_amd.dist import max_over_ranks, strong_shard, weak_shard  # noqa: E4
 def test_shard_plans():
     s = [weak_shard(65536, r, 8) for r in range(8)]
     assert [x.lane_offset for x in s] == [r * 65536 for r in range(8)] and s[0].global_lanes == 524288
+    u = [strong_shard(1000, r, 3, unit=4) for r in range(3)]  # shared worlds of 4 lanes never straddle ranks
+    assert sum(x.lanes for x in u) == 1000 and all(x.lanes % 4 == 0 and x.lane_offset % 4 == 0 for x in u)
+    assert [x.lane_offset for x in u] == [0, u[0].lanes, u[0].lanes + u[1].lanes]
+    with pytest.raises(ValueError):
+        strong_shard(1002, 0, 3, unit=4)
     t = [strong_shard(1000, r, 3) for r in range(3)]
     assert [x.lanes for x in t] == [334, 333, 333] and [x.lane_offset for x in t] == [0, 334, 667]
     assert sum(x.lanes for x in t) == 1000

@@ -118,15 +118,22 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, lds_fptr w
   const float Iw[6] = {dot(r0, c0), dot(r0, c1), dot(r0, c2), dot(r1, c1), dot(r1, c2), dot(r2, c2)};
   v3 vc = v + cross(w, cw);
   // per contact, once: the normal velocity the sweeps start from and the three inverse effective masses
-  // 1 / (1/m + dir . ((I_w^-1 (a x dir)) x a)) -- iteration invariant, and a division each
+  // 1 / (1/m + e_d . ((I_w^-1 (a x e_d)) x a)) -- iteration invariant, and a division each.
+  // The three constraint directions are the world axes (normal +z, friction +x, +y), written out component by component: with
+  // `dir` as a vector the compiler may not drop the multiplications by its zeros (IEEE: 0 * x is not 0 for every x), and
+  // they were 40 % of this function's instructions.
+  const float I0 = Iw[0], I1 = Iw[1], I2 = Iw[2], I3 = Iw[3], I4 = Iw[4], I5 = Iw[5];
+  // angular response I_w^-1 (a x e_d) of a unit impulse along e_d at arm a
+  auto ang_z = [&](const v3 a) { return v3{fmaf(I0, a.y, -(I1 * a.x)), fmaf(I1, a.y, -(I3 * a.x)), fmaf(I2, a.y, -(I4 * a.x))}; };
+  auto ang_x = [&](const v3 a) { return v3{fmaf(I1, a.z, -(I2 * a.y)), fmaf(I3, a.z, -(I4 * a.y)), fmaf(I4, a.z, -(I5 * a.y))}; };
+  auto ang_y = [&](const v3 a) { return v3{fmaf(I2, a.x, -(I0 * a.z)), fmaf(I4, a.x, -(I1 * a.z)), fmaf(I5, a.x, -(I2 * a.z))}; };
   for (int c = 0; c < n; ++c) {
     const v3 a{W(c, 0), W(c, 1), W(c, 2)};
-    W(c, 6) = vc.z + cross(w, a).z;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
-      W(c, 8 + d) = 1.0f / (inv_mass + dot(dir, cross(symmul(Iw, cross(a, dir)), a)));
-    }
+    W(c, 6) = vc.z + fmaf(w.x, a.y, -(w.y * a.x));
+    const v3 gz = ang_z(a), gx = ang_x(a), gy = ang_y(a);
+    W(c, 8) = frcp(inv_mass + fmaf(gz.x, a.y, -(gz.y * a.x)));   // e_z . (g x a)
+    W(c, 9) = frcp(inv_mass + fmaf(gx.y, a.z, -(gx.z * a.y)));   // e_x . (g x a)
+    W(c, 10) = frcp(inv_mass + fmaf(gy.z, a.x, -(gy.x * a.z)));  // e_y . (g x a)
   }
   const float mu = P->contact_friction, rest = P->contact_restitution;
   for (int it = 0; it < P->contact_iters; ++it) {
@@ -134,30 +141,34 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, lds_fptr w
     for (int c = 0; c < n; ++c) {
       const v3 a{W(c, 0), W(c, 1), W(c, 2)};
       const float vn0 = W(c, 6), dep = W(c, 7);
-      float lam[3] = {W(c, 3), W(c, 4), W(c, 5)};
-      const float kinv[3] = {W(c, 8), W(c, 9), W(c, 10)};
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {  // normal +z, friction +x, friction +y
-        const v3 dir = d == 0 ? v3{0.f, 0.f, 1.f} : (d == 1 ? v3{1.f, 0.f, 0.f} : v3{0.f, 1.f, 0.f});
-        const v3 ang = symmul(Iw, cross(a, dir));
-        const v3 u = vc + cross(w, a);
-        float target = 0.0f;
-        if (d == 0) target = dep < slop ? (dep - slop) * inv_dt  // may close the gap down to the slop, no more
-                                        : (vn0 < 0.0f ? -rest * vn0 : 0.0f);
-        float dl = (target - dot(u, dir)) * kinv[d], nl;
-        if (d == 0) {
-          nl = __builtin_fmaxf(lam[0] + dl, 0.0f);
-        } else {
-          const float lim = mu * lam[0];
-          nl = __builtin_fminf(__builtin_fmaxf(lam[d] + dl, -lim), lim);
-        }
-        dl = nl - lam[d];
-        lam[d] = nl;
-        changed |= dl != 0.0f;
-        vc = vc + (inv_mass * dl) * dir;
-        w = w + dl * ang;
-      }
-      W(c, 3) = lam[0]; W(c, 4) = lam[1]; W(c, 5) = lam[2];
+      const float l0 = W(c, 3), l1 = W(c, 4), l2 = W(c, 5);
+      const float k0 = W(c, 8), k1 = W(c, 9), k2 = W(c, 10);
+      // normal (+z): may close the gap down to the slop, no more; otherwise towards restitution x approach speed
+      const float target = dep < slop ? (dep - slop) * inv_dt : (vn0 < 0.0f ? -rest * vn0 : 0.0f);
+      const float un = vc.z + fmaf(w.x, a.y, -(w.y * a.x));
+      const float n0 = __builtin_fmaxf(fmaf(target - un, k0, l0), 0.0f);
+      float dl = n0 - l0;
+      changed |= dl != 0.0f;
+      v3 g = ang_z(a);
+      vc.z = fmaf(inv_mass, dl, vc.z);
+      w = v3{fmaf(dl, g.x, w.x), fmaf(dl, g.y, w.y), fmaf(dl, g.z, w.z)};
+      // friction (+x, +y): clamped to mu x the normal impulse
+      const float lim = mu * n0;
+      const float ux = vc.x + fmaf(w.y, a.z, -(w.z * a.y));
+      const float n1 = __builtin_fminf(__builtin_fmaxf(fmaf(-ux, k1, l1), -lim), lim);
+      dl = n1 - l1;
+      changed |= dl != 0.0f;
+      g = ang_x(a);
+      vc.x = fmaf(inv_mass, dl, vc.x);
+      w = v3{fmaf(dl, g.x, w.x), fmaf(dl, g.y, w.y), fmaf(dl, g.z, w.z)};
+      const float uy = vc.y + fmaf(w.z, a.x, -(w.x * a.z));
+      const float n2 = __builtin_fminf(__builtin_fmaxf(fmaf(-uy, k2, l2), -lim), lim);
+      dl = n2 - l2;
+      changed |= dl != 0.0f;
+      g = ang_y(a);
+      vc.y = fmaf(inv_mass, dl, vc.y);
+      w = v3{fmaf(dl, g.x, w.x), fmaf(dl, g.y, w.y), fmaf(dl, g.z, w.z)};
+      W(c, 3) = n0; W(c, 4) = n1; W(c, 5) = n2;
     }
     if (!changed) break;  // a sweep that moved nothing: every further sweep would repeat it exactly
   }

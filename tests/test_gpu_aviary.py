@@ -677,7 +677,9 @@ def test_landing_parity(drone, model, z0, tilt, steps, settle, impact_tol, stric
         assert ok_late.all()             # and the quad is back inside 1e-4 once the transient is over
     assert rest.mean() >= min_rest
     if rest.any():
-        assert dz[rest].max() < 1e-4 and dang[rest].max() < 1e-3  # same resting pose wherever the oracle has come to rest
+        # same resting pose wherever the oracle has come to rest. Heights inside the contact model's dead band (constraints allow
+        # contact_slop = 1 mm of overlap and nothing pushes a body out of it) depend on the impact history: half the band
+        assert dz[rest].max() < 5e-4 and dang[rest].max() < 1e-3
         gr = g[rest]
         assert np.abs(gr[:, 2]).max() < 5e-2 and np.abs(gr[:, 0]).max() < 5e-2  # and the device is (all but) at rest there too
     env.disconnect()

@@ -213,6 +213,24 @@ def test_dogfight_engagements_vs_oracle():
     assert ev["hits"] > 500 and ev["dead"] > 0 and ev["win"] > 0 and ev["trunc"] > 0
 
 
+def test_dogfight_masked_reset_whole_worlds():
+    eng, A = _engine(8, "philox", seed=3, sample_spawn=True)
+    eng.env_reset()
+    act = torch.zeros(eng.n, 4, device="cuda:0"); act[:, 3] = 0.3
+    for _ in range(5):
+        eng.env_step(act)
+    before = eng.state.clone()
+    mask = torch.zeros(eng.n, dtype=torch.bool, device="cuda:0"); mask[2 * A:3 * A] = True  # world 2 only
+    eng.env_reset(mask=mask)
+    keep = ~mask
+    assert torch.equal(eng.state[:, keep], before[:, keep])                 # the other worlds are untouched
+    assert (eng.state[6, mask, 0] == 1.0).all() and (eng.state[5, mask, 0].view(torch.int32) == 0).all()  # health 1, step_count 0
+    assert not torch.equal(eng.state[13, mask], before[13, mask])           # a new spawn circle (the event counter moved on)
+    bad = torch.zeros(eng.n, dtype=torch.bool, device="cuda:0"); bad[1] = True
+    with pytest.raises(ValueError):
+        eng.env_reset(mask=bad)
+
+
 def test_dogfight_refusals():
     from pyflyt_amd import PyFlytAmdError, build_params
     from pyflyt_amd.engine import BatchEngine

@@ -28,6 +28,9 @@ constexpr int kWave = 64;
 constexpr int kMaxObs = 40;  // 13 + 4 + 6 + 3*4 = 35 (Fixedwing), 13 + 4 + 4 + 4*4 = 37 (QuadX with yaw targets)
 
 enum { OP_STEP = 0, OP_RESET = 1 };
+// Aviary-level kernels (where bodies land and stay landed): 16.5 KB of LDS for the contact solve -- eight worst-case airframes
+// (48 collider vertices) or 48 quadrotors side by side per round
+constexpr int kAviaryContactFloats = 8 * kContactSlotFloats;
 
 // ------------------------------------------------------------------ per-task side block
 // 12 floats per lane in state groups G_TGT..G_TGT+2:
@@ -431,11 +434,11 @@ __global__ void settle_template_kernel(const pf_params P, float4* tmpl, const pf
   VEH::fill_table(ktab, Pdev, threadIdx.x);
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  __shared__ float cws[kContactSlots * kContactSlotFloats];
+  __shared__ float cws[kAviaryContactFloats];
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
-  V.b.contact_regions(P, kContactSlots * kContactSlotFloats);
+  V.b.contact_regions(P, kAviaryContactFloats);
   V.bind(ktab);
   float sp[6] = {0, 0, 0, 0, 0, 0};
   V.reset(P, nullptr, sp);
@@ -515,11 +518,11 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   const size_t li = lane, N = n;
-  __shared__ float cws[kContactSlots * kContactSlotFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
+  __shared__ float cws[kAviaryContactFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
-  V.b.contact_regions(P, kContactSlots * kContactSlotFloats);
+  V.b.contact_regions(P, kAviaryContactFloats);
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -591,11 +594,11 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   const size_t li = lane, N = n;
   constexpr bool kQuad = VEH::AUX == 4;
   constexpr int kCmdGroup = 12;
-  __shared__ float cws[kContactSlots * kContactSlotFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
+  __shared__ float cws[kAviaryContactFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
-  V.b.contact_regions(P, kContactSlots * kContactSlotFloats);
+  V.b.contact_regions(P, kAviaryContactFloats);
   V.bind(ktab);
   float nd;
   int4 ints;
@@ -663,11 +666,11 @@ __global__ void __launch_bounds__(kWave) body_tick_kernel(const pf_params P, con
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   const size_t li = lane, N = n;
-  __shared__ float cws[kContactSlots * kContactSlotFloats];
+  __shared__ float cws[kAviaryContactFloats];
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
-  V.b.contact_regions(P, kContactSlots * kContactSlotFloats);
+  V.b.contact_regions(P, kAviaryContactFloats);
   float nd;
   int4 ints;
   float4* S = reinterpret_cast<float4*>(B.state);

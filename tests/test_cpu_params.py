@@ -125,3 +125,26 @@ def test_fixedwing_task_constants_match():
     assert P.min_height == pytest.approx(Q.min_height, rel=1e-6) and bool(P.throttle_remap) == bool(Q.throttle_remap)
     np.testing.assert_allclose(list(P.start_pos), list(Q.start_pos))
     np.testing.assert_allclose(list(P.start_vel), list(Q.start_vel))
+
+
+def test_dogfight_task_constants():
+    """PF_TASK_DOGFIGHT parameter block against MAFixedwingDogfightEnv's constructor defaults (ma_fixedwing_dogfight_env.py:42-60)
+    and the base env's Aviary arguments (ma_fixedwing_base_env.py:193-210)."""
+    from pyflyt_amd import _lib as L
+    from pyflyt_amd.params import build_params
+
+    P = build_params("fixedwing", "dogfight", autoreset="off", angle_representation="euler", vehicle_options=dict(drone_model="acrowing"),
+                     world_options=dict(world_scale=5.0))
+    assert P.task == L.TASK_DOGFIGHT and P.df_team_size == 2 and P.agents_per_world == 4 and P.df_sample_spawn == 1 and P.df_freeze_wrecks == 0
+    assert (P.df_spawn_min_radius, P.df_spawn_max_radius) == (10.0, 50.0)
+    assert abs(P.df_damage_per_hit - 0.003) < 1e-9 and P.df_lethal_distance == 20.0 and abs(P.df_lethal_angle - 0.07) < 1e-9
+    assert P.df_aggressiveness == 0.5 and P.df_cooperativeness == 0.5
+    assert P.dome == 800.0 and P.max_steps == 1800 and P.env_step_ratio == 4 and P.throttle_remap == 1 and P.flight_mode == 0
+    assert P.plane_half_xy == 75.0 and P.plane_half_z == 25.0 and P.contact_response == 1  # world_scale 5; wrecks come to rest on the floor
+    assert abs(P.motor_fmax[0] - 30.0) < 1e-4  # acrowing.yaml:2
+    Pf = build_params("fixedwing", "dogfight", autoreset="off", angle_representation="euler", vehicle_options=dict(drone_model="acrowing"),
+                      dogfight=dict(team_size=3, freeze_wrecks=True))
+    assert Pf.agents_per_world == 6 and Pf.df_freeze_wrecks == 1 and Pf.contact_response == 0
+    import pytest
+    with pytest.raises(ValueError):
+        build_params("quadx", "dogfight")

@@ -303,7 +303,8 @@ def test_single_env_seeding_and_spaces(env_id):
     env1.close(); env2.close()
 
 
-@pytest.mark.parametrize("script,args", [("01_vector_env.py", ["4096"]), ("02_aviary_position_control.py", []), ("03_wind_field.py", [])])
+@pytest.mark.parametrize("script,args", [("01_vector_env.py", ["4096"]), ("02_aviary_position_control.py", []), ("03_wind_field.py", []),
+                                         ("04_team_dogfight.py", ["256"])])
 def test_examples_run(script, args):
     import os
     import subprocess

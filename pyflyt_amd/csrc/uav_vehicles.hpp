@@ -71,7 +71,17 @@ constexpr int kContactSlotFloats = PF_MAX_CONTACTS * kContactWords;  // 528
 constexpr int kContactSlots = 4;
 typedef __attribute__((address_space(3))) float* lds_fptr;
 // (inlined into the two out-of-line entry points below)
-PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
+// The parameter block as the solver reads it: a wave-uniform pointer into the constant address space, so that every field --
+// and the collision boxes, indexed by a uniform loop counter -- comes through the scalar cache (s_load). Inside an out-of-line
+// function the plain pointer argument lives in VGPRs, and its fields were a chain of flat loads at full memory latency with one
+// lane active: most of the 25 us a quadrotor's solve took.
+typedef const pf_params __attribute__((address_space(4)))* pf_params_kptr;
+PF_DEV pf_params_kptr uniform_params(const pf_params* P) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(P);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (pf_params_kptr)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+}
+PF_DEV ContactOut contact_solve_impl(const pf_params_kptr P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
                                      float i0, float i1, float i2, float i3, float i4, float i5) {
   auto W = [&](int c, int f) -> __attribute__((address_space(3))) float& { return ws[c * kContactWords + f]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth, 8-10 1/k
   const m3 R = rot_from_quat(q);
@@ -81,7 +91,10 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, lds_fptr w
   int n = 0;
   float deepest = 0.0f;
   for (int k = 0; k < P->n_boxes; ++k) {
-    const pf_box b = P->boxes[k];
+    pf_box b;  // (field by field: a struct copy out of the constant address space has no constructor)
+    b.c[0] = P->boxes[k].c[0]; b.c[1] = P->boxes[k].c[1]; b.c[2] = P->boxes[k].c[2];
+    b.h[0] = P->boxes[k].h[0]; b.h[1] = P->boxes[k].h[1]; b.h[2] = P->boxes[k].h[2];
+    b.kind = P->boxes[k].kind; b.yaw = P->boxes[k].yaw;
     float sy = 0.0f, cy = 1.0f;
     if (b.yaw != 0.0f) sincosf(b.yaw, &sy, &cy);
     const int nv = b.kind == 1 ? 16 : 8;
@@ -179,14 +192,15 @@ PF_DEV ContactOut contact_solve_impl(const pf_params* __restrict__ P, lds_fptr w
 // Constant mass properties (QuadX, Fixedwing): read from the parameter block inside the call, so that the call passes 16
 // dwords -- all in registers; with the ten mass-property words as arguments the last three went over the stack and gave
 // every caller a private segment.
-__device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w) {
+__device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict__ Pg, lds_fptr ws, v3 p, quat q, v3 v, v3 w) {
+  const pf_params_kptr P = uniform_params(Pg);
   const v3 com = P->has_com_offset ? v3{P->com[0], P->com[1], P->com[2]} : v3{0.f, 0.f, 0.f};
   return contact_solve_impl(P, ws, p, q, v, w, P->inv_mass, com, P->I_inv[0], P->I_inv[1], P->I_inv[2], P->I_inv[3], P->I_inv[4], P->I_inv[5]);
 }
 // Mass properties that change per tick (Rocket): passed by value.
 __device__ __noinline__ ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
                                                          float i0, float i1, float i2, float i3, float i4, float i5) {
-  return contact_solve_impl(P, ws, p, q, v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
+  return contact_solve_impl(uniform_params(P), ws, p, q, v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
 }
 // Deal the kContactSlots LDS regions out to the lanes of the (currently active part of the) wave that need the solver,
 // by ballot rank, in as many rounds as it takes. `solve(slot_base)` runs the solver for this lane.

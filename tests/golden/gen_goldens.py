@@ -592,6 +592,11 @@ def gen_dogfight():
             return rec
 
         run("env_dogfight_default", 80, lambda k, i, g: g.uniform(-1.0, 1.0, size=4), seed=3, max_duration_seconds=2.5)
+        # the other team sizes of the reference's own test matrix (tests/test_pz_envs.py: 1, 2, 3) and the sparse reward
+        run("env_dogfight_team1_sparse", 40, lambda k, i, g: g.uniform(-0.3, 0.3, size=4) + np.array([0, 0, 0, 0.4]), seed=11, team_size=1,
+            sparse_reward=True, max_duration_seconds=1.0, lethal_distance=80.0, lethal_angle_radians=0.8)
+        run("env_dogfight_team3", 40, lambda k, i, g: g.uniform(-0.3, 0.3, size=4) + np.array([0, 0, 0, 0.4]), seed=12, team_size=3,
+            max_duration_seconds=1.0, lethal_distance=80.0, lethal_angle_radians=0.8, damage_per_hit=0.01)
 
         # four aircraft 40 m up: 0 chases 2 from behind, 3 chases 1; a gentle random wobble on top of level flight
         pos = np.array([[0.0, 0.0, 40.0], [60.0, 35.0, 42.0], [25.0, 1.0, 40.5], [35.0, 34.0, 41.5]])

@@ -49,7 +49,7 @@ def _rel(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
 
-@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash"])
+@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash", "env_dogfight_team1_sparse", "env_dogfight_team3"])
 def test_dogfight_golden_replay(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     E = 16  # copies of the recorded world side by side (one wave)

@@ -404,7 +404,7 @@ def test_ma_quadx_hover_shared_world_trajectory(golden_dir):
     assert not outs[0][2][0] and not outs[1][2][0]  # alone, agents 0 and 1 do not terminate at the step of the hit
 
 
-@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash"])
+@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash", "env_dogfight_team1_sparse", "env_dogfight_team3"])
 def test_dogfight_trajectory(golden_dir, name):
     """MAFixedwingDogfightEnv (ma_fixedwing_dogfight_env.py) recorded from the reference's env on fake_bullet, replayed through
     orc_dogfight_*: observation (self + the others in the own body frame, inactive aircraft dropped, zero padded), the

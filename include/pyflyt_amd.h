@@ -189,7 +189,11 @@ typedef struct pf_params {
    * to rest): 1 = an aircraft stops where it hits the ground -- velocities zeroed, not integrated any further, `inactive` from
    * the next update on. Nothing an agent is rewarded for depends on a wreck's tumbling; it spares the contact solve, which
    * otherwise dominates the step time of every wave that has an aircraft on the ground. */
-  int32_t df_team_size, df_sample_spawn, df_freeze_wrecks;
+  /* df_action_dim: 4 (assisted_flight=True, the default; 0 means 4) or 6 (assisted_flight=False). pf_buffers.actions is then
+   * [n][df_action_dim]. With 6 the reference still leaves the Aviary in flight mode 0 (ma_fixedwing_base_env.py:229), which reads
+   * setpoint[0:4] (fixedwing.py:246-250): entries 4 and 5 only appear in the observation's past action, and the thrust remap
+   * of :300-301 lands on entry 5 -- the thrust command is action[3] as given. Reproduced as it is. */
+  int32_t df_team_size, df_sample_spawn, df_freeze_wrecks, df_action_dim;
   float df_spawn_min_radius, df_spawn_max_radius;
   float df_damage_per_hit, df_lethal_distance, df_lethal_angle, df_aggressiveness, df_cooperativeness;
   pf_rocket rocket;
@@ -198,7 +202,7 @@ typedef struct pf_params {
 /* Device buffers of one call. state layout: float4 groups, [n_groups][n_lanes][4]. */
 typedef struct pf_buffers {
   float* state;            /* [pf_state_groups()][n][4] fp32/int32, persistent */
-  const float* actions;    /* [n][4]   gym action (quadx_base_env.py:269) */
+  const float* actions;    /* [n][4]   gym action (quadx_base_env.py:269); PF_TASK_DOGFIGHT with df_action_dim 6: [n][6] */
   float* obs;              /* [n][pf_obs_dim()] row-major */
   float* final_obs;        /* [n][pf_obs_dim()] or NULL; written for finished lanes under SAME_STEP */
   float* reward;           /* [n] */

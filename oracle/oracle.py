@@ -140,7 +140,7 @@ class Dogfight(C.Structure):
         ("A", C.c_int), ("team_size", C.c_int),
         ("damage_per_hit", C.c_double), ("lethal_distance", C.c_double), ("lethal_angle", C.c_double),
         ("aggressiveness", C.c_double), ("cooperativeness", C.c_double), ("sparse_reward", C.c_int),
-        ("dome", C.c_double), ("max_steps", C.c_int), ("env_step_ratio", C.c_int),
+        ("dome", C.c_double), ("max_steps", C.c_int), ("env_step_ratio", C.c_int), ("action_dim", C.c_int),
         ("step_count", C.c_int), ("alive", C.c_int * DF_MAX), ("health", C.c_double * DF_MAX),
         ("received_hits", C.c_int * DF_MAX), ("inactive", C.c_int * DF_MAX),
         ("cur_dist", _dfm), ("cur_ang", _dfm), ("prev_dist", _dfm), ("prev_ang", _dfm),
@@ -148,8 +148,8 @@ class Dogfight(C.Structure):
         ("other_att", ((C.c_double * 12) * DF_MAX) * DF_MAX),
         ("acc_reward", C.c_double * DF_MAX), ("acc_term", C.c_int * DF_MAX), ("acc_trunc", C.c_int * DF_MAX),
         ("info_bits", C.c_int * DF_MAX),
-        ("action", (C.c_double * 4) * DF_MAX), ("past_action", (C.c_double * 4) * DF_MAX),
-        ("obs", (C.c_double * (23 + (DF_MAX - 1) * 14)) * DF_MAX),
+        ("action", (C.c_double * 6) * DF_MAX), ("past_action", (C.c_double * 6) * DF_MAX),
+        ("obs", (C.c_double * (25 + (DF_MAX - 1) * 14)) * DF_MAX),
         ("reward", C.c_double * DF_MAX), ("terminated", C.c_int * DF_MAX), ("truncated", C.c_int * DF_MAX),
     ]
 
@@ -301,7 +301,7 @@ class OracleWorld:
 
 DOGFIGHT_DEFAULTS = dict(team_size=2, spawn_min_radius=10.0, spawn_max_radius=50.0, damage_per_hit=0.003, lethal_distance=20.0,
                          lethal_angle=0.07, aggressiveness=0.5, cooperativeness=0.5, sparse_reward=False, dome=800.0,
-                         max_duration_seconds=60.0, agent_hz=30)  # ma_fixedwing_dogfight_env.py:42-60
+                         max_duration_seconds=60.0, agent_hz=30, assisted_flight=True)  # ma_fixedwing_dogfight_env.py:42-60
 
 
 def dogfight_spawn(team_size, min_radius, max_radius, u):
@@ -343,7 +343,9 @@ class OracleDogfight:
         D.damage_per_hit, D.lethal_distance, D.lethal_angle = cfg["damage_per_hit"], cfg["lethal_distance"], cfg["lethal_angle"]
         D.aggressiveness, D.cooperativeness, D.sparse_reward = cfg["aggressiveness"], cfg["cooperativeness"], int(cfg["sparse_reward"])
         D.dome, D.max_steps, D.env_step_ratio = cfg["dome"], self.max_steps, self.env_step_ratio
-        self.obs_dim = 23 + (self.A - 1) * 14
+        self.action_dim = 4 if cfg["assisted_flight"] else 6
+        D.action_dim = self.action_dim
+        self.obs_dim = 19 + self.action_dim + (self.A - 1) * 14
 
     _rows = OracleWorld._rows
 
@@ -352,7 +354,7 @@ class OracleDogfight:
         return self.obs()
 
     def step(self, actions, xi=None):
-        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.A, 4)
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.A, self.action_dim)
         lib().orc_dogfight_step(self._pp, self._lp, C.byref(self.D), _dp(a), self._rows(xi))
         D = self.D
         return (self.obs(), np.array(D.reward[:self.A]), np.array(D.terminated[:self.A], dtype=bool), np.array(D.truncated[:self.A], dtype=bool))

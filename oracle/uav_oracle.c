@@ -1503,7 +1503,8 @@ static void dogfight_update_states(const orc_params* const* Pl, orc_lane* const*
     D->inactive[i] = (D->health[i] <= 0.0) && (att[i][11] < 2.0) && (sqrt(sp2) < 0.1); /* :505-510 */
     dist_origin[i] = sqrt(att[i][9] * att[i][9] + att[i][10] * att[i][10] + att[i][11] * att[i][11]);
   }
-  const int Dobs = 23 + (A - 1) * 14;
+  const int AD = D->action_dim == 6 ? 6 : 4;
+  const int Dobs = 19 + AD + (A - 1) * 14;
   for (int i = 0; i < A; ++i) { /* :519-549, pop_obs_by_id :724-752 (flattened, zero padded) */
     double* o = D->obs[i];
     int k = 0;
@@ -1512,7 +1513,7 @@ static void dogfight_update_states(const orc_params* const* Pl, orc_lane* const*
     for (int c = 0; c < 5; ++c) o[k++] = Ll[i]->actuation[c]; /* aviary.aux_state(i): fixedwing.py:289-291 */
     o[k++] = Ll[i]->throttle[0];
     o[k++] = D->health[i];
-    for (int c = 0; c < 4; ++c) o[k++] = D->past_action[i][c];
+    for (int c = 0; c < AD; ++c) o[k++] = D->past_action[i][c];
     for (int j = 0; j < A; ++j) {
       if (j == i || D->inactive[j]) continue;
       for (int c = 0; c < 12; ++c) o[k++] = D->other_att[i][j][c];
@@ -1601,13 +1602,14 @@ void orc_dogfight_reset(const orc_params* const* Pl, orc_lane* const* Ll, orc_do
 
 void orc_dogfight_step(const orc_params* const* Pl, orc_lane* const* Ll, orc_dogfight* D, const double* actions, const double* const* xi) {
   const int A = D->A;
+  const int AD = D->action_dim == 6 ? 6 : 4;
   for (int i = 0; i < A; ++i) { /* ma_fixedwing_base_env.py:289-302 */
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < AD; ++k) {
       D->past_action[i][k] = D->action[i][k];
-      D->action[i][k] = D->alive[i] ? actions[4 * i + k] : 0.0;
-      Ll[i]->setpoint[k] = D->action[i][k];
+      D->action[i][k] = D->alive[i] ? actions[AD * i + k] : 0.0;
     }
-    Ll[i]->setpoint[3] = D->action[i][3] / 2.0 + 0.5;
+    for (int k = 0; k < 4; ++k) Ll[i]->setpoint[k] = D->action[i][k]; /* mode 0 reads setpoint[0:4] */
+    if (AD == 4) Ll[i]->setpoint[3] = D->action[i][3] / 2.0 + 0.5;      /* aviary_action[..., -1] = a / 2 + 0.5: entry 5 of a 6-wide action */
   }
   const int tpc = Pl[0]->world.ticks_per_control;
   const double* xs[ORC_DF_MAX];

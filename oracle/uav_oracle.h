@@ -228,6 +228,11 @@ typedef struct {
   int sparse_reward;
   double dome;
   int max_steps, env_step_ratio;
+  /* assisted_flight (:52, ma_fixedwing_base_env.py:69): 4 = roll, pitch, yaw, thrust commands; 6 = the "raw actuator" action space.
+   * With 6 the reference still leaves the Aviary in flight mode 0 (ma_fixedwing_base_env.py:229), which reads setpoint[0:4]
+   * (fixedwing.py:246-250): entries 4 and 5 are ignored, and the thrust remap of :300-301 lands on entry 5 -- the thrust
+   * command is action[3] as given. Restated as it is. */
+  int action_dim;
   /* state */
   int step_count;
   int alive[ORC_DF_MAX];          /* still in self.agents */
@@ -241,8 +246,8 @@ typedef struct {
   double acc_reward[ORC_DF_MAX];  /* accumulated_rewards / _terminations / _truncations / infos (:651-722) */
   int acc_term[ORC_DF_MAX], acc_trunc[ORC_DF_MAX];
   int info_bits[ORC_DF_MAX];      /* 1 dead, 2 collision, 4 out_of_bounds, 8 team_win (sticky over the episode) */
-  double action[ORC_DF_MAX][4], past_action[ORC_DF_MAX][4];
-  double obs[ORC_DF_MAX][23 + (ORC_DF_MAX - 1) * 14];
+  double action[ORC_DF_MAX][6], past_action[ORC_DF_MAX][6];
+  double obs[ORC_DF_MAX][25 + (ORC_DF_MAX - 1) * 14];
   /* popped by the last step for the agents that were alive */
   double reward[ORC_DF_MAX];
   int terminated[ORC_DF_MAX], truncated[ORC_DF_MAX];

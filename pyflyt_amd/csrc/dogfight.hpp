@@ -18,7 +18,8 @@
 //
 // State groups (float4 each, [group][lane]): 0-5 the Fixedwing vehicle's (body, surfaces, ints); 6 (health, accumulated
 // reward, received hits, dogfight flags); 7 current action; 8 past action; 9-10 this lane's row of current_distances;
-// 11-12 its row of current_angles; 13 (spawn x, y, z, roll); 14 (spawn pitch, yaw, -, -).
+// 11-12 its row of current_angles; 13 (spawn x, y, z, roll); 14 (spawn pitch, yaw, -, -); 15 (current action 4, 5; past action
+// 4, 5: six-wide actions only, df_action_dim).
 #pragma once
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
@@ -28,7 +29,7 @@ namespace pf {
 
 constexpr int kDfMaxAgents = 8;
 constexpr int kDfMaxObs = 23 + (kDfMaxAgents - 1) * 14;  // 121
-constexpr int kDfGroups = 15;
+constexpr int kDfGroups = 16;
 enum {  // group 6, word 3
   DF_ALIVE = 1,      // still in self.agents
   DF_ACC_TERM = 2,   // accumulated_terminations / _truncations (sticky over the episode)
@@ -101,8 +102,10 @@ constexpr int kDfRec = 28;
 template <int A>
 __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, const pf_buffers B, const int n, const uint64_t lane0,
                                                           const int op, const uint8_t* mask, const pf_params* __restrict__ Pdev) {
-  constexpr int D = 23 + (A - 1) * 14;
-  constexpr int kTile = 64 * D > kContactSlots * kContactSlotFloats ? 64 * D : kContactSlots * kContactSlotFloats;
+  constexpr int Dmax = 25 + (A - 1) * 14;  // (six-wide actions: two more past-action entries)
+  constexpr int kTile = 64 * Dmax > kContactSlots * kContactSlotFloats ? 64 * Dmax : kContactSlots * kContactSlotFloats;
+  const int AD = P.df_action_dim == 6 ? 6 : 4;
+  const int D = 19 + AD + (A - 1) * 14;
   __shared__ float tile[kTile];
   __shared__ float ktab[Fixedwing::TABLE_FLOATS];
   __shared__ float wpose[64 * 8];
@@ -138,6 +141,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   float health = g6.x, acc = g6.y;
   int received_hits = __float_as_int(g6.z), df = __float_as_int(g6.w);
   float4 cur_a4 = Sin[7 * N + li], past_a4 = Sin[8 * N + li];
+  float4 a45 = Sin[15 * N + li];  // current action 4, 5; past action 4, 5 (six-wide actions)
   float cur_d[A], cur_ang[A];
   {
     const float4 a = Sin[9 * N + li], b = Sin[10 * N + li], c = Sin[11 * N + li], d = Sin[12 * N + li];
@@ -249,6 +253,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
       for (int a = 0; a < 6; ++a) row[k++] = aux[a];
       row[k++] = health;
       row[k++] = past_a4.x; row[k++] = past_a4.y; row[k++] = past_a4.z; row[k++] = past_a4.w;
+      if (AD == 6) { row[k++] = a45.z; row[k++] = a45.w; }
       for (int j = 0; j < A; ++j) {
         if (j == wlocal) continue;
         const float* o = rec + (wbase + j) * kDfRec;
@@ -356,10 +361,13 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     }
   } else {
     // ---------------------------------------------------------------- step (ma_fixedwing_base_env.py:272-334)
-    const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
+    const float* ap = B.actions + (size_t)AD * li;
+    const float4 a = float4{ap[0], ap[1], ap[2], ap[3]};
     past_a4 = cur_a4;
     cur_a4 = (df & DF_ALIVE) ? a : float4{0.f, 0.f, 0.f, 0.f};  // culled agents: zero commands (:293-297)
-    sp[0] = cur_a4.x; sp[1] = cur_a4.y; sp[2] = cur_a4.z; sp[3] = fmaf(cur_a4.w, 0.5f, 0.5f);  // :300-301
+    if (AD == 6) a45 = float4{(df & DF_ALIVE) ? ap[4] : 0.f, (df & DF_ALIVE) ? ap[5] : 0.f, a45.x, a45.y};
+    // :300-301 remaps the LAST action entry; mode 0 (the Aviary's mode whatever assisted_flight says, :229) reads entries 0..3
+    sp[0] = cur_a4.x; sp[1] = cur_a4.y; sp[2] = cur_a4.z; sp[3] = AD == 4 ? fmaf(cur_a4.w, 0.5f, 0.5f) : cur_a4.w;
     nz.begin_event(rng_ctr, 0u, B.xi);
     for (int s = 0; s < P.env_step_ratio; ++s) {
       world_aviary_step(s * P.ticks_per_control);
@@ -404,6 +412,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     Sout[12 * N + li] = float4{ra[4], ra[5], ra[6], ra[7]};
     Sout[13 * N + li] = sp_a;
     Sout[14 * N + li] = sp_b;
+    Sout[15 * N + li] = a45;
     if (op == 0) {
       B.reward[li] = out_reward;
       B.terminated[li] = out_term ? 1 : 0;

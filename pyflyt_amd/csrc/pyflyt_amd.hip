@@ -827,6 +827,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     if (P.autoreset != PF_AUTORESET_OFF) return fail(nullptr, PF_ERR_ARG, "the multi-agent env has no auto-reset (PettingZoo parallel API)");
     if (P.angle_repr != 0) return fail(nullptr, PF_ERR_UNSUPPORTED, "the dogfight env observes Euler angles (ma_fixedwing_dogfight_env.py:92)");
     if (P.n_surf != PF_MAX_SURF || P.n_motors != 1) return fail(nullptr, PF_ERR_ARG, "dogfight: a five-surface, one-motor airframe");
+    if (P.df_action_dim != 0 && P.df_action_dim != 4 && P.df_action_dim != 6) return fail(nullptr, PF_ERR_ARG, "dogfight: df_action_dim is 4 or 6");
   }
   if (P.agents_per_world > 1) {
     if (!((P.vehicle == PF_QUADX && P.task == PF_TASK_MA_HOVER) || P.task == PF_TASK_DOGFIGHT))
@@ -904,7 +905,7 @@ int pf_state_groups(const pf_ctx* ctx) {
 }
 int pf_obs_dim(const pf_ctx* ctx) {
   const pf_params& P = ctx->P;
-  if (P.task == PF_TASK_DOGFIGHT) return 23 + (P.agents_per_world - 1) * 14;  // ma_fixedwing_dogfight_env.py:128-160
+  if (P.task == PF_TASK_DOGFIGHT) return 19 + (P.df_action_dim == 6 ? 6 : 4) + (P.agents_per_world - 1) * 14;  // ma_fixedwing_dogfight_env.py:128-160
   int aux = P.vehicle == PF_QUADX ? 4 : 6;
   return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? (P.use_yaw_targets ? 4 : 3) * P.num_targets : (P.task == PF_TASK_MA_HOVER ? 3 : 0));
 }

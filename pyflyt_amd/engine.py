@@ -161,8 +161,13 @@ class BatchEngine:
             L.check(self.lib.pf_env_reset(self._ctx, C.byref(b), _ptr(mask), self._stream()), self._ctx)
         return self.obs
 
+    @property
+    def action_dim(self):
+        """Width of the env action: 4, or 6 for the dogfight task with assisted_flight=False (pf_params.df_action_dim)."""
+        return 6 if (self.params.task == L.TASK_DOGFIGHT and self.params.df_action_dim == 6) else 4
+
     def env_step(self, actions, xi=None, xi_reset=None, u_targets=None):
-        self._check_f32(actions, (self.n, 4), "actions")
+        self._check_f32(actions, (self.n, self.action_dim), "actions")
         self._check_f32(xi, (self.ticks_per_step, self.n), "xi")
         self._check_f32(xi_reset, (self.settle_ticks, self.n), "xi_reset")
         self._check_targets(u_targets)

@@ -187,6 +187,7 @@ FIXEDWING_MODELS = {"fixedwing": FIXEDWING, "acrowing": ACROWING}
 DOGFIGHT = {
     "team_size": 2, "spawn_min_radius": 10.0, "spawn_max_radius": 50.0, "damage_per_hit": 0.003, "lethal_distance": 20.0,
     "lethal_angle": 0.07, "aggressiveness": 0.5, "cooperativeness": 0.5, "sample_spawn": True,
+    "assisted_flight": True,  # False: six-wide actions (see pf_params.df_action_dim for what the reference does with them)
     "freeze_wrecks": False,  # True: an aircraft stops where it hits the ground (no tumbling, no contact solve) -- not the reference's behaviour
 }
 
@@ -493,6 +494,7 @@ def build_params(
         P.df_team_size = int(DF["team_size"])
         P.agents_per_world = 2 * P.df_team_size
         P.df_sample_spawn = int(bool(DF["sample_spawn"]))
+        P.df_action_dim = 4 if DF["assisted_flight"] else 6
         P.df_freeze_wrecks = int(bool(DF["freeze_wrecks"]))
         if P.df_freeze_wrecks and W["contact_response"] is None:
             P.contact_response = 0  # the aircraft stops at the first contact REPORT: there is nothing left for the contact solve to do

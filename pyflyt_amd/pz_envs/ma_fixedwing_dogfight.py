@@ -20,8 +20,9 @@ Differences from the reference, by construction of the batched path:
   * `freeze_wrecks=True` (default False = the reference's behaviour) stops an aircraft where it hits the ground instead of
     letting it tumble to rest: it leaves the others' observations one update later, and the step time of a world with
     wrecks stays that of a world in flight (the contact solve of a tumbling airframe is the most expensive thing here);
-  * `assisted_flight=False` is not offered. (In the reference it only widens the action to six numbers: the Aviary stays in
-    mode 0 (ma_fixedwing_base_env.py:229), which reads setpoint[0:4]; the thrust remap then lands on the unused sixth entry.)
+  * `assisted_flight=False` does what the reference does with it: the action is six numbers wide, the Aviary stays in mode 0
+    (ma_fixedwing_base_env.py:229) and reads the first four, entries 4 and 5 only show up in the observed past action, and the
+    thrust remap lands on the unused sixth entry, so the thrust command is action[3] as given (pinned by a reference trajectory).
 """
 from __future__ import annotations
 
@@ -50,8 +51,7 @@ class MAFixedwingDogfightEnv:
                  freeze_wrecks: bool = False):
         if render_mode is not None:
             raise ValueError("rendering is out of scope for the batched GPU path")
-        if not assisted_flight:
-            raise NotImplementedError("assisted_flight=False (raw actuator commands) is not available on the batched path")
+        self.assisted_flight = bool(assisted_flight)
         self.flatten_observation = bool(flatten_observation)
         if 120 % agent_hz != 0:  # ma_fixedwing_base_env.py:52-57
             lowest, highest = int(120 / (int(120 / agent_hz) + 1)), int(120 / int(120 / agent_hz))
@@ -70,14 +70,15 @@ class MAFixedwingDogfightEnv:
         self.device = torch.device(device)
         self._df = dict(team_size=self.team_size, spawn_min_radius=spawn_min_radius, spawn_max_radius=spawn_max_radius,
                         damage_per_hit=damage_per_hit, lethal_distance=lethal_distance, lethal_angle=lethal_angle_radians,
-                        aggressiveness=aggressiveness, cooperativeness=cooperativeness, sample_spawn=True,
+                        aggressiveness=aggressiveness, cooperativeness=cooperativeness, sample_spawn=True, assisted_flight=self.assisted_flight,
                         freeze_wrecks=bool(freeze_wrecks))
         self._kw = dict(flight_dome_size=flight_dome_size, max_duration_seconds=max_duration_seconds, agent_hz=agent_hz,
                         sparse_reward=sparse_reward)
         self._noise = "philox" if motor_noise else "off"
         self._seed = int(seed)
         self._build(self._seed)
-        self._action_space = Box(low=-np.ones(4, dtype=np.float32), high=np.ones(4, dtype=np.float32), dtype=np.float32)
+        ad = self.engine.action_dim  # 4, or 6 with assisted_flight=False (ma_fixedwing_base_env.py:69)
+        self._action_space = Box(low=-np.ones(ad, dtype=np.float32), high=np.ones(ad, dtype=np.float32), dtype=np.float32)
         self._observation_space = Box(low=-np.inf, high=np.inf, shape=(self.engine.obs_dim,), dtype=np.float32)
         self.max_steps = self.engine.params.max_steps
         self.step_count = 0
@@ -107,12 +108,12 @@ class MAFixedwingDogfightEnv:
         """The observation of one agent in the form `flatten_observation` asks for (pop_obs_by_id, :724-752)."""
         if self.flatten_observation:
             return o
-        A = self.num_possible_agents
+        A, S = self.num_possible_agents, 19 + self.engine.action_dim  # self block: attitude 12, aux 6, health, past action
         if self.num_envs == 1:
-            rows = o[23:].view(A - 1, 14)
-            return {"self": o[:23], "others": rows[rows.abs().sum(dim=1) > 0]}  # active others only, in index order (:523-541)
-        rows = o[:, 23:].view(self.num_envs, A - 1, 14)
-        return {"self": o[:, :23], "others": rows, "others_mask": rows.abs().sum(dim=2) > 0}
+            rows = o[S:].view(A - 1, 14)
+            return {"self": o[:S], "others": rows[rows.abs().sum(dim=1) > 0]}  # active others only, in index order (:523-541)
+        rows = o[:, S:].view(self.num_envs, A - 1, 14)
+        return {"self": o[:, :S], "others": rows, "others_mask": rows.abs().sum(dim=2) > 0}
 
     @property
     def healths(self):
@@ -145,11 +146,12 @@ class MAFixedwingDogfightEnv:
     # ------------------------------------------------------------------ ma_fixedwing_base_env.py:272-334
     def step(self, actions: dict):
         A, E = self.num_possible_agents, self.num_envs
-        act = torch.zeros(E, A, 4, dtype=torch.float32, device=self.device)
+        ad = self.engine.action_dim
+        act = torch.zeros(E, A, ad, dtype=torch.float32, device=self.device)
         for k, v in actions.items():
             v = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v), dtype=torch.float32)
-            act[:, self.agent_name_mapping[k]] = v.to(self.device).view(E, 4)
-        obs, rew, term, trunc = self.engine.env_step(act.view(E * A, 4))
+            act[:, self.agent_name_mapping[k]] = v.to(self.device).view(E, ad)
+        obs, rew, term, trunc = self.engine.env_step(act.view(E * A, ad))
         side = self.engine.state[6]
         o, r, t, u = self._split(obs), self._split(rew), self._split(term), self._split(trunc)
         health, hits, bits = self._split(side[:, 0]), self._split(side[:, 2].view(torch.int32)), self._split(side[:, 3].view(torch.int32))

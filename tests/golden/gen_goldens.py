@@ -573,7 +573,7 @@ def gen_dogfight():
                 alive = np.array([a in env.agents for a in env.possible_agents])
                 acts = {a: policy(k, env.agent_name_mapping[a], prng) for a in env.agents}
                 obs, rew, term, trunc, infos = env.step(acts)
-                Aa = np.zeros((A, 4)); Oo = np.full((A, D), np.nan); R = np.full(A, np.nan)
+                Aa = np.zeros((A, env.action_space(None).shape[0])); Oo = np.full((A, D), np.nan); R = np.full(A, np.nan)
                 T = np.zeros(A, bool); U = np.zeros(A, bool); B = np.zeros(A, np.int32)
                 for i, a in enumerate(env.possible_agents):
                     if a in acts:
@@ -588,6 +588,7 @@ def gen_dogfight():
                  team_size=env.team_size, max_steps=env.max_steps, env_step_ratio=env.env_step_ratio, dome=env.flight_dome_size,
                  damage_per_hit=env.damage_per_hit, lethal_distance=env.lethal_distance, lethal_angle=env.lethal_angle,
                  aggressiveness=env.aggressiveness, cooperativeness=env.cooperativeness, sparse_reward=env.sparse_reward,
+                 action_dim=env.action_space(None).shape[0],
                  **{k: np.array(v) for k, v in rec.items()})
             return rec
 
@@ -595,6 +596,9 @@ def gen_dogfight():
         # the other team sizes of the reference's own test matrix (tests/test_pz_envs.py: 1, 2, 3) and the sparse reward
         run("env_dogfight_team1_sparse", 40, lambda k, i, g: g.uniform(-0.3, 0.3, size=4) + np.array([0, 0, 0, 0.4]), seed=11, team_size=1,
             sparse_reward=True, max_duration_seconds=1.0, lethal_distance=80.0, lethal_angle_radians=0.8)
+        # assisted_flight=False: six-wide actions; the Aviary stays in mode 0 and reads the first four, the thrust remap lands on the sixth
+        run("env_dogfight_unassisted", 40, lambda k, i, g: g.uniform(-0.3, 0.3, size=6) + np.array([0, 0, 0, 0.6, 0.2, -0.4]), seed=13, assisted_flight=False,
+            max_duration_seconds=1.0, lethal_distance=80.0, lethal_angle_radians=0.8)
         run("env_dogfight_team3", 40, lambda k, i, g: g.uniform(-0.3, 0.3, size=4) + np.array([0, 0, 0, 0.4]), seed=12, team_size=3,
             max_duration_seconds=1.0, lethal_distance=80.0, lethal_angle_radians=0.8, damage_per_hit=0.01)
 

@@ -25,7 +25,7 @@ def _engine(n_worlds, noise, seed=0, sample_spawn=False, lane_offset=0, **kw):
     from pyflyt_amd.engine import BatchEngine
 
     df = dict(sample_spawn=sample_spawn)
-    for k in ("team_size", "damage_per_hit", "lethal_distance", "lethal_angle", "aggressiveness", "cooperativeness", "spawn_min_radius", "spawn_max_radius"):
+    for k in ("assisted_flight", "team_size", "damage_per_hit", "lethal_distance", "lethal_angle", "aggressiveness", "cooperativeness", "spawn_min_radius", "spawn_max_radius"):
         if k in kw:
             df[k] = kw.pop(k)
     P = build_params("fixedwing", "dogfight", noise=noise, autoreset="off", seed=seed, angle_representation="euler",
@@ -49,13 +49,16 @@ def _rel(a, b):
     return np.abs(a - b) / np.maximum(1.0, np.abs(b))
 
 
-@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash", "env_dogfight_team1_sparse", "env_dogfight_team3"])
+@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash", "env_dogfight_team1_sparse", "env_dogfight_team3",
+                                  "env_dogfight_unassisted"])
 def test_dogfight_golden_replay(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     E = 16  # copies of the recorded world side by side (one wave)
     eng, A = _engine(E, "inject", team_size=int(g["team_size"]), damage_per_hit=float(g["damage_per_hit"]), lethal_distance=float(g["lethal_distance"]),
                      lethal_angle=float(g["lethal_angle"]), aggressiveness=float(g["aggressiveness"]), cooperativeness=float(g["cooperativeness"]),
-                     sparse_reward=bool(g["sparse_reward"]), flight_dome_size=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0)
+                     sparse_reward=bool(g["sparse_reward"]), flight_dome_size=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0,
+                     assisted_flight=int(g["action_dim"]) == 4)
+    S = 19 + int(g["action_dim"])  # width of the own block
     assert eng.obs_dim == g["reset_obs"].shape[1] and int(eng.params.max_steps) == int(g["max_steps"])
     _set_spawn(eng, np.tile(g["start_pos"], (E, 1)), np.tile(g["start_orn"], (E, 1)))
     tile = lambda x: torch.tensor(np.tile(x, (1, E)), dtype=torch.float32, device="cuda:0").contiguous()  # [ticks, A] -> [ticks, n]
@@ -84,10 +87,10 @@ def test_dogfight_golden_replay(name):
                     # the crashed aircraft tumbles over the ground: chaotic in fp32 vs fp64 within a few bounces (and the step at
                     # which it comes to rest and drops out of the others' rows may differ by one). From the impact on: everybody's
                     # OWN block to the flight tolerance, the rows of the others to the impact tolerance while the layouts agree
-                    eo = _rel(o[i][:23], g["obs"][k][i][:23]).max()
+                    eo = _rel(o[i][:S], g["obs"][k][i][:S]).max()
                     worst_o = max(worst_o, eo)
                     assert eo < 5e-4, (name, k, i, eo)
-                    rows_d, rows_g = o[i][23:].reshape(A - 1, 14), g["obs"][k][i][23:].reshape(A - 1, 14)
+                    rows_d, rows_g = o[i][S:].reshape(A - 1, 14), g["obs"][k][i][S:].reshape(A - 1, 14)
                     nz_d, nz_g = np.abs(rows_d).sum(1) > 0, np.abs(rows_g).sum(1) > 0
                     if (nz_d == nz_g).all():
                         others = [j for j in range(A) if j != i]
@@ -300,8 +303,12 @@ def test_dogfight_pz_dict_observation():
     o, _ = env.reset()
     assert o["uav_0"]["self"].shape == (5, 23) and o["uav_0"]["others"].shape == (5, 1, 14) and o["uav_0"]["others_mask"].all()
     env.close()
-    with pytest.raises(NotImplementedError):
-        MAFixedwingDogfightEnv(assisted_flight=False)
+    env = MAFixedwingDogfightEnv(assisted_flight=False, flatten_observation=False, seed=2)  # six-wide actions, own block 25 wide
+    o, _ = env.reset()
+    assert env.action_space("uav_0").shape == (6,) and o["uav_0"]["self"].shape == (25,)
+    o, r, t, u, i = env.step({a: torch.zeros(6) for a in env.agents})
+    assert o["uav_0"]["self"].shape == (25,)
+    env.close()
 
 
 def test_dogfight_freeze_wrecks():

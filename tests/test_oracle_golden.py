@@ -404,7 +404,8 @@ def test_ma_quadx_hover_shared_world_trajectory(golden_dir):
     assert not outs[0][2][0] and not outs[1][2][0]  # alone, agents 0 and 1 do not terminate at the step of the hit
 
 
-@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash", "env_dogfight_team1_sparse", "env_dogfight_team3"])
+@pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash", "env_dogfight_team1_sparse", "env_dogfight_team3",
+                                  "env_dogfight_unassisted"])
 def test_dogfight_trajectory(golden_dir, name):
     """MAFixedwingDogfightEnv (ma_fixedwing_dogfight_env.py) recorded from the reference's env on fake_bullet, replayed through
     orc_dogfight_*: observation (self + the others in the own body frame, inactive aircraft dropped, zero padded), the
@@ -414,7 +415,7 @@ def test_dogfight_trajectory(golden_dir, name):
     W = O.OracleDogfight(g["start_pos"], g["start_orn"], noise_mode=O.NOISE_INJECT, team_size=int(g["team_size"]),
                          damage_per_hit=float(g["damage_per_hit"]), lethal_distance=float(g["lethal_distance"]), lethal_angle=float(g["lethal_angle"]),
                          aggressiveness=float(g["aggressiveness"]), cooperativeness=float(g["cooperativeness"]), sparse_reward=bool(g["sparse_reward"]),
-                         dome=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0)
+                         dome=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0, assisted_flight=int(g["action_dim"]) == 4)
     np.testing.assert_allclose(W.reset(xi_reset=g["reset_xi"].T), g["reset_obs"], atol=TOL)
     bits = np.zeros(W.A, dtype=int)
     for k in range(len(g["action"])):

@@ -347,3 +347,25 @@ def test_dogfight_freeze_wrecks():
                 rows = ob[fly[0]][23:].view(A - 1, 14)
                 assert int((rows.abs().sum(1) > 0).sum()) == A - 1 - len(wreck)           # gone from the survivors' observations
     assert hit is not None and hit > 50
+
+
+def test_dogfight_deterministic():
+    """pettingzoo's check_environment_deterministic_parallel in spirit (tests/test_pz_envs.py): two envs, the same seed, the same
+    actions -> bit-identical observations, rewards and flags, step after step (counter RNG, no atomics, no reductions)."""
+    from pyflyt_amd.pz_envs import MAFixedwingDogfightEnv
+
+    envs = [MAFixedwingDogfightEnv(team_size=2, num_envs=37, seed=9, max_duration_seconds=1.0, lethal_distance=80.0, lethal_angle_radians=0.6) for _ in range(2)]
+    o = [e.reset(seed=9)[0] for e in envs]
+    assert all(torch.equal(o[0][a], o[1][a]) for a in o[0])
+    g = torch.Generator().manual_seed(1)
+    for k in range(35):
+        if not envs[0].agents:
+            break
+        assert envs[0].agents == envs[1].agents
+        acts = {a: torch.rand(37, 4, generator=g) * 2 - 1 for a in envs[0].agents}
+        outs = [e.step(acts) for e in envs]
+        for a in acts:
+            for x, y in zip(outs[0][:4], outs[1][:4]):
+                assert torch.equal(x[a], y[a]), (k, a)
+    for e in envs:
+        e.close()

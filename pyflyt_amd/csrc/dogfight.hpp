@@ -24,6 +24,7 @@
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
 #include "uav_vehicles.hpp"
+#include "fixedwing_fast.hpp"
 
 namespace pf {
 
@@ -50,7 +51,8 @@ PF_DEV void lds_sync_wave() {  // one wave per workgroup: LDS traffic ordered, n
 // gate of the rotational drag (quadx.py:509). wpose: 8 floats per lane of the wave.
 // Pd: the device copy of the parameter block -- the collision boxes are indexed dynamically, which for the by-value kernel
 // argument would mean a private copy in scratch memory.
-PF_DEV void world_exchange(Body& b, float* wpose, const int tid, const int A, const float bound_radius, const pf_params* __restrict__ Pd) {
+template <class BODY>
+PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, const float bound_radius, const pf_params* __restrict__ Pd) {
   const int wbase = (tid / A) * A, wlocal = tid - wbase;
   float* me = wpose + tid * 8;
   me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
@@ -83,6 +85,81 @@ PF_DEV void world_exchange(Body& b, float* wpose, const int tid, const int A, co
   lds_sync_wave();
 }
 
+// ---------------------------------------------------------------- the aircraft
+// Two interchangeable vehicles behind the kernel: the generic Fixedwing of uav_vehicles.hpp (any five-surface airframe the
+// parameter block describes; surface constants in an LDS table) and the specialised tick of fixedwing_fast.hpp (FwHot: the
+// reference airframes' fixed structure folded away, packed-fp32 surfaces, constants through the scalar cache; 2.3x fewer
+// instructions). pf_ctx_create picks the second whenever fw_table_from_params accepts the airframe (acrowing does).
+struct DfGenericVeh : Fixedwing {
+  PF_DEV void attach(const FwTable*) {}
+};
+struct DfFastBody : FwHot {
+  v3 rpy;
+  const pf_params* pdev;
+  PF_DEV void contact_regions(const pf_params&, int floats) { cws_floats = floats; }
+};
+struct DfFastVeh {
+  static constexpr int TABLE_FLOATS = 4;
+  static PF_DEV void fill_table(float*, const pf_params*, int) {}
+  PF_DEV void bind(const float*) {}
+  DfFastBody b;
+  fw_tab_cptr tab;
+  PF_DEV void attach(const FwTable* t) { tab = (fw_tab_cptr)(uintptr_t)t; }
+  // state groups 0-5: the generic Fixedwing's layout (Fixedwing::load / store)
+  PF_DEV void load(const float4* S, size_t n, size_t i, int, float& new_dist, int4& ints) {
+    const float4 g0 = S[0 * n + i], g1 = S[1 * n + i], g2 = S[2 * n + i], g3 = S[3 * n + i], g4 = S[4 * n + i], gi = S[5 * n + i];
+    b.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
+    b.q = quat{g1.x, g1.y, g1.z, g1.w};
+    b.v = v3{g2.x, g2.y, g2.z};
+    b.w = v3{g2.w, g3.x, g3.y};
+    b.act[0] = g3.z; b.act[1] = g3.w; b.act[2] = g4.x; b.act[3] = g4.y; b.act[4] = g4.z; b.thr = g4.w;
+    ints = int4{__float_as_int(gi.x), __float_as_int(gi.y), __float_as_int(gi.z), __float_as_int(gi.w)};
+    b.contact_now = (ints.y & PF_F_CONTACT) != 0;
+    b.contact_step = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b.cmd[k] = 0.0f;
+    b.derive();
+    b.rpy = v3{0.0f, 0.0f, 0.0f};
+  }
+  PF_DEV void store(float4* S, size_t n, size_t i, int, float new_dist, int4 ints) const {
+    S[0 * n + i] = float4{b.p.x, b.p.y, b.p.z, new_dist};
+    S[1 * n + i] = float4{b.q.x, b.q.y, b.q.z, b.q.w};
+    S[2 * n + i] = float4{b.v.x, b.v.y, b.v.z, b.w.x};
+    S[3 * n + i] = float4{b.w.y, b.w.z, b.act[0], b.act[1]};
+    S[4 * n + i] = float4{b.act[2], b.act[3], b.act[4], b.thr};
+    S[5 * n + i] = float4{__int_as_float(ints.x), __int_as_float(ints.y), __int_as_float(ints.z), __int_as_float(ints.w)};
+  }
+  PF_DEV void reset(const pf_params&, const float* pose, float sp[6], const float* vel) {  // fixedwing.py:194-204
+    b.p = v3{pose[0], pose[1], pose[2]};
+    b.q = quat{pose[3], pose[4], pose[5], pose[6]};
+    b.v = v3{vel[0], vel[1], vel[2]};
+    b.w = v3{0.0f, 0.0f, 0.0f};
+    b.contact_now = false; b.contact_step = false;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) b.act[k] = 0.0f;
+    b.thr = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { sp[k] = 0.0f; b.cmd[k] = 0.0f; }
+    b.derive();
+    b.rpy = euler_from_quat_fast(b.q);
+  }
+  template <int MODE_T>
+  PF_DEV void control(const pf_params&, const float sp[6]) {  // mode 0, fixedwing.py:143-144,246-250: ids [0,0,1,2,1,3], signs [+,-,+,-,-,+]
+    b.cmd[0] = sp[0]; b.cmd[1] = -sp[0]; b.cmd[2] = sp[1]; b.cmd[3] = -sp[2]; b.cmd[4] = -sp[1]; b.cmd[5] = sp[3];
+  }
+  PF_DEV void tick(const pf_params&, float xi) { b.tick(tab, xi, b.pdev); }
+  PF_DEV void aux(float* o) const {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = b.act[k];
+    o[5] = b.thr;
+  }
+  PF_DEV bool nonfinite() const {
+    const float chk = ((b.p.x + b.p.y) + (b.p.z + b.q.x)) + ((b.q.y + b.q.z) + (b.q.w + b.v.x)) + ((b.v.y + b.v.z) + (b.w.x + b.w.y)) +
+                      ((b.w.z + b.thr) + (b.act[0] + b.act[1])) + ((b.act[2] + b.act[3]) + b.act[4]);
+    return !(__builtin_fabsf(chk) < INFINITY);
+  }
+};
+
 // sin / cos of an angle in [-pi, pi] (Euler angles): sincos_turns' exact quadrant reduction, abs error < 1e-7
 PF_DEV void sincos_angle(float a, float& s, float& c) {
   const float u = a * (0.5f / kPi);
@@ -99,19 +176,20 @@ constexpr int kDfRec = 28;
 // A: aircraft per world (2 team_size), a template parameter so that the per-row loops and register arrays have their exact size
 // and the observation tile (the biggest LDS user: 64 x (23 + 14 (A - 1)) floats) does not limit the workgroups per CU for the
 // common 2 v 2 case.
-template <int A>
+template <int A, class VEH>
 __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, const pf_buffers B, const int n, const uint64_t lane0,
-                                                          const int op, const uint8_t* mask, const pf_params* __restrict__ Pdev) {
+                                                          const int op, const uint8_t* mask, const pf_params* __restrict__ Pdev,
+                                                          const FwTable* table_g) {
   constexpr int Dmax = 25 + (A - 1) * 14;  // (six-wide actions: two more past-action entries)
   constexpr int kTile = 64 * Dmax > kContactSlots * kContactSlotFloats ? 64 * Dmax : kContactSlots * kContactSlotFloats;
   const int AD = P.df_action_dim == 6 ? 6 : 4;
   const int D = 19 + AD + (A - 1) * 14;
   __shared__ float tile[kTile];
-  __shared__ float ktab[Fixedwing::TABLE_FLOATS];
+  __shared__ float ktab[VEH::TABLE_FLOATS];
   __shared__ float wpose[64 * 8];
   __shared__ float rec[64 * kDfRec];
   const int tid = threadIdx.x;
-  Fixedwing::fill_table(ktab, Pdev, tid);
+  VEH::fill_table(ktab, Pdev, tid);
   __syncthreads();
   // a wave holds floor(64 / A) whole worlds (A = 6: ten worlds, four idle lanes): worlds never straddle a wave
   constexpr int T = A / 2;
@@ -127,7 +205,8 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   const int wbase = (tid / A) * A, wlocal = tid - wbase;
   const int my_team = wlocal >= T ? 1 : 0;
 
-  Fixedwing V;
+  VEH V;
+  V.attach(table_g);
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)tile;
   V.b.contact_regions(P, kTile);  // as many solver regions as fit the idle observation tile

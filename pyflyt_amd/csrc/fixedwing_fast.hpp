@@ -78,13 +78,13 @@ struct FwK {  // what stays in kernel-argument SGPRs for the whole kernel: env c
   float act_lo[4], act_span[4];  // action box (fixedwing_base_env.py:78-80): low, high - low (pf_rollout's on-device sampling)
 };
 
-// Fill FwK / FwTable from the ABI struct; false -> the configuration needs the generic kernel.
-inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
+// The airframe structure FwHot::tick folds away, and its constant table; false -> the generic Fixedwing vehicle is needed.
+// (Shared by the Fixedwing-Waypoints kernel below and the dogfight kernel, dogfight.hpp.)
+inline bool fw_table_from_params(const pf_params& P, FwTable& T) {
   FwSurf S[5];
   FwBody& Bd = T.body;
-  if (P.vehicle != PF_FIXEDWING || P.flight_mode != 0 || P.task != PF_TASK_WAYPOINTS) return false;
+  if (P.vehicle != PF_FIXEDWING || P.flight_mode != 0) return false;
   if (P.n_surf != 5 || P.n_motors != 1 || P.ticks_per_control != 2) return false;
-  if (P.env_step_ratio < 1 || P.env_step_ratio > 4 || P.num_targets < 1 || P.num_targets > 4) return false;
   const int ids[6] = {0, 0, 1, 2, 1, 3};
   const float sg[6] = {1.f, -1.f, 1.f, -1.f, -1.f, 1.f};
   for (int k = 0; k < 6; ++k)
@@ -99,7 +99,6 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
   }
   if (P.motor_r[0][0] != 0.f || P.motor_r[0][1] != 0.f || P.motor_r[0][2] != 0.f) return false;
   if (P.thrust_unit[0][0] != 1.f || P.thrust_unit[0][1] != 0.f || P.thrust_unit[0][2] != 0.f) return false;
-  if (P.wp_yaw_penalty != 0.f) return false;
   for (int k = 0; k < P.n_boxes; ++k)
     if (P.boxes[k].kind != 0) return false;  // fw_floor_contact tests boxes only
   Bd.dt = P.dt; Bd.half_dt = 0.5f * P.dt; Bd.gravity_z = P.gravity_z; Bd.vmax = P.max_coord_vel; Bd.inv_mass = P.inv_mass;
@@ -109,13 +108,6 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
   Bd.m_a = P.motor_dt_over_tau[0]; Bd.m_noise = P.motor_noise[0]; Bd.fmax = P.motor_fmax[0]; Bd.tmax = P.motor_tmax[0];
   Bd.slab_xy = P.plane_half_xy; Bd.slab_bottom = -2.0f * P.plane_half_z;
   for (int k = 0; k < 5; ++k) Bd.pad[k] = 0.f;
-  K.dome2 = P.dome * P.dome; K.goal_reach = P.goal_reach_distance; K.min_height = P.min_height;
-  K.dome09m1 = P.dome * 0.9f - 1.0f; K.wp_dist_reward = P.wp_dist_reward;
-  K.task_sparse = P.sparse_reward; K.angle_repr = P.angle_repr; K.num_targets = P.num_targets; K.max_steps = P.max_steps;
-  K.env_step_ratio = P.env_step_ratio; K.throttle_remap = P.throttle_remap;
-  K.noise_mode = P.noise_mode; K.autoreset = P.autoreset;
-  K.seed_lo = (uint32_t)P.seed; K.seed_hi = (uint32_t)(P.seed >> 32);
-  for (int k = 0; k < 4; ++k) { K.act_lo[k] = P.action_low[k]; K.act_span[k] = P.action_high[k] - P.action_low[k]; }
   for (int i = 0; i < 5; ++i) {
     const pf_surface& s = P.surf[i];
     FwSurf& o = S[i];
@@ -135,6 +127,21 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
     o.defl_lim = f2{a.defl_lim, b.defl_lim}; o.dt_tau = f2{a.dt_tau, b.dt_tau}; o.hra = f2{a.hra, b.hra}; o.chord = f2{a.chord, b.chord};
   }
   T.vtail = S[3];
+  return true;
+}
+
+// Fill FwK / FwTable from the ABI struct for the Fixedwing-Waypoints kernel; false -> the configuration needs the generic kernel.
+inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
+  if (P.task != PF_TASK_WAYPOINTS || !fw_table_from_params(P, T)) return false;
+  if (P.env_step_ratio < 1 || P.env_step_ratio > 4 || P.num_targets < 1 || P.num_targets > 4) return false;
+  if (P.wp_yaw_penalty != 0.f) return false;
+  K.dome2 = P.dome * P.dome; K.goal_reach = P.goal_reach_distance; K.min_height = P.min_height;
+  K.dome09m1 = P.dome * 0.9f - 1.0f; K.wp_dist_reward = P.wp_dist_reward;
+  K.task_sparse = P.sparse_reward; K.angle_repr = P.angle_repr; K.num_targets = P.num_targets; K.max_steps = P.max_steps;
+  K.env_step_ratio = P.env_step_ratio; K.throttle_remap = P.throttle_remap;
+  K.noise_mode = P.noise_mode; K.autoreset = P.autoreset;
+  K.seed_lo = (uint32_t)P.seed; K.seed_hi = (uint32_t)(P.seed >> 32);
+  for (int k = 0; k < 4; ++k) { K.act_lo[k] = P.action_low[k]; K.act_span[k] = P.action_high[k] - P.action_low[k]; }
   return true;
 }
 
@@ -191,6 +198,10 @@ struct FwHot {
   m3 R; v3 wb, vb;
   bool contact_now, contact_step;
   lds_fptr cws;  // the wave's LDS regions for the contact solver (aliased onto the observation tile, idle during the ticks)
+  int cws_floats = 64 * 35;
+  // shared worlds (dogfight.hpp): this tick's drone-drone verdict, ORed into the contact report; the world-global bit is only
+  // exchanged (the rotational-drag gate it feeds exists on the quadrotor, quadx.py:509)
+  bool peer_contact = false, world_contact = false;
 
   PF_DEV void derive() {  // unit quaternion (quat_integrate / the settled template): scale 2
     const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
@@ -479,6 +490,7 @@ struct FwHot {
     if (__any(near)) {
       if (near) contact_now = fw_floor_contact(p.x, p.y, p.z, R, Pfull);
     }
+    contact_now = contact_now || peer_contact;
     // free-base multibody tick, composite of point masses: COM offset, full symmetric inertia
     const v3 com{K.com[0], K.com[1], K.com[2]};
     tau = tau - cross(com, F);
@@ -504,7 +516,7 @@ struct FwHot {
         const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
         v = o.v; w = o.w;
         lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
-      }, min(64, (64 * 35) / stride), stride);
+      }, min(64, cws_floats / stride), stride);
     }
     p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, K.half_dt);

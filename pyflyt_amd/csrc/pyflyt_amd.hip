@@ -724,6 +724,7 @@ struct pf_ctx {
   bool fast_fw;
   pf::FwK FK;
   pf::FwTable* surf_dev;  // pre-combined surface + body constants (scalar-loaded per tick)
+  bool df_fast;           // dogfight: the aircraft run on the specialised Fixedwing tick (dogfight.hpp: DfFastVeh)
 };
 static thread_local char g_err[256] = "";
 
@@ -858,13 +859,14 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
   pf::FwTable fsurf;
   c->fast_fw = pf::fwk_from_params(P, c->FK, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;
+  c->df_fast = P.task == PF_TASK_DOGFIGHT && pf::fw_table_from_params(P, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;
   {  // device copy of the parameter block (LDS constant tables, the out-of-line floor test)
     int cur = -1;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
     hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
     if (e == hipSuccess) e = hipMemcpy(c->P_dev, &c->P, sizeof(pf_params), hipMemcpyHostToDevice);
-    if (e == hipSuccess && c->fast_fw) {
+    if (e == hipSuccess && (c->fast_fw || c->df_fast)) {
       e = hipMalloc((void**)&c->surf_dev, sizeof(fsurf));
       if (e == hipSuccess) e = hipMemcpy(c->surf_dev, &fsurf, sizeof(fsurf), hipMemcpyHostToDevice);
     }
@@ -910,7 +912,7 @@ int pf_obs_dim(const pf_ctx* ctx) {
   return (P.angle_repr ? 13 : 12) + 4 + aux + (P.task == PF_TASK_WAYPOINTS ? (P.use_yaw_targets ? 4 : 3) * P.num_targets : (P.task == PF_TASK_MA_HOVER ? 3 : 0));
 }
 int pf_n_lanes(const pf_ctx* ctx) { return ctx->n; }
-int pf_ctx_is_specialised(const pf_ctx* ctx) { return ctx->fast ? 1 : ((ctx->fast_fw && ctx->tmpl) ? 2 : 0); }
+int pf_ctx_is_specialised(const pf_ctx* ctx) { return ctx->fast ? 1 : (((ctx->fast_fw && ctx->tmpl) || ctx->df_fast) ? 2 : 0); }
 
 static int ensure_device(pf_ctx* ctx) {
   int cur = -1;
@@ -934,13 +936,10 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
   if (P.task == PF_TASK_DOGFIGHT) {
     const int lpw = (64 / P.agents_per_world) * P.agents_per_world;  // whole worlds per wave
     const dim3 grid((ctx->n + lpw - 1) / lpw);
-#define PF_DF(AA) hipLaunchKernelGGL(pf::dogfight_env_kernel<AA>, grid, dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->P_dev)
-    switch (P.agents_per_world) {
-      case 2: PF_DF(2); break;
-      case 4: PF_DF(4); break;
-      case 6: PF_DF(6); break;
-      default: PF_DF(8); break;
-    }
+#define PF_DF(AA, VV) hipLaunchKernelGGL((pf::dogfight_env_kernel<AA, VV>), grid, dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->P_dev, ctx->surf_dev)
+#define PF_DFA(VV) switch (P.agents_per_world) { case 2: PF_DF(2, VV); break; case 4: PF_DF(4, VV); break; case 6: PF_DF(6, VV); break; default: PF_DF(8, VV); break; }
+    if (ctx->df_fast) { PF_DFA(pf::DfFastVeh) } else { PF_DFA(pf::DfGenericVeh) }
+#undef PF_DFA
 #undef PF_DF
   } else if (ctx->fast) {
     if (P.task == PF_TASK_HOVER) launch_fast<PF_TASK_HOVER>(ctx, b, op, mask, s);

@@ -52,7 +52,11 @@ PF_DEV void lds_sync_wave() {  // one wave per workgroup: LDS traffic ordered, n
 // Pd: the device copy of the parameter block -- the collision boxes are indexed dynamically, which for the by-value kernel
 // argument would mean a private copy in scratch memory.
 template <class BODY>
-PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, const float bound_radius, const pf_params* __restrict__ Pd) {
+// at_rest: this body is not integrated any more (a wreck at rest): it still publishes its pose and reads the world's contact bit,
+// but runs no box tests of its own -- two wrecks that came down within a wingspan of each other would otherwise run 36 box
+// pairs x 15 axes in every tick for the rest of the episode (one such pair in 16 384 worlds made every launch 5x longer).
+PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, const float bound_radius, const pf_params* __restrict__ Pd,
+                           const bool at_rest = false) {
   const int wbase = (tid / A) * A, wlocal = tid - wbase;
   float* me = wpose + tid * 8;
   me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
@@ -64,7 +68,7 @@ PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, co
     world |= o[7] != 0.0f;
     const v3 d{b.p.x - o[0], b.p.y - o[1], b.p.z - o[2]};
     const float rr = 2.0f * bound_radius;
-    if (dot(d, d) <= rr * rr) {  // bounding spheres touch: the box tests, this drone's boxes in the peer's box frames
+    if (!at_rest && dot(d, d) <= rr * rr) {  // bounding spheres touch: the box tests, this drone's boxes in the peer's box frames
       const m3 Rb = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
       const m3& Ra = b.R;
       const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
@@ -249,7 +253,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     // contact: the collision verdict of :667-670 stays up.
     const bool wreck = (df & (DF_INACTIVE | DF_FROZEN)) != 0;
     for (int t = 0; t < P.ticks_per_control; ++t) {
-      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev);
+      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev, wreck);
       if (!wreck) V.tick(P, nz.get(flat_base + t));
     }
     if (wreck) V.b.contact_step = V.b.contact_now;

@@ -147,13 +147,19 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
 
 // 15-axis box tests of the airframe's collision boxes against the ground box; out of line, runs only
 // in waves that have a lane within one bounding radius of the floor.
-__device__ __noinline__ bool fw_floor_contact(float px, float py, float pz, m3 R, const pf_params* P) {
+// (the parameter block through the scalar cache: inside an out-of-line function the plain pointer lives in VGPRs and its fields
+//  were flat loads at full memory latency, six boxes one after the other, in every tick of every wave that has a low flyer --
+//  the tail of the kernel's time in a population that is crashing; see uav_vehicles.hpp: uniform_params)
+__device__ __noinline__ bool fw_floor_contact(float px, float py, float pz, m3 R, const pf_params* Pg) {
+  const pf_params_kptr P = uniform_params(Pg);
   const float hb[3] = {P->plane_half_xy, P->plane_half_xy, P->plane_half_z};
   const v3 cb{0.0f, 0.0f, -P->plane_half_z};
   bool hit = false;
-  for (int k = 0; k < P->n_boxes; ++k) {
+  const int nb = P->n_boxes;
+  for (int k = 0; k < nb; ++k) {
+    const float bh[3] = {P->boxes[k].h[0], P->boxes[k].h[1], P->boxes[k].h[2]};
     v3 c = v3{px, py, pz} + mul(R, v3{P->boxes[k].c[0], P->boxes[k].c[1], P->boxes[k].c[2]});
-    hit |= box_overlaps_aabb(c, R, P->boxes[k].h, cb, hb);
+    hit |= box_overlaps_aabb(c, R, bh, cb, hb);
   }
   return hit;
 }

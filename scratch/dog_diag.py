@@ -17,6 +17,8 @@ for i, a in enumerate(ring):
     eng.sample_actions(a, i); a.mul_(float(os.environ.get("AMP", "0.15"))); a[:, 3] += 0.4
 eng.env_reset(); torch.cuda.synchronize()
 for blk in range(14):
+    if os.environ.get("RESET_AT") and blk * 50 == int(os.environ["RESET_AT"]):
+        eng.env_reset()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(50):
@@ -24,4 +26,6 @@ for blk in range(14):
     e1.record(); torch.cuda.synchronize()
     f = eng.flags(); side = eng.state[6, :, 3].view(torch.int32); z = eng.state[0, :, 2]
     print(f"steps {50*(blk+1):4d}: {e0.elapsed_time(e1)/50*1e3:8.1f} us/step  contact {int((f & PL.F_CONTACT).ne(0).sum()):6d}  inactive {int((side & 8).ne(0).sum()):6d}"
-          f"  alive {int((side & 1).ne(0).sum()):6d}  z<2 {int((z < 2).sum()):6d}  mean z {float(z.mean()):.1f}")
+          f"  alive {int((side & 1).ne(0).sum()):6d}  z<2 {int((z < 2).sum()):6d}  mean z {float(z.mean()):.1f}"
+          f"  nonfinite {int((f & PL.F_NONFINITE).ne(0).sum())}  oob {int((side & 64).ne(0).sum())}  max|xy| {float(eng.state[0, :, :2].abs().max()):.0f}  min z {float(z.min()):.0f}"
+          f"  max|w| {float(eng.state[3, :, :2].abs().max()):.0f}")

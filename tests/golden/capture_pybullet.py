@@ -8,7 +8,8 @@ build container or on the GPU boxes, which is why the Bullet boundary is "parity
     python -m pytest tests/test_pybullet_capture.py    # oracle (CPU) and, with -m gpu, the HIP path against them
 
 What it records: for every case of tests/golden/gen_goldens.py's Aviary set (all 9 QuadX flight modes, both
-Fixedwing modes, primitive_drone, acrowing, Rocket, the three floor drops) the per-Aviary-step
+Fixedwing modes, primitive_drone, acrowing, Rocket, the three floor drops; plus, when pettingzoo is installed, the three
+MAFixedwingDogfightEnv scenarios of gen_goldens.gen_dogfight at the env level) the per-Aviary-step
 `state(0)` (4,3), `aux_state(0)`, the setpoints applied, and `contact_array.any()`, with the SAME spawn poses and
 the SAME setpoint schedule as the committed fixtures -- but on real Bullet and with the motor noise forced to
 zero (the generator's `normal()` returns 0), so that a difference can only come from the physics engine.
@@ -34,8 +35,8 @@ class ZeroNoiseRNG:
     """np.random.Generator stand-in handed to Aviary(np_random=...): normal() -> 0 (no motor / booster noise,
     motors.py:134-138, boosters.py:230-233), everything else from a seeded generator."""
 
-    def __init__(self, seed):
-        self._g = np.random.default_rng(seed)
+    def __init__(self, seed, factory=None):
+        self._g = (factory or np.random.default_rng)(seed)
 
     def normal(self, *a, **k):
         return 0.0
@@ -134,6 +135,69 @@ CASES = (
 )
 
 
+def run_dogfight(name, n_steps, policy, seed, spawn=None, **kw):
+    """MAFixedwingDogfightEnv on the real stack, motor noise forced to zero: same recording as gen_goldens.gen_dogfight (actions,
+    observations, rewards, flags, health, hit counts per step; NaN / zero rows for culled agents)."""
+    from PyFlyt.pz_envs.fixedwing_envs.ma_fixedwing_dogfight_env import MAFixedwingDogfightEnv
+
+    orig = np.random.default_rng
+    np.random.default_rng = lambda seed_=None: ZeroNoiseRNG(seed_, factory=orig)  # the Aviary's generator (aviary.py:258-262): no motor noise
+    try:
+        env = MAFixedwingDogfightEnv(**kw)
+        if spawn is not None:
+            env._get_start_pos_orn = lambda seed_: (spawn[0].copy(), spawn[1].copy())
+        A, D = env.num_possible_agents, env.observation_space(None).shape[0]
+        obs, infos = env.reset(seed=seed)
+        reset_obs = np.stack([obs[a] for a in env.possible_agents])
+        rec = dict(action=[], obs=[], reward=[], term=[], trunc=[], alive=[], health=[], received_hits=[], contact=[])
+        prng = orig(seed + 1000)
+        for k in range(n_steps):
+            if len(env.agents) == 0:
+                break
+            alive = np.array([a in env.agents for a in env.possible_agents])
+            acts = {a: policy(k, env.agent_name_mapping[a], prng) for a in env.agents}
+            obs, rew, term, trunc, infos = env.step(acts)
+            Aa = np.zeros((A, env.action_space(None).shape[0])); Oo = np.full((A, D), np.nan); R = np.full(A, np.nan)
+            T = np.zeros(A, bool); U = np.zeros(A, bool)
+            for i, a in enumerate(env.possible_agents):
+                if a in acts:
+                    Aa[i] = acts[a]; Oo[i] = obs[a]; R[i] = rew[a]; T[i] = term[a]; U[i] = trunc[a]
+            rec["action"].append(Aa); rec["obs"].append(Oo); rec["reward"].append(R); rec["term"].append(T); rec["trunc"].append(U)
+            rec["alive"].append(alive); rec["health"].append(env.healths.copy()); rec["received_hits"].append(env.received_hits.copy())
+            rec["contact"].append(bool(np.any(env.aviary.contact_array)))
+        out = dict(start_pos=env.start_pos, start_orn=env.start_orn, reset_obs=reset_obs, team_size=env.team_size, max_steps=env.max_steps,
+                   dome=env.flight_dome_size, damage_per_hit=env.damage_per_hit, lethal_distance=env.lethal_distance, lethal_angle=env.lethal_angle,
+                   aggressiveness=env.aggressiveness, cooperativeness=env.cooperativeness, sparse_reward=env.sparse_reward,
+                   action_dim=env.action_space(None).shape[0], noise=False, **{k: np.array(v) for k, v in rec.items()})
+        env.close()
+        return out
+    finally:
+        np.random.default_rng = orig
+
+
+def dogfight_cases():
+    """The scenarios of gen_goldens.gen_dogfight (same spawn poses, same action policies)."""
+    pos_e = np.array([[0.0, 0.0, 40.0], [60.0, 35.0, 42.0], [25.0, 1.0, 40.5], [35.0, 34.0, 41.5]])
+    orn_e = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.02], [0.0, 0.0, 0.03]])
+    pos_c = np.array([[10.0, 0.0, 30.0], [0.0, 20.0, 3.0], [-30.0, 0.0, 35.0], [0.0, -370.0, 30.0]])
+    orn_c = np.array([[0.0, 0.0, 0.0], [0.0, 0.6, np.pi / 2], [0.0, 0.0, 3.0], [0.0, 0.0, -np.pi / 2]])
+
+    def chase(k, i, g):
+        return np.array([0.0, 0.0, 0.0, 0.6]) + g.uniform(-0.05, 0.05, size=4)
+
+    def crash(k, i, g):
+        a = np.array([0.0, 0.02, 0.0, 0.5]) + g.uniform(-0.1, 0.1, size=4)
+        if i == 1:
+            a[1], a[3] = -1.0, -1.0
+        return a
+
+    return [
+        ("env_dogfight_default", 80, lambda k, i, g: g.uniform(-1.0, 1.0, size=4), 3, None, dict(max_duration_seconds=2.5)),
+        ("env_dogfight_engage", 200, chase, 5, (pos_e, orn_e), dict(damage_per_hit=0.02, lethal_distance=40.0, lethal_angle_radians=0.25, max_duration_seconds=20.0)),
+        ("env_dogfight_crash", 260, crash, 7, (pos_c, orn_c), dict(flight_dome_size=400.0, max_duration_seconds=8.0)),
+    ]
+
+
 def main():
     try:
         import pybullet
@@ -151,6 +215,17 @@ def main():
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
         print(f"wrote {path}: {steps} Aviary steps, first contact at {int(np.argmax(d['contact'])) if d['contact'].any() else None}")
+    try:
+        import pettingzoo  # noqa: F401
+    except ImportError:
+        print("pettingzoo is not installed: the MAFixedwingDogfightEnv captures are skipped")
+        return
+    for name, steps, policy, seed, spawn, kw in dogfight_cases():
+        d = run_dogfight(name, steps, policy, seed, spawn, **kw)
+        d.update(prov)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
+        print(f"wrote {path}: {len(d['action'])} env steps, first contact at {int(np.argmax(d['contact'])) if d['contact'].any() else None}")
 
 
 if __name__ == "__main__":

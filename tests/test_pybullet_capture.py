@@ -18,7 +18,8 @@ import pytest
 from oracle import oracle as O
 
 CAP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pybullet")
-FILES = sorted(glob.glob(os.path.join(CAP, "*.npz")))
+FILES = sorted(glob.glob(os.path.join(CAP, "aviary_*.npz")))
+DOGFIGHT_FILES = sorted(glob.glob(os.path.join(CAP, "env_dogfight_*.npz")))
 needs_capture = pytest.mark.skipif(not FILES, reason="no real-PyBullet capture under tests/golden/pybullet/ "
                                                       "(run tests/golden/capture_pybullet.py where PyFlyt + pybullet are installed)")
 
@@ -96,3 +97,26 @@ def test_hip_against_real_pybullet(path):
         worst = max(worst, tg.state_err(eng, g["states"][k], g["aux"][k]))
     print(f"{name}: HIP vs real pybullet, worst {worst:.2e}")
     assert worst < 1e-4, worst
+
+
+@pytest.mark.skipif(not DOGFIGHT_FILES, reason="no real-PyBullet dogfight capture under tests/golden/pybullet/")
+@pytest.mark.parametrize("path", DOGFIGHT_FILES or [None])
+def test_oracle_dogfight_against_real_pybullet(path):
+    """MAFixedwingDogfightEnv recorded from the real stack (motor noise zeroed) against orc_dogfight_*: everything up to the first
+    contact anywhere in the world (after it the contact model is ours, not Bullet's)."""
+    g = np.load(path)
+    W = O.OracleDogfight(g["start_pos"], g["start_orn"], noise_mode=O.NOISE_OFF, team_size=int(g["team_size"]),
+                         damage_per_hit=float(g["damage_per_hit"]), lethal_distance=float(g["lethal_distance"]), lethal_angle=float(g["lethal_angle"]),
+                         aggressiveness=float(g["aggressiveness"]), cooperativeness=float(g["cooperativeness"]), sparse_reward=bool(g["sparse_reward"]),
+                         dome=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0, assisted_flight=int(g["action_dim"]) == 4)
+    np.testing.assert_allclose(W.reset(), g["reset_obs"], rtol=1e-6, atol=1e-6)
+    first_contact = int(np.argmax(g["contact"])) if g["contact"].any() else len(g["action"])
+    for k in range(min(first_contact, len(g["action"]))):
+        alive = g["alive"][k]
+        obs, rew, term, trunc = W.step(g["action"][k])
+        for i in range(W.A):
+            if alive[i]:
+                np.testing.assert_allclose(obs[i], g["obs"][k][i], rtol=1e-6, atol=1e-6, err_msg=f"step {k} agent {i}")
+                assert abs(rew[i] - g["reward"][k][i]) <= 1e-5 * max(1.0, abs(g["reward"][k][i]))
+                assert bool(term[i]) == bool(g["term"][k][i]) and bool(trunc[i]) == bool(g["trunc"][k][i])
+        np.testing.assert_allclose(W.health, g["health"][k], atol=1e-6)

@@ -42,3 +42,30 @@ def gimbal_yaw(roll, yaw, sign):
     roll_out = 0, pitch_out = +-pi/2, yaw_out = 2 atan2(-+x, +-y) = yaw -+ roll (wrapped to (-pi, pi])."""
     y = yaw - sign * roll
     return (y + np.pi) % (2 * np.pi) - np.pi
+
+
+def dogfight_tail_chase_expectations(damage, aggressiveness, cooperativeness, env_step_ratio=4):
+    """1 v 1 tail chase with the quarry permanently in the hunter's cone (sparse reward): per env step the hit count after it, the
+    hunter's and the quarry's popped reward, and whether the episode ends. One hit per update: the reset's update (its reward is
+    popped by the first step), then env_step_ratio per step; health = 1 - damage * hits in float32 as the reference keeps it; dead
+    at health <= 1e-3; the update that kills overrides the hunter's accumulated reward with 300 (team win) -- the quarry's
+    accumulated penalties stay."""
+    import numpy as np
+
+    out, hits, acc_h, acc_q = [], 1, 20.0 + cooperativeness, -20.0 * (1.0 - aggressiveness)  # the reset's update
+    health = np.float32(1.0) - np.float32(damage * 1)
+    done = False
+    while not done:
+        for _ in range(env_step_ratio):
+            hits += 1
+            health = np.float32(np.float64(health) - damage)
+            health = max(health, np.float32(0.0))
+            acc_h += 20.0 + cooperativeness
+            acc_q += -20.0 * (1.0 - aggressiveness)
+            if health <= 1e-3:
+                done = True
+                acc_h = 300.0
+            # (the reference keeps accumulating through the rest of the step; a dead quarry is still "hit")
+        out.append((hits, acc_h, acc_q, done))
+        acc_h, acc_q = 0.0, 0.0
+    return out

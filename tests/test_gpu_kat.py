@@ -329,3 +329,44 @@ def test_contact_friction_stops_a_slide():
     x, vx = out[0.5]
     assert np.abs(x - 1.0 / (2 * 0.5 * kat.G)).max() < 0.1 * 0.102 and np.abs(vx).max() < 1e-3  # stops after v^2 / (2 mu g)
     assert np.abs(out[0.0][1] - (1.0 - 7.35e-4 / kat.MASS)).max() < 2e-3  # frictionless: only the body drag slows it
+
+
+def test_dogfight_known_answers_gpu():
+    """The dogfight bookkeeping's closed-form answers (tests/kat.py: dogfight_tail_chase_expectations, see the oracle's twin in
+    test_oracle_kat.py) on the device: 1 v 1 tail chase, one hit per update, health, the kill and the team win in the same update."""
+    import numpy as np
+    import torch
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+    from kat import dogfight_tail_chase_expectations
+
+    dmg = 0.05
+    P = build_params("fixedwing", "dogfight", noise="off", autoreset="off", angle_representation="euler", sparse_reward=True, max_duration_seconds=10.0,
+                     vehicle_options=dict(drone_model="acrowing"), world_options=dict(world_scale=5.0),
+                     dogfight=dict(team_size=1, sample_spawn=False, damage_per_hit=dmg, lethal_distance=40.0, lethal_angle=0.2))
+    E = 32
+    eng = BatchEngine(P, 2 * E, device="cuda:0")
+    sp = torch.zeros(2, 2 * E, 4, device="cuda:0")
+    sp[0, 0::2, :3] = torch.tensor([0.0, 0.0, 60.0], device="cuda:0")   # the hunter
+    sp[0, 1::2, :3] = torch.tensor([25.0, 0.0, 60.0], device="cuda:0")  # its quarry, 25 m dead ahead on the same heading
+    eng.state[13:15] = sp
+    obs = eng.env_reset().clone()
+    side = eng.state[6]
+    assert (side[0::2, 2].view(torch.int32) == 0).all() and (side[1::2, 2].view(torch.int32) == 1).all()
+    assert torch.allclose(obs[0::2, 23 + 9:23 + 12].norm(dim=1), torch.full((E,), 25.0, device="cuda:0"), atol=1e-4)
+    assert (obs[0::2, 23 + 9] > 24.9).all() and (obs[1::2, 23 + 9] < -24.9).all() and (obs[:, 23 + 13] == 0).all()
+    act = torch.tensor([0.0, 0.0, 0.0, 0.2], device="cuda:0").repeat(2 * E, 1)
+    for k, (hits, r_hunter, r_quarry, done) in enumerate(dogfight_tail_chase_expectations(dmg, aggressiveness=0.5, cooperativeness=0.5)):
+        o, r, t, u = eng.env_step(act)
+        side = eng.state[6]
+        assert (side[1::2, 2].view(torch.int32) == hits).all() and (side[0::2, 2].view(torch.int32) == 0).all(), k
+        assert torch.allclose(r[0::2], torch.full((E,), float(r_hunter), device="cuda:0"), atol=1e-3), (k, r[0].item(), r_hunter)
+        assert torch.allclose(r[1::2], torch.full((E,), float(r_quarry), device="cuda:0"), atol=1e-3), (k, r[1].item(), r_quarry)
+        assert bool(t.all()) == done and bool(t.any()) == done and not bool(u.any())
+        assert torch.allclose(side[1::2, 0], torch.full((E,), max(0.0, 1 - dmg * hits), device="cuda:0"), atol=1e-5)
+        if done:
+            bits = side[:, 3].view(torch.int32)
+            assert ((bits[0::2] & 128) != 0).all() and ((bits[1::2] & 16) != 0).all()  # team_win / dead
+            break
+    else:
+        raise AssertionError("the quarry never died")

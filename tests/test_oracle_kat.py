@@ -239,3 +239,36 @@ def test_rocket_settles_on_its_legs():
 def test_contact_response_can_be_switched_off():
     t = _drop("quadx", [0.0, 0.0, 0.2], [0.0, 0.0, 0.0], 240, world_contact_response=0)
     assert t[-1, 2] < -3.0 and t[:, 12].any()  # detection only: the drone falls through the (10 m thick) slab
+
+
+def test_dogfight_known_answers():
+    """MAFixedwingDogfightEnv bookkeeping with answers that do not need the physics: 1 v 1, the hunter 25 m dead astern of its
+    quarry on the same heading. Both fly the same trajectory, so the separation stays (25, 0, 0) and the engagement angles
+    stay 0 (hunter) and pi (quarry): one hit per update -- the reset's update, then env_step_ratio = 4 per env step -- health
+    1 - damage * hits (ma_fixedwing_dogfight_env.py:499-503), the quarry dies at hits >= (1 - 1e-3) / damage (:665-666) and the
+    hunter wins in the same update (:682-690, reward overridden with 300); until then the hunter collects 20 per hit
+    (+ cooperativeness, its own team's hits), the quarry -20 (1 - aggressiveness) per hit (:597-617)."""
+    from kat import dogfight_tail_chase_expectations
+
+    dmg, lethal = 0.05, 40.0
+    pos = np.array([[0.0, 0.0, 60.0], [25.0, 0.0, 60.0]])
+    W = O.OracleDogfight(pos, np.zeros((2, 3)), team_size=1, damage_per_hit=dmg, lethal_distance=lethal, lethal_angle=0.2, sparse_reward=True,
+                         max_duration_seconds=10.0)
+    obs = W.reset()
+    exp = dogfight_tail_chase_expectations(dmg, aggressiveness=0.5, cooperativeness=0.5)
+    assert np.array(W.D.received_hits[:2]).tolist() == [0, 1] and abs(W.health[1] - (1 - dmg)) < 1e-7
+    # the other aircraft in the own body frame: 25 m away (exactly: both fly the same trajectory), ahead of the hunter, astern of the quarry
+    assert abs(np.linalg.norm(obs[0][23 + 9:23 + 12]) - 25.0) < 1e-9 and abs(np.linalg.norm(obs[1][23 + 9:23 + 12]) - 25.0) < 1e-9
+    assert obs[0][23 + 9] > 24.9 and obs[1][23 + 9] < -24.9
+    assert obs[0][23 + 13] == 0.0 and obs[0][18] == 1.0 and abs(obs[0][23 + 12] - (1 - dmg)) < 1e-7  # opponent flag, own health, its health
+    for k, (hits, r_hunter, r_quarry, done) in enumerate(exp):
+        obs, rew, term, trunc = W.step(np.tile([0.0, 0.0, 0.0, 0.2], (2, 1)))
+        assert int(W.D.received_hits[1]) == hits and int(W.D.received_hits[0]) == 0, (k, W.D.received_hits[1], hits)
+        assert abs(rew[0] - r_hunter) < 1e-6 and abs(rew[1] - r_quarry) < 1e-6, (k, rew, r_hunter, r_quarry)
+        assert bool(term[0]) == done and bool(term[1]) == done and not trunc.any()
+        assert abs(W.health[1] - max(0.0, 1 - dmg * hits)) < 1e-6
+        if done:
+            assert (int(W.D.info_bits[0]) & 8) and (int(W.D.info_bits[1]) & 1)  # team_win / dead
+            break
+    else:
+        raise AssertionError("the quarry never died")

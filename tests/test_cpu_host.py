@@ -43,6 +43,11 @@ def test_no_cpu_fallback(built):
         pytest.skip("GPU present")
     with pytest.raises(PyFlytAmdError):
         BatchEngine(build_params("quadx", "hover"), 64)
+    from pyflyt_amd.pz_envs import MAFixedwingDogfightEnv, MAQuadXHoverEnv
+
+    for env_cls in (MAFixedwingDogfightEnv, MAQuadXHoverEnv):  # the PettingZoo facades have no CPU path either
+        with pytest.raises(PyFlytAmdError):
+            env_cls(device="cuda:0")
     # the C entry point itself refuses as well
     from pyflyt_amd import _lib
 

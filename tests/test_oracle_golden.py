@@ -438,6 +438,21 @@ def test_dogfight_trajectory(golden_dir, name):
         assert any(W.D.inactive[:W.A])  # a dead aircraft at rest on the ground has dropped out of the observations
 
 
+def test_dogfight_spawn_against_reference_output(golden_dir):
+    """orc_dogfight_spawn against what the reference's own `_get_start_pos_orn(seed=3)` returned when the default fixture was
+    recorded (its start_pos / start_orn): the uniforms are re-drawn from np.random.RandomState(3) in the reference's draw order."""
+    g = load(golden_dir, "env_dogfight_default")
+    team, lo, hi = int(g["team_size"]), 10.0, 50.0
+    rs = np.random.RandomState(seed=3)
+    u0 = rs.uniform(0.0, 2 * np.pi) / (2 * np.pi)
+    ur = (rs.uniform(low=lo, high=hi, size=(2 * team,)) - lo) / (hi - lo)
+    uh = (rs.uniform(low=lo, high=hi, size=(2 * team,)) - lo) / (hi - lo)
+    uy = rs.random(2 * team)
+    pos, rpy, vel = O.dogfight_spawn(team, lo, hi, np.concatenate([[u0], ur, uh, uy]))
+    np.testing.assert_allclose(pos, g["start_pos"], atol=1e-10)
+    np.testing.assert_allclose(rpy, g["start_orn"], atol=1e-10)
+
+
 def test_dogfight_spawn_restatement():
     """orc_dogfight_spawn against the reference's _get_start_pos_orn arithmetic (ma_fixedwing_dogfight_env.py:176-213), fed the
     draws of the same np.random.RandomState."""

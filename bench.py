@@ -53,8 +53,8 @@ def parse():
                     help="weak: --batch lanes PER GPU (BASELINE config 5); strong: --batch lanes in TOTAL cut over the GPUs "
                          "(the metric's 'batch=65536 at 1/2/4/8' point)")
     ap.add_argument("--no-contact-response", action="store_true",
-                    help="contact DETECTION only (round-1 semantics: an episode still ends on the floor, but its terminal observation "
-                         "lacks the impact impulse); diagnostic, not the headline configuration")
+                    help="opt OUT of stepSimulation's contact solve (world_options contact_response=False): contact DETECTION only, "
+                         "a departure from the reference; diagnostic A/B, never the headline configuration (the default has the solve on)")
     ap.add_argument("--world", action="append", default=[], metavar="KEY=VALUE",
                     help="override an entry of pyflyt_amd.params.WORLD (diagnostic), e.g. --world contact_iters=6")
     ap.add_argument("--rollout-steps", type=int, default=100, help="env steps per pf_rollout launch of the second, state-resident figure (0 = skip)")
@@ -72,7 +72,7 @@ def make_engine(env, batch, device, lane_offset, noise, contact_response=True, w
         return BatchEngine(P, batch, device=device, lane_offset=lane_offset)
     vehicle, task = {"hover": ("quadx", "hover"), "quadx_waypoints": ("quadx", "waypoints"),
                      "fixedwing_waypoints": ("fixedwing", "waypoints")}[env]
-    wo = {} if contact_response else dict(contact_response=False)
+    wo = {} if contact_response else dict(contact_response=False)  # (default: the solve is ON, as in the reference)
     for kv in world:
         k, v = kv.split("=", 1)
         wo[k] = float(v) if "." in v or "e" in v.lower() else int(v)
@@ -280,10 +280,11 @@ def main():
             out["rollout"] = {
                 "k": kk, "launches": reps, "ms_per_step": 1e3 * per_step, "value": total_lanes / (rwall / (reps * kk)),
                 "value_event_timed": total_lanes / per_step,
-                # against the one-launch-per-step algorithmic bytes -- what the judge's 0.40 bar is quoted on
-                "frac": ALGO_BYTES[args.env] * n / per_step / 1e9 / HBM_PEAK_GBS,
-                # and against what this launch shape actually has to move
-                "bytes_per_step_moved": moved, "frac_moved": moved * n / per_step / 1e9 / HBM_PEAK_GBS,
+                # the rollout's HBM fraction: the bytes this launch shape actually moves per env step
+                "bytes_per_step_moved": moved, "frac": moved * n / per_step / 1e9 / HBM_PEAK_GBS,
+                # NOT a roofline fraction: the one-launch-per-step algorithmic bytes (state round trip included)
+                # divided by the rollout's time -- a speed ratio against the per-step launch shape, kept for continuity with r02
+                "nominal_vs_per_step_bytes": ALGO_BYTES[args.env] * n / per_step / 1e9 / HBM_PEAK_GBS,
                 "kernel": ("pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel") + "<..., ROLL=1>", "launch_us": rev / reps * 1e6,
                 "note": "k env steps per launch, state in registers, on-device action sampling (pf_sample_actions keys); bit-identical to k x pf_env_step (tests/test_gpu_rollout.py)",
             }

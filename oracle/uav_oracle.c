@@ -840,14 +840,12 @@ void orc_params_acrowing(orc_params* P) {
   orc_finalize(P);
 }
 void orc_task_hover(orc_params* P) { /* quadx_hover_env.py:32-37 */
-  P->world.contact_response = 0; /* the env ends the episode in the Aviary step that reports the contact: detection only by default */
   P->task = ORC_TASK_HOVER;
   P->flight_mode = 0; P->dome = 3.0; P->max_steps = 400; P->env_step_ratio = 3;
   P->start_pos[0] = 0; P->start_pos[1] = 0; P->start_pos[2] = 1.0;
   P->sparse_reward = 0; P->angle_repr = 1; P->num_targets = 0; P->collide_any = 0; P->throttle_remap = 0;
 }
 void orc_task_quadx_waypoints(orc_params* P) { /* quadx_waypoints_env.py:38-47,87 */
-  P->world.contact_response = 0; /* the env ends the episode in the Aviary step that reports the contact: detection only by default */
   P->task = ORC_TASK_WAYPOINTS;
   P->flight_mode = 0; P->dome = 5.0; P->max_steps = 300; P->env_step_ratio = 4;
   P->start_pos[0] = 0; P->start_pos[1] = 0; P->start_pos[2] = 1.0;
@@ -857,7 +855,6 @@ void orc_task_quadx_waypoints(orc_params* P) { /* quadx_waypoints_env.py:38-47,8
   P->use_yaw_targets = 0; P->goal_reach_angle = 0.1; /* quadx_waypoints_env.py:40,42 */
 }
 void orc_task_fixedwing_waypoints(orc_params* P) { /* fixedwing_waypoints_env.py:36-45,63,81 */
-  P->world.contact_response = 0; /* the env ends the episode in the Aviary step that reports the contact: detection only by default */
   P->task = ORC_TASK_WAYPOINTS;
   P->flight_mode = 0; P->dome = 100.0; P->max_steps = 3600; P->env_step_ratio = 4;
   P->start_pos[0] = 0; P->start_pos[1] = 0; P->start_pos[2] = 10.0;
@@ -868,7 +865,6 @@ void orc_task_fixedwing_waypoints(orc_params* P) { /* fixedwing_waypoints_env.py
 }
 
 void orc_task_ma_hover(orc_params* P) { /* pz_envs/quadx_envs/ma_quadx_hover_env.py:36-52 */
-  P->world.contact_response = 0; /* the env ends the episode in the Aviary step that reports the contact: detection only by default */
   P->task = ORC_TASK_MA_HOVER;
   P->flight_mode = 0; P->dome = 10.0; P->max_steps = 1200; P->env_step_ratio = 3;
   P->sparse_reward = 0; P->angle_repr = 1; P->num_targets = 0; P->collide_any = 0; P->throttle_remap = 0;

@@ -1,0 +1,26 @@
+"""profiling tool: throughput of the MA hover task (generic kernel) at 65536 agents."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pyflyt_amd import build_params
+from pyflyt_amd.engine import BatchEngine
+n = 65536
+P = build_params("quadx", "ma_hover", noise="philox", autoreset="off")
+eng = BatchEngine(P, n)
+acts = [torch.empty(n, 4, device="cuda") for _ in range(16)]
+for i, a in enumerate(acts): eng.sample_actions(a, i)
+# MA start poses live in the side block: the facade sets them; reuse it
+from pyflyt_amd.pz_envs import MAQuadXHoverEnv
+env = MAQuadXHoverEnv(num_envs=n // 4, seed=0)
+env.reset(seed=0)
+e = env.engine
+torch.cuda.synchronize()
+for rep in range(2):
+    t0 = time.perf_counter()
+    for k in range(200):
+        e.env_step(acts[k % 16])
+        if k % 25 == 24:
+            e.env_reset(mask=(e.terminated | e.truncated))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"ma_hover: {dt / 200 * 1e6:.1f} us/step, {n * 200 / dt / 1e9:.2f} G agent-steps/s")

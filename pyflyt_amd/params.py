@@ -203,10 +203,10 @@ WORLD: dict[str, Any] = {
     # contact response against that slab: a named-parameter model of what stepSimulation does after collision detection
     # (vertex contacts, projected Gauss-Seidel at the velocity level, position-level penetration recovery; DESIGN.md
     # section 3), with Bullet's defaults: restitution 0, lateral friction 0.5 (body) x 1.0 (plane.urdf), erp 0.2
-    # None = by task: ON for the Aviary-level surface (landings), OFF for the gym / PettingZoo env tasks, which end the episode in
-    # the Aviary step that reports the contact -- there the response could only alter that one terminal observation, and it
-    # costs every env step ~12 %. True / False force it.
-    "contact_response": None,
+    # ON everywhere, as in the reference (stepSimulation, aviary.py:516, always solves its contacts). False is an explicit
+    # opt-out: contact DETECTION only -- bodies pass through the floor; for the gym env tasks, which end the episode in the
+    # Aviary step that reports the contact, it alters that terminal observation only.
+    "contact_response": True,
     "contact_restitution": 0.0,
     "contact_friction": 0.5,
     "contact_erp": 0.2,
@@ -327,7 +327,7 @@ def build_params(
     P.plane_half_xy = W["plane_half_xy"] * W["world_scale"]
     P.plane_half_z = W["plane_half_z"] * W["world_scale"]
     # contact response against the ground slab (named-parameter model; Bullet's defaults)
-    P.contact_response = int(task in ("none", "dogfight")) if W["contact_response"] is None else int(bool(W["contact_response"]))
+    P.contact_response = int(bool(W["contact_response"]))
     P.contact_restitution, P.contact_friction, P.contact_erp = W["contact_restitution"], W["contact_friction"], W["contact_erp"]
     P.contact_iters = int(W["contact_iters"])
     P.contact_margin = W["contact_margin"]  # (lengths of the contact model itself: not scaled with the world, as in
@@ -496,7 +496,7 @@ def build_params(
         P.df_sample_spawn = int(bool(DF["sample_spawn"]))
         P.df_action_dim = 4 if DF["assisted_flight"] else 6
         P.df_freeze_wrecks = int(bool(DF["freeze_wrecks"]))
-        if P.df_freeze_wrecks and W["contact_response"] is None:
+        if P.df_freeze_wrecks and "contact_response" not in (world_options or {}):
             P.contact_response = 0  # the aircraft stops at the first contact REPORT: there is nothing left for the contact solve to do
         P.df_spawn_min_radius, P.df_spawn_max_radius = float(DF["spawn_min_radius"]), float(DF["spawn_max_radius"])
         P.df_damage_per_hit, P.df_lethal_distance, P.df_lethal_angle = float(DF["damage_per_hit"]), float(DF["lethal_distance"]), float(DF["lethal_angle"])

@@ -299,12 +299,16 @@ def flat_obs(env, obs, num_targets):
     return np.array(obs, dtype=np.float64)
 
 
-def run_env(make, n_steps, seed, action_fn, num_targets=0, ticks=6, contact_response=False):
-    """contact_response: the gym / PettingZoo env tasks default to contact DETECTION only (they end the episode in the Aviary
-    step that reports the contact; pyflyt_amd.params.WORLD); `True` records the same env with the response on."""
+def run_env(make, n_steps, seed, action_fn, num_targets=0, ticks=6, contact_response=True):
+    """contact_response: every env task runs what stepSimulation does (aviary.py:516), contact solve included -- fake_bullet's
+    own default, left alone here. `False` records the explicit opt-out (`world_options=dict(contact_response=False)`:
+    contact DETECTION only, bodies pass through the floor), which only the detect-only fixture uses."""
     from oracle import fake_bullet
 
-    fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = contact_response
+    assert fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE is True
+    if contact_response:
+        return _run_env(make, n_steps, seed, action_fn, num_targets, ticks)
+    fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = False
     try:
         return _run_env(make, n_steps, seed, action_fn, num_targets, ticks)
     finally:
@@ -373,9 +377,10 @@ def lowthrust_quad_action(env, rng, k):
 
 
 def gen_envs_crash():
+    # (the terminal observations carry the impact impulses of stepSimulation's contact solve)
     save("env_hover_crash", **run_env(lambda: QuadXHoverEnv(), 150, 8, lowthrust_quad_action, ticks=6))
-    # the same episodes with the contact response on: the terminal observations carry the impact impulses
-    save("env_hover_crash_response", **run_env(lambda: QuadXHoverEnv(), 150, 8, lowthrust_quad_action, ticks=6, contact_response=True))
+    # the same episodes under the explicit opt-out world_options=dict(contact_response=False): detection only
+    save("env_hover_crash_detect_only", **run_env(lambda: QuadXHoverEnv(), 150, 8, lowthrust_quad_action, ticks=6, contact_response=False))
     # the fixedwing cannot reach the 30 m x 30 m floor box from its default start (z=10, 20 m/s), so
     # floor contact for it is pinned at Aviary level, from a low start
     d = run_aviary("fixedwing", 0, 60, seed=12, start_pos=[0.0, 0.0, 0.8], start_orn=[0.2, 0.25, 0.0], noise=True)
@@ -418,7 +423,6 @@ def gen_ma_hover():
     from oracle import fake_bullet
 
     np.random.default_rng = recording_default_rng
-    fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = False  # env tasks: detection only by default (see run_env)
     try:
         env = MAQuadXHoverEnv(flight_dome_size=2.5, max_duration_seconds=1.0)  # small dome/duration: both exits occur
         rng = orig(123)
@@ -431,12 +435,12 @@ def gen_ma_hover():
             rec["reset_xi"].append(r.drain("normal").reshape(-1, 4))  # [tick][drone]
             return r
 
-        r = do_reset(0)
+        r = do_reset(1000)
         n_ag = len(env.possible_agents)
         for k in range(90):
             if len(env.agents) == 0:
                 rec["reset_before"].append(k)
-                r = do_reset(k)
+                r = do_reset(1000 + k)
             alive = [a in env.agents for a in env.possible_agents]
             acts = {a: np.array([*rng.uniform(-1.0, 1.0, size=3), rng.uniform(0.2, 0.7)]) for a in env.agents}
             obs, rew, term, trunc, infos = env.step(acts)
@@ -487,12 +491,12 @@ def gen_ma_hover_shared():
             rec["reset_xi"].append(r.drain("normal").reshape(-1, 4))
             return r
 
-        r = do_reset(0)
+        r = do_reset(1000)
         n_ag = len(env.possible_agents)
         for k in range(140):
             if len(env.agents) == 0:
                 rec["reset_before"].append(k)
-                r = do_reset(k)
+                r = do_reset(1000 + k)
             alive = [a in env.agents for a in env.possible_agents]
             # agents 0 and 1 steer towards each other (roll-rate commands of opposite sign), the others hover / sink
             acts = {}

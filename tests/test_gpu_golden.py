@@ -61,7 +61,7 @@ ENVS = [
     ("env_hover_gentle_trunc", "quadx", "hover", dict(max_duration_seconds=0.5)),
     ("env_hover_euler_sparse", "quadx", "hover", dict(angle_representation="euler", sparse_reward=True)),
     ("env_hover_crash", "quadx", "hover", {}),
-    ("env_hover_crash_response", "quadx", "hover", dict(world_options=dict(contact_response=True))),
+    ("env_hover_crash_detect_only", "quadx", "hover", dict(world_options=dict(contact_response=False))),
     ("env_quadx_waypoints_random", "quadx", "waypoints", {}),
     ("env_quadx_waypoints_reach", "quadx", "waypoints", dict(goal_reach_distance=2.5)),
     ("env_fixedwing_waypoints_random", "fixedwing", "waypoints", {}),

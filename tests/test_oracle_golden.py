@@ -267,7 +267,7 @@ ENVS = [
     ("env_hover_gentle_trunc", "hover", {"max_steps": 20}),
     ("env_hover_euler_sparse", "hover", {"angle_repr": 0, "sparse_reward": 1}),
     ("env_hover_crash", "hover", {}),
-    ("env_hover_crash_response", "hover", {"world_contact_response": 1}),
+    ("env_hover_crash_detect_only", "hover", {"world_contact_response": 0}),
     ("env_quadx_waypoints_random", "quadx_waypoints", {}),
     ("env_quadx_waypoints_reach", "quadx_waypoints", {"goal_reach_distance": 2.5}),
     ("env_fixedwing_waypoints_random", "fixedwing_waypoints", {}),

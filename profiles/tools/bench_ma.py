@@ -1,6 +1,6 @@
 """profiling tool: throughput of the MA hover task (generic kernel) at 65536 agents."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine

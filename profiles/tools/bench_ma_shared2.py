@@ -1,6 +1,6 @@
 """profiling tool: where the shared-world MA hover step goes: contact response on / off, generic kernel."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine

@@ -1,6 +1,6 @@
 """profiling tool: dogfight step time vs the population's state (flying / on the ground / wreck at rest)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from pyflyt_amd import _lib as PL

@@ -1,6 +1,6 @@
 """profiling tool: eager env steps for rocprofv3 with config knobs (SETTLE, NOISE env vars)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine

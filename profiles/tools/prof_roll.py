@@ -1,6 +1,6 @@
 """profiling tool: pf_rollout launches for rocprofv3 (N, K, REPS, TASK, NOISE env vars)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine

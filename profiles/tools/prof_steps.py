@@ -1,6 +1,6 @@
 """profiling tool: run a few hundred eager env steps for rocprofv3 (not part of the product)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine

@@ -1,6 +1,6 @@
 """profiling tool: soak -- 50k graph-replayed env steps per env kind, finite outputs, counters advance, episode statistics sane."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine

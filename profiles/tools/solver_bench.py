@@ -1,6 +1,6 @@
 """profiling tool: time per physics tick with every body resting on the floor (the contact solve runs for every lane in every tick)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pyflyt_amd.core import Aviary
 N = int(os.environ.get("N", "16384"))

@@ -1,6 +1,6 @@
 """Copies the judged artefacts from gpurun_out/r01 into profiles/r01 and prints the summary numbers."""
 import csv, collections, glob, json, os, shutil
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src, dst = os.path.join(R, "gpurun_out", "r01"), os.path.join(R, "profiles", "r01")
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "bench_*.json")):

@@ -6,7 +6,7 @@ import json
 import os
 import shutil
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src, dst = os.path.join(R, "gpurun_out", "r02"), os.path.join(R, "profiles", "r02")
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "bench_*.json")):

@@ -185,10 +185,10 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
                                                           const int op, const uint8_t* mask, const pf_params* __restrict__ Pdev,
                                                           const FwTable* table_g) {
   constexpr int Dmax = 25 + (A - 1) * 14;  // (six-wide actions: two more past-action entries)
-  constexpr int kTile = 64 * Dmax > kContactSlots * kContactSlotFloats ? 64 * Dmax : kContactSlots * kContactSlotFloats;
+  constexpr int kTile = 64 * Dmax > kContactSlotFloats ? 64 * Dmax : kContactSlotFloats;  // (at least one worst-case solver region)
   const int AD = P.df_action_dim == 6 ? 6 : 4;
   const int D = 19 + AD + (A - 1) * 14;
-  __shared__ float tile[kTile];
+  __shared__ __attribute__((aligned(16))) float tile[kTile];
   __shared__ float ktab[VEH::TABLE_FLOATS];
   __shared__ float wpose[64 * 8];
   __shared__ float rec[64 * kDfRec];

@@ -517,7 +517,7 @@ struct FwHot {
       act = (fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop);
     }
     if (__any(act)) {
-      const int stride = Pfull->contact_max_points * kContactWords;
+      const int stride = (Pfull->contact_max_points + 1) * kContactWords;
       contact_rounds(act && Pfull->contact_response, cws, [&](lds_fptr slot) {
         const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
         v = o.v; w = o.w;
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
   constexpr bool ROLLOUT = ROLL != 0;
   constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 6 + 12;
-  __shared__ float tile[64 * kMaxD];
+  __shared__ __attribute__((aligned(16))) float tile[64 * kMaxD];
   const int tid = threadIdx.x;
   const int wave_base = blockIdx.x * 64;
   const int lane = wave_base + tid;
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, co
   fw_tab_cptr surf = (fw_tab_cptr)(uintptr_t)table_g;
 
   FwHot V;
-  static_assert(64 * kMaxD >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
+  static_assert(64 * kMaxD >= kContactSlotFloats, "the contact solver's LDS regions alias the observation tile: at least one worst-case region");
   V.cws = (lds_fptr)tile;
   float tgt[4][3];
   float new_dist, old_dist;

@@ -28,9 +28,9 @@ constexpr int kWave = 64;
 constexpr int kMaxObs = 40;  // 13 + 4 + 6 + 3*4 = 35 (Fixedwing), 13 + 4 + 4 + 4*4 = 37 (QuadX with yaw targets)
 
 enum { OP_STEP = 0, OP_RESET = 1 };
-// Aviary-level kernels (where bodies land and stay landed): 16.5 KB of LDS for the contact solve -- eight worst-case airframes
-// (48 collider vertices) or 48 quadrotors side by side per round
-constexpr int kAviaryContactFloats = 8 * kContactSlotFloats;
+// Aviary-level kernels (where bodies land and stay landed): 40 KB of LDS for the contact solve -- every lane of a wave of
+// quadrotors (8 collider vertices x 20 floats) in one round, ten worst-case airframes (48 vertices) side by side
+constexpr int kAviaryContactFloats = 64 * 9 * kContactWords;
 
 // ------------------------------------------------------------------ per-task side block
 // 12 floats per lane in state groups G_TGT..G_TGT+2:
@@ -84,7 +84,7 @@ template <class VEH, int TASK, int MODE_T>
 __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_buffers B, const int n,
                                                     const uint64_t lane0, const int op, const uint8_t* mask,
                                                     const float4* __restrict__ tmpl, const pf_params* __restrict__ Pdev) {
-  __shared__ float tile[kWave * kMaxObs];
+  __shared__ __attribute__((aligned(16))) float tile[kWave * kMaxObs];
   __shared__ float ktab[VEH::TABLE_FLOATS];
   __shared__ float wpose[kWave * 8];  // shared worlds: each lane's pose and contact bit, exchanged once per tick
   const int tid = threadIdx.x;
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   const int mode = (MODE_T == kRuntimeMode) ? P.flight_mode : MODE_T;
   constexpr bool kSide = (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER);
 
-  static_assert(kWave * kMaxObs >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
+  static_assert(kWave * kMaxObs >= kContactSlotFloats, "the contact solver's LDS regions alias the observation tile: at least one worst-case region");
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)tile;  // (idle during the physics ticks)
@@ -434,7 +434,7 @@ __global__ void settle_template_kernel(const pf_params P, float4* tmpl, const pf
   VEH::fill_table(ktab, Pdev, threadIdx.x);
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  __shared__ float cws[kAviaryContactFloats];
+  __shared__ __attribute__((aligned(16))) float cws[kAviaryContactFloats];
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, c
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   const size_t li = lane, N = n;
-  __shared__ float cws[kAviaryContactFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
+  __shared__ __attribute__((aligned(16))) float cws[kAviaryContactFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, c
   const size_t li = lane, N = n;
   constexpr bool kQuad = VEH::AUX == 4;
   constexpr int kCmdGroup = 12;
-  __shared__ float cws[kAviaryContactFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
+  __shared__ __attribute__((aligned(16))) float cws[kAviaryContactFloats];  // the contact solver's LDS regions (uav_vehicles.hpp)
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
@@ -666,7 +666,7 @@ __global__ void __launch_bounds__(kWave) body_tick_kernel(const pf_params P, con
   const int lane = blockIdx.x * kWave + threadIdx.x;
   if (lane >= n) return;
   const size_t li = lane, N = n;
-  __shared__ float cws[kAviaryContactFloats];
+  __shared__ __attribute__((aligned(16))) float cws[kAviaryContactFloats];
   VEH V;
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)cws;
@@ -1080,5 +1080,12 @@ int pf_body_tick(pf_ctx* ctx, const pf_buffers* b, int n_ticks, void* stream) {
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;
 }
+
+#ifdef PF_PHASE_TRACE
+// diagnostic variant only (profiles/tools/phase_trace.py): copy out the per-wave phase stamps of the last quadx_m0 launch
+int pf_debug_phase_trace(unsigned long long* out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_phase_trace), sizeof(unsigned long long) * (size_t)n_words, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 }  // extern "C"

@@ -286,7 +286,7 @@ struct QuadHot {
       }
       if (__any(act)) {
         // regions sized for this airframe's own contact count: the single box needs 8 x 11 floats, 26 lanes per round
-        const int stride = Pfull->contact_max_points * kContactWords;
+        const int stride = (Pfull->contact_max_points + 1) * kContactWords;
         const int slots = min(64, cws_floats / stride);
         contact_rounds(act, cws, [&](lds_fptr slot) {
           const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v(), w());
@@ -301,6 +301,17 @@ struct QuadHot {
     contact_step |= contact_now;
   }
 };
+
+// Per-wave phase timeline (profiles/tools/phase_trace.py): a diagnostic build switch, -DPF_PHASE_TRACE. Each wave of the
+// one-step-per-launch instantiation stamps the shader clock (s_memtime) at its phase boundaries and its first lane writes the
+// stamps to a device array the variant library exports; the product build has none of it.
+#ifdef PF_PHASE_TRACE
+constexpr int kPhaseStamps = 13;
+__device__ unsigned long long g_phase_trace[4096 * kPhaseStamps];
+#define PF_STAMP(i) do { if (ROLL == 0) { pf_ts[i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define PF_STAMP(i) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // The kernel. Control flow is deliberately flat -- a prologue, one uniform-trip-count loop over the
@@ -326,7 +337,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 4 + 16;  // attitude + 4 targets x (delta, yaw error)
   constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
-  __shared__ float tile[LPW * kMaxD];
+  __shared__ __attribute__((aligned(16))) float tile[LPW * kMaxD];
   __shared__ float sxi[64 * kSettleMax];
   __shared__ int spos[64];
   __shared__ uint32_t sctr[64];
@@ -338,9 +349,14 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   const size_t N = (size_t)n;
   const float4* Sin = reinterpret_cast<const float4*>(B.state);
   float4* Sout = reinterpret_cast<float4*>(B.state);
+#ifdef PF_PHASE_TRACE
+  unsigned long long pf_ts[kPhaseStamps];
+  pf_ts[11] = __builtin_amdgcn_s_memrealtime();  // 100 MHz wall clock: aligns the waves of different CUs
+#endif
+  PF_STAMP(0);
 
   QuadHot V;
-  static_assert(LPW * kMaxD >= kContactSlots * kContactSlotFloats, "the contact solver's LDS regions alias the observation tile");
+  static_assert(LPW * kMaxD >= kContactSlotFloats, "the contact solver's LDS regions alias the observation tile: at least one worst-case region");
   V.cws = (lds_fptr)tile;
   V.cws_floats = LPW * kMaxD;
   float tgt[4][3];
@@ -355,9 +371,11 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li],
            g5 = Sin[5 * N + li];
     rng_ctr = (uint32_t)__float_as_int(gi.z);
+    PF_STAMP(1);  // (the int group has arrived)
     if (NOISE == PF_NOISE_PHILOX) {
       if (op == 0) zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
     }
+    PF_STAMP(2);  // (the step's Philox call done)
     V.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
     V.q = quat{g1.x, g1.y, g1.z, g1.w};
     V.set_wv(v3{g2.w, g3.x, g3.y}, v3{g2.x, g2.y, g2.z});
@@ -394,6 +412,10 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   V.contact_now = (flags & PF_F_CONTACT) != 0;
   V.contact_step = false;
   V.derive();
+#ifdef PF_PHASE_TRACE
+  asm volatile("" ::"v"(V.wb.x), "v"(V.vb.z));
+#endif
+  PF_STAMP(3);  // (every state group has arrived and is unpacked)
   bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
 
   bool active;
@@ -618,6 +640,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   was_reset = false;
   prepare_settle_noise(do_reset);
   if (do_reset) reset_lane();
+  PF_STAMP(4);  // (NEXT_STEP resets done)
 
   // ---------------------------------------------------------------- the env step
   const bool stepping = active && !was_reset && op == 0;
@@ -724,6 +747,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       if (TASK != PF_TASK_MA_HOVER) go = !(term || trunc);
     }
   }
+  PF_STAMP(5);  // (the env step's Aviary steps done)
   const float out_reward = stepping ? reward : 0.0f;
   const bool out_term = stepping && term, out_trunc = stepping && trunc;
   if (stepping) {
@@ -756,8 +780,11 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
 
   // ---------------------------------------------------------------- outputs
   // observation tile first, persistent state after it: nothing waits on the state stores
+  PF_STAMP(6);
   if (active) write_obs_row();
+  PF_STAMP(7);  // (observation row computed and written to LDS)
   flush_tile(B.obs + toff * D);
+  PF_STAMP(8);  // (observation tile stores issued)
   if (active) {
     if (pop_pending) { pop_target(); pop_pending = false; }
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
@@ -788,6 +815,16 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       Sout[14 * N + li] = float4{tgt[2][2], tgt[3][0], tgt[3][1], tgt[3][2]};
     }
   }
+#ifdef PF_PHASE_TRACE
+  PF_STAMP(9);  // (state stores issued)
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): every store acknowledged
+  PF_STAMP(10);
+  pf_ts[12] = __builtin_amdgcn_s_memrealtime();
+  if (ROLL == 0 && tid == 0 && blockIdx.x < 4096) {
+#pragma unroll
+    for (int i = 0; i < kPhaseStamps; ++i) g_phase_trace[blockIdx.x * kPhaseStamps + i] = pf_ts[i];
+  }
+#endif
 }
 
 }  // namespace pf

@@ -50,164 +50,240 @@ PF_DEV float pid1(float kp, float ki, float kd, float lim, float T, float invT, 
 // ------------------------------------------------------------------------------------------
 // Contact response against the ground slab: what stepSimulation does after collision detection, as the
 // named-parameter model documented at pf_params.contact_response (oracle/uav_oracle.c:contact_solve is the fp64
-// restatement, oracle/fake_bullet.py:_solve_contacts the independent second one). Contact vertices at or below
-// the slab's top face at the pre-integration pose (p, q); contact_iters projected Gauss-Seidel sweeps on the COM
-// velocity / angular velocity (world frame); returns the new base twist and the deepest penetration.
-// Out of line on purpose: it runs only for lanes within one bounding radius of the floor, its per-contact arrays
-// are dynamically indexed (scratch memory), and that frame must not leak into the callers' register allocation.
+// restatement, oracle/fake_bullet.py:_solve_contacts the independent second one). Contact vertices within the contact
+// margin of the slab's top face at the pre-integration pose (p, q); contact_iters projected Gauss-Seidel sweeps on the COM
+// velocity / angular velocity (world frame), in collider / vertex order; returns the new base twist and the deepest
+// penetration.
+//
+// How it is laid out for one wavefront lane per body (round 3; round 2's version spent ~60 instructions and eleven dependent
+// LDS reads per contact per sweep, profiles/README.md):
+//   * a lone wave issues one instruction per four clocks whatever it is, and the Gauss-Seidel recurrence is serial in the
+//     contacts, so the time of a solve IS (contacts x sweeps x instructions per row triple): everything that does not depend
+//     on the running twist is computed ONCE per contact into a 20-float record -- arm, the normal row's target velocity, and
+//     for each of the three rows the angular response I_w^-1 (a x e_d) and the inverse effective mass -- so that a row is
+//     2 (row velocity) + 2..3 (projected impulse) + 1 (delta) + 4 (twist update) instructions;
+//   * the records live in LDS (dynamically indexed; as private arrays they would be scratch memory) as five float4 each, read
+//     with five ds_read_b128 ONE CONTACT AHEAD of their use (two register sets, the loop unrolled by two), so the sweep never
+//     waits on LDS; the only write per contact and sweep is its three accumulated impulses;
+//   * vertex generation per box: the eight heights come from seven partial sums of the box's half axes' z components, a box
+//     whose lowest vertex clears the margin is skipped after four instructions, and only a vertex that passes the height test
+//     gets its x / y offsets and its record;
+//   * a contact whose accumulated impulse is zero and whose row velocity is already above its target (a speculative contact
+//     that is not closing: most of the vertices a tumbling airframe has within the margin) is skipped after six instructions
+//     when that holds for every lane in the sweep at that moment -- the full update would compute exact zeros;
+//   * a sweep that moved nothing ends the solve (every further sweep would repeat it exactly).
 struct ContactOut {
   v3 v, w;
   float deepest;
 };
-// Per-contact working set: arm (3), accumulated impulses (3), initial normal velocity, depth, the three inverse
-// effective masses. It lives in LDS: the arrays are dynamically indexed (as private arrays they gave every kernel a 1.4 KB/lane
-// scratch segment: env steps 1.5x slower), and the sweeps are a chain of dependent loads (in a global-memory workspace every
-// sweep paid a full memory round trip that a lone wave per SIMD cannot hide: +0.9 us per env step). Only a few lanes of a
-// wave need the solver in the same tick, so kContactSlots regions are enough; callers deal them out by ballot rank
-// (Body::respond) and come back for another round if more lanes ask. The hot kernels alias the regions onto their
-// observation tile, which is idle during the physics ticks.
-constexpr int kContactWords = 11;
-constexpr int kContactSlotFloats = PF_MAX_CONTACTS * kContactWords;  // 528
-constexpr int kContactSlots = 4;
+// Per-contact record, five float4: (arm.xyz, normal target velocity) (gz.xyz, kz) (gx.xyz, kx) (gy.xyz, ky) (ln, lx, ly, -).
+// Only a few lanes of a wave need the solver in the same tick, so the callers cut their LDS (the hot kernels: the observation
+// tile, idle during the physics ticks) into regions sized for the airframe's own worst-case contact count and deal them out by
+// ballot rank (Body::respond, contact_rounds), coming back for another round if more lanes ask.
+constexpr int kContactWords = 20;
+constexpr int kContactSlotFloats = (PF_MAX_CONTACTS + 1) * kContactWords;  // worst-case region (+ the sentinel record): 980 floats
 typedef __attribute__((address_space(3))) float* lds_fptr;
-// (inlined into the two out-of-line entry points below)
+typedef __attribute__((address_space(3))) pf_f4v* lds_f4ptr;  // (the native vector type: HIP's float4 class has no LDS-qualified assignment)
 // The parameter block as the solver reads it: a wave-uniform pointer into the constant address space, so that every field --
 // and the collision boxes, indexed by a uniform loop counter -- comes through the scalar cache (s_load). Inside an out-of-line
 // function the plain pointer argument lives in VGPRs, and its fields were a chain of flat loads at full memory latency with one
-// lane active: most of the 25 us a quadrotor's solve took.
+// lane active.
 typedef const pf_params __attribute__((address_space(4)))* pf_params_kptr;
 PF_DEV pf_params_kptr uniform_params(const pf_params* P) {
   const uintptr_t a = reinterpret_cast<uintptr_t>(P);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
   return (pf_params_kptr)(((uintptr_t)hi << 32) | (uintptr_t)lo);
 }
+// The per-body part of the solve that does not depend on where the contact vertices come from: records are appended with
+// add(), then sweeps() runs the projected Gauss-Seidel iteration. W4: this lane's LDS region.
+struct ContactSet {
+  lds_f4ptr W4;
+  int n;
+  float deepest;
+  v3 cw;                // R com: the arms are taken from the centre of mass
+  float I0, I1, I2, I3, I4, I5;  // world-frame inverse inertia R I^-1 R^T (symmetric xx xy xz yy yz zz)
+  float inv_mass, slop, inv_dt, rest;
+  v3 vc, w;             // the running twist: COM velocity, angular velocity
+  PF_DEV void begin(lds_fptr ws, const m3& R, v3 com, float im, v3 v_, v3 w_, float i0, float i1, float i2, float i3, float i4, float i5,
+                    float slop_, float inv_dt_, float rest_) {
+    W4 = (lds_f4ptr)ws; n = 0; deepest = 0.0f;
+    cw = mul(R, com);
+    const float Ii[6] = {i0, i1, i2, i3, i4, i5};
+    const v3 r0{R.m00, R.m01, R.m02}, r1{R.m10, R.m11, R.m12}, r2{R.m20, R.m21, R.m22};
+    const v3 c0 = symmul(Ii, r0), c1 = symmul(Ii, r1), c2 = symmul(Ii, r2);
+    I0 = dot(r0, c0); I1 = dot(r0, c1); I2 = dot(r0, c2); I3 = dot(r1, c1); I4 = dot(r1, c2); I5 = dot(r2, c2);
+    inv_mass = im; slop = slop_; inv_dt = inv_dt_; rest = rest_;
+    w = w_;
+    vc = v_ + cross(w_, cw);
+  }
+  // A contact vertex at world offset `off` from the base origin, `depth` below the slab's top face (negative: above it, inside
+  // the margin). The three constraint directions are the world axes (normal +z, friction +x, +y), written out component by
+  // component: with the direction as a vector the compiler may not drop the multiplications by its zeros.
+  PF_DEV void add(v3 off, float depth) {
+    const v3 a = off - cw;
+    // angular response I_w^-1 (a x e_d) of a unit impulse along e_d at arm a, and 1 / (1/m + e_d . ((I_w^-1 (a x e_d)) x a))
+    const v3 gz{fmaf(I0, a.y, -(I1 * a.x)), fmaf(I1, a.y, -(I3 * a.x)), fmaf(I2, a.y, -(I4 * a.x))};
+    const v3 gx{fmaf(I1, a.z, -(I2 * a.y)), fmaf(I3, a.z, -(I4 * a.y)), fmaf(I4, a.z, -(I5 * a.y))};
+    const v3 gy{fmaf(I2, a.x, -(I0 * a.z)), fmaf(I4, a.x, -(I1 * a.z)), fmaf(I5, a.x, -(I2 * a.z))};
+    const float kz = frcp(inv_mass + fmaf(gz.x, a.y, -(gz.y * a.x)));
+    const float kx = frcp(inv_mass + fmaf(gx.y, a.z, -(gx.z * a.y)));
+    const float ky = frcp(inv_mass + fmaf(gy.z, a.x, -(gy.x * a.z)));
+    // normal row: may close the gap down to the slop, no more; otherwise towards restitution x approach speed
+    const float vn0 = vc.z + fmaf(w.x, a.y, -(w.y * a.x));
+    const float tgt = depth < slop ? (depth - slop) * inv_dt : (vn0 < 0.0f ? -rest * vn0 : 0.0f);
+    lds_f4ptr r = W4 + 5 * n;
+    r[0] = pf_f4v{a.x, a.y, a.z, tgt};
+    r[1] = pf_f4v{gz.x, gz.y, gz.z, kz};
+    r[2] = pf_f4v{gx.x, gx.y, gx.z, kx};
+    r[3] = pf_f4v{gy.x, gy.y, gy.z, ky};
+    r[4] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    deepest = __builtin_fmaxf(deepest, depth);
+    ++n;
+  }
+  // one contact of one sweep; returns the OR of the three impulse deltas' bits (zero: nothing moved)
+  PF_DEV uint32_t row3(const pf_f4v r0, const pf_f4v r1, const pf_f4v r2, const pf_f4v r3, const pf_f4v r4, const float mu, lds_f4ptr lout) {
+    const float un = fmaf(w.x, r0.y, fmaf(-w.y, r0.x, vc.z));
+    // (a contact with no accumulated impulse whose normal velocity is not below its target stays at exactly zero: n0 = 0,
+    //  friction clamped to +-0; skipped when every lane of the wave agrees -- which includes the lanes that are past their
+    //  last contact and sit on the sentinel record)
+    const bool idle = (r4.x == 0.0f) && (un >= r0.w);
+    if (__builtin_amdgcn_ballot_w64(!idle) == 0ull) return 0u;
+    const float n0 = __builtin_fmaxf(fmaf(r0.w - un, r1.w, r4.x), 0.0f);
+    const float d0 = n0 - r4.x;
+    vc.z = fmaf(inv_mass, d0, vc.z);
+    w = v3{fmaf(d0, r1.x, w.x), fmaf(d0, r1.y, w.y), fmaf(d0, r1.z, w.z)};
+    const float lim = mu * n0;  // friction rows: clamped to mu x the normal impulse
+    const float ux = fmaf(w.y, r0.z, fmaf(-w.z, r0.y, vc.x));
+    const float n1 = med3(fmaf(-ux, r2.w, r4.y), -lim, lim);
+    const float d1 = n1 - r4.y;
+    vc.x = fmaf(inv_mass, d1, vc.x);
+    w = v3{fmaf(d1, r2.x, w.x), fmaf(d1, r2.y, w.y), fmaf(d1, r2.z, w.z)};
+    const float uy = fmaf(w.z, r0.x, fmaf(-w.x, r0.z, vc.y));
+    const float n2 = med3(fmaf(-uy, r3.w, r4.z), -lim, lim);
+    const float d2 = n2 - r4.z;
+    vc.y = fmaf(inv_mass, d2, vc.y);
+    w = v3{fmaf(d2, r3.x, w.x), fmaf(d2, r3.y, w.y), fmaf(d2, r3.z, w.z)};
+    *lout = pf_f4v{n0, n1, n2, 0.0f};
+    // (r4.w is the record's padding word, always zero: reading it HERE keeps its register out of the allocator's hands until the
+    //  row is done -- reused earlier, it made the row wait for the whole prefetch it belongs to)
+    return (__float_as_uint(d0) | __float_as_uint(d1) | __float_as_uint(d2) | __float_as_uint(r4.w)) & 0x7fffffffu;
+  }
+  // Wave-uniform control flow: the contact counter and the sweep counter are scalars, a lane that is past its last contact reads
+  // its sentinel record (zero impulse, target -FLT_MAX, zero effective masses: the row update is an exact no-op), and the solve
+  // ends when a sweep moved nothing in any lane (a lane whose own sweep moved nothing would repeat it exactly). No exec-mask
+  // bookkeeping in the loop: on a lone wave a scalar instruction costs an issue slot like any other.
+  PF_DEV void sweeps(const int iters, const float mu) {
+    W4[5 * n + 0] = pf_f4v{0.0f, 0.0f, 0.0f, -3.4028235e38f};
+    W4[5 * n + 1] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    W4[5 * n + 2] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    W4[5 * n + 3] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    W4[5 * n + 4] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    if (!__any(n > 0)) return;
+    typedef __attribute__((address_space(3))) char* lds_cptr;
+    const lds_cptr base = (lds_cptr)W4;
+    const uint32_t end = (uint32_t)n * 80u;  // byte offset of the sentinel
+    auto rec = [&](uint32_t off) { return (lds_f4ptr)(base + (off < end ? off : end)); };
+    for (int it = 0; it < iters; ++it) {
+      uint32_t chg = 0u;
+      // two register sets, each loaded one contact ahead of its use
+      pf_f4v a0 = W4[0], a1 = W4[1], a2 = W4[2], a3 = W4[3], a4 = W4[4];
+      uint32_t off = 0u;  // (wave-uniform)
+      for (;;) {
+        lds_f4ptr pa = rec(off), nb = rec(off + 80u);
+        const pf_f4v b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3], b4 = nb[4];
+        chg |= row3(a0, a1, a2, a3, a4, mu, pa + 4);
+        off += 80u;
+        if (!__any(off < end)) break;
+        lds_f4ptr na = rec(off + 80u);
+        a0 = na[0]; a1 = na[1]; a2 = na[2]; a3 = na[3]; a4 = na[4];
+        chg |= row3(b0, b1, b2, b3, b4, mu, nb + 4);
+        off += 80u;
+        if (!__any(off < end)) break;
+      }
+      if (!__any(chg != 0u)) break;  // a sweep that moved nothing: every further sweep would repeat it exactly
+    }
+  }
+  PF_DEV ContactOut finish(v3 v_in, v3 w_in) const {
+    if (n == 0) return ContactOut{v_in, w_in, 0.0f};
+    return ContactOut{vc - cross(w, cw), w, __builtin_fmaxf(deepest - slop, 0.0f)};
+  }
+};
+// (inlined into the two out-of-line entry points below)
 PF_DEV ContactOut contact_solve_impl(const pf_params_kptr P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
                                      float i0, float i1, float i2, float i3, float i4, float i5) {
-  auto W = [&](int c, int f) -> __attribute__((address_space(3))) float& { return ws[c * kContactWords + f]; };  // 0-2 arm, 3 ln, 4 lx, 5 ly, 6 vn0, 7 depth, 8-10 1/k
   const m3 R = rot_from_quat(q);
-  const v3 cw = mul(R, com);
-  const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin, slop = P->contact_slop;
-  const float inv_dt = 1.0f / P->dt;
-  int n = 0;
-  float deepest = 0.0f;
-  for (int k = 0; k < P->n_boxes; ++k) {
-    pf_box b;  // (field by field: a struct copy out of the constant address space has no constructor)
-    b.c[0] = P->boxes[k].c[0]; b.c[1] = P->boxes[k].c[1]; b.c[2] = P->boxes[k].c[2];
-    b.h[0] = P->boxes[k].h[0]; b.h[1] = P->boxes[k].h[1]; b.h[2] = P->boxes[k].h[2];
-    b.kind = P->boxes[k].kind; b.yaw = P->boxes[k].yaw;
+  const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin;
+  ContactSet S;
+  S.begin(ws, R, com, inv_mass, v, w, i0, i1, i2, i3, i4, i5, P->contact_slop, 1.0f / P->dt, P->contact_restitution);
+  const int nb = P->n_boxes;
+  for (int k = 0; k < nb; ++k) {
+    const float bc0 = P->boxes[k].c[0], bc1 = P->boxes[k].c[1], bc2 = P->boxes[k].c[2];
+    const float bh0 = P->boxes[k].h[0], bh1 = P->boxes[k].h[1], bh2 = P->boxes[k].h[2];
+    const int kind = P->boxes[k].kind;
+    const float yaw = P->boxes[k].yaw;
     float sy = 0.0f, cy = 1.0f;
-    if (b.yaw != 0.0f) sincosf(b.yaw, &sy, &cy);
-    const int nv = b.kind == 1 ? 16 : 8;
-    for (int i = 0; i < nv; ++i) {
-      float l0, l1, l2;
-      if (b.kind == 1) {  // end disc -z then +z, rim point j at j * 45 degrees from the link x axis
+    if (yaw != 0.0f) sincosf(yaw, &sy, &cy);  // (wave-uniform)
+    const v3 cwk = mul(R, v3{bc0, bc1, bc2});
+    if (kind == 1) {  // cylinder: 8 rim points per end disc, -z then +z; rim point j at j * 45 degrees from the link x axis
+#pragma unroll 1
+      for (int i = 0; i < 16; ++i) {
         const int j = i & 7;
         const float c45 = (j == 0) ? 1.0f : ((j == 4) ? -1.0f : ((j == 2 || j == 6) ? 0.0f : ((j == 1 || j == 7) ? 0.70710678f : -0.70710678f)));
         const int js = (j + 6) & 7;
         const float s45 = (js == 0) ? 1.0f : ((js == 4) ? -1.0f : ((js == 2 || js == 6) ? 0.0f : ((js == 1 || js == 7) ? 0.70710678f : -0.70710678f)));
-        l0 = b.h[0] * c45; l1 = b.h[0] * s45; l2 = (i >> 3) ? b.h[2] : -b.h[2];
-      } else {
-        l0 = (i & 1) ? b.h[0] : -b.h[0]; l1 = (i & 2) ? b.h[1] : -b.h[1]; l2 = (i & 4) ? b.h[2] : -b.h[2];
+        const float l0 = bh0 * c45, l1 = bh0 * s45, l2 = (i >> 3) ? bh2 : -bh2;
+        const v3 off = cwk + mul(R, v3{cy * l0 - sy * l1, sy * l0 + cy * l1, l2});
+        const v3 x = p + off;
+        if (S.n < PF_MAX_CONTACTS && x.z <= margin && x.z >= -hz2 && __builtin_fabsf(x.x) <= hxy && __builtin_fabsf(x.y) <= hxy) S.add(off, -x.z);
       }
-      const v3 bl{b.c[0] + cy * l0 - sy * l1, b.c[1] + sy * l0 + cy * l1, b.c[2] + l2};
-      const v3 off = mul(R, bl);
-      const v3 x = p + off;
-      if (n < PF_MAX_CONTACTS && x.z <= margin && x.z >= -hz2 && __builtin_fabsf(x.x) <= hxy && __builtin_fabsf(x.y) <= hxy) {
-        const v3 a = off - cw;
-        W(n, 0) = a.x; W(n, 1) = a.y; W(n, 2) = a.z;
-        W(n, 3) = 0.0f; W(n, 4) = 0.0f; W(n, 5) = 0.0f;
-        W(n, 7) = -x.z;
-        deepest = __builtin_fmaxf(deepest, -x.z);
-        ++n;
+      continue;
+    }
+    // box: half axes in the world frame (the link frame is the base frame yawed about z)
+    const v3 ex{bh0 * fmaf(R.m00, cy, R.m01 * sy), bh0 * fmaf(R.m10, cy, R.m11 * sy), bh0 * fmaf(R.m20, cy, R.m21 * sy)};
+    const v3 ey{bh1 * fmaf(R.m01, cy, -(R.m00 * sy)), bh1 * fmaf(R.m11, cy, -(R.m10 * sy)), bh1 * fmaf(R.m21, cy, -(R.m20 * sy))};
+    const v3 ez{bh2 * R.m02, bh2 * R.m12, bh2 * R.m22};
+    const float zc = p.z + cwk.z;
+    if (zc - (__builtin_fabsf(ex.z) + __builtin_fabsf(ey.z) + __builtin_fabsf(ez.z)) > margin) continue;  // the whole box clears the margin
+    const float za0 = zc - ex.z, za1 = zc + ex.z;
+    const float zb[4] = {za0 - ey.z, za1 - ey.z, za0 + ey.z, za1 + ey.z};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // vertex i: x sign bit 0, y sign bit 1, z sign bit 2 (the oracle's order)
+      const float z = (i & 4) ? zb[i & 3] + ez.z : zb[i & 3] - ez.z;
+      if (z <= margin && z >= -hz2) {
+        const float sx = (i & 1) ? 1.0f : -1.0f, syv = (i & 2) ? 1.0f : -1.0f, sz = (i & 4) ? 1.0f : -1.0f;
+        const v3 off{fmaf(sx, ex.x, fmaf(syv, ey.x, fmaf(sz, ez.x, cwk.x))), fmaf(sx, ex.y, fmaf(syv, ey.y, fmaf(sz, ez.y, cwk.y))), z - p.z};
+        if (S.n < PF_MAX_CONTACTS && __builtin_fabsf(p.x + off.x) <= hxy && __builtin_fabsf(p.y + off.y) <= hxy) S.add(off, -z);
       }
     }
   }
-  ContactOut out{v, w, __builtin_fmaxf(deepest - slop, 0.0f)};
-  if (n == 0) return out;
-  // world-frame inverse inertia R I^-1 R^T (symmetric)
-  const float Ii[6] = {i0, i1, i2, i3, i4, i5};
-  const v3 r0{R.m00, R.m01, R.m02}, r1{R.m10, R.m11, R.m12}, r2{R.m20, R.m21, R.m22};
-  const v3 c0 = symmul(Ii, r0), c1 = symmul(Ii, r1), c2 = symmul(Ii, r2);
-  const float Iw[6] = {dot(r0, c0), dot(r0, c1), dot(r0, c2), dot(r1, c1), dot(r1, c2), dot(r2, c2)};
-  v3 vc = v + cross(w, cw);
-  // per contact, once: the normal velocity the sweeps start from and the three inverse effective masses
-  // 1 / (1/m + e_d . ((I_w^-1 (a x e_d)) x a)) -- iteration invariant, and a division each.
-  // The three constraint directions are the world axes (normal +z, friction +x, +y), written out component by component: with
-  // `dir` as a vector the compiler may not drop the multiplications by its zeros (IEEE: 0 * x is not 0 for every x), and
-  // they were 40 % of this function's instructions.
-  const float I0 = Iw[0], I1 = Iw[1], I2 = Iw[2], I3 = Iw[3], I4 = Iw[4], I5 = Iw[5];
-  // angular response I_w^-1 (a x e_d) of a unit impulse along e_d at arm a
-  auto ang_z = [&](const v3 a) { return v3{fmaf(I0, a.y, -(I1 * a.x)), fmaf(I1, a.y, -(I3 * a.x)), fmaf(I2, a.y, -(I4 * a.x))}; };
-  auto ang_x = [&](const v3 a) { return v3{fmaf(I1, a.z, -(I2 * a.y)), fmaf(I3, a.z, -(I4 * a.y)), fmaf(I4, a.z, -(I5 * a.y))}; };
-  auto ang_y = [&](const v3 a) { return v3{fmaf(I2, a.x, -(I0 * a.z)), fmaf(I4, a.x, -(I1 * a.z)), fmaf(I5, a.x, -(I2 * a.z))}; };
-  for (int c = 0; c < n; ++c) {
-    const v3 a{W(c, 0), W(c, 1), W(c, 2)};
-    W(c, 6) = vc.z + fmaf(w.x, a.y, -(w.y * a.x));
-    const v3 gz = ang_z(a), gx = ang_x(a), gy = ang_y(a);
-    W(c, 8) = frcp(inv_mass + fmaf(gz.x, a.y, -(gz.y * a.x)));   // e_z . (g x a)
-    W(c, 9) = frcp(inv_mass + fmaf(gx.y, a.z, -(gx.z * a.y)));   // e_x . (g x a)
-    W(c, 10) = frcp(inv_mass + fmaf(gy.z, a.x, -(gy.x * a.z)));  // e_y . (g x a)
-  }
-  const float mu = P->contact_friction, rest = P->contact_restitution;
-  for (int it = 0; it < P->contact_iters; ++it) {
-    bool changed = false;
-    for (int c = 0; c < n; ++c) {
-      const v3 a{W(c, 0), W(c, 1), W(c, 2)};
-      const float vn0 = W(c, 6), dep = W(c, 7);
-      const float l0 = W(c, 3), l1 = W(c, 4), l2 = W(c, 5);
-      const float k0 = W(c, 8), k1 = W(c, 9), k2 = W(c, 10);
-      // normal (+z): may close the gap down to the slop, no more; otherwise towards restitution x approach speed
-      const float target = dep < slop ? (dep - slop) * inv_dt : (vn0 < 0.0f ? -rest * vn0 : 0.0f);
-      const float un = vc.z + fmaf(w.x, a.y, -(w.y * a.x));
-      const float n0 = __builtin_fmaxf(fmaf(target - un, k0, l0), 0.0f);
-      float dl = n0 - l0;
-      changed |= dl != 0.0f;
-      v3 g = ang_z(a);
-      vc.z = fmaf(inv_mass, dl, vc.z);
-      w = v3{fmaf(dl, g.x, w.x), fmaf(dl, g.y, w.y), fmaf(dl, g.z, w.z)};
-      // friction (+x, +y): clamped to mu x the normal impulse
-      const float lim = mu * n0;
-      const float ux = vc.x + fmaf(w.y, a.z, -(w.z * a.y));
-      const float n1 = __builtin_fminf(__builtin_fmaxf(fmaf(-ux, k1, l1), -lim), lim);
-      dl = n1 - l1;
-      changed |= dl != 0.0f;
-      g = ang_x(a);
-      vc.x = fmaf(inv_mass, dl, vc.x);
-      w = v3{fmaf(dl, g.x, w.x), fmaf(dl, g.y, w.y), fmaf(dl, g.z, w.z)};
-      const float uy = vc.y + fmaf(w.z, a.x, -(w.x * a.z));
-      const float n2 = __builtin_fminf(__builtin_fmaxf(fmaf(-uy, k2, l2), -lim), lim);
-      dl = n2 - l2;
-      changed |= dl != 0.0f;
-      g = ang_y(a);
-      vc.y = fmaf(inv_mass, dl, vc.y);
-      w = v3{fmaf(dl, g.x, w.x), fmaf(dl, g.y, w.y), fmaf(dl, g.z, w.z)};
-      W(c, 3) = n0; W(c, 4) = n1; W(c, 5) = n2;
-    }
-    if (!changed) break;  // a sweep that moved nothing: every further sweep would repeat it exactly
-  }
-  out.w = w;
-  out.v = vc - cross(w, cw);
-  return out;
+  S.sweeps(P->contact_iters, P->contact_friction);
+  return S.finish(v, w);
 }
 // Constant mass properties (QuadX, Fixedwing): read from the parameter block inside the call, so that the call passes 16
 // dwords -- all in registers; with the ten mass-property words as arguments the last three went over the stack and gave
 // every caller a private segment.
-__device__ __noinline__ ContactOut contact_solve_dev(const pf_params* __restrict__ Pg, lds_fptr ws, v3 p, quat q, v3 v, v3 w) {
+// (PF_SOLVE_INLINE: A/B build switch -- the solver inlined at every call site instead of called)
+#ifdef PF_SOLVE_INLINE
+#define PF_SOLVE_ATTR __device__ __forceinline__
+#else
+#define PF_SOLVE_ATTR __device__ __noinline__
+#endif
+PF_SOLVE_ATTR ContactOut contact_solve_dev(const pf_params* __restrict__ Pg, lds_fptr ws, v3 p, quat q, v3 v, v3 w) {
   const pf_params_kptr P = uniform_params(Pg);
   const v3 com = P->has_com_offset ? v3{P->com[0], P->com[1], P->com[2]} : v3{0.f, 0.f, 0.f};
   return contact_solve_impl(P, ws, p, q, v, w, P->inv_mass, com, P->I_inv[0], P->I_inv[1], P->I_inv[2], P->I_inv[3], P->I_inv[4], P->I_inv[5]);
 }
 // Mass properties that change per tick (Rocket): passed by value.
-__device__ __noinline__ ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
+PF_SOLVE_ATTR ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
                                                          float i0, float i1, float i2, float i3, float i4, float i5) {
   return contact_solve_impl(uniform_params(P), ws, p, q, v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
 }
-// Deal the kContactSlots LDS regions out to the lanes of the (currently active part of the) wave that need the solver,
+// Deal the LDS regions out to the lanes of the (currently active part of the) wave that need the solver,
 // by ballot rank, in as many rounds as it takes. `solve(slot_base)` runs the solver for this lane.
 // slots x stride floats behind `ws`: the callers size the regions for the airframe's own contact count (pf_params.contact_max_points:
 // a quadrotor's single box needs 8 x 11 floats, so 29 lanes fit where the worst case fits 4).
 template <class F>
-PF_DEV void contact_rounds(bool need, lds_fptr ws, F&& solve, const int slots = kContactSlots, const int stride = kContactSlotFloats) {
+PF_DEV void contact_rounds(bool need, lds_fptr ws, F&& solve, const int slots, const int stride) {
   unsigned long long m = __ballot(need);
   while (m != 0ull) {
     const int rank = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
@@ -229,11 +305,11 @@ struct Body {
   v3 rpy;       // quadx.py:526 (refreshed once per Aviary step)
   bool contact_now, contact_step;
   // shared world (PF_TASK_MA_HOVER with agents_per_world > 1); both false for a drone that is alone in its world
-  int cslots = kContactSlots, cstride = kContactSlotFloats;  // LDS regions behind `cws`: how many, how far apart (contact_regions)
+  int cslots = 1, cstride = kContactSlotFloats;  // LDS regions behind `cws`: how many, how far apart (contact_regions)
   // `floats` of LDS behind cws, cut into regions of this airframe's own worst-case contact count
   PF_DEV void contact_regions(const pf_params& P, int floats) {
     const int pts = (P.contact_max_points > 0 && P.contact_max_points <= PF_MAX_CONTACTS) ? P.contact_max_points : PF_MAX_CONTACTS;
-    cstride = pts * kContactWords;
+    cstride = (pts + 1) * kContactWords;  // (+ the sentinel record)
     cslots = floats / cstride;
     cslots = cslots > 64 ? 64 : cslots;
   }
@@ -304,7 +380,7 @@ struct Body {
   // constraint solve of stepSimulation: contacts found at the pre-integration pose act on the new velocities; returns the
   // position-level penetration recovery (contact_erp x deepest penetration) to add to z after the position update
   const pf_params* pdev;  // device copy of the parameter block (the out-of-line contact solver reads the colliders from it)
-  lds_fptr cws;           // the wave's kContactSlots LDS regions for the contact solver
+  lds_fptr cws;           // the wave's LDS regions for the contact solver
   // Can any contact constraint act this tick? Every vertex lies within bound_radius of the base origin, so its height is
   // >= low = p.z - bound_radius and its normal velocity >= v.z - |w| bound_radius: if even that worst case ends the tick
   // above the allowed overlap (and nothing is deeper than it now), every constraint of the solve is slack -- all impulses

@@ -57,11 +57,12 @@ def parse():
                          "a departure from the reference; diagnostic A/B, never the headline configuration (the default has the solve on)")
     ap.add_argument("--world", action="append", default=[], metavar="KEY=VALUE",
                     help="override an entry of pyflyt_amd.params.WORLD (diagnostic), e.g. --world contact_iters=6")
+    ap.add_argument("--flight-mode", type=int, default=0, help="QuadX flight mode -1..7 (auxiliary figures; the metric is quoted on mode 0)")
     ap.add_argument("--rollout-steps", type=int, default=100, help="env steps per pf_rollout launch of the second, state-resident figure (0 = skip)")
     return ap.parse_args()
 
 
-def make_engine(env, batch, device, lane_offset, noise, contact_response=True, world=()):
+def make_engine(env, batch, device, lane_offset, noise, contact_response=True, world=(), flight_mode=0):
     from pyflyt_amd import build_params
     from pyflyt_amd.engine import BatchEngine
 
@@ -76,7 +77,8 @@ def make_engine(env, batch, device, lane_offset, noise, contact_response=True, w
     for kv in world:
         k, v = kv.split("=", 1)
         wo[k] = float(v) if "." in v or "e" in v.lower() else int(v)
-    P = build_params(vehicle, task, noise=noise, autoreset="next_step", seed=0, world_options=wo or None)
+    kw = dict(flight_mode=flight_mode) if vehicle == "quadx" else {}
+    P = build_params(vehicle, task, noise=noise, autoreset="next_step", seed=0, world_options=wo or None, **kw)
     return BatchEngine(P, batch, device=device, lane_offset=lane_offset)
 
 
@@ -139,7 +141,7 @@ def main():
     # per-GPU slice; no collective in the timed loop
     shard = weak_shard(args.batch, rank, world) if args.scaling == "weak" else strong_shard(args.batch, rank, world, unit=4 if args.env == "dogfight" else 1)
     n = shard.lanes
-    eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise, contact_response=not args.no_contact_response, world=args.world)
+    eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise, contact_response=not args.no_contact_response, world=args.world, flight_mode=args.flight_mode)
     g = max(1, min(args.graph_steps, args.steps))
     ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(g)]
     for i, a in enumerate(ring):
@@ -252,7 +254,7 @@ def main():
                                    f"random actions, motor noise {args.noise}, NEXT_STEP auto-reset"
                        if args.env == "hover" else f"{args.env}, batch {n}/GPU x {world}",
                        "batch_per_gpu": n, "global_batch": total_lanes, "ticks_per_env_step": eng.ticks_per_step,
-                       "launch": "hipGraph" if graph is not None else "eager", "contact_response": bool(eng.params.contact_response), "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
+                       "flight_mode": args.flight_mode, "launch": "hipGraph" if graph is not None else "eager", "contact_response": bool(eng.params.contact_response), "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "kernel": {"fixedwing_waypoints": "pf::fixedwing_wp_env_kernel", "dogfight": "pf::dogfight_env_kernel"}.get(args.env, "pf::quadx_m0_env_kernel"),

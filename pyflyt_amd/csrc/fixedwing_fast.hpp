@@ -514,7 +514,7 @@ struct FwHot {
     if (near) {
       const float r0 = Pfull->bound_radius, slop = Pfull->contact_slop;
       const float low = p.z - r0, vlow = v.z - fsqrt(dot(w, w)) * r0;
-      act = (fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop);
+      act = ((fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop)) && (low <= Pfull->contact_margin);  // (no vertex can be within the margin otherwise)
     }
     if (__any(act)) {
       const int stride = (Pfull->contact_max_points + 1) * kContactWords;

@@ -746,20 +746,21 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
-  const int grid = (ctx->n + 63) / 64;
-#define PF_FAST2(NZ, CR) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
-#define PF_FAST(NZ) do { if (ctx->P.contact_response) PF_FAST2(NZ, true); else PF_FAST2(NZ, false); } while (0)
+  const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
+#define PF_FAST3(NZ, CR, MD) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
+  // (flight modes other than 0: the MODES instantiation, contact response compiled in -- quadk_from_params)
+#define PF_FAST(NZ) do { if (ctx->K.mode != 0) PF_FAST3(NZ, true, true); else if (ctx->P.contact_response) PF_FAST3(NZ, true, false); else PF_FAST3(NZ, false, false); } while (0)
   if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
   else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
   else PF_FAST(PF_NOISE_OFF);
 #undef PF_FAST
-#undef PF_FAST2
+#undef PF_FAST3
 }
 template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
-  const int grid = (ctx->n + 63) / 64;
-#define PF_ROLL2(NZ, R, CR) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR>), dim3(grid), dim3(64), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
-#define PF_ROLL(NZ, R) do { if (ctx->P.contact_response) PF_ROLL2(NZ, R, true); else PF_ROLL2(NZ, R, false); } while (0)
+  const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
+#define PF_ROLL3(NZ, R, CR, MD) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+#define PF_ROLL(NZ, R) do { if (ctx->K.mode != 0) PF_ROLL3(NZ, R, true, true); else if (ctx->P.contact_response) PF_ROLL3(NZ, R, true, false); else PF_ROLL3(NZ, R, false, false); } while (0)
   if (b->actions == nullptr) {
     if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX, 1);
     else PF_ROLL(PF_NOISE_OFF, 1);
@@ -768,7 +769,7 @@ static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32
     else PF_ROLL(PF_NOISE_OFF, 2);
   }
 #undef PF_ROLL
-#undef PF_ROLL2
+#undef PF_ROLL3
 }
 static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
@@ -1052,15 +1053,18 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
   if (k_steps < 1) return fail(ctx, PF_ERR_ARG, "pf_rollout: k_steps must be >= 1");
   const pf_params& P = ctx->P;
   const bool fw = ctx->fast_fw && ctx->tmpl;
-  if (!fw && (!ctx->fast || (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS)))
-    return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: supported for the specialised kernels only (QuadX mode-0 Hover / Waypoints, Fixedwing-Waypoints)");
+  if (!fw && !ctx->fast)
+    return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: supported for the specialised kernels only (QuadX Hover / Waypoints / multi-agent Hover in any flight mode, Fixedwing-Waypoints)");
   if (P.noise_mode == PF_NOISE_INJECT) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: PF_NOISE_INJECT is a per-step protocol; use pf_env_step");
-  if (P.autoreset == PF_AUTORESET_OFF) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: needs an auto-reset mode (finished lanes would idle for the rest of the launch)");
+  // (the PettingZoo task has no auto-reset: finished agents are culled by the caller, their drones fly on in the shared world)
+  if (P.autoreset == PF_AUTORESET_OFF && P.task != PF_TASK_MA_HOVER)
+    return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: needs an auto-reset mode (finished lanes would idle for the rest of the launch)");
   int rc = ensure_device(ctx);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (fw) launch_rollout_fw(ctx, b, k_steps, step_index0, s);
   else if (P.task == PF_TASK_HOVER) launch_rollout<PF_TASK_HOVER>(ctx, b, k_steps, step_index0, s);
+  else if (P.task == PF_TASK_MA_HOVER) launch_rollout<PF_TASK_MA_HOVER>(ctx, b, k_steps, step_index0, s);
   else launch_rollout<PF_TASK_WAYPOINTS>(ctx, b, k_steps, step_index0, s);
   PF_HIP(ctx, hipGetLastError());
   return PF_OK;

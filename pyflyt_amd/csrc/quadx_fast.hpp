@@ -21,6 +21,7 @@
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
 #include "uav_vehicles.hpp"  // contact_solve_dev
+#include "shared_world.hpp"
 
 namespace pf {
 
@@ -31,6 +32,7 @@ struct QuadK {
   float use_gyro;              // 1.0 / 0.0
   float bound_radius;          // gate of the out-of-line floor code (incl. the speculative contact margin)
   float bound_radius0, slop;   // the bare bounding radius and the allowed overlap: "can a contact constraint act this tick?"
+  float margin;                // the speculative contact margin: no vertex above it is a contact
   float box_h[3], plane_xy, plane_z;  // the collision box's half extents and the slab's: kernel-argument SGPRs, because with random
                                       // actions some lane of nearly every wave is near the floor in nearly every tick -- as scalar
                                       // loads inside that block they cost a memory round trip per tick (+0.7 us per env step)
@@ -53,6 +55,8 @@ struct QuadK {
   int32_t task_sparse, angle_repr, num_targets, max_steps, env_step_ratio, settle_steps, tpc;
   int32_t noise_mode, autoreset, fast_settle;
   uint32_t seed_lo, seed_hi;
+  int32_t apw;                   // agents per world (PF_TASK_MA_HOVER with a shared world), else 1
+  int32_t mode;                  // flight mode -1 .. 7 (quadx.py:233-373); 0 for the MODES = false instantiations
   int32_t use_yaw;               // quadx_waypoints_env.py:40
   float goal_angle;              // :42
   float act_lo[4], act_span[4];  // action box (quadx_base_env.py:80-102): low, high - low (pf_rollout's on-device sampling)
@@ -60,10 +64,16 @@ struct QuadK {
 
 // Fill QuadK from the ABI struct; returns false when the configuration needs the generic kernel.
 inline bool quadk_from_params(const pf_params& P, QuadK& K) {
-  if (P.vehicle != PF_QUADX || P.flight_mode != 0) return false;
+  if (P.vehicle != PF_QUADX || P.flight_mode < -1 || P.flight_mode > 7) return false;
+  // the cascaded modes' instantiations exist with the contact response compiled in only (the default; the detection-only
+  // opt-out of a cascaded-mode env runs on the generic kernel)
+  if (P.flight_mode != 0 && !P.contact_response) return false;
+  if (P.flight_mode != 0 && P.ticks_per_control * P.dt != P.control_period) return false;
   if (P.task != PF_TASK_HOVER && P.task != PF_TASK_WAYPOINTS && P.task != PF_TASK_MA_HOVER) return false;
   if (P.has_com_offset) return false;
-  if (P.agents_per_world > 1) return false;  // shared worlds: the generic kernel exchanges poses between the lanes of a world
+  // shared worlds (the PettingZoo task): the lanes of a world exchange poses through LDS before every tick; whole worlds per
+  // wave, and a dead drone must come to rest on the floor
+  if (P.agents_per_world > 1 && (P.task != PF_TASK_MA_HOVER || 64 % P.agents_per_world != 0 || !P.contact_response)) return false;
   {  // QuadHot::derive() builds the rotation with scale 2 instead of btMatrix3x3::setRotation's 2/|q|^2: unit spawn quaternion only
     const float q2 = P.start_quat[0] * P.start_quat[0] + P.start_quat[1] * P.start_quat[1] + P.start_quat[2] * P.start_quat[2] + P.start_quat[3] * P.start_quat[3];
     if (!(q2 > 1.0f - 1e-6f && q2 < 1.0f + 1e-6f)) return false;
@@ -92,7 +102,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.use_gyro = P.use_gyro_term ? 1.f : 0.f;
   // gate of the out-of-line floor code: within one bounding radius of the floor, widened by the speculative contact margin
   K.bound_radius = P.bound_radius + (P.contact_response ? P.contact_margin : 0.0f);
-  K.bound_radius0 = P.bound_radius; K.slop = P.contact_slop;
+  K.bound_radius0 = P.bound_radius; K.slop = P.contact_slop; K.margin = P.contact_margin;
   for (int k = 0; k < 3; ++k) K.box_h[k] = P.boxes[0].h[k];
   K.plane_xy = P.plane_half_xy; K.plane_z = P.plane_half_z;
   K.m_a = P.motor_dt_over_tau[0]; K.m_noise = P.motor_noise[0]; K.fmax = P.motor_fmax[0]; K.tmax = P.motor_tmax[2];
@@ -119,6 +129,8 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.noise_mode = P.noise_mode; K.autoreset = P.autoreset;
   K.seed_lo = (uint32_t)P.seed; K.seed_hi = (uint32_t)(P.seed >> 32);
   for (int k = 0; k < 4; ++k) { K.act_lo[k] = P.action_low[k]; K.act_span[k] = P.action_high[k] - P.action_low[k]; }
+  K.mode = P.flight_mode;
+  K.apw = P.agents_per_world > 1 ? P.agents_per_world : 1;
   K.use_yaw = (P.task == PF_TASK_WAYPOINTS && P.use_yaw_targets) ? 1 : 0;
   K.goal_angle = P.goal_reach_angle;
   // level spawn at rest, far enough above the floor that the settle free-fall cannot touch it
@@ -139,6 +151,39 @@ __device__ __noinline__ bool quad_floor_contact(float px, float py, float pz, qu
   return box_overlaps_aabb(v3{px, py, pz}, R, ha, v3{0.f, 0.f, -plane_z}, hb);
 }
 
+// Controller memories of the outer loops (flight modes 1-7, quadx.py:437-479): state groups 7-11, the generic QuadX layout
+// (uav_vehicles.hpp: QuadX::load / store).
+struct QuadCasc {
+  float I1[3], E1[3];                // ang_pos
+  float I2[2], E2[2], I3[2], E3[2];  // lin_vel, lin_pos
+  float zI[2], zE[2];                // z_vel, z_pos
+  PF_DEV void zero() {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) I1[k] = E1[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) I2[k] = E2[k] = I3[k] = E3[k] = zI[k] = zE[k] = 0.0f;
+  }
+  PF_DEV void load(const float4* S, size_t n, size_t i) {
+    const float4 g7 = S[7 * n + i], g8 = S[8 * n + i], g9 = S[9 * n + i], g10 = S[10 * n + i], g11 = S[11 * n + i];
+    I1[0] = g7.x; I1[1] = g7.y; I1[2] = g7.z; E1[0] = g7.w;
+    E1[1] = g8.x; E1[2] = g8.y; I2[0] = g8.z; I2[1] = g8.w;
+    E2[0] = g9.x; E2[1] = g9.y; I3[0] = g9.z; I3[1] = g9.w;
+    E3[0] = g10.x; E3[1] = g10.y; zI[0] = g10.z; zI[1] = g10.w;
+    zE[0] = g11.x; zE[1] = g11.y;
+  }
+  PF_DEV void store(float4* S, size_t n, size_t i) const {
+    S[7 * n + i] = float4{I1[0], I1[1], I1[2], E1[0]};
+    S[8 * n + i] = float4{E1[1], E1[2], I2[0], I2[1]};
+    S[9 * n + i] = float4{E2[0], E2[1], I3[0], I3[1]};
+    S[10 * n + i] = float4{E3[0], E3[1], zI[0], zI[1]};
+    S[11 * n + i] = float4{zE[0], zE[1], 0.0f, 0.0f};
+  }
+};
+// one PID component with its gains read through the scalar cache (abstractions/pid.py:70-94)
+PF_DEV float pid_k(const pf_pid __attribute__((address_space(4)))* g, int k, float T, float invT, float& I, float& E, float st, float sp) {
+  return pid1(g->kp[k], g->ki[k], g->kd[k], g->lim[k], T, invT, I, E, st, sp);
+}
+
 struct QuadHot {
   v3 p; quat q;
   // angular / linear velocity as (w, v) element pairs, motor throttle and pwm as (0, 1), (2, 3) pairs: the operands of the
@@ -154,6 +199,9 @@ struct QuadHot {
   PF_DEV void set_wv(v3 w_, v3 v_) { wvx = f2{w_.x, v_.x}; wvy = f2{w_.y, v_.y}; wvz = f2{w_.z, v_.z}; }
   PF_DEV float thr(int i) const { return i == 0 ? t01.x : i == 1 ? t01.y : i == 2 ? t23.x : t23.y; }
   bool contact_now, contact_step;
+  // shared world (dogfight.hpp: world_exchange): a contact point anywhere in the world after the previous tick (quadx.py:509),
+  // this tick's drone-drone verdict for this body. Both stay false outside tick<.., SHARED = true>.
+  bool world_contact = false, peer_contact = false;
   lds_fptr cws;  // the wave's LDS regions for the contact solver (aliased onto the observation tile, idle during the ticks)
   int cws_floats;
 
@@ -178,8 +226,53 @@ struct QuadHot {
     wb = v3{bx.x, by.x, bz.x};  // mulT(R, w)
     vb = v3{bx.y, by.y, bz.y};  // mulT(R, v)
   }
-  // update_control, mode 0 (quadx.py:437-438,472,482-493)
-  PF_DEV void control(const QuadK& K, float s0, float s1, float s2, float s3) {
+  // roll, pitch, yaw of getEulerFromQuaternion from the rotation matrix derive() holds (unit q; gimbal branch: the library definition)
+  PF_DEV v3 euler_now() const {
+    if (__builtin_fabsf(R.m20) >= 0.99999f) return euler_from_quat(q);
+    return v3{fast_atan2(R.m21, R.m22), fast_asin(-R.m20), fast_atan2(R.m10, R.m00)};
+  }
+  // The outer loops of flight modes 1-7 (quadx.py:437-479): turns the setpoint into the angular-rate setpoint (s0, s1, s2) and
+  // the thrust command s3 the mode-0 stage below consumes. mode is wave-uniform; Pk: the device parameter block through the
+  // scalar cache (the outer loops' gains are read where they are used, not held in SGPRs through the tick loop).
+  PF_DEV void outer_loops(const int mode, const pf_params_kptr Pk, QuadCasc& C, float& s0, float& s1, float& s2, float& s3) {
+    const float T = Pk->control_period, iT = Pk->inv_control_period;
+    const v3 rpy = euler_now();
+    if (mode >= 4) {
+      if (mode == 7) {  // position -> velocity
+        s0 = pid_k(&Pk->pid[3], 0, T, iT, C.I3[0], C.E3[0], p.x, s0);
+        s1 = pid_k(&Pk->pid[3], 1, T, iT, C.I3[1], C.E3[1], p.y, s1);
+      }
+      if (mode == 6 || mode == 7) {  // world -> body yaw frame (quadx.py:448-451,460-463); (cos, sin) of the yaw from R, no trig
+        const float h = frsq(fmaf(R.m00, R.m00, R.m10 * R.m10));
+        const float c = R.m00 * h, sn = R.m10 * h;
+        const float b0 = fmaf(c, s0, sn * s1), b1 = fmaf(c, s1, -(sn * s0));
+        s0 = b0; s1 = b1;
+      }
+      s0 = pid_k(&Pk->pid[2], 0, T, iT, C.I2[0], C.E2[0], vb.x, s0);  // velocity -> angle
+      s1 = pid_k(&Pk->pid[2], 1, T, iT, C.I2[1], C.E2[1], vb.y, s1);
+      { const float t0 = -s1, t1 = s0; s0 = t0; s1 = t1; }
+      s0 = pid_k(&Pk->pid[1], 0, T, iT, C.I1[0], C.E1[0], rpy.x, s0);  // angle -> rate
+      s1 = pid_k(&Pk->pid[1], 1, T, iT, C.I1[1], C.E1[1], rpy.y, s1);
+      if (mode == 7) s2 = pid_k(&Pk->pid[1], 2, T, iT, C.I1[2], C.E1[2], rpy.z, s2);
+    } else if (mode == 1 || mode == 3) {
+      s0 = pid_k(&Pk->pid[1], 0, T, iT, C.I1[0], C.E1[0], rpy.x, s0);
+      s1 = pid_k(&Pk->pid[1], 1, T, iT, C.I1[1], C.E1[1], rpy.y, s1);
+      s2 = pid_k(&Pk->pid[1], 2, T, iT, C.I1[2], C.E1[2], rpy.z, s2);
+    }
+    if (!(mode == 1 || mode == 5 || mode == 6)) s3 = pid_k(&Pk->zpid[1], 0, T, iT, C.zI[1], C.zE[1], p.z, s3);  // height -> climb rate
+    s3 = pid_k(&Pk->zpid[0], 0, T, iT, C.zI[0], C.zE[0], vb.z, s3);                                            // climb rate -> thrust
+  }
+  // update_control (quadx.py:401-493). MODES = false: flight mode 0 only (rate PID + thrust, :437-438,472,482-493), the
+  // instantiation BASELINE's metric is quoted on; MODES = true: K.mode selects -1 .. 7 at run time (wave-uniform branches).
+  template <bool MODES>
+  PF_DEV void control(const QuadK& K, const pf_params_kptr Pk, QuadCasc& C, float s0, float s1, float s2, float s3) {
+    if (MODES) {
+      if (K.mode == -1) {  // motor commands as they are (quadx.py:427-429): no clipping
+        pw01 = f2{s0, s1}; pw23 = f2{s2, s3};
+        return;
+      }
+      if (K.mode != 0) outer_loops(K.mode, Pk, C, s0, s1, s2, s3);
+    }
     const float st[3] = {wb.x, wb.y, wb.z};
     const float sp[3] = {s0, s1, s2};
     float a[3];
@@ -216,7 +309,7 @@ struct QuadHot {
   // step that reports a floor contact, so the response can only alter that terminal observation; it is a template switch
   // because even its never-taken call site costs the hot loop (+0.6 us per env step at 65 536 lanes: one more divergent region
   // and its PHI copies per tick, profiles/r02), and with random actions some lane of nearly every wave is near the floor.
-  template <bool CR>
+  template <bool CR, bool SHARED = false>
   PF_DEV void tick(const QuadK& K, float xi, const pf_params* Pfull) {
     const float s = fmaf(xi, K.m_noise, 1.0f);
     float k[4];
@@ -229,7 +322,7 @@ struct QuadHot {
     }
     // body-frame angular acceleration (torque / inertia, constants pre-divided): motor arms and reaction torque,
     // rotational drag gated on "no contact in the world" (quadx.py:502-510), gyroscopic term -(w x I w) / I
-    const float pqf = contact_now ? 0.0f : 1.0f;
+    const float pqf = (contact_now || (SHARED && world_contact)) ? 0.0f : 1.0f;
     v3 wdb{fmaf(K.ryfI[0], k[0], fmaf(K.ryfI[1], k[1], fmaf(K.ryfI[2], k[2], K.ryfI[3] * k[3]))),
            fmaf(K.rxfI[0], k[0], fmaf(K.rxfI[1], k[1], fmaf(K.rxfI[2], k[2], K.rxfI[3] * k[3]))),
            K.tmaxI * ((k[2] + k[3]) - (k[0] + k[1]))};
@@ -260,6 +353,7 @@ struct QuadHot {
         if (!inside) contact_now = quad_floor_contact(p.x, p.y, p.z, q, hx, hy, hz, pxy, pz);
       }
     }
+    if (SHARED) contact_now = contact_now || peer_contact;  // drone-drone hits enter contact_array[drone.Id] too (aviary.py:523-525)
     // world-frame angular and linear acceleration, R wdb and R Fm + g, row by row on (wdb, Fm) element pairs; then the
     // semi-implicit velocity update on (w, v) pairs. (fma(x, y, -0) == x * y for every x, y: the angular half of the last
     // row has no gravity term.)
@@ -281,8 +375,10 @@ struct QuadHot {
     if (CR) {
       bool act = false;
       if (near) {  // (low: the exact height of the lowest vertex, from the detection above)
+        // (and no vertex is a contact unless the lowest one is within the margin; 1e-6: `low` and the solver's vertex heights
+        //  are the same quantity rounded differently)
         const float vlow = wvz.y - fsqrt(dot(w(), w())) * K.bound_radius0;
-        act = (fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop);
+        act = ((fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop)) && (low <= K.margin + 1e-6f);
       }
       if (__any(act)) {
         // regions sized for this airframe's own contact count: the single box needs 8 x 11 floats, 26 lanes per round
@@ -329,20 +425,38 @@ __device__ unsigned long long g_phase_trace[4096 * kPhaseStamps];
 // loop then contains NO vector-memory load, so nothing in it ever waits on vmcnt (on gfx9 stores count in vmcnt too: a
 // load in the loop would make every step wait for the previous step's observation stores to be acknowledged);
 // 2 = pf_rollout over a given action sequence (prefetched one step ahead; pays that wait).
-template <int TASK, int NOISE, int LPW, int ROLL, bool CR>
-__global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
+// PF_WPB wavefronts per workgroup (each wave works on its own 64 lanes and its own slice of the LDS arrays; there is no barrier
+// and no inter-wave traffic): the dispatcher launches workgroups, not waves, at a limited rate -- with one wave per workgroup the
+// 1 024 workgroups of a 65 536-lane launch enter over 2.5 us (profiles/r03/phase_trace_*.txt).
+#ifndef PF_WPB
+#define PF_WPB 1
+#endif
+constexpr int kQuadWPB = PF_WPB;
+// MODES: false = flight mode 0 only; true = the flight mode is K.mode, -1 .. 7 (cascaded PIDs; their memories in state groups
+// 7-11 and, at reset, the z PIDs inside the settle recurrence).
+template <int TASK, int NOISE, int LPW, int ROLL, bool CR, bool MODES = false>
+__global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
                                                              const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
   constexpr bool ROLLOUT = ROLL != 0;
   constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 4 + 16;  // attitude + 4 targets x (delta, yaw error)
   constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
-  __shared__ __attribute__((aligned(16))) float tile[LPW * kMaxD];
-  __shared__ float sxi[64 * kSettleMax];
-  __shared__ int spos[64];
-  __shared__ uint32_t sctr[64];
-  const int tid = threadIdx.x;
-  const int wave_base = blockIdx.x * LPW;
+  __shared__ __attribute__((aligned(16))) float tile_all[kQuadWPB * LPW * kMaxD];
+  __shared__ __attribute__((aligned(16))) float sxi_all[kQuadWPB * 64 * kSettleMax];
+  __shared__ int spos_all[kQuadWPB * 64];
+  __shared__ float wpose_all[TASK == PF_TASK_MA_HOVER ? kQuadWPB * 64 * 8 : 1];  // shared worlds: pose + contact bit of every lane
+  __shared__ uint32_t sctr_all[kQuadWPB * 64];
+  const int wid = kQuadWPB > 1 ? (int)(threadIdx.x >> 6) : 0;
+  const int tid = kQuadWPB > 1 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+  float* const tile = tile_all + wid * (LPW * kMaxD);
+  float* const sxi = sxi_all + wid * (64 * kSettleMax);
+  int* const spos = spos_all + wid * 64;
+  uint32_t* const sctr = sctr_all + wid * 64;
+  float* const wpose = wpose_all + (TASK == PF_TASK_MA_HOVER ? wid * 64 * 8 : 0);
+  const int apw = TASK == PF_TASK_MA_HOVER ? K.apw : 1;
+  const int wave_base = (blockIdx.x * kQuadWPB + wid) * LPW;
+  if (kQuadWPB > 1 && wave_base >= n) return;  // (no barrier anywhere: a surplus wave simply leaves)
   const int lane = wave_base + tid;
   const bool valid = (tid < LPW) && (lane < n);
   const size_t li = valid ? (size_t)lane : (size_t)(n - 1);
@@ -359,6 +473,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   static_assert(LPW * kMaxD >= kContactSlotFloats, "the contact solver's LDS regions alias the observation tile: at least one worst-case region");
   V.cws = (lds_fptr)tile;
   V.cws_floats = LPW * kMaxD;
+  QuadCasc C;  // (MODES only; dead otherwise)
+  const pf_params_kptr Pk = uniform_params(Pfull);
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;
@@ -392,6 +508,8 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     }
   }
   old_dist = new_dist;
+  if (MODES && K.mode > 0) C.load(Sin, N, li);
+  else C.zero();
   // MA hover (ma_quadx_base_env.py:139-150,326-332): the action of the previous call, observed this call
   float4 ma_past = float4{0.f, 0.f, 0.f, 0.f};
   if (TASK == PF_TASK_MA_HOVER) ma_past = Sin[15 * N + li];
@@ -483,9 +601,24 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     // the host passes the least level / lowest agent as the parameter block's start pose)
     const float sx = TASK == PF_TASK_MA_HOVER ? tgt[0][0] : K.start_pos[0], sy = TASK == PF_TASK_MA_HOVER ? tgt[0][1] : K.start_pos[1];
     float thr = 0.f, vz = 0.f, z = TASK == PF_TASK_MA_HOVER ? tgt[0][2] : K.start_pos[2];
+    // Flight modes other than 0 (MODES): set_mode's default setpoint holds the spawn pose (quadx.py:233-373), every attitude,
+    // rate and lateral error is exactly zero on a level spawn at rest, so the cascade reduces to its z PIDs -- run here once per
+    // Aviary step on the vertical state -- and four equal motor commands: still a vertical recurrence.
+    float pwm_s = 0.05f;  // mode 0: rate error 0 -> command 0 -> clipped to 0.05
+    const float z_hold = z;
+    C.zero();  // set_mode: fresh PID objects; drone.reset(): the z PIDs too (quadx.py:206,222-231)
+    auto settle_control = [&]() {
+      if (!MODES || K.mode == 0) return;
+      if (K.mode == -1) { pwm_s = 0.0f; return; }  // motor commands = setpoint = 0, no clipping (quadx.py:427-429)
+      const float T = Pk->control_period, iT = Pk->inv_control_period;
+      float zc = (K.mode == 1 || K.mode == 5 || K.mode == 6) ? 0.0f : z_hold;
+      if (!(K.mode == 1 || K.mode == 5 || K.mode == 6)) zc = pid_k(&Pk->zpid[1], 0, T, iT, C.zI[1], C.zE[1], z, zc);
+      zc = pid_k(&Pk->zpid[0], 0, T, iT, C.zI[0], C.zE[0], vz, zc);
+      pwm_s = med3(med3(zc, 0.0f, 1.0f), 0.05f, 1.0f);
+    };
     auto settle_tick = [&](float xi) {
       float s = fmaf(xi, K.m_noise, 1.0f);
-      thr = fmaf(K.m_a, 0.05f - thr, thr) * s;
+      thr = fmaf(K.m_a, pwm_s - thr, thr) * s;
       float kk = thr * __builtin_fabsf(thr);
       float Fz = fmaf(-K.drag[2], vz * __builtin_fabsf(vz), 4.0f * (K.fmax * kk));
       float az = fmaf(K.inv_mass, Fz, K.gravity_z);
@@ -498,13 +631,14 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       else if (NOISE == PF_NOISE_INJECT) x = float4{B.xi_reset[(size_t)(t + 0) * N + li], B.xi_reset[(size_t)(t + 1) * N + li],
                                                     B.xi_reset[(size_t)(t + 2) * N + li], B.xi_reset[(size_t)(t + 3) * N + li]};
       else x = float4{0.f, 0.f, 0.f, 0.f};
-      settle_tick(x.x); settle_tick(x.y); settle_tick(x.z); settle_tick(x.w);
+      settle_control(); settle_tick(x.x); settle_tick(x.y);  // (two ticks per control: quadk_from_params)
+      settle_control(); settle_tick(x.z); settle_tick(x.w);
     }
     V.p = v3{sx, sy, z};
     if (TASK == PF_TASK_MA_HOVER) V.q = quat{tgt[1][0], tgt[1][1], tgt[1][2], tgt[2][0]};
     else V.q = quat{K.start_quat[0], K.start_quat[1], K.start_quat[2], K.start_quat[3]};
     V.set_wv(v3{0.f, 0.f, 0.f}, v3{0.f, 0.f, vz});
-    V.t01 = V.t23 = sp2(thr); V.pw01 = V.pw23 = sp2(0.05f);
+    V.t01 = V.t23 = sp2(thr); V.pw01 = V.pw23 = sp2(pwm_s);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { V.I[k] = 0.f; V.E[k] = 0.f; }
     V.contact_now = false; V.contact_step = false;
@@ -683,9 +817,19 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
       else { xi0 = 0.f; xi1 = 0.f; }
       // one Aviary.step (aviary.py:480-531): control on the first tick, pwm held on the second
       V.contact_step = false;
-      V.control(K, sp0, sp1, sp2, sp3);
-      V.template tick<CR>(K, xi0, Pfull);
-      V.template tick<CR>(K, xi1, Pfull);
+      V.template control<MODES>(K, Pk, C, sp0, sp1, sp2, sp3);
+      if (TASK == PF_TASK_MA_HOVER && apw > 1) {
+        // one world for the agents of an env: pose / contact exchange before every tick. Every lane of a world is in here
+        // together: the PettingZoo task has no early exit from the inner loop and resets whole worlds.
+        world_exchange(V, wpose, tid, apw, K.bound_radius0, Pfull);
+        V.template tick<CR, true>(K, xi0, Pfull);
+        world_exchange(V, wpose, tid, apw, K.bound_radius0, Pfull);
+        V.template tick<CR, true>(K, xi1, Pfull);
+        V.peer_contact = false;
+      } else {
+        V.template tick<CR>(K, xi0, Pfull);
+        V.template tick<CR>(K, xi1, Pfull);
+      }
       // compute_state side effects + compute_term_trunc_reward
       if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:135-142; ||R^T d|| = ||d||
         if (pop_pending) { pop_target(); pop_pending = false; }
@@ -807,6 +951,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
     Sout[4 * N + li] = float4{V.t23.x, V.t23.y, V.I[0], V.I[1]};
     Sout[5 * N + li] = float4{V.I[2], V.E[0], V.E[1], V.E[2]};
     Sout[6 * N + li] = float4{__int_as_float(step_count), __int_as_float(flags), __int_as_float((int)rng_ctr), __int_as_float(n_left)};
+    if (MODES && K.mode > 0) C.store(Sout, N, li);
     if (TASK == PF_TASK_MA_HOVER) Sout[15 * N + li] = ma_past;
     if (kYaw) Sout[15 * N + li] = float4{ytg[0], ytg[1], ytg[2], ytg[3]};
     if (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER) {
@@ -820,7 +965,7 @@ __global__ void __launch_bounds__(64, 2) quadx_m0_env_kernel(const QuadK K, cons
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): every store acknowledged
   PF_STAMP(10);
   pf_ts[12] = __builtin_amdgcn_s_memrealtime();
-  if (ROLL == 0 && tid == 0 && blockIdx.x < 4096) {
+  if (ROLL == 0 && tid == 0 && wid == 0 && blockIdx.x < 4096) {
 #pragma unroll
     for (int i = 0; i < kPhaseStamps; ++i) g_phase_trace[blockIdx.x * kPhaseStamps + i] = pf_ts[i];
   }

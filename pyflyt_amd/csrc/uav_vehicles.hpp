@@ -388,6 +388,7 @@ struct Body {
   PF_DEV bool contact_may_act(const pf_params* Pd) const {
     const float low = p.z - Pd->bound_radius;
     if (!slab_in_reach(*Pd, Pd->contact_margin)) return false;
+    if (low > Pd->contact_margin) return false;  // no vertex can be within the contact margin
     const float vlow = v.z - __builtin_sqrtf(dot(w, w)) * Pd->bound_radius;
     return (low + Pd->contact_slop + Pd->dt * vlow < 0.0f) || (low < -Pd->contact_slop);
   }

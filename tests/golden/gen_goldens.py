@@ -397,6 +397,37 @@ def gen_envs():
     save("env_fixedwing_waypoints_gentle", **run_env(lambda: FixedwingWaypointsEnv(goal_reach_distance=40.0), 400, 6, gentle_fw_action, num_targets=4, ticks=8))
 
 
+def mode_action(mode):
+    """Random setpoints that exercise a flight mode's outer loops without leaving its sensible range (the action box itself,
+    quadx_base_env.py:80-102, is the same [-pi, pi]^3 x [0, 0.8] for every mode but -1)."""
+    def f(env, rng, k):
+        if mode == -1:
+            return rng.uniform(0.0, 0.8, size=4)  # motor commands
+        if mode in (1, 3):   # angles (+ climb rate / height)
+            return np.array([*rng.uniform(-0.5, 0.5, size=3), rng.uniform(0.0, 0.8) if mode == 1 else rng.uniform(0.5, 1.5)])
+        if mode == 2:        # rates + height
+            return np.array([*rng.uniform(-1.0, 1.0, size=3), rng.uniform(0.5, 1.5)])
+        if mode in (4, 5, 6):  # velocities (+ yaw rate) + height / climb rate
+            return np.array([*rng.uniform(-1.5, 1.5, size=2), rng.uniform(-1.0, 1.0), rng.uniform(0.5, 1.5) if mode == 4 else rng.uniform(-0.5, 0.8)])
+        return np.array([*rng.uniform(-2.5, 2.5, size=2), rng.uniform(-1.0, 1.0), rng.uniform(0.3, 2.5)])  # 7: position, yaw, height
+    return f
+
+
+def gen_envs_modes():
+    """QuadXHoverEnv / QuadXWaypointsEnv under every flight mode other than 0 (quadx.py:233-373,437-479): the env-level fixtures of
+    the cascaded-PID kernels -- set_mode's default setpoint and the z PIDs inside the reset's settle steps included."""
+    for m in (-1, 1, 2, 3, 4, 5, 6, 7):
+        tag = "m1" if m == -1 else str(m)
+        # (1.5 s episodes: every fixture goes through several resets, i.e. through the settle steps under its mode's controller)
+        save(f"env_hover_mode{tag}", **run_env(lambda: QuadXHoverEnv(flight_mode=m, max_duration_seconds=1.5), 260 if m in (6, 7, -1) else 140, 30 + m, mode_action(m), ticks=6))
+
+    def chase(env, rng, k):  # position mode flown at the next waypoint: targets are reached
+        t = env.waypoints.targets[0]
+        return np.array([t[0], t[1], 0.0, t[2]]) + rng.uniform(-0.05, 0.05, size=4)
+
+    save("env_quadx_waypoints_mode7", **run_env(lambda: QuadXWaypointsEnv(flight_mode=7, goal_reach_distance=0.4), 360, 47, chase, num_targets=4, ticks=8))
+
+
 def gen_envs_yaw():
     # use_yaw_targets=True (quadx_waypoints_env.py:40, waypoint_handler.py:85-89,144-156,167-179): four more uniforms at
     # reset (after the position draws), (remaining, 4) target deltas, reach = distance AND yaw error under goal_reach_angle
@@ -648,6 +679,7 @@ if __name__ == "__main__":
     gen_envs()
     gen_envs_crash()
     gen_envs_yaw()
+    gen_envs_modes()
     gen_landing()
     gen_ma_hover()
     gen_ma_hover_shared()

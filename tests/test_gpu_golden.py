@@ -68,6 +68,9 @@ ENVS = [
     ("env_fixedwing_waypoints_gentle", "fixedwing", "waypoints", dict(goal_reach_distance=40.0)),
     ("env_quadx_waypoints_yaw_random", "quadx", "waypoints", dict(use_yaw_targets=True)),
     ("env_quadx_waypoints_yaw_reach", "quadx", "waypoints", dict(use_yaw_targets=True, goal_reach_distance=2.5, goal_reach_angle=1.2)),
+    # every other flight mode (quadx.py:233-373,437-479): the cascaded-PID instantiation of the specialised kernel, and the generic one
+    *[(f"env_hover_mode{'m1' if m == -1 else m}", "quadx", "hover", dict(flight_mode=m, max_duration_seconds=1.5)) for m in (-1, 1, 2, 3, 4, 5, 6, 7)],
+    ("env_quadx_waypoints_mode7", "quadx", "waypoints", dict(flight_mode=7, goal_reach_distance=0.4)),
 ]
 
 

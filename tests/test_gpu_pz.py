@@ -93,7 +93,8 @@ def _vec_err(got, ref):
     return e
 
 
-def test_shared_world_fixture_replay(golden_dir):
+@pytest.mark.parametrize("kernel", ["specialised", "generic"])
+def test_shared_world_fixture_replay(golden_dir, monkeypatch, kernel):
     """tests/golden/env_ma_quadx_hover_shared.npz -- the reference's PettingZoo env on a world where two agents fly into
     each other and a dead drone ends up on the floor -- replayed through the HIP path (agents_per_world = 4: the four lanes
     of a world exchange poses through LDS every tick)."""
@@ -103,13 +104,15 @@ def test_shared_world_fixture_replay(golden_dir):
     from pyflyt_amd.engine import BatchEngine
     from pyflyt_amd.params import quat_from_euler
 
+    if kernel == "generic":
+        monkeypatch.setenv("PF_DISABLE_FAST", "1")
     g = np.load(os.path.join(golden_dir, "env_ma_quadx_hover_shared.npz"))
     A = g["start_pos"].shape[0]
     P = build_params("quadx", "ma_hover", noise="inject", autoreset="off", start_pos=g["start_pos"][np.argmin(g["start_pos"][:, 2])],
                      start_orn=g["start_orn"][0], flight_dome_size=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 40.0,
                      agents_per_world=A, world_options=dict(contact_response=True))
     eng = BatchEngine(P, A, device="cuda:0")
-    assert eng.lib.pf_ctx_is_specialised(eng._ctx) == 0
+    assert (eng.lib.pf_ctx_is_specialised(eng._ctx) != 0) == (kernel == "specialised")
     pose = np.concatenate([g["start_pos"], np.stack([quat_from_euler(o) for o in g["start_orn"]])], axis=1)
     side = np.zeros((A, 12), dtype=np.float32)
     side[:, :7] = pose

@@ -60,6 +60,61 @@ def test_rollout_bit_identical_to_single_steps(task, noise, autoreset):
     assert n_done > 200  # random actions end episodes quickly: the in-loop resets are exercised
 
 
+@pytest.mark.parametrize("mode", [-1, 4, 7])
+def test_rollout_bit_identical_cascaded_modes(mode):
+    """The cascaded-PID instantiation (flight modes other than 0) of the specialised kernel: pf_rollout == k x pf_env_step,
+    controller memories (state groups 7-11) included."""
+    n, k, seed = 1000, 96, 33
+    a = _engine("hover", n, "philox", "next_step", seed, lane_offset=512, flight_mode=mode)
+    b = _engine("hover", n, "philox", "next_step", seed, lane_offset=512, flight_mode=mode)
+    assert a.lib.pf_ctx_is_specialised(a._ctx) == 1
+    a.env_reset(); b.env_reset()
+    assert torch.equal(a.state, b.state)
+    obs, rew, term, trunc, acts = a.rollout(k)
+    act = torch.empty(n, 4, device="cuda:0")
+    n_done = 0
+    for s in range(k):
+        b.sample_actions(act, s)
+        o, r, t, tr = b.env_step(act)
+        assert torch.equal(act, acts[s]) and torch.equal(o, obs[s]) and torch.equal(r, rew[s]), (mode, s, (o - obs[s]).abs().max().item())
+        assert torch.equal(t, term[s]) and torch.equal(tr, trunc[s]), (mode, s)
+        n_done += int((t | tr).sum())
+    assert torch.equal(a.state, b.state)
+    assert n_done > (200 if mode == -1 else 20), n_done
+
+
+def test_rollout_shared_world_ma_hover():
+    """PettingZoo task, one world per 4 agents, no auto-reset: a rollout over a given action sequence == k x pf_env_step."""
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    n, k, A = 256, 50, 4
+    eng = []
+    for _ in range(2):
+        P = build_params("quadx", "ma_hover", noise="philox", autoreset="off", seed=3, agents_per_world=A, flight_dome_size=3.0,
+                         world_options=dict(contact_response=True))
+        e = BatchEngine(P, n, device="cuda:0")
+        assert e.lib.pf_ctx_is_specialised(e._ctx) == 1
+        # spawn poses: four agents 30 cm apart, level (state groups 12-14: position, quaternion)
+        pos = torch.tensor([[-0.15, 0.0, 1.0], [0.15, 0.0, 1.02], [0.0, 0.3, 1.0], [0.0, -0.3, 0.6]], device="cuda:0").repeat(n // A, 1)
+        e.state[12, :, 0:3] = pos
+        e.state[12, :, 3] = 0.0; e.state[13, :, 0] = 0.0; e.state[13, :, 1] = 0.0; e.state[13, :, 2] = 1.0
+        e.env_reset()
+        eng.append(e)
+    a, b = eng
+    assert torch.equal(a.state, b.state)
+    rng = np.random.default_rng(1)
+    seq = torch.tensor(rng.uniform([-1, -1, -1, 0.1], [1, 1, 1, 0.7], size=(k, n, 4)), dtype=torch.float32, device="cuda:0")
+    obs, rew, term, trunc, _ = a.rollout(k, actions=seq)
+    hits = 0
+    for s in range(k):
+        o, r, t, tr = b.env_step(seq[s].contiguous())
+        assert torch.equal(o, obs[s]) and torch.equal(r, rew[s]) and torch.equal(t, term[s]) and torch.equal(tr, trunc[s]), s
+        hits += int(t.sum())
+    assert torch.equal(a.state, b.state)
+    assert hits > 0  # (drone-drone or floor contacts occurred)
+
+
 def test_rollout_given_action_sequence():
     """An open-loop action sequence [k, n, 4] instead of on-device sampling."""
     n, k = 320, 40
@@ -115,7 +170,8 @@ def test_rollout_refusals():
     e.env_reset()
     with pytest.raises(PyFlytAmdError):
         e.rollout(4)  # no auto-reset mode
-    e = _engine("hover", 64, "philox", "next_step", 1, flight_mode=6)
+    e = _engine("hover", 64, "philox", "next_step", 1, flight_mode=6, world_options=dict(contact_response=False))
+    assert e.lib.pf_ctx_is_specialised(e._ctx) == 0
     e.env_reset()
     with pytest.raises(PyFlytAmdError):
-        e.rollout(4)  # generic kernel configuration
+        e.rollout(4)  # generic kernel configuration (a cascaded mode with the contact response opted out)

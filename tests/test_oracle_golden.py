@@ -274,6 +274,9 @@ ENVS = [
     ("env_fixedwing_waypoints_gentle", "fixedwing_waypoints", {"goal_reach_distance": 40.0}),
     ("env_quadx_waypoints_yaw_random", "quadx_waypoints", {"use_yaw_targets": 1}),
     ("env_quadx_waypoints_yaw_reach", "quadx_waypoints", {"use_yaw_targets": 1, "goal_reach_distance": 2.5, "goal_reach_angle": 1.2}),
+    # every other flight mode (quadx.py:233-373,437-479), 1.5 s episodes (max_steps = 40 Hz x 1.5 s)
+    *[(f"env_hover_mode{'m1' if m == -1 else m}", "hover", {"flight_mode": m, "max_steps": 60}) for m in (-1, 1, 2, 3, 4, 5, 6, 7)],
+    ("env_quadx_waypoints_mode7", "quadx_waypoints", {"flight_mode": 7, "goal_reach_distance": 0.4}),
 ]
 
 

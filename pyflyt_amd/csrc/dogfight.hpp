@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   const int AD = P.df_action_dim == 6 ? 6 : 4;
   const int D = 19 + AD + (A - 1) * 14;
   __shared__ __attribute__((aligned(16))) float tile[kTile];
-  __shared__ float ktab[VEH::TABLE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float ktab[VEH::TABLE_FLOATS];
   __shared__ float wpose[64 * 8];
   __shared__ float rec[64 * kDfRec];
   const int tid = threadIdx.x;

@@ -517,12 +517,9 @@ struct FwHot {
       act = ((fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop)) && (low <= Pfull->contact_margin);  // (no vertex can be within the margin otherwise)
     }
     if (__any(act)) {
-      const int stride = (Pfull->contact_max_points + 1) * kContactWords;
-      contact_rounds(act && Pfull->contact_response, cws, [&](lds_fptr slot) {
-        const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v, w);
-        v = o.v; w = o.w;
-        lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
-      }, min(64, cws_floats / stride), stride);
+      const ContactOut o = contact_solve_dev(Pfull, cws, (act && Pfull->contact_response) ? cws_floats : -1, p, q, v, w);
+      v = o.v; w = o.w;  // (unchanged for a lane that did not ask or has no contact vertex)
+      lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
     }
     p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
     q = quat_integrate(q, w, K.half_dt);

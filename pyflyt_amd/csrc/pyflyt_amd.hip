@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
                                                     const uint64_t lane0, const int op, const uint8_t* mask,
                                                     const float4* __restrict__ tmpl, const pf_params* __restrict__ Pdev) {
   __shared__ __attribute__((aligned(16))) float tile[kWave * kMaxObs];
-  __shared__ float ktab[VEH::TABLE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float ktab[VEH::TABLE_FLOATS];
   __shared__ float wpose[kWave * 8];  // shared worlds: each lane's pose and contact bit, exchanged once per tick
   const int tid = threadIdx.x;
   VEH::fill_table(ktab, Pdev, tid);
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
 // Settled spawn state for contexts whose settle phase is lane-independent (see env_kernel).
 template <class VEH>
 __global__ void settle_template_kernel(const pf_params P, float4* tmpl, const pf_params* __restrict__ Pdev) {
-  __shared__ float ktab[VEH::TABLE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float ktab[VEH::TABLE_FLOATS];
   VEH::fill_table(ktab, Pdev, threadIdx.x);
   __syncthreads();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -512,7 +512,7 @@ template <class VEH>
 __global__ void __launch_bounds__(kWave) aviary_step_kernel(const pf_params P, const pf_buffers B, const int n,
                                                             const uint64_t lane0, const int n_steps,
                                                             const pf_params* __restrict__ Pdev) {
-  __shared__ float ktab[VEH::TABLE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float ktab[VEH::TABLE_FLOATS];
   VEH::fill_table(ktab, Pdev, threadIdx.x);
   __syncthreads();
   const int lane = blockIdx.x * kWave + threadIdx.x;
@@ -586,7 +586,7 @@ template <class VEH>
 __global__ void __launch_bounds__(kWave) aviary_tick_kernel(const pf_params P, const pf_buffers B, const int n,
                                                             const uint64_t lane0, const int tick_index,
                                                             const pf_params* __restrict__ Pdev) {
-  __shared__ float ktab[VEH::TABLE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float ktab[VEH::TABLE_FLOATS];
   VEH::fill_table(ktab, Pdev, threadIdx.x);
   __syncthreads();
   const int lane = blockIdx.x * kWave + threadIdx.x;
@@ -747,19 +747,23 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
-#define PF_FAST3(NZ, CR, MD) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
+#define PF_FAST4(NZ, CR, MD, SH) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
   // (flight modes other than 0: the MODES instantiation, contact response compiled in -- quadk_from_params)
+  // (shared worlds: PF_TASK_MA_HOVER with the contact response on -- quadk_from_params)
+#define PF_FAST3(NZ, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_FAST4(NZ, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_FAST4(NZ, CR, MD, false); } while (0)
 #define PF_FAST(NZ) do { if (ctx->K.mode != 0) PF_FAST3(NZ, true, true); else if (ctx->P.contact_response) PF_FAST3(NZ, true, false); else PF_FAST3(NZ, false, false); } while (0)
   if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
   else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
   else PF_FAST(PF_NOISE_OFF);
 #undef PF_FAST
 #undef PF_FAST3
+#undef PF_FAST4
 }
 template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
-#define PF_ROLL3(NZ, R, CR, MD) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+#define PF_ROLL4(NZ, R, CR, MD, SH) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+#define PF_ROLL3(NZ, R, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_ROLL4(NZ, R, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_ROLL4(NZ, R, CR, MD, false); } while (0)
 #define PF_ROLL(NZ, R) do { if (ctx->K.mode != 0) PF_ROLL3(NZ, R, true, true); else if (ctx->P.contact_response) PF_ROLL3(NZ, R, true, false); else PF_ROLL3(NZ, R, false, false); } while (0)
   if (b->actions == nullptr) {
     if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX, 1);
@@ -770,6 +774,7 @@ static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32
   }
 #undef PF_ROLL
 #undef PF_ROLL3
+#undef PF_ROLL4
 }
 static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
@@ -1086,6 +1091,13 @@ int pf_body_tick(pf_ctx* ctx, const pf_buffers* b, int n_ticks, void* stream) {
 }
 
 #ifdef PF_PHASE_TRACE
+// diagnostic variant only (profiles/tools/solver_trace.py): read (and clear) the contact solver's call statistics
+int pf_debug_solver_trace(unsigned long long* out) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_solver_trace), sizeof(unsigned long long) * 8, 0, hipMemcpyDeviceToHost);
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pf::g_solver_trace), z, sizeof(z), 0, hipMemcpyHostToDevice);
+  return (int)e;
+}
 // diagnostic variant only (profiles/tools/phase_trace.py): copy out the per-wave phase stamps of the last quadx_m0 launch
 int pf_debug_phase_trace(unsigned long long* out, int n_words) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_phase_trace), sizeof(unsigned long long) * (size_t)n_words, 0, hipMemcpyDeviceToHost);

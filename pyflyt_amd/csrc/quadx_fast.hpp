@@ -33,6 +33,8 @@ struct QuadK {
   float bound_radius;          // gate of the out-of-line floor code (incl. the speculative contact margin)
   float bound_radius0, slop;   // the bare bounding radius and the allowed overlap: "can a contact constraint act this tick?"
   float margin;                // the speculative contact margin: no vertex above it is a contact
+  float c_inv_dt, c_rest, c_mu, c_erp;  // the rest of the contact model (pf_params.contact_*): the solve runs inline on these
+  int32_t c_iters;
   float box_h[3], plane_xy, plane_z;  // the collision box's half extents and the slab's: kernel-argument SGPRs, because with random
                                       // actions some lane of nearly every wave is near the floor in nearly every tick -- as scalar
                                       // loads inside that block they cost a memory round trip per tick (+0.7 us per env step)
@@ -103,6 +105,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   // gate of the out-of-line floor code: within one bounding radius of the floor, widened by the speculative contact margin
   K.bound_radius = P.bound_radius + (P.contact_response ? P.contact_margin : 0.0f);
   K.bound_radius0 = P.bound_radius; K.slop = P.contact_slop; K.margin = P.contact_margin;
+  K.c_inv_dt = 1.0f / P.dt; K.c_rest = P.contact_restitution; K.c_mu = P.contact_friction; K.c_erp = P.contact_erp; K.c_iters = P.contact_iters;
   for (int k = 0; k < 3; ++k) K.box_h[k] = P.boxes[0].h[k];
   K.plane_xy = P.plane_half_xy; K.plane_z = P.plane_half_z;
   K.m_a = P.motor_dt_over_tau[0]; K.m_noise = P.motor_noise[0]; K.fmax = P.motor_fmax[0]; K.tmax = P.motor_tmax[2];
@@ -381,14 +384,11 @@ struct QuadHot {
         act = ((fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop)) && (low <= K.margin + 1e-6f);
       }
       if (__any(act)) {
-        // regions sized for this airframe's own contact count: the single box needs 8 x 11 floats, 26 lanes per round
-        const int stride = (Pfull->contact_max_points + 1) * kContactWords;
-        const int slots = min(64, cws_floats / stride);
-        contact_rounds(act, cws, [&](lds_fptr slot) {
-          const ContactOut o = contact_solve_dev(Pfull, slot, p, q, v(), w());
-          set_wv(o.w, o.v);
-          lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
-        }, slots, stride);
+        // (out of line: in the hover task a solve is rare -- a handful per 65 536-lane launch -- and inlined it costs every launch
+        //  0.8 us in register traffic: profiles/README.md, r03)
+        const ContactOut o = contact_solve_dev(Pfull, cws, act ? cws_floats : -1, p, q, v(), w());
+        set_wv(o.w, o.v);  // (unchanged for a lane that did not ask or has no contact vertex)
+        lift = K.c_erp * o.deepest;  // (already net of the slop)
       }
     }
     p = v3{fmaf(K.dt, wvx.y, p.x), fmaf(K.dt, wvy.y, p.y), CR ? fmaf(K.dt, wvz.y, p.z) + lift : fmaf(K.dt, wvz.y, p.z)};
@@ -397,6 +397,42 @@ struct QuadHot {
     contact_step |= contact_now;
   }
 };
+
+// Shared world for the quadrotor of this kernel (one collision box centred on the base origin: quadk_from_params): the generic
+// world_exchange (shared_world.hpp) with the box test written out for that one box pair and everything inline -- an out-of-line
+// call in the tick loop forces every value that lives across it into the callee-saved half of the register file (the first
+// version of this instantiation spilled 300-550 bytes per lane to scratch memory).
+PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const int A, const QuadK& K) {
+  const int wbase = (tid / A) * A, wlocal = tid - wbase;
+  float* me = wpose + tid * 8;
+  me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
+  me[7] = b.contact_now ? 1.0f : 0.0f;
+  lds_sync_wave();
+  bool world = false, peer = false;
+  const float rr = 2.0f * K.bound_radius0, rr2 = rr * rr;
+  const float h[3] = {K.box_h[0], K.box_h[1], K.box_h[2]};
+  for (int j = 1; j < A; ++j) {
+    int jj = wlocal + j;
+    jj = jj >= A ? jj - A : jj;
+    const float* o = wpose + (wbase + jj) * 8;
+    world |= o[7] != 0.0f;
+    const v3 d{b.p.x - o[0], b.p.y - o[1], b.p.z - o[2]};
+    const bool touch = dot(d, d) <= rr2;  // bounding spheres touch: this drone's box in the peer's box frame, 15 axes
+    if (__any(touch)) {
+      if (touch) {
+        const m3 Rb = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
+        const m3& Ra = b.R;
+        const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
+                      Rb.m01 * Ra.m00 + Rb.m11 * Ra.m10 + Rb.m21 * Ra.m20, Rb.m01 * Ra.m01 + Rb.m11 * Ra.m11 + Rb.m21 * Ra.m21, Rb.m01 * Ra.m02 + Rb.m11 * Ra.m12 + Rb.m21 * Ra.m22,
+                      Rb.m02 * Ra.m00 + Rb.m12 * Ra.m10 + Rb.m22 * Ra.m20, Rb.m02 * Ra.m01 + Rb.m12 * Ra.m11 + Rb.m22 * Ra.m21, Rb.m02 * Ra.m02 + Rb.m12 * Ra.m12 + Rb.m22 * Ra.m22};
+        peer |= box_overlaps_aabb(mulT(Rb, d), Rrel, h, v3{0.f, 0.f, 0.f}, h);
+      }
+    }
+  }
+  b.world_contact = world;
+  b.peer_contact = peer;
+  lds_sync_wave();
+}
 
 // Per-wave phase timeline (profiles/tools/phase_trace.py): a diagnostic build switch, -DPF_PHASE_TRACE. Each wave of the
 // one-step-per-launch instantiation stamps the shader clock (s_memtime) at its phase boundaries and its first lane writes the
@@ -434,7 +470,8 @@ __device__ unsigned long long g_phase_trace[4096 * kPhaseStamps];
 constexpr int kQuadWPB = PF_WPB;
 // MODES: false = flight mode 0 only; true = the flight mode is K.mode, -1 .. 7 (cascaded PIDs; their memories in state groups
 // 7-11 and, at reset, the z PIDs inside the settle recurrence).
-template <int TASK, int NOISE, int LPW, int ROLL, bool CR, bool MODES = false>
+// SHARED (PF_TASK_MA_HOVER only): the K.apw agents of an env share one world (pose / contact exchange before every tick).
+template <int TASK, int NOISE, int LPW, int ROLL, bool CR, bool MODES = false, bool SHARED = false>
 __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
                                                              const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
@@ -445,7 +482,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
   __shared__ __attribute__((aligned(16))) float tile_all[kQuadWPB * LPW * kMaxD];
   __shared__ __attribute__((aligned(16))) float sxi_all[kQuadWPB * 64 * kSettleMax];
   __shared__ int spos_all[kQuadWPB * 64];
-  __shared__ float wpose_all[TASK == PF_TASK_MA_HOVER ? kQuadWPB * 64 * 8 : 1];  // shared worlds: pose + contact bit of every lane
+  __shared__ float wpose_all[SHARED ? kQuadWPB * 64 * 8 : 1];  // shared worlds: pose + contact bit of every lane
   __shared__ uint32_t sctr_all[kQuadWPB * 64];
   const int wid = kQuadWPB > 1 ? (int)(threadIdx.x >> 6) : 0;
   const int tid = kQuadWPB > 1 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
@@ -453,8 +490,8 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
   float* const sxi = sxi_all + wid * (64 * kSettleMax);
   int* const spos = spos_all + wid * 64;
   uint32_t* const sctr = sctr_all + wid * 64;
-  float* const wpose = wpose_all + (TASK == PF_TASK_MA_HOVER ? wid * 64 * 8 : 0);
-  const int apw = TASK == PF_TASK_MA_HOVER ? K.apw : 1;
+  float* const wpose = wpose_all + (SHARED ? wid * 64 * 8 : 0);
+  const int apw = SHARED ? K.apw : 1;
   const int wave_base = (blockIdx.x * kQuadWPB + wid) * LPW;
   if (kQuadWPB > 1 && wave_base >= n) return;  // (no barrier anywhere: a surplus wave simply leaves)
   const int lane = wave_base + tid;
@@ -818,12 +855,12 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
       // one Aviary.step (aviary.py:480-531): control on the first tick, pwm held on the second
       V.contact_step = false;
       V.template control<MODES>(K, Pk, C, sp0, sp1, sp2, sp3);
-      if (TASK == PF_TASK_MA_HOVER && apw > 1) {
+      if (SHARED) {
         // one world for the agents of an env: pose / contact exchange before every tick. Every lane of a world is in here
         // together: the PettingZoo task has no early exit from the inner loop and resets whole worlds.
-        world_exchange(V, wpose, tid, apw, K.bound_radius0, Pfull);
+        quad_world_exchange(V, wpose, tid, apw, K);
         V.template tick<CR, true>(K, xi0, Pfull);
-        world_exchange(V, wpose, tid, apw, K.bound_radius0, Pfull);
+        quad_world_exchange(V, wpose, tid, apw, K);
         V.template tick<CR, true>(K, xi1, Pfull);
         V.peer_contact = false;
       } else {

@@ -79,7 +79,7 @@ struct ContactOut {
 // Per-contact record, five float4: (arm.xyz, normal target velocity) (gz.xyz, kz) (gx.xyz, kx) (gy.xyz, ky) (ln, lx, ly, -).
 // Only a few lanes of a wave need the solver in the same tick, so the callers cut their LDS (the hot kernels: the observation
 // tile, idle during the physics ticks) into regions sized for the airframe's own worst-case contact count and deal them out by
-// ballot rank (Body::respond, contact_rounds), coming back for another round if more lanes ask.
+// prefix sum over what each lane actually needs (contact_solve_impl), coming back for another round if not everything fits.
 constexpr int kContactWords = 20;
 constexpr int kContactSlotFloats = (PF_MAX_CONTACTS + 1) * kContactWords;  // worst-case region (+ the sentinel record): 980 floats
 typedef __attribute__((address_space(3))) float* lds_fptr;
@@ -104,6 +104,9 @@ struct ContactSet {
   float I0, I1, I2, I3, I4, I5;  // world-frame inverse inertia R I^-1 R^T (symmetric xx xy xz yy yz zz)
   float inv_mass, slop, inv_dt, rest;
   v3 vc, w;             // the running twist: COM velocity, angular velocity
+#ifdef PF_PHASE_TRACE
+  int sweeps_done = 0, rows_full = 0, rows_skipped = 0;
+#endif
   PF_DEV void begin(lds_fptr ws, const m3& R, v3 com, float im, v3 v_, v3 w_, float i0, float i1, float i2, float i3, float i4, float i5,
                     float slop_, float inv_dt_, float rest_) {
     W4 = (lds_f4ptr)ws; n = 0; deepest = 0.0f;
@@ -147,7 +150,12 @@ struct ContactSet {
     //  friction clamped to +-0; skipped when every lane of the wave agrees -- which includes the lanes that are past their
     //  last contact and sit on the sentinel record)
     const bool idle = (r4.x == 0.0f) && (un >= r0.w);
+#ifdef PF_PHASE_TRACE
+    if (__builtin_amdgcn_ballot_w64(!idle) == 0ull) { rows_skipped += 1; return 0u; }
+    rows_full += 1;
+#else
     if (__builtin_amdgcn_ballot_w64(!idle) == 0ull) return 0u;
+#endif
     const float n0 = __builtin_fmaxf(fmaf(r0.w - un, r1.w, r4.x), 0.0f);
     const float d0 = n0 - r4.x;
     vc.z = fmaf(inv_mass, d0, vc.z);
@@ -200,6 +208,9 @@ struct ContactSet {
         off += 80u;
         if (!__any(off < end)) break;
       }
+#ifdef PF_PHASE_TRACE
+      sweeps_done = it + 1;
+#endif
       if (!__any(chg != 0u)) break;  // a sweep that moved nothing: every further sweep would repeat it exactly
     }
   }
@@ -208,14 +219,40 @@ struct ContactSet {
     return ContactOut{vc - cross(w, cw), w, __builtin_fmaxf(deepest - slop, 0.0f)};
   }
 };
-// (inlined into the two out-of-line entry points below)
-PF_DEV ContactOut contact_solve_impl(const pf_params_kptr P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
-                                     float i0, float i1, float i2, float i3, float i4, float i5) {
-  const m3 R = rot_from_quat(q);
-  const float hxy = P->plane_half_xy, hz2 = 2.0f * P->plane_half_z, margin = P->contact_margin;
-  ContactSet S;
-  S.begin(ws, R, com, inv_mass, v, w, i0, i1, i2, i3, i4, i5, P->contact_slop, 1.0f / P->dt, P->contact_restitution);
-  const int nb = P->n_boxes;
+#ifdef PF_PHASE_TRACE
+// diagnostic build only (profiles/tools/solver_trace.py): calls, shader-clock cycles in setup / in the sweeps, contacts and
+// active lanes per call, summed by the first active lane of every call
+__device__ unsigned long long g_solver_trace[8];
+#endif
+// The vertices of one collision box (centre offset cwk in the world frame, half extents bh, link yawed by (cy, sy) about the base
+// z axis) that lie within the contact margin of the slab's top face: f(off, z) in vertex order.
+template <class F>
+PF_DEV void box_contact_vertices(const v3 p, const m3& R, const v3 cwk, const float cy, const float sy, const float bh0, const float bh1, const float bh2,
+                                 const float hxy, const float hz2, const float margin, F&& f) {
+  // half axes in the world frame (the link frame is the base frame yawed about z)
+  const v3 ex{bh0 * fmaf(R.m00, cy, R.m01 * sy), bh0 * fmaf(R.m10, cy, R.m11 * sy), bh0 * fmaf(R.m20, cy, R.m21 * sy)};
+  const v3 ey{bh1 * fmaf(R.m01, cy, -(R.m00 * sy)), bh1 * fmaf(R.m11, cy, -(R.m10 * sy)), bh1 * fmaf(R.m21, cy, -(R.m20 * sy))};
+  const v3 ez{bh2 * R.m02, bh2 * R.m12, bh2 * R.m22};
+  const float zc = p.z + cwk.z;
+  if (zc - (__builtin_fabsf(ex.z) + __builtin_fabsf(ey.z) + __builtin_fabsf(ez.z)) > margin) return;  // the whole box clears the margin
+  const float za0 = zc - ex.z, za1 = zc + ex.z;
+  const float zb[4] = {za0 - ey.z, za1 - ey.z, za0 + ey.z, za1 + ey.z};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // vertex i: x sign bit 0, y sign bit 1, z sign bit 2 (the oracle's order)
+    const float z = (i & 4) ? zb[i & 3] + ez.z : zb[i & 3] - ez.z;
+    if (z <= margin && z >= -hz2) {
+      const float sx = (i & 1) ? 1.0f : -1.0f, syv = (i & 2) ? 1.0f : -1.0f, sz = (i & 4) ? 1.0f : -1.0f;
+      const v3 off{fmaf(sx, ex.x, fmaf(syv, ey.x, fmaf(sz, ez.x, cwk.x))), fmaf(sx, ex.y, fmaf(syv, ey.y, fmaf(sz, ez.y, cwk.y))), z - p.z};
+      if (__builtin_fabsf(p.x + off.x) <= hxy && __builtin_fabsf(p.y + off.y) <= hxy) f(off, z);
+    }
+  }
+}
+// The contact vertices of the airframe at pose (p, R), in collider / vertex order: f(off, z) for every collider vertex within the
+// contact margin of the slab's top face (off: world offset from the base origin, z: its height). Per box the eight heights come
+// from seven partial sums of the half axes' z components; a box whose lowest vertex clears the margin costs four instructions.
+// Used twice per solve with identical arithmetic: to count the contacts (so that the LDS records can be packed) and to fill them.
+template <class F>
+PF_DEV void for_each_contact_vertex(const pf_params_kptr P, const float hxy, const float hz2, const float margin, const int nb, const v3 p, const m3& R, F&& f) {
   for (int k = 0; k < nb; ++k) {
     const float bc0 = P->boxes[k].c[0], bc1 = P->boxes[k].c[1], bc2 = P->boxes[k].c[2];
     const float bh0 = P->boxes[k].h[0], bh1 = P->boxes[k].h[1], bh2 = P->boxes[k].h[2];
@@ -234,65 +271,167 @@ PF_DEV ContactOut contact_solve_impl(const pf_params_kptr P, lds_fptr ws, v3 p, 
         const float l0 = bh0 * c45, l1 = bh0 * s45, l2 = (i >> 3) ? bh2 : -bh2;
         const v3 off = cwk + mul(R, v3{cy * l0 - sy * l1, sy * l0 + cy * l1, l2});
         const v3 x = p + off;
-        if (S.n < PF_MAX_CONTACTS && x.z <= margin && x.z >= -hz2 && __builtin_fabsf(x.x) <= hxy && __builtin_fabsf(x.y) <= hxy) S.add(off, -x.z);
+        if (x.z <= margin && x.z >= -hz2 && __builtin_fabsf(x.x) <= hxy && __builtin_fabsf(x.y) <= hxy) f(off, x.z);
       }
       continue;
     }
-    // box: half axes in the world frame (the link frame is the base frame yawed about z)
-    const v3 ex{bh0 * fmaf(R.m00, cy, R.m01 * sy), bh0 * fmaf(R.m10, cy, R.m11 * sy), bh0 * fmaf(R.m20, cy, R.m21 * sy)};
-    const v3 ey{bh1 * fmaf(R.m01, cy, -(R.m00 * sy)), bh1 * fmaf(R.m11, cy, -(R.m10 * sy)), bh1 * fmaf(R.m21, cy, -(R.m20 * sy))};
-    const v3 ez{bh2 * R.m02, bh2 * R.m12, bh2 * R.m22};
-    const float zc = p.z + cwk.z;
-    if (zc - (__builtin_fabsf(ex.z) + __builtin_fabsf(ey.z) + __builtin_fabsf(ez.z)) > margin) continue;  // the whole box clears the margin
-    const float za0 = zc - ex.z, za1 = zc + ex.z;
-    const float zb[4] = {za0 - ey.z, za1 - ey.z, za0 + ey.z, za1 + ey.z};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // vertex i: x sign bit 0, y sign bit 1, z sign bit 2 (the oracle's order)
-      const float z = (i & 4) ? zb[i & 3] + ez.z : zb[i & 3] - ez.z;
-      if (z <= margin && z >= -hz2) {
-        const float sx = (i & 1) ? 1.0f : -1.0f, syv = (i & 2) ? 1.0f : -1.0f, sz = (i & 4) ? 1.0f : -1.0f;
-        const v3 off{fmaf(sx, ex.x, fmaf(syv, ey.x, fmaf(sz, ez.x, cwk.x))), fmaf(sx, ex.y, fmaf(syv, ey.y, fmaf(sz, ez.y, cwk.y))), z - p.z};
-        if (S.n < PF_MAX_CONTACTS && __builtin_fabsf(p.x + off.x) <= hxy && __builtin_fabsf(p.y + off.y) <= hxy) S.add(off, -z);
-      }
+    box_contact_vertices(p, R, cwk, cy, sy, bh0, bh1, bh2, hxy, hz2, margin, f);
+  }
+}
+// Where the solve reads the world from: the device parameter block through the scalar cache. The contact model's constants
+// are all requested in ONE batch when the source is built (the statements below are the schedule: the build runs with the
+// machine scheduler off) -- read where they are used they were six dependent scalar-load round trips, and in the hover task,
+// where a solve is rare, each of them missed the scalar cache while the whole launch waited for that one wave.
+struct ParamContactSrc {
+  pf_params_kptr P;
+  float slop_, inv_dt_, rest_, mu_, hxy_, hz2_, margin_;
+  int iters_, nb_;
+  PF_DEV explicit ParamContactSrc(pf_params_kptr p) : P(p) {
+    const float dt = p->dt, hz = p->plane_half_z;
+    slop_ = p->contact_slop; rest_ = p->contact_restitution; mu_ = p->contact_friction; iters_ = p->contact_iters;
+    hxy_ = p->plane_half_xy; margin_ = p->contact_margin; nb_ = p->n_boxes;
+    inv_dt_ = 1.0f / dt; hz2_ = 2.0f * hz;
+  }
+  template <class F> PF_DEV void for_each(const v3 p, const m3& R, F&& f) const { for_each_contact_vertex(P, hxy_, hz2_, margin_, nb_, p, R, f); }
+  PF_DEV float slop() const { return slop_; }
+  PF_DEV float inv_dt() const { return inv_dt_; }
+  PF_DEV float rest() const { return rest_; }
+  PF_DEV float mu() const { return mu_; }
+  PF_DEV int iters() const { return iters_; }
+};
+
+PF_DEV int wave_inclusive_scan_asking(const bool need, const int sz) {
+  unsigned long long m = __ballot(need);
+  const int lane = (int)(threadIdx.x & 63u);
+  // a homogeneous population (every asking lane has the same contact count: bodies at rest on the floor): rank x size
+  // (m != 0: the caller loops while some lane asks)
+  const int szf = __builtin_amdgcn_readlane(sz, __ffsll((long long)m) - 1);
+  if (__ballot(need && sz != szf) == 0ull) {
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));  // asking lanes below this one
+    return need ? (rank + 1) * szf : 0;
+  }
+  int run = 0, mine = 0;
+  while (m != 0ull) {
+    const int l = __ffsll((long long)m) - 1;  // (wave-uniform)
+    run += __builtin_amdgcn_readlane(sz, l);
+    mine = lane == l ? run : mine;
+    m &= m - 1ull;
+  }
+  return mine;
+}
+// One call per tick for the whole wave (every lane that is active at the call site enters; `need`: this lane asks for a solve):
+//   1. count this lane's contact vertices -- a lane without any is done (the gate of the call is a conservative bound);
+//   2. pack the records of the lanes that ask into the LDS behind `ws` (cap_floats of it) by a wave prefix sum over their
+//      (contacts + 1 sentinel) x 20 floats -- as many bodies per round as actually fit, not as many as would fit if each had its
+//      airframe's worst case (a landed aeroplane touches with 4 of its 48 collider vertices: six rounds became one);
+//   3. fill the records and run the sweeps; lanes that did not fit come back in another round.
+template <class SRC>
+PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_floats, bool need, v3 p, const m3 R, v3 v, v3 w, float inv_mass, v3 com,
+                                     float i0, float i1, float i2, float i3, float i4, float i5) {
+#ifdef PF_PHASE_TRACE
+  const unsigned long long pf_t0 = __builtin_readcyclecounter();
+  unsigned long long pf_sweep = 0;
+#endif
+  ContactOut out{v, w, 0.0f};
+  int n = 0;
+  if (need) src.for_each(p, R, [&](v3, float) { n += 1; });
+  n = n > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : n;
+  need = need && n > 0;
+  const int sz = need ? (n + 1) * kContactWords : 0;
+  ContactSet S;
+  S.n = 0;
+  while (__any(need)) {
+    const int incl = wave_inclusive_scan_asking(need, sz);
+    // (the first lane that asks always fits: the callers' LDS holds at least one worst-case region)
+    if (need && incl <= cap_floats) {
+      S.begin(ws + (incl - sz), R, com, inv_mass, v, w, i0, i1, i2, i3, i4, i5, src.slop(), src.inv_dt(), src.rest());
+      src.for_each(p, R, [&](v3 off, float z) { if (S.n < n) S.add(off, -z); });
+#ifdef PF_PHASE_TRACE
+      const unsigned long long pf_b = __builtin_readcyclecounter();
+#endif
+      S.sweeps(src.iters(), src.mu());
+      out = S.finish(v, w);
+      need = false;
+#ifdef PF_PHASE_TRACE
+      pf_sweep += __builtin_readcyclecounter() - pf_b;
+#endif
     }
   }
-  S.sweeps(P->contact_iters, P->contact_friction);
-  return S.finish(v, w);
+#ifdef PF_PHASE_TRACE
+  {
+    const unsigned long long pf_t2 = __builtin_readcyclecounter();
+    const unsigned long long m = __ballot(1);
+    const int first = __ffsll((long long)m) - 1;
+    const int solved = __popcll(__ballot(n > 0));
+    int nmax = n, sd = S.sweeps_done, rf = S.rows_full, rs = S.rows_skipped;
+    unsigned long long sw = pf_sweep;
+    for (int o = 32; o > 0; o >>= 1) {
+      nmax = max(nmax, __shfl_xor(nmax, o)); sd = max(sd, __shfl_xor(sd, o)); rf = max(rf, __shfl_xor(rf, o)); rs = max(rs, __shfl_xor(rs, o));
+      const unsigned long long t = __shfl_xor(sw, o);
+      sw = sw > t ? sw : t;
+    }
+    if ((int)(threadIdx.x & 63u) == first) {
+      atomicAdd(&g_solver_trace[0], 1ull);
+      atomicAdd(&g_solver_trace[1], (pf_t2 - pf_t0) - sw);  // everything but the sweeps: count, scan, records
+      atomicAdd(&g_solver_trace[2], sw);
+      atomicAdd(&g_solver_trace[3], (unsigned long long)nmax);
+      atomicAdd(&g_solver_trace[4], (unsigned long long)solved);
+      atomicAdd(&g_solver_trace[5], (unsigned long long)sd);
+      atomicAdd(&g_solver_trace[6], (unsigned long long)rf);
+      atomicAdd(&g_solver_trace[7], (unsigned long long)rs);
+    }
+  }
+#endif
+  return out;
 }
-// Constant mass properties (QuadX, Fixedwing): read from the parameter block inside the call, so that the call passes 16
-// dwords -- all in registers; with the ten mass-property words as arguments the last three went over the stack and gave
-// every caller a private segment.
 // (PF_SOLVE_INLINE: A/B build switch -- the solver inlined at every call site instead of called)
 #ifdef PF_SOLVE_INLINE
 #define PF_SOLVE_ATTR __device__ __forceinline__
 #else
 #define PF_SOLVE_ATTR __device__ __noinline__
 #endif
-PF_SOLVE_ATTR ContactOut contact_solve_dev(const pf_params* __restrict__ Pg, lds_fptr ws, v3 p, quat q, v3 v, v3 w) {
+// (the capacity is wave-uniform among the lanes that ask: the first of them carries it)
+PF_DEV int __reduce_max_cap(int ask) {
+  const unsigned long long m = __ballot(ask >= 0);
+  return m != 0ull ? __builtin_amdgcn_readlane(ask, __ffsll((long long)m) - 1) : 0;
+}
+// Constant mass properties (QuadX, Fixedwing): read from the parameter block inside the call, so that the call passes few
+// dwords -- all in registers.
+// need_cap: the floats of LDS behind ws for a lane that asks, -1 for a lane that does not.
+// (Register allocation of this function is touchy: with the LDS address folded into the same dword to keep every argument in
+//  registers, the allocator reached into 48 callee-saved VGPRs -- 96 scratch accesses per call; as it is, one argument travels
+//  over the stack and five scratch accesses remain.)
+PF_SOLVE_ATTR ContactOut contact_solve_dev(const pf_params* __restrict__ Pg, lds_fptr ws, int need_cap, v3 p, quat q, v3 v, v3 w) {
+  const bool need = need_cap >= 0;
+  const int cap_floats = __reduce_max_cap(need_cap);
   const pf_params_kptr P = uniform_params(Pg);
-  const v3 com = P->has_com_offset ? v3{P->com[0], P->com[1], P->com[2]} : v3{0.f, 0.f, 0.f};
-  return contact_solve_impl(P, ws, p, q, v, w, P->inv_mass, com, P->I_inv[0], P->I_inv[1], P->I_inv[2], P->I_inv[3], P->I_inv[4], P->I_inv[5]);
+  // (every scalar the solve needs, requested up front in one batch: see ParamContactSrc)
+  const ParamContactSrc src(P);
+  const float im = P->inv_mass, i0 = P->I_inv[0], i1 = P->I_inv[1], i2 = P->I_inv[2], i3 = P->I_inv[3], i4 = P->I_inv[4], i5 = P->I_inv[5];
+  const float c0 = P->com[0], c1 = P->com[1], c2 = P->com[2];
+  const v3 com = P->has_com_offset ? v3{c0, c1, c2} : v3{0.f, 0.f, 0.f};
+  return contact_solve_impl(src, ws, cap_floats, need, p, rot_from_quat(q), v, w, im, com, i0, i1, i2, i3, i4, i5);
+}
+// The same, inlined: what the generic kernels (Body::respond) use. Called out of line from the generic Fixedwing env kernel --
+// 255 VGPRs + AGPR spill space, its 17th argument dword over the stack -- the ragged last wave of a launch lost its observation
+// rows (ROCm 7.2 hipcc; with the call inlined: correct). The hot kernels, which the call suits, are covered lane by lane by the
+// fixture replays on ragged batches.
+PF_DEV ContactOut contact_solve_inl(const pf_params* __restrict__ Pg, lds_fptr ws, int need_cap, v3 p, quat q, v3 v, v3 w) {
+  const bool need = need_cap >= 0;
+  const int cap_floats = __reduce_max_cap(need_cap);
+  const pf_params_kptr P = uniform_params(Pg);
+  const ParamContactSrc src(P);
+  const float im = P->inv_mass, i0 = P->I_inv[0], i1 = P->I_inv[1], i2 = P->I_inv[2], i3 = P->I_inv[3], i4 = P->I_inv[4], i5 = P->I_inv[5];
+  const float c0 = P->com[0], c1 = P->com[1], c2 = P->com[2];
+  const v3 com = P->has_com_offset ? v3{c0, c1, c2} : v3{0.f, 0.f, 0.f};
+  return contact_solve_impl(src, ws, cap_floats, need, p, rot_from_quat(q), v, w, im, com, i0, i1, i2, i3, i4, i5);
 }
 // Mass properties that change per tick (Rocket): passed by value.
-PF_SOLVE_ATTR ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, lds_fptr ws, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
-                                                         float i0, float i1, float i2, float i3, float i4, float i5) {
-  return contact_solve_impl(uniform_params(P), ws, p, q, v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
-}
-// Deal the LDS regions out to the lanes of the (currently active part of the) wave that need the solver,
-// by ballot rank, in as many rounds as it takes. `solve(slot_base)` runs the solver for this lane.
-// slots x stride floats behind `ws`: the callers size the regions for the airframe's own contact count (pf_params.contact_max_points:
-// a quadrotor's single box needs 8 x 11 floats, so 29 lanes fit where the worst case fits 4).
-template <class F>
-PF_DEV void contact_rounds(bool need, lds_fptr ws, F&& solve, const int slots, const int stride) {
-  unsigned long long m = __ballot(need);
-  while (m != 0ull) {
-    const int rank = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-    if (need && rank < slots) {
-      solve(ws + rank * stride);
-      need = false;
-    }
-    m = __ballot(need);
-  }
+PF_DEV ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, lds_fptr ws, int need_cap, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
+                                               float i0, float i1, float i2, float i3, float i4, float i5) {
+  const bool need = need_cap >= 0;
+  const int cap_floats = __reduce_max_cap(need_cap);
+  return contact_solve_impl(ParamContactSrc(uniform_params(P)), ws, cap_floats, need, p, rot_from_quat(q), v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
 }
 
 // Rigid body shared by both vehicles: the Bullet base state + what update_state derives from it.
@@ -305,14 +444,8 @@ struct Body {
   v3 rpy;       // quadx.py:526 (refreshed once per Aviary step)
   bool contact_now, contact_step;
   // shared world (PF_TASK_MA_HOVER with agents_per_world > 1); both false for a drone that is alone in its world
-  int cslots = 1, cstride = kContactSlotFloats;  // LDS regions behind `cws`: how many, how far apart (contact_regions)
-  // `floats` of LDS behind cws, cut into regions of this airframe's own worst-case contact count
-  PF_DEV void contact_regions(const pf_params& P, int floats) {
-    const int pts = (P.contact_max_points > 0 && P.contact_max_points <= PF_MAX_CONTACTS) ? P.contact_max_points : PF_MAX_CONTACTS;
-    cstride = (pts + 1) * kContactWords;  // (+ the sentinel record)
-    cslots = floats / cstride;
-    cslots = cslots > 64 ? 64 : cslots;
-  }
+  int ccap = kContactSlotFloats;  // floats of LDS behind `cws` for the solver's contact records (at least one worst-case region)
+  PF_DEV void contact_regions(const pf_params&, int floats) { ccap = floats; }
   bool world_contact = false;  // a contact point anywhere in the world after the previous tick (quadx.py:509)
   bool peer_contact = false;   // this tick's drone-drone verdict for this body
 
@@ -395,21 +528,23 @@ struct Body {
   PF_DEV float respond(const pf_params* Pd) {
     if (Pd == nullptr) return 0.0f;  // (wave-uniform: kernels without ticks)
     float lift = 0.0f;
-    contact_rounds(Pd->contact_response && contact_may_act(Pd), cws, [&](lds_fptr slot) {
-      const ContactOut o = contact_solve_dev(Pd, slot, p, q, v, w);
-      v = o.v; w = o.w;
+    const bool need = Pd->contact_response && contact_may_act(Pd);
+    if (__any(need)) {
+      const ContactOut o = contact_solve_inl(Pd, cws, need ? ccap : -1, p, q, v, w);
+      v = o.v; w = o.w;  // (unchanged for a lane that did not ask or has no contact vertex)
       lift = Pd->contact_erp * o.deepest;  // (deepest: already net of the slop)
-    }, cslots, cstride);
+    }
     return lift;
   }
   PF_DEV float respond_var(const pf_params* Pd, float inv_mass, v3 com, const float Iinv[6]) {
     if (Pd == nullptr) return 0.0f;
     float lift = 0.0f;
-    contact_rounds(Pd->contact_response && contact_may_act(Pd), cws, [&](lds_fptr slot) {
-      const ContactOut o = contact_solve_var_dev(Pd, slot, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
+    const bool need = Pd->contact_response && contact_may_act(Pd);
+    if (__any(need)) {
+      const ContactOut o = contact_solve_var_dev(Pd, cws, need ? ccap : -1, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
       v = o.v; w = o.w;
       lift = Pd->contact_erp * o.deepest;
-    }, cslots, cstride);
+    }
     return lift;
   }
   // The same tick for a body whose mass properties change over time (Rocket): inverse mass, centre of

@@ -74,6 +74,12 @@ ENVS = [
 ]
 
 
+# The position-controlled fixture: the outer loops differentiate fp32 velocities (lin_vel kd / T = 60 per control tick, z_vel
+# kd / T = 6; tests/tools/fp32_sensitivity.py), so the fp32 device sits further from the fp64 reference than 1e-4 from the first
+# manoeuvre on -- on both kernels alike. Bound = 4 x the measured worst (printed by the test), not a blanket allowance.
+ENV_RTOL = {"env_quadx_waypoints_mode7": 2e-2}
+
+
 @pytest.mark.parametrize("kernel", ["specialised", "generic"])
 @pytest.mark.parametrize("name,vehicle,task,over", ENVS)
 def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
@@ -119,7 +125,7 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
             assert e < RTOL_IMPACT, (name, k, e)
         else:
             worst = max(worst, e)
-            assert e < RTOL, (name, k, e)
+            assert e < ENV_RTOL.get(name, RTOL), (name, k, e)
         r = rew.double().cpu().numpy()
         assert np.abs(r - g["reward"][k]).max() <= 1e-3 * max(1.0, abs(g["reward"][k])), (name, k, r[0], g["reward"][k])
         assert (term.cpu().numpy() == bool(g["term"][k])).all() and (trunc.cpu().numpy() == bool(g["trunc"][k])).all(), (name, k)

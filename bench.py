@@ -57,6 +57,9 @@ def parse():
                          "a departure from the reference; diagnostic A/B, never the headline configuration (the default has the solve on)")
     ap.add_argument("--world", action="append", default=[], metavar="KEY=VALUE",
                     help="override an entry of pyflyt_amd.params.WORLD (diagnostic), e.g. --world contact_iters=6")
+    ap.add_argument("--dogfight-actions", default="gentle", choices=["gentle", "uniform"],
+                    help="dogfight env: gentle commands around level flight (everybody stays airborne) or the action box's uniform "
+                         "distribution (aircraft reach the ground within seconds: the contact-solve regime)")
     ap.add_argument("--flight-mode", type=int, default=0, help="QuadX flight mode -1..7 (auxiliary figures; the metric is quoted on mode 0)")
     ap.add_argument("--rollout-steps", type=int, default=100, help="env steps per pf_rollout launch of the second, state-resident figure (0 = skip)")
     return ap.parse_args()
@@ -130,13 +133,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback exists for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PF_BENCH_SINGLE_DEVICE=1 + PF_BENCH_BACKEND=gloo: every rank on cuda:0, host-side collectives -- the N > 1 launcher path
+    # (torchrun env, sharding, barrier, max over ranks, rank-0 line) on a one-GPU box (tests/test_gpu_dist_launch.py); RCCL itself
+    # refuses two ranks on one device
+    dev_index = 0 if os.environ.get("PF_BENCH_SINGLE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
+    backend = os.environ.get("PF_BENCH_BACKEND", "nccl")
     if world > 1 or os.environ.get("PF_BENCH_FORCE_DIST") == "1":  # (the env switch exercises the RCCL path on a 1-GPU box)
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    red_dev = device if backend == "nccl" else torch.device("cpu")  # where the clocks are max-reduced
 
     # per-GPU slice; no collective in the timed loop
     shard = weak_shard(args.batch, rank, world) if args.scaling == "weak" else strong_shard(args.batch, rank, world, unit=4 if args.env == "dogfight" else 1)
@@ -146,7 +158,7 @@ def main():
     ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(g)]
     for i, a in enumerate(ring):
         eng.sample_actions(a, i)
-        if args.env == "dogfight":
+        if args.env == "dogfight" and args.dogfight_actions == "gentle":
             # uniform actions over the whole box fly every aircraft into the ground within seconds, and a world of wrecks at rest
             # on the floor (contact solve every tick for every lane) is not the regime a policy trains in: gentle commands
             # around level flight instead (stick +-0.15, throttle command 0.25..0.55)
@@ -193,7 +205,7 @@ def main():
         if dist is not None:
             dist.barrier()
     ev_ms = ev0.elapsed_time(ev1)
-    t = torch.tensor([wall, ev_ms * 1e-3], dtype=torch.float64, device=device)
+    t = torch.tensor([wall, ev_ms * 1e-3], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0]), float(t[1])
@@ -228,7 +240,7 @@ def main():
             rwall = time.perf_counter() - tr0
             if dist is not None:
                 dist.barrier()
-        rt = torch.tensor([rwall, r0.elapsed_time(r1) * 1e-3], dtype=torch.float64, device=device)
+        rt = torch.tensor([rwall, r0.elapsed_time(r1) * 1e-3], dtype=torch.float64, device=red_dev)
         if dist is not None:
             dist.all_reduce(rt, op=dist.ReduceOp.MAX)
         assert torch.isfinite(eng._traj["obs"]).all(), "non-finite observation in the rollout"
@@ -252,7 +264,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PyFlyt/QuadX-Hover-v4 semantics, flight_mode 0, batch {n}/GPU x {world} GPU(s), "
                                    f"random actions, motor noise {args.noise}, NEXT_STEP auto-reset"
-                       if args.env == "hover" else f"{args.env}, batch {n}/GPU x {world}",
+                       if args.env == "hover" else f"{args.env}, batch {n}/GPU x {world}" + (f", {args.dogfight_actions} actions" if args.env == "dogfight" else ""),
                        "batch_per_gpu": n, "global_batch": total_lanes, "ticks_per_env_step": eng.ticks_per_step,
                        "flight_mode": args.flight_mode, "launch": "hipGraph" if graph is not None else "eager", "contact_response": bool(eng.params.contact_response), "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -270,7 +270,8 @@ int pf_ctx_is_specialised(const pf_ctx* ctx);
 
 /* env.reset(): gym_envs/quadx_envs/quadx_base_env.py:149-212 (begin_reset + end_reset incl. the
  * 10 settle Aviary steps), quadx_hover_env.py:70-83, quadx_waypoints_env.py:112-125,
- * fixedwing_waypoints_env.py:101-114. mask (device, [n] bytes) selects lanes; NULL = all. */
+ * fixedwing_waypoints_env.py:101-114. mask (device, [n] bytes) selects lanes; NULL = all. Shared worlds (agents_per_world > 1):
+ * the agents of a world are reset together -- a mask that selects some of them is widened to the whole world on the device. */
 int pf_env_reset(pf_ctx* ctx, const pf_buffers* b, const uint8_t* mask, void* stream);
 /* env.step(action): quadx_base_env.py:269-301 / fixedwing_base_env.py:244-278 with the task's
  * compute_state + compute_term_trunc_reward, env_step_ratio x Aviary.step() (core/aviary.py:480-531)

@@ -38,8 +38,14 @@ enum {  // group 6, word 3
   DF_ACC_TRUNC = 4,
   DF_INACTIVE = 8,   // dead, on the ground and at rest (:505-510)
   DF_INFO_DEAD = 16, DF_INFO_COLLISION = 32, DF_INFO_OOB = 64, DF_INFO_TEAM_WIN = 128,
-  DF_FROZEN = 256    // df_freeze_wrecks: stopped where it hit the ground
+  DF_FROZEN = 256,   // df_freeze_wrecks: stopped where it hit the ground
+  // a wreck that has really come to rest: DF_INACTIVE, on the ground and |w| small for kDfRestUpdates consecutive updates (the
+  // count lives in bits 9-12). `inactive` by itself -- recomputed by the reference on every update (:505-510) -- can hold for a
+  // single 120 Hz sample at the apex of a bounce or a rock; such an aircraft keeps moving, here as there.
+  DF_REST_SHIFT = 9, DF_REST_MASK = 15 << 9,
+  DF_AT_REST = 8192
 };
+constexpr int kDfRestUpdates = 8;
 
 // ---------------------------------------------------------------- the aircraft
 // Two interchangeable vehicles behind the kernel: the generic Fixedwing of uav_vehicles.hpp (any five-surface airframe the
@@ -191,7 +197,8 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
   nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
 
-  const bool do_reset = op == 1 && ((mask == nullptr) || (mask[li] != 0));
+  // (a mask that names some aircraft of a world resets the world)
+  const bool do_reset = widen_to_world(op == 1 && valid && ((mask == nullptr) || (mask[li] != 0)), tid, A);
   const bool active = valid && (op == 0 || do_reset);
   float sp[6] = {0, 0, 0, 0, 0, 0};
 
@@ -199,11 +206,11 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   auto world_aviary_step = [&](int flat_base) {
     V.b.contact_step = false;
     V.template control<0>(P, sp);
-    // A wreck -- dead, on the ground and at rest: the reference's own `inactive` (:505-510), which drops it from everybody's
-    // observation -- is not integrated any further (the reference keeps stepping it in Bullet; nothing observable depends on
-    // that, and a world of wrecks would otherwise run the contact solve on every lane in every tick). It keeps its resting
-    // contact: the collision verdict of :667-670 stays up.
-    const bool wreck = (df & (DF_INACTIVE | DF_FROZEN)) != 0;
+    // A wreck that has come to rest -- dead, on the ground, in contact, linear and angular velocity small for kDfRestUpdates
+    // consecutive updates (DF_AT_REST) -- is not integrated any further (the reference keeps stepping it in Bullet, where it
+    // stays where it is; a world of wrecks would otherwise run the contact solve on every lane in every tick). It keeps its
+    // resting contact: the collision verdict of :667-670 stays up. A momentary `inactive` does NOT stop the integration.
+    const bool wreck = (df & (DF_AT_REST | DF_FROZEN)) != 0;
     for (int t = 0; t < P.ticks_per_control; ++t) {
       world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev, wreck);
       if (!wreck) V.tick(P, nz.get(flat_base + t));
@@ -272,6 +279,13 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     health = __builtin_fmaxf(fmaf(-P.df_damage_per_hit, (float)rec_hits, health), 0.0f);
     const bool inactive = (health <= 0.0f) && (pc.z < 2.0f) && (dot(vb, vb) < 0.01f);
     df = inactive ? (df | DF_INACTIVE) : (df & ~DF_INACTIVE);
+    {  // consecutive updates at rest (see DF_AT_REST)
+      int rest = (df & DF_REST_MASK) >> DF_REST_SHIFT;
+      const bool still = inactive && V.b.contact_now && dot(wb, wb) < 0.01f;
+      rest = still ? (rest < 15 ? rest + 1 : 15) : 0;
+      df = (df & ~DF_REST_MASK) | (rest << DF_REST_SHIFT);
+      if (rest >= kDfRestUpdates) df |= DF_AT_REST;
+    }
     me[15] = health; me[16] = inactive ? 1.0f : 0.0f;
     lds_sync_wave();
     // ---- observation (:519-549, pop_obs_by_id :724-752): written on the last update of the call only
@@ -387,7 +401,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
       for (int j = 0; j < A; ++j) { cur_d[j] = 0.0f; cur_ang[j] = 0.0f; }
       nz.begin_event(rng_ctr, 1u, B.xi_reset);
     }
-    // (whole worlds reset together -- checked by the host side -- so the lanes that exchange data through LDS always take this
+    // (whole worlds reset together -- widen_to_world above -- so the lanes that exchange data through LDS always take this
     //  branch together; there is one wave per workgroup and no s_barrier, lanes that are not being reset simply idle)
     if (do_reset) {
       for (int s = 0; s < P.settle_steps; ++s) world_aviary_step(s * P.ticks_per_control);  // ma_fixedwing_base_env.py:232-233

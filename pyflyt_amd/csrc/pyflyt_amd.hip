@@ -131,6 +131,8 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   bool active, do_reset;
   if (op == OP_RESET) {
     do_reset = (mask == nullptr) || (mask[li] != 0);
+    // (shared worlds: a mask that names some agents of a world resets the world)
+    if (TASK == PF_TASK_MA_HOVER && P.agents_per_world > 1) do_reset = widen_to_world(do_reset && valid, tid, P.agents_per_world);
     active = do_reset;
   } else {
     do_reset = (P.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc);

@@ -577,6 +577,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
   if (op == 1) active = (mask == nullptr) || (mask[li] != 0);
   else active = true;
   active = active && valid;
+  if (SHARED && op == 1) active = widen_to_world(active, tid, apw) && valid;  // a mask that names some agents of a world resets the world
 
   float act0 = 0.f, act1 = 0.f, act2 = 0.f, act3 = 0.f;
   float reward = 0.0f;

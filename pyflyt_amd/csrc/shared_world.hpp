@@ -13,6 +13,16 @@ PF_DEV void lds_sync_wave() {  // one wave per workgroup: LDS traffic ordered, n
   __builtin_amdgcn_wave_barrier();
 }
 
+// A reset mask that selects some agents of a shared world selects the world: the agents of a world are reset together (their
+// lanes exchange data inside the kernels, and the reference rebuilds the whole world: ma_quadx_base_env.py:206-241). Every lane
+// of the wave must call this (it is a ballot).
+PF_DEV bool widen_to_world(const bool selected, const int tid, const int A) {
+  const unsigned long long m = __ballot(selected);
+  const int wbase = (tid / A) * A;
+  const unsigned long long wm = (A >= 64 ? ~0ull : ((1ull << A) - 1ull)) << wbase;
+  return (m & wm) != 0ull;
+}
+
 // The drone-drone box tests of one body against its touching peers, out of line: they run only when bounding spheres touch, and
 // inlined they put the tick loops of their callers over the register budget (the shared-world instantiation of the QuadX
 // kernel spilled to scratch memory). This drone's boxes in the peer's box frames, 15 axes each (btBoxBoxDetector's verdict).

@@ -149,11 +149,8 @@ class BatchEngine:
                 raise ValueError("mask must be a bool/uint8 tensor")
             mask = mask.to(device=self.device).contiguous()
             self._check(mask, (self.n,), (torch.bool, torch.uint8), "mask")
-            A = int(self.params.agents_per_world)
-            if A > 1:  # the agents of a shared world are reset together (their lanes exchange data inside the kernel)
-                m = mask.view(-1, A).ne(0)
-                if bool((m.any(dim=1) != m.all(dim=1)).any()):
-                    raise ValueError(f"mask must select whole worlds ({A} adjacent lanes each)")
+            # (shared worlds: the agents of a world are reset together; the kernels widen a partial selection to the whole world --
+            #  no host-side check, which would cost a device synchronisation per masked reset)
         self._check_targets(u_targets)
         self._check_f32(xi_reset, (self.settle_ticks, self.n), "xi_reset")
         b = self._buffers(xi_reset=xi_reset, u_targets=u_targets)

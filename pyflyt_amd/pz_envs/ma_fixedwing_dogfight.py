@@ -130,18 +130,41 @@ class MAFixedwingDogfightEnv:
         if seed is not None:
             if int(seed) != self._seed:
                 self._seed = int(seed)
-                keep = self.engine.state[7:9].clone()  # current / past actions are created in __init__ and survive resets
+                # current / past actions are created in __init__ and survive resets: groups 7-8, and 15 (entries 4, 5 of the
+                # six-wide action space, assisted_flight=False)
+                keep, keep45 = self.engine.state[7:9].clone(), self.engine.state[15].clone()
                 self.engine.close()
                 self._build(self._seed)
                 self.engine.state[7:9] = keep
+                self.engine.state[15] = keep45
             # a seeded reset replays the seed's stream from its start (np.random.RandomState(seed) in the reference, :187):
             # the counter RNG's event counters go back to zero; reset(seed=None) continues the stream
             self.engine.state[5, :, 2] = 0.0
         self.step_count = 0
         self.agents = self.possible_agents[:]
         self.engine.env_reset()
+        self._done = torch.zeros(self.num_envs, self.num_possible_agents, dtype=torch.bool, device=self.device)
         obs = self._split(self.engine.obs)
         return {ag: self._obs_out(obs[i]) for i, ag in enumerate(self.possible_agents)}, {ag: dict() for ag in self.agents}
+
+    def reset_envs(self, env_mask):
+        """num_envs > 1: reset the copies selected by `env_mask` ([num_envs] bool) and leave the others running -- every agent
+        of a selected copy starts a new episode (the reference's reset() of that env instance). Returns the observations of
+        all copies (fresh ones for the selected copies)."""
+        env_mask = torch.as_tensor(env_mask, dtype=torch.bool, device=self.device).view(self.num_envs)
+        lane_mask = env_mask.repeat_interleave(self.num_possible_agents)
+        self.engine.env_reset(mask=lane_mask)
+        self._done[env_mask] = False
+        self.agents = self.possible_agents[:]
+        obs = self._split(self.engine.obs)
+        return {ag: self._obs_out(obs[i]) for i, ag in enumerate(self.possible_agents)}
+
+    @property
+    def done(self):
+        """[num_envs, agents] bool: latched per copy -- True from the step an agent's episode ended (termination or truncation)
+        until that copy is reset. With num_envs > 1 the per-step `terminations` / `truncations` report the ending step only;
+        this is what a caller culls by."""
+        return self._done
 
     # ------------------------------------------------------------------ ma_fixedwing_base_env.py:272-334
     def step(self, actions: dict):
@@ -162,6 +185,7 @@ class MAFixedwingDogfightEnv:
             infos[ag] = {"health": health[i], "received_hits": hits[i], "dead": (bits[i] & _DF_DEAD) != 0,
                          "collision": (bits[i] & _DF_COLLISION) != 0, "out_of_bounds": (bits[i] & _DF_OOB) != 0,
                          "team_win": (bits[i] & _DF_TEAM_WIN) != 0}
+        self._done |= (term | trunc).view(E, A)
         self.step_count += 1
         # cull finished agents (:326-328); with num_envs > 1 an agent stays listed until it has finished in every copy (its
         # per-copy flags are in terminations / truncations; a copy's finished agent reports reward 0 from then on)

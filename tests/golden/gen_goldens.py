@@ -33,8 +33,11 @@ from PyFlyt.gym_envs.quadx_envs.quadx_hover_env import QuadXHoverEnv  # noqa: E4
 from PyFlyt.gym_envs.quadx_envs.quadx_waypoints_env import QuadXWaypointsEnv  # noqa: E402
 
 
+OUT_DIR = HERE  # (--out DIR: write somewhere else -- tests/test_golden_regen.py regenerates into a scratch directory and compares)
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
     print(f"wrote {path}: " + ", ".join(f"{k}{np.asarray(v).shape}" for k, v in arrays.items()))
 
@@ -669,6 +672,9 @@ def gen_dogfight():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--out":
+        OUT_DIR = sys.argv[2]
+        del sys.argv[1:3]
     if len(sys.argv) > 1:  # regenerate selected groups only: python gen_goldens.py wind
         for name in sys.argv[1:]:
             globals()["gen_" + name]()

@@ -68,12 +68,17 @@ def test_fullsize_slices_match_oracle(env_id, name, n):
             ro, rr, rt, ru, _ = orc.step(a[o:o + w].cpu().numpy(), autoreset=1)
             e = relerr(obs[o:o + w].cpu().numpy().astype(np.float64), ro, G).max(axis=1)
             er = np.abs(rew[o:o + w].cpu().numpy() - rr) / np.maximum(1.0, np.abs(rr))
-            ok[j] &= (term[o:o + w].cpu().numpy() == rt) & (trunc[o:o + w].cpu().numpy() == ru) & (e < RTOL) & (er < 1e-3)
+            # an observation within reach of the floor carries the contact solve's impulses: RTOL_IMPACT there (z is entry 12
+            # of the attitude block; tests/test_gpu_golden.py, tests/tools/fp32_contact_sensitivity.py), 1e-4 everywhere else
+            tol = np.where(ro[:, 12] < 0.12, 5e-3, RTOL) if "fixedwing" not in name else RTOL
+            ok[j] &= (term[o:o + w].cpu().numpy() == rt) & (trunc[o:o + w].cpu().numpy() == ru) & (e < tol) & (er < 1e-3)
             if ok[j].any():
                 worst = max(worst, e[ok[j]].max())
     bad = 1.0 - np.concatenate(ok).mean()
     print(f"{name} n={n}: worst rel err {worst:.2e}, dropped {bad:.4f}")
-    assert bad <= 0.005, bad
+    # strict for the quadrotor configurations: no lane may leave the comparison; the aeroplane may lose lanes to classified
+    # discrete-event flips within one step (tests/test_gpu_parity.py), at most 0.5 %
+    assert bad <= (0.005 if "fixedwing" in name else 0.0), bad
     assert torch.isfinite(obs).all()
     env.close()
 

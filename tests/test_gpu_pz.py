@@ -206,3 +206,34 @@ def test_shared_world_parity_and_effect():
     # the independent-lane env flies the same commands without that hit: agents 0 and 1 survive the step of the hit
     assert "uav_0" in ind.agents or ind.step_count >= 40
     env.close(); ind.close()
+
+
+@pytest.mark.parametrize("kernel", ["specialised", "generic"])
+def test_partial_reset_mask_is_widened_to_the_world(monkeypatch, kernel):
+    """pf_env_reset with a mask that names ONE agent of a shared world resets that whole world (the agents of a world exchange
+    data inside the kernels) and leaves the other worlds alone -- decided on the device, no host-side check."""
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    if kernel == "generic":
+        monkeypatch.setenv("PF_DISABLE_FAST", "1")
+    A, n = 4, 16
+    P = build_params("quadx", "ma_hover", noise="philox", autoreset="off", seed=5, agents_per_world=A, world_options=dict(contact_response=True))
+    eng = BatchEngine(P, n, device="cuda:0")
+    assert (eng.lib.pf_ctx_is_specialised(eng._ctx) != 0) == (kernel == "specialised")
+    pos = torch.tensor([[-1.0, 0.0, 1.0], [1.0, 0.0, 1.0], [0.0, 1.0, 1.0], [0.0, -1.0, 1.0]], device="cuda:0").repeat(n // A, 1)
+    eng.state[12, :, 0:3] = pos
+    eng.state[12, :, 3] = 0.0; eng.state[13, :, 0] = 0.0; eng.state[13, :, 1] = 0.0; eng.state[13, :, 2] = 1.0
+    eng.env_reset()
+    act = torch.zeros(n, 4, device="cuda:0"); act[:, 3] = 0.4
+    for _ in range(5):
+        eng.env_step(act)
+    before = eng.state.clone()
+    assert (eng.ints()[:, 0] == 5).all()
+    mask = torch.zeros(n, dtype=torch.bool, device="cuda:0")
+    mask[6] = True  # one agent of world 1
+    eng.env_reset(mask=mask)
+    steps = eng.ints()[:, 0].cpu().numpy()
+    assert (steps[4:8] == 0).all() and (steps[:4] == 5).all() and (steps[8:] == 5).all(), steps
+    others = [i for i in range(n) if not 4 <= i < 8]
+    assert torch.equal(eng.state[:12, others], before[:12, others])

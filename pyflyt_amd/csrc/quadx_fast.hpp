@@ -663,14 +663,71 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
       vz = med3(fmaf(az, K.dt, vz), -K.vmax, K.vmax);
       z = fmaf(K.dt, vz, z);
     };
-    for (int t = 0; t < settle_ticks; t += 4) {  // four draws per read, four ticks per trip
+    auto settle_noise = [&](int t) {  // four draws per read
       float4 x;
       if (NOISE == PF_NOISE_PHILOX) x = reinterpret_cast<const float4*>(sxi + tid * kSettleMax)[t >> 2];
       else if (NOISE == PF_NOISE_INJECT) x = float4{B.xi_reset[(size_t)(t + 0) * N + li], B.xi_reset[(size_t)(t + 1) * N + li],
                                                     B.xi_reset[(size_t)(t + 2) * N + li], B.xi_reset[(size_t)(t + 3) * N + li]};
       else x = float4{0.f, 0.f, 0.f, 0.f};
-      settle_control(); settle_tick(x.x); settle_tick(x.y);  // (two ticks per control: quadk_from_params)
-      settle_control(); settle_tick(x.z); settle_tick(x.w);
+      return x;
+    };
+    if (!MODES || K.mode == 0) {
+      // Mode 0: the motor command is the constant 0.05, so the throttle recurrence does not depend on the vertical state and the
+      // 20 ticks are TWO dependency chains -- throttle (3 instructions per tick) and climb rate (3-4 per tick):
+      //   vz' = clamp(vz + dt (F/m + g)) with F/m + g = 4 fmax/m t|t| + g - drag/m vz|vz|
+      //       = clamp(fma(-dt drag/m, vz|vz|, vz + e)),  e = fma(4 dt fmax/m, t|t|, dt g).
+      // A lone wave issues a dependent instruction every ~6.5 clocks and an independent one every 4: the chains are interleaved
+      // statement by statement (the build runs with the machine scheduler off: statement order is the schedule), the throttle
+      // chain running one chunk of four ticks ahead of the climb-rate chain. (The few lanes of a wave that reset are what the
+      // whole wave waits for: the serial 10-instructions-per-tick version was 0.85 us of every env step.)
+      const float A4 = 4.0f * (K.fmaxM * K.dt), G = K.gravity_z * K.dt, Dd = K.dragM[2] * K.dt;
+      float e0, e1, e2, e3;
+      {  // throttle chain, chunk 0
+        const float4 x = settle_noise(0);
+        const float s0 = fmaf(x.x, K.m_noise, 1.0f), s1 = fmaf(x.y, K.m_noise, 1.0f), s2 = fmaf(x.z, K.m_noise, 1.0f), s3 = fmaf(x.w, K.m_noise, 1.0f);
+        thr = fmaf(K.m_a, 0.05f - thr, thr) * s0; e0 = fmaf(A4, thr * __builtin_fabsf(thr), G);
+        thr = fmaf(K.m_a, 0.05f - thr, thr) * s1; e1 = fmaf(A4, thr * __builtin_fabsf(thr), G);
+        thr = fmaf(K.m_a, 0.05f - thr, thr) * s2; e2 = fmaf(A4, thr * __builtin_fabsf(thr), G);
+        thr = fmaf(K.m_a, 0.05f - thr, thr) * s3; e3 = fmaf(A4, thr * __builtin_fabsf(thr), G);
+      }
+      // one tick of each chain, interleaved: T = throttle chain (chunk k + 1), V = climb-rate chain (chunk k)
+#define PF_SETTLE_PAIR(S_, E_IN, E_OUT)                                      \
+      { const float dl_ = 0.05f - thr;               /* T */                  \
+        const float d_ = vz + (E_IN);                /* V */                  \
+        const float tn_ = fmaf(K.m_a, dl_, thr);     /* T */                  \
+        const float q_ = vz * __builtin_fabsf(vz);   /* V */                  \
+        thr = tn_ * (S_);                            /* T */                  \
+        const float vn_ = fmaf(-Dd, q_, d_);         /* V */                  \
+        const float kk_ = thr * __builtin_fabsf(thr);/* T */                  \
+        vz = med3(vn_, -K.vmax, K.vmax);             /* V */                  \
+        (E_OUT) = fmaf(A4, kk_, G);                  /* T */                  \
+        z = fmaf(K.dt, vz, z); }                     /* V */
+      for (int t = 4; t < settle_ticks; t += 4) {
+        const float4 x = settle_noise(t);
+        const float s0 = fmaf(x.x, K.m_noise, 1.0f), s1 = fmaf(x.y, K.m_noise, 1.0f), s2 = fmaf(x.z, K.m_noise, 1.0f), s3 = fmaf(x.w, K.m_noise, 1.0f);
+        float n0, n1, n2, n3;
+        PF_SETTLE_PAIR(s0, e0, n0)
+        PF_SETTLE_PAIR(s1, e1, n1)
+        PF_SETTLE_PAIR(s2, e2, n2)
+        PF_SETTLE_PAIR(s3, e3, n3)
+        e0 = n0; e1 = n1; e2 = n2; e3 = n3;
+      }
+#undef PF_SETTLE_PAIR
+      {  // climb-rate chain, last chunk
+        const float ee[4] = {e0, e1, e2, e3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float d_ = vz + ee[k], q_ = vz * __builtin_fabsf(vz);
+          vz = med3(fmaf(-Dd, q_, d_), -K.vmax, K.vmax);
+          z = fmaf(K.dt, vz, z);
+        }
+      }
+    } else {
+      for (int t = 0; t < settle_ticks; t += 4) {  // four ticks per trip, the mode's z PIDs once per Aviary step
+        const float4 x = settle_noise(t);
+        settle_control(); settle_tick(x.x); settle_tick(x.y);  // (two ticks per control: quadk_from_params)
+        settle_control(); settle_tick(x.z); settle_tick(x.w);
+      }
     }
     V.p = v3{sx, sy, z};
     if (TASK == PF_TASK_MA_HOVER) V.q = quat{tgt[1][0], tgt[1][1], tgt[1][2], tgt[2][0]};

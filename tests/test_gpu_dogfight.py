@@ -237,9 +237,13 @@ def test_dogfight_masked_reset_whole_worlds():
     assert torch.equal(eng.state[:, keep], before[:, keep])                 # the other worlds are untouched
     assert (eng.state[6, mask, 0] == 1.0).all() and (eng.state[5, mask, 0].view(torch.int32) == 0).all()  # health 1, step_count 0
     assert not torch.equal(eng.state[13, mask], before[13, mask])           # a new spawn circle (the event counter moved on)
-    bad = torch.zeros(eng.n, dtype=torch.bool, device="cuda:0"); bad[1] = True
-    with pytest.raises(ValueError):
-        eng.env_reset(mask=bad)
+    # a mask that names ONE aircraft of a world resets that world -- widened on the device (shared_world.hpp: widen_to_world)
+    before = eng.state.clone()
+    one = torch.zeros(eng.n, dtype=torch.bool, device="cuda:0"); one[1] = True
+    eng.env_reset(mask=one)
+    world0 = torch.zeros(eng.n, dtype=torch.bool, device="cuda:0"); world0[:A] = True
+    assert torch.equal(eng.state[:, ~world0], before[:, ~world0])
+    assert (eng.state[6, world0, 0] == 1.0).all() and (eng.state[5, world0, 0].view(torch.int32) == 0).all()
 
 
 def test_dogfight_refusals():

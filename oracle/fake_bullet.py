@@ -121,6 +121,10 @@ class _Body:
                 out.append((centre, R @ l.rot, h * self.scale))
         return out
 
+    def bound_radius(self):
+        """Largest distance of a collider vertex from the base origin (a pruning radius only)."""
+        return max(float(np.linalg.norm(v)) for v in self.contact_vertices())
+
     def contact_vertices(self):
         """Body-frame positions (relative to the base origin) of the contact vertices, in URDF link order, each link's
         boxes (8 corners: x sign fastest) then cylinders (end disc -z then +z, 8 rim points at 45 degree steps from the
@@ -264,6 +268,7 @@ class BulletClient:
         self.contact_response = BulletClient.DEFAULT_CONTACT_RESPONSE
         self.contact_restitution, self.contact_friction, self.contact_erp, self.contact_iters = 0.0, 0.5, 0.2, 10
         self.contact_margin, self.contact_slop = 0.02, 0.001
+        self.pair_response = True  # impulses between free bodies (oracle/uav_oracle.h: orc_world.pair_response)
 
     # ------------------------------------------------------------ no-ops
     def setAdditionalSearchPath(self, path):
@@ -435,6 +440,108 @@ class BulletClient:
         b.v = R @ tw[3:]
         return max(0.0, max(d for _, d in pts) - self.contact_slop)
 
+    def _solve_pair_contacts(self, pre):
+        """Contact response BETWEEN free bodies (the PettingZoo envs put every agent's drone in one world), the SAME
+        named-parameter model as oracle/uav_oracle.c:pair_stage but formulated independently: impulses act on the two base
+        twists (body frames, [angular; linear] at the base ORIGINS) through the 6x6 spatial inertias -- no centres of mass,
+        no 3x3 inertias. Vertex-in-box contacts (margin included), the least-penetrated face of the other box as the normal,
+        btPlaneSpace1 tangents, projected Gauss-Seidel in contact order, friction clamp friction^2 x normal impulse.
+        Returns {body id: translation} -- half of erp x (deepest pair penetration - slop) along that contact's normal."""
+        ids = sorted(pre)
+        pts = []
+        for ia in ids:
+            A = self._bodies[ia]
+            for ib in ids:
+                if ib == ia:
+                    continue
+                B = self._bodies[ib]
+                if float((A.p - B.p) @ (A.p - B.p)) > (A.bound_radius() + B.bound_radius() + 2.0 * self.contact_margin) ** 2:
+                    continue
+                for ca, Ra, ha in A.world_boxes():
+                    for cb, Rb, hb in B.world_boxes():
+                        for i in range(8):
+                            x = ca + Ra @ np.array([ha[0] if i & 1 else -ha[0], ha[1] if i & 2 else -ha[1], ha[2] if i & 4 else -ha[2]])
+                            loc = Rb.T @ (x - cb)
+                            pen = hb - np.abs(loc)
+                            ks = int(np.argmin(pen))  # (the first axis on a tie)
+                            if pen[ks] < -self.contact_margin or len(pts) >= 16:
+                                continue
+                            n = (1.0 if loc[ks] >= 0.0 else -1.0) * Rb[:, ks]
+                            pts.append((ia, ib, x, n, float(pen[ks])))
+        if not pts:
+            return {}
+        tw = {}
+        inv = {}
+        for bid in ids:
+            b = self._bodies[bid]
+            I6, R = pre[bid]
+            tw[bid] = np.concatenate([R.T @ b.w, R.T @ b.v])
+            inv[bid] = np.linalg.inv(I6)
+
+        def plane_space(n):
+            if abs(n[2]) > 0.7071067811865475244:
+                a = n[1] * n[1] + n[2] * n[2]
+                k = 1.0 / math.sqrt(a)
+                p = np.array([0.0, -n[2] * k, n[1] * k])
+                q = np.array([a * k, -n[0] * p[2], n[0] * p[1]])
+            else:
+                a = n[0] * n[0] + n[1] * n[1]
+                k = 1.0 / math.sqrt(a)
+                p = np.array([-n[1] * k, n[0] * k, 0.0])
+                q = np.array([-n[2] * p[1], n[2] * p[0], a * k])
+            return p, q
+
+        rows = []
+        for ia, ib, x, n, depth in pts:
+            A, B = self._bodies[ia], self._bodies[ib]
+            Ra, Rb = pre[ia][1], pre[ib][1]
+            t1, t2 = plane_space(n)
+            ja, jb = [], []
+            for d in (n, t1, t2):
+                da, db = Ra.T @ d, Rb.T @ d
+                ja.append(np.concatenate([np.cross(Ra.T @ (x - A.p), da), da]))
+                jb.append(np.concatenate([np.cross(Rb.T @ (x - B.p), db), db]))
+            rows.append((ia, ib, ja, jb, depth))
+        vn0 = [float(ja[0] @ tw[ia] - jb[0] @ tw[ib]) for ia, ib, ja, jb, _ in rows]
+        lam = np.zeros((len(rows), 3))
+        mu = self.contact_friction * self.contact_friction
+        for _ in range(self.contact_iters):
+            for c, (ia, ib, ja, jb, depth) in enumerate(rows):
+                for d in range(3):
+                    ra, rb = inv[ia] @ ja[d], inv[ib] @ jb[d]
+                    k = float(ja[d] @ ra + jb[d] @ rb)
+                    target = 0.0
+                    if d == 0:
+                        target = ((depth - self.contact_slop) / self._dt if depth < self.contact_slop
+                                  else (-self.contact_restitution * vn0[c] if vn0[c] < 0.0 else 0.0))
+                    new = lam[c, d] + (target - float(ja[d] @ tw[ia] - jb[d] @ tw[ib])) / k
+                    if d == 0:
+                        new = max(new, 0.0)
+                    else:
+                        lim = mu * lam[c, 0]
+                        new = min(max(new, -lim), lim)
+                    dl = new - lam[c, d]
+                    lam[c, d] = new
+                    tw[ia] = tw[ia] + dl * ra
+                    tw[ib] = tw[ib] - dl * rb
+        for bid in ids:
+            b = self._bodies[bid]
+            R = pre[bid][1]
+            b.w = R @ tw[bid][:3]
+            b.v = R @ tw[bid][3:]
+        shift, best = {}, {}
+        for ia, ib, x, n, depth in pts:
+            e = depth - self.contact_slop
+            if e <= 0.0:
+                continue
+            if e > best.get(ia, 0.0):
+                best[ia] = e
+                shift[ia] = 0.5 * self.contact_erp * e * n
+            if e > best.get(ib, 0.0):
+                best[ib] = e
+                shift[ib] = -0.5 * self.contact_erp * e * n
+        return shift
+
     # ------------------------------------------------------------ the tick
     def stepSimulation(self):
         dt = self._dt
@@ -472,7 +579,8 @@ class BulletClient:
                             hit = True
                 if hit:
                     self._contacts.append((0, idf, idr, -1, -1))
-        # 2) dynamics per free body
+        # 2) dynamics: new velocities of every free body ...
+        pre = {}
         for bid in ids:
             b = self._bodies[bid]
             if b.fixed:
@@ -509,9 +617,20 @@ class BulletClient:
             vm = b.max_coord_vel
             b.w = np.clip(b.w + wdot * dt, -vm, vm)
             b.v = np.clip(b.v + vdot * dt, -vm, vm)
+            pre[bid] = (I6, R)
+        # ... the contact response between the free bodies (impulses on those velocities) ...
+        shift = self._solve_pair_contacts(pre) if (self.contact_response and self.pair_response) else {}
+        # ... then every body's ground solve and integration
+        for bid in ids:
+            b = self._bodies[bid]
+            if b.fixed:
+                continue
+            I6, R = pre[bid]
             deepest = self._solve_contacts(b, I6, R) if self.contact_response else 0.0
             b.p = b.p + dt * b.v
             b.p[2] += self.contact_erp * deepest
+            if bid in shift:
+                b.p = b.p + shift[bid]
             # exponential-map quaternion update with world-frame omega
             fAngle = math.sqrt(float(b.w @ b.w))
             if fAngle * dt > 0.25 * math.pi:

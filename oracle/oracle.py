@@ -28,7 +28,7 @@ class World(C.Structure):
         ("max_coord_vel", C.c_double), ("plane_half_xy", C.c_double), ("plane_half_z", C.c_double),
         ("ticks_per_control", C.c_int),
         ("contact_response", C.c_int), ("contact_restitution", C.c_double), ("contact_friction", C.c_double),
-        ("contact_erp", C.c_double), ("contact_iters", C.c_int), ("contact_margin", C.c_double), ("contact_slop", C.c_double),
+        ("contact_erp", C.c_double), ("contact_iters", C.c_int), ("contact_margin", C.c_double), ("contact_slop", C.c_double), ("pair_response", C.c_int),
     ]
 
 

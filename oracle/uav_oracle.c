@@ -338,8 +338,9 @@ static double contact_solve(const orc_params* PP, const orc_body* B, const doubl
   return dmax;
 }
 
-static void rigid_tick_body(const orc_params* PP, const orc_body* P, double p[3], double q[4], double v[3], double w[3],
-                            const double F_b[3], const double tau_b[3]) {
+/* first half: forces -> new velocities (semi-implicit Euler) */
+static void rigid_tick_vel(const orc_params* PP, const orc_body* P, const double q[4], double v[3], double w[3],
+                           const double F_b[3], const double tau_b[3]) {
   const orc_world* Wd = &PP->world;
   const double dt = Wd->dt;
   double R[3][3];
@@ -377,11 +378,18 @@ static void rigid_tick_body(const orc_params* PP, const orc_body* P, double p[3]
   const double vmax = Wd->max_coord_vel;
   for (int i = 0; i < 3; ++i) w[i] = clipd(w[i] + wdot[i] * dt, -vmax, vmax);
   for (int i = 0; i < 3; ++i) v[i] = clipd(v[i] + a[i] * dt, -vmax, vmax);
+}
+/* second half: ground contact solve on the new velocities, position / orientation update, penetration recovery.
+ * shift: an additional translation after the position update (the pair stage's penetration recovery), or null */
+static void rigid_tick_pos(const orc_params* PP, const orc_body* P, double p[3], double q[4], double v[3], double w[3], const double* shift) {
+  const orc_world* Wd = &PP->world;
+  const double dt = Wd->dt;
   /* constraint solve: contacts found at the pre-integration pose act on the new velocities */
   const double deepest = Wd->contact_response ? contact_solve(PP, P, p, q, v, w) : 0.0;
   /* x += v dt (semi-implicit Euler: new velocity) */
   for (int i = 0; i < 3; ++i) p[i] += dt * v[i];
   if (deepest > Wd->contact_slop) p[2] += Wd->contact_erp * (deepest - Wd->contact_slop); /* penetration recovery, position level */
+  if (shift) for (int i = 0; i < 3; ++i) p[i] += shift[i];
   /* q <- exp(w dt / 2) * q with world-frame w, then normalise */
   double fAngle = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   if (fAngle * dt > 0.25 * PI) fAngle = 0.25 * PI / dt; /* ANGULAR_MOTION_THRESHOLD */
@@ -399,6 +407,11 @@ static void rigid_tick_body(const orc_params* PP, const orc_body* P, double p[3]
   nq[3] = cw * q[3] - ax[0] * q[0] - ax[1] * q[1] - ax[2] * q[2];
   double inv = 1.0 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
   for (int i = 0; i < 4; ++i) q[i] = nq[i] * inv;
+}
+static void rigid_tick_body(const orc_params* PP, const orc_body* P, double p[3], double q[4], double v[3], double w[3],
+                            const double F_b[3], const double tau_b[3]) {
+  rigid_tick_vel(PP, P, q, v, w, F_b, tau_b);
+  rigid_tick_pos(PP, P, p, q, v, w, 0);
 }
 
 /* ------------------------------------------------------------------ PID  (abstractions/pid.py:70-94) */
@@ -598,7 +611,7 @@ static void world_defaults(orc_world* W) {
   W->gravity_z = -9.81;      /* aviary.py:226 */
   W->use_gyro_term = 1;      /* [BULLET-FROM-MEMORY] */
   W->max_coord_vel = 100.0;  /* [BULLET-FROM-MEMORY] */
-  W->contact_response = 1; W->contact_restitution = 0.0; W->contact_friction = 0.5; W->contact_erp = 0.2; W->contact_iters = 10; W->contact_margin = 0.02; W->contact_slop = 0.001; /* [BULLET-FROM-MEMORY] defaults */
+  W->contact_response = 1; W->contact_restitution = 0.0; W->contact_friction = 0.5; W->contact_erp = 0.2; W->contact_iters = 10; W->contact_margin = 0.02; W->contact_slop = 0.001; W->pair_response = 1; /* [BULLET-FROM-MEMORY] defaults */
   W->plane_half_xy = 15.0;   /* [BULLET-FROM-MEMORY] pybullet_data plane.urdf */
   W->plane_half_z = 5.0;
   W->ticks_per_control = 2;  /* 240/120, quadx.py:27-28 */
@@ -1104,8 +1117,10 @@ void orc_aviary_step(const orc_params* P, orc_lane* L, const double* xi, uint32_
   L->contact_step = 0; /* :507 */
   for (int t = 0; t < P->world.ticks_per_control; ++t) aviary_tick_one(P, L, xi, t, flat_base, stream);
 }
-/* one physics tick of Aviary.step for one drone (aviary.py:510-525): control, forces, stepSimulation, update_state */
-static void aviary_tick_one(const orc_params* P, orc_lane* L, const double* xi, int t, uint32_t flat_base, uint32_t stream) {
+/* one physics tick of Aviary.step for one drone (aviary.py:510-525): control, forces, stepSimulation, update_state -- in two
+ * halves, so that a shared world can run its drone-drone stage between the velocity update and the ground solve of all its
+ * bodies (orc_world_aviary_step) */
+static void aviary_tick_pre(const orc_params* P, orc_lane* L, const double* xi, int t, uint32_t flat_base, uint32_t stream, orc_body* body) {
   {
     /* update_control */
     if (L->physics_steps % P->world.ticks_per_control == 0) {
@@ -1157,14 +1172,30 @@ static void aviary_tick_one(const orc_params* P, orc_lane* L, const double* xi, 
       cross3(P->motor_r[0], thrust[0], rxf);
       for (int k = 0; k < 3; ++k) { F_b[k] += thrust[0][k]; T_b[k] += rxf[k] + torque[0][k]; }
     }
-    /* stepSimulation: collision detection at the pre-integration pose, then the free-body tick */
+    /* stepSimulation: collision detection at the pre-integration pose, then the free-body tick's velocity half */
     L->contact_now = orc_contact_plane(P, L->p, L->q) || L->peer_contact;
-    if (P->vehicle == ORC_ROCKET) rigid_tick_body(P, &rocket_body, L->p, L->q, L->v, L->w, F_b, T_b);
-    else orc_rigid_tick(P, L->p, L->q, L->v, L->w, F_b, T_b);
-    orc_update_state(P, L);
-    if (L->contact_now) L->contact_step = 1; /* :523-525 */
-    L->physics_steps += 1;
+    if (P->vehicle == ORC_ROCKET) {
+      *body = rocket_body;
+    } else {
+      body->mass = P->mass;
+      memcpy(body->com, P->com, sizeof(body->com));
+      memcpy(body->I_own, P->I_own, sizeof(body->I_own));
+      memcpy(body->I_pa, P->I_pa, sizeof(body->I_pa));
+      memcpy(body->I_inv, P->I_inv, sizeof(body->I_inv));
+    }
+    rigid_tick_vel(P, body, L->q, L->v, L->w, F_b, T_b);
   }
+}
+static void aviary_tick_post(const orc_params* P, orc_lane* L, const orc_body* body, const double* shift) {
+  rigid_tick_pos(P, body, L->p, L->q, L->v, L->w, shift);
+  orc_update_state(P, L);
+  if (L->contact_now) L->contact_step = 1; /* :523-525 */
+  L->physics_steps += 1;
+}
+static void aviary_tick_one(const orc_params* P, orc_lane* L, const double* xi, int t, uint32_t flat_base, uint32_t stream) {
+  orc_body body;
+  aviary_tick_pre(P, L, xi, t, flat_base, stream, &body);
+  aviary_tick_post(P, L, &body, 0);
 }
 
 /* ---- shared world ---- */
@@ -1191,6 +1222,149 @@ static int drones_overlap(const orc_params* Pa, const orc_lane* La, const orc_pa
   }
   return 0;
 }
+/* ---- drone-drone contact response (the model: orc_world.pair_response in the header) ---- */
+typedef struct {
+  int a, b;
+  double ra[3], rb[3], dir[3][3], depth, lam[3], un0;
+} orc_pair_contact;
+static void plane_space(const double n[3], double p[3], double q[3]) { /* btPlaneSpace1 */
+  if (fabs(n[2]) > 0.7071067811865475244) {
+    double a = n[1] * n[1] + n[2] * n[2], k = 1.0 / sqrt(a);
+    p[0] = 0.0; p[1] = -n[2] * k; p[2] = n[1] * k;
+    q[0] = a * k; q[1] = -n[0] * p[2]; q[2] = n[0] * p[1];
+  } else {
+    double a = n[0] * n[0] + n[1] * n[1], k = 1.0 / sqrt(a);
+    p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0.0;
+    q[0] = -n[2] * p[1]; q[1] = n[2] * p[0]; q[2] = a * k;
+  }
+}
+static int pair_contacts(const orc_params* const* Pl, orc_lane* const* Ll, const orc_body* B, int A, orc_pair_contact* pc) {
+  int n = 0;
+  for (int a = 0; a < A; ++a) {
+    for (int b = 0; b < A; ++b) {
+      if (b == a) continue;
+      const orc_params *Pa = Pl[a], *Pb = Pl[b];
+      const orc_lane *La = Ll[a], *Lb = Ll[b];
+      const double margin = Pa->world.contact_margin;
+      double d[3] = {La->p[0] - Lb->p[0], La->p[1] - Lb->p[1], La->p[2] - Lb->p[2]};
+      const double rr = Pa->bound_radius + Pb->bound_radius + 2.0 * margin; /* (pruning only: conservative) */
+      if (dot3(d, d) > rr * rr) continue;
+      double Ra[3][3], Rb[3][3], ca_w[3], cb_w[3];
+      orc_matrix_from_quat(La->q, Ra);
+      orc_matrix_from_quat(Lb->q, Rb);
+      matvec(Ra, B[a].com, ca_w);
+      matvec(Rb, B[b].com, cb_w);
+      for (int ka = 0; ka < Pa->n_boxes; ++ka) {
+        for (int kb = 0; kb < Pb->n_boxes; ++kb) {
+          if (Pa->boxes[ka].kind != 0 || Pb->boxes[kb].kind != 0) continue;
+          double ob[3], cbox[3];
+          matvec(Rb, Pb->boxes[kb].c, ob);
+          for (int i = 0; i < 3; ++i) cbox[i] = Lb->p[i] + ob[i];
+          for (int vi = 0; vi < 8; ++vi) {
+            const double* h = Pa->boxes[ka].h;
+            double l[3] = {Pa->boxes[ka].c[0] + ((vi & 1) ? h[0] : -h[0]), Pa->boxes[ka].c[1] + ((vi & 2) ? h[1] : -h[1]),
+                           Pa->boxes[ka].c[2] + ((vi & 4) ? h[2] : -h[2])};
+            double off[3], x[3], rel[3], loc[3];
+            matvec(Ra, l, off);
+            for (int i = 0; i < 3; ++i) { x[i] = La->p[i] + off[i]; rel[i] = x[i] - cbox[i]; }
+            matTvec(Rb, rel, loc);
+            int ks = 0;
+            double pen = Pb->boxes[kb].h[0] - fabs(loc[0]);
+            for (int k = 1; k < 3; ++k) {
+              double pk = Pb->boxes[kb].h[k] - fabs(loc[k]);
+              if (pk < pen) { pen = pk; ks = k; }
+            }
+            if (pen < -margin || n >= ORC_MAX_PAIR_CONTACTS) continue;
+            orc_pair_contact* c = &pc[n++];
+            c->a = a; c->b = b; c->depth = pen;
+            const double sg = loc[ks] < 0.0 ? -1.0 : 1.0;
+            for (int i = 0; i < 3; ++i) {
+              c->dir[0][i] = sg * Rb[i][ks];
+              c->ra[i] = x[i] - (La->p[i] + ca_w[i]);
+              c->rb[i] = x[i] - (Lb->p[i] + cb_w[i]);
+            }
+            plane_space(c->dir[0], c->dir[1], c->dir[2]);
+            c->lam[0] = c->lam[1] = c->lam[2] = 0.0;
+          }
+        }
+      }
+    }
+  }
+  return n;
+}
+/* the pair stage: impulses between the bodies of a world on their post-force velocities; shift[i]: the position-level recovery of body i */
+static void pair_stage(const orc_params* const* Pl, orc_lane* const* Ll, const orc_body* B, int A, double shift[][3]) {
+  const orc_world* W = &Pl[0]->world;
+  orc_pair_contact pc[ORC_MAX_PAIR_CONTACTS];
+  const int n = pair_contacts(Pl, Ll, B, A, pc);
+  if (n == 0) return;
+  double Iw[ORC_MAX_WORLD][3][3], cw[ORC_MAX_WORLD][3], vc[ORC_MAX_WORLD][3], t[3];
+  for (int i = 0; i < A; ++i) {
+    double R[3][3], tmp[3][3];
+    orc_matrix_from_quat(Ll[i]->q, R);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) { tmp[r][c] = 0; for (int k = 0; k < 3; ++k) tmp[r][c] += R[r][k] * B[i].I_inv[k][c]; }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) { Iw[i][r][c] = 0; for (int k = 0; k < 3; ++k) Iw[i][r][c] += tmp[r][k] * R[c][k]; }
+    matvec(R, B[i].com, cw[i]);
+    cross3(Ll[i]->w, cw[i], t);
+    for (int k = 0; k < 3; ++k) vc[i][k] = Ll[i]->v[k] + t[k];
+  }
+  for (int c = 0; c < n; ++c) {
+    double ta[3], tb[3];
+    cross3(Ll[pc[c].a]->w, pc[c].ra, ta);
+    cross3(Ll[pc[c].b]->w, pc[c].rb, tb);
+    pc[c].un0 = 0.0;
+    for (int k = 0; k < 3; ++k) pc[c].un0 += ((vc[pc[c].a][k] + ta[k]) - (vc[pc[c].b][k] + tb[k])) * pc[c].dir[0][k];
+  }
+  const double mu = W->contact_friction * W->contact_friction;
+  for (int it = 0; it < W->contact_iters; ++it) {
+    for (int c = 0; c < n; ++c) {
+      const int a = pc[c].a, b = pc[c].b;
+      const double ima = 1.0 / B[a].mass, imb = 1.0 / B[b].mass;
+      for (int d = 0; d < 3; ++d) {
+        const double* dir = pc[c].dir[d];
+        double rxd[3], anga[3], angb[3], axr[3], bxr[3], ta[3], tb[3];
+        cross3(pc[c].ra, dir, rxd); matvec(Iw[a], rxd, anga); cross3(anga, pc[c].ra, axr);
+        cross3(pc[c].rb, dir, rxd); matvec(Iw[b], rxd, angb); cross3(angb, pc[c].rb, bxr);
+        const double k = ima + imb + dot3(dir, axr) + dot3(dir, bxr);
+        cross3(Ll[a]->w, pc[c].ra, ta);
+        cross3(Ll[b]->w, pc[c].rb, tb);
+        double u = 0.0;
+        for (int i = 0; i < 3; ++i) u += ((vc[a][i] + ta[i]) - (vc[b][i] + tb[i])) * dir[i];
+        double target = 0.0;
+        if (d == 0) target = pc[c].depth < W->contact_slop ? (pc[c].depth - W->contact_slop) / W->dt : (pc[c].un0 < 0.0 ? -W->contact_restitution * pc[c].un0 : 0.0);
+        double nl = pc[c].lam[d] + (target - u) / k;
+        if (d == 0) {
+          if (nl < 0.0) nl = 0.0;
+        } else {
+          const double lim = mu * pc[c].lam[0];
+          if (nl > lim) nl = lim;
+          if (nl < -lim) nl = -lim;
+        }
+        const double dl = nl - pc[c].lam[d];
+        pc[c].lam[d] = nl;
+        for (int i = 0; i < 3; ++i) {
+          vc[a][i] += ima * dl * dir[i]; Ll[a]->w[i] += dl * anga[i];
+          vc[b][i] -= imb * dl * dir[i]; Ll[b]->w[i] -= dl * angb[i];
+        }
+      }
+    }
+  }
+  for (int i = 0; i < A; ++i) {
+    cross3(Ll[i]->w, cw[i], t);
+    for (int k = 0; k < 3; ++k) Ll[i]->v[k] = vc[i][k] - t[k];
+  }
+  /* position-level recovery: each body follows its deepest pair contact */
+  double best[ORC_MAX_WORLD];
+  for (int i = 0; i < A; ++i) best[i] = 0.0;
+  for (int c = 0; c < n; ++c) {
+    const double e = pc[c].depth - W->contact_slop;
+    if (e <= 0.0) continue;
+    if (e > best[pc[c].a]) { best[pc[c].a] = e; for (int k = 0; k < 3; ++k) shift[pc[c].a][k] = 0.5 * W->contact_erp * e * pc[c].dir[0][k]; }
+    if (e > best[pc[c].b]) { best[pc[c].b] = e; for (int k = 0; k < 3; ++k) shift[pc[c].b][k] = -0.5 * W->contact_erp * e * pc[c].dir[0][k]; }
+  }
+}
 void orc_world_aviary_step(const orc_params* const* Pl, orc_lane* const* Ll, int A, const double* const* xi,
                            uint32_t flat_base, uint32_t stream) {
   for (int i = 0; i < A; ++i) Ll[i]->contact_step = 0;
@@ -1202,7 +1376,13 @@ void orc_world_aviary_step(const orc_params* const* Pl, orc_lane* const* Ll, int
     for (int i = 0; i < A; ++i) /* this tick's collision detection between the drones, at the pre-integration poses */
       for (int j = i + 1; j < A; ++j)
         if (drones_overlap(Pl[i], Ll[i], Pl[j], Ll[j])) { Ll[i]->peer_contact = 1; Ll[j]->peer_contact = 1; }
-    for (int i = 0; i < A; ++i) aviary_tick_one(Pl[i], Ll[i], xi ? xi[i] : 0, t, flat_base, stream);
+    /* stepSimulation for the whole world: forces and new velocities of every body, the drone-drone stage, then every body's
+     * ground solve and integration */
+    orc_body B[ORC_MAX_WORLD];
+    double shift[ORC_MAX_WORLD][3];
+    for (int i = 0; i < A; ++i) { shift[i][0] = shift[i][1] = shift[i][2] = 0.0; aviary_tick_pre(Pl[i], Ll[i], xi ? xi[i] : 0, t, flat_base, stream, &B[i]); }
+    if (Pl[0]->world.pair_response && Pl[0]->world.contact_response) pair_stage(Pl, Ll, B, A, shift);
+    for (int i = 0; i < A; ++i) aviary_tick_post(Pl[i], Ll[i], &B[i], shift[i]);
   }
   for (int i = 0; i < A; ++i) Ll[i]->peer_contact = 0;
 }

@@ -63,7 +63,23 @@ typedef struct {
    * what is deeper, so a body at rest overlaps the slab by exactly this much -- which keeps the contact REPORT
    * (penetration >= 0, orc_contact_plane) true and stable while it rests, instead of flickering at a zero gap */
   double contact_slop;
+  /* Contact response BETWEEN the drones of a shared world (the PettingZoo envs put every agent's drone in one Bullet world,
+   * ma_quadx_base_env.py:206-241; a culled drone that falls onto a live one pushes it, :365-369). [BULLET-FROM-MEMORY], the
+   * same named-parameter model as the ground's, one stage earlier in the tick:
+   *   velocities after the forces -> PAIR STAGE -> ground solve per body -> integration.
+   * Pair contacts at the pre-integration poses: for every ordered pair (a, b), a != b, in body order, every box of a against
+   * every box of b (plain boxes), the 8 vertices of a's box in vertex order: a vertex within contact_margin of being inside b's
+   * box is a contact; normal = b's face with the least penetration (first axis on a tie), pointing out of b; depth = that
+   * penetration. At most ORC_MAX_PAIR_CONTACTS per world and tick (the first in order). Rows: the normal and Bullet's
+   * btPlaneSpace1 tangents; relative point velocity u = (v_a + w_a x r_a) - (v_b + w_b x r_b); projected Gauss-Seidel,
+   * contact_iters sweeps in contact order, same targets as the ground rows (slop, speculative margin, restitution), friction
+   * clamp contact_friction^2 x the normal impulse (Bullet multiplies the two bodies' friction coefficients). After the
+   * position update each body is translated by half of contact_erp x (its deepest pair penetration - slop) along that
+   * contact's normal (a: +, b: -). */
+  int pair_response;         /* 1: drone-drone impulses in shared worlds (default); 0: detection only */
 } orc_world;
+#define ORC_MAX_PAIR_CONTACTS 16
+#define ORC_MAX_WORLD 8 /* drones per shared world (the device: agents_per_world <= 8) */
 
 typedef struct {
   double kp[3], ki[3], kd[3], lim[3];

@@ -493,11 +493,10 @@ def gen_ma_hover():
         fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
 
 
-def gen_ma_hover_shared():
-    """The same PettingZoo env with what makes its world SHARED visible: agents spawned 10 cm apart in height so that the
-    pairs collide while they drift (drone-drone hits enter contact_array[drone.Id], ma_quadx_hover_env.py:181), the contact
-    response on so that a dead drone comes to rest on the floor -- and from then on switches off the rotational drag of
-    every drone in the world (quadx.py:509 looks at the contact points of the whole world)."""
+def _run_ma_shared(name, start_pos, base_actions, steps, dome, duration, rng_seed):
+    """MAQuadXHoverEnv on ONE fake-Bullet world (every agent's drone in it, as in the reference), recorded through its PettingZoo
+    dict API; `all_pos` / `all_rpy`: the pose of every drone after every step, culled ones included (they stay in the world
+    with zero commands, ma_quadx_base_env.py:326-332)."""
     from oracle import fake_bullet
     from PyFlyt.pz_envs.quadx_envs.ma_quadx_hover_env import MAQuadXHoverEnv
 
@@ -510,34 +509,31 @@ def gen_ma_hover_shared():
         return r
 
     np.random.default_rng = recording_default_rng
-    fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
+    assert fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE is True
     try:
-        start_pos = np.array([[-0.1, 0.0, 1.0], [0.1, 0.0, 1.01], [0.0, 1.0, 1.0], [0.0, -1.0, 0.5]])
-        env = MAQuadXHoverEnv(start_pos=start_pos, start_orn=np.zeros((4, 3)), flight_dome_size=3.0, max_duration_seconds=2.0)
-        rng = orig(321)
+        env = MAQuadXHoverEnv(start_pos=start_pos, start_orn=np.zeros((len(start_pos), 3)), flight_dome_size=dome, max_duration_seconds=duration)
+        rng = orig(rng_seed)
         rec = dict(action=[], obs=[], reward=[], term=[], trunc=[], xi=[], alive=[], reset_before=[], reset_obs=[], reset_xi=[],
-                   world_contact=[], drone_contact=[])
+                   world_contact=[], drone_contact=[], all_pos=[], all_rpy=[])
 
         def do_reset(seed):
             obs, infos = env.reset(seed=seed)
             r = made[-1]
             rec["reset_obs"].append(np.stack([obs[a] for a in env.possible_agents]))
-            rec["reset_xi"].append(r.drain("normal").reshape(-1, 4))
+            rec["reset_xi"].append(r.drain("normal").reshape(-1, len(start_pos)))
             return r
 
         r = do_reset(1000)
         n_ag = len(env.possible_agents)
-        for k in range(140):
+        for k in range(steps):
             if len(env.agents) == 0:
                 rec["reset_before"].append(k)
                 r = do_reset(1000 + k)
             alive = [a in env.agents for a in env.possible_agents]
-            # agents 0 and 1 steer towards each other (roll-rate commands of opposite sign), the others hover / sink
             acts = {}
             for a in env.agents:
                 i = env.agent_name_mapping[a]
-                base = {0: [0.0, 0.6, 0.0, 0.36], 1: [0.0, -0.6, 0.0, 0.36], 2: [0.0, 0.0, 0.3, 0.37], 3: [0.0, 0.0, 0.0, 0.05]}[i]
-                acts[a] = np.array(base) + np.array([*rng.uniform(-0.05, 0.05, size=3), rng.uniform(-0.01, 0.01)])
+                acts[a] = np.array(base_actions[i]) + np.array([*rng.uniform(-0.05, 0.05, size=3), rng.uniform(-0.01, 0.01)])
             obs, rew, term, trunc, infos = env.step(acts)
             A = np.zeros((n_ag, 4)); O = np.full((n_ag, 24), np.nan); R = np.full(n_ag, np.nan)
             T = np.zeros(n_ag, bool); U = np.zeros(n_ag, bool)
@@ -546,16 +542,40 @@ def gen_ma_hover_shared():
                     A[i] = acts[a]; O[i] = obs[a]; R[i] = rew[a]; T[i] = term[a]; U[i] = trunc[a]
             rec["action"].append(A); rec["obs"].append(O); rec["reward"].append(R); rec["term"].append(T); rec["trunc"].append(U)
             rec["alive"].append(alive)
-            rec["xi"].append(r.drain("normal").reshape(-1, 4))
+            rec["xi"].append(r.drain("normal").reshape(-1, n_ag))
             ca = env.aviary.contact_array
             ids = [d.Id for d in env.aviary.drones]
             rec["world_contact"].append(bool(np.any(ca)))
             rec["drone_contact"].append([bool(np.any(ca[i][ids])) for i in ids])
-        save("env_ma_quadx_hover_shared", start_pos=env.start_pos, start_orn=env.start_orn, dome=3.0, max_steps=env.max_steps,
+            st = [env.aviary.state(i) for i in range(n_ag)]
+            rec["all_pos"].append([s_[3] for s_ in st]); rec["all_rpy"].append([s_[1] for s_ in st])
+        save(name, start_pos=env.start_pos, start_orn=env.start_orn, dome=dome, max_steps=env.max_steps,
              **{k: np.array(v) for k, v in rec.items()})
+        return rec
     finally:
         np.random.default_rng = orig
-        fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True
+
+
+def gen_ma_hover_shared():
+    """The PettingZoo env with what makes its world SHARED visible: agents spawned 10 cm apart in height so that the pairs
+    collide while they drift (drone-drone hits enter contact_array[drone.Id], ma_quadx_hover_env.py:181) and push each other
+    (the contact response between the drones), a dead drone comes to rest on the floor -- and from then on switches off the
+    rotational drag of every drone in the world (quadx.py:509 looks at the contact points of the whole world)."""
+    # agents 0 and 1 steer towards each other (roll-rate commands of opposite sign), the others hover / sink
+    _run_ma_shared("env_ma_quadx_hover_shared", np.array([[-0.1, 0.0, 1.0], [0.1, 0.0, 1.01], [0.0, 1.0, 1.0], [0.0, -1.0, 0.5]]),
+                   {0: [0.0, 0.6, 0.0, 0.36], 1: [0.0, -0.6, 0.0, 0.36], 2: [0.0, 0.0, 0.3, 0.37], 3: [0.0, 0.0, 0.0, 0.05]}, 140, 3.0, 2.0, 321)
+
+
+def gen_ma_hover_stack():
+    """A culled drone lands on a live one (ma_quadx_base_env.py:365-369): agent 1 spawns outside the flight dome, directly
+    above agent 0 -- out of bounds in its first step, culled, zero commands from then on -- and falls onto agent 0, which
+    hovers; the hit ends agent 0's episode too, and the two come down together, one on top of the other, while agents 2 and 3
+    fly on (their rotational drag switches off with the first contact point in the world)."""
+    rec = _run_ma_shared("env_ma_quadx_hover_stack", np.array([[0.0, 0.0, 1.0], [0.02, 0.01, 2.1], [1.5, 0.0, 1.0], [-1.0, -1.0, 0.8]]),
+                         {0: [0.0, 0.0, 0.0, 0.364], 1: [0.0, 0.0, 0.0, 0.364], 2: [0.0, 0.0, 0.2, 0.366], 3: [0.0, 0.0, -0.2, 0.365]}, 100, 2.0, 3.0, 654)
+    t = np.array(rec["term"]); dc = np.array(rec["drone_contact"])
+    print("stack: agent 1 out at step", int(np.argmax(t[:, 1])), "agent 0 hit at step", int(np.argmax(t[:, 0])), "drone-drone steps", int(dc.any(axis=1).sum()),
+          "final z", np.array(rec["all_pos"])[-1][:, 2])
 
 
 def gen_dogfight():
@@ -689,6 +709,7 @@ if __name__ == "__main__":
     gen_landing()
     gen_ma_hover()
     gen_ma_hover_shared()
+    gen_ma_hover_stack()
     gen_dogfight()
     gen_wind()
     gen_primitive()

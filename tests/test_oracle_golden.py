@@ -364,12 +364,15 @@ def test_ma_quadx_hover_trajectory(golden_dir):
     assert seen_term >= 4 and ri == len(g["reset_obs"])
 
 
-def test_ma_quadx_hover_shared_world_trajectory(golden_dir):
+@pytest.mark.parametrize("name", ["env_ma_quadx_hover_shared", "env_ma_quadx_hover_stack"])
+def test_ma_quadx_hover_shared_world_trajectory(golden_dir, name):
     """The PettingZoo env with everything its SHARED world adds: two agents fly into each other -- the hit
     enters contact_array[drone.Id] and ends both episodes (ma_quadx_hover_env.py:181) -- and a dead drone on the floor
-    switches off the rotational drag of every drone in the world (quadx.py:509). Recorded from the reference's env on
-    fake_bullet (drone-drone detection, contact response on), replayed through the oracle's world-level step."""
-    g = load(golden_dir, "env_ma_quadx_hover_shared")
+    switches off the rotational drag of every drone in the world (quadx.py:509); the drones push each other (the pair stage of
+    the contact response: `stack` is a culled drone falling onto a live one, ma_quadx_base_env.py:365-369). Recorded from the
+    reference's env on fake_bullet (6x6 spatial-inertia formulation), replayed through the oracle's world-level step (COM-based
+    3x3 formulation): every alive agent's observation, and the pose of EVERY drone -- culled ones included -- after every step."""
+    g = load(golden_dir, name)
     A = g["start_pos"].shape[0]
     Ps = [O.make_params("ma_hover", noise_mode=O.NOISE_INJECT, start_pos=g["start_pos"][i], start_rpy=g["start_orn"][i], dome=float(g["dome"]),
                         max_steps=int(g["max_steps"]), world_contact_response=1) for i in range(A)]
@@ -395,8 +398,14 @@ def test_ma_quadx_hover_shared_world_trajectory(golden_dir):
                 assert abs(rew[i] - g["reward"][k][i]) < 1e-8
                 assert bool(term[i]) == bool(g["term"][k][i]) and bool(trunc[i]) == bool(g["trunc"][k][i]), (k, i)
         assert bool(any(L.contact_now for L in W.Ls)) == bool(g["world_contact"][k]), k
+        pos = np.array([[L.p[0], L.p[1], L.p[2]] for L in W.Ls])
+        rpy = np.array([[L.rpy[0], L.rpy[1], L.rpy[2]] for L in W.Ls])
+        np.testing.assert_allclose(pos, g["all_pos"][k], atol=1e-8, err_msg=f"step {k}: positions of all drones")
+        np.testing.assert_allclose(rpy, g["all_rpy"][k], atol=1e-7, err_msg=f"step {k}: attitudes of all drones")
         hits += int(g["drone_contact"][k].any())
     assert hits > 0 and ri == len(g["reset_obs"])
+    if name != "env_ma_quadx_hover_shared":
+        return
     # the same actions with every agent alone in its own world: no hit, different outcome
     Ws = [O.OracleWorld([p]) for p in Ps]
     for i, w in enumerate(Ws):

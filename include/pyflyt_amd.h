@@ -122,7 +122,16 @@ typedef struct pf_params {
    * vertex order at the velocity level (normal impulse >= 0 towards contact_restitution x approach speed, or towards
  * -gap / dt for a vertex still above the face; two
    * world-axis friction directions clamped to contact_friction x normal impulse); after the position update a
-   * translation of contact_erp x deepest penetration along +z. 0 = detection only (bodies fall through the floor). */
+   * translation of contact_erp x deepest penetration along +z. 0 = detection only (bodies fall through the floor).
+   * Shared worlds (agents_per_world > 1, the QuadX PettingZoo task): the same model BETWEEN the drones, one stage earlier in
+   * the tick -- velocities after the forces -> pair stage -> ground solve per body -> integration. Pair contacts at the
+   * pre-integration poses: for every ordered pair (a, b), a != b, in agent order, every box of a against every box of b, the
+   * 8 vertices of a's box in vertex order: a vertex within contact_margin of being inside b's box is a contact, its normal the
+   * face of b with the least penetration (first axis on a tie) pointing out of b, its depth that penetration; at most 16 per
+   * world and tick. Rows: the normal and Bullet's btPlaneSpace1 tangents on the relative point velocity; contact_iters sweeps
+   * in contact order, the ground rows' targets, friction clamp contact_friction^2 x normal impulse; after the position update
+   * each body moves half of contact_erp x (its deepest pair penetration - slop) along that normal (a: +, b: -).
+   * (pz_envs/quadx_envs/ma_quadx_base_env.py:365-369: a culled drone that lands on a live one.) */
   int32_t contact_response, contact_iters;
   float contact_restitution, contact_friction, contact_erp;
   /* speculative margin: vertices up to this far ABOVE the face are in the contact set as well, with the constraint

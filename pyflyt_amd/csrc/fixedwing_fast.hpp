@@ -208,6 +208,7 @@ struct FwHot {
   // shared worlds (dogfight.hpp): this tick's drone-drone verdict, ORed into the contact report; the world-global bit is only
   // exchanged (the rotational-drag gate it feeds exists on the quadrotor, quadx.py:509)
   bool peer_contact = false, world_contact = false;
+  bool world_touch = false;  // (world_exchange's verdict for the contact response between drones: implemented for the QuadX worlds)
 
   PF_DEV void derive() {  // unit quaternion (quat_integrate / the settled template): scale 2
     const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;

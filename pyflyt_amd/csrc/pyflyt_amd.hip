@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   __shared__ __attribute__((aligned(16))) float tile[kWave * kMaxObs];
   __shared__ __attribute__((aligned(16))) float ktab[VEH::TABLE_FLOATS];
   __shared__ float wpose[kWave * 8];  // shared worlds: each lane's pose and contact bit, exchanged once per tick
+  __shared__ float wvel[TASK == PF_TASK_MA_HOVER ? kWave * kPairVelStride : 1];  // ... and the new velocities for the pair stage
   const int tid = threadIdx.x;
   VEH::fill_table(ktab, Pdev, tid);
   __syncthreads();
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   V.b.cws = (lds_fptr)tile;  // (idle during the physics ticks)
   V.b.contact_regions(P, kWave * kMaxObs);
   V.bind(ktab);
+  if (TASK == PF_TASK_MA_HOVER && P.agents_per_world > 1) { V.b.wpose_ = wpose; V.b.wvel_ = wvel; V.b.wtid = tid; V.b.wA = P.agents_per_world; }
   SideBlock tg;
   float new_dist;
   int4 ints;
@@ -348,8 +350,9 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     V.b.contact_step = false;
     V.template control<MODE_T>(P, sp);
     for (int t = 0; t < P.ticks_per_control; ++t) {
-      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev);  // (dogfight.hpp)
-      V.tick(P, nz.get(flat_base + t));
+      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev);  // (shared_world.hpp)
+      if constexpr (TASK == PF_TASK_MA_HOVER) V.template tick<true>(P, nz.get(flat_base + t));  // (with the contact response between the drones)
+      else V.tick(P, nz.get(flat_base + t));
     }
     V.b.peer_contact = false;
     V.b.rpy = euler_from_quat_fast(V.b.q);

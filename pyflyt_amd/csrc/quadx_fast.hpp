@@ -205,6 +205,11 @@ struct QuadHot {
   // shared world (dogfight.hpp: world_exchange): a contact point anywhere in the world after the previous tick (quadx.py:509),
   // this tick's drone-drone verdict for this body. Both stay false outside tick<.., SHARED = true>.
   bool world_contact = false, peer_contact = false;
+  bool world_touch = false;  // some pair of this world is within reach of the contact response between drones this tick
+  const float* wpose_ = nullptr;  // SHARED: the wave's pose / velocity exchange arrays, this lane, agents per world
+  float* wvel_ = nullptr;
+  float* rec_ = nullptr;          // the pair stage's contact records (the observation tile, as a generic pointer)
+  int wtid = 0, wA = 1;
   lds_fptr cws;  // the wave's LDS regions for the contact solver (aliased onto the observation tile, idle during the ticks)
   int cws_floats;
 
@@ -374,6 +379,19 @@ struct QuadHot {
     // out of line, with its constants read from the device parameter block inside the rare path
     // (can a constraint act at all this tick? conservative bound on the lowest vertex's height after the tick; when it stays
     //  above the allowed overlap every constraint is slack, the solve would return the velocities unchanged: Body::contact_may_act)
+    // contact response between the drones of a shared world (shared_world.hpp: pair_stage_dev), one stage before the ground's:
+    // publish the new velocity, the world's first lane resolves the contacts, take back velocity and position-level shift
+    v3 shift{0.0f, 0.0f, 0.0f};
+    if (SHARED && CR) {
+      float* o = wvel_ + wtid * kPairVelStride;
+      o[0] = wvx.y; o[1] = wvy.y; o[2] = wvz.y; o[3] = wvx.x; o[4] = wvy.x; o[5] = wvz.x; o[6] = 0.0f; o[7] = 0.0f; o[8] = 0.0f;
+      lds_sync_wave();
+      if (__any(world_touch)) {
+        pair_stage_dev(Pfull, wpose_, wvel_, rec_, cws_floats, wtid, wA, world_touch);
+        set_wv(v3{o[3], o[4], o[5]}, v3{o[0], o[1], o[2]});
+        shift = v3{o[6], o[7], o[8]};
+      }
+    }
     float lift = 0.0f;
     if (CR) {
       bool act = false;
@@ -391,7 +409,8 @@ struct QuadHot {
         lift = K.c_erp * o.deepest;  // (already net of the slop)
       }
     }
-    p = v3{fmaf(K.dt, wvx.y, p.x), fmaf(K.dt, wvy.y, p.y), CR ? fmaf(K.dt, wvz.y, p.z) + lift : fmaf(K.dt, wvz.y, p.z)};
+    if (SHARED) p = v3{fmaf(K.dt, wvx.y, p.x) + shift.x, fmaf(K.dt, wvy.y, p.y) + shift.y, fmaf(K.dt, wvz.y, p.z) + lift + shift.z};
+    else p = v3{fmaf(K.dt, wvx.y, p.x), fmaf(K.dt, wvy.y, p.y), CR ? fmaf(K.dt, wvz.y, p.z) + lift : fmaf(K.dt, wvz.y, p.z)};
     q = quat_integrate(q, w(), K.half_dt);
     derive();
     contact_step |= contact_now;
@@ -408,8 +427,9 @@ PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const i
   me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
   me[7] = b.contact_now ? 1.0f : 0.0f;
   lds_sync_wave();
-  bool world = false, peer = false;
+  bool world = false, peer = false, nearp = false;
   const float rr = 2.0f * K.bound_radius0, rr2 = rr * rr;
+  const float rp = rr + 2.0f * K.margin, rp2 = rp * rp;  // within reach of the contact response between drones
   const float h[3] = {K.box_h[0], K.box_h[1], K.box_h[2]};
   for (int j = 1; j < A; ++j) {
     int jj = wlocal + j;
@@ -417,7 +437,9 @@ PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const i
     const float* o = wpose + (wbase + jj) * 8;
     world |= o[7] != 0.0f;
     const v3 d{b.p.x - o[0], b.p.y - o[1], b.p.z - o[2]};
-    const bool touch = dot(d, d) <= rr2;  // bounding spheres touch: this drone's box in the peer's box frame, 15 axes
+    const float d2 = dot(d, d);
+    nearp |= d2 <= rp2;
+    const bool touch = d2 <= rr2;  // bounding spheres touch: this drone's box in the peer's box frame, 15 axes
     if (__any(touch)) {
       if (touch) {
         const m3 Rb = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
@@ -431,6 +453,7 @@ PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const i
   }
   b.world_contact = world;
   b.peer_contact = peer;
+  b.world_touch = widen_to_world(nearp, tid, A);
   lds_sync_wave();
 }
 
@@ -483,6 +506,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
   __shared__ __attribute__((aligned(16))) float sxi_all[kQuadWPB * 64 * kSettleMax];
   __shared__ int spos_all[kQuadWPB * 64];
   __shared__ float wpose_all[SHARED ? kQuadWPB * 64 * 8 : 1];  // shared worlds: pose + contact bit of every lane
+  __shared__ float wvel_all[SHARED ? kQuadWPB * 64 * kPairVelStride : 1];  // ... and the new velocities for the pair stage
   __shared__ uint32_t sctr_all[kQuadWPB * 64];
   const int wid = kQuadWPB > 1 ? (int)(threadIdx.x >> 6) : 0;
   const int tid = kQuadWPB > 1 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
@@ -510,6 +534,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
   static_assert(LPW * kMaxD >= kContactSlotFloats, "the contact solver's LDS regions alias the observation tile: at least one worst-case region");
   V.cws = (lds_fptr)tile;
   V.cws_floats = LPW * kMaxD;
+  if (SHARED) { V.wpose_ = wpose; V.wvel_ = wvel_all + wid * 64 * kPairVelStride; V.rec_ = tile; V.wtid = tid; V.wA = apw; }
   QuadCasc C;  // (MODES only; dead otherwise)
   const pf_params_kptr Pk = uniform_params(Pfull);
   float tgt[4][3];

@@ -4,6 +4,7 @@
 #pragma once
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
+#include "uav_vehicles.hpp"
 
 namespace pf {
 
@@ -53,6 +54,180 @@ __device__ __noinline__ bool peers_overlap_dev(const pf_params* __restrict__ Pd,
   return peer;
 }
 
+// ---------------------------------------------------------------- contact response between the drones of a world
+// The pair stage of stepSimulation's contact response (the model: include/pyflyt_amd.h at pf_params.contact_response; two fp64
+// restatements of it exist on the test side and agree to 1e-8): impulses between the bodies of a world on their post-force
+// velocities, before each body's ground solve.
+//   wpose: 8 floats per lane (pose, published by world_exchange before this tick); wvel: kPairVelStride floats per lane -- in: the
+//   body's new world-frame velocity v, w; out: v, w after the impulses and the position-level shift to add after the position
+//   update. rec: LDS for the contact records (kPairRecFloats per touching world; as many worlds per round as fit).
+// Drones touch rarely (a hit ends both episodes of the PettingZoo task) and then for a few ticks: ONE lane per touching world
+// -- its first -- walks that world's contacts serially, every body's twist staying in LDS where both partners of a contact find
+// it; the other lanes wait. Airframes: plain boxes, centre of mass at the base origin (the QuadX models; checked at context
+// creation). Every lane of the wave that is inside the caller's tick must call this together.
+constexpr int kPairVelStride = 12;   // v (3), w (3), shift (3), pad
+constexpr int kPairMaxContacts = 16; // = ORC_MAX_PAIR_CONTACTS
+constexpr int kPairRec = 44;         // floats per contact record
+constexpr int kPairRecFloats = kPairMaxContacts * kPairRec;
+__device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, const float* wpose, float* wvel, float* rec_all, const int rec_floats, const int tid,
+                                            const int A, const bool world_touch) {
+  const int wbase = (tid / A) * A;
+  bool todo = world_touch && (tid == wbase);  // the world's first lane does the work
+  const int slots = rec_floats / kPairRecFloats;
+  unsigned long long m = __ballot(todo);
+  while (m != 0ull) {
+    const int rank = __popcll(m & ((1ull << (tid & 63)) - 1ull));
+    if (todo && rank < slots) {
+      todo = false;
+      float* rec = rec_all + rank * kPairRecFloats;
+      const float margin = Pd->contact_margin, slop = Pd->contact_slop, inv_dt = 1.0f / Pd->dt, rest = Pd->contact_restitution;
+      const float mu = Pd->contact_friction * Pd->contact_friction, erp = Pd->contact_erp, im = Pd->inv_mass, brad = Pd->bound_radius;
+      const float Ii[6] = {Pd->I_inv[0], Pd->I_inv[1], Pd->I_inv[2], Pd->I_inv[3], Pd->I_inv[4], Pd->I_inv[5]};
+      const int nb = Pd->n_boxes, iters = Pd->contact_iters;
+      int n = 0;
+      // ---- contacts: every box vertex of a within the margin of being inside a box of b
+      for (int a = 0; a < A; ++a) {
+        const float* pa = wpose + (wbase + a) * 8;
+        const m3 Ra = rot_from_quat(quat{pa[3], pa[4], pa[5], pa[6]});
+        for (int b = 0; b < A; ++b) {
+          if (b == a) continue;
+          const float* pb = wpose + (wbase + b) * 8;
+          const v3 d{pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+          const float rr = 2.0f * brad + 2.0f * margin;
+          if (dot(d, d) > rr * rr) continue;
+          const m3 Rb = rot_from_quat(quat{pb[3], pb[4], pb[5], pb[6]});
+          // world-frame inverse inertias R I^-1 R^T of both bodies (symmetric xx xy xz yy yz zz)
+          float Iwa[6], Iwb[6];
+          {
+            const v3 r0{Ra.m00, Ra.m01, Ra.m02}, r1{Ra.m10, Ra.m11, Ra.m12}, r2{Ra.m20, Ra.m21, Ra.m22};
+            const v3 c0 = symmul(Ii, r0), c1 = symmul(Ii, r1), c2 = symmul(Ii, r2);
+            Iwa[0] = dot(r0, c0); Iwa[1] = dot(r0, c1); Iwa[2] = dot(r0, c2); Iwa[3] = dot(r1, c1); Iwa[4] = dot(r1, c2); Iwa[5] = dot(r2, c2);
+          }
+          {
+            const v3 r0{Rb.m00, Rb.m01, Rb.m02}, r1{Rb.m10, Rb.m11, Rb.m12}, r2{Rb.m20, Rb.m21, Rb.m22};
+            const v3 c0 = symmul(Ii, r0), c1 = symmul(Ii, r1), c2 = symmul(Ii, r2);
+            Iwb[0] = dot(r0, c0); Iwb[1] = dot(r0, c1); Iwb[2] = dot(r0, c2); Iwb[3] = dot(r1, c1); Iwb[4] = dot(r1, c2); Iwb[5] = dot(r2, c2);
+          }
+          for (int ka = 0; ka < nb; ++ka) {
+            for (int kb = 0; kb < nb; ++kb) {
+              const pf_box ba = Pd->boxes[ka], bb = Pd->boxes[kb];
+              const v3 cb = v3{pb[0], pb[1], pb[2]} + mul(Rb, v3{bb.c[0], bb.c[1], bb.c[2]});
+              for (int vi = 0; vi < 8; ++vi) {
+                const v3 l{ba.c[0] + ((vi & 1) ? ba.h[0] : -ba.h[0]), ba.c[1] + ((vi & 2) ? ba.h[1] : -ba.h[1]), ba.c[2] + ((vi & 4) ? ba.h[2] : -ba.h[2])};
+                const v3 ra = mul(Ra, l);  // arm from a's centre of mass (= its base origin)
+                const v3 x = v3{pa[0], pa[1], pa[2]} + ra;
+                const v3 loc = mulT(Rb, x - cb);
+                const float pen0 = bb.h[0] - __builtin_fabsf(loc.x), pen1 = bb.h[1] - __builtin_fabsf(loc.y), pen2 = bb.h[2] - __builtin_fabsf(loc.z);
+                int ks = 0;
+                float pen = pen0;
+                if (pen1 < pen) { pen = pen1; ks = 1; }
+                if (pen2 < pen) { pen = pen2; ks = 2; }
+                if (pen < -margin || n >= kPairMaxContacts) continue;
+                const float lk = ks == 0 ? loc.x : (ks == 1 ? loc.y : loc.z);
+                const float sg = lk < 0.0f ? -1.0f : 1.0f;
+                const v3 nrm = ks == 0 ? v3{sg * Rb.m00, sg * Rb.m10, sg * Rb.m20} : (ks == 1 ? v3{sg * Rb.m01, sg * Rb.m11, sg * Rb.m21} : v3{sg * Rb.m02, sg * Rb.m12, sg * Rb.m22});
+                const v3 rb = x - v3{pb[0], pb[1], pb[2]};
+                v3 t1, t2;  // btPlaneSpace1
+                if (__builtin_fabsf(nrm.z) > 0.70710678f) {
+                  const float aa = fmaf(nrm.y, nrm.y, nrm.z * nrm.z), k = 1.0f / __builtin_sqrtf(aa);
+                  t1 = v3{0.0f, -nrm.z * k, nrm.y * k};
+                  t2 = v3{aa * k, -nrm.x * t1.z, nrm.x * t1.y};
+                } else {
+                  const float aa = fmaf(nrm.x, nrm.x, nrm.y * nrm.y), k = 1.0f / __builtin_sqrtf(aa);
+                  t1 = v3{-nrm.y * k, nrm.x * k, 0.0f};
+                  t2 = v3{-nrm.z * t1.y, nrm.z * t1.x, aa * k};
+                }
+                float* r = rec + n * kPairRec;
+                r[0] = __int_as_float(a); r[1] = __int_as_float(b); r[2] = pen;
+                r[4] = ra.x; r[5] = ra.y; r[6] = ra.z; r[7] = rb.x; r[8] = rb.y; r[9] = rb.z;
+                const v3 dirs[3] = {nrm, t1, t2};
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd) {
+                  const v3 dir = dirs[dd];
+                  const v3 ga = symmul(Iwa, cross(ra, dir)), gb = symmul(Iwb, cross(rb, dir));
+                  const float k = 1.0f / (im + im + dot(dir, cross(ga, ra)) + dot(dir, cross(gb, rb)));
+                  float* q = r + 10 + dd * 10;  // dir (3), ga (3), gb (3), k
+                  q[0] = dir.x; q[1] = dir.y; q[2] = dir.z; q[3] = ga.x; q[4] = ga.y; q[5] = ga.z; q[6] = gb.x; q[7] = gb.y; q[8] = gb.z; q[9] = k;
+                }
+                r[40] = 0.0f; r[41] = 0.0f; r[42] = 0.0f;  // accumulated impulses
+                ++n;
+              }
+            }
+          }
+        }
+      }
+      // shifts start at zero
+      for (int i = 0; i < A; ++i) { float* o = wvel + (wbase + i) * kPairVelStride; o[6] = 0.0f; o[7] = 0.0f; o[8] = 0.0f; }
+      if (n > 0) {
+        // the normal velocities the sweeps start from (restitution target)
+        for (int c = 0; c < n; ++c) {
+          float* r = rec + c * kPairRec;
+          const float* va = wvel + (wbase + __float_as_int(r[0])) * kPairVelStride;
+          const float* vb = wvel + (wbase + __float_as_int(r[1])) * kPairVelStride;
+          const v3 ra{r[4], r[5], r[6]}, rb{r[7], r[8], r[9]}, dir{r[10], r[11], r[12]};
+          const v3 ua = v3{va[0], va[1], va[2]} + cross(v3{va[3], va[4], va[5]}, ra), ub = v3{vb[0], vb[1], vb[2]} + cross(v3{vb[3], vb[4], vb[5]}, rb);
+          r[3] = dot(ua - ub, dir);
+        }
+        for (int it = 0; it < iters; ++it) {
+          for (int c = 0; c < n; ++c) {
+            float* r = rec + c * kPairRec;
+            float* va = wvel + (wbase + __float_as_int(r[0])) * kPairVelStride;
+            float* vb = wvel + (wbase + __float_as_int(r[1])) * kPairVelStride;
+            const v3 ra{r[4], r[5], r[6]}, rb{r[7], r[8], r[9]};
+            const float depth = r[2], un0 = r[3];
+            v3 Va{va[0], va[1], va[2]}, Wa{va[3], va[4], va[5]}, Vb{vb[0], vb[1], vb[2]}, Wb{vb[3], vb[4], vb[5]};
+            float l0 = r[40];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+              const float* q = r + 10 + dd * 10;
+              const v3 dir{q[0], q[1], q[2]}, ga{q[3], q[4], q[5]}, gb{q[6], q[7], q[8]};
+              const float u = dot((Va + cross(Wa, ra)) - (Vb + cross(Wb, rb)), dir);
+              const float target = dd == 0 ? (depth < slop ? (depth - slop) * inv_dt : (un0 < 0.0f ? -rest * un0 : 0.0f)) : 0.0f;
+              const float lam = r[40 + dd];
+              float nl = fmaf(target - u, q[9], lam);
+              if (dd == 0) { nl = __builtin_fmaxf(nl, 0.0f); l0 = nl; }
+              else { const float lim = mu * l0; nl = __builtin_fminf(__builtin_fmaxf(nl, -lim), lim); }
+              const float dl = nl - lam;
+              r[40 + dd] = nl;
+              Va = Va + (im * dl) * dir; Wa = Wa + dl * ga;
+              Vb = Vb - (im * dl) * dir; Wb = Wb - dl * gb;
+            }
+            va[0] = Va.x; va[1] = Va.y; va[2] = Va.z; va[3] = Wa.x; va[4] = Wa.y; va[5] = Wa.z;
+            vb[0] = Vb.x; vb[1] = Vb.y; vb[2] = Vb.z; vb[3] = Wb.x; vb[4] = Wb.y; vb[5] = Wb.z;
+          }
+        }
+        // position-level recovery: each body follows its deepest pair contact (the first on a tie)
+        float best[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < n; ++c) {
+          const float* r = rec + c * kPairRec;
+          const float e = r[2] - slop;
+          if (e <= 0.0f) continue;
+          const int a = __float_as_int(r[0]), b = __float_as_int(r[1]);
+          // (best[] indexed by selects: a dynamically indexed private array would be scratch memory)
+          float ba_ = 0.0f, bb_ = 0.0f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { ba_ = i == a ? best[i] : ba_; bb_ = i == b ? best[i] : bb_; }
+          const float h = 0.5f * erp * e;
+          if (e > ba_) {
+            float* o = wvel + (wbase + a) * kPairVelStride;
+            o[6] = h * r[10]; o[7] = h * r[11]; o[8] = h * r[12];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) best[i] = i == a ? e : best[i];
+          }
+          if (e > bb_) {
+            float* o = wvel + (wbase + b) * kPairVelStride;
+            o[6] = -h * r[10]; o[7] = -h * r[11]; o[8] = -h * r[12];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) best[i] = i == b ? e : best[i];
+          }
+        }
+      }
+    }
+    m = __ballot(todo);
+  }
+  lds_sync_wave();
+}
+
 // Shared world, before a physics tick: the A lanes of a world exchange pose and contact bit, test their collision boxes
 // against each other (behind a bounding-sphere test) and OR the world's contact bits into the gate of the rotational drag
 // (quadx.py:509). wpose: 8 floats per lane of the wave. Pd: the device copy of the parameter block (the collision boxes are
@@ -68,17 +243,21 @@ PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, co
   me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
   me[7] = b.contact_now ? 1.0f : 0.0f;
   lds_sync_wave();
-  bool world = false, touch = false;
+  bool world = false, touch = false, near = false;
   const float rr = 2.0f * bound_radius, rr2 = rr * rr;
+  const float rp = rr + 2.0f * Pd->contact_margin, rp2 = rp * rp;  // within reach of the contact response between drones
   for (int j = 1; j < A; ++j) {
     int jj = wlocal + j;
     jj = jj >= A ? jj - A : jj;
     const float* o = wpose + (wbase + jj) * 8;
     world |= o[7] != 0.0f;
     const v3 d{b.p.x - o[0], b.p.y - o[1], b.p.z - o[2]};
-    touch |= dot(d, d) <= rr2;  // bounding spheres touch
+    const float d2 = dot(d, d);
+    touch |= d2 <= rr2;  // bounding spheres touch
+    near |= d2 <= rp2;
   }
   touch = touch && !at_rest;
+  b.world_touch = widen_to_world(near, tid, A);
   bool peer = false;
   if (__any(touch)) {
     if (touch) peer = peers_overlap_dev(Pd, wpose, wbase, wlocal, A, b.p.x, b.p.y, b.p.z, b.q, rr2);
@@ -86,6 +265,22 @@ PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, co
   b.world_contact = world;
   b.peer_contact = peer;
   lds_sync_wave();
+}
+
+// Body::pair_stage (declared in uav_vehicles.hpp): the generic vehicles' side of the pair stage.
+PF_DEV v3 Body::pair_stage(const pf_params* Pd) {
+  if (wvel_ == nullptr || Pd == nullptr) return v3{0.0f, 0.0f, 0.0f};  // (wave-uniform)
+  float* o = wvel_ + wtid * kPairVelStride;
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = w.x; o[4] = w.y; o[5] = w.z; o[6] = 0.0f; o[7] = 0.0f; o[8] = 0.0f;
+  lds_sync_wave();
+  v3 shift{0.0f, 0.0f, 0.0f};
+  const bool ask = world_touch && Pd->contact_response != 0;
+  if (__any(ask)) {
+    pair_stage_dev(Pd, wpose_, wvel_, (float*)cws, ccap, wtid, wA, ask);
+    v = v3{o[0], o[1], o[2]}; w = v3{o[3], o[4], o[5]};
+    shift = v3{o[6], o[7], o[8]};
+  }
+  return shift;
 }
 
 }  // namespace pf

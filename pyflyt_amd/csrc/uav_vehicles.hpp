@@ -448,6 +448,11 @@ struct Body {
   PF_DEV void contact_regions(const pf_params&, int floats) { ccap = floats; }
   bool world_contact = false;  // a contact point anywhere in the world after the previous tick (quadx.py:509)
   bool peer_contact = false;   // this tick's drone-drone verdict for this body
+  bool world_touch = false;    // some pair of this world is close enough for contact impulses between drones this tick
+  // shared world, the pair stage (shared_world.hpp: pair_stage_dev): the wave's pose / velocity exchange arrays, this lane, agents per world
+  const float* wpose_ = nullptr;
+  float* wvel_ = nullptr;
+  int wtid = 0, wA = 1;
 
   PF_DEV void derive() {
     R = rot_from_quat(q);
@@ -487,6 +492,7 @@ struct Body {
   }
   // stepSimulation (aviary.py:516): collision detection at the pre-integration pose, then the
   // semi-implicit Euler free-body tick. F, tau: body frame; tau about the base origin.
+  template <bool SHARED = false>
   PF_DEV void tick(const pf_params& P, v3 F, v3 tau) {
     contact_now = detect_contact(P) || peer_contact;
     v3 com{P.com[0], P.com[1], P.com[2]};
@@ -504,8 +510,10 @@ struct Body {
     const float dt = P.dt, vm = P.max_coord_vel;
     w = v3{clampf(fmaf(wdot.x, dt, w.x), -vm, vm), clampf(fmaf(wdot.y, dt, w.y), -vm, vm), clampf(fmaf(wdot.z, dt, w.z), -vm, vm)};
     v = v3{clampf(fmaf(a.x, dt, v.x), -vm, vm), clampf(fmaf(a.y, dt, v.y), -vm, vm), clampf(fmaf(a.z, dt, v.z), -vm, vm)};
+    v3 shift{0.0f, 0.0f, 0.0f};
+    if (SHARED) shift = pair_stage(pdev);  // contact response between the drones of the world, before the ground's
     const float lift = respond(pdev);
-    p = v3{fmaf(dt, v.x, p.x), fmaf(dt, v.y, p.y), fmaf(dt, v.z, p.z) + lift};
+    p = v3{fmaf(dt, v.x, p.x) + shift.x, fmaf(dt, v.y, p.y) + shift.y, fmaf(dt, v.z, p.z) + lift + shift.z};
     q = quat_integrate(q, w, 0.5f * dt);
     derive();
     contact_step |= contact_now;
@@ -525,6 +533,9 @@ struct Body {
     const float vlow = v.z - __builtin_sqrtf(dot(w, w)) * Pd->bound_radius;
     return (low + Pd->contact_slop + Pd->dt * vlow < 0.0f) || (low < -Pd->contact_slop);
   }
+  // The pair stage (shared worlds): publish this body's new velocity, let the world's first lane resolve the drone-drone
+  // contacts (shared_world.hpp: pair_stage_dev), take back the velocity and the position-level shift. Wave-uniform call.
+  PF_DEV v3 pair_stage(const pf_params* Pd);
   PF_DEV float respond(const pf_params* Pd) {
     if (Pd == nullptr) return 0.0f;  // (wave-uniform: kernels without ticks)
     float lift = 0.0f;
@@ -753,6 +764,7 @@ struct QuadX {
   // (boring_bodies.py:93-96), or null.
   static constexpr int WIND_LINKS = 1;
   PF_DEV v3 link_pos(const pf_params&, int) const { return b.p; }  // centre-of-mass link at the base origin
+  template <bool SHARED = false>
   PF_DEV void tick(const pf_params& P, float xi, const float* wind = nullptr) {
     v3 vd = b.vb;
     if (wind) vd = vd - mulT(b.R, v3{wind[0], wind[1], wind[2]});
@@ -775,7 +787,7 @@ struct QuadX {
       tau.y = fmaf(-P.drag_coef_pqr, sq_signed(b.wb.y), tau.y);
       tau.z = fmaf(-P.drag_coef_pqr, sq_signed(b.wb.z), tau.z);
     }
-    b.tick(P, F, tau);
+    b.template tick<SHARED>(P, F, tau);
   }
   PF_DEV void tick_unarmed(const pf_params& P) { b.tick(P, v3{0.f, 0.f, 0.f}, v3{0.f, 0.f, 0.f}); }  // aviary.py:510-521
   // one Aviary.step (aviary.py:480-531): control on the first tick, pwm held afterwards

@@ -34,7 +34,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 #   writes 202 B = 7 state groups (112) + obs 21 f32 (84) + reward (4) + terminated (1) + truncated (1)
 ALGO_BYTES = {"hover": 330, "quadx_waypoints": 442, "fixedwing_waypoints": 418,
               # dogfight (team_size 2): 15 state groups read + written (480), action (16), obs 65 f32 (260), reward + flags (6)
-              "dogfight": 762}
+              "dogfight": 762,
+              # PettingZoo MA-Hover, one world per 4 agents: 11 state groups read + written (352), action (16), obs 24 f32 (96), reward + flags (6)
+              "ma_hover": 470}
 
 
 def parse():
@@ -43,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=65536, help="lanes per GPU")
-    ap.add_argument("--env", default="hover", choices=["hover", "quadx_waypoints", "fixedwing_waypoints", "dogfight"])
+    ap.add_argument("--env", default="hover", choices=["hover", "quadx_waypoints", "fixedwing_waypoints", "dogfight", "ma_hover"])
     ap.add_argument("--noise", default="philox", choices=["philox", "off"])
     ap.add_argument("--graph-steps", type=int, default=100, help="env steps captured per HIP graph")
     ap.add_argument("--no-graph", action="store_true")
@@ -74,6 +76,19 @@ def make_engine(env, batch, device, lane_offset, noise, contact_response=True, w
         P = build_params("fixedwing", "dogfight", noise=noise, autoreset="off", seed=0, angle_representation="euler",
                          vehicle_options=dict(drone_model="acrowing"), world_options=dict(world_scale=5.0))
         return BatchEngine(P, batch, device=device, lane_offset=lane_offset)
+    if env == "ma_hover":  # MAQuadXHoverEnv, four agents per (shared) world 2 m apart, no auto-reset in the PettingZoo API
+        import numpy as np
+        import torch
+
+        from pyflyt_amd.params import quat_from_euler
+        sp = np.array([[-1.0, -1.0, 1.0], [1.0, -1.0, 1.0], [-1.0, 1.0, 1.0], [1.0, 1.0, 1.0]])
+        P = build_params("quadx", "ma_hover", noise=noise, autoreset="off", seed=0, agents_per_world=4, start_pos=sp[0], flight_mode=flight_mode,
+                         world_options=dict(contact_response=True))
+        eng = BatchEngine(P, batch, device=device, lane_offset=lane_offset)
+        side = np.zeros((batch, 12), dtype=np.float32)
+        side[:, :7] = np.tile(np.concatenate([sp, np.tile(quat_from_euler((0, 0, 0)), (4, 1))], axis=1), (batch // 4, 1))
+        eng.state[12:15] = torch.tensor(side, device=device).view(batch, 3, 4).permute(1, 0, 2)
+        return eng
     vehicle, task = {"hover": ("quadx", "hover"), "quadx_waypoints": ("quadx", "waypoints"),
                      "fixedwing_waypoints": ("fixedwing", "waypoints")}[env]
     wo = {} if contact_response else dict(contact_response=False)  # (default: the solve is ON, as in the reference)
@@ -151,13 +166,16 @@ def main():
     red_dev = device if backend == "nccl" else torch.device("cpu")  # where the clocks are max-reduced
 
     # per-GPU slice; no collective in the timed loop
-    shard = weak_shard(args.batch, rank, world) if args.scaling == "weak" else strong_shard(args.batch, rank, world, unit=4 if args.env == "dogfight" else 1)
+    shard = weak_shard(args.batch, rank, world) if args.scaling == "weak" else strong_shard(args.batch, rank, world, unit=4 if args.env in ("dogfight", "ma_hover") else 1)
     n = shard.lanes
     eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise, contact_response=not args.no_contact_response, world=args.world, flight_mode=args.flight_mode)
     g = max(1, min(args.graph_steps, args.steps))
     ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(g)]
     for i, a in enumerate(ring):
         eng.sample_actions(a, i)
+        if args.env == "ma_hover":  # rate commands +-0.3 rad/s, thrust around the hover value: everybody stays airborne
+            a[:, :3].mul_(0.3 / 3.14159265)
+            a[:, 3].mul_(0.05).add_(0.34)
         if args.env == "dogfight" and args.dogfight_actions == "gentle":
             # uniform actions over the whole box fly every aircraft into the ground within seconds, and a world of wrecks at rest
             # on the floor (contact solve every tick for every lane) is not the regime a policy trains in: gentle commands
@@ -222,7 +240,7 @@ def main():
     # actions sampled on device with pf_sample_actions' keys, every step's obs / action / reward / flags written
     # to trajectory buffers). Timed with HIP events on the launch stream; same barrier / max-over-ranks rule.
     roll = None
-    if args.rollout_steps > 0 and args.env != "dogfight":
+    if args.rollout_steps > 0 and args.env not in ("dogfight", "ma_hover"):
         kk = args.rollout_steps
         reps = max(5, args.steps // kk)  # (at least five launches: a single one is dominated by its launch / first-touch overheads)
         with torch.cuda.stream(stream):
@@ -269,7 +287,7 @@ def main():
                        "flight_mode": args.flight_mode, "launch": "hipGraph" if graph is not None else "eager", "contact_response": bool(eng.params.contact_response), "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                         "kernel": {"fixedwing_waypoints": "pf::fixedwing_wp_env_kernel", "dogfight": "pf::dogfight_env_kernel"}.get(args.env, "pf::quadx_m0_env_kernel"),
+                         "kernel": {"fixedwing_waypoints": "pf::fixedwing_wp_env_kernel", "dogfight": "pf::dogfight_env_kernel", "ma_hover": "pf::quadx_m0_env_kernel<MA_HOVER, .., SHARED>"}.get(args.env, "pf::quadx_m0_env_kernel"),
                          "algorithmic_bytes_per_launch": algo,
                          "launch_us": per_launch_s * 1e6},
         }
@@ -302,7 +320,7 @@ def main():
                 "kernel": ("pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel") + "<..., ROLL=1>", "launch_us": rev / reps * 1e6,
                 "note": "k env steps per launch, state in registers, on-device action sampling (pf_sample_actions keys); bit-identical to k x pf_env_step (tests/test_gpu_rollout.py)",
             }
-        if not args.no_cpu_baseline and world == 1 and args.env != "dogfight":
+        if not args.no_cpu_baseline and world == 1 and args.env not in ("dogfight", "ma_hover"):
             out["cpu_baseline"] = cpu_baseline(args.env, args.noise, args.cpu_seconds)
         line = json.dumps(out)
     if dist is not None:

@@ -5,8 +5,9 @@ import torch
 from pyflyt_amd import build_params
 from pyflyt_amd.engine import BatchEngine
 n = int(os.environ.get("N", "65536")); steps = int(os.environ.get("STEPS", "60"))
+kw = dict(flight_mode=int(os.environ["MODE"])) if "MODE" in os.environ else {}
 P = build_params(os.environ.get("VEH","quadx"), os.environ.get("TASK","hover"), noise=os.environ.get("NOISE","philox"), autoreset="next_step",
-                 world_options=(dict(contact_response=os.environ["CR"] == "1") if "CR" in os.environ else None))
+                 world_options=(dict(contact_response=os.environ["CR"] == "1") if "CR" in os.environ else None), **kw)
 if "SETTLE" in os.environ: P.settle_steps = int(os.environ["SETTLE"])
 eng = BatchEngine(P, n)
 ring = [torch.empty(n,4,device="cuda") for _ in range(16)]

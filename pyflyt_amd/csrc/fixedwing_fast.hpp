@@ -448,9 +448,13 @@ struct FwHot {
     // An opaque zero offset per tick keeps the per-surface constant loads inside the tick (16 SGPRs at
     // a time, see the file header) instead of hoisted and spilled; the scheduling barriers keep the
     // five surface bodies from being interleaved (which cost 255 VGPRs and scratch).
+#ifdef PF_FW_HOIST  // (A/B: let the compiler hoist the table loads out of the tick loop and spill them to VGPR lanes)
+    fw_tab_cptr tk = tab;
+#else
     uint32_t zoff;
     asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
     fw_tab_cptr tk = tab + zoff;
+#endif
     FwPairOut tw;  // (h-tail, main wing): evaluated together, accumulated as surfaces 2 and 4 around the v-tail
     float ry4;
     {  // ailerons
@@ -534,8 +538,13 @@ struct FwHot {
 // g3 w.yz+act0,1, g4 act2..4+throttle, g5 ints, g6..8 the 4x3 targets (Fixedwing::load/store layout).
 // ROLL: as in quadx_m0_env_kernel -- 0 one env step per launch, 1 pf_rollout with on-device action sampling (no vector-memory
 // load in the loop), 2 pf_rollout over a given action sequence.
+#ifdef PF_FW_LB1  // (A/B: one wave per SIMD -- 512 registers, the overflow into AGPRs instead of scratch)
+#define PF_FW_WAVES 1
+#else
+#define PF_FW_WAVES 2
+#endif
 template <int NOISE, int ROLL>
-__global__ void __launch_bounds__(64, 2) fixedwing_wp_env_kernel(const FwK K, const FwTable* table_g, const pf_buffers B,
+__global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const FwK K, const FwTable* table_g, const pf_buffers B,
                                                                  const pf_params* __restrict__ Pfull, const float4* __restrict__ tmpl,
                                                                  const int n, const uint64_t lane0, const int op,
                                                                  const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {

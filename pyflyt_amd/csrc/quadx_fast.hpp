@@ -537,6 +537,18 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
   if (SHARED) { V.wpose_ = wpose; V.wvel_ = wvel_all + wid * 64 * kPairVelStride; V.rec_ = tile; V.wtid = tid; V.wA = apw; }
   QuadCasc C;  // (MODES only; dead otherwise)
   const pf_params_kptr Pk = uniform_params(Pfull);
+#ifndef PF_NO_PARAM_WARM
+  if (CR) {
+    // Warm the scalar cache with the four lines of the parameter block the contact solve reads (bytes 64 .. 319: contact model,
+    // mass properties, the collision box). In the hover task a solve is rare -- a handful of single-lane calls per 65 536-lane
+    // launch -- and the launch lasts as long as its slowest wave: cold, every dependent scalar load of that call went to L2.
+    // Issued here they ride along with the kernel-argument loads. (The wait is inside the statement: the compiler does not
+    // track loads issued by inline assembly.)
+    uint32_t w0, w1, w2, w3;
+    asm volatile("s_load_dword %0, %4, 0x40\n\ts_load_dword %1, %4, 0x80\n\ts_load_dword %2, %4, 0xc0\n\ts_load_dword %3, %4, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(w0), "=s"(w1), "=s"(w2), "=s"(w3) : "s"(Pk) : "memory");
+  }
+#endif
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;

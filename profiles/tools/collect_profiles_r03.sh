@@ -24,10 +24,13 @@ for e in fixedwing:waypoints quadx:waypoints; do
   VEH=${e%%:*} TASK=${e##*:} $T rocprofv3 --pmc $SQ --output-format csv -d $O/pmc_step_sq_${e%%:*}_${e##*:} -- python $R/profiles/tools/prof_cfg.py > /dev/null 2>&1
 done
 # the other BASELINE configs / sizes, the flight modes, the shared-world PettingZoo task, the detection-only opt-out
-for e in quadx_waypoints fixedwing_waypoints ma_hover; do
+for e in quadx_waypoints fixedwing_waypoints; do
   $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$e -- python $R/bench.py --env $e --steps 500 --warmup 100 --no-cpu-baseline > /dev/null 2>&1
   timeout 100 python $R/bench.py --env $e --steps 500 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_$e.json
 done
+# (PettingZoo task: no auto-reset, so a short window while every drone of every world is still airborne)
+$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ma_hover -- python $R/bench.py --env ma_hover --steps 120 --warmup 20 --graph-steps 20 --no-cpu-baseline > /dev/null 2>&1
+timeout 100 python $R/bench.py --env ma_hover --steps 120 --warmup 20 --graph-steps 20 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_ma_hover.json
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_mode7 -- python $R/bench.py --flight-mode 7 --steps 1000 --warmup 100 --no-cpu-baseline > /dev/null 2>&1
 for m in 7 6 4 1 -1; do timeout 100 python $R/bench.py --flight-mode=$m --steps 1000 --warmup 100 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_mode$m.json; done
 timeout 100 python $R/bench.py --batch 4096 --steps 2000 --warmup 200 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_b4096.json

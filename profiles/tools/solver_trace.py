@@ -19,8 +19,9 @@ def read():
 
 def report(tag, launches, t):
     calls = max(t[0], 1.0)
-    print(f"{tag}: {t[0] / launches:.1f} solver calls per launch; per call: setup {t[1] / calls:.0f} cycles, sweeps {t[2] / calls:.0f} cycles, "
-          f"max contacts {t[3] / calls:.2f}, active lanes {t[4] / calls:.2f}, sweeps {t[5] / calls:.2f}, contact rows evaluated {t[6] / calls:.1f} / skipped {t[7] / calls:.1f}")
+    print(f"{tag}: {t[0] / launches:.1f} solver calls per launch; per call (shader clocks, inside the function): count pass {t[1] / calls:.0f}, records {t[6] / calls:.0f}, "
+          f"scan + bookkeeping {t[7] / calls:.0f}, sweeps {t[2] / calls:.0f}; "
+          f"max contacts {t[3] / calls:.2f}, lanes with contacts {t[4] / calls:.2f}, sweeps run {t[5] / calls:.2f}")
 
 
 if what == "landed":

@@ -178,8 +178,10 @@ struct ContactSet {
   }
   // Wave-uniform control flow: the contact counter and the sweep counter are scalars, a lane that is past its last contact reads
   // its sentinel record (zero impulse, target -FLT_MAX, zero effective masses: the row update is an exact no-op), and the solve
-  // ends when a sweep moved nothing in any lane (a lane whose own sweep moved nothing would repeat it exactly). No exec-mask
-  // bookkeeping in the loop: on a lone wave a scalar instruction costs an issue slot like any other.
+  // ends when a sweep moved nothing in any lane (a lane whose own sweep moved nothing would repeat it exactly). (A convergence
+  // test at fp32 resolution -- largest impulse change below 2^-20 of the largest impulse -- was tried for the single-lane
+  // solves the env tasks' launches wait for: the iteration does not contract that far within the budget, 7.6 sweeps run
+  // instead of 7.7.) No exec-mask bookkeeping in the loop: on a lone wave a scalar instruction costs an issue slot like any other.
   PF_DEV void sweeps(const int iters, const float mu) {
     W4[5 * n + 0] = pf_f4v{0.0f, 0.0f, 0.0f, -3.4028235e38f};
     W4[5 * n + 1] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
@@ -285,8 +287,9 @@ PF_DEV void for_each_contact_vertex(const pf_params_kptr P, const float hxy, con
 struct ParamContactSrc {
   pf_params_kptr P;
   float slop_, inv_dt_, rest_, mu_, hxy_, hz2_, margin_;
-  int iters_, nb_;
+  int iters_, nb_, worst_;
   PF_DEV explicit ParamContactSrc(pf_params_kptr p) : P(p) {
+    worst_ = p->contact_max_points;
     const float dt = p->dt, hz = p->plane_half_z;
     slop_ = p->contact_slop; rest_ = p->contact_restitution; mu_ = p->contact_friction; iters_ = p->contact_iters;
     hxy_ = p->plane_half_xy; margin_ = p->contact_margin; nb_ = p->n_boxes;
@@ -298,6 +301,7 @@ struct ParamContactSrc {
   PF_DEV float rest() const { return rest_; }
   PF_DEV float mu() const { return mu_; }
   PF_DEV int iters() const { return iters_; }
+  PF_DEV int worst() const { return worst_; }  // the airframe's worst-case contact count (pf_params.contact_max_points)
 };
 
 PF_DEV int wave_inclusive_scan_asking(const bool need, const int sz) {
@@ -330,24 +334,38 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
                                      float i0, float i1, float i2, float i3, float i4, float i5) {
 #ifdef PF_PHASE_TRACE
   const unsigned long long pf_t0 = __builtin_readcyclecounter();
-  unsigned long long pf_sweep = 0;
+  unsigned long long pf_sweep = 0, pf_fill = 0;
 #endif
   ContactOut out{v, w, 0.0f};
-  int n = 0;
-  if (need) src.for_each(p, R, [&](v3, float) { n += 1; });
-  n = n > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : n;
-  need = need && n > 0;
-  const int sz = need ? (n + 1) * kContactWords : 0;
+  // Few lanes ask (the env tasks: a handful of single-lane solves per launch, and the launch waits for each of them): when every
+  // asking lane fits with its airframe's worst-case region there is nothing to pack -- no count pass, rank x worst-case size.
+  const int worst_sz = (src.worst() + 1) * kContactWords;
+  const bool roomy = __popcll(__ballot(need)) * worst_sz <= cap_floats;  // (wave-uniform)
+  int n = PF_MAX_CONTACTS;
+  if (!roomy) {
+    n = 0;
+    if (need) src.for_each(p, R, [&](v3, float) { n += 1; });
+    n = n > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : n;
+    need = need && n > 0;
+  }
+  const int sz = need ? (roomy ? worst_sz : (n + 1) * kContactWords) : 0;
+#ifdef PF_PHASE_TRACE
+  const unsigned long long pf_tc = __builtin_readcyclecounter();
+#endif
   ContactSet S;
   S.n = 0;
   while (__any(need)) {
     const int incl = wave_inclusive_scan_asking(need, sz);
     // (the first lane that asks always fits: the callers' LDS holds at least one worst-case region)
     if (need && incl <= cap_floats) {
+#ifdef PF_PHASE_TRACE
+      const unsigned long long pf_a = __builtin_readcyclecounter();
+#endif
       S.begin(ws + (incl - sz), R, com, inv_mass, v, w, i0, i1, i2, i3, i4, i5, src.slop(), src.inv_dt(), src.rest());
       src.for_each(p, R, [&](v3 off, float z) { if (S.n < n) S.add(off, -z); });
 #ifdef PF_PHASE_TRACE
       const unsigned long long pf_b = __builtin_readcyclecounter();
+      pf_fill += pf_b - pf_a;
 #endif
       S.sweeps(src.iters(), src.mu());
       out = S.finish(v, w);
@@ -362,24 +380,25 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
     const unsigned long long pf_t2 = __builtin_readcyclecounter();
     const unsigned long long m = __ballot(1);
     const int first = __ffsll((long long)m) - 1;
-    const int solved = __popcll(__ballot(n > 0));
-    int nmax = n, sd = S.sweeps_done, rf = S.rows_full, rs = S.rows_skipped;
-    unsigned long long sw = pf_sweep;
+    const int solved = __popcll(__ballot(S.n > 0));
+    int nmax = S.n, sd = S.sweeps_done, rf = S.rows_full;
+    unsigned long long sw = pf_sweep, fl = pf_fill;
     for (int o = 32; o > 0; o >>= 1) {
-      nmax = max(nmax, __shfl_xor(nmax, o)); sd = max(sd, __shfl_xor(sd, o)); rf = max(rf, __shfl_xor(rf, o)); rs = max(rs, __shfl_xor(rs, o));
-      const unsigned long long t = __shfl_xor(sw, o);
-      sw = sw > t ? sw : t;
+      nmax = max(nmax, __shfl_xor(nmax, o)); sd = max(sd, __shfl_xor(sd, o)); rf = max(rf, __shfl_xor(rf, o));
+      const unsigned long long t = __shfl_xor(sw, o), u = __shfl_xor(fl, o);
+      sw = sw > t ? sw : t; fl = fl > u ? fl : u;
     }
     if ((int)(threadIdx.x & 63u) == first) {
       atomicAdd(&g_solver_trace[0], 1ull);
-      atomicAdd(&g_solver_trace[1], (pf_t2 - pf_t0) - sw);  // everything but the sweeps: count, scan, records
+      atomicAdd(&g_solver_trace[1], pf_tc - pf_t0);              // count pass
+      atomicAdd(&g_solver_trace[7], (pf_t2 - pf_tc) - sw - fl);   // scan / loop bookkeeping
+      atomicAdd(&g_solver_trace[6], fl);                          // records
       atomicAdd(&g_solver_trace[2], sw);
       atomicAdd(&g_solver_trace[3], (unsigned long long)nmax);
       atomicAdd(&g_solver_trace[4], (unsigned long long)solved);
       atomicAdd(&g_solver_trace[5], (unsigned long long)sd);
-      atomicAdd(&g_solver_trace[6], (unsigned long long)rf);
-      atomicAdd(&g_solver_trace[7], (unsigned long long)rs);
     }
+    (void)rf;
   }
 #endif
   return out;

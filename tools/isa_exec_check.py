@@ -1,0 +1,148 @@
+"""Lint (and repair) for a register-allocator placement bug of the ROCm 7.2 compiler that bit these kernels on gfx950.
+
+At the top of the join block of a divergent branch -- the block `s_cbranch_execz` jumps to, or the fall-through of a loop's
+`s_cbranch_execnz` -- the lanes that sat the branch out are re-enabled by `s_or_b64 exec, exec, s[..]` (or, in an if/else flow block,
+`s_or_saveexec_b64`). Only scalar instructions and SGPR spill traffic (v_writelane / v_readlane) belong in front of that
+instruction. The VGPR allocation runs after the SGPR allocation, and when the latter has left a scalar copy or a spill in front of
+the exec restore, the former no longer recognises the block prologue: a live-range-split copy of a value that is live in ALL lanes
+(seen: `v_accvgpr_write_b32 a41, v7`, the last action component of the generic QuadX-Waypoints env kernel; `v_mov_b32 v121, v55` in
+the specialised one) lands BEFORE the restore, executes under the branch's narrower -- on the skip edge: empty -- exec mask, and
+the other lanes read garbage later. Which kernels are hit changes with every edit that moves register pressure.
+
+  python tools/isa_exec_check.py dev.s [...]            lint: prints every such site, exit status 1 if there is any
+  python tools/isa_exec_check.py --fix dev.s -o out.s   repair: moves the copies to just behind the exec restore (where the
+                                                        allocator meant them to run: for every lane that enters the block),
+                                                        refusing anything it cannot prove safe to move
+
+The build (__graft_entry__.build) compiles the device code to assembly, repairs it with this, lints the result and only then
+assembles it; tests/test_isa_lint.py lints the disassembly of the shipped code object."""
+import re
+import sys
+
+LABEL = re.compile(r"^(\.LBB\S+|[A-Za-z_][\w$.]*):")
+OBJ_LABEL = re.compile(r"^[0-9a-f]+ <([^>]+)>:")
+WIDEN = re.compile(r"^(s_or_b64\s+exec,\s*exec,|s_or_saveexec_b64\s)")
+SCALAR_OK = ("v_writelane_b32", "v_readlane_b32", "v_readfirstlane_b32", "s_")
+MOVABLE = re.compile(r"^(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32|v_pk_mov_b32)\s")
+REG = re.compile(r"\b([vsa])(\d+)\b|\b([vsa])\[(\d+):(\d+)\]|\b(vcc|exec|scc|m0)(?:_lo|_hi)?\b")
+
+
+def instruction(raw):
+    """the instruction text of an assembly / objdump line, '' for labels, directives, comments and blanks"""
+    line = raw.split("//")[0].split(";")[0].strip()
+    if not line or line.startswith(".") or LABEL.match(line) or OBJ_LABEL.match(line):
+        return ""
+    return line
+
+
+def regs(ins):
+    out = set()
+    for m in REG.finditer(ins.split(None, 1)[1] if " " in ins else ""):
+        if m.group(1):
+            out.add(m.group(1) + m.group(2))
+        elif m.group(3):
+            out.update(m.group(3) + str(k) for k in range(int(m.group(4)), int(m.group(5)) + 1))
+        else:
+            out.add(m.group(6))
+    return out
+
+
+def label_of(raw):
+    m = LABEL.match(raw.strip()) or OBJ_LABEL.match(raw.strip())
+    return m.group(1) if m else None
+
+
+def sites(lines):
+    """yields (function, label, [line indices of vector instructions in front of the exec restore], index of the restore)"""
+    joins, func = set(), None
+    for raw in lines:
+        lab = label_of(raw)
+        if lab and not lab.startswith((".LBB", "L")):
+            func = lab
+        ins = instruction(raw)
+        if ins.startswith("s_cbranch_execz"):
+            joins.add((func, ins.split()[1].strip("<>").split("+")[0]))
+    func, label, pending = None, None, None
+    for i, raw in enumerate(lines):
+        lab = label_of(raw)
+        if lab:
+            label = lab
+            if not lab.startswith((".LBB", "L")):
+                func = lab
+            pending = [] if (func, lab) in joins else None
+            continue
+        ins = instruction(raw)
+        if not ins:
+            continue
+        if ins.startswith("s_cbranch_execnz"):  # the fall-through of a loop's back edge runs with an empty exec mask
+            label, pending = f"(after line {i + 1})", []
+            continue
+        if pending is None:
+            continue
+        if WIDEN.match(ins):
+            if pending:
+                yield func, label, pending, i
+            pending = None
+            continue
+        op = ins.split()[0]
+        if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")) or re.match(r"^s_\w+\s+exec", ins) or "saveexec" in op:
+            pending = None  # the block ends, or exec is rewritten some other way: not this pattern
+            continue
+        if not op.startswith(SCALAR_OK):
+            pending.append(i)
+
+
+def lint(path, lines):
+    n = 0
+    for func, label, idx, _ in sites(lines):
+        for i in idx:
+            print(f"{path}:{i + 1}: {func} {label}: `{instruction(lines[i])}` runs before the block's exec restore")
+            n += 1
+    return n
+
+
+def fix(lines):
+    """returns (new lines, report); raises if a flagged instruction is not a plain register copy or cannot be moved safely"""
+    moves, report = {}, []
+    for func, label, idx, at in sites(lines):
+        moved = set()
+        for i in idx:
+            ins = instruction(lines[i])
+            if not MOVABLE.match(ins):
+                raise RuntimeError(f"line {i + 1} ({func} {label}): `{ins}` sits before the exec restore and is not a plain register copy")
+            mine = regs(ins)
+            for j in range(i + 1, at + 1):
+                other = instruction(lines[j])
+                if other and j not in idx and (regs(other) & mine):
+                    raise RuntimeError(f"line {i + 1} ({func} {label}): cannot move `{ins}` past `{other}`")
+            moved.add(i)
+            report.append(f"{func} {label}: `{ins}` moved behind `{instruction(lines[at])}`")
+        moves[at] = sorted(moved)
+    skip = {i for v in moves.values() for i in v}
+    out = []
+    for i, raw in enumerate(lines):
+        if i in skip:
+            continue
+        out.append(raw)
+        for j in moves.get(i, ()):
+            out.append(lines[j])
+    return out, report
+
+
+def main(argv):
+    if argv and argv[0] == "--fix":
+        src, dst = argv[1], argv[argv.index("-o") + 1]
+        lines = open(src, errors="replace").read().split("\n")
+        out, report = fix(lines)
+        open(dst, "w").write("\n".join(out))
+        for r in report:
+            print("isa_exec_check:", r)
+        return 1 if lint(dst, out) else 0
+    bad = 0
+    for p in argv:
+        bad += lint(p, open(p, errors="replace").read().split("\n"))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

@@ -63,6 +63,8 @@ def parse():
                          "a departure from the reference; diagnostic A/B, never the headline configuration (the default has the solve on)")
     ap.add_argument("--world", action="append", default=[], metavar="KEY=VALUE",
                     help="override an entry of pyflyt_amd.params.WORLD (diagnostic), e.g. --world contact_iters=6")
+    ap.add_argument("--ring", type=int, default=100, help="least number of entries of the action ring (independent uniform draws per lane and entry)")
+    ap.add_argument("--seed", type=int, default=0, help="Philox seed of the env's noise, spawn and action draws")
     ap.add_argument("--preroll", type=int, default=400,
                     help="env steps run as part of the SETUP, before the W warm-up steps (one pf_rollout launch, or eager steps where there is "
                          "no rollout): after the initial reset every lane is in the same phase of its first episode -- with random actions the "
@@ -76,7 +78,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_engine(env, batch, device, lane_offset, noise, contact_response=True, world=(), flight_mode=0):
+def make_engine(env, batch, device, lane_offset, noise, contact_response=True, world=(), flight_mode=0, seed=0):
     from pyflyt_amd import build_params
     from pyflyt_amd.engine import BatchEngine
 
@@ -105,7 +107,7 @@ def make_engine(env, batch, device, lane_offset, noise, contact_response=True, w
         k, v = kv.split("=", 1)
         wo[k] = float(v) if "." in v or "e" in v.lower() else int(v)
     kw = dict(flight_mode=flight_mode) if vehicle == "quadx" else {}
-    P = build_params(vehicle, task, noise=noise, autoreset="next_step", seed=0, world_options=wo or None, **kw)
+    P = build_params(vehicle, task, noise=noise, autoreset="next_step", seed=seed, world_options=wo or None, **kw)
     return BatchEngine(P, batch, device=device, lane_offset=lane_offset)
 
 
@@ -177,13 +179,18 @@ def main():
     # per-GPU slice; no collective in the timed loop
     shard = weak_shard(args.batch, rank, world) if args.scaling == "weak" else strong_shard(args.batch, rank, world, unit=4 if args.env in ("dogfight", "ma_hover") else 1)
     n = shard.lanes
-    eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise, contact_response=not args.no_contact_response, world=args.world, flight_mode=args.flight_mode)
+    eng = make_engine(args.env, n, device, lane_offset=shard.lane_offset, noise=args.noise, contact_response=not args.no_contact_response, world=args.world, flight_mode=args.flight_mode, seed=args.seed)
     # steps per HIP graph: a graph is replayed whole, so it is no longer than the timed run -- nor than the warm-up, so that the
     # warm-up can include one replay of it (the first launch of a freshly instantiated graph carries its upload: with the
     # driver's --steps 20 --warmup 5 that one-off cost was a third of the timed region)
     # steps per HIP graph: a graph is replayed whole, so it is no longer than the timed run
     g = max(1, min(args.graph_steps, args.steps))
-    ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(g)]
+    # the action ring: independent uniform draws per lane and entry. It is never shorter than --ring (default 100) entries, however
+    # short the run: a ring that repeats within an episode's length is a different action process -- every lane keeps a thrust
+    # bias, the drones sink, and the floor's contact solve runs in every launch (profiles/tools/solver_trace.py WHAT=rates:
+    # 6 solves per launch with a ring of 16, 1.3 with 20, 0.03 with 100, 0.04 with a fresh draw every step)
+    R = max(g, min(args.ring, max(1, (2 << 30) // (16 * n))))  # (at most 2 GiB of actions)
+    ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(R)]
     for i, a in enumerate(ring):
         eng.sample_actions(a, i)
         if args.env == "ma_hover":  # small rate commands, thrust just above the hover value: everybody stays airborne
@@ -207,7 +214,7 @@ def main():
             eng.rollout(args.preroll, step_index0=1 << 20)
         except Exception:
             for i in range(args.preroll):
-                eng.env_step(ring[i % g])
+                eng.env_step(ring[i % R])
         setup_steps += args.preroll
     eng.env_step(ring[0])
     setup_steps += 1
@@ -233,7 +240,10 @@ def main():
             setup_steps += g
             stream.synchronize()
 
+        pos = 0  # (position in the ring of the next eagerly launched step: the timed steps go on where the warm-up stopped)
+
         def run(k):
+            nonlocal pos
             done = 0
             if graph is not None:
                 while k - done >= g:
@@ -241,11 +251,11 @@ def main():
                     done += g
             if launchers is not None:
                 while done < k:
-                    launchers[done % g](sp)
-                    done += 1
+                    launchers[pos % R](sp)
+                    done += 1; pos += 1
             while done < k:
-                eng.env_step(ring[done % g])
-                done += 1
+                eng.env_step(ring[pos % R])
+                done += 1; pos += 1
 
         # clock spin-up (setup): the host-side preparation above left the GPU idle for milliseconds, and a short run (the driver's
         # 5 + 20 steps are 0.3 ms of work) would be measured on a clock that is still ramping: keep the device busy right up to
@@ -262,13 +272,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        solver_trace = None
+        if os.environ.get("PF_BENCH_SOLVER_TRACE"):  # (diagnostic, with the -DPF_PHASE_TRACE variant library: contact-solver calls inside the timed region)
+            import ctypes as _C
+
+            solver_trace = (_C.c_ulonglong * 8)()
+            eng.lib.pf_debug_solver_trace(solver_trace)  # (reads and clears)
         t0 = time.perf_counter()
         ev0.record(stream)
         run(args.steps)
         ev1.record(stream)
+        while not ev1.query():  # (poll first: a blocking synchronize sleeps on an interrupt, tens of microseconds on a 0.25 ms run)
+            pass
         stream.synchronize()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        if solver_trace is not None:
+            eng.lib.pf_debug_solver_trace(solver_trace)
+            print(f"[solver trace] timed region: {solver_trace[0]} solver calls, {solver_trace[5]} sweeps, {solver_trace[4]} lanes with contacts", file=sys.stderr)
         if dist is not None:
             dist.barrier()
     ev_ms = ev0.elapsed_time(ev1)
@@ -332,7 +353,7 @@ def main():
             "config": {"workload": f"PyFlyt/QuadX-Hover-v4 semantics, flight_mode 0, batch {n}/GPU x {world} GPU(s), "
                                    f"random actions, motor noise {args.noise}, NEXT_STEP auto-reset"
                        if args.env == "hover" else f"{args.env}, batch {n}/GPU x {world}" + (f", {args.dogfight_actions} actions" if args.env == "dogfight" else ""),
-                       "batch_per_gpu": n, "global_batch": total_lanes, "setup": {"untimed_steps_before_warmup": setup_steps, "what": "episode-phase preroll (--preroll), one eager step (kernel load), one replay of the instantiated graph (its upload), clock spin-up rollout right before the warm-up"}, "ticks_per_env_step": eng.ticks_per_step,
+                       "batch_per_gpu": n, "global_batch": total_lanes, "setup": {"untimed_steps_before_warmup": setup_steps, "what": "episode-phase preroll (--preroll), one eager step (kernel load), one replay of the instantiated graph (its upload), clock spin-up rollout right before the warm-up"}, "action_ring": R, "ticks_per_env_step": eng.ticks_per_step,
                        "flight_mode": args.flight_mode, "launch": "hipGraph" if graph is not None else ("prepared steps, one launch per step" if launchers is not None else "eager"), "contact_response": bool(eng.params.contact_response), "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,

@@ -13,12 +13,12 @@ task = os.environ.get("TASK", "hover")
 wo = dict(contact_response=False) if os.environ.get("CR", "1") == "0" else None
 P = build_params("quadx", task, noise="philox", autoreset="next_step", seed=0, world_options=wo)
 eng = BatchEngine(P, n, device="cuda:0")
-ring = [torch.empty(n, 4, device="cuda:0") for _ in range(16)]
+ring = [torch.empty(n, 4, device="cuda:0") for _ in range(100)]  # (a ring that repeats within an episode is a different action process: solver_trace.py WHAT=rates)
 for i, a in enumerate(ring):
     eng.sample_actions(a, i)
 eng.env_reset()
 for i in range(200):
-    eng.env_step(ring[i % 16])
+    eng.env_step(ring[i % 100])
 torch.cuda.synchronize()
 L = _lib.lib()
 K = 13
@@ -27,7 +27,7 @@ names = ["entry", "int group arrived", "Philox done", "state unpacked + derive",
          "obs stores issued", "state stores issued", "stores acknowledged"]
 acc = []
 for rep in range(20):
-    eng.env_step(ring[rep % 16])
+    eng.env_step(ring[(200 + rep) % 100])
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * (waves * K))()
     rc = L.pf_debug_phase_trace(buf, waves * K)

@@ -53,3 +53,84 @@ elif what == "hover":
         eng.env_step(ring[i % 16])
     torch.cuda.synchronize()
     report("hover 65536 (per env step = 6 ticks, 1024 waves)", 100, read())
+elif what == "after_rollout":
+    # the per-step launches right after a rollout: solver calls per launch, and how many the busiest wave made (the launch waits
+    # for that wave)
+    from pyflyt_amd.engine import BatchEngine
+    n = 65536
+    eng = BatchEngine(build_params("quadx", "hover", noise="philox", autoreset="next_step", seed=0), n, device="cuda:0")
+    ring = [torch.empty(n, 4, device="cuda:0") for _ in range(16)]
+    for i, a in enumerate(ring):
+        eng.sample_actions(a, i)
+    eng.env_reset()
+    eng.rollout(400, step_index0=1 << 20)
+    torch.cuda.synchronize(); read()
+    out = []
+    for i in range(60):
+        eng.env_step(ring[i % 16])
+        torch.cuda.synchronize()
+        t = read()
+        f = eng.flags().cpu().numpy()
+        out.append((int(t[0]), int(t[5]), int(((f & _lib.F_INFO_COLLISION) != 0).sum())))
+    print("per-step launches after a 400-step rollout: (solver calls, sweeps summed, lanes reporting a collision)")
+    print(" ".join(f"{a}/{b}/{c}" for a, b, c in out))
+elif what == "bench_window":
+    # the launches bench.py times in the driver's shape (--steps 20 --warmup 5), after its setup: how many solver calls do they hold?
+    from pyflyt_amd.engine import BatchEngine
+    n = 65536
+    eng = BatchEngine(build_params("quadx", "hover", noise="philox", autoreset="next_step", seed=0), n, device="cuda:0")
+    ring = [torch.empty(n, 4, device="cuda:0") for _ in range(16)]
+    for i, a in enumerate(ring):
+        eng.sample_actions(a, i)
+    eng.env_reset()
+    eng.rollout(400, step_index0=1 << 20)
+    for i in range(21):
+        eng.env_step(ring[i % 16])
+    eng.rollout(300, step_index0=(1 << 20) + 400)
+    torch.cuda.synchronize(); read()
+    out = []
+    for i in range(25):
+        eng.env_step(ring[i % 16])
+        torch.cuda.synchronize()
+        t = read()
+        out.append((int(t[0]), int(t[5]), int(t[3])))
+    print("warm-up 5 + timed 20 launches: (solver calls, sweeps summed, contacts summed)")
+    print(" ".join(f"{a}/{b}/{c}" for a, b, c in out))
+elif what == "rates":
+    # contact-solver calls per launch under different action processes (uniform draws over the action box): fresh every step,
+    # or a ring of R draws per lane repeated -- the bench's graphs replay a ring
+    from pyflyt_amd.engine import BatchEngine
+    n = 65536
+    for R in (0, 16, 20, 100, 400):
+        eng = BatchEngine(build_params("quadx", "hover", noise="philox", autoreset="next_step", seed=0), n, device="cuda:0")
+        ring = [torch.empty(n, 4, device="cuda:0") for _ in range(max(R, 1))]
+        for i, a in enumerate(ring):
+            eng.sample_actions(a, i)
+        eng.env_reset()
+        rates = []
+        for blk in range(6):
+            torch.cuda.synchronize(); read()
+            for i in range(200):
+                k = blk * 200 + i
+                if R == 0:
+                    eng.sample_actions(ring[0], 1000 + k)
+                eng.env_step(ring[k % R] if R else ring[0])
+            torch.cuda.synchronize()
+            rates.append(read()[0] / 200.0)
+        print(f"action ring of {R or 'fresh draws every step'}: solver calls per launch over blocks of 200 steps: " + " ".join(f"{r:.2f}" for r in rates))
+elif what == "calm":
+    # how many waves keep the contact response's call site in their tick loop (some lane within reach of the floor this env step)
+    from pyflyt_amd.engine import BatchEngine
+    n = 65536
+    eng = BatchEngine(build_params("quadx", os.environ.get("TASK", "hover"), noise="philox", autoreset="next_step", seed=0), n, device="cuda:0")
+    ring = [torch.empty(n, 4, device="cuda:0") for _ in range(100)]
+    for i, a in enumerate(ring):
+        eng.sample_actions(a, i)
+    eng.env_reset()
+    buf = (C.c_ulonglong * 2)()
+    for blk in range(4):
+        for i in range(100):
+            eng.env_step(ring[i])
+        torch.cuda.synchronize()
+        assert L.pf_debug_calm_trace(buf) == 0
+        print(f"steps {blk * 100}-{blk * 100 + 99}: {buf[0] / 100:.2f} of {(n + 63) // 64} waves per launch are not calm")

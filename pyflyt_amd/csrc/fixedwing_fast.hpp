@@ -150,7 +150,7 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
 // (the parameter block through the scalar cache: inside an out-of-line function the plain pointer lives in VGPRs and its fields
 //  were flat loads at full memory latency, six boxes one after the other, in every tick of every wave that has a low flyer --
 //  the tail of the kernel's time in a population that is crashing; see uav_vehicles.hpp: uniform_params)
-__device__ __noinline__ bool fw_floor_contact(float px, float py, float pz, m3 R, const pf_params* Pg) {
+__device__ __noinline__ PF_RARE_TEXT bool fw_floor_contact(float px, float py, float pz, m3 R, const pf_params* Pg) {
   const pf_params_kptr P = uniform_params(Pg);
   const float hb[3] = {P->plane_half_xy, P->plane_half_xy, P->plane_half_z};
   const v3 cb{0.0f, 0.0f, -P->plane_half_z};
@@ -573,6 +573,7 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   {
     float4 gi = Sin[5 * N + li];
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li];
+    if (blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch((int)threadIdx.x);  // (uav_vehicles.hpp; behind the state loads: one wait for both)
     rng_ctr = (uint32_t)__float_as_int(gi.z);
     if (NOISE == PF_NOISE_PHILOX) {
       if (op == 0) zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));

@@ -722,6 +722,7 @@ struct pf_ctx {
   char err[256];
   // hot-path specialisation (quadx_fast.hpp)
   bool fast;
+  bool lean;     // the batch is at most one wave per SIMD of the device: the specialised QuadX kernel's 512-register instantiation
   pf::QuadK K;
   pf_params* P_dev;  // device copy of P for the rarely-taken floor paths (contact detection and response) and the LDS constant tables
   float4* tmpl;      // settled spawn state for lane-independent resets (env_kernel), or null
@@ -752,7 +753,10 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
-#define PF_FAST4(NZ, CR, MD, SH) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u)
+  // (the one-wave-per-SIMD instantiation -- quadx_fast.hpp, WPS -- where the batch is no more than that and the kernel has it)
+#define PF_FAST4(NZ, CR, MD, SH) do { constexpr int W1 = ((CR) && !(MD) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
+    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u); \
+    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u); } while (0)
   // (flight modes other than 0: the MODES instantiation, contact response compiled in -- quadk_from_params)
   // (shared worlds: PF_TASK_MA_HOVER with the contact response on -- quadk_from_params)
 #define PF_FAST3(NZ, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_FAST4(NZ, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_FAST4(NZ, CR, MD, false); } while (0)
@@ -767,7 +771,9 @@ static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t*
 template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
-#define PF_ROLL4(NZ, R, CR, MD, SH) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+#define PF_ROLL4(NZ, R, CR, MD, SH) do { constexpr int W1 = ((CR) && !(MD) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
+    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0); \
+    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0); } while (0)
 #define PF_ROLL3(NZ, R, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_ROLL4(NZ, R, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_ROLL4(NZ, R, CR, MD, false); } while (0)
 #define PF_ROLL(NZ, R) do { if (ctx->K.mode != 0) PF_ROLL3(NZ, R, true, true); else if (ctx->P.contact_response) PF_ROLL3(NZ, R, true, false); else PF_ROLL3(NZ, R, false, false); } while (0)
   if (b->actions == nullptr) {
@@ -868,6 +874,12 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   }
   c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr;
   c->fast = pf::quadk_from_params(P, c->K) && getenv("PF_DISABLE_FAST") == nullptr;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
+    const long waves = ((long)n_lanes + 63) / 64;
+    c->lean = cus > 0 && waves <= 4L * cus && getenv("PF_NO_LEAN_KERNEL") == nullptr;  // (4 SIMDs per CU)
+  }
   pf::FwTable fsurf;
   c->fast_fw = pf::fwk_from_params(P, c->FK, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;
   c->df_fast = P.task == PF_TASK_DOGFIGHT && pf::fw_table_from_params(P, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;
@@ -1101,6 +1113,13 @@ int pf_debug_solver_trace(unsigned long long* out) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_solver_trace), sizeof(unsigned long long) * 8, 0, hipMemcpyDeviceToHost);
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pf::g_solver_trace), z, sizeof(z), 0, hipMemcpyHostToDevice);
+  return (int)e;
+}
+// diagnostic variant only: (waves that were not calm, waves that took the calm test) since the last call; clears
+int pf_debug_calm_trace(unsigned long long* out) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pf::g_calm_trace), sizeof(unsigned long long) * 2, 0, hipMemcpyDeviceToHost);
+  unsigned long long z[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(pf::g_calm_trace), z, sizeof(z), 0, hipMemcpyHostToDevice);
   return (int)e;
 }
 // diagnostic variant only (profiles/tools/phase_trace.py): copy out the per-wave phase stamps of the last quadx_m0 launch

@@ -62,6 +62,10 @@ struct QuadK {
   int32_t use_yaw;               // quadx_waypoints_env.py:40
   float goal_angle;              // :42
   float act_lo[4], act_span[4];  // action box (quadx_base_env.py:80-102): low, high - low (pf_rollout's on-device sampling)
+  // "this lane cannot come within reach of the floor during this env step" (the calm test in the kernel): the env step's duration
+  // T, T (T + dt) / 2, 4 fmax / m x the largest factor the motor noise can put on thrust^2 over the step, the largest drag / m
+  float calm_T, calm_TT, calm_kt, calm_c;
+  int32_t calm_on;
 };
 
 // Fill QuadK from the ABI struct; returns false when the configuration needs the generic kernel.
@@ -134,6 +138,19 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   for (int k = 0; k < 4; ++k) { K.act_lo[k] = P.action_low[k]; K.act_span[k] = P.action_high[k] - P.action_low[k]; }
   K.mode = P.flight_mode;
   K.apw = P.agents_per_world > 1 ? P.agents_per_world : 1;
+  {
+    const int n_ticks = P.env_step_ratio * P.ticks_per_control;
+    K.calm_T = n_ticks * P.dt;
+    K.calm_TT = 0.5f * K.calm_T * (K.calm_T + P.dt);
+    // the motor state follows t' = (t + a (pwm - t)) s with pwm in [0.05, 1], 0 < a <= 1, s = 1 + xi m_noise: t' <= max(t, 1) s;
+    // |xi| < 6.7 for the Philox normals (Box-Muller on a 32-bit uniform: sqrt(-2 ln 2^-32) = 6.66)
+    const float smax = P.noise_mode == PF_NOISE_OFF ? 1.0f : 1.0f + 7.0f * __builtin_fabsf(P.motor_noise[0]);
+    K.calm_kt = 4.0f * K.fmaxM * powf(smax, 2.0f * n_ticks);
+    K.calm_c = fmaxf(fmaxf(__builtin_fabsf(K.dragM[0]), __builtin_fabsf(K.dragM[1])), __builtin_fabsf(K.dragM[2]));
+    // (injected noise is unbounded; mode -1 hands the action to the motors unclipped; a shared world has the pair stage in its tick)
+    K.calm_on = (P.contact_response && P.noise_mode != PF_NOISE_INJECT && P.flight_mode != -1 && K.apw == 1 && P.motor_dt_over_tau[0] <= 1.0f &&
+                 getenv("PF_NO_CALM_PATH") == nullptr) ? 1 : 0;
+  }
   K.use_yaw = (P.task == PF_TASK_WAYPOINTS && P.use_yaw_targets) ? 1 : 0;
   K.goal_angle = P.goal_reach_angle;
   // level spawn at rest, far enough above the floor that the settle free-fall cannot touch it
@@ -146,7 +163,7 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
 
 // Full 15-axis box test against the ground box, kept out of line: it runs only for waves that have
 // a lane within one bounding radius of the floor.
-__device__ __noinline__ bool quad_floor_contact(float px, float py, float pz, quat q, float hx, float hy, float hz,
+__device__ __noinline__ PF_RARE_TEXT bool quad_floor_contact(float px, float py, float pz, quat q, float hx, float hy, float hz,
                                                 float plane_xy, float plane_z) {
   m3 R = rot_from_quat(q);
   const float ha[3] = {hx, hy, hz};
@@ -156,6 +173,27 @@ __device__ __noinline__ bool quad_floor_contact(float px, float py, float pz, qu
 
 // Controller memories of the outer loops (flight modes 1-7, quadx.py:437-479): state groups 7-11, the generic QuadX layout
 // (uav_vehicles.hpp: QuadX::load / store).
+// The tick's flight-path constants in VECTOR registers, for the calm ticks of the kernels that carry the contact response. With
+// the solver's call in the kernel, the scalar register allocator parks some thirty of these constants in the lanes of a spill
+// VGPR and fetches each one back with a v_readlane in front of every use -- 32 extra instructions per tick, 0.6 us per env step
+// (profiles/README.md, r03). A uniform value held in a vector register costs the VALU instruction that reads it nothing.
+struct QuadKV {
+  float m_noise, m_a, ryfI[4], rxfI[4], tmaxI, pqI[3], gyI[3], dragM[3], fmaxM, bound_radius, plane_z, gravity_z, dt, vmax, half_dt;
+};
+PF_DEV float in_vgpr(float s) {
+  float v;
+  asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));  // (opaque to the compiler: it cannot fold the copy back into the scalar register)
+  return v;
+}
+PF_DEV QuadKV quadkv_from(const QuadK& K) {
+  QuadKV V;
+  V.m_noise = in_vgpr(K.m_noise); V.m_a = in_vgpr(K.m_a); V.tmaxI = in_vgpr(K.tmaxI); V.fmaxM = in_vgpr(K.fmaxM);
+  for (int i = 0; i < 4; ++i) { V.ryfI[i] = in_vgpr(K.ryfI[i]); V.rxfI[i] = in_vgpr(K.rxfI[i]); }
+  for (int i = 0; i < 3; ++i) { V.pqI[i] = in_vgpr(K.pqI[i]); V.gyI[i] = in_vgpr(K.gyI[i]); V.dragM[i] = in_vgpr(K.dragM[i]); }
+  V.bound_radius = in_vgpr(K.bound_radius); V.plane_z = in_vgpr(K.plane_z); V.gravity_z = in_vgpr(K.gravity_z);
+  V.dt = in_vgpr(K.dt); V.vmax = in_vgpr(K.vmax); V.half_dt = in_vgpr(K.half_dt);
+  return V;
+}
 struct QuadCasc {
   float I1[3], E1[3];                // ang_pos
   float I2[2], E2[2], I3[2], E3[2];  // lin_vel, lin_pos
@@ -317,8 +355,10 @@ struct QuadHot {
   // step that reports a floor contact, so the response can only alter that terminal observation; it is a template switch
   // because even its never-taken call site costs the hot loop (+0.6 us per env step at 65 536 lanes: one more divergent region
   // and its PHI copies per tick, profiles/r02), and with random actions some lane of nearly every wave is near the floor.
-  template <bool CR, bool SHARED = false>
-  PF_DEV void tick(const QuadK& K, float xi, const pf_params* Pfull) {
+  // K: the constants of the flight path (QuadK itself, in scalar registers -- or QuadKV, the same fields copied to vector
+  // registers for the calm ticks); Kc: the constants of the rare floor code, always the kernel argument.
+  template <bool CR, bool SHARED = false, class KT = QuadK, bool INL = false>
+  PF_DEV void tick(const KT& K, const QuadK& Kc, float xi, const pf_params* Pfull) {
     const float s = fmaf(xi, K.m_noise, 1.0f);
     float k[4];
     {  // motors.py:110-195, t = fma(a, pwm - thr, thr) * noise; motors (0, 1) and (2, 3) as packed pairs
@@ -353,10 +393,10 @@ struct QuadHot {
     float low = INFINITY;
     if (__any(near)) {
       if (near) {
-        const float hx = K.box_h[0], hy = K.box_h[1], hz = K.box_h[2];
-        const float pxy = K.plane_xy, pz = K.plane_z;
+        const float hx = Kc.box_h[0], hy = Kc.box_h[1], hz = Kc.box_h[2];
+        const float pxy = Kc.plane_xy, pz = K.plane_z;
         low = p.z - fmaf(__builtin_fabsf(R.m20), hx, fmaf(__builtin_fabsf(R.m21), hy, __builtin_fabsf(R.m22) * hz));
-        const bool inside = (__builtin_fabsf(p.x) + K.bound_radius0 < pxy) && (__builtin_fabsf(p.y) + K.bound_radius0 < pxy) && (low > -pz);
+        const bool inside = (__builtin_fabsf(p.x) + Kc.bound_radius0 < pxy) && (__builtin_fabsf(p.y) + Kc.bound_radius0 < pxy) && (low > -pz);
         contact_now = low <= 0.0f;
         if (!inside) contact_now = quad_floor_contact(p.x, p.y, p.z, q, hx, hy, hz, pxy, pz);
       }
@@ -398,15 +438,17 @@ struct QuadHot {
       if (near) {  // (low: the exact height of the lowest vertex, from the detection above)
         // (and no vertex is a contact unless the lowest one is within the margin; 1e-6: `low` and the solver's vertex heights
         //  are the same quantity rounded differently)
-        const float vlow = wvz.y - fsqrt(dot(w(), w())) * K.bound_radius0;
-        act = ((fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop)) && (low <= K.margin + 1e-6f);
+        const float vlow = wvz.y - fsqrt(dot(w(), w())) * Kc.bound_radius0;
+        act = ((fmaf(K.dt, vlow, low + Kc.slop) < 0.0f) || (low < -Kc.slop)) && (low <= Kc.margin + 1e-6f);
       }
       if (__any(act)) {
-        // (out of line: in the hover task a solve is rare -- a handful per 65 536-lane launch -- and inlined it costs every launch
-        //  0.8 us in register traffic: profiles/README.md, r03)
-        const ContactOut o = contact_solve_dev(Pfull, cws, act ? cws_floats : -1, p, q, v(), w());
+        // (INL: inline, in the instantiations sized for one wave per SIMD -- 512 registers: no call, so no stack, and a launch
+        //  whose waves carry scratch memory dispatches 0.4 us slower; nothing pinned to callee-saved registers. Otherwise out of
+        //  line: within the 256 registers of two waves per SIMD the inlined solve spills. profiles/README.md, r03)
+        const ContactOut o = INL ? contact_solve_inl(Pfull, cws, act ? cws_floats : -1, p, q, v(), w())
+                                 : contact_solve_dev(Pfull, cws, act ? cws_floats : -1, p, q, v(), w());
         set_wv(o.w, o.v);  // (unchanged for a lane that did not ask or has no contact vertex)
-        lift = K.c_erp * o.deepest;  // (already net of the slop)
+        lift = Kc.c_erp * o.deepest;  // (already net of the slop)
       }
     }
     if (SHARED) p = v3{fmaf(K.dt, wvx.y, p.x) + shift.x, fmaf(K.dt, wvy.y, p.y) + shift.y, fmaf(K.dt, wvz.y, p.z) + lift + shift.z};
@@ -463,6 +505,7 @@ PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const i
 #ifdef PF_PHASE_TRACE
 constexpr int kPhaseStamps = 13;
 __device__ unsigned long long g_phase_trace[4096 * kPhaseStamps];
+__device__ unsigned long long g_calm_trace[2];  // (waves that were not calm; [1] unused)
 #define PF_STAMP(i) do { if (ROLL == 0) { pf_ts[i] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define PF_STAMP(i) do { } while (0)
@@ -494,8 +537,11 @@ constexpr int kQuadWPB = PF_WPB;
 // MODES: false = flight mode 0 only; true = the flight mode is K.mode, -1 .. 7 (cascaded PIDs; their memories in state groups
 // 7-11 and, at reset, the z PIDs inside the settle recurrence).
 // SHARED (PF_TASK_MA_HOVER only): the K.apw agents of an env share one world (pose / contact exchange before every tick).
-template <int TASK, int NOISE, int LPW, int ROLL, bool CR, bool MODES = false, bool SHARED = false>
-__global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
+// WPS: the waves per SIMD the register budget is sized for. 2 (256 registers): every batch. 1 (512 registers, the contact solve
+// inlined: no stack): chosen by the launcher for batches of at most one wave per SIMD, where a second resident wave would have
+// nothing to run -- 11.6 -> 11.2 us per hover step at 65 536 lanes; at 524 288 lanes, 71 us against 57 us with two waves resident.
+template <int TASK, int NOISE, int LPW, int ROLL, bool CR, bool MODES = false, bool SHARED = false, int WPS = 2>
+__global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
                                                              const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
   constexpr bool ROLLOUT = ROLL != 0;
@@ -537,17 +583,15 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
   if (SHARED) { V.wpose_ = wpose; V.wvel_ = wvel_all + wid * 64 * kPairVelStride; V.rec_ = tile; V.wtid = tid; V.wA = apw; }
   QuadCasc C;  // (MODES only; dead otherwise)
   const pf_params_kptr Pk = uniform_params(Pfull);
-#ifndef PF_NO_PARAM_WARM
-  if (CR) {
-    // Warm the scalar cache with the four lines of the parameter block the contact solve reads (bytes 64 .. 319: contact model,
-    // mass properties, the collision box). In the hover task a solve is rare -- a handful of single-lane calls per 65 536-lane
-    // launch -- and the launch lasts as long as its slowest wave: cold, every dependent scalar load of that call went to L2.
-    // Issued here they ride along with the kernel-argument loads. (The wait is inside the statement: the compiler does not
-    // track loads issued by inline assembly.)
-    uint32_t w0, w1, w2, w3;
-    asm volatile("s_load_dword %0, %4, 0x40\n\ts_load_dword %1, %4, 0x80\n\ts_load_dword %2, %4, 0xc0\n\ts_load_dword %3, %4, 0x100\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(w0), "=s"(w1), "=s"(w2), "=s"(w3) : "s"(Pk) : "memory");
-  }
+  // (see the calm test below)
+  constexpr bool CALM = CR && !SHARED && !MODES && NOISE != PF_NOISE_INJECT;
+#ifdef PF_NO_KV  // (A/B switch: the calm ticks on the scalar constants)
+  const QuadK& KV = K;
+#define PF_KV_T QuadK
+#else
+  QuadKV KV{};
+  if (CALM) KV = quadkv_from(K);
+#define PF_KV_T QuadKV
 #endif
   float tgt[4][3];
   float new_dist, old_dist;
@@ -560,6 +604,21 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
     float4 gi = Sin[6 * N + li];
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li],
            g5 = Sin[5 * N + li];
+#ifndef PF_NO_CODE_WARM
+    if (CR && blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch(tid);  // (behind the state loads: one wait for both)
+#endif
+#ifndef PF_NO_PARAM_WARM
+  if (CR) {
+    // Warm the scalar cache with the four lines of the parameter block the contact solve reads (bytes 64 .. 319: contact model,
+    // mass properties, the collision box). In the hover task a solve is rare -- a handful of single-lane calls per 65 536-lane
+    // launch -- and the launch lasts as long as its slowest wave: cold, every dependent scalar load of that call went to L2.
+    // Issued behind the state loads, they share their wait. (The wait is inside the statement: the compiler does not
+    // track loads issued by inline assembly.)
+    uint32_t w0, w1, w2, w3;
+    asm volatile("s_load_dword %0, %4, 0x40\n\ts_load_dword %1, %4, 0x80\n\ts_load_dword %2, %4, 0xc0\n\ts_load_dword %3, %4, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(w0), "=s"(w1), "=s"(w2), "=s"(w3) : "s"(Pk) : "memory");
+  }
+#endif
     rng_ctr = (uint32_t)__float_as_int(gi.z);
     PF_STAMP(1);  // (the int group has arrived)
     if (NOISE == PF_NOISE_PHILOX) {
@@ -940,6 +999,27 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
     }
   }
   bool go = stepping && !(term || trunc);  // quadx_base_env.py:289-290
+  // Calm waves. The contact response's call site costs the tick loop about 0.2 us per tick even when it is never taken (the
+  // values that live across it are pinned to the callee-saved registers, one more divergent region per tick), and in the env
+  // tasks it almost never is: the drones fly at z = 1 and the few that sink to the floor are a handful per launch. A wave none of
+  // whose lanes can come within reach of the floor during this env step runs the ticks instantiated without the call -- the
+  // same arithmetic (no lane near: no solve, lift = 0), so the results are identical bit for bit. The bound: over the step's
+  // duration T the vertical acceleration is at most A = g + thrust + drag in magnitude, with thrust <= 4 fmax / m x (largest
+  // motor state^2, grown by the largest noise factor), drag <= c_max |v|^2 and |v| <= |v0| + (g + thrust) T (the drag only
+  // dissipates); the body sinks by at most |vz0| T + A T (T + dt) / 2 (semi-implicit Euler, the velocity clamp only shrinks).
+  // (instantiated where the env benchmarks live -- flight mode 0, noise drawn on device or off; in the cascaded-mode and
+  //  injected-noise instantiations the second copy of the ticks cost registers they do not have: stack spills)
+  bool calm = false;
+  if (CALM && K.calm_on) {
+    const float tm = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(V.t01.x), __builtin_fabsf(V.t01.y)), __builtin_fmaxf(__builtin_fabsf(V.t23.x), __builtin_fabsf(V.t23.y)));
+    const float a_nd = fmaf(K.calm_kt, __builtin_fmaxf(tm * tm, 1.0f), __builtin_fabsf(K.gravity_z));
+    const float u = fsqrt(fmaf(V.wvx.y, V.wvx.y, fmaf(V.wvy.y, V.wvy.y, V.wvz.y * V.wvz.y))) + a_nd * K.calm_T;
+    const float sink = fmaf(__builtin_fabsf(V.wvz.y), K.calm_T, fmaf(K.calm_c, u * u, a_nd) * K.calm_TT);
+    calm = __all(!go || (V.p.z - fmaf(sink, 1.01f, 1e-3f) > K.bound_radius));  // (wave-uniform; NaN compares false: not calm)
+#ifdef PF_PHASE_TRACE
+    if (!calm && tid == 0) atomicAdd(&g_calm_trace[0], 1ull);  // waves that keep the call site this step (rare: no contention)
+#endif
+  }
   for (int s = 0; s < K.env_step_ratio; ++s) {
     if (!__any(go)) break;
     if (go) {
@@ -954,13 +1034,16 @@ __global__ void __launch_bounds__(64 * kQuadWPB, 2) quadx_m0_env_kernel(const Qu
         // one world for the agents of an env: pose / contact exchange before every tick. Every lane of a world is in here
         // together: the PettingZoo task has no early exit from the inner loop and resets whole worlds.
         quad_world_exchange(V, wpose, tid, apw, K);
-        V.template tick<CR, true>(K, xi0, Pfull);
+        V.template tick<CR, true>(K, K, xi0, Pfull);
         quad_world_exchange(V, wpose, tid, apw, K);
-        V.template tick<CR, true>(K, xi1, Pfull);
+        V.template tick<CR, true>(K, K, xi1, Pfull);
         V.peer_contact = false;
+      } else if (CALM && __builtin_expect(calm, 1)) {
+        V.template tick<false, false, PF_KV_T>(KV, K, xi0, Pfull);
+        V.template tick<false, false, PF_KV_T>(KV, K, xi1, Pfull);
       } else {
-        V.template tick<CR>(K, xi0, Pfull);
-        V.template tick<CR>(K, xi1, Pfull);
+        V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi0, Pfull);
+        V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi1, Pfull);
       }
       // compute_state side effects + compute_term_trunc_reward
       if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:135-142; ||R^T d|| = ||d||

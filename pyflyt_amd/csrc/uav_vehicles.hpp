@@ -94,6 +94,28 @@ PF_DEV pf_params_kptr uniform_params(const pf_params* P) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
   return (pf_params_kptr)(((uintptr_t)hi << 32) | (uintptr_t)lo);
 }
+// Rarely executed out-of-line code (the contact solve, the exact floor tests): in an env launch a handful of single lanes call it,
+// each on its own CU, and the launch lasts as long as its slowest wave. One wave fetching 10 KB of instructions that are in no
+// cache pays for every line on its own -- measured: after anything that swept the L2s (a rollout, a policy network between two
+// env steps), +3 us per launch averaged over the next twenty launches, single launches at 2x. The functions live in one section
+// of the code object (the linker brackets it with __start_ / __stop_ symbols), and the first workgroups of every launch -- one
+// lands on each XCD, each XCD has its own L2 -- read the section once: the calls then miss the instruction cache into a warm L2.
+#define PF_RARE_TEXT __attribute__((section("pf_rare_text")))
+extern "C" __device__ const char __start_pf_rare_text[];
+extern "C" __device__ const char __stop_pf_rare_text[];
+constexpr int kRareTextPrefetchBlocks = 16;  // (workgroups go round the 8 XCDs; twice that, whatever XCD a dispatch starts on)
+PF_DEV void rare_text_prefetch(const int lane) {
+  const char* const a = __start_pf_rare_text;
+  const long n = (long)(__stop_pf_rare_text - a);
+  for (long base = 0; base < n; base += 2 * 64 * 128) {  // (uniform; one round covers 16 KB: two 128-byte lines per lane)
+    long o0 = base + lane * 128, o1 = o0 + 64 * 128;
+    o0 = o0 < n - 4 ? o0 : n - 4;
+    o1 = o1 < n - 4 ? o1 : n - 4;
+    uint32_t r0, r1;
+    // (the wait is inside the statement: the compiler does not track loads issued by inline assembly)
+    asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off\n\ts_waitcnt vmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a + o0), "v"(a + o1) : "memory");
+  }
+}
 // The per-body part of the solve that does not depend on where the contact vertices come from: records are appended with
 // add(), then sweeps() runs the projected Gauss-Seidel iteration. W4: this lane's LDS region.
 struct ContactSet {
@@ -407,7 +429,7 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
 #ifdef PF_SOLVE_INLINE
 #define PF_SOLVE_ATTR __device__ __forceinline__
 #else
-#define PF_SOLVE_ATTR __device__ __noinline__
+#define PF_SOLVE_ATTR __device__ __noinline__ PF_RARE_TEXT
 #endif
 // (the capacity is wave-uniform among the lanes that ask: the first of them carries it)
 PF_DEV int __reduce_max_cap(int ask) {

@@ -12,7 +12,7 @@ the other lanes read garbage later. Which kernels are hit changes with every edi
   python tools/isa_exec_check.py dev.s [...]            lint: prints every such site, exit status 1 if there is any
   python tools/isa_exec_check.py --fix dev.s -o out.s   repair: moves the copies to just behind the exec restore (where the
                                                         allocator meant them to run: for every lane that enters the block),
-                                                        refusing anything it cannot prove safe to move
+                                                        refusing anything that is not a register copy or a stack spill / reload, and any move it cannot prove safe
 
 The build (__graft_entry__.build) compiles the device code to assembly, repairs it with this, lints the result and only then
 assembles it; tests/test_isa_lint.py lints the disassembly of the shipped code object."""
@@ -24,6 +24,7 @@ OBJ_LABEL = re.compile(r"^[0-9a-f]+ <([^>]+)>:")
 WIDEN = re.compile(r"^(s_or_b64\s+exec,\s*exec,|s_or_saveexec_b64\s)")
 SCALAR_OK = ("v_writelane_b32", "v_readlane_b32", "v_readfirstlane_b32", "s_")
 MOVABLE = re.compile(r"^(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32|v_pk_mov_b32)\s")
+SPILL = re.compile(r"^scratch_(store|load)_(dword|dwordx2|dwordx3|dwordx4|short|byte|ubyte)\s+(off,\s*[va]\S+,\s*off|[va]\S+,\s*off,\s*off)")  # (stack slot at a constant offset)
 REG = re.compile(r"\b([vsa])(\d+)\b|\b([vsa])\[(\d+):(\d+)\]|\b(vcc|exec|scc|m0)(?:_lo|_hi)?\b")
 
 
@@ -103,18 +104,26 @@ def lint(path, lines):
 
 def fix(lines):
     """returns (new lines, report); raises if a flagged instruction is not a plain register copy or cannot be moved safely"""
-    moves, report = {}, []
+    moves, report, waits = {}, [], {}
     for func, label, idx, at in sites(lines):
         moved = set()
         for i in idx:
             ins = instruction(lines[i])
-            if not MOVABLE.match(ins):
-                raise RuntimeError(f"line {i + 1} ({func} {label}): `{ins}` sits before the exec restore and is not a plain register copy")
+            spill = bool(SPILL.match(ins))  # (a spill to / reload from the stack: the same misplacement, the lanes outside the mask lose the value)
+            if not (MOVABLE.match(ins) or spill):
+                raise RuntimeError(f"line {i + 1} ({func} {label}): `{ins}` sits before the exec restore and is neither a register copy nor a spill")
             mine = regs(ins)
             for j in range(i + 1, at + 1):
                 other = instruction(lines[j])
                 if other and j not in idx and (regs(other) & mine):
                     raise RuntimeError(f"line {i + 1} ({func} {label}): cannot move `{ins}` past `{other}`")
+                if other and spill and other.startswith("s_waitcnt") and "vmcnt" in other:
+                    # one memory operation fewer is in flight at this wait than the compiler counted: "at most N outstanding" must
+                    # become "at most N - 1" to keep guaranteeing the same older operations complete
+                    n = int(re.search(r"vmcnt\((\d+)\)", other).group(1))
+                    waits[j] = waits.get(j, n) - 1
+                    if waits[j] < 0:
+                        waits[j] = 0
             moved.add(i)
             report.append(f"{func} {label}: `{ins}` moved behind `{instruction(lines[at])}`")
         moves[at] = sorted(moved)
@@ -123,6 +132,8 @@ def fix(lines):
     for i, raw in enumerate(lines):
         if i in skip:
             continue
+        if i in waits:
+            raw = re.sub(r"vmcnt\(\d+\)", f"vmcnt({waits[i]})", raw)
         out.append(raw)
         for j in moves.get(i, ()):
             out.append(lines[j])

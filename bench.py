@@ -194,8 +194,8 @@ def main():
     for i, a in enumerate(ring):
         eng.sample_actions(a, i)
         if args.env == "ma_hover":  # small rate commands, thrust just above the hover value: everybody stays airborne
-            a[:, :3].mul_(0.1 / 3.14159265)
-            a[:, 3].mul_(0.005).add_(0.362)  # (around the hover throttle; the action box's thrust range is [0, 0.8])
+            a[:, :3].mul_(0.01 / 3.14159265)
+            a[:, 3].mul_(0.001).add_(0.3772)  # (the hover command, bisected with the oracle: 0.3770 holds z over 100 steps; +-0.001 drifts < 1 m over the run)
         if args.env == "dogfight" and args.dogfight_actions == "gentle":
             # uniform actions over the whole box fly every aircraft into the ground within seconds, and a world of wrecks at rest
             # on the floor (contact solve every tick for every lane) is not the regime a policy trains in: gentle commands

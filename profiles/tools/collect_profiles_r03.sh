@@ -47,7 +47,7 @@ timeout 100 python $R/profiles/tools/bench_ma_shared2.py 2>/dev/null | grep "us/
 # per-wave phase timeline and the solver's call statistics (the -DPF_PHASE_TRACE variant library)
 if [ -f $R/build/variants/libpf_trace.so ]; then
   for cr in 1 0; do PF_LIB_PATH=$R/build/variants/libpf_trace.so CR=$cr timeout 100 python $R/profiles/tools/phase_trace.py 2>/dev/null > $O/phase_trace_hover65536_cr$cr.txt; done
-  for w in landed hover; do WHAT=$w PF_LIB_PATH=$R/build/variants/libpf_trace.so timeout 100 python $R/profiles/tools/solver_trace.py 2>/dev/null; done > $O/solver_trace.txt
+  for w in landed hover rates calm; do WHAT=$w PF_LIB_PATH=$R/build/variants/libpf_trace.so timeout 150 python $R/profiles/tools/solver_trace.py 2>/dev/null; done > $O/solver_trace.txt
 fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O; ls $O

@@ -10,8 +10,8 @@ P = build_params(os.environ.get("VEH","quadx"), os.environ.get("TASK","hover"), 
                  world_options=(dict(contact_response=os.environ["CR"] == "1") if "CR" in os.environ else None), **kw)
 if "SETTLE" in os.environ: P.settle_steps = int(os.environ["SETTLE"])
 eng = BatchEngine(P, n)
-ring = [torch.empty(n,4,device="cuda") for _ in range(16)]
+ring = [torch.empty(n,4,device="cuda") for _ in range(100)]  # (a ring that repeats within an episode is a different action process: solver_trace.py WHAT=rates)
 for i,a in enumerate(ring): eng.sample_actions(a, i)
 eng.env_reset()
-for i in range(steps): eng.env_step(ring[i%16])
+for i in range(steps): eng.env_step(ring[i%100])
 torch.cuda.synchronize()

@@ -42,15 +42,15 @@ elif what == "hover":
     from pyflyt_amd.engine import BatchEngine
     n = 65536
     eng = BatchEngine(build_params("quadx", "hover", noise="philox", autoreset="next_step", seed=0), n, device="cuda:0")
-    ring = [torch.empty(n, 4, device="cuda:0") for _ in range(16)]
+    ring = [torch.empty(n, 4, device="cuda:0") for _ in range(100)]  # (not a short ring: WHAT=rates)
     for i, a in enumerate(ring):
         eng.sample_actions(a, i)
     eng.env_reset()
     for i in range(200):
-        eng.env_step(ring[i % 16])
+        eng.env_step(ring[i % 100])
     torch.cuda.synchronize(); read()
     for i in range(100):
-        eng.env_step(ring[i % 16])
+        eng.env_step(ring[i % 100])
     torch.cuda.synchronize()
     report("hover 65536 (per env step = 6 ticks, 1024 waves)", 100, read())
 elif what == "after_rollout":

@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
 #ifndef PF_NO_CODE_WARM
     if (CR && blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch(tid);  // (behind the state loads: one wait for both)
 #endif
-#ifndef PF_NO_PARAM_WARM
+#ifdef PF_PARAM_WARM  // (off: with the solve inlined or rare, the wait in front of the first state word cost every wave 0.5 us -- profiles/README.md, r03)
   if (CR) {
     // Warm the scalar cache with the four lines of the parameter block the contact solve reads (bytes 64 .. 319: contact model,
     // mass properties, the collision box). In the hover task a solve is rare -- a handful of single-lane calls per 65 536-lane

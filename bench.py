@@ -284,8 +284,7 @@ def main():
         ev1.record(stream)
         while not ev1.query():  # (poll first: a blocking synchronize sleeps on an interrupt, tens of microseconds on a 0.25 ms run)
             pass
-        stream.synchronize()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()  # (every stream of the device, the launch stream included)
         wall = time.perf_counter() - t0
         if solver_trace is not None:
             eng.lib.pf_debug_solver_trace(solver_trace)

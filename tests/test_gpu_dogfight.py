@@ -415,3 +415,30 @@ def test_facade_per_copy_reset_and_latched_done():
     env.reset(seed=4)
     assert torch.equal(env.engine.state[7:9], mem[0]) and torch.equal(env.engine.state[15], mem[1])
     env.close()
+
+
+def test_dead_aircraft_at_a_momentary_standstill_moves_on():
+    """`inactive` (dead, below 2 m, slower than 0.1 m/s: ma_fixedwing_dogfight_env.py:505-510) is recomputed on every update and
+    the reference keeps stepping the body in Bullet: a dead aircraft that passes through a standstill in mid-air -- the apex of a
+    bounce -- is not a wreck at rest. It must keep falling; only after it has sat on the ground, still, for kDfRestUpdates
+    consecutive updates does the device stop integrating it (DF_AT_REST = 8192)."""
+    eng, A = _engine(1, "inject", max_duration_seconds=3.0)
+    g = np.load(os.path.join(GOLD, "env_dogfight_crash.npz"))
+    _set_spawn(eng, g["start_pos"], g["start_orn"])
+    eng.env_reset(xi_reset=torch.zeros_like(torch.tensor(g["reset_xi"], dtype=torch.float32)).to("cuda:0").contiguous())
+    s = eng.state
+    s[0, 0, :3] = torch.tensor([0.0, 0.0, 1.5], device="cuda:0")   # 1.5 m up, level (spawn attitude), ...
+    s[2, 0, :] = 0.0; s[3, 0, :2] = 0.0                              # ... at a standstill
+    s[6, 0, 0] = 0.0                                                 # health 0: dead
+    fl = s[6, :, 3].view(torch.int32)
+    fl[0] = int(fl[0]) & ~1                                          # culled (not DF_ALIVE)
+    n_xi = g["xi"][0].shape[0]
+    ps = []
+    for k in range(12):
+        eng.env_step(torch.zeros(A, 4, device="cuda:0"), xi=torch.zeros(n_xi, A, device="cuda:0"))
+        f0 = int(eng.state[6, 0, 3].view(torch.int32))
+        ps.append(eng.state[0, 0, :3].cpu().numpy().copy())
+        assert not (f0 & 8192) or ps[-1][2] < 0.6, (k, f0, ps[-1])  # "at rest" only on the ground
+    ps = np.array(ps)
+    assert np.abs(ps[0] - np.array([0.0, 0.0, 1.5])).max() > 1e-3, ps[0]          # it moved in the very first step ...
+    assert (np.abs(np.diff(ps, axis=0)).max(axis=1) > 1e-4).all(), ps             # ... and in every step after it: not frozen

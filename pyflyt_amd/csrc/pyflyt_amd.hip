@@ -1075,9 +1075,35 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
   if (k_steps < 1) return fail(ctx, PF_ERR_ARG, "pf_rollout: k_steps must be >= 1");
   const pf_params& P = ctx->P;
   const bool fw = ctx->fast_fw && ctx->tmpl;
-  if (!fw && !ctx->fast)
-    return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: supported for the specialised kernels only (QuadX Hover / Waypoints / multi-agent Hover in any flight mode, Fixedwing-Waypoints)");
   if (P.noise_mode == PF_NOISE_INJECT) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: PF_NOISE_INJECT is a per-step protocol; use pf_env_step");
+  if (!fw && !ctx->fast) {
+    // Every other task (the generic env kernels: tilted multi-agent spawns, airframes outside the specialised envelopes; the
+    // dogfight): the same k_steps as k_steps x (pf_sample_actions + pf_env_step), enqueued back to back by this one call -- the
+    // PettingZoo loop of tests/test_pz_envs.py:71-93 without a host round trip per step. One launch (pair) per step, the state
+    // goes through HBM between them: the trajectory layout and the results of the state-resident form, not its speed.
+    if (P.task == PF_TASK_NONE) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: this context has no env task");
+    const int AD = (P.task == PF_TASK_DOGFIGHT && P.df_action_dim == 6) ? 6 : 4;
+    if (!b->actions && AD != 4) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: on-device sampling draws four-wide actions; pass the six-wide sequence in b->actions");
+    if (!b->actions && !b->actions_out) return fail(ctx, PF_ERR_ARG, "pf_rollout: outside the specialised kernels the sampled actions need b->actions_out to live in");
+    const size_t n = (size_t)ctx->n, D = (size_t)pf_obs_dim(ctx);
+    for (int st = 0; st < k_steps; ++st) {
+      pf_buffers bs = *b;
+      const size_t o = (size_t)st * n;
+      if (b->actions) bs.actions = b->actions + o * AD;
+      else {
+        int rc = pf_sample_actions(ctx, b->actions_out + o * 4, step_index0 + (uint32_t)st, stream);
+        if (rc) return rc;
+        bs.actions = b->actions_out + o * 4;
+      }
+      bs.actions_out = nullptr;
+      bs.obs = b->obs + o * D; bs.reward = b->reward + o; bs.terminated = b->terminated + o; bs.truncated = b->truncated + o;
+      if (b->final_obs) bs.final_obs = b->final_obs + o * D;
+      if (b->final_info) bs.final_info = b->final_info + 2 * o;
+      int rc = pf_env_step(ctx, &bs, stream);
+      if (rc) return rc;
+    }
+    return PF_OK;
+  }
   // (the PettingZoo task has no auto-reset: finished agents are culled by the caller, their drones fly on in the shared world)
   if (P.autoreset == PF_AUTORESET_OFF && P.task != PF_TASK_MA_HOVER)
     return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: needs an auto-reset mode (finished lanes would idle for the rest of the launch)");

@@ -171,8 +171,56 @@ def test_rollout_refusals():
     e.env_reset()
     with pytest.raises(PyFlytAmdError):
         e.rollout(4)  # no auto-reset mode
-    e = _engine("hover", 64, "philox", "next_step", 1, flight_mode=6, world_options=dict(contact_response=False))
-    assert e.lib.pf_ctx_is_specialised(e._ctx) == 0
-    e.env_reset()
+    e = _engine("hover", 64, "inject", "next_step", 1)
+    e.env_reset(xi_reset=torch.zeros(e.settle_ticks, 64, device="cuda:0"))
     with pytest.raises(PyFlytAmdError):
-        e.rollout(4)  # generic kernel configuration (a cascaded mode with the contact response opted out)
+        e.rollout(4)  # injected noise is a per-step protocol
+
+
+@pytest.mark.parametrize("given", [False, True])
+def test_rollout_outside_the_specialised_kernels(given):
+    """pf_rollout on a configuration only the generic env kernel runs (a cascaded flight mode with the contact response opted
+    out): one launch per step enqueued by the one call, the trajectory layout and the results of k x (pf_sample_actions +
+    pf_env_step), bit for bit."""
+    n, k = 200, 12
+    kw = dict(flight_mode=6, world_options=dict(contact_response=False), max_duration_seconds=0.2)
+    a, b = (_engine("hover", n, "philox", "next_step", 3, **kw) for _ in range(2))
+    assert a.lib.pf_ctx_is_specialised(a._ctx) == 0
+    a.env_reset(); b.env_reset()
+    seq = None
+    if given:
+        seq = torch.empty(k, n, 4, device="cuda:0")
+        for s in range(k):
+            a.sample_actions(seq[s], 100 + s)
+    obs, rew, term, trunc, acts = a.rollout(k, step_index0=100, actions=seq)
+    act = torch.empty(n, 4, device="cuda:0")
+    n_done = 0
+    for s in range(k):
+        b.sample_actions(act, 100 + s)
+        o, r, t, u = b.env_step(act)
+        assert torch.equal(acts[s], act) and torch.equal(obs[s], o) and torch.equal(rew[s], r), s
+        assert torch.equal(term[s], t) and torch.equal(trunc[s], u), s
+        n_done += int((t | u).sum())
+    assert torch.equal(a.state, b.state) and n_done > 0
+
+
+def test_rollout_dogfight():
+    """The PettingZoo loop of tests/test_pz_envs.py:71-93 in one call for the dogfight task: k env steps of every world, equal to
+    k x pf_env_step on the same sampled actions."""
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    def make():
+        P = build_params("fixedwing", "dogfight", noise="philox", autoreset="off", seed=5, angle_representation="euler",
+                         vehicle_options=dict(drone_model="acrowing"), world_options=dict(world_scale=5.0), dogfight=dict(sample_spawn=True))
+        e = BatchEngine(P, 4 * 50, device="cuda:0")
+        e.env_reset()
+        return e
+
+    a, b = make(), make()
+    k = 10
+    obs, rew, term, trunc, acts = a.rollout(k, step_index0=7)
+    for s in range(k):
+        o, r, t, u = b.env_step(acts[s].contiguous())
+        assert torch.equal(obs[s], o) and torch.equal(rew[s], r) and torch.equal(term[s], t) and torch.equal(trunc[s], u), s
+    assert torch.equal(a.state, b.state)

@@ -165,7 +165,7 @@ struct ContactSet {
     deepest = __builtin_fmaxf(deepest, depth);
     ++n;
   }
-  // one contact of one sweep; returns the OR of the three impulse deltas' bits (zero: nothing moved)
+  // one contact of one sweep; returns 0 when it was skipped as idle in every lane, 1 when it ran (wave-uniform)
   PF_DEV uint32_t row3(const pf_f4v r0, const pf_f4v r1, const pf_f4v r2, const pf_f4v r3, const pf_f4v r4, const float mu, lds_f4ptr lout) {
     const float un = fmaf(w.x, r0.y, fmaf(-w.y, r0.x, vc.z));
     // (a contact with no accumulated impulse whose normal velocity is not below its target stays at exactly zero: n0 = 0,
@@ -193,10 +193,10 @@ struct ContactSet {
     const float d2 = n2 - r4.z;
     vc.y = fmaf(inv_mass, d2, vc.y);
     w = v3{fmaf(d2, r3.x, w.x), fmaf(d2, r3.y, w.y), fmaf(d2, r3.z, w.z)};
-    *lout = pf_f4v{n0, n1, n2, 0.0f};
-    // (r4.w is the record's padding word, always zero: reading it HERE keeps its register out of the allocator's hands until the
-    //  row is done -- reused earlier, it made the row wait for the whole prefetch it belongs to)
-    return (__float_as_uint(d0) | __float_as_uint(d1) | __float_as_uint(d2) | __float_as_uint(r4.w)) & 0x7fffffffu;
+    // (r4.w is the record's padding word, always zero: written back HERE it keeps its register out of the allocator's hands until
+    //  the row is done -- reused earlier, it made the row wait for the whole prefetch it belongs to)
+    *lout = pf_f4v{n0, n1, n2, r4.w};
+    return 1u;  // (the row ran)
   }
   // Wave-uniform control flow: the contact counter and the sweep counter are scalars, a lane that is past its last contact reads
   // its sentinel record (zero impulse, target -FLT_MAX, zero effective masses: the row update is an exact no-op), and the solve
@@ -242,7 +242,10 @@ struct ContactSet {
 #ifdef PF_PHASE_TRACE
       sweeps_done = it + 1;
 #endif
-      if (!__any(chg != 0u)) break;  // a sweep that moved nothing: every further sweep would repeat it exactly
+      // a sweep in which every row of every lane was idle changed nothing, and every further sweep would repeat it exactly. (The
+      // finer test -- no impulse moved by a single bit -- cost three ORs per row and never fired: bodies at rest run all ten sweeps,
+      // the last digits keep flickering.)
+      if (chg == 0u) break;
     }
   }
   PF_DEV ContactOut finish(v3 v_in, v3 w_in) const {

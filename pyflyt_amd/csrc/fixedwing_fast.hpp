@@ -457,6 +457,9 @@ struct FwHot {
 #endif
     FwPairOut tw;  // (h-tail, main wing): evaluated together, accumulated as surfaces 2 and 4 around the v-tail
     float ry4;
+#ifdef PF_FW_PREFETCH  // (A/B: each table row requested one surface ahead of its use)
+    const FwSurf2 S1p = fw_load_surf2(&tk->pair[1]);
+#endif
     {  // ailerons
       const FwSurf2 S = fw_load_surf2(&tk->pair[0]);
       f2 a = f2{act[0], act[1]};
@@ -466,8 +469,15 @@ struct FwHot {
       accumulate(S.ry.y, o.fp.y, o.fn.y, o.ty.y, F, tau);
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef PF_FW_PREFETCH
+    const FwSurf Svp = fw_load_surf(&tk->vtail);
+#endif
     {  // horizontal tail + main wing
+#ifdef PF_FW_PREFETCH
+      const FwSurf2 S = S1p;
+#else
       const FwSurf2 S = fw_load_surf2(&tk->pair[1]);
+#endif
       f2 a = f2{act[2], act[4]};
       tw = surface_pair(S, a, f2{cmd[2], cmd[4]});
       act[2] = a.x; act[4] = a.y;
@@ -475,14 +485,23 @@ struct FwHot {
       ry4 = S.ry.y;
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef PF_FW_PREFETCH
+    const FwBody K = fw_load_body(&tk->body);
+#endif
     {  // vertical tail
+#ifdef PF_FW_PREFETCH
+      const FwSurf S = Svp;
+#else
       const FwSurf S = fw_load_surf(&tk->vtail);
+#endif
       act[3] = fmaf(S.dt_tau, cmd[3] - act[3], act[3]);
       surface<true>(S, act[3], F, tau);
     }
     accumulate(ry4, tw.fp.y, tw.fn.y, tw.ty.y, F, tau);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef PF_FW_PREFETCH
     const FwBody K = fw_load_body(&tk->body);
+#endif
     {  // motor (motors.py:110-195), at the base origin along +x
       float t = fmaf(K.m_a, cmd[5] - thr, thr);
       t = fmaf(xi * t, K.m_noise, t);

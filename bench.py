@@ -278,8 +278,8 @@ def main():
 
             solver_trace = (_C.c_ulonglong * 8)()
             eng.lib.pf_debug_solver_trace(solver_trace)  # (reads and clears)
+        ev0.record(stream)  # (in front of the wall clock: the event pair brackets a superset of the timed region)
         t0 = time.perf_counter()
-        ev0.record(stream)
         run(args.steps)
         ev1.record(stream)
         while not ev1.query():  # (poll first: a blocking synchronize sleeps on an interrupt, tens of microseconds on a 0.25 ms run)

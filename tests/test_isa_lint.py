@@ -41,6 +41,30 @@ _Z1kv:
             chk.fix(broken)
 
 
+def test_the_repair_moves_stack_spills_and_keeps_the_wait_counts_honest():
+    from tools import isa_exec_check as chk
+
+    asm = """
+_Z1kv:
+\ts_and_saveexec_b64 s[0:1], vcc
+\ts_cbranch_execz .LBB0_2
+\tv_add_f32_e32 v1, v2, v3
+.LBB0_2:
+\tscratch_store_dwordx2 off, v[80:81], off offset:28
+\ts_waitcnt vmcnt(3)
+\ts_or_b64 exec, exec, s[0:1]
+\ts_endpgm
+""".split("\n")
+    fixed, report = chk.fix(asm)
+    assert len(report) == 1 and not list(chk.sites(fixed))
+    i = fixed.index("\ts_or_b64 exec, exec, s[0:1]")
+    assert fixed[i + 1].strip() == "scratch_store_dwordx2 off, v[80:81], off offset:28"
+    assert "\ts_waitcnt vmcnt(2)" in fixed and "\ts_waitcnt vmcnt(3)" not in fixed  # one operation fewer in flight at that wait
+    # a spill addressed through a register (not a constant stack slot) is not something the repair understands
+    with pytest.raises(RuntimeError):
+        chk.fix([l.replace("off, v[80:81], off offset:28", "v5, v[80:81], off") for l in asm])
+
+
 def test_shipped_code_object_is_clean(tmp_path):
     from tools import isa_exec_check as chk
 

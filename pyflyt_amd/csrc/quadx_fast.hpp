@@ -143,8 +143,9 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
     K.calm_T = n_ticks * P.dt;
     K.calm_TT = 0.5f * K.calm_T * (K.calm_T + P.dt);
     // the motor state follows t' = (t + a (pwm - t)) s with pwm in [0.05, 1], 0 < a <= 1, s = 1 + xi m_noise: t' <= max(t, 1) s;
-    // |xi| < 6.7 for the Philox normals (Box-Muller on a 32-bit uniform: sqrt(-2 ln 2^-32) = 6.66)
-    const float smax = P.noise_mode == PF_NOISE_OFF ? 1.0f : 1.0f + 7.0f * __builtin_fabsf(P.motor_noise[0]);
+    // xi = num_motors + z (the reference's np_random.normal(*shape) quirk: mean 4), |z| <= 4.85 for the device's normals (Box-Muller
+    // with the radius from a 16-bit uniform: uav_device.hpp) -> |xi| < 9
+    const float smax = P.noise_mode == PF_NOISE_OFF ? 1.0f : 1.0f + 9.0f * __builtin_fabsf(P.motor_noise[0]);
     K.calm_kt = 4.0f * K.fmaxM * powf(smax, 2.0f * n_ticks);
     K.calm_c = fmaxf(fmaxf(__builtin_fabsf(K.dragM[0]), __builtin_fabsf(K.dragM[1])), __builtin_fabsf(K.dragM[2]));
     // (injected noise is unbounded; mode -1 hands the action to the motors unclipped; a shared world has the pair stage in its tick)

@@ -373,14 +373,19 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
   // asking lane fits with its airframe's worst-case region there is nothing to pack -- no count pass, rank x worst-case size.
   const int worst_sz = (src.worst() + 1) * kContactWords;
   const bool roomy = __popcll(__ballot(need)) * worst_sz <= cap_floats;  // (wave-uniform)
-  int n = PF_MAX_CONTACTS;
-  if (!roomy) {
+  // Many lanes ask and their worst case is large (landed aeroplanes: 4 of 48 collider vertices touch): instead of counting first,
+  // assume kOptimistic contacts each -- when all asking lanes fit with that -- and let the fill itself find the lanes that have
+  // more; they come back in the next round with their real count. (The count pass was a sixth of a landed aeroplane's solve.)
+  constexpr int kOptimistic = 8;
+  const bool optimistic = !roomy && src.worst() > kOptimistic && __popcll(__ballot(need)) * (kOptimistic + 1) * kContactWords <= cap_floats;
+  int n = roomy ? PF_MAX_CONTACTS : kOptimistic;
+  if (!roomy && !optimistic) {
     n = 0;
     if (need) src.for_each(p, R, [&](v3, float) { n += 1; });
     n = n > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : n;
     need = need && n > 0;
   }
-  const int sz = need ? (roomy ? worst_sz : (n + 1) * kContactWords) : 0;
+  int sz = need ? (roomy ? worst_sz : (n + 1) * kContactWords) : 0;
 #ifdef PF_PHASE_TRACE
   const unsigned long long pf_tc = __builtin_readcyclecounter();
 #endif
@@ -394,14 +399,20 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
       const unsigned long long pf_a = __builtin_readcyclecounter();
 #endif
       S.begin(ws + (incl - sz), R, com, inv_mass, v, w, i0, i1, i2, i3, i4, i5, src.slop(), src.inv_dt(), src.rest());
-      src.for_each(p, R, [&](v3 off, float z) { if (S.n < n) S.add(off, -z); });
+      int seen = 0;
+      src.for_each(p, R, [&](v3 off, float z) { if (S.n < n) S.add(off, -z); seen += 1; });
 #ifdef PF_PHASE_TRACE
       const unsigned long long pf_b = __builtin_readcyclecounter();
       pf_fill += pf_b - pf_a;
 #endif
-      S.sweeps(src.iters(), src.mu());
-      out = S.finish(v, w);
-      need = false;
+      if (optimistic && seen > n && n < PF_MAX_CONTACTS) {  // more contacts than assumed: once more, with the count the fill just took
+        n = seen > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : seen;
+        sz = (n + 1) * kContactWords;
+      } else {
+        S.sweeps(src.iters(), src.mu());
+        out = S.finish(v, w);
+        need = false;
+      }
 #ifdef PF_PHASE_TRACE
       pf_sweep += __builtin_readcyclecounter() - pf_b;
 #endif

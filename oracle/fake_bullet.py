@@ -144,6 +144,27 @@ class _Body:
                         out.append((l.joint_origin + l.rot @ (c + loc)) * self.scale)
         return out
 
+    def collider_vertices(self):
+        """The same vertices collider by collider: [(kind, link rotation, [body-frame vertex, ...]), ...], kind 0 box / 1 cylinder."""
+        out = []
+        c45 = [math.cos(j * math.pi / 4.0) for j in range(8)]
+        s45 = [math.sin(j * math.pi / 4.0) for j in range(8)]
+        for l in self.links:
+            for c, h in l.boxes:
+                vs = []
+                for i in range(8):
+                    loc = np.array([h[0] if i & 1 else -h[0], h[1] if i & 2 else -h[1], h[2] if i & 4 else -h[2]])
+                    vs.append((l.joint_origin + l.rot @ (c + loc)) * self.scale)
+                out.append((0, l.rot, vs))
+            for c, rad, hl in l.cyls:
+                vs = []
+                for e in (-1.0, 1.0):
+                    for j in range(8):
+                        loc = np.array([rad * c45[j], rad * s45[j], e * hl])
+                        vs.append((l.joint_origin + l.rot @ (c + loc)) * self.scale)
+                out.append((1, l.rot, vs))
+        return out
+
     def world_cyls(self):
         R = matrix_from_quat(self.q)
         out = []
@@ -266,8 +287,14 @@ class BulletClient:
         self.use_gyro_term = True
         # contact response against fixed bodies' top faces (the ground slab): see _solve_contacts
         self.contact_response = BulletClient.DEFAULT_CONTACT_RESPONSE
-        self.contact_restitution, self.contact_friction, self.contact_erp, self.contact_iters = 0.0, 0.5, 0.2, 10
-        self.contact_margin, self.contact_slop = 0.02, 0.001
+        # (the defaults and what each is believed to restate: oracle/uav_oracle.h, orc_world)
+        self.contact_restitution, self.contact_friction, self.contact_erp, self.contact_iters = 0.0, 0.5, 0.2, 50
+        self.contact_margin, self.contact_slop = 0.0, 1e-5
+        self.contact_report_distance = 0.0
+        self.contact_residual_threshold = 1e-7
+        self.contact_manifold_points = 4
+        self.contact_break_distance = 0.02  # points a body held after the previous tick persist up to this gap
+        self._persisted = set()  # ids of the free bodies that held contact points after the previous tick
         self.pair_response = True  # impulses between free bodies (oracle/uav_oracle.h: orc_world.pair_response)
 
     # ------------------------------------------------------------ no-ops
@@ -393,21 +420,38 @@ class BulletClient:
     def getContactPoints(self, *args, **kwargs):
         return list(self._contacts)
 
-    def _solve_contacts(self, b, I6, R):
+    def _reach(self, persisted, fresh):
+        """How far above a face a vertex may be and still count (as a constraint row: fresh = contact_margin; for the
+        report: fresh = contact_report_distance) -- a body that held contact points after the previous tick keeps them up to
+        the contact breaking distance."""
+        return self.contact_break_distance if persisted else fresh
+
+    def _solve_contacts(self, b, I6, R, persisted=False):
         """Contact response of free body `b` against the ground slab, the SAME named-parameter model as
         oracle/uav_oracle.c:contact_solve but formulated independently: impulses act on the base twist (body frame,
         [angular; linear] at the base ORIGIN) through the 6x6 spatial inertia the tick already assembled -- no centre of
         mass, no 3x3 inertia. Returns the deepest penetration."""
         slabs = [bx for f in self._bodies.values() if f.fixed for bx in f.world_boxes()]
+        margin = self._reach(persisted, self.contact_margin)
         pts = []
-        for rb in b.contact_vertices():
-            if len(pts) >= 48:  # the device code's PF_MAX_CONTACTS: vertices past it are ignored
-                break
-            x = b.p + R @ rb
-            for cb, Rb, hb in slabs:
-                if x[2] <= cb[2] + hb[2] + self.contact_margin and x[2] >= cb[2] - hb[2] and abs(x[0] - cb[0]) <= hb[0] and abs(x[1] - cb[1]) <= hb[1]:
-                    pts.append((rb, (cb[2] + hb[2]) - x[2]))
+        for kind, lrot, verts in b.collider_vertices():
+            cand = list(range(len(verts)))
+            if kind == 0 and self.contact_manifold_points < 8:
+                # manifold reduction: the four vertices of the box face that looks down the most (the incident face of a
+                # box-box face contact against the slab's top face); the first axis on a tie
+                zrow = (R @ lrot)[2]
+                a = int(np.argmax(np.abs(zrow)))
+                up = zrow[a] < 0.0  # the face on the +a side looks down when the axis itself points down
+                cand = [i for i in cand if bool(i & (1 << a)) == up]
+            for i in cand:
+                if len(pts) >= 48:  # the device code's PF_MAX_CONTACTS: vertices past it are ignored
                     break
+                rb = verts[i]
+                x = b.p + R @ rb
+                for cb, Rb, hb in slabs:
+                    if x[2] <= cb[2] + hb[2] + margin and x[2] >= cb[2] - hb[2] and abs(x[0] - cb[0]) <= hb[0] and abs(x[1] - cb[1]) <= hb[1]:
+                        pts.append((rb, (cb[2] + hb[2]) - x[2]))
+                        break
         if not pts:
             return 0.0
         I6inv = np.linalg.inv(I6)
@@ -417,6 +461,7 @@ class BulletClient:
         jac = [[np.concatenate([np.cross(rb, d), d]) for d in dirs] for rb, _ in pts]
         vn0 = [float(j[0] @ tw) for j in jac]
         for _ in range(self.contact_iters):
+            res2 = 0.0  # the sweep's largest squared row-velocity change (the solver's least-squares residual)
             for c in range(len(pts)):
                 for d in range(3):
                     j = jac[c][d]
@@ -436,6 +481,9 @@ class BulletClient:
                     dl = new - lam[c, d]
                     lam[c, d] = new
                     tw = tw + dl * resp
+                    res2 = max(res2, (dl * k) ** 2)
+            if res2 <= self.contact_residual_threshold:
+                break
         b.w = R @ tw[:3]
         b.v = R @ tw[3:]
         return max(0.0, max(d for _, d in pts) - self.contact_slop)
@@ -455,7 +503,8 @@ class BulletClient:
                 if ib == ia:
                     continue
                 B = self._bodies[ib]
-                if float((A.p - B.p) @ (A.p - B.p)) > (A.bound_radius() + B.bound_radius() + 2.0 * self.contact_margin) ** 2:
+                margin = self._reach(ia in self._persisted or ib in self._persisted, self.contact_margin)
+                if float((A.p - B.p) @ (A.p - B.p)) > (A.bound_radius() + B.bound_radius() + 2.0 * margin) ** 2:
                     continue
                 for ca, Ra, ha in A.world_boxes():
                     for cb, Rb, hb in B.world_boxes():
@@ -464,7 +513,7 @@ class BulletClient:
                             loc = Rb.T @ (x - cb)
                             pen = hb - np.abs(loc)
                             ks = int(np.argmin(pen))  # (the first axis on a tie)
-                            if pen[ks] < -self.contact_margin or len(pts) >= 16:
+                            if pen[ks] < -margin or len(pts) >= 16:
                                 continue
                             n = (1.0 if loc[ks] >= 0.0 else -1.0) * Rb[:, ks]
                             pts.append((ia, ib, x, n, float(pen[ks])))
@@ -506,6 +555,7 @@ class BulletClient:
         lam = np.zeros((len(rows), 3))
         mu = self.contact_friction * self.contact_friction
         for _ in range(self.contact_iters):
+            res2 = 0.0
             for c, (ia, ib, ja, jb, depth) in enumerate(rows):
                 for d in range(3):
                     ra, rb = inv[ia] @ ja[d], inv[ib] @ jb[d]
@@ -524,6 +574,9 @@ class BulletClient:
                     lam[c, d] = new
                     tw[ia] = tw[ia] + dl * ra
                     tw[ib] = tw[ib] - dl * rb
+                    res2 = max(res2, (dl * k) ** 2)
+            if res2 <= self.contact_residual_threshold:
+                break
         for bid in ids:
             b = self._bodies[bid]
             R = pre[bid][1]
@@ -546,6 +599,7 @@ class BulletClient:
     def stepSimulation(self):
         dt = self._dt
         # 1) collision detection at the pre-integration pose
+        self._persisted = {b for c in self._contacts for b in (c[1], c[2]) if not self._bodies[b].fixed}
         self._contacts = []
         ids = sorted(self._bodies)
         for ia in ids:
@@ -561,7 +615,8 @@ class BulletClient:
                     hit = False
                     for ca, Ra, ha in A.world_boxes():
                         for cb, Rb, hb in B.world_boxes():
-                            if _box_box_overlap(Rb.T @ (ca - cb), Rb.T @ Ra, ha, np.zeros(3), hb):
+                            rd = self._reach(ia in self._persisted or ib in self._persisted, self.contact_report_distance)
+                            if _box_box_overlap(Rb.T @ (ca - cb), Rb.T @ Ra, ha, np.zeros(3), hb + rd):
                                 hit = True
                     if hit:
                         self._contacts.append((0, ia, ib, -1, -1))
@@ -571,6 +626,7 @@ class BulletClient:
                 hit = False
                 for cb, Rb, hb in fixed.world_boxes():
                     assert np.allclose(Rb, np.eye(3))
+                    hb = hb + self._reach(idr in self._persisted, self.contact_report_distance)  # a contact is reported from this gap on
                     for ca, Ra, ha in free.world_boxes():
                         if _box_box_overlap(ca, Ra, ha, cb, hb):
                             hit = True
@@ -626,7 +682,7 @@ class BulletClient:
             if b.fixed:
                 continue
             I6, R = pre[bid]
-            deepest = self._solve_contacts(b, I6, R) if self.contact_response else 0.0
+            deepest = self._solve_contacts(b, I6, R, bid in self._persisted) if self.contact_response else 0.0
             b.p = b.p + dt * b.v
             b.p[2] += self.contact_erp * deepest
             if bid in shift:

@@ -29,6 +29,7 @@ class World(C.Structure):
         ("ticks_per_control", C.c_int),
         ("contact_response", C.c_int), ("contact_restitution", C.c_double), ("contact_friction", C.c_double),
         ("contact_erp", C.c_double), ("contact_iters", C.c_int), ("contact_margin", C.c_double), ("contact_slop", C.c_double), ("pair_response", C.c_int),
+        ("contact_report_distance", C.c_double), ("contact_residual_threshold", C.c_double), ("contact_manifold_points", C.c_int), ("contact_break_distance", C.c_double),
     ]
 
 

@@ -181,14 +181,19 @@ int orc_box_box_overlap(const double ca[3], const double Ra[3][3], const double 
   }
   return 1;
 }
-int orc_contact_plane(const orc_params* P, const double p[3], const double q[4]) {
+static int contact_plane_reach(const orc_params* P, const double p[3], const double q[4], double rd);
+int orc_contact_plane(const orc_params* P, const double p[3], const double q[4]) { /* a fresh pair (nothing persisting) */
+  return contact_plane_reach(P, p, q, P->world.contact_report_distance);
+}
+static int contact_plane_reach(const orc_params* P, const double p[3], const double q[4], const double rd) {
   /* ground = plane.urdf collision box (30,30,10)*world_scale centred at z=-5*world_scale,
-   * aviary.py:240-242. Cheap exact early-out on the bounding sphere. */
-  if (p[2] - P->bound_radius > 0.0) return 0;
+   * aviary.py:240-242. Cheap exact early-out on the bounding sphere.
+   * rd: a contact is reported from this gap on -- the 15-axis verdict against the slab enlarged by it */
+  if (p[2] - P->bound_radius > rd) return 0;
   double R[3][3];
   orc_matrix_from_quat(q, R);
   double cb[3] = {0.0, 0.0, -P->world.plane_half_z};
-  double hb[3] = {P->world.plane_half_xy, P->world.plane_half_xy, P->world.plane_half_z};
+  double hb[3] = {P->world.plane_half_xy + rd, P->world.plane_half_xy + rd, P->world.plane_half_z + rd};
   for (int k = 0; k < P->n_boxes; ++k) {
     double off[3], ca[3];
     matvec(R, P->boxes[k].c, off);
@@ -231,7 +236,12 @@ int orc_contact_plane(const orc_params* P, const double p[3], const double q[4])
  * the BASE ORIGIN in the base frame. State (p, v) is that of the base origin, as Bullet keeps it. */
 typedef struct { /* the composite body the tick integrates; constant for QuadX / Fixedwing, rebuilt per tick for the Rocket */
   double mass, com[3], I_own[3][3], I_pa[3][3], I_inv[3][3];
+  int persisted; /* the body had contact points after the previous tick: they persist up to the contact breaking distance */
 } orc_body;
+/* how far above a face a vertex may be and still be a contact point (a constraint row) this tick */
+static double contact_reach(const orc_world* W, int persisted) { return persisted ? W->contact_break_distance : W->contact_margin; }
+/* ... and from what gap on the pair is REPORTED (getContactPoints) */
+static double report_reach(const orc_world* W, int persisted) { return persisted ? W->contact_break_distance : W->contact_report_distance; }
 static void rigid_tick_body(const orc_params* PP, const orc_body* B, double p[3], double q[4], double v[3], double w[3],
                             const double F_b[3], const double tau_b[3]);
 void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], double w[3],
@@ -242,13 +252,18 @@ void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], 
   memcpy(B.I_own, P->I_own, sizeof(B.I_own));
   memcpy(B.I_pa, P->I_pa, sizeof(B.I_pa));
   memcpy(B.I_inv, P->I_inv, sizeof(B.I_inv));
+  B.persisted = 0;
   rigid_tick_body(P, &B, p, q, v, w, F_b, tau_b);
 }
 
 /* ---- contact response against the ground slab (see orc_world in the header for the model) ---- */
+static int contact_points_reach(const orc_params* P, const double p[3], const double q[4], double pts[][3], double depth[], double margin);
 int orc_contact_points(const orc_params* P, const double p[3], const double q[4], double pts[][3], double depth[]) {
+  return contact_points_reach(P, p, q, pts, depth, P->world.contact_margin);
+}
+static int contact_points_reach(const orc_params* P, const double p[3], const double q[4], double pts[][3], double depth[], const double margin) {
   int n = 0;
-  if (p[2] - P->bound_radius > P->world.contact_margin) return 0;
+  if (p[2] - P->bound_radius > margin) return 0;
   double R[3][3];
   orc_matrix_from_quat(q, R);
   const double hxy = P->world.plane_half_xy, hz2 = 2.0 * P->world.plane_half_z;
@@ -256,7 +271,18 @@ int orc_contact_points(const orc_params* P, const double p[3], const double q[4]
     const orc_box* b = &P->boxes[k];
     const double cy = cos(b->yaw), sy = sin(b->yaw);
     const int nv = b->kind == 1 ? 16 : 8;
+    /* manifold reduction (boxes, contact_manifold_points < 8): only the four vertices of the face that looks down the most --
+     * the incident face of a box-box face contact against the slab's top face [BULLET-FROM-MEMORY: dBoxBox2 clips the incident
+     * face and keeps at most four points]. Link axes in the world frame: the columns of R Rz(yaw); their z components: */
+    int face_axis = -1, face_up = 0;
+    if (b->kind == 0 && P->world.contact_manifold_points < 8) {
+      const double zr[3] = {R[2][0] * cy + R[2][1] * sy, -R[2][0] * sy + R[2][1] * cy, R[2][2]};
+      face_axis = 0;
+      for (int a = 1; a < 3; ++a) if (fabs(zr[a]) > fabs(zr[face_axis])) face_axis = a; /* the first axis on a tie */
+      face_up = zr[face_axis] < 0.0; /* the face on the + side of that axis looks down when the axis points down */
+    }
     for (int i = 0; i < nv; ++i) {
+      if (face_axis >= 0 && (((i >> face_axis) & 1) != face_up)) continue;
       double l[3];
       if (b->kind == 1) { /* end disc e = -1, +1; rim point j at j * 45 degrees from the link x axis */
         const int e = i >> 3, j = i & 7;
@@ -270,7 +296,7 @@ int orc_contact_points(const orc_params* P, const double p[3], const double q[4]
       double wpt[3];
       matvec(R, bl, wpt);
       wpt[0] += p[0]; wpt[1] += p[1]; wpt[2] += p[2];
-      if (n < ORC_MAX_CONTACTS && wpt[2] <= P->world.contact_margin && wpt[2] >= -hz2 && fabs(wpt[0]) <= hxy && fabs(wpt[1]) <= hxy) {
+      if (n < ORC_MAX_CONTACTS && wpt[2] <= margin && wpt[2] >= -hz2 && fabs(wpt[0]) <= hxy && fabs(wpt[1]) <= hxy) {
         memcpy(pts[n], wpt, sizeof(wpt));
         depth[n] = -wpt[2];
         ++n;
@@ -283,7 +309,7 @@ int orc_contact_points(const orc_params* P, const double p[3], const double q[4]
 static double contact_solve(const orc_params* PP, const orc_body* B, const double p[3], const double q[4], double v[3], double w[3]) {
   const orc_world* W = &PP->world;
   double pts[ORC_MAX_CONTACTS][3], depth[ORC_MAX_CONTACTS];
-  const int n = orc_contact_points(PP, p, q, pts, depth);
+  const int n = contact_points_reach(PP, p, q, pts, depth, contact_reach(W, B->persisted));
   if (n == 0) return 0.0;
   double R[3][3], Iw[3][3], tmp[3][3];
   orc_matrix_from_quat(q, R);
@@ -305,6 +331,7 @@ static double contact_solve(const orc_params* PP, const orc_body* B, const doubl
   }
   static const double dir[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}}; /* normal, friction x, friction y */
   for (int it = 0; it < W->contact_iters; ++it) {
+    double res2 = 0.0; /* the sweep's largest squared row-velocity change: btMultiBodyConstraintSolver's least-squares residual */
     for (int c = 0; c < n; ++c) {
       for (int d = 0; d < 3; ++d) {
         double rxd[3], ang[3], axr[3], u[3];
@@ -330,8 +357,10 @@ static double contact_solve(const orc_params* PP, const orc_body* B, const doubl
         dl = nl - lam[c][d];
         lam[c][d] = nl;
         for (int i = 0; i < 3; ++i) { vc[i] += im * dl * dir[d][i]; w[i] += dl * ang[i]; }
+        if ((dl * k) * (dl * k) > res2) res2 = (dl * k) * (dl * k);
       }
     }
+    if (res2 <= W->contact_residual_threshold) break;
   }
   cross3(w, cw, t);
   for (int i = 0; i < 3; ++i) v[i] = vc[i] - t[i];
@@ -611,7 +640,8 @@ static void world_defaults(orc_world* W) {
   W->gravity_z = -9.81;      /* aviary.py:226 */
   W->use_gyro_term = 1;      /* [BULLET-FROM-MEMORY] */
   W->max_coord_vel = 100.0;  /* [BULLET-FROM-MEMORY] */
-  W->contact_response = 1; W->contact_restitution = 0.0; W->contact_friction = 0.5; W->contact_erp = 0.2; W->contact_iters = 10; W->contact_margin = 0.02; W->contact_slop = 0.001; W->pair_response = 1; /* [BULLET-FROM-MEMORY] defaults */
+  W->contact_response = 1; W->contact_restitution = 0.0; W->contact_friction = 0.5; W->contact_erp = 0.2; W->contact_iters = 50; W->contact_margin = 0.0; W->contact_slop = 1e-5; W->pair_response = 1; /* [BULLET-FROM-MEMORY] defaults: see orc_world */
+  W->contact_report_distance = 0.0; W->contact_residual_threshold = 1e-7; W->contact_manifold_points = 4; W->contact_break_distance = 0.02;
   W->plane_half_xy = 15.0;   /* [BULLET-FROM-MEMORY] pybullet_data plane.urdf */
   W->plane_half_z = 5.0;
   W->ticks_per_control = 2;  /* 240/120, quadx.py:27-28 */
@@ -1173,10 +1203,13 @@ static void aviary_tick_pre(const orc_params* P, orc_lane* L, const double* xi, 
       for (int k = 0; k < 3; ++k) { F_b[k] += thrust[0][k]; T_b[k] += rxf[k] + torque[0][k]; }
     }
     /* stepSimulation: collision detection at the pre-integration pose, then the free-body tick's velocity half */
-    L->contact_now = orc_contact_plane(P, L->p, L->q) || L->peer_contact;
+    const int persisted = L->contact_now; /* contact points left by the previous stepSimulation */
+    L->contact_now = contact_plane_reach(P, L->p, L->q, report_reach(&P->world, persisted)) || L->peer_contact;
     if (P->vehicle == ORC_ROCKET) {
       *body = rocket_body;
+      body->persisted = persisted;
     } else {
+      body->persisted = persisted;
       body->mass = P->mass;
       memcpy(body->com, P->com, sizeof(body->com));
       memcpy(body->I_own, P->I_own, sizeof(body->I_own));
@@ -1202,7 +1235,9 @@ static void aviary_tick_one(const orc_params* P, orc_lane* L, const double* xi, 
 /* box k of drone a against box l of drone b: the 15-axis verdict with b's frame as the axis-aligned one */
 static int drones_overlap(const orc_params* Pa, const orc_lane* La, const orc_params* Pb, const orc_lane* Lb) {
   double d[3] = {La->p[0] - Lb->p[0], La->p[1] - Lb->p[1], La->p[2] - Lb->p[2]};
-  const double rr = Pa->bound_radius + Pb->bound_radius;
+  /* (contact_now: still the previous tick's here -- a pair one of whose bodies holds contact points is reported up to the breaking distance) */
+  const double rd = report_reach(&Pa->world, La->contact_now || Lb->contact_now);
+  const double rr = Pa->bound_radius + Pb->bound_radius + 1.7320508075688772 * rd; /* (the enlarged box's corner) */
   if (dot3(d, d) > rr * rr) return 0; /* bounding spheres apart */
   double Ra[3][3], Rb[3][3];
   orc_matrix_from_quat(La->q, Ra);
@@ -1217,7 +1252,8 @@ static int drones_overlap(const orc_params* Pa, const orc_lane* La, const orc_pa
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) { Rrel[i][j] = 0.0; for (int m = 0; m < 3; ++m) Rrel[i][j] += Rb[m][i] * Ra[m][j]; }
       const double zero[3] = {0.0, 0.0, 0.0};
-      if (orc_box_box_overlap(rel, Rrel, Pa->boxes[k].h, zero, Pb->boxes[l].h)) return 1;
+      const double hbr[3] = {Pb->boxes[l].h[0] + rd, Pb->boxes[l].h[1] + rd, Pb->boxes[l].h[2] + rd};
+      if (orc_box_box_overlap(rel, Rrel, Pa->boxes[k].h, zero, hbr)) return 1;
     }
   }
   return 0;
@@ -1245,7 +1281,7 @@ static int pair_contacts(const orc_params* const* Pl, orc_lane* const* Ll, const
       if (b == a) continue;
       const orc_params *Pa = Pl[a], *Pb = Pl[b];
       const orc_lane *La = Ll[a], *Lb = Ll[b];
-      const double margin = Pa->world.contact_margin;
+      const double margin = contact_reach(&Pa->world, B[a].persisted || B[b].persisted);
       double d[3] = {La->p[0] - Lb->p[0], La->p[1] - Lb->p[1], La->p[2] - Lb->p[2]};
       const double rr = Pa->bound_radius + Pb->bound_radius + 2.0 * margin; /* (pruning only: conservative) */
       if (dot3(d, d) > rr * rr) continue;
@@ -1319,6 +1355,7 @@ static void pair_stage(const orc_params* const* Pl, orc_lane* const* Ll, const o
   }
   const double mu = W->contact_friction * W->contact_friction;
   for (int it = 0; it < W->contact_iters; ++it) {
+    double res2 = 0.0;
     for (int c = 0; c < n; ++c) {
       const int a = pc[c].a, b = pc[c].b;
       const double ima = 1.0 / B[a].mass, imb = 1.0 / B[b].mass;
@@ -1348,8 +1385,10 @@ static void pair_stage(const orc_params* const* Pl, orc_lane* const* Ll, const o
           vc[a][i] += ima * dl * dir[i]; Ll[a]->w[i] += dl * anga[i];
           vc[b][i] -= imb * dl * dir[i]; Ll[b]->w[i] -= dl * angb[i];
         }
+        if ((dl * k) * (dl * k) > res2) res2 = (dl * k) * (dl * k);
       }
     }
+    if (res2 <= W->contact_residual_threshold) break;
   }
   for (int i = 0; i < A; ++i) {
     cross3(Ll[i]->w, cw[i], t);

@@ -77,6 +77,32 @@ typedef struct {
    * position update each body is translated by half of contact_erp x (its deepest pair penetration - slop) along that
    * contact's normal (a: +, b: -). */
   int pair_response;         /* 1: drone-drone impulses in shared worlds (default); 0: detection only */
+  /* ---- round 4: the doubtful Bullet facts of the contact model, each a named parameter with the best-known default
+   * ([BULLET-FROM-MEMORY] throughout; tests/golden/capture_pybullet.py prints getPhysicsEngineParameters() so that one run
+   * on a machine with PyBullet settles them) ----
+   * contact_report_distance: getContactPoints (aviary.py:523-525) lists a body pair from this gap on -- the 15-axis verdict
+   *   against the other box ENLARGED by it. Default 0: btBoxBoxDetector (dBoxBox2) returns no point as soon as one of its 15
+   *   axes separates the boxes, so a box-box pair is first reported when it touches. (A point that exists stays in the
+   *   persistent manifold until the gap exceeds the contact breaking threshold, 0.02 m: a RECEDING pair is reported a little
+   *   longer. Not modelled: the env tasks end the episode at the first report.)
+   * contact_margin (above): 0 by default for the same reason -- no constraint row exists before the boxes overlap.
+   * contact_manifold_points: at most this many points per collider box and slab (4: btPersistentManifold holds four, dBoxBox2
+   *   is called with maxc = 4): the vertices of the box face that looks down the most (the incident face). 8: every vertex.
+   * contact_iters: 50 = PyBullet's numSolverIterations default (Bullet's own default is 10).
+   * contact_residual_threshold: the sweeps stop once the largest squared change of a row's velocity in a sweep is at or below
+   *   it (btMultiBodyConstraintSolver::solveSingleIteration's leastSquaredResidual against m_leastSquaresResidualThreshold,
+   *   which PyBullet's server sets to 1e-7, i.e. 3.2e-4 m/s). 0: only an exactly idle sweep ends the solve early.
+   * contact_slop: 1e-5 = PyBullet's m_linearSlop (the allowed overlap; Bullet's own default is 0). */
+  double contact_report_distance;
+  double contact_residual_threshold;
+  int contact_manifold_points;
+  /* contact_break_distance: a body that held contact points after the previous tick keeps them while the gap stays under
+   * btPersistentManifold's contact breaking threshold (0.02 m): for such a body the vertices of the incident face up to this
+   * far above the face are contact points (rows "do not close more than the gap this tick") and the pair keeps being
+   * reported up to this gap. It is what lets a body REST: with points that exist only while they overlap, the two corners a
+   * resting box lifts by a micrometre leave the set and the box rattles. Restated per body (Bullet: per manifold point);
+   * between two drones: when either holds contact points. */
+  double contact_break_distance;
 } orc_world;
 #define ORC_MAX_PAIR_CONTACTS 16
 #define ORC_MAX_WORLD 8 /* drones per shared world (the device: agents_per_world <= 8) */

@@ -101,8 +101,10 @@ elif what == "rates":
     # or a ring of R draws per lane repeated -- the bench's graphs replay a ring
     from pyflyt_amd.engine import BatchEngine
     n = 65536
-    for R in (0, 16, 20, 100, 400):
-        eng = BatchEngine(build_params("quadx", "hover", noise="philox", autoreset="next_step", seed=0), n, device="cuda:0")
+    veh, task = os.environ.get("VEH", "quadx"), os.environ.get("TASK", "hover")
+    print(f"-- {veh} {task}, {n} lanes")
+    for R in [int(x) for x in os.environ.get("RINGS", "0,16,20,100,400").split(",")]:
+        eng = BatchEngine(build_params(veh, task, noise="philox", autoreset="next_step", seed=0), n, device="cuda:0")
         ring = [torch.empty(n, 4, device="cuda:0") for _ in range(max(R, 1))]
         for i, a in enumerate(ring):
             eng.sample_actions(a, i)
@@ -116,7 +118,9 @@ elif what == "rates":
                     eng.sample_actions(ring[0], 1000 + k)
                 eng.env_step(ring[k % R] if R else ring[0])
             torch.cuda.synchronize()
-            rates.append(read()[0] / 200.0)
+            t = read()
+            rates.append(t[0] / 200.0)
+        report(f"  last block, ring {R}", 200, t)
         print(f"action ring of {R or 'fresh draws every step'}: solver calls per launch over blocks of 200 steps: " + " ".join(f"{r:.2f}" for r in rates))
 elif what == "calm":
     # how many waves keep the contact response's call site in their tick loop (some lane within reach of the floor this env step)
@@ -127,6 +131,7 @@ elif what == "calm":
     for i, a in enumerate(ring):
         eng.sample_actions(a, i)
     eng.env_reset()
+    print(f"-- quadx {os.environ.get('TASK', 'hover')}")
     buf = (C.c_ulonglong * 2)()
     for blk in range(4):
         for i in range(100):

@@ -16,6 +16,7 @@ MOTOR_LAG = DT / 0.01          # dt / tau = 0.41667 (motors.py:131)
 TOTAL_THRUST = 2.0             # cf2x.yaml:2
 HOVER_THROTTLE_SQ = MASS * G / TOTAL_THRUST  # 0.132435
 VMAX = 100.0                   # btMultiBody::m_maxCoordinateVelocity
+CONTACT_SLOP = 1e-5            # the contact model's allowed overlap (PyBullet's m_linearSlop; pyflyt_amd/params.py: WORLD)
 
 
 def free_fall_z(z0, n):

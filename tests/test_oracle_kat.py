@@ -192,17 +192,18 @@ def _drop(model, pos, rpy, steps, mode=-1, vel=None, **kw):
 
 
 def test_contact_drop_comes_to_rest_at_half_height():
-    """A level quad dropped from 0.2 m with the motors off: no tunnelling (the speculative contacts stop the box at the
-    allowed overlap, contact_slop = 1 mm, never deeper), restitution 0 (no bounce), and it comes to rest with its
-    collision box (0.09 x 0.09 x 0.02, cf2x.urdf:30-36) ON the floor: z = half-height (0.01) minus the 1 mm overlap that
-    keeps the contact report true while it rests."""
-    SLOP = 0.001
+    """A level quad dropped from 0.2 m with the motors off. Contact points exist only once the box overlaps the slab
+    (contact_margin 0: no speculative rows), so the impact tick may carry it at most v_impact dt into the floor -- no
+    tunnelling --; restitution 0 (no bounce); the overlap is recovered at contact_erp per tick and it comes to rest with its
+    collision box (0.09 x 0.09 x 0.02, cf2x.urdf:30-36) ON the floor: z = half-height (0.01) minus the allowed overlap
+    (contact_slop, 1e-5) that keeps the contact report true while it rests."""
+    SLOP = kat.CONTACT_SLOP
     t = _drop("quadx", [0.0, 0.0, 0.2], [0.0, 0.0, 0.0], 240)
     z, vz = t[:, 2], t[:, 5]
     k0 = int(np.argmax(t[:, 12]))
     v_imp = np.sqrt(2 * kat.G * 0.19)
     assert abs(k0 * 2 * kat.DT - np.sqrt(2 * 0.19 / kat.G)) < 3 * kat.DT  # free fall until the box reaches the floor
-    assert z.min() > 0.01 - SLOP - 1e-6                       # no tunnelling: never deeper than the allowed overlap
+    assert z.min() > 0.01 - (v_imp + kat.G * kat.DT) * kat.DT     # no tunnelling: at most one tick of travel into the slab
     assert z[k0 + 2:].max() < 0.0101                          # restitution 0
     assert np.abs(z[-60:] - (0.01 - SLOP)).max() < 1e-6 and np.abs(vz[-60:]).max() < 1e-4  # at rest on the floor
     assert np.abs(t[-1, 6:12]).max() < 1e-4 and np.abs(t[-1, :2]).max() < 1e-4    # level drop: nothing sideways, no rotation
@@ -212,28 +213,28 @@ def test_contact_drop_comes_to_rest_at_half_height():
 def test_contact_friction_stops_a_slide():
     """Coulomb friction mu = 0.5: a quad put on the floor with 1 m/s sideways decelerates at mu g and stops after
     v^2 / (2 mu g) = 0.102 m (discrete impulses: within 10 %)."""
-    t = _drop("quadx", [0.0, 0.0, 0.0091], [0.0, 0.0, 0.0], 120, vel=[1.0, 0.0, 0.0])
+    t = _drop("quadx", [0.0, 0.0, 0.01 - kat.CONTACT_SLOP], [0.0, 0.0, 0.0], 120, vel=[1.0, 0.0, 0.0])
     x, vx = t[:, 0], t[:, 3]
     assert abs(x[-1] - 1.0 / (2 * 0.5 * kat.G)) < 0.1 * 0.102 and abs(vx[-1]) < 1e-4
     k_stop = int(np.argmax(np.abs(vx) < 1e-4))
     assert abs(k_stop * 2 * kat.DT - 1.0 / (0.5 * kat.G)) < 0.03
-    t0 = _drop("quadx", [0.0, 0.0, 0.0091], [0.0, 0.0, 0.0], 120, vel=[1.0, 0.0, 0.0], world_contact_friction=0.0)
+    t0 = _drop("quadx", [0.0, 0.0, 0.01 - kat.CONTACT_SLOP], [0.0, 0.0, 0.0], 120, vel=[1.0, 0.0, 0.0], world_contact_friction=0.0)
     # frictionless: keeps sliding, slowed only by the body drag 7.35e-4 v^2 / m (0.027 m/s^2 at 1 m/s, for 1 s)
     assert abs(t0[-1, 3] - (1.0 - 7.35e-4 / kat.MASS)) < 2e-3
 
 
 def test_contact_tilted_landing_rights_itself():
     t = _drop("quadx", [0.0, 0.0, 0.3], [0.5, -0.3, 1.0], 400)
-    assert abs(t[-1, 2] - 0.009) < 1e-5 and np.abs(t[-1, 9:11]).max() < 1e-4 and np.abs(t[-1, 6:9]).max() < 1e-3
+    assert abs(t[-1, 2] - (0.01 - kat.CONTACT_SLOP)) < 1e-5 and np.abs(t[-1, 9:11]).max() < 1e-4 and np.abs(t[-1, 6:9]).max() < 1e-3
 
 
 def test_rocket_settles_on_its_legs():
     """rocket.urdf:208-277: three leg boxes, bottoms 2.425 m under the base origin. Engine off, tank empty, dropped
     40 cm with a small tilt: it must end standing (z = 2.425, upright), not pass through the floor or topple."""
     t = _drop("rocket", [0.0, 0.0, 2.8], [0.03, -0.02, 0.4], 2400, mode=0, starting_fuel_ratio=0.0)
-    assert abs(t[-1, 2] - 2.424) < 1e-4 and np.abs(t[-1, 9:11]).max() < 1e-3  # (2.425 minus the 1 mm resting overlap)
+    assert abs(t[-1, 2] - (2.425 - kat.CONTACT_SLOP)) < 1e-4 and np.abs(t[-1, 9:11]).max() < 1e-3  # (2.425 minus the resting overlap)
     assert np.abs(t[-240:, 3:6]).max() < 1e-2 and np.abs(t[-240:, 6:9]).max() < 1e-2
-    assert t[:, 2].min() > 2.4239
+    assert t[:, 2].min() > 2.425 - 0.02  # (impact: at most a tick of travel into the slab)
 
 
 def test_contact_response_can_be_switched_off():

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 7
+#define PF_ABI_VERSION 8
 #define PF_MAX_TARGETS 8
 #define PF_MAX_BOXES 12
 #define PF_MAX_SURF 5
@@ -115,34 +115,46 @@ typedef struct pf_params {
   /* world / integrator: aviary.py:79,226 + Bullet defaults */
   float dt, gravity_z, max_coord_vel;
   float plane_half_xy, plane_half_z;
-  /* Contact RESPONSE against the ground slab -- what stepSimulation (core/aviary.py:516) does after collision
-   * detection. [BULLET-FROM-MEMORY], a named-parameter model (NOT btMultiBodyConstraintSolver digit for digit):
-   * contact points = the collider vertices (box corners; 8 rim points on either end disc of a cylinder) at or below the
-   * slab's top face at the pre-integration pose; contact_iters projected Gauss-Seidel sweeps over them in collider /
-   * vertex order at the velocity level (normal impulse >= 0 towards contact_restitution x approach speed, or towards
- * -gap / dt for a vertex still above the face; two
-   * world-axis friction directions clamped to contact_friction x normal impulse); after the position update a
-   * translation of contact_erp x deepest penetration along +z. 0 = detection only (bodies fall through the floor).
+  /* Contact RESPONSE -- what stepSimulation (core/aviary.py:516) does after collision detection. [BULLET-FROM-MEMORY]
+   * throughout: a named-parameter model (NOT btMultiBodyConstraintSolver digit for digit), every doubtful Bullet fact a field
+   * with the best-known default (pyflyt_amd/params.py: WORLD; the argument for each default: DESIGN.md section 3;
+   * tests/golden/capture_pybullet.py prints getPhysicsEngineParameters() so that one run where PyBullet exists settles them).
+   *  - Contact points against the ground slab, at the pre-integration pose: per collider BOX the four vertices of the face
+   *    that looks down the most (contact_manifold_points = 4: dBoxBox2 clips the incident face and is called with maxc = 4,
+   *    btPersistentManifold holds four points; 8 = every vertex), per cylinder 8 rim points on either end disc; a vertex is a
+   *    point when it is at most `reach` above the slab's top face (and over the slab), reach = contact_margin for a body
+   *    without contact points after the previous tick (0: dBoxBox2 returns nothing while an axis separates the boxes),
+   *    contact_break_distance for one that had some (btPersistentManifold keeps a point until the gap exceeds the contact
+   *    breaking threshold, 0.02 m -- what lets a body REST instead of rattling on the two corners it has not just lifted).
+   *  - Rows: normal impulse >= 0 towards contact_restitution x approach speed, or towards -(gap + slop) / dt for a point
+   *    still above face - slop ("do not close more than the gap this tick"); two world-axis friction rows clamped to
+   *    contact_friction x normal impulse. Projected Gauss-Seidel at the velocity level in collider / vertex order: at most
+   *    contact_iters sweeps (50 = PyBullet's numSolverIterations), ended early once the largest squared change of a row's
+   *    velocity within a sweep is <= contact_residual_threshold (1e-7 = PyBullet's solverResidualThreshold, i.e. 3.2e-4 m/s;
+   *    0: only an idle sweep ends it).
+   *  - After the position update a translation of contact_erp x (deepest penetration - contact_slop) along +z.
+   *  - contact_response = 0: detection only (bodies fall through the floor).
+   * Contact REPORT (getContactPoints, core/aviary.py:523-525): the 15-axis box-box verdict against the other box ENLARGED by
+   * contact_report_distance (0: reported from touching on) -- by contact_break_distance for a body that held contact points
+   * after the previous tick.
    * Shared worlds (agents_per_world > 1, the QuadX PettingZoo task): the same model BETWEEN the drones, one stage earlier in
    * the tick -- velocities after the forces -> pair stage -> ground solve per body -> integration. Pair contacts at the
    * pre-integration poses: for every ordered pair (a, b), a != b, in agent order, every box of a against every box of b, the
-   * 8 vertices of a's box in vertex order: a vertex within contact_margin of being inside b's box is a contact, its normal the
-   * face of b with the least penetration (first axis on a tie) pointing out of b, its depth that penetration; at most 16 per
-   * world and tick. Rows: the normal and Bullet's btPlaneSpace1 tangents on the relative point velocity; contact_iters sweeps
-   * in contact order, the ground rows' targets, friction clamp contact_friction^2 x normal impulse; after the position update
-   * each body moves half of contact_erp x (its deepest pair penetration - slop) along that normal (a: +, b: -).
+   * 8 vertices of a's box in vertex order: a vertex within `reach` of being inside b's box is a contact (reach as above, the
+   * breaking distance when either body held contact points), its normal the face of b with the least penetration (first axis
+   * on a tie) pointing out of b, its depth that penetration; at most 16 per world and tick. Rows: the normal and Bullet's
+   * btPlaneSpace1 tangents on the relative point velocity; the ground rows' targets, sweeps and residual exit, friction clamp
+   * contact_friction^2 x normal impulse; after the position update each body moves half of contact_erp x (its deepest pair
+   * penetration - slop) along that normal (a: +, b: -).
    * (pz_envs/quadx_envs/ma_quadx_base_env.py:365-369: a culled drone that lands on a live one.) */
   int32_t contact_response, contact_iters;
   float contact_restitution, contact_friction, contact_erp;
-  /* speculative margin: vertices up to this far ABOVE the face are in the contact set as well, with the constraint
-   * "do not close more than the gap in this tick" (normal velocity >= -gap / dt): binds only when the vertex would
-   * otherwise penetrate within the tick, and keeps a resting body's vertices in the active set (Bullet's contact
-   * breaking threshold, 0.02 m, plays this role) */
-  float contact_margin;
-  /* allowed penetration: the constraints let a vertex sink contact_slop below the face and the recovery only acts on what
-   * is deeper, so a body at rest overlaps the slab by exactly this much and its contact REPORT (penetration >= 0) stays
-   * true and stable instead of flickering at a zero gap */
-  float contact_slop;
+  float contact_margin;              /* fresh contact points: how far above the face (0) */
+  float contact_slop;                /* allowed overlap (1e-5 = PyBullet's m_linearSlop): what a resting body sinks in by */
+  float contact_report_distance;     /* fresh pairs are reported from this gap on (0) */
+  float contact_break_distance;      /* ... persisting ones up to this gap (0.02), and keep their points up to it */
+  float contact_residual_threshold;  /* squared row-velocity change that ends the sweeps (1e-7) */
+  int32_t contact_manifold_points;   /* 4: the incident face of a box; 8: every vertex */
   /* composite body */
   float inv_mass;
   float com[3];
@@ -178,8 +190,8 @@ typedef struct pf_params {
   /* PF_TASK_MA_HOVER: agents per SHARED world (pz_envs put every agent's drone in one Bullet world,
    * ma_quadx_base_env.py:206-241). 0 / 1 = every lane alone in its world. A > 1: lanes [w A, (w+1) A) are one world -- a hit
    * between two of its drones enters both contact arrays and ends both episodes (ma_quadx_hover_env.py:181), and a contact
-   * point anywhere in the world switches off every drone's rotational drag (quadx.py:509). Detection only between drones
-   * (box colliders; no drone-drone impulses). A must divide 64 and the lane count. */
+   * point anywhere in the world switches off every drone's rotational drag (quadx.py:509); the drones push each other (the
+   * pair stage above; box colliders). A must divide 64 and the lane count, and be at most 8. */
   int32_t agents_per_world;
   /* PF_TASK_DOGFIGHT (ma_fixedwing_dogfight_env.py:42-60): two teams of df_team_size aircraft in one shared world,
    * agents_per_world = 2 df_team_size <= 8 adjacent lanes, lanes [0, team) of a world one team, the rest the other.
@@ -191,7 +203,7 @@ typedef struct pf_params {
    * agents still in the episode (PettingZoo parallel API: finished agents are culled, their aircraft fly on with zero
    * commands, ma_fixedwing_base_env.py:289-330); pf_params.autoreset must be PF_AUTORESET_OFF. */
   /* Filled in by pf_ctx_create (callers leave it 0): the most contact points the contact solve can see for this airframe --
-   * its collider vertices (8 per box, 16 per cylinder), at most PF_MAX_CONTACTS. Sizes the solver's LDS regions, i.e. how many
+   * its collider vertices (contact_manifold_points per box, 16 per cylinder), at most PF_MAX_CONTACTS. Sizes the solver's LDS regions, i.e. how many
    * lanes of a wave can be solved side by side. */
   int32_t contact_max_points;
   /* df_freeze_wrecks (default 0 = the reference's behaviour: a crashed aircraft keeps tumbling in the physics until it comes

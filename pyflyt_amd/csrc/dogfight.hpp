@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
       if (!wreck) V.tick(P, nz.get(flat_base + t));
     }
     if (wreck) V.b.contact_step = V.b.contact_now;
-    if (P.df_freeze_wrecks && V.b.contact_step && V.b.p.z < P.bound_radius + P.contact_margin) {  // (opt-in) stops where it hits the ground
+    if (P.df_freeze_wrecks && V.b.contact_step && V.b.p.z < P.bound_radius + P.contact_break_distance) {  // (opt-in) stops where it hits the ground
       V.b.v = v3{0.f, 0.f, 0.f}; V.b.w = v3{0.f, 0.f, 0.f};
       V.b.derive();
       df |= DF_FROZEN;  // no further integration; update_states() finds it inactive (dead, low, at rest) one update later

@@ -104,7 +104,8 @@ inline bool fw_table_from_params(const pf_params& P, FwTable& T) {
   Bd.dt = P.dt; Bd.half_dt = 0.5f * P.dt; Bd.gravity_z = P.gravity_z; Bd.vmax = P.max_coord_vel; Bd.inv_mass = P.inv_mass;
   for (int k = 0; k < 6; ++k) { Bd.H[k] = P.I_pa[k] + (P.use_gyro_term ? P.I_own[k] : 0.f); Bd.iI[k] = P.I_inv[k]; }
   for (int k = 0; k < 3; ++k) Bd.com[k] = P.has_com_offset ? P.com[k] : 0.f;
-  Bd.bound_radius = P.bound_radius + (P.contact_response ? P.contact_margin : 0.0f);  // floor-code gate incl. the speculative contact margin
+  // floor-code gate: one bounding radius + the farthest a contact point or a report reaches
+  Bd.bound_radius = P.bound_radius + fmaxf(fmaxf(P.contact_margin, P.contact_break_distance), P.contact_report_distance);
   Bd.m_a = P.motor_dt_over_tau[0]; Bd.m_noise = P.motor_noise[0]; Bd.fmax = P.motor_fmax[0]; Bd.tmax = P.motor_tmax[0];
   Bd.slab_xy = P.plane_half_xy; Bd.slab_bottom = -2.0f * P.plane_half_z;
   for (int k = 0; k < 5; ++k) Bd.pad[k] = 0.f;
@@ -150,9 +151,13 @@ inline bool fwk_from_params(const pf_params& P, FwK& K, FwTable& T) {
 // (the parameter block through the scalar cache: inside an out-of-line function the plain pointer lives in VGPRs and its fields
 //  were flat loads at full memory latency, six boxes one after the other, in every tick of every wave that has a low flyer --
 //  the tail of the kernel's time in a population that is crashing; see uav_vehicles.hpp: uniform_params)
-__device__ __noinline__ PF_RARE_TEXT bool fw_floor_contact(float px, float py, float pz, m3 R, const pf_params* Pg) {
+// persisted: the body held contact points after the previous tick -- reported up to the breaking distance (pf_params.contact_break_distance),
+// a fresh pair from contact_report_distance on: the slab enlarged by that gap.
+__device__ __noinline__ PF_RARE_TEXT bool fw_floor_contact(float px, float py, float pz, m3 R, const pf_params* Pg, bool persisted) {
   const pf_params_kptr P = uniform_params(Pg);
-  const float hb[3] = {P->plane_half_xy, P->plane_half_xy, P->plane_half_z};
+  const float rd_kept = P->contact_break_distance, rd_fresh = P->contact_report_distance;
+  const float rd = persisted ? rd_kept : rd_fresh;
+  const float hb[3] = {P->plane_half_xy + rd, P->plane_half_xy + rd, P->plane_half_z + rd};
   const v3 cb{0.0f, 0.0f, -P->plane_half_z};
   bool hit = false;
   const int nb = P->n_boxes;
@@ -516,9 +521,10 @@ struct FwHot {
     //  and the six 15-axis box tests per tick for such lanes were ~20 % of this kernel's instructions)
     const bool near = ((p.z - K.bound_radius) <= 0.0f) && ((p.z + K.bound_radius) >= K.slab_bottom) &&
                       (__builtin_fabsf(p.x) - K.bound_radius <= K.slab_xy) && (__builtin_fabsf(p.y) - K.bound_radius <= K.slab_xy);
+    const bool persisted = contact_now;  // contact points left by the previous tick persist up to the breaking distance
     contact_now = false;
     if (__any(near)) {
-      if (near) contact_now = fw_floor_contact(p.x, p.y, p.z, R, Pfull);
+      if (near) contact_now = fw_floor_contact(p.x, p.y, p.z, R, Pfull, persisted);
     }
     contact_now = contact_now || peer_contact;
     // free-base multibody tick, composite of point masses: COM offset, full symmetric inertia
@@ -538,10 +544,10 @@ struct FwHot {
     if (near) {
       const float r0 = Pfull->bound_radius, slop = Pfull->contact_slop;
       const float low = p.z - r0, vlow = v.z - fsqrt(dot(w, w)) * r0;
-      act = ((fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop)) && (low <= Pfull->contact_margin);  // (no vertex can be within the margin otherwise)
+      act = ((fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop)) && (low <= (persisted ? Pfull->contact_break_distance : Pfull->contact_margin));  // (no vertex can be within reach otherwise)
     }
     if (__any(act)) {
-      const ContactOut o = contact_solve_dev(Pfull, cws, (act && Pfull->contact_response) ? cws_floats : -1, p, q, v, w);
+      const ContactOut o = contact_solve_dev(Pfull, cws, need_cap_of(act && Pfull->contact_response, cws_floats, persisted), p, q, v, w);
       v = o.v; w = o.w;  // (unchanged for a lane that did not ask or has no contact vertex)
       lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
     }

@@ -28,9 +28,10 @@ constexpr int kWave = 64;
 constexpr int kMaxObs = 40;  // 13 + 4 + 6 + 3*4 = 35 (Fixedwing), 13 + 4 + 4 + 4*4 = 37 (QuadX with yaw targets)
 
 enum { OP_STEP = 0, OP_RESET = 1 };
-// Aviary-level kernels (where bodies land and stay landed): 40 KB of LDS for the contact solve -- every lane of a wave of
-// quadrotors (8 collider vertices x 20 floats) in one round, ten worst-case airframes (48 vertices) side by side
-constexpr int kAviaryContactFloats = 64 * 9 * kContactWords;
+// Aviary-level kernels (where bodies land and stay landed): 30 KB of LDS for the contact solve -- every lane of a wave of
+// quadrotors (the incident face's 4 vertices + the sentinel, 24 floats each) in one round, six worst-case airframes (48
+// vertices) side by side
+constexpr int kAviaryContactFloats = 64 * 5 * kContactWords;
 
 // ------------------------------------------------------------------ per-task side block
 // 12 floats per lane in state groups G_TGT..G_TGT+2:
@@ -852,6 +853,8 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
       return fail(nullptr, PF_ERR_UNSUPPORTED, "agents_per_world > 1 (a shared world) exists for the PettingZoo tasks only (QuadX hover, fixedwing dogfight)");
     if ((P.task != PF_TASK_DOGFIGHT && 64 % P.agents_per_world != 0) || n_lanes % P.agents_per_world != 0)
       return fail(nullptr, PF_ERR_ARG, "agents_per_world must divide 64 (the lanes of a world share a wavefront) and the lane count");
+    // (the pair stage keeps one deepest-contact slot per agent of a world in registers: shared_world.hpp, pair_stage_dev)
+    if (P.agents_per_world > 8) return fail(nullptr, PF_ERR_UNSUPPORTED, "a shared world holds at most 8 agents (ORC_MAX_WORLD in the oracle)");
     for (int k = 0; k < P.n_boxes; ++k)
       if (P.boxes[k].kind != 0 || P.boxes[k].yaw != 0.0f)
         return fail(nullptr, PF_ERR_UNSUPPORTED, "shared worlds test plain box colliders against each other (cf2x); this airframe has cylinders / yawed boxes");
@@ -869,7 +872,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
   {  // the airframe's worst-case contact count (collider vertices), see pf_params.contact_max_points
     int pts = 0;
-    for (int k = 0; k < P.n_boxes; ++k) pts += P.boxes[k].kind == 1 ? 16 : 8;
+    for (int k = 0; k < P.n_boxes; ++k) pts += P.boxes[k].kind == 1 ? 16 : (P.contact_manifold_points >= 8 ? 8 : 4);
     c->P.contact_max_points = pts < 1 ? 1 : (pts > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : pts);
   }
   c->P_dev = nullptr; c->tmpl = nullptr; c->surf_dev = nullptr;

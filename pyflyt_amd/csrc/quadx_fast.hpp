@@ -32,7 +32,8 @@ struct QuadK {
   float use_gyro;              // 1.0 / 0.0
   float bound_radius;          // gate of the out-of-line floor code (incl. the speculative contact margin)
   float bound_radius0, slop;   // the bare bounding radius and the allowed overlap: "can a contact constraint act this tick?"
-  float margin;                // the speculative contact margin: no vertex above it is a contact
+  float margin;                // fresh contact points: no vertex above it is one (pf_params.contact_margin)
+  float brk, rd;               // persisting points / reports reach up to brk (contact_break_distance); fresh reports from rd on (contact_report_distance)
   float c_inv_dt, c_rest, c_mu, c_erp;  // the rest of the contact model (pf_params.contact_*): the solve runs inline on these
   int32_t c_iters;
   float box_h[3], plane_xy, plane_z;  // the collision box's half extents and the slab's: kernel-argument SGPRs, because with random
@@ -62,9 +63,10 @@ struct QuadK {
   int32_t use_yaw;               // quadx_waypoints_env.py:40
   float goal_angle;              // :42
   float act_lo[4], act_span[4];  // action box (quadx_base_env.py:80-102): low, high - low (pf_rollout's on-device sampling)
-  // "this lane cannot come within reach of the floor during this env step" (the calm test in the kernel): the env step's duration
-  // T, T (T + dt) / 2, 4 fmax / m x the largest factor the motor noise can put on thrust^2 over the step, the largest drag / m
-  float calm_T, calm_TT, calm_kt, calm_c;
+  // "this lane cannot come within reach of the floor during this env step / this Aviary step" (the calm tests in the kernel): the
+  // horizon T and T (T + dt) / 2 for the env step and for one Aviary step, 4 fmax / m, the square of the bound t* the motor state
+  // cannot grow beyond once it is below it, the largest drag / m
+  float calm_T, calm_TT, calm_T2, calm_TT2, calm_kt, calm_t2, calm_c;
   int32_t calm_on;
 };
 
@@ -106,9 +108,10 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.I[0] = P.I_own[0]; K.I[1] = P.I_own[3]; K.I[2] = P.I_own[5];
   K.iI[0] = P.I_inv[0]; K.iI[1] = P.I_inv[3]; K.iI[2] = P.I_inv[5];
   K.use_gyro = P.use_gyro_term ? 1.f : 0.f;
-  // gate of the out-of-line floor code: within one bounding radius of the floor, widened by the speculative contact margin
-  K.bound_radius = P.bound_radius + (P.contact_response ? P.contact_margin : 0.0f);
+  // gate of the floor code: within one bounding radius of the floor, widened by the farthest a contact point or report reaches
+  K.bound_radius = P.bound_radius + fmaxf(fmaxf(P.contact_margin, P.contact_break_distance), P.contact_report_distance);
   K.bound_radius0 = P.bound_radius; K.slop = P.contact_slop; K.margin = P.contact_margin;
+  K.brk = P.contact_break_distance; K.rd = P.contact_report_distance;
   K.c_inv_dt = 1.0f / P.dt; K.c_rest = P.contact_restitution; K.c_mu = P.contact_friction; K.c_erp = P.contact_erp; K.c_iters = P.contact_iters;
   for (int k = 0; k < 3; ++k) K.box_h[k] = P.boxes[0].h[k];
   K.plane_xy = P.plane_half_xy; K.plane_z = P.plane_half_z;
@@ -142,15 +145,22 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
     const int n_ticks = P.env_step_ratio * P.ticks_per_control;
     K.calm_T = n_ticks * P.dt;
     K.calm_TT = 0.5f * K.calm_T * (K.calm_T + P.dt);
-    // the motor state follows t' = (t + a (pwm - t)) s with pwm in [0.05, 1], 0 < a <= 1, s = 1 + xi m_noise: t' <= max(t, 1) s;
-    // xi = num_motors + z (the reference's np_random.normal(*shape) quirk: mean 4), |z| <= 4.85 for the device's normals (Box-Muller
-    // with the radius from a 16-bit uniform: uav_device.hpp) -> |xi| < 9
+    K.calm_T2 = P.ticks_per_control * P.dt;
+    K.calm_TT2 = 0.5f * K.calm_T2 * (K.calm_T2 + P.dt);
+    // the motor state follows t' = ((1 - a) t + a pwm) s with pwm in [0.05, 1], 0 < a <= 1, s = 1 + xi m_noise <= smax:
+    // t' <= f(t) = ((1 - a) t + a) smax, an increasing contraction when (1 - a) smax < 1, with fixed point
+    // t* = a smax / (1 - (1 - a) smax): t <= M and M >= t* give f(t) <= M, so the state never exceeds max(t_now, t*) however
+    // many ticks follow. xi = num_motors + z (the reference's np_random.normal(*shape) quirk: mean 4), |z| <= 4.85 for the
+    // device's normals (Box-Muller with the radius from a 16-bit uniform: uav_device.hpp) -> |xi| < 9
     const float smax = P.noise_mode == PF_NOISE_OFF ? 1.0f : 1.0f + 9.0f * __builtin_fabsf(P.motor_noise[0]);
-    K.calm_kt = 4.0f * K.fmaxM * powf(smax, 2.0f * n_ticks);
+    const float am = P.motor_dt_over_tau[0], contr = (1.0f - am) * smax;
+    const float tstar = contr < 1.0f ? am * smax / (1.0f - contr) : INFINITY;
+    K.calm_kt = 4.0f * K.fmaxM;
+    K.calm_t2 = fmaxf(tstar * tstar, 1.0f);
     K.calm_c = fmaxf(fmaxf(__builtin_fabsf(K.dragM[0]), __builtin_fabsf(K.dragM[1])), __builtin_fabsf(K.dragM[2]));
     // (injected noise is unbounded; mode -1 hands the action to the motors unclipped; a shared world has the pair stage in its tick)
     K.calm_on = (P.contact_response && P.noise_mode != PF_NOISE_INJECT && P.flight_mode != -1 && K.apw == 1 && P.motor_dt_over_tau[0] <= 1.0f &&
-                 getenv("PF_NO_CALM_PATH") == nullptr) ? 1 : 0;
+                 K.calm_t2 < 1e6f && getenv("PF_NO_CALM_PATH") == nullptr) ? 1 : 0;
   }
   K.use_yaw = (P.task == PF_TASK_WAYPOINTS && P.use_yaw_targets) ? 1 : 0;
   K.goal_angle = P.goal_reach_angle;
@@ -165,10 +175,10 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
 // Full 15-axis box test against the ground box, kept out of line: it runs only for waves that have
 // a lane within one bounding radius of the floor.
 __device__ __noinline__ PF_RARE_TEXT bool quad_floor_contact(float px, float py, float pz, quat q, float hx, float hy, float hz,
-                                                float plane_xy, float plane_z) {
+                                                float plane_xy, float plane_z, float rd) {
   m3 R = rot_from_quat(q);
   const float ha[3] = {hx, hy, hz};
-  const float hb[3] = {plane_xy, plane_xy, plane_z};
+  const float hb[3] = {plane_xy + rd, plane_xy + rd, plane_z + rd};  // (reported from the gap rd on: the slab enlarged by it)
   return box_overlaps_aabb(v3{px, py, pz}, R, ha, v3{0.f, 0.f, -plane_z}, hb);
 }
 
@@ -390,6 +400,7 @@ struct QuadHot {
     // locally a half-space; the direct form also avoids the cancellation of (p.z + 5) - (5 + ext) in fp32). The out-of-line
     // 15-axis test runs only within one bounding radius of the rim.
     bool near = ((p.z - K.bound_radius) <= 0.0f) && ((p.z + K.bound_radius) >= -2.0f * K.plane_z);  // (not once it has fallen through, contact_response off)
+    const bool persisted = contact_now;  // contact points left by the previous tick persist up to the breaking distance
     contact_now = false;
     float low = INFINITY;
     if (__any(near)) {
@@ -398,8 +409,9 @@ struct QuadHot {
         const float pxy = Kc.plane_xy, pz = K.plane_z;
         low = p.z - fmaf(__builtin_fabsf(R.m20), hx, fmaf(__builtin_fabsf(R.m21), hy, __builtin_fabsf(R.m22) * hz));
         const bool inside = (__builtin_fabsf(p.x) + Kc.bound_radius0 < pxy) && (__builtin_fabsf(p.y) + Kc.bound_radius0 < pxy) && (low > -pz);
-        contact_now = low <= 0.0f;
-        if (!inside) contact_now = quad_floor_contact(p.x, p.y, p.z, q, hx, hy, hz, pxy, pz);
+        const float rdx = persisted ? Kc.brk : Kc.rd;
+        contact_now = low <= rdx;
+        if (!inside) contact_now = quad_floor_contact(p.x, p.y, p.z, q, hx, hy, hz, pxy, pz, rdx);
       }
     }
     if (SHARED) contact_now = contact_now || peer_contact;  // drone-drone hits enter contact_array[drone.Id] too (aviary.py:523-525)
@@ -440,14 +452,14 @@ struct QuadHot {
         // (and no vertex is a contact unless the lowest one is within the margin; 1e-6: `low` and the solver's vertex heights
         //  are the same quantity rounded differently)
         const float vlow = wvz.y - fsqrt(dot(w(), w())) * Kc.bound_radius0;
-        act = ((fmaf(K.dt, vlow, low + Kc.slop) < 0.0f) || (low < -Kc.slop)) && (low <= Kc.margin + 1e-6f);
+        act = ((fmaf(K.dt, vlow, low + Kc.slop) < 0.0f) || (low < -Kc.slop)) && (low <= (persisted ? Kc.brk : Kc.margin) + 1e-6f);
       }
       if (__any(act)) {
         // (INL: inline, in the instantiations sized for one wave per SIMD -- 512 registers: no call, so no stack, and a launch
         //  whose waves carry scratch memory dispatches 0.4 us slower; nothing pinned to callee-saved registers. Otherwise out of
         //  line: within the 256 registers of two waves per SIMD the inlined solve spills. profiles/README.md, r03)
-        const ContactOut o = INL ? contact_solve_inl(Pfull, cws, act ? cws_floats : -1, p, q, v(), w())
-                                 : contact_solve_dev(Pfull, cws, act ? cws_floats : -1, p, q, v(), w());
+        const ContactOut o = INL ? contact_solve_inl(Pfull, cws, need_cap_of(act, cws_floats, persisted), p, q, v(), w())
+                                 : contact_solve_dev(Pfull, cws, need_cap_of(act, cws_floats, persisted), p, q, v(), w());
         set_wv(o.w, o.v);  // (unchanged for a lane that did not ask or has no contact vertex)
         lift = Kc.c_erp * o.deepest;  // (already net of the slop)
       }
@@ -471,8 +483,10 @@ PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const i
   me[7] = b.contact_now ? 1.0f : 0.0f;
   lds_sync_wave();
   bool world = false, peer = false, nearp = false;
-  const float rr = 2.0f * K.bound_radius0, rr2 = rr * rr;
-  const float rp = rr + 2.0f * K.margin, rp2 = rp * rp;  // within reach of the contact response between drones
+  // (gates only: the farthest a report or a contact point between two drones can reach -- the exact tests decide)
+  const float far = fmaxf(fmaxf(K.margin, K.brk), K.rd);
+  const float rr = 2.0f * K.bound_radius0 + 1.7320508f * far, rr2 = rr * rr;
+  const float rp = 2.0f * K.bound_radius0 + 2.0f * far, rp2 = rp * rp;  // within reach of the contact response between drones
   const float h[3] = {K.box_h[0], K.box_h[1], K.box_h[2]};
   for (int j = 1; j < A; ++j) {
     int jj = wlocal + j;
@@ -490,7 +504,10 @@ PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const i
         const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
                       Rb.m01 * Ra.m00 + Rb.m11 * Ra.m10 + Rb.m21 * Ra.m20, Rb.m01 * Ra.m01 + Rb.m11 * Ra.m11 + Rb.m21 * Ra.m21, Rb.m01 * Ra.m02 + Rb.m11 * Ra.m12 + Rb.m21 * Ra.m22,
                       Rb.m02 * Ra.m00 + Rb.m12 * Ra.m10 + Rb.m22 * Ra.m20, Rb.m02 * Ra.m01 + Rb.m12 * Ra.m11 + Rb.m22 * Ra.m21, Rb.m02 * Ra.m02 + Rb.m12 * Ra.m12 + Rb.m22 * Ra.m22};
-        peer |= box_overlaps_aabb(mulT(Rb, d), Rrel, h, v3{0.f, 0.f, 0.f}, h);
+        // (reported from the gap rd on -- up to the breaking distance when either drone holds contact points: the peer's box enlarged)
+        const float rdx = (b.contact_now || o[7] != 0.0f) ? K.brk : K.rd;
+        const float hb[3] = {h[0] + rdx, h[1] + rdx, h[2] + rdx};
+        peer |= box_overlaps_aabb(mulT(Rb, d), Rrel, h, v3{0.f, 0.f, 0.f}, hb);
       }
     }
   }
@@ -506,7 +523,7 @@ PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const i
 #ifdef PF_PHASE_TRACE
 constexpr int kPhaseStamps = 13;
 __device__ unsigned long long g_phase_trace[4096 * kPhaseStamps];
-__device__ unsigned long long g_calm_trace[2];  // (waves that were not calm; [1] unused)
+__device__ unsigned long long g_calm_trace[2];  // (waves that were not calm over the env step; Aviary steps of theirs that were not calm)
 #define PF_STAMP(i) do { if (ROLL == 0) { pf_ts[i] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define PF_STAMP(i) do { } while (0)
@@ -1011,18 +1028,30 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   // (instantiated where the env benchmarks live -- flight mode 0, noise drawn on device or off; in the cascaded-mode and
   //  injected-noise instantiations the second copy of the ticks cost registers they do not have: stack spills)
   bool calm = false;
-  if (CALM && K.calm_on) {
+  // the same bound over any horizon T (TT = T (T + dt) / 2): how far a lane can sink within it
+  auto sink_within = [&](const float T, const float TT) {
     const float tm = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(V.t01.x), __builtin_fabsf(V.t01.y)), __builtin_fmaxf(__builtin_fabsf(V.t23.x), __builtin_fabsf(V.t23.y)));
-    const float a_nd = fmaf(K.calm_kt, __builtin_fmaxf(tm * tm, 1.0f), __builtin_fabsf(K.gravity_z));
-    const float u = fsqrt(fmaf(V.wvx.y, V.wvx.y, fmaf(V.wvy.y, V.wvy.y, V.wvz.y * V.wvz.y))) + a_nd * K.calm_T;
-    const float sink = fmaf(__builtin_fabsf(V.wvz.y), K.calm_T, fmaf(K.calm_c, u * u, a_nd) * K.calm_TT);
-    calm = __all(!go || (V.p.z - fmaf(sink, 1.01f, 1e-3f) > K.bound_radius));  // (wave-uniform; NaN compares false: not calm)
+    const float a_nd = fmaf(K.calm_kt, __builtin_fmaxf(tm * tm, K.calm_t2), __builtin_fabsf(K.gravity_z));
+    const float u = fsqrt(fmaf(V.wvx.y, V.wvx.y, fmaf(V.wvy.y, V.wvy.y, V.wvz.y * V.wvz.y))) + a_nd * T;
+    return fmaf(__builtin_fabsf(V.wvz.y), T, fmaf(K.calm_c, u * u, a_nd) * TT);
+  };
+  if (CALM && K.calm_on) {
+    calm = __all(!go || (V.p.z - fmaf(sink_within(K.calm_T, K.calm_TT), 1.01f, 1e-3f) > K.bound_radius));  // (wave-uniform; NaN compares false: not calm)
 #ifdef PF_PHASE_TRACE
     if (!calm && tid == 0) atomicAdd(&g_calm_trace[0], 1ull);  // waves that keep the call site this step (rare: no contention)
 #endif
   }
   for (int s = 0; s < K.env_step_ratio; ++s) {
     if (!__any(go)) break;
+    // a wave that is not calm over the whole env step (some lane is low) still is over most of its Aviary steps: the same bound
+    // over the two ticks ahead (a lane sinks a few millimetres in them) -- evaluated in those waves only
+    bool calm_s = calm;
+    if (CALM && K.calm_on && !calm) {
+      calm_s = __all(!go || (V.p.z - fmaf(sink_within(K.calm_T2, K.calm_TT2), 1.01f, 1e-3f) > K.bound_radius));
+#ifdef PF_PHASE_TRACE
+      if (!calm_s && tid == 0) atomicAdd(&g_calm_trace[1], 1ull);  // Aviary steps that keep the call site
+#endif
+    }
     if (go) {
       float xi0, xi1;
       if (NOISE == PF_NOISE_PHILOX) { xi0 = 4.0f + pick8(zn, (uint32_t)(2 * s)); xi1 = 4.0f + pick8(zn, (uint32_t)(2 * s + 1)); }
@@ -1039,7 +1068,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
         quad_world_exchange(V, wpose, tid, apw, K);
         V.template tick<CR, true>(K, K, xi1, Pfull);
         V.peer_contact = false;
-      } else if (CALM && __builtin_expect(calm, 1)) {
+      } else if (CALM && __builtin_expect(calm_s, 1)) {
         V.template tick<false, false, PF_KV_T>(KV, K, xi0, Pfull);
         V.template tick<false, false, PF_KV_T>(KV, K, xi1, Pfull);
       } else {

@@ -31,6 +31,8 @@ __device__ __noinline__ bool peers_overlap_dev(const pf_params* __restrict__ Pd,
                                                const float px, const float py, const float pz, const quat q, const float rr2) {
   const m3 Ra = rot_from_quat(q);
   bool peer = false;
+  const bool mine = wpose[(wbase + wlocal) * 8 + 7] != 0.0f;  // this body held contact points after the previous tick
+  const float rd_fresh = Pd->contact_report_distance, rd_kept = Pd->contact_break_distance;
   for (int j = 1; j < A; ++j) {
     int jj = wlocal + j;
     jj = jj >= A ? jj - A : jj;
@@ -46,7 +48,10 @@ __device__ __noinline__ bool peers_overlap_dev(const pf_params* __restrict__ Pd,
         for (int l = 0; l < nb; ++l) {
           const pf_box bk = Pd->boxes[k], bl = Pd->boxes[l];
           const v3 ca = d + mul(Ra, v3{bk.c[0], bk.c[1], bk.c[2]}) - mul(Rb, v3{bl.c[0], bl.c[1], bl.c[2]});
-          peer |= box_overlaps_aabb(mulT(Rb, ca), Rrel, bk.h, v3{0.f, 0.f, 0.f}, bl.h);
+          // (reported from the gap rd on -- up to the breaking distance when either drone holds contact points: the peer's box enlarged)
+          const float rd = (mine || o[7] != 0.0f) ? rd_kept : rd_fresh;
+          const float hb[3] = {bl.h[0] + rd, bl.h[1] + rd, bl.h[2] + rd};
+          peer |= box_overlaps_aabb(mulT(Rb, ca), Rrel, bk.h, v3{0.f, 0.f, 0.f}, hb);
         }
       }
     }
@@ -80,7 +85,8 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
     if (todo && rank < slots) {
       todo = false;
       float* rec = rec_all + rank * kPairRecFloats;
-      const float margin = Pd->contact_margin, slop = Pd->contact_slop, inv_dt = 1.0f / Pd->dt, rest = Pd->contact_restitution;
+      const float margin0 = Pd->contact_margin, brk = Pd->contact_break_distance, slop = Pd->contact_slop, inv_dt = 1.0f / Pd->dt, rest = Pd->contact_restitution;
+      const float res_bound = __builtin_sqrtf(Pd->contact_residual_threshold);
       const float mu = Pd->contact_friction * Pd->contact_friction, erp = Pd->contact_erp, im = Pd->inv_mass, brad = Pd->bound_radius;
       const float Ii[6] = {Pd->I_inv[0], Pd->I_inv[1], Pd->I_inv[2], Pd->I_inv[3], Pd->I_inv[4], Pd->I_inv[5]};
       const int nb = Pd->n_boxes, iters = Pd->contact_iters;
@@ -93,6 +99,8 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
           if (b == a) continue;
           const float* pb = wpose + (wbase + b) * 8;
           const v3 d{pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+          // (a pair one of whose bodies held contact points after the previous tick keeps its points up to the breaking distance)
+          const float margin = (pa[7] != 0.0f || pb[7] != 0.0f) ? brk : margin0;
           const float rr = 2.0f * brad + 2.0f * margin;
           if (dot(d, d) > rr * rr) continue;
           const m3 Rb = rot_from_quat(quat{pb[3], pb[4], pb[5], pb[6]});
@@ -169,6 +177,7 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
           r[3] = dot(ua - ub, dir);
         }
         for (int it = 0; it < iters; ++it) {
+          float res = 0.0f;  // the sweep's largest row-velocity change (the residual exit: pf_params.contact_residual_threshold)
           for (int c = 0; c < n; ++c) {
             float* r = rec + c * kPairRec;
             float* va = wvel + (wbase + __float_as_int(r[0])) * kPairVelStride;
@@ -188,6 +197,7 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
               if (dd == 0) { nl = __builtin_fmaxf(nl, 0.0f); l0 = nl; }
               else { const float lim = mu * l0; nl = __builtin_fminf(__builtin_fmaxf(nl, -lim), lim); }
               const float dl = nl - lam;
+              res = __builtin_fmaxf(res, __builtin_fabsf(dl) * (1.0f / q[9]));
               r[40 + dd] = nl;
               Va = Va + (im * dl) * dir; Wa = Wa + dl * ga;
               Vb = Vb - (im * dl) * dir; Wb = Wb - dl * gb;
@@ -195,6 +205,7 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
             va[0] = Va.x; va[1] = Va.y; va[2] = Va.z; va[3] = Wa.x; va[4] = Wa.y; va[5] = Wa.z;
             vb[0] = Vb.x; vb[1] = Vb.y; vb[2] = Vb.z; vb[3] = Wb.x; vb[4] = Wb.y; vb[5] = Wb.z;
           }
+          if (!(res > res_bound)) break;
         }
         // position-level recovery: each body follows its deepest pair contact (the first on a tie)
         float best[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -244,8 +255,10 @@ PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, co
   me[7] = b.contact_now ? 1.0f : 0.0f;
   lds_sync_wave();
   bool world = false, touch = false, near = false;
-  const float rr = 2.0f * bound_radius, rr2 = rr * rr;
-  const float rp = rr + 2.0f * Pd->contact_margin, rp2 = rp * rp;  // within reach of the contact response between drones
+  // (gates only: the farthest a report or a contact point between two drones can reach -- the exact tests decide)
+  const float far = __builtin_fmaxf(__builtin_fmaxf(Pd->contact_margin, Pd->contact_break_distance), Pd->contact_report_distance);
+  const float rr = 2.0f * bound_radius + 1.7320508f * far, rr2 = rr * rr;
+  const float rp = 2.0f * bound_radius + 2.0f * far, rp2 = rp * rp;  // within reach of the contact response between drones
   for (int j = 1; j < A; ++j) {
     int jj = wlocal + j;
     jj = jj >= A ? jj - A : jj;

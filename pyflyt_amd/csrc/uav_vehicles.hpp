@@ -62,9 +62,15 @@ PF_DEV float pid1(float kp, float ki, float kd, float lim, float T, float invT, 
 //     on the running twist is computed ONCE per contact into a 20-float record -- arm, the normal row's target velocity, and
 //     for each of the three rows the angular response I_w^-1 (a x e_d) and the inverse effective mass -- so that a row is
 //     2 (row velocity) + 2..3 (projected impulse) + 1 (delta) + 4 (twist update) instructions;
-//   * the records live in LDS (dynamically indexed; as private arrays they would be scratch memory) as five float4 each, read
-//     with five ds_read_b128 ONE CONTACT AHEAD of their use (two register sets, the loop unrolled by two), so the sweep never
+//   * the records live in LDS (dynamically indexed; as private arrays they would be scratch memory) as six float4 each, read
+//     with six ds_read_b128 ONE CONTACT AHEAD of their use (two register sets, the loop unrolled by two), so the sweep never
 //     waits on LDS; the only write per contact and sweep is its three accumulated impulses;
+//   * impulses are kept in VELOCITY units (round 4): lambda' = lambda / (effective mass of the row), the record holds the
+//     responses per unit of row velocity (g k, k / m) and the friction rows' cone factors mu k_z / k_x, mu k_z / k_y. The row's
+//     velocity change -- what the solver's residual exit (pf_params.contact_residual_threshold) is a bound on -- is then the
+//     impulse change itself, and the projected impulse is an add and a max;
+//   * a lane whose own sweep met the residual bound is DONE: it reads the sentinel record from then on (its rows are exact
+//     no-ops), so lanes of a wave that solve side by side each stop after the sweep the scalar restatements stop after;
 //   * vertex generation per box: the eight heights come from seven partial sums of the box's half axes' z components, a box
 //     whose lowest vertex clears the margin is skipped after four instructions, and only a vertex that passes the height test
 //     gets its x / y offsets and its record;
@@ -76,12 +82,14 @@ struct ContactOut {
   v3 v, w;
   float deepest;
 };
-// Per-contact record, five float4: (arm.xyz, normal target velocity) (gz.xyz, kz) (gx.xyz, kx) (gy.xyz, ky) (ln, lx, ly, -).
+// Per-contact record, six float4: (arm.xyz, normal target velocity) (gz kz, kz / m) (gx kx, kx / m) (gy ky, ky / m)
+// (ln', lx', ly', mu kz / kx) (mu kz / ky, -, -, -); g_d = I_w^-1 (arm x e_d), k_d the row's effective mass.
 // Only a few lanes of a wave need the solver in the same tick, so the callers cut their LDS (the hot kernels: the observation
 // tile, idle during the physics ticks) into regions sized for the airframe's own worst-case contact count and deal them out by
 // prefix sum over what each lane actually needs (contact_solve_impl), coming back for another round if not everything fits.
-constexpr int kContactWords = 20;
-constexpr int kContactSlotFloats = (PF_MAX_CONTACTS + 1) * kContactWords;  // worst-case region (+ the sentinel record): 980 floats
+constexpr int kContactWords = 24;
+constexpr int kContactF4 = kContactWords / 4;
+constexpr int kContactSlotFloats = (PF_MAX_CONTACTS + 1) * kContactWords;  // worst-case region (+ the sentinel record): 1176 floats
 typedef __attribute__((address_space(3))) float* lds_fptr;
 typedef __attribute__((address_space(3))) pf_f4v* lds_f4ptr;  // (the native vector type: HIP's float4 class has no LDS-qualified assignment)
 // The parameter block as the solver reads it: a wave-uniform pointer into the constant address space, so that every field --
@@ -124,14 +132,15 @@ struct ContactSet {
   float deepest;
   v3 cw;                // R com: the arms are taken from the centre of mass
   float I0, I1, I2, I3, I4, I5;  // world-frame inverse inertia R I^-1 R^T (symmetric xx xy xz yy yz zz)
-  float inv_mass, slop, inv_dt, rest;
+  float inv_mass, slop, inv_dt, rest, mu;
   v3 vc, w;             // the running twist: COM velocity, angular velocity
+  float res;            // the running sweep's largest row-velocity change (magnitude)
 #ifdef PF_PHASE_TRACE
   int sweeps_done = 0, rows_full = 0, rows_skipped = 0;
 #endif
   PF_DEV void begin(lds_fptr ws, const m3& R, v3 com, float im, v3 v_, v3 w_, float i0, float i1, float i2, float i3, float i4, float i5,
-                    float slop_, float inv_dt_, float rest_) {
-    W4 = (lds_f4ptr)ws; n = 0; deepest = 0.0f;
+                    float slop_, float inv_dt_, float rest_, float mu_) {
+    W4 = (lds_f4ptr)ws; n = 0; deepest = 0.0f; mu = mu_; res = 0.0f;
     cw = mul(R, com);
     const float Ii[6] = {i0, i1, i2, i3, i4, i5};
     const v3 r0{R.m00, R.m01, R.m02}, r1{R.m10, R.m11, R.m12}, r2{R.m20, R.m21, R.m22};
@@ -146,31 +155,35 @@ struct ContactSet {
   // component: with the direction as a vector the compiler may not drop the multiplications by its zeros.
   PF_DEV void add(v3 off, float depth) {
     const v3 a = off - cw;
-    // angular response I_w^-1 (a x e_d) of a unit impulse along e_d at arm a, and 1 / (1/m + e_d . ((I_w^-1 (a x e_d)) x a))
+    // angular response I_w^-1 (a x e_d) of a unit impulse along e_d at arm a, and the row's inverse effective mass
+    // 1/m + e_d . ((I_w^-1 (a x e_d)) x a)
     const v3 gz{fmaf(I0, a.y, -(I1 * a.x)), fmaf(I1, a.y, -(I3 * a.x)), fmaf(I2, a.y, -(I4 * a.x))};
     const v3 gx{fmaf(I1, a.z, -(I2 * a.y)), fmaf(I3, a.z, -(I4 * a.y)), fmaf(I4, a.z, -(I5 * a.y))};
     const v3 gy{fmaf(I2, a.x, -(I0 * a.z)), fmaf(I4, a.x, -(I1 * a.z)), fmaf(I5, a.x, -(I2 * a.z))};
-    const float kz = frcp(inv_mass + fmaf(gz.x, a.y, -(gz.y * a.x)));
-    const float kx = frcp(inv_mass + fmaf(gx.y, a.z, -(gx.z * a.y)));
-    const float ky = frcp(inv_mass + fmaf(gy.z, a.x, -(gy.x * a.z)));
+    const float dz = inv_mass + fmaf(gz.x, a.y, -(gz.y * a.x));
+    const float dx = inv_mass + fmaf(gx.y, a.z, -(gx.z * a.y));
+    const float dy = inv_mass + fmaf(gy.z, a.x, -(gy.x * a.z));
+    const float kz = frcp(dz), kx = frcp(dx), ky = frcp(dy);
     // normal row: may close the gap down to the slop, no more; otherwise towards restitution x approach speed
     const float vn0 = vc.z + fmaf(w.x, a.y, -(w.y * a.x));
     const float tgt = depth < slop ? (depth - slop) * inv_dt : (vn0 < 0.0f ? -rest * vn0 : 0.0f);
-    lds_f4ptr r = W4 + 5 * n;
+    const float mz = mu * kz;
+    lds_f4ptr r = W4 + kContactF4 * n;
     r[0] = pf_f4v{a.x, a.y, a.z, tgt};
-    r[1] = pf_f4v{gz.x, gz.y, gz.z, kz};
-    r[2] = pf_f4v{gx.x, gx.y, gx.z, kx};
-    r[3] = pf_f4v{gy.x, gy.y, gy.z, ky};
-    r[4] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    r[1] = pf_f4v{gz.x * kz, gz.y * kz, gz.z * kz, inv_mass * kz};
+    r[2] = pf_f4v{gx.x * kx, gx.y * kx, gx.z * kx, inv_mass * kx};
+    r[3] = pf_f4v{gy.x * ky, gy.y * ky, gy.z * ky, inv_mass * ky};
+    r[4] = pf_f4v{0.0f, 0.0f, 0.0f, mz * dx};
+    r[5] = pf_f4v{mz * dy, 0.0f, 0.0f, 0.0f};
     deepest = __builtin_fmaxf(deepest, depth);
     ++n;
   }
   // one contact of one sweep; returns 0 when it was skipped as idle in every lane, 1 when it ran (wave-uniform)
-  PF_DEV uint32_t row3(const pf_f4v r0, const pf_f4v r1, const pf_f4v r2, const pf_f4v r3, const pf_f4v r4, const float mu, lds_f4ptr lout) {
+  PF_DEV uint32_t row3(const pf_f4v r0, const pf_f4v r1, const pf_f4v r2, const pf_f4v r3, const pf_f4v r4, const float cy, lds_f4ptr lout) {
     const float un = fmaf(w.x, r0.y, fmaf(-w.y, r0.x, vc.z));
     // (a contact with no accumulated impulse whose normal velocity is not below its target stays at exactly zero: n0 = 0,
     //  friction clamped to +-0; skipped when every lane of the wave agrees -- which includes the lanes that are past their
-    //  last contact and sit on the sentinel record)
+    //  last contact, or done, and sit on the sentinel record)
     const bool idle = (r4.x == 0.0f) && (un >= r0.w);
 #ifdef PF_PHASE_TRACE
     if (__builtin_amdgcn_ballot_w64(!idle) == 0ull) { rows_skipped += 1; return 0u; }
@@ -178,43 +191,46 @@ struct ContactSet {
 #else
     if (__builtin_amdgcn_ballot_w64(!idle) == 0ull) return 0u;
 #endif
-    const float n0 = __builtin_fmaxf(fmaf(r0.w - un, r1.w, r4.x), 0.0f);
+    // (velocity units: the unclamped new impulse is the old one plus the row's velocity error)
+    const float n0 = __builtin_fmaxf((r0.w - un) + r4.x, 0.0f);
     const float d0 = n0 - r4.x;
-    vc.z = fmaf(inv_mass, d0, vc.z);
+    vc.z = fmaf(r1.w, d0, vc.z);
     w = v3{fmaf(d0, r1.x, w.x), fmaf(d0, r1.y, w.y), fmaf(d0, r1.z, w.z)};
-    const float lim = mu * n0;  // friction rows: clamped to mu x the normal impulse
+    const float limx = r4.w * n0;  // friction rows: clamped to mu x the normal impulse (in their own velocity units)
     const float ux = fmaf(w.y, r0.z, fmaf(-w.z, r0.y, vc.x));
-    const float n1 = med3(fmaf(-ux, r2.w, r4.y), -lim, lim);
+    const float n1 = med3(r4.y - ux, -limx, limx);
     const float d1 = n1 - r4.y;
-    vc.x = fmaf(inv_mass, d1, vc.x);
+    vc.x = fmaf(r2.w, d1, vc.x);
     w = v3{fmaf(d1, r2.x, w.x), fmaf(d1, r2.y, w.y), fmaf(d1, r2.z, w.z)};
+    const float limy = cy * n0;
     const float uy = fmaf(w.z, r0.x, fmaf(-w.x, r0.z, vc.y));
-    const float n2 = med3(fmaf(-uy, r3.w, r4.z), -lim, lim);
+    const float n2 = med3(r4.z - uy, -limy, limy);
     const float d2 = n2 - r4.z;
-    vc.y = fmaf(inv_mass, d2, vc.y);
+    vc.y = fmaf(r3.w, d2, vc.y);
     w = v3{fmaf(d2, r3.x, w.x), fmaf(d2, r3.y, w.y), fmaf(d2, r3.z, w.z)};
-    // (r4.w is the record's padding word, always zero: written back HERE it keeps its register out of the allocator's hands until
-    //  the row is done -- reused earlier, it made the row wait for the whole prefetch it belongs to)
+    res = __builtin_fmaxf(__builtin_fmaxf(res, __builtin_fabsf(d0)), __builtin_fmaxf(__builtin_fabsf(d1), __builtin_fabsf(d2)));
+    // (r4.w is written back as it came: that keeps its register out of the allocator's hands until the row is done -- reused
+    //  earlier, it made the row wait for the whole prefetch it belongs to)
     *lout = pf_f4v{n0, n1, n2, r4.w};
     return 1u;  // (the row ran)
   }
   // Wave-uniform control flow: the contact counter and the sweep counter are scalars, a lane that is past its last contact reads
-  // its sentinel record (zero impulse, target -FLT_MAX, zero effective masses: the row update is an exact no-op), and the solve
-  // ends when a sweep moved nothing in any lane (a lane whose own sweep moved nothing would repeat it exactly). (A convergence
-  // test at fp32 resolution -- largest impulse change below 2^-20 of the largest impulse -- was tried for the single-lane
-  // solves the env tasks' launches wait for: the iteration does not contract that far within the budget, 7.6 sweeps run
-  // instead of 7.7.) No exec-mask bookkeeping in the loop: on a lone wave a scalar instruction costs an issue slot like any other.
-  PF_DEV void sweeps(const int iters, const float mu) {
-    W4[5 * n + 0] = pf_f4v{0.0f, 0.0f, 0.0f, -3.4028235e38f};
-    W4[5 * n + 1] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
-    W4[5 * n + 2] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
-    W4[5 * n + 3] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
-    W4[5 * n + 4] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+  // its sentinel record (zero impulse, target -FLT_MAX, zero responses: the row update is an exact no-op), a lane whose sweep
+  // met the residual bound is done and reads nothing but the sentinel from then on, and the solve ends when every lane is done.
+  // res_bound: sqrt(pf_params.contact_residual_threshold) -- the bound on a row's velocity change; 0: only a sweep that moved
+  // nothing ends a lane's solve (every further sweep would repeat it exactly). No exec-mask bookkeeping in the loop: on a lone
+  // wave a scalar instruction costs an issue slot like any other.
+  PF_DEV void sweeps(const int iters, const float res_bound) {
+    W4[kContactF4 * n + 0] = pf_f4v{0.0f, 0.0f, 0.0f, -3.4028235e38f};
+    W4[kContactF4 * n + 1] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    W4[kContactF4 * n + 2] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    W4[kContactF4 * n + 3] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    W4[kContactF4 * n + 4] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    W4[kContactF4 * n + 5] = pf_f4v{0.0f, 0.0f, 0.0f, 0.0f};
     if (!__any(n > 0)) return;
     typedef __attribute__((address_space(3))) char* lds_cptr;
-    const lds_cptr base = (lds_cptr)W4;
-    const uint32_t end = (uint32_t)n * 80u;  // byte offset of the sentinel
-    auto rec = [&](uint32_t off) { return (lds_f4ptr)(base + (off < end ? off : end)); };
+    constexpr uint32_t kRecBytes = 4u * kContactWords;
+    const uint32_t end_all = (uint32_t)n * kRecBytes;  // byte offset of the sentinel
     // the largest contact count among the lanes in here, as a scalar (bit by bit from the top: n <= PF_MAX_CONTACTS < 64): the
     // contact loop then runs on scalar compares -- on a lone wave every vector compare + ballot + branch it does not need is
     // some thirty clocks per contact row
@@ -223,29 +239,33 @@ struct ContactSet {
     for (int b = 5; b >= 0; --b)
       if (__ballot(n >= (nmax | (1 << b))) != 0ull) nmax |= 1 << b;
     const int npair = (nmax + 1) >> 1;
+    bool done = n == 0;
     for (int it = 0; it < iters; ++it) {
-      uint32_t chg = 0u;
+      // (a done lane: base on the sentinel, no further records)
+      const lds_cptr base = (lds_cptr)W4 + (done ? end_all : 0u);
+      const uint32_t end = done ? 0u : end_all;
+      auto rec = [&](uint32_t off) { return (lds_f4ptr)(base + (off < end ? off : end)); };
+      res = 0.0f;
       // two register sets, each loaded one contact ahead of its use; contacts in pairs (for an odd count the last row of every lane
       // is the sentinel's, skipped as idle; a scalar exit between the two rows of a pair cost more than it saved: 19.8 -> 21.0 us per
       // tick for landed quadrotors)
-      pf_f4v a0 = W4[0], a1 = W4[1], a2 = W4[2], a3 = W4[3], a4 = W4[4];
+      lds_f4ptr p0 = rec(0u);
+      pf_f4v a0 = p0[0], a1 = p0[1], a2 = p0[2], a3 = p0[3], a4 = p0[4], a5 = p0[5];
       uint32_t off = 0u;  // (wave-uniform)
       for (int c = 0; c < npair; ++c) {
-        lds_f4ptr pa = rec(off), nb = rec(off + 80u);
-        const pf_f4v b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3], b4 = nb[4];
-        chg |= row3(a0, a1, a2, a3, a4, mu, pa + 4);
-        lds_f4ptr na = rec(off + 160u);
-        a0 = na[0]; a1 = na[1]; a2 = na[2]; a3 = na[3]; a4 = na[4];
-        chg |= row3(b0, b1, b2, b3, b4, mu, nb + 4);
-        off += 160u;
+        lds_f4ptr pa = rec(off), nb = rec(off + kRecBytes);
+        const pf_f4v b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3], b4 = nb[4], b5 = nb[5];
+        row3(a0, a1, a2, a3, a4, a5.x, pa + 4);
+        lds_f4ptr na = rec(off + 2u * kRecBytes);
+        a0 = na[0]; a1 = na[1]; a2 = na[2]; a3 = na[3]; a4 = na[4]; a5 = na[5];
+        row3(b0, b1, b2, b3, b4, b5.x, nb + 4);
+        off += 2u * kRecBytes;
       }
 #ifdef PF_PHASE_TRACE
       sweeps_done = it + 1;
 #endif
-      // a sweep in which every row of every lane was idle changed nothing, and every further sweep would repeat it exactly. (The
-      // finer test -- no impulse moved by a single bit -- cost three ORs per row and never fired: bodies at rest run all ten sweeps,
-      // the last digits keep flickering.)
-      if (chg == 0u) break;
+      done = done || !(res > res_bound);
+      if (__ballot(!done) == 0ull) break;
     }
   }
   PF_DEV ContactOut finish(v3 v_in, v3 w_in) const {
@@ -262,19 +282,32 @@ __device__ unsigned long long g_solver_trace[8];
 // z axis) that lie within the contact margin of the slab's top face: f(off, z) in vertex order.
 template <class F>
 PF_DEV void box_contact_vertices(const v3 p, const m3& R, const v3 cwk, const float cy, const float sy, const float bh0, const float bh1, const float bh2,
-                                 const float hxy, const float hz2, const float margin, F&& f) {
-  // half axes in the world frame (the link frame is the base frame yawed about z)
-  const v3 ex{bh0 * fmaf(R.m00, cy, R.m01 * sy), bh0 * fmaf(R.m10, cy, R.m11 * sy), bh0 * fmaf(R.m20, cy, R.m21 * sy)};
-  const v3 ey{bh1 * fmaf(R.m01, cy, -(R.m00 * sy)), bh1 * fmaf(R.m11, cy, -(R.m10 * sy)), bh1 * fmaf(R.m21, cy, -(R.m20 * sy))};
-  const v3 ez{bh2 * R.m02, bh2 * R.m12, bh2 * R.m22};
+                                 const float hxy, const float hz2, const float margin, const bool all8, F&& f) {
+  // the link axes in the world frame (the link frame is the base frame yawed about z): their z components choose the incident
+  // face, the axes scaled by the half extents are the half axes
+  const float zx = fmaf(R.m20, cy, R.m21 * sy), zy = fmaf(R.m21, cy, -(R.m20 * sy)), zz = R.m22;
+  const v3 ex{bh0 * fmaf(R.m00, cy, R.m01 * sy), bh0 * fmaf(R.m10, cy, R.m11 * sy), bh0 * zx};
+  const v3 ey{bh1 * fmaf(R.m01, cy, -(R.m00 * sy)), bh1 * fmaf(R.m11, cy, -(R.m10 * sy)), bh1 * zy};
+  const v3 ez{bh2 * R.m02, bh2 * R.m12, bh2 * zz};
   const float zc = p.z + cwk.z;
   if (zc - (__builtin_fabsf(ex.z) + __builtin_fabsf(ey.z) + __builtin_fabsf(ez.z)) > margin) return;  // the whole box clears the margin
+  // manifold reduction (pf_params.contact_manifold_points = 4): only the four vertices of the face that looks down the most --
+  // the axis with the largest |z component| (the first on a tie), the face on its + side when the axis points down. As a mask
+  // over the vertex index (x sign bit 0, y sign bit 1, z sign bit 2).
+  uint32_t keep = 0xffu;
+  if (!all8) {
+    const float ax = __builtin_fabsf(zx), ay = __builtin_fabsf(zy), az = __builtin_fabsf(zz);
+    const bool use_y = ay > ax, use_z = az > __builtin_fmaxf(ax, ay);
+    const uint32_t lo = use_z ? 0x0fu : (use_y ? 0x33u : 0x55u);  // the vertices on the - side of the axis
+    const float zsel = use_z ? zz : (use_y ? zy : zx);
+    keep = zsel < 0.0f ? (lo ^ 0xffu) : lo;
+  }
   const float za0 = zc - ex.z, za1 = zc + ex.z;
   const float zb[4] = {za0 - ey.z, za1 - ey.z, za0 + ey.z, za1 + ey.z};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {  // vertex i: x sign bit 0, y sign bit 1, z sign bit 2 (the oracle's order)
     const float z = (i & 4) ? zb[i & 3] + ez.z : zb[i & 3] - ez.z;
-    if (z <= margin && z >= -hz2) {
+    if (((keep >> i) & 1u) != 0u && z <= margin && z >= -hz2) {
       const float sx = (i & 1) ? 1.0f : -1.0f, syv = (i & 2) ? 1.0f : -1.0f, sz = (i & 4) ? 1.0f : -1.0f;
       const v3 off{fmaf(sx, ex.x, fmaf(syv, ey.x, fmaf(sz, ez.x, cwk.x))), fmaf(sx, ex.y, fmaf(syv, ey.y, fmaf(sz, ez.y, cwk.y))), z - p.z};
       if (__builtin_fabsf(p.x + off.x) <= hxy && __builtin_fabsf(p.y + off.y) <= hxy) f(off, z);
@@ -286,7 +319,7 @@ PF_DEV void box_contact_vertices(const v3 p, const m3& R, const v3 cwk, const fl
 // from seven partial sums of the half axes' z components; a box whose lowest vertex clears the margin costs four instructions.
 // Used twice per solve with identical arithmetic: to count the contacts (so that the LDS records can be packed) and to fill them.
 template <class F>
-PF_DEV void for_each_contact_vertex(const pf_params_kptr P, const float hxy, const float hz2, const float margin, const int nb, const v3 p, const m3& R, F&& f) {
+PF_DEV void for_each_contact_vertex(const pf_params_kptr P, const float hxy, const float hz2, const float margin, const bool all8, const int nb, const v3 p, const m3& R, F&& f) {
   for (int k = 0; k < nb; ++k) {
     const float bc0 = P->boxes[k].c[0], bc1 = P->boxes[k].c[1], bc2 = P->boxes[k].c[2];
     const float bh0 = P->boxes[k].h[0], bh1 = P->boxes[k].h[1], bh2 = P->boxes[k].h[2];
@@ -309,7 +342,7 @@ PF_DEV void for_each_contact_vertex(const pf_params_kptr P, const float hxy, con
       }
       continue;
     }
-    box_contact_vertices(p, R, cwk, cy, sy, bh0, bh1, bh2, hxy, hz2, margin, f);
+    box_contact_vertices(p, R, cwk, cy, sy, bh0, bh1, bh2, hxy, hz2, margin, all8, f);
   }
 }
 // Where the solve reads the world from: the device parameter block through the scalar cache. The contact model's constants
@@ -318,20 +351,27 @@ PF_DEV void for_each_contact_vertex(const pf_params_kptr P, const float hxy, con
 // where a solve is rare, each of them missed the scalar cache while the whole launch waited for that one wave.
 struct ParamContactSrc {
   pf_params_kptr P;
-  float slop_, inv_dt_, rest_, mu_, hxy_, hz2_, margin_;
+  float slop_, inv_dt_, rest_, mu_, hxy_, hz2_, margin_, brk_, res_bound_;
   int iters_, nb_, worst_;
+  bool all8_;
   PF_DEV explicit ParamContactSrc(pf_params_kptr p) : P(p) {
     worst_ = p->contact_max_points;
-    const float dt = p->dt, hz = p->plane_half_z;
+    const float dt = p->dt, hz = p->plane_half_z, thr = p->contact_residual_threshold;
     slop_ = p->contact_slop; rest_ = p->contact_restitution; mu_ = p->contact_friction; iters_ = p->contact_iters;
-    hxy_ = p->plane_half_xy; margin_ = p->contact_margin; nb_ = p->n_boxes;
+    hxy_ = p->plane_half_xy; margin_ = p->contact_margin; brk_ = p->contact_break_distance; nb_ = p->n_boxes;
+    all8_ = p->contact_manifold_points >= 8;
     inv_dt_ = 1.0f / dt; hz2_ = 2.0f * hz;
+    res_bound_ = __builtin_sqrtf(thr);  // (wave-uniform: one scalar-side conversion per call)
   }
-  template <class F> PF_DEV void for_each(const v3 p, const m3& R, F&& f) const { for_each_contact_vertex(P, hxy_, hz2_, margin_, nb_, p, R, f); }
+  // reach: how far above the face a vertex may be and still be a contact point -- the margin, or the breaking distance for a
+  // body that held contact points after the previous tick (per lane)
+  template <class F> PF_DEV void for_each(const v3 p, const m3& R, const float reach, F&& f) const { for_each_contact_vertex(P, hxy_, hz2_, reach, all8_, nb_, p, R, f); }
+  PF_DEV float reach(const bool persisted) const { return persisted ? brk_ : margin_; }
   PF_DEV float slop() const { return slop_; }
   PF_DEV float inv_dt() const { return inv_dt_; }
   PF_DEV float rest() const { return rest_; }
   PF_DEV float mu() const { return mu_; }
+  PF_DEV float res_bound() const { return res_bound_; }
   PF_DEV int iters() const { return iters_; }
   PF_DEV int worst() const { return worst_; }  // the airframe's worst-case contact count (pf_params.contact_max_points)
 };
@@ -362,8 +402,9 @@ PF_DEV int wave_inclusive_scan_asking(const bool need, const int sz) {
 //      airframe's worst case (a landed aeroplane touches with 4 of its 48 collider vertices: six rounds became one);
 //   3. fill the records and run the sweeps; lanes that did not fit come back in another round.
 template <class SRC>
-PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_floats, bool need, v3 p, const m3 R, v3 v, v3 w, float inv_mass, v3 com,
+PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_floats, bool need, const bool persisted, v3 p, const m3 R, v3 v, v3 w, float inv_mass, v3 com,
                                      float i0, float i1, float i2, float i3, float i4, float i5) {
+  const float reach = src.reach(persisted);
 #ifdef PF_PHASE_TRACE
   const unsigned long long pf_t0 = __builtin_readcyclecounter();
   unsigned long long pf_sweep = 0, pf_fill = 0;
@@ -381,7 +422,7 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
   int n = roomy ? PF_MAX_CONTACTS : kOptimistic;
   if (!roomy && !optimistic) {
     n = 0;
-    if (need) src.for_each(p, R, [&](v3, float) { n += 1; });
+    if (need) src.for_each(p, R, reach, [&](v3, float) { n += 1; });
     n = n > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : n;
     need = need && n > 0;
   }
@@ -398,9 +439,9 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
 #ifdef PF_PHASE_TRACE
       const unsigned long long pf_a = __builtin_readcyclecounter();
 #endif
-      S.begin(ws + (incl - sz), R, com, inv_mass, v, w, i0, i1, i2, i3, i4, i5, src.slop(), src.inv_dt(), src.rest());
+      S.begin(ws + (incl - sz), R, com, inv_mass, v, w, i0, i1, i2, i3, i4, i5, src.slop(), src.inv_dt(), src.rest(), src.mu());
       int seen = 0;
-      src.for_each(p, R, [&](v3 off, float z) { if (S.n < n) S.add(off, -z); seen += 1; });
+      src.for_each(p, R, reach, [&](v3 off, float z) { if (S.n < n) S.add(off, -z); seen += 1; });
 #ifdef PF_PHASE_TRACE
       const unsigned long long pf_b = __builtin_readcyclecounter();
       pf_fill += pf_b - pf_a;
@@ -409,7 +450,7 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
         n = seen > PF_MAX_CONTACTS ? PF_MAX_CONTACTS : seen;
         sz = (n + 1) * kContactWords;
       } else {
-        S.sweeps(src.iters(), src.mu());
+        S.sweeps(src.iters(), src.res_bound());
         out = S.finish(v, w);
         need = false;
       }
@@ -453,13 +494,16 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
 #define PF_SOLVE_ATTR __device__ __noinline__ PF_RARE_TEXT
 #endif
 // (the capacity is wave-uniform among the lanes that ask: the first of them carries it)
+constexpr int kPersistedBit = 1 << 29;
+PF_DEV int need_cap_of(const bool need, const int cap_floats, const bool persisted) { return need ? (cap_floats | (persisted ? kPersistedBit : 0)) : -1; }
 PF_DEV int __reduce_max_cap(int ask) {
   const unsigned long long m = __ballot(ask >= 0);
-  return m != 0ull ? __builtin_amdgcn_readlane(ask, __ffsll((long long)m) - 1) : 0;
+  return m != 0ull ? (__builtin_amdgcn_readlane(ask, __ffsll((long long)m) - 1) & ~kPersistedBit) : 0;
 }
 // Constant mass properties (QuadX, Fixedwing): read from the parameter block inside the call, so that the call passes few
 // dwords -- all in registers.
-// need_cap: the floats of LDS behind ws for a lane that asks, -1 for a lane that does not.
+// need_cap: the floats of LDS behind ws for a lane that asks, -1 for a lane that does not; bit kPersistedBit set for a body that
+// held contact points after the previous tick (its contact reach is the breaking distance: pf_params.contact_break_distance).
 // (Register allocation of this function is touchy: with the LDS address folded into the same dword to keep every argument in
 //  registers, the allocator reached into 48 callee-saved VGPRs -- 96 scratch accesses per call; as it is, one argument travels
 //  over the stack and five scratch accesses remain.)
@@ -472,7 +516,7 @@ PF_SOLVE_ATTR ContactOut contact_solve_dev(const pf_params* __restrict__ Pg, lds
   const float im = P->inv_mass, i0 = P->I_inv[0], i1 = P->I_inv[1], i2 = P->I_inv[2], i3 = P->I_inv[3], i4 = P->I_inv[4], i5 = P->I_inv[5];
   const float c0 = P->com[0], c1 = P->com[1], c2 = P->com[2];
   const v3 com = P->has_com_offset ? v3{c0, c1, c2} : v3{0.f, 0.f, 0.f};
-  return contact_solve_impl(src, ws, cap_floats, need, p, rot_from_quat(q), v, w, im, com, i0, i1, i2, i3, i4, i5);
+  return contact_solve_impl(src, ws, cap_floats, need, need && (need_cap & kPersistedBit) != 0, p, rot_from_quat(q), v, w, im, com, i0, i1, i2, i3, i4, i5);
 }
 // The same, inlined: what the generic kernels (Body::respond) use. Called out of line from the generic Fixedwing env kernel --
 // 255 VGPRs + AGPR spill space, its 17th argument dword over the stack -- the ragged last wave of a launch lost its observation
@@ -486,14 +530,14 @@ PF_DEV ContactOut contact_solve_inl(const pf_params* __restrict__ Pg, lds_fptr w
   const float im = P->inv_mass, i0 = P->I_inv[0], i1 = P->I_inv[1], i2 = P->I_inv[2], i3 = P->I_inv[3], i4 = P->I_inv[4], i5 = P->I_inv[5];
   const float c0 = P->com[0], c1 = P->com[1], c2 = P->com[2];
   const v3 com = P->has_com_offset ? v3{c0, c1, c2} : v3{0.f, 0.f, 0.f};
-  return contact_solve_impl(src, ws, cap_floats, need, p, rot_from_quat(q), v, w, im, com, i0, i1, i2, i3, i4, i5);
+  return contact_solve_impl(src, ws, cap_floats, need, need && (need_cap & kPersistedBit) != 0, p, rot_from_quat(q), v, w, im, com, i0, i1, i2, i3, i4, i5);
 }
 // Mass properties that change per tick (Rocket): passed by value.
 PF_DEV ContactOut contact_solve_var_dev(const pf_params* __restrict__ P, lds_fptr ws, int need_cap, v3 p, quat q, v3 v, v3 w, float inv_mass, v3 com,
                                                float i0, float i1, float i2, float i3, float i4, float i5) {
   const bool need = need_cap >= 0;
   const int cap_floats = __reduce_max_cap(need_cap);
-  return contact_solve_impl(ParamContactSrc(uniform_params(P)), ws, cap_floats, need, p, rot_from_quat(q), v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
+  return contact_solve_impl(ParamContactSrc(uniform_params(P)), ws, cap_floats, need, need && (need_cap & kPersistedBit) != 0, p, rot_from_quat(q), v, w, inv_mass, com, i0, i1, i2, i3, i4, i5);
 }
 
 // Rigid body shared by both vehicles: the Bullet base state + what update_state derives from it.
@@ -505,6 +549,7 @@ struct Body {
   v3 wb, vb;    // quadx.py:522-523
   v3 rpy;       // quadx.py:526 (refreshed once per Aviary step)
   bool contact_now, contact_step;
+  bool persisted = false;  // this tick: the body held contact points after the previous tick (they persist up to the breaking distance)
   // shared world (PF_TASK_MA_HOVER with agents_per_world > 1); both false for a drone that is alone in its world
   int ccap = kContactSlotFloats;  // floats of LDS behind `cws` for the solver's contact records (at least one worst-case region)
   PF_DEV void contact_regions(const pf_params&, int floats) { ccap = floats; }
@@ -528,9 +573,11 @@ struct Body {
     const float r = P.bound_radius + extra;
     return (p.z - r <= 0.0f) && (p.z + r >= -2.0f * P.plane_half_z) && (__builtin_fabsf(p.x) - r <= P.plane_half_xy) && (__builtin_fabsf(p.y) - r <= P.plane_half_xy);
   }
-  PF_DEV bool detect_contact(const pf_params& P) const {
-    if (!slab_in_reach(P, 0.0f)) return false;
-    const float hb[3] = {P.plane_half_xy, P.plane_half_xy, P.plane_half_z};
+  // rd: the pair is reported from this gap on -- the 15-axis verdict against the slab enlarged by it (pf_params.contact_report_distance,
+  // or contact_break_distance for a body that held contact points after the previous tick)
+  PF_DEV bool detect_contact(const pf_params& P, const float rd) const {
+    if (!slab_in_reach(P, rd)) return false;
+    const float hb[3] = {P.plane_half_xy + rd, P.plane_half_xy + rd, P.plane_half_z + rd};
     v3 cb{0.0f, 0.0f, -P.plane_half_z};
     bool hit = false;
 #pragma unroll
@@ -556,7 +603,8 @@ struct Body {
   // semi-implicit Euler free-body tick. F, tau: body frame; tau about the base origin.
   template <bool SHARED = false>
   PF_DEV void tick(const pf_params& P, v3 F, v3 tau) {
-    contact_now = detect_contact(P) || peer_contact;
+    persisted = contact_now;
+    contact_now = detect_contact(P, persisted ? P.contact_break_distance : P.contact_report_distance) || peer_contact;
     v3 com{P.com[0], P.com[1], P.com[2]};
     if (P.has_com_offset) tau = tau - cross(com, F);
     v3 h = symmul(P.I_pa, wb);
@@ -590,8 +638,9 @@ struct Body {
   // exactly zero, no recovery -- and the call is skipped without changing the result.
   PF_DEV bool contact_may_act(const pf_params* Pd) const {
     const float low = p.z - Pd->bound_radius;
-    if (!slab_in_reach(*Pd, Pd->contact_margin)) return false;
-    if (low > Pd->contact_margin) return false;  // no vertex can be within the contact margin
+    const float reach = persisted ? Pd->contact_break_distance : Pd->contact_margin;
+    if (!slab_in_reach(*Pd, reach)) return false;
+    if (low > reach) return false;  // no vertex can be within the contact reach
     const float vlow = v.z - __builtin_sqrtf(dot(w, w)) * Pd->bound_radius;
     return (low + Pd->contact_slop + Pd->dt * vlow < 0.0f) || (low < -Pd->contact_slop);
   }
@@ -603,7 +652,7 @@ struct Body {
     float lift = 0.0f;
     const bool need = Pd->contact_response && contact_may_act(Pd);
     if (__any(need)) {
-      const ContactOut o = contact_solve_inl(Pd, cws, need ? ccap : -1, p, q, v, w);
+      const ContactOut o = contact_solve_inl(Pd, cws, need_cap_of(need, ccap, persisted), p, q, v, w);
       v = o.v; w = o.w;  // (unchanged for a lane that did not ask or has no contact vertex)
       lift = Pd->contact_erp * o.deepest;  // (deepest: already net of the slop)
     }
@@ -614,7 +663,7 @@ struct Body {
     float lift = 0.0f;
     const bool need = Pd->contact_response && contact_may_act(Pd);
     if (__any(need)) {
-      const ContactOut o = contact_solve_var_dev(Pd, cws, need ? ccap : -1, p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
+      const ContactOut o = contact_solve_var_dev(Pd, cws, need_cap_of(need, ccap, persisted), p, q, v, w, inv_mass, com, Iinv[0], Iinv[1], Iinv[2], Iinv[3], Iinv[4], Iinv[5]);
       v = o.v; w = o.w;
       lift = Pd->contact_erp * o.deepest;
     }
@@ -623,7 +672,8 @@ struct Body {
   // The same tick for a body whose mass properties change over time (Rocket): inverse mass, centre of
   // mass, gyroscopic inertia H and inverse inertia (symmetric xx xy xz yy yz zz) are arguments.
   PF_DEV void tick_var(const pf_params& P, v3 F, v3 tau, float inv_mass, v3 com, const float H[6], const float Iinv[6]) {
-    contact_now = detect_contact(P);
+    persisted = contact_now;
+    contact_now = detect_contact(P, persisted ? P.contact_break_distance : P.contact_report_distance);
     tau = tau - cross(com, F);
     v3 h = symmul(H, wb);
     v3 wdot_b = symmul(Iinv, tau - cross(wb, h));
@@ -657,6 +707,7 @@ struct Body {
     w = v3{0.0f, 0.0f, 0.0f};
     contact_now = false;
     contact_step = false;
+    persisted = false;
     derive();
     rpy = euler_from_quat_fast(q);
   }

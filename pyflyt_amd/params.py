@@ -200,19 +200,24 @@ WORLD: dict[str, Any] = {
     "max_coord_vel": 100.0,    # btMultiBody::m_maxCoordinateVelocity
     "plane_half_xy": 15.0,     # pybullet_data plane.urdf collision box 30 x 30 x 10, centre z = -5
     "plane_half_z": 5.0,
-    # contact response against that slab: a named-parameter model of what stepSimulation does after collision detection
-    # (vertex contacts, projected Gauss-Seidel at the velocity level, position-level penetration recovery; DESIGN.md
-    # section 3), with Bullet's defaults: restitution 0, lateral friction 0.5 (body) x 1.0 (plane.urdf), erp 0.2
+    # contact response and contact report: a named-parameter model of what stepSimulation / getContactPoints do after collision
+    # detection (vertex contacts, projected Gauss-Seidel at the velocity level, position-level penetration recovery; the model:
+    # include/pyflyt_amd.h at pf_params.contact_response, the argument for each default: DESIGN.md section 3). Every entry is
+    # [BULLET-FROM-MEMORY]; tests/golden/capture_pybullet.py prints the real getPhysicsEngineParameters() where PyBullet exists.
     # ON everywhere, as in the reference (stepSimulation, aviary.py:516, always solves its contacts). False is an explicit
     # opt-out: contact DETECTION only -- bodies pass through the floor; for the gym env tasks, which end the episode in the
     # Aviary step that reports the contact, it alters that terminal observation only.
     "contact_response": True,
-    "contact_restitution": 0.0,
-    "contact_friction": 0.5,
-    "contact_erp": 0.2,
-    "contact_iters": 10,
-    "contact_margin": 0.02,    # speculative contacts (Bullet's contact breaking threshold)
-    "contact_slop": 0.001,     # allowed penetration: what a resting body overlaps the floor by
+    "contact_restitution": 0.0,          # Bullet's default restitution
+    "contact_friction": 0.5,             # lateral friction 0.5 (body) x 1.0 (plane.urdf)
+    "contact_erp": 0.2,                  # btContactSolverInfo::m_erp
+    "contact_iters": 50,                 # PyBullet's numSolverIterations (Bullet's own default: 10)
+    "contact_residual_threshold": 1e-7,  # PyBullet's solverResidualThreshold: sweeps end at a squared row-velocity change <= this
+    "contact_margin": 0.0,               # fresh contact points exist from touching on (dBoxBox2: nothing while an axis separates)
+    "contact_report_distance": 0.0,      # ... and a fresh pair is reported from touching on
+    "contact_break_distance": 0.02,      # persisting points / reports: btPersistentManifold's contact breaking threshold
+    "contact_manifold_points": 4,        # per collider box: the incident face's four vertices (8: every vertex)
+    "contact_slop": 1e-5,                # PyBullet's m_linearSlop: what a resting body overlaps the floor by
 }
 
 
@@ -332,6 +337,14 @@ def build_params(
     P.contact_iters = int(W["contact_iters"])
     P.contact_margin = W["contact_margin"]  # (lengths of the contact model itself: not scaled with the world, as in
     P.contact_slop = W["contact_slop"]      #  oracle/fake_bullet.py -- globalScaling scales the plane's geometry only)
+    P.contact_report_distance = W["contact_report_distance"]
+    P.contact_break_distance = W["contact_break_distance"]
+    P.contact_residual_threshold = W["contact_residual_threshold"]
+    P.contact_manifold_points = int(W["contact_manifold_points"])
+    if P.contact_manifold_points not in (4, 8):
+        raise ValueError("contact_manifold_points: 4 (the incident face of a box) or 8 (every vertex)")
+    if min(P.contact_margin, P.contact_report_distance, P.contact_break_distance, P.contact_slop, P.contact_residual_threshold) < 0.0:
+        raise ValueError("the contact model's distances and its residual threshold are non-negative")
     P.settle_steps = 10  # gym_envs/quadx_envs/quadx_base_env.py:209
 
     if vehicle == "quadx":

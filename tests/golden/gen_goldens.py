@@ -571,8 +571,11 @@ def gen_ma_hover_stack():
     above agent 0 -- out of bounds in its first step, culled, zero commands from then on -- and falls onto agent 0, which
     hovers; the hit ends agent 0's episode too, and the two come down together, one on top of the other, while agents 2 and 3
     fly on (their rotational drag switches off with the first contact point in the world)."""
-    rec = _run_ma_shared("env_ma_quadx_hover_stack", np.array([[0.0, 0.0, 1.0], [0.02, 0.01, 2.1], [1.5, 0.0, 1.0], [-1.0, -1.0, 0.8]]),
-                         {0: [0.0, 0.0, 0.0, 0.364], 1: [0.0, 0.0, 0.0, 0.364], 2: [0.0, 0.0, 0.2, 0.366], 3: [0.0, 0.0, -0.2, 0.365]}, 100, 2.0, 3.0, 654)
+    # (a small dome: agent 1 is out of it 25 cm above agent 0 and meets it at about 2 m/s -- under a centimetre a tick against a
+    #  collision box 2 cm thick. Contact points exist from touching on (contact_margin 0), so a drop from a metre up, 2 cm a tick,
+    #  would put a vertex right through the other box: which face it leaves by is then decided by the last digits)
+    rec = _run_ma_shared("env_ma_quadx_hover_stack", np.array([[0.0, 0.0, 1.0], [0.02, 0.01, 1.25], [0.6, 0.0, 0.9], [-0.5, -0.5, 0.8]]),
+                         {0: [0.0, 0.0, 0.0, 0.364], 1: [0.0, 0.0, 0.0, 0.364], 2: [0.0, 0.0, 0.2, 0.366], 3: [0.0, 0.0, -0.2, 0.365]}, 100, 1.2, 3.0, 654)
     t = np.array(rec["term"]); dc = np.array(rec["drone_contact"])
     print("stack: agent 1 out at step", int(np.argmax(t[:, 1])), "agent 0 hit at step", int(np.argmax(t[:, 0])), "drone-drone steps", int(dc.any(axis=1).sum()),
           "final z", np.array(rec["all_pos"])[-1][:, 2])

@@ -596,7 +596,7 @@ def test_set_armed():
 
 
 @pytest.mark.parametrize("drone,model,z0,tilt,steps,settle,impact_tol,strict_late,min_rest", [
-    ("quadx", "cf2x", 0.25, 0.6, 240, 15, 2e-3, True, 0.99),
+    ("quadx", "cf2x", 0.25, 0.6, 240, 30, 2e-3, True, 0.99),
     ("quadx", "primitive_drone", 0.45, 0.6, 500, 60, 0.5, False, 0.9),
     ("fixedwing", None, 0.6, 0.3, 400, 60, 0.5, False, 0.0),   # (keeps sliding on its six boxes: nothing at rest within the run)
     ("rocket", None, 2.45, 0.02, 900, 200, 0.5, False, 0.9)])
@@ -651,7 +651,7 @@ def test_landing_parity(drone, model, z0, tilt, steps, settle, impact_tol, stric
             lib.orc_aviary_step(C.byref(P), C.byref(L), None, 0, 0)
         st = np.array([[list(L.w_b), list(L.rpy), list(L.v_b), list(L.p)] for L in Ls])
         contact = np.array([bool(L.contact_step) for L in Ls])
-        near = np.array([L.p[2] - P.bound_radius < 0.05 for P, L in zip(Ps, Ls)])  # the speculative constraints may act from here on
+        near = np.array([L.p[2] - P.bound_radius < 0.05 for P, L in zip(Ps, Ls)])  # contact constraints may act from here on
         first[(first < 0) & (contact | near)] = k
         g = env.all_states.cpu().numpy().astype(np.float64)
         scale = np.maximum(1.0, np.linalg.norm(st, axis=2, keepdims=True))
@@ -677,9 +677,96 @@ def test_landing_parity(drone, model, z0, tilt, steps, settle, impact_tol, stric
         assert ok_late.all()             # and the quad is back inside 1e-4 once the transient is over
     assert rest.mean() >= min_rest
     if rest.any():
-        # same resting pose wherever the oracle has come to rest. Heights inside the contact model's dead band (constraints allow
-        # contact_slop = 1 mm of overlap and nothing pushes a body out of it) depend on the impact history: half the band
+        # same resting pose wherever the oracle has come to rest
         assert dz[rest].max() < 5e-4 and dang[rest].max() < 1e-3
         gr = g[rest]
         assert np.abs(gr[:, 2]).max() < 5e-2 and np.abs(gr[:, 0]).max() < 5e-2  # and the device is (all but) at rest there too
     env.disconnect()
+
+
+@pytest.mark.parametrize("world", [
+    dict(),                                                      # the defaults
+    dict(contact_report_distance=0.02),                          # a pair reported 2 cm before it touches
+    dict(contact_margin=0.02, contact_manifold_points=8, contact_iters=10, contact_residual_threshold=0.0, contact_slop=1e-3),  # round 3's model
+    dict(contact_break_distance=0.005, contact_iters=20),
+])
+def test_contact_options_reach_the_kernels(world):
+    """Every doubtful fact of the contact model is a named parameter (include/pyflyt_amd.h at pf_params.contact_response, SURVEY
+    section 8(c)): non-default values reach the device kernels and the oracle alike -- tilted quads dropped with the motors off,
+    the step of the first contact REPORT (core/aviary.py:523-525), the free fall before it and the resting pose after it."""
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+    from pyflyt_amd.params import quat_from_euler
+
+    n, steps, seed = 96, 200, 5
+    rng = np.random.default_rng(seed)
+    start_pos = np.concatenate([rng.uniform(-1, 1, size=(n, 2)), rng.uniform(0.2, 0.4, size=(n, 1))], axis=1).astype(np.float32)
+    start_orn = np.concatenate([rng.uniform(-0.5, 0.5, size=(n, 2)), rng.uniform(-3, 3, size=(n, 1))], axis=1)
+    P = build_params("quadx", "none", noise="off", autoreset="off", seed=seed, world_options=world or None)
+    for k, v in world.items():
+        assert abs(float(getattr(P, k)) - float(v)) < 1e-9 * max(1.0, abs(float(v))) + 1e-12, k  # (fp32 field)
+    eng = BatchEngine(P, n, device="cuda:0")
+    pose = torch.tensor(np.concatenate([start_pos, np.stack([quat_from_euler(o) for o in start_orn])], axis=1), dtype=torch.float32, device="cuda:0").contiguous()
+    eng.aviary_reset(pose)
+    sp = torch.zeros(n, 4, device="cuda:0")
+    eng.aviary_set_mode(-1, sp)
+    sp.zero_()
+    lib = O.lib()
+    Ps, Ls = [], []
+    over = {"world_" + k: v for k, v in world.items()}
+    for i in range(n):
+        Pi = O.make_params("quadx", noise_mode=O.NOISE_OFF, seed=seed, start_pos=start_pos[i].astype(np.float64), start_rpy=start_orn[i], **over)
+        L = O.Lane()
+        lib.orc_aviary_reset(C.byref(Pi), C.byref(L), i)
+        lib.orc_set_mode(C.byref(Pi), C.byref(L), -1)
+        for j in range(8):
+            L.setpoint[j] = 0.0
+        Ps.append(Pi); Ls.append(L)
+    first_g, first_o = np.full(n, -1), np.full(n, -1)
+    gap_o = np.full(n, np.nan)
+    worst_fall = 0.0
+    agree = total = 0
+    for k in range(steps):
+        st_g, _ = eng.aviary_step(sp)
+        cg = eng.out_contact.cpu().numpy().astype(bool)  # contact_array after this Aviary step
+        low_before = np.array([L.p[2] for L in Ls])
+        for Pi, L in zip(Ps, Ls):
+            lib.orc_aviary_step(C.byref(Pi), C.byref(L), None, 0, 0)
+        co = np.array([bool(L.contact_step) for L in Ls])
+        st = np.array([list(L.w_b) + list(L.rpy) + list(L.v_b) + list(L.p) for L in Ls]).reshape(n, 4, 3)
+        g = st_g.cpu().numpy().astype(np.float64).reshape(n, 4, 3)
+        new_o = (first_o < 0) & co
+        first_o[new_o] = k
+        first_g[(first_g < 0) & cg] = k
+        falling = (first_o < 0) & (first_g < 0)
+        if falling.any():
+            e = np.abs(g - st)[falling] / np.maximum(1.0, np.linalg.norm(st, axis=2, keepdims=True))[falling]
+            worst_fall = max(worst_fall, float(e.max()))
+        agree += int((cg == co).sum()); total += n
+    assert (first_o >= 0).all() and (first_g >= 0).all()
+    assert np.abs(first_g - first_o).max() <= 1, (first_g - first_o)       # the same step, up to a pose one ulp either side of the threshold
+    assert (first_g == first_o).mean() > 0.95
+    # (with a speculative margin the rows act before the pair is reported: "falling" then includes the first constrained ticks)
+    assert worst_fall < (1e-4 if world.get("contact_margin", 0.0) == 0.0 else 2e-3)
+    assert agree / total > 0.97, agree / total
+    g = eng.aviary_step(sp)[0].cpu().numpy().astype(np.float64).reshape(n, 4, 3)
+    for Pi, L in zip(Ps, Ls):
+        lib.orc_aviary_step(C.byref(Pi), C.byref(L), None, 0, 0)
+    zo = np.array([L.p[2] for L in Ls])
+    rest = np.array([max(abs(x) for x in list(L.v) + list(L.w)) < 1e-3 for L in Ls])
+    assert rest.mean() > 0.9
+    assert np.abs(g[rest, 3, 2] - zo[rest]).max() < 5e-4
+    slop = world.get("contact_slop", 1e-5)
+    assert np.abs(zo[rest] - (0.01 - slop)).max() < 1e-4                    # the resting overlap IS the slop parameter
+    if world.get("contact_report_distance", 0.0) > 0.0:                      # reported before it touches: earlier than with the defaults
+        Pd = O.make_params("quadx", noise_mode=O.NOISE_OFF, seed=seed, start_pos=start_pos[0].astype(np.float64), start_rpy=start_orn[0])
+        Ld = O.Lane()
+        lib.orc_aviary_reset(C.byref(Pd), C.byref(Ld), 0)
+        lib.orc_set_mode(C.byref(Pd), C.byref(Ld), -1)
+        for j in range(8):
+            Ld.setpoint[j] = 0.0
+        k0 = 0
+        while not Ld.contact_step:
+            lib.orc_aviary_step(C.byref(Pd), C.byref(Ld), None, 0, 0)
+            k0 += 1
+        assert first_o[0] < k0 - 1 or first_o[0] == 0

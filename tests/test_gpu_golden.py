@@ -22,6 +22,9 @@ RTOL = 1e-4
 # observations / states that carry a floor impact (the contact solver's impulses): see tests/test_gpu_parity.py and
 # tests/tools/fp32_contact_sensitivity.py -- an fp32 build of the oracle itself is this far from the fp64 one there
 RTOL_IMPACT = 5e-3
+# a 9.5 m rocket dropped at a tilt topples: the fp32 sensitivity of that transient (tests/tools/fp32_contact_sensitivity.py: an fp32
+# build of the ORACLE is up to 5e-1 away from the fp64 one there); measured 9.8e-3
+IMPACT_TOL = {"aviary_rocket_drop": 3e-2}
 N = 70
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -279,7 +282,7 @@ def test_aviary_fixture_replay(name):
         if bound is None:
             # from one Aviary step before the first reported contact on, the trajectory carries the contact solver's impulses
             touched = bool(g["contact"][: k + 2].any())
-            assert e < (RTOL_IMPACT if touched else RTOL), (name, k, e)
+            assert e < (IMPACT_TOL.get(name, RTOL_IMPACT) if touched else RTOL), (name, k, e)
         elif k < bound[0]:
             assert e < RTOL, (name, k, e)
         elif bound[1] is not None:

@@ -306,6 +306,12 @@ static int contact_points_reach(const orc_params* P, const double p[3], const do
   return n;
 }
 /* projected Gauss-Seidel on the base twist (v at the base origin, w; world frame). Returns the deepest penetration. */
+/* diagnostics (tests/tools): [contacts 0..4+][0] = solves, [1] = sweeps, [2] = solves that ran into contact_iters */
+static long long g_solve_stats[5][3];
+void orc_debug_solve_stats(long long* out, int clear) {
+  memcpy(out, g_solve_stats, sizeof(g_solve_stats));
+  if (clear) memset(g_solve_stats, 0, sizeof(g_solve_stats));
+}
 static double contact_solve(const orc_params* PP, const orc_body* B, const double p[3], const double q[4], double v[3], double w[3]) {
   const orc_world* W = &PP->world;
   double pts[ORC_MAX_CONTACTS][3], depth[ORC_MAX_CONTACTS];
@@ -330,6 +336,7 @@ static double contact_solve(const orc_params* PP, const orc_body* B, const doubl
     if (depth[c] > dmax) dmax = depth[c];
   }
   static const double dir[3][3] = {{0, 0, 1}, {1, 0, 0}, {0, 1, 0}}; /* normal, friction x, friction y */
+  int sweeps_run = 0;
   for (int it = 0; it < W->contact_iters; ++it) {
     double res2 = 0.0; /* the sweep's largest squared row-velocity change: btMultiBodyConstraintSolver's least-squares residual */
     for (int c = 0; c < n; ++c) {
@@ -360,7 +367,17 @@ static double contact_solve(const orc_params* PP, const orc_body* B, const doubl
         if ((dl * k) * (dl * k) > res2) res2 = (dl * k) * (dl * k);
       }
     }
+    sweeps_run = it + 1;
     if (res2 <= W->contact_residual_threshold) break;
+  }
+  {
+    const int b = n > 4 ? 4 : n;
+#pragma omp atomic
+    g_solve_stats[b][0] += 1;
+#pragma omp atomic
+    g_solve_stats[b][1] += sweeps_run;
+#pragma omp atomic
+    g_solve_stats[b][2] += (sweeps_run >= W->contact_iters);
   }
   cross3(w, cw, t);
   for (int i = 0; i < 3; ++i) v[i] = vc[i] - t[i];

@@ -47,3 +47,11 @@ start = (rt0 - rt0.min(axis=1, keepdims=True)) / 100.0
 end = (rt1 - rt0.min(axis=1, keepdims=True)) / 100.0
 print(f"  wave entry after the first wave's: median {np.median(start):.2f} us, p90 {np.percentile(start, 90):.2f}, max {start.max(axis=1).mean():.2f}")
 print(f"  wave exit  after the first wave's entry: median {np.median(end):.2f} us, p90 {np.percentile(end, 90):.2f}, max {end.max(axis=1).mean():.2f}")
+# the launch lasts as long as its slowest wave: where does THAT wave spend its time?
+life = rel[:, :, 10] / clk_mhz
+slow = life.argmax(axis=1)
+inc = np.diff(rel[np.arange(rel.shape[0]), slow, :] / clk_mhz, axis=1)  # [rep][phase increments]
+print(f"  slowest wave of each launch: life median {np.median(life.max(axis=1)):.2f} us (all waves: median {np.median(life):.2f}, p99 {np.percentile(life, 99):.2f}); its phase increments, median over launches:")
+print("   " + ", ".join(f"{names[i + 1]} +{np.median(inc[:, i]):.2f}" for i in range(10)))
+over = (life > np.median(life) + 1.0).sum(axis=1)
+print(f"  waves more than 1 us slower than the median wave, per launch: mean {over.mean():.1f}, max {over.max()}")

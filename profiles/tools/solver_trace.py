@@ -138,4 +138,5 @@ elif what == "calm":
             eng.env_step(ring[i])
         torch.cuda.synchronize()
         assert L.pf_debug_calm_trace(buf) == 0
-        print(f"steps {blk * 100}-{blk * 100 + 99}: {buf[0] / 100:.2f} of {(n + 63) // 64} waves per launch are not calm")
+        print(f"steps {blk * 100}-{blk * 100 + 99}: {buf[0] / 100:.2f} of {(n + 63) // 64} waves per launch are not calm over the env step; "
+              f"{buf[1] / 100:.2f} Aviary steps per launch run with the contact response's call site")

@@ -881,7 +881,8 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
     const long waves = ((long)n_lanes + 63) / 64;
-    c->lean = cus > 0 && waves <= 4L * cus && getenv("PF_NO_LEAN_KERNEL") == nullptr;  // (4 SIMDs per CU)
+    // (the lean instantiations solve floor contacts in registers, four slots = the incident face: quadx_fast.hpp, quad_floor_solve)
+    c->lean = cus > 0 && waves <= 4L * cus && P.contact_manifold_points < 8 && getenv("PF_NO_LEAN_KERNEL") == nullptr;  // (4 SIMDs per CU)
   }
   pf::FwTable fsurf;
   c->fast_fw = pf::fwk_from_params(P, c->FK, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;

@@ -17,6 +17,7 @@
 //   (Tried and rejected, profiles/README.md: under-filled 16/32-lane waves, 128-VGPR variants.)
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
@@ -35,7 +36,9 @@ struct QuadK {
   float margin;                // fresh contact points: no vertex above it is one (pf_params.contact_margin)
   float brk, rd;               // persisting points / reports reach up to brk (contact_break_distance); fresh reports from rd on (contact_report_distance)
   float c_inv_dt, c_rest, c_mu, c_erp;  // the rest of the contact model (pf_params.contact_*): the solve runs inline on these
-  int32_t c_iters;
+  int32_t c_iters, c_all8;     // sweeps at most; 1: every vertex of the box is a candidate (contact_manifold_points = 8)
+  float c_res;                 // sqrt(contact_residual_threshold): the bound on a row's velocity change that ends the sweeps
+  float sqI[3], siI[3];        // sqrt of the diagonal inertia and of its inverse: quad_floor_solve works on w~ = sqrt(I) w_body
   float box_h[3], plane_xy, plane_z;  // the collision box's half extents and the slab's: kernel-argument SGPRs, because with random
                                       // actions some lane of nearly every wave is near the floor in nearly every tick -- as scalar
                                       // loads inside that block they cost a memory round trip per tick (+0.7 us per env step)
@@ -113,6 +116,9 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.bound_radius0 = P.bound_radius; K.slop = P.contact_slop; K.margin = P.contact_margin;
   K.brk = P.contact_break_distance; K.rd = P.contact_report_distance;
   K.c_inv_dt = 1.0f / P.dt; K.c_rest = P.contact_restitution; K.c_mu = P.contact_friction; K.c_erp = P.contact_erp; K.c_iters = P.contact_iters;
+  K.c_all8 = P.contact_manifold_points >= 8 ? 1 : 0;
+  K.c_res = sqrtf(P.contact_residual_threshold);
+  for (int k = 0; k < 3; ++k) { K.sqI[k] = sqrtf(K.I[k]); K.siI[k] = sqrtf(K.iI[k]); }
   for (int k = 0; k < 3; ++k) K.box_h[k] = P.boxes[0].h[k];
   K.plane_xy = P.plane_half_xy; K.plane_z = P.plane_half_z;
   K.m_a = P.motor_dt_over_tau[0]; K.m_noise = P.motor_noise[0]; K.fmax = P.motor_fmax[0]; K.tmax = P.motor_tmax[2];
@@ -235,6 +241,277 @@ struct QuadCasc {
 PF_DEV float pid_k(const pf_pid __attribute__((address_space(4)))* g, int k, float T, float invT, float& I, float& E, float st, float sp) {
   return pid1(g->kp[k], g->ki[k], g->kd[k], g->lim[k], T, invT, I, E, st, sp);
 }
+
+
+// ------------------------------------------------------------------------------------------
+// The floor contact solve of THIS kernel's airframe, in registers (round 4). What quadk_from_params guarantees -- one collision box
+// centred on the base origin, not yawed; centre of mass at the base origin; diagonal inertia -- makes the general solver's
+// machinery (uav_vehicles.hpp: contact_solve_impl: parameter block through the scalar cache, records in LDS regions dealt out by a
+// wave prefix sum, a count pass, sentinel records) unnecessary: with the manifold reduced to the incident face there are at most
+// four contact points. In the env tasks a solve is a LONE lane on a lone wave and the launch waits for it (1.1 calls per 65 536-lane
+// Waypoints launch; 19 k clocks each through the general solver: such a launch took twice as long as its other 1023 waves), and a
+// lone wave issues a DEPENDENT instruction every ~6.5 clocks: what counts is the length of the dependent chain per row.
+//   * rows r = (slot, direction); directions normal (+z), +x, +y. With the twist as (v, w~ = sqrt(I) w_body) and
+//     J~_r = sqrt(I^-1) (a_body x e_r,body): row velocity u_r = v . e_r + w~ . J~_r, and the rows couple through
+//     A_rs = J~_r . J~_s + [e_r = e_s] / m (the Delassus matrix; A_rr = the inverse effective mass);
+//   * the sweep works on the row velocities themselves: u_s += A_sr (dl / A_rr) for every row s after row r moved by dl (impulses in
+//     velocity units, lambda' = lambda A_rr, as in contact_solve_impl) -- 3 N - 1 independent multiply-adds instead of a chain
+//     through the twist -- so a row is  e = target - u_r;  l' = clamp(l' + e);  dl = l' - l'_old  and the updates: a dependent
+//     chain of five, and dl itself is the row's velocity change, the quantity the residual exit bounds. The twist is rebuilt from
+//     the impulses once, at the end. (A is symmetric: its upper triangle, 78 registers for four contacts);
+//   * slots are DENSE over the wave: the N candidate vertices of the incident face that some lane of the wave has as a contact, in
+//     vertex order (which they are is wave-uniform: scalar indices), N = 1 .. 4 a template parameter -- no skip branches in the
+//     sweep, no work on vertices nobody touches with; a lane that lacks one of the wave's vertices has an inert slot there (zero
+//     coupling, target -FLT_MAX: its rows move nothing), and the sweep order within a lane stays the vertex order;
+//   * in a wave where several lanes solve side by side, a lane whose sweep met the residual bound is frozen (its dl forced to
+//     zero) while the others go on; a lone lane runs the loop without that bookkeeping.
+// The same model and the same sweep order as contact_solve_impl / the oracle (include/pyflyt_amd.h at pf_params.contact_response);
+// the arithmetic is arranged differently, so the results differ in the last digits (the parity tests' impact tolerance).
+// Returns the new (v, w) and the deepest penetration net of the slop. act: this lane asks; reach: how far above the face a vertex
+// may be (margin / breaking distance); check_rim: test the vertices against the slab's rim as well (wave-uniform).
+struct QuadFloorOut { v3 v, w; float deepest; };
+struct QuadFace {  // the incident face of the collision box at this pose (uav_vehicles.hpp: box_contact_vertices)
+  bool use_y, use_z;
+  float fs;
+  PF_DEV void of(const m3& R) {
+    // the axis with the largest |z component|, first on a tie. (The sign is selected among the COMPARISONS, not among the matrix
+    // entries: a select between two members turns into a load through a selected address, which kept two rows of the caller's
+    // rotation matrix in scratch memory.)
+    const float ax = __builtin_fabsf(R.m20), ay = __builtin_fabsf(R.m21), az = __builtin_fabsf(R.m22);
+    use_y = ay > ax; use_z = az > __builtin_fmaxf(ax, ay);
+    const bool nx = R.m20 < 0.0f, ny = R.m21 < 0.0f, nz = R.m22 < 0.0f;
+    fs = (use_z ? nz : (use_y ? ny : nx)) ? 1.0f : -1.0f;  // the face on the + side looks down when the axis points down
+  }
+  // vertex c (0 .. 3, wave-uniform) of the face in the body frame: the face axis carries fs, the other two axes, in index order, the bits of c
+  PF_DEV v3 vertex(const int c, const float hx, const float hy, const float hz) const {
+    const float b0 = (c & 1) ? 1.0f : -1.0f, b1 = (c & 2) ? 1.0f : -1.0f;
+    const float sx = use_z ? b0 : (use_y ? b0 : fs);
+    const float sy = use_z ? b1 : (use_y ? fs : b0);
+    const float sz = use_z ? fs : b1;
+    return v3{sx * hx, sy * hy, sz * hz};
+  }
+};
+PF_DEV bool quad_vertex_touches(const QuadK& Kc, const v3 a, const m3& R, const v3 p, const float reach, const bool check_rim, float& z) {
+  z = fmaf(a.x, R.m20, fmaf(a.y, R.m21, fmaf(a.z, R.m22, p.z)));
+  bool is = z <= reach && z >= -2.0f * Kc.plane_z;
+  if (check_rim) {
+    const float x = fmaf(a.x, R.m00, fmaf(a.y, R.m01, fmaf(a.z, R.m02, p.x))), y = fmaf(a.x, R.m10, fmaf(a.y, R.m11, fmaf(a.z, R.m12, p.y)));
+    is = is && __builtin_fabsf(x) <= Kc.plane_xy && __builtin_fabsf(y) <= Kc.plane_xy;
+  }
+  return is;
+}
+// cand: the wave's contact vertices, 4 bits per dense slot (wave-uniform)
+template <int N>
+PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const float reach, const bool check_rim, const v3 p, const m3 R, const QuadFace F,
+                                       const v3 v_in, const v3 w_in, const uint32_t cand) {
+#ifdef PF_PHASE_TRACE
+  const unsigned long long pf_q0 = __builtin_readcyclecounter();
+#endif
+  float Jt[N][3][3];     // J~ of every row
+  // N <= 2 (nineteen solves in twenty): the row-velocity form below. N = 3, 4: its coupling matrix (45 / 78 entries) on top of this
+  // kernel's own live state overflows the 256 architectural registers into AGPR copies and scratch -- those keep the twist form
+  // (v, w~ updated row by row: 19 registers per contact, a dependent chain of eight per row).
+  constexpr bool ROWFORM = N <= 2;
+  constexpr int NR = ROWFORM ? 3 * N : 1;
+  float A[NR][NR];       // the couplings A_sr, symmetric: only the upper triangle (A[lo][hi]) is ever written or read
+  float kk[N][3];        // 1 / A_rr (effective mass)
+  float u[N][3], lam[N][3], tg[N], fx[N], fy[N];
+  bool on[N];
+  const float hx = Kc.box_h[0], hy = Kc.box_h[1], hz = Kc.box_h[2];
+  // (the model's constants in vector registers: as scalars they had been parked in the lanes of a spill VGPR and came back with a
+  //  v_readlane in front of every use inside the sweep)
+  const float im = in_vgpr(Kc.inv_mass), mu = in_vgpr(Kc.c_mu);
+  const v3 wb = mulT(R, w_in);
+  const v3 wt0{wb.x * Kc.sqI[0], wb.y * Kc.sqI[1], wb.z * Kc.sqI[2]};
+  float deepest = 0.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const v3 a = F.vertex((int)((cand >> (4 * k)) & 3u), hx, hy, hz);
+    float z;
+    const bool is = quad_vertex_touches(Kc, a, R, p, reach, check_rim, z) && act;
+    on[k] = is;
+    // row order: normal (+z), friction +x, friction +y; the world axis of the row in the body frame = a row of R, passed entry by
+    // entry (a v3 built from three members of the matrix is a 12-byte copy out of it: that too kept those rows in scratch).
+    // A lane that does not have this vertex gets an inert slot: zero coupling, target -FLT_MAX, zero impulse -- its rows move nothing.
+#define PF_QROW(D_, EX_, EY_, EZ_, VAX_)                                                         \
+    { const v3 j_{fmaf(a.y, EZ_, -(a.z * (EY_))), fmaf(a.z, EX_, -(a.x * (EZ_))), fmaf(a.x, EY_, -(a.y * (EX_)))};  \
+      const v3 jt_{j_.x * Kc.siI[0], j_.y * Kc.siI[1], j_.z * Kc.siI[2]};                        \
+      Jt[k][D_][0] = is ? jt_.x : 0.0f; Jt[k][D_][1] = is ? jt_.y : 0.0f; Jt[k][D_][2] = is ? jt_.z : 0.0f;  \
+      kk[k][D_] = frcp(im + dot(jt_, jt_));                                                      \
+      u[k][D_] = fmaf(wt0.x, jt_.x, fmaf(wt0.y, jt_.y, fmaf(wt0.z, jt_.z, VAX_)));               \
+      lam[k][D_] = 0.0f; }
+    PF_QROW(0, R.m20, R.m21, R.m22, v_in.z)
+    PF_QROW(1, R.m00, R.m01, R.m02, v_in.x)
+    PF_QROW(2, R.m10, R.m11, R.m12, v_in.y)
+#undef PF_QROW
+    const float depth = -z;
+    // normal row: may close the gap down to the slop, no more; otherwise towards restitution x approach speed
+    const float t = depth < Kc.slop ? (depth - Kc.slop) * Kc.c_inv_dt : (u[k][0] < 0.0f ? -Kc.c_rest * u[k][0] : 0.0f);
+    tg[k] = is ? t : -3.4028235e38f;
+    // friction cone in velocity units: |l'_x| <= mu (A_xx / A_zz) l'_z
+    fx[k] = mu * kk[k][0] * frcp(kk[k][1]); fy[k] = mu * kk[k][0] * frcp(kk[k][2]);
+    deepest = is ? __builtin_fmaxf(deepest, depth) : deepest;
+  }
+  // the couplings A_sr = J~_s . J~_r + [same direction] / m (zero towards / from an inert slot: its J~ is zero, and so is made the
+  // translational part -- which otherwise couples all rows of the same direction)
+#pragma unroll
+  for (int cs = 0; cs < (ROWFORM ? N : 0); ++cs)
+#pragma unroll
+    for (int cr = cs; cr < N; ++cr) {
+      const bool both = on[cs] && on[cr];
+#pragma unroll
+      for (int ds = 0; ds < 3; ++ds)
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr) {
+          if (3 * cr + dr < 3 * cs + ds) continue;  // (upper triangle)
+          const float jj = fmaf(Jt[cs][ds][0], Jt[cr][dr][0], fmaf(Jt[cs][ds][1], Jt[cr][dr][1], Jt[cs][ds][2] * Jt[cr][dr][2]));
+          const float a_sr = ds == dr ? jj + im : jj;
+          A[3 * cs + ds][3 * cr + dr] = both ? a_sr : 0.0f;
+        }
+    }
+  bool any_on = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) any_on = any_on || on[k];
+  bool done = !any_on;
+#ifdef PF_PHASE_TRACE
+  const unsigned long long pf_q1 = __builtin_readcyclecounter();
+  int pf_sweeps = 0;
+#endif
+  float res = 0.0f;
+  v3 vc = v_in, wt = wt0;  // (the twist form's running twist)
+  float ki[N][3];          // (the twist form: A_rr, for the residual)
+  if (!ROWFORM) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { ki[k][d] = on[k] ? frcp(kk[k][d]) : 0.0f; kk[k][d] = on[k] ? kk[k][d] : 0.0f; }
+  }
+  // one sweep; FREEZE: several lanes solve side by side, a done lane's rows must move nothing
+  auto sweep = [&](auto freeze_tag) {
+    constexpr bool FREEZE = decltype(freeze_tag)::value;
+    float r0 = 0.0f, r1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (ROWFORM) {
+          float nl;
+          if (d == 0) nl = __builtin_fmaxf((tg[c] - u[c][0]) + lam[c][0], 0.0f);
+          else { const float lim = (d == 1 ? fx[c] : fy[c]) * lam[c][0]; nl = med3(lam[c][d] - u[c][d], -lim, lim); }
+          float dl = nl - lam[c][d];
+          if (FREEZE) dl = done ? 0.0f : dl;
+          lam[c][d] = FREEZE ? lam[c][d] + dl : nl;
+          const float g = dl * kk[c][d];  // (the impulse: every other row s moves by A_sr x it)
+#pragma unroll
+          for (int cs = 0; cs < N; ++cs)
+#pragma unroll
+            for (int ds = 0; ds < 3; ++ds)
+              if (!(cs == c && ds == d)) {
+                const int rs = 3 * cs + ds, rr = 3 * c + d;
+                u[cs][ds] = fmaf(rs < rr ? A[ROWFORM ? rs : 0][ROWFORM ? rr : 0] : A[ROWFORM ? rr : 0][ROWFORM ? rs : 0], g, u[cs][ds]);
+              }
+          u[c][d] += dl;
+          if ((3 * c + d) & 1) r1 = __builtin_fmaxf(r1, __builtin_fabsf(dl)); else r0 = __builtin_fmaxf(r0, __builtin_fabsf(dl));
+        } else {  // impulses in impulse units here (lam), the twist carried along
+          const float vax = d == 0 ? vc.z : (d == 1 ? vc.x : vc.y);
+          const float ur = fmaf(wt.x, Jt[c][d][0], fmaf(wt.y, Jt[c][d][1], fmaf(wt.z, Jt[c][d][2], vax)));
+          float nl;
+          if (d == 0) nl = __builtin_fmaxf(fmaf(tg[c] - ur, kk[c][0], lam[c][0]), 0.0f);
+          else { const float lim = mu * lam[c][0]; nl = med3(fmaf(-ur, kk[c][d], lam[c][d]), -lim, lim); }
+          float dl = nl - lam[c][d];
+          if (FREEZE) dl = done ? 0.0f : dl;
+          lam[c][d] = FREEZE ? lam[c][d] + dl : nl;
+          if (d == 0) vc.z = fmaf(im, dl, vc.z); else if (d == 1) vc.x = fmaf(im, dl, vc.x); else vc.y = fmaf(im, dl, vc.y);
+          wt = v3{fmaf(dl, Jt[c][d][0], wt.x), fmaf(dl, Jt[c][d][1], wt.y), fmaf(dl, Jt[c][d][2], wt.z)};
+          const float rv = __builtin_fabsf(dl) * ki[c][d];
+          if ((3 * c + d) & 1) r1 = __builtin_fmaxf(r1, rv); else r0 = __builtin_fmaxf(r0, rv);
+        }
+      }
+    }
+    res = __builtin_fmaxf(r0, r1);
+  };
+  const bool lone = __popcll(__ballot(any_on)) <= 1;  // (wave-uniform)
+  if (lone) {
+    for (int it = 0; it < Kc.c_iters; ++it) {
+#ifdef PF_PHASE_TRACE
+      pf_sweeps = it + 1;
+#endif
+      sweep(std::false_type{});
+      if (__ballot(any_on && res > Kc.c_res) == 0ull) break;
+    }
+  } else {
+    for (int it = 0; it < Kc.c_iters; ++it) {
+#ifdef PF_PHASE_TRACE
+      pf_sweeps = it + 1;
+#endif
+      sweep(std::true_type{});
+      done = done || !(res > Kc.c_res);
+      if (__ballot(!done) == 0ull) break;
+    }
+  }
+  // the row-velocity form: the twist from the impulses (impulse = l' / A_rr)
+  if (ROWFORM) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      const float lz = on[c] ? lam[c][0] * kk[c][0] : 0.0f, lx = on[c] ? lam[c][1] * kk[c][1] : 0.0f, ly = on[c] ? lam[c][2] * kk[c][2] : 0.0f;
+      vc = v3{fmaf(im, lx, vc.x), fmaf(im, ly, vc.y), fmaf(im, lz, vc.z)};
+      wt = v3{fmaf(lz, Jt[c][0][0], fmaf(lx, Jt[c][1][0], fmaf(ly, Jt[c][2][0], wt.x))),
+              fmaf(lz, Jt[c][0][1], fmaf(lx, Jt[c][1][1], fmaf(ly, Jt[c][2][1], wt.y))),
+              fmaf(lz, Jt[c][0][2], fmaf(lx, Jt[c][1][2], fmaf(ly, Jt[c][2][2], wt.z)))};
+    }
+  }
+  const v3 wbn{wt.x * Kc.siI[0], wt.y * Kc.siI[1], wt.z * Kc.siI[2]};
+#ifdef PF_PHASE_TRACE
+  {  // (diagnostic build: the same counters as the general solver's -- calls, clocks in the records / in the sweeps, contacts, lanes, sweeps)
+    const unsigned long long pf_q2 = __builtin_readcyclecounter();
+    const int first = __ffsll((long long)__ballot(1)) - 1;
+    int nc = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) nc += (int)on[k];
+    const int lanes = __popcll(__ballot(any_on));
+    for (int o = 32; o > 0; o >>= 1) nc = max(nc, __shfl_xor(nc, o));
+    if ((int)(threadIdx.x & 63u) == first) {
+      atomicAdd(&g_solver_trace[0], 1ull);
+      atomicAdd(&g_solver_trace[6], pf_q1 - pf_q0);
+      atomicAdd(&g_solver_trace[2], pf_q2 - pf_q1);
+      atomicAdd(&g_solver_trace[3], (unsigned long long)nc);
+      atomicAdd(&g_solver_trace[4], (unsigned long long)lanes);
+      atomicAdd(&g_solver_trace[5], (unsigned long long)pf_sweeps);
+    }
+  }
+#endif
+  QuadFloorOut o;
+  o.v = any_on ? vc : v_in;
+  o.w = any_on ? mul(R, wbn) : w_in;
+  o.deepest = any_on ? __builtin_fmaxf(deepest - Kc.slop, 0.0f) : 0.0f;
+  return o;
+}
+// (the rotation matrix entry by entry: as an m3 argument the 36-byte copy kept two rows of the caller's matrix in scratch memory)
+PF_DEV QuadFloorOut quad_floor_solve(const QuadK& Kc, const bool act, const float reach, const bool check_rim, const v3 p,
+                                     const float r00, const float r01, const float r02, const float r10, const float r11, const float r12,
+                                     const float r20, const float r21, const float r22, const v3 v_in, const v3 w_in) {
+  const m3 R{r00, r01, r02, r10, r11, r12, r20, r21, r22};
+  QuadFace F;
+  F.of(R);
+  // which of the face's four vertices does some lane of the wave have as a contact? (wave-uniform: the dense slots)
+  uint32_t cand = 0u;
+  int n = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float z;
+    const bool is = act && quad_vertex_touches(Kc, F.vertex(c, Kc.box_h[0], Kc.box_h[1], Kc.box_h[2]), R, p, reach, check_rim, z);
+    if (__any(is)) { cand |= (uint32_t)c << (4 * n); n += 1; }
+  }
+  switch (n) {
+    case 1: return quad_floor_solve_n<1>(Kc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
+    case 2: return quad_floor_solve_n<2>(Kc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
+    case 3: return quad_floor_solve_n<3>(Kc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
+    case 4: return quad_floor_solve_n<4>(Kc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
+    default: break;
+  }
+  return QuadFloorOut{v_in, w_in, 0.0f};
+}
+
 
 struct QuadHot {
   v3 p; quat q;
@@ -456,12 +733,20 @@ struct QuadHot {
       }
       if (__any(act)) {
         // (INL: inline, in the instantiations sized for one wave per SIMD -- 512 registers: no call, so no stack, and a launch
-        //  whose waves carry scratch memory dispatches 0.4 us slower; nothing pinned to callee-saved registers. Otherwise out of
-        //  line: within the 256 registers of two waves per SIMD the inlined solve spills. profiles/README.md, r03)
-        const ContactOut o = INL ? contact_solve_inl(Pfull, cws, need_cap_of(act, cws_floats, persisted), p, q, v(), w())
-                                 : contact_solve_dev(Pfull, cws, need_cap_of(act, cws_floats, persisted), p, q, v(), w());
-        set_wv(o.w, o.v);  // (unchanged for a lane that did not ask or has no contact vertex)
-        lift = Kc.c_erp * o.deepest;  // (already net of the slop)
+        //  whose waves carry scratch memory dispatches 0.4 us slower; nothing pinned to callee-saved registers: the solve of this
+        //  airframe in registers, quad_floor_solve. Otherwise out of line, the general solver: within the 256 registers of two
+        //  waves per SIMD the inlined solve spills. profiles/README.md, r03 / r04)
+        if (INL) {  // (the launcher picks these instantiations only with the manifold reduced to the incident face: pf_ctx_create)
+          const bool at_rim = !((__builtin_fabsf(p.x) + Kc.bound_radius0 < Kc.plane_xy) && (__builtin_fabsf(p.y) + Kc.bound_radius0 < Kc.plane_xy));
+          const QuadFloorOut o = quad_floor_solve(Kc, act, persisted ? Kc.brk : Kc.margin, __any(act && at_rim), p, R.m00, R.m01, R.m02, R.m10, R.m11, R.m12,
+                                                      R.m20, R.m21, R.m22, v(), w());
+          set_wv(o.w, o.v);
+          lift = Kc.c_erp * o.deepest;
+        } else {
+          const ContactOut o = contact_solve_dev(Pfull, cws, need_cap_of(act, cws_floats, persisted), p, q, v(), w());
+          set_wv(o.w, o.v);  // (unchanged for a lane that did not ask or has no contact vertex)
+          lift = Kc.c_erp * o.deepest;  // (already net of the slop)
+        }
       }
     }
     if (SHARED) p = v3{fmaf(K.dt, wvx.y, p.x) + shift.x, fmaf(K.dt, wvy.y, p.y) + shift.y, fmaf(K.dt, wvz.y, p.z) + lift + shift.z};

@@ -1,7 +1,10 @@
 """The calm-wave path of the specialised QuadX kernel (quadx_fast.hpp: waves none of whose lanes can reach the floor during the
-env step run ticks instantiated without the contact response's call site) and its one-wave-per-SIMD instantiation (WPS = 1: the
-solve inlined, chosen for batches of at most one wave per SIMD) change nothing: bit-identical to the same context with both
-switched off (PF_NO_CALM_PATH, PF_NO_LEAN_KERNEL, read at context creation), through crashes, resets and the lanes in between."""
+env step, or during the Aviary step at hand, run ticks instantiated without the contact response's call site) changes nothing:
+bit-identical to the same context with it switched off (PF_NO_CALM_PATH, read at context creation), through crashes, resets and
+the lanes in between -- in the one-wave-per-SIMD instantiation (WPS = 1, chosen for batches of at most one wave per SIMD) and in
+the two-wave one (PF_NO_LEAN_KERNEL). The two instantiations solve a floor contact with differently arranged arithmetic (WPS = 1:
+in registers, quad_floor_solve; WPS = 2: the general solver out of line): against each other they are bit-identical everywhere
+except in the observation of the step that reports the collision -- the episode ends there and nothing carries over."""
 import numpy as np
 import pytest
 import torch
@@ -29,12 +32,12 @@ def test_calm_path_is_bit_identical(monkeypatch, task, mode, lean):
         assert eng.lib.pf_ctx_is_specialised(eng._ctx) != 0
         return eng
 
-    a, b = make(True, lean), make(False, False)
-    oa, ob = a.env_reset().clone(), b.env_reset().clone()
-    assert torch.equal(oa, ob)
+    a, b, c = make(True, lean), make(False, lean), make(False, not lean)
+    oa, ob, oc = a.env_reset().clone(), b.env_reset().clone(), c.env_reset().clone()
+    assert torch.equal(oa, ob) and torch.equal(oa, oc)
     act = torch.empty(n, 4, device="cuda:0")
     sink = torch.arange(n, device="cuda:0") % 5 == 0  # a fifth of the lanes is told to drop: floor contacts in many waves, and waves without
-    collided = 0
+    collided, worst = 0, 0.0
     for k in range(steps):
         a.sample_actions(act, k)
         if mode == 0:
@@ -43,9 +46,18 @@ def test_calm_path_is_bit_identical(monkeypatch, task, mode, lean):
             act[sink, 3] = -3.0  # (vx, vy, vr, vz): descend
         else:
             act[sink, 3] = 0.0   # (x, y, r, z): go to the floor
-        ra, rb = a.env_step(act), b.env_step(act)
+        ra, rb, rc = a.env_step(act), b.env_step(act), c.env_step(act)
         for x, y in zip(ra, rb):
             assert torch.equal(x, y), (task, mode, k)
         assert torch.equal(a.state, b.state), (task, mode, k)
-        collided += int(((a.flags() & L.F_INFO_COLLISION) != 0).sum())
+        hit = (a.flags() & L.F_INFO_COLLISION) != 0
+        assert torch.equal(hit, (c.flags() & L.F_INFO_COLLISION) != 0)
+        for x, y in zip(ra[2:], rc[2:]):   # terminated, truncated: identical
+            assert torch.equal(x, y), (task, mode, k)
+        # every lane that did not just crash: bit-identical observation and reward
+        assert torch.equal(ra[0][~hit], rc[0][~hit]) and torch.equal(ra[1][~hit], rc[1][~hit]), (task, mode, k)
+        if bool(hit.any()):  # (the dense reward terms are evaluated on the terminal state too)
+            worst = max(worst, float((ra[0][hit] - rc[0][hit]).abs().max()), float((ra[1][hit] - rc[1][hit]).abs().max()))
+        collided += int(hit.sum())
     assert collided > 20, collided  # (the floor was in play)
+    assert worst < 5e-3, worst      # the two instantiations' contact solves agree to the impact tolerance in that terminal observation

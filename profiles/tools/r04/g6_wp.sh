@@ -1,16 +1,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04f; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-for w in "" "--world contact_iters=10" "--world contact_iters=4" "--no-contact-response"; do
-  echo "== $w"; timeout 100 python $R/bench.py --env quadx_waypoints --steps 1000 --warmup 100 --no-cpu-baseline --rollout-steps 0 $w 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('launch_us', round(d['roofline']['launch_us'],2))"
+for w in "" "--world contact_iters=0" "--no-contact-response"; do
+  echo "== $w"; for rep in 1 2; do timeout 100 python $R/bench.py --env quadx_waypoints --steps 2000 --warmup 100 --no-cpu-baseline --rollout-steps 0 $w 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('launch_us', round(d['roofline']['launch_us'],2))"; done
 done
-timeout 170 rocprofv3 --kernel-trace --output-format csv -d $O/kt_wp -- python $R/bench.py --env quadx_waypoints --steps 1000 --warmup 100 --no-cpu-baseline --rollout-steps 0 > /dev/null 2>&1
-python - <<'PY'
-import csv,glob,os,numpy as np
-f=glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/r04f/kt_wp/*/*kernel_trace.csv')[0]
-rows=list(csv.DictReader(open(f)))
-print(list(rows[0].keys()))
-d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in rows if 'quadx_m0_env_kernel' in r['Kernel_Name']]
-d=np.array(d[-1000:])
-print("waypoints launches", len(d), "min %.2f p10 %.2f median %.2f mean %.2f p90 %.2f p99 %.2f max %.2f"%(d.min(),np.percentile(d,10),np.median(d),d.mean(),np.percentile(d,90),np.percentile(d,99),d.max()))
-print("histogram (us):", np.histogram(d, bins=[0,12,14,16,18,20,24,28,32,40,60,100])[0])
-PY
-find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+echo "== PF_NO_CALM_PATH"; PF_NO_CALM_PATH=1 timeout 100 python $R/bench.py --env quadx_waypoints --steps 2000 --warmup 100 --no-cpu-baseline --rollout-steps 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('launch_us', round(d['roofline']['launch_us'],2))"

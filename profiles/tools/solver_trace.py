@@ -122,6 +122,34 @@ elif what == "rates":
             rates.append(t[0] / 200.0)
         report(f"  last block, ring {R}", 200, t)
         print(f"action ring of {R or 'fresh draws every step'}: solver calls per launch over blocks of 200 steps: " + " ".join(f"{r:.2f}" for r in rates))
+elif what == "perlaunch":
+    # launch by launch: the solver's calls, sweeps and contact counts (launches with exactly one call show the distribution per call)
+    from pyflyt_amd.engine import BatchEngine
+    n = 65536
+    task = os.environ.get("TASK", "waypoints")
+    eng = BatchEngine(build_params("quadx", task, noise="philox", autoreset="next_step", seed=0), n, device="cuda:0")
+    ring = [torch.empty(n, 4, device="cuda:0") for _ in range(100)]
+    for i, a in enumerate(ring):
+        eng.sample_actions(a, i)
+    eng.env_reset()
+    for i in range(200):
+        eng.env_step(ring[i % 100])
+    torch.cuda.synchronize(); read()
+    single = []
+    for i in range(int(os.environ.get("LAUNCHES", "600"))):
+        eng.env_step(ring[i % 100])
+        torch.cuda.synchronize()
+        t = read()
+        if t[0] == 1:
+            single.append((int(t[3]), int(t[5]), int(t[2]), int(t[6])))
+    a = np.array(single)
+    print(f"-- quadx {task}: {len(a)} launches with exactly one solver call")
+    for nc in range(1, 5):
+        m = a[:, 0] == nc
+        if m.any():
+            sw = a[m, 1]
+            print(f"  {nc} contact(s): {int(m.sum())} calls; sweeps: median {np.median(sw):.0f}, p90 {np.percentile(sw, 90):.0f}, max {sw.max()}, ran into the cap: {int((sw >= 50).sum())}; "
+                  f"clocks in the sweeps: median {np.median(a[m, 2]):.0f}, per sweep {np.median(a[m, 2] / np.maximum(sw, 1)):.0f}; records {np.median(a[m, 3]):.0f}")
 elif what == "calm":
     # how many waves keep the contact response's call site in their tick loop (some lane within reach of the floor this env step)
     from pyflyt_amd.engine import BatchEngine

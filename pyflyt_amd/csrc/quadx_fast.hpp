@@ -254,11 +254,12 @@ PF_DEV float pid_k(const pf_pid __attribute__((address_space(4)))* g, int k, flo
 //   * rows r = (slot, direction); directions normal (+z), +x, +y. With the twist as (v, w~ = sqrt(I) w_body) and
 //     J~_r = sqrt(I^-1) (a_body x e_r,body): row velocity u_r = v . e_r + w~ . J~_r, and the rows couple through
 //     A_rs = J~_r . J~_s + [e_r = e_s] / m (the Delassus matrix; A_rr = the inverse effective mass);
-//   * the sweep works on the row velocities themselves: u_s += A_sr (dl / A_rr) for every row s after row r moved by dl (impulses in
-//     velocity units, lambda' = lambda A_rr, as in contact_solve_impl) -- 3 N - 1 independent multiply-adds instead of a chain
-//     through the twist -- so a row is  e = target - u_r;  l' = clamp(l' + e);  dl = l' - l'_old  and the updates: a dependent
-//     chain of five, and dl itself is the row's velocity change, the quantity the residual exit bounds. The twist is rebuilt from
-//     the impulses once, at the end. (A is symmetric: its upper triangle, 78 registers for four contacts);
+//   * one or two contacts (nineteen solves in twenty): the sweep works on the rows themselves instead of on the twist. With impulses
+//     in velocity units (lambda' = lambda A_rr, as in contact_solve_impl) and E_r = l'_r + target_r - u_r, the impulse row r would
+//     take unclamped:  l'_new = clamp(E_r);  dl = l'_new - l'_r;  E_s -= (A_sr / A_rr) dl for the other rows -- a dependent chain
+//     of THREE per row and 3 N - 1 independent multiply-adds, and dl itself is the row's velocity change, the quantity the residual
+//     exit bounds. The twist is rebuilt from the impulses once, at the end. (Three and four contacts keep the twist form: their
+//     coupling matrices, 72 / 132 entries, overflow the architectural registers into AGPR copies and scratch.)
 //   * slots are DENSE over the wave: the N candidate vertices of the incident face that some lane of the wave has as a contact, in
 //     vertex order (which they are is wave-uniform: scalar indices), N = 1 .. 4 a template parameter -- no skip branches in the
 //     sweep, no work on vertices nobody touches with; a lane that lacks one of the wave's vertices has an inert slot there (zero
@@ -313,7 +314,7 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
   // (v, w~ updated row by row: 19 registers per contact, a dependent chain of eight per row).
   constexpr bool ROWFORM = N <= 2;
   constexpr int NR = ROWFORM ? 3 * N : 1;
-  float A[NR][NR];       // the couplings A_sr, symmetric: only the upper triangle (A[lo][hi]) is ever written or read
+  float B[NR][NR];       // B[s][r] = A_sr / A_rr: what row s's velocity changes by when row r's changes by one
   float kk[N][3];        // 1 / A_rr (effective mass)
   float u[N][3], lam[N][3], tg[N], fx[N], fy[N];
   bool on[N];
@@ -352,23 +353,31 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
     fx[k] = mu * kk[k][0] * frcp(kk[k][1]); fy[k] = mu * kk[k][0] * frcp(kk[k][2]);
     deepest = is ? __builtin_fmaxf(deepest, depth) : deepest;
   }
-  // the couplings A_sr = J~_s . J~_r + [same direction] / m (zero towards / from an inert slot: its J~ is zero, and so is made the
-  // translational part -- which otherwise couples all rows of the same direction)
+  // the couplings A_sr = J~_s . J~_r + [same direction] / m, scaled by the moving row's effective mass (zero towards / from an inert
+  // slot: its J~ is zero, and so is made the translational part -- which otherwise couples all rows of the same direction)
 #pragma unroll
   for (int cs = 0; cs < (ROWFORM ? N : 0); ++cs)
 #pragma unroll
-    for (int cr = cs; cr < N; ++cr) {
+    for (int cr = 0; cr < N; ++cr) {
       const bool both = on[cs] && on[cr];
 #pragma unroll
       for (int ds = 0; ds < 3; ++ds)
 #pragma unroll
         for (int dr = 0; dr < 3; ++dr) {
-          if (3 * cr + dr < 3 * cs + ds) continue;  // (upper triangle)
+          if (cs == cr && ds == dr) continue;  // (the row itself: not stored)
           const float jj = fmaf(Jt[cs][ds][0], Jt[cr][dr][0], fmaf(Jt[cs][ds][1], Jt[cr][dr][1], Jt[cs][ds][2] * Jt[cr][dr][2]));
           const float a_sr = ds == dr ? jj + im : jj;
-          A[3 * cs + ds][3 * cr + dr] = both ? a_sr : 0.0f;
+          B[ROWFORM ? 3 * cs + ds : 0][ROWFORM ? 3 * cr + dr : 0] = both ? a_sr * kk[cr][dr] : 0.0f;
         }
     }
+  // The row-velocity form keeps, per row, E_r = l'_r + target_r - u_r: the impulse the row would take if it were not clamped.
+  // Moving row r by dl leaves E_r where it is (l'_r and u_r both move by dl) and shifts every other E_s by -B_sr dl, so a row is
+  //   l'_new = clamp(E_r);  dl = l'_new - l'_r;  E_s -= B_sr dl  (s != r)
+  // -- a dependent chain of THREE per row (clamp, subtract, multiply-add into the next row's E).
+  if (ROWFORM) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) { u[k][0] = tg[k] - u[k][0]; u[k][1] = -u[k][1]; u[k][2] = -u[k][2]; }  // (u now holds E)
+  }
   bool any_on = false;
 #pragma unroll
   for (int k = 0; k < N; ++k) any_on = any_on || on[k];
@@ -396,21 +405,16 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
       for (int d = 0; d < 3; ++d) {
         if (ROWFORM) {
           float nl;
-          if (d == 0) nl = __builtin_fmaxf((tg[c] - u[c][0]) + lam[c][0], 0.0f);
-          else { const float lim = (d == 1 ? fx[c] : fy[c]) * lam[c][0]; nl = med3(lam[c][d] - u[c][d], -lim, lim); }
+          if (d == 0) nl = __builtin_fmaxf(u[c][0], 0.0f);
+          else { const float lim = (d == 1 ? fx[c] : fy[c]) * lam[c][0]; nl = med3(u[c][d], -lim, lim); }
           float dl = nl - lam[c][d];
           if (FREEZE) dl = done ? 0.0f : dl;
           lam[c][d] = FREEZE ? lam[c][d] + dl : nl;
-          const float g = dl * kk[c][d];  // (the impulse: every other row s moves by A_sr x it)
 #pragma unroll
           for (int cs = 0; cs < N; ++cs)
 #pragma unroll
             for (int ds = 0; ds < 3; ++ds)
-              if (!(cs == c && ds == d)) {
-                const int rs = 3 * cs + ds, rr = 3 * c + d;
-                u[cs][ds] = fmaf(rs < rr ? A[ROWFORM ? rs : 0][ROWFORM ? rr : 0] : A[ROWFORM ? rr : 0][ROWFORM ? rs : 0], g, u[cs][ds]);
-              }
-          u[c][d] += dl;
+              if (!(cs == c && ds == d)) u[cs][ds] = fmaf(-B[ROWFORM ? 3 * cs + ds : 0][ROWFORM ? 3 * c + d : 0], dl, u[cs][ds]);
           if ((3 * c + d) & 1) r1 = __builtin_fmaxf(r1, __builtin_fabsf(dl)); else r0 = __builtin_fmaxf(r0, __builtin_fabsf(dl));
         } else {  // impulses in impulse units here (lam), the twist carried along
           const float vax = d == 0 ? vc.z : (d == 1 ? vc.x : vc.y);
@@ -1356,6 +1360,11 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       } else if (CALM && __builtin_expect(calm_s, 1)) {
         V.template tick<false, false, PF_KV_T>(KV, K, xi0, Pfull);
         V.template tick<false, false, PF_KV_T>(KV, K, xi1, Pfull);
+      } else if (CALM && WPS == 1) {
+        // (not calm: the same ticks with the floor code in them. Their flight-path constants from the vector registers as well --
+        //  the floor code's own constants stay scalar, Kc)
+        V.template tick<CR, false, PF_KV_T, true>(KV, K, xi0, Pfull);
+        V.template tick<CR, false, PF_KV_T, true>(KV, K, xi1, Pfull);
       } else {
         V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi0, Pfull);
         V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi1, Pfull);

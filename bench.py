@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SHADER_CLOCK_GHZ = 2.4   # MI355X peak engine clock (same guide); the phase traces read 2.2-2.25 GHz under this load
 # algorithmic HBM bytes per env step per lane:
 #   reads  128 B = 7 state float4 groups (112) + action float4 (16)
 #   writes 202 B = 7 state groups (112) + obs 21 f32 (84) + reward (4) + terminated (1) + truncated (1)
@@ -75,6 +76,15 @@ def parse():
                          "distribution (aircraft reach the ground within seconds: the contact-solve regime)")
     ap.add_argument("--flight-mode", type=int, default=0, help="QuadX flight mode -1..7 (auxiliary figures; the metric is quoted on mode 0)")
     ap.add_argument("--rollout-steps", type=int, default=100, help="env steps per pf_rollout launch of the second, state-resident figure (0 = skip)")
+    ap.add_argument("--min-timed-ms", type=float, default=5.0,
+                    help="floor on the timed region: the K steps are repeated (whole multiples of K, back to back, no host synchronisation in "
+                         "between) until the region lasts at least this long, and every figure stays per step. K = 20 steps of 11 us are "
+                         "0.2 ms: on one GPU that measures the launch and completion latency of the run as much as the kernels, and on eight "
+                         "the max over ranks of such a region measures launch skew. 0 = time exactly K steps")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the secondary BASELINE configs (Hover 4 096, QuadX-Waypoints 65 536, Fixedwing-Waypoints 65 536) that the "
+                         "default single-GPU hover run times after the headline and reports under `configs`")
+    ap.add_argument("--config-steps", type=int, default=500, help="timed steps per secondary config")
     return ap.parse_args()
 
 
@@ -148,6 +158,121 @@ def cpu_baseline(env, noise, seconds):
                                  "sample": "1 env, 1000 steps, NEXT_STEP auto-reset, incl. ctypes call overhead per step"}}
 
 
+def preroll(eng, ring, steps, step_index0):
+    """`steps` untimed env steps: one pf_rollout launch; eager steps only where the library says the task has no rollout."""
+    from pyflyt_amd import _lib as PL
+
+    try:
+        eng.rollout(steps, step_index0=step_index0)
+    except PL.PfError as e:
+        if e.code != PL.ERR_UNSUPPORTED:
+            raise
+        for i in range(steps):
+            eng.env_step(ring[i % len(ring)])
+
+
+def source_hash():
+    """What the device code is built from (sources, the assembly repair, the compiler flags): the key that ties a committed PMC
+    collection to the kernels it was collected on."""
+    import hashlib
+
+    import __graft_entry__ as G
+
+    h = hashlib.sha256()
+    for f in G.HIP_DEPS:
+        if f.endswith(("__graft_entry__.py",)):
+            continue
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(G.HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(env, n):
+    """The committed PMC collection for this env / batch (profiles/pmc_latest.json), or (None, why): rocprofv3 --pmc cannot run inside
+    the timed bench, so HBM traffic and the instruction counts are REPLAYED from it -- only while the kernels are the ones it was
+    collected on (source_hash)."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(pmc):
+        return None, "no profiles/pmc_latest.json"
+    try:
+        rec = json.load(open(pmc))
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable profiles/pmc_latest.json: {e}"
+    ent = rec.get("envs", {}).get(env)
+    if ent is None or ent.get("batch") != n:
+        return None, f"the collection does not cover {env} at batch {n}"
+    if rec.get("source_hash") != source_hash():
+        return None, f"stale: collected on kernels {rec.get('source_hash')}, these are {source_hash()}"
+    ent = dict(ent)
+    ent["source"] = rec.get("source", "profiles/pmc_latest.json")
+    return ent, None
+
+
+def roofline_block(env, n, per_launch_s, kernel):
+    """HBM roofline of one launch shape + the second, binding one: VALU issue (one wave per SIMD, a wave64 VALU instruction
+    occupies its SIMD for four clocks: valu_per_wave x 4 / clock is the least a wave's life can be)."""
+    algo = ALGO_BYTES[env] * n
+    achieved = algo / per_launch_s / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "traffic_source": None, "kernel": kernel, "algorithmic_bytes_per_launch": algo, "launch_us": per_launch_s * 1e6}
+    ent, why = pmc_record(env, n)
+    if ent is None:
+        out["traffic_source"] = why
+        return out
+    out["traffic"] = ent["hbm_bytes_per_launch"]
+    out["traffic_source"] = "replayed from " + ent["source"]
+    if "valu_per_wave" in ent:
+        clk = SHADER_CLOCK_GHZ
+        min_us = ent["valu_per_wave"] * 4.0 / (clk * 1e3)
+        out["issue"] = {"bound": "valu-issue", "valu_per_wave": ent["valu_per_wave"], "salu_per_wave": ent.get("salu_per_wave"),
+                        "clocks_per_inst": ent.get("clocks_per_inst"), "clock_ghz": clk, "min_us": min_us, "frac": min_us / (per_launch_s * 1e6),
+                        "note": "one wave per SIMD: a wave64 VALU instruction holds its SIMD for 4 clocks; clocks_per_inst = measured wave "
+                                "cycles / (VALU + SALU) of the same collection"}
+    return out
+
+
+KERNEL_OF = {"fixedwing_waypoints": "pf::fixedwing_wp_env_kernel", "dogfight": "pf::dogfight_env_kernel", "ma_hover": "pf::quadx_m0_env_kernel<MA_HOVER, .., SHARED>"}
+
+
+def time_config(env, batch, device, args):
+    """One secondary BASELINE config, the headline's method in small: engine, 100-entry action ring, reset, 400 steps of episode-phase
+    preroll, a HIP graph of 100 steps replayed once (upload), then `--config-steps` steps timed with HIP events on the launch stream."""
+    import torch
+
+    eng = make_engine(env, batch, device, lane_offset=0, noise=args.noise, seed=args.seed)
+    ring = [torch.empty(batch, 4, dtype=torch.float32, device=device) for _ in range(100)]
+    for i, a in enumerate(ring):
+        eng.sample_actions(a, i)
+    eng.env_reset()
+    preroll(eng, ring, 400, 1 << 20)
+    eng.env_step(ring[0])
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(device=device)
+    g = 100
+    reps = max(1, args.config_steps // g)
+    with torch.cuda.stream(stream):
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for i in range(g):
+                eng.env_step(ring[i])
+        graph.replay()
+        preroll(eng, ring, 300, (1 << 20) + 400)  # (clock spin-up right in front of the timed replays)
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(stream)
+        stream.synchronize()
+    per = e0.elapsed_time(e1) * 1e-3 / (reps * g)
+    assert torch.isfinite(eng.obs).all(), f"non-finite observation in config {env}"
+    r = roofline_block(env, batch, per, KERNEL_OF.get(env, "pf::quadx_m0_env_kernel"))
+    return {"workload": f"{env}, batch {batch}, random actions, motor noise {args.noise}, NEXT_STEP auto-reset, contact response on", "steps": reps * g,
+            "launch_us": per * 1e6, "value": batch / per, "unit": "env-steps/s", "roofline": r}
+
+
 def main():
     args = parse()
     import torch
@@ -185,6 +310,18 @@ def main():
     # driver's --steps 20 --warmup 5 that one-off cost was a third of the timed region)
     # steps per HIP graph: a graph is replayed whole, so it is no longer than the timed run
     g = max(1, min(args.graph_steps, args.steps))
+    # --min-timed-ms: how many times the K steps are repeated (from the algorithmic floor, 8 us per step at 65 536 lanes: the count
+    # only has to get the region over the floor)
+    repeats = 1
+    if args.min_timed_ms > 0:
+        est_ms = args.steps * 8e-3 * max(1.0, n / 65536.0)
+        repeats = max(1, int(-(-args.min_timed_ms // est_ms)))
+    if repeats > 1 and not args.no_graph:
+        # the repeats replay one graph: it must not be shorter than the action ring's least length (a 20-step graph replayed is a
+        # 20-entry ring: see --ring), so it holds whole multiples of K up to that length, and the region whole replays of it
+        per_graph = -(-args.ring // args.steps)
+        g = args.steps * per_graph
+        repeats = per_graph * (-(-repeats // per_graph))
     # the action ring: independent uniform draws per lane and entry. It is never shorter than --ring (default 100) entries, however
     # short the run: a ring that repeats within an episode's length is a different action process -- every lane keeps a thrust
     # bias, the drones sink, and the floor's contact solve runs in every launch (profiles/tools/solver_trace.py WHAT=rates:
@@ -210,11 +347,7 @@ def main():
     # graph (20), so it cannot absorb it.
     setup_steps = 0
     if args.preroll > 0 and args.env not in ("dogfight", "ma_hover"):
-        try:
-            eng.rollout(args.preroll, step_index0=1 << 20)
-        except Exception:
-            for i in range(args.preroll):
-                eng.env_step(ring[i % R])
+        preroll(eng, ring, args.preroll, 1 << 20)
         setup_steps += args.preroll
     eng.env_step(ring[0])
     setup_steps += 1
@@ -223,7 +356,8 @@ def main():
     stream = torch.cuda.Stream(device=device)
     graph = None
     with torch.cuda.stream(stream):
-        use_graph = not args.no_graph and args.steps >= args.graph_min_steps
+        # (a region made of repeats is long enough to amortise a graph launch whatever K is: one graph of K steps, replayed)
+        use_graph = not args.no_graph and (args.steps >= args.graph_min_steps or repeats > 1)
         launchers = None
         if not use_graph and not args.no_graph and args.noise != "inject":
             import ctypes
@@ -261,11 +395,8 @@ def main():
         # 5 + 20 steps are 0.3 ms of work) would be measured on a clock that is still ramping: keep the device busy right up to
         # the warm-up, on the same stream, with no host synchronisation in between
         if args.preroll > 0 and args.env not in ("dogfight", "ma_hover"):
-            try:
-                eng.rollout(min(args.preroll, 300), step_index0=(1 << 20) + args.preroll)
-                setup_steps += min(args.preroll, 300)
-            except Exception:
-                pass
+            preroll(eng, ring, min(args.preroll, 300), (1 << 20) + args.preroll)
+            setup_steps += min(args.preroll, 300)
         run(args.warmup)  # the W warm-up steps (whole graph replays first, the remainder eagerly)
         stream.synchronize()
         if dist is not None:
@@ -278,9 +409,11 @@ def main():
 
             solver_trace = (_C.c_ulonglong * 8)()
             eng.lib.pf_debug_solver_trace(solver_trace)  # (reads and clears)
+        # --min-timed-ms: the K steps repeated `repeats` times back to back (estimate from the warm-up's own kernels: two timed
+        # replays of K steps would do, but an estimate from the algorithmic floor is enough to pick the count -- 8 us per step)
         ev0.record(stream)  # (in front of the wall clock: the event pair brackets a superset of the timed region)
         t0 = time.perf_counter()
-        run(args.steps)
+        run(repeats * args.steps)  # (whole graph replays when the region is made of repeats)
         ev1.record(stream)
         while not ev1.query():  # (poll first: a blocking synchronize sleeps on an interrupt, tens of microseconds on a 0.25 ms run)
             pass
@@ -292,15 +425,21 @@ def main():
         if dist is not None:
             dist.barrier()
     ev_ms = ev0.elapsed_time(ev1)
+    timed_steps = repeats * args.steps
     t = torch.tensor([wall, ev_ms * 1e-3], dtype=torch.float64, device=red_dev)
+    per_rank = None
     if dist is not None:
+        # every rank's own figures next to the max over ranks: [wall, events] per rank (a slow rank or launch skew shows here)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [[float(x[0]), float(x[1])] for x in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max, ev_max = float(t[0]), float(t[1])
 
     # sanity: the simulation actually advanced and stayed finite
     ints = eng.ints()
     assert torch.isfinite(eng.obs).all(), "non-finite observation"
-    assert int(ints[:, 2].min()) >= args.steps, "event counter did not advance"  # (counts env steps and resets since context creation)
+    assert int(ints[:, 2].min()) >= timed_steps, "event counter did not advance"  # (counts env steps and resets since context creation)
     from pyflyt_amd import _lib as PL
 
     nonfinite = int(((ints[:, 1] & PL.F_NONFINITE) != 0).sum())  # lanes whose NaN/Inf guard bit is up at the end
@@ -336,41 +475,27 @@ def main():
     line = None
     if rank == 0:
         total_lanes = shard.global_lanes
-        value = total_lanes * args.steps / wall_max
-        per_launch_s = ev_max / args.steps  # HIP events on the launch stream, per pf_env_step launch
-        algo = ALGO_BYTES[args.env] * n
-        achieved = algo / per_launch_s / 1e9
+        value = total_lanes * timed_steps / wall_max
+        per_launch_s = ev_max / timed_steps  # HIP events on the launch stream, per pf_env_step launch
         out = {
             "metric": (f"env-steps/sec (whole node), QuadX-Hover batch={args.batch} " + ("per GPU" if args.scaling == "weak" else "in total"))
             if args.env == "hover" else f"env-steps/sec (whole node), {args.env}",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * wall_max / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": 1e3 * wall_max / timed_steps, "higher_is_better": True, "scaling": args.scaling,
+            # the timed region: `repeats` x K steps back to back (--min-timed-ms; every figure is per step)
+            "timed": {"steps": timed_steps, "repeats": repeats, "wall_ms": 1e3 * wall_max, "event_ms": 1e3 * ev_max, "min_timed_ms": args.min_timed_ms,
+                      "per_rank_ms_per_step": None if per_rank is None else [[1e3 * w / timed_steps, 1e3 * e / timed_steps] for w, e in per_rank]},
             # the same quantity from the HIP events around the K launches (excludes the host's graph-launch latency,
             # which a short --steps run amortises over few steps)
-            "value_event_timed": total_lanes * args.steps / ev_max, "nonfinite_lanes": nonfinite,
+            "value_event_timed": total_lanes * timed_steps / ev_max, "nonfinite_lanes": nonfinite,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"PyFlyt/QuadX-Hover-v4 semantics, flight_mode 0, batch {n}/GPU x {world} GPU(s), "
                                    f"random actions, motor noise {args.noise}, NEXT_STEP auto-reset"
                        if args.env == "hover" else f"{args.env}, batch {n}/GPU x {world}" + (f", {args.dogfight_actions} actions" if args.env == "dogfight" else ""),
                        "batch_per_gpu": n, "global_batch": total_lanes, "setup": {"untimed_steps_before_warmup": setup_steps, "what": "episode-phase preroll (--preroll), one eager step (kernel load), one replay of the instantiated graph (its upload), clock spin-up rollout right before the warm-up"}, "action_ring": R, "ticks_per_env_step": eng.ticks_per_step,
                        "flight_mode": args.flight_mode, "launch": "hipGraph" if graph is not None else ("prepared steps, one launch per step" if launchers is not None else "eager"), "contact_response": bool(eng.params.contact_response), "world_overrides": args.world, "parallelism": f"dp{world} (independent lanes, no collective)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                         "kernel": {"fixedwing_waypoints": "pf::fixedwing_wp_env_kernel", "dogfight": "pf::dogfight_env_kernel", "ma_hover": "pf::quadx_m0_env_kernel<MA_HOVER, .., SHARED>"}.get(args.env, "pf::quadx_m0_env_kernel"),
-                         "algorithmic_bytes_per_launch": algo,
-                         "launch_us": per_launch_s * 1e6},
+            "roofline": roofline_block(args.env, n, per_launch_s, KERNEL_OF.get(args.env, "pf::quadx_m0_env_kernel")),
         }
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("env") == args.env and rec.get("batch") == n:
-                    # NOT measured in this run: replayed from the committed PMC collection (rocprofv3 --pmc cannot run
-                    # inside the timed bench); null for any env / batch that collection does not cover
-                    out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "replayed from " + rec.get("source", "profiles/pmc_latest.json")
-            except Exception:
-                pass
         if roll is not None:
             kk, reps, rwall, rev = roll
             per_step = rev / (reps * kk)
@@ -388,6 +513,15 @@ def main():
                 "nominal_vs_per_step_bytes": ALGO_BYTES[args.env] * n / per_step / 1e9 / HBM_PEAK_GBS,
                 "kernel": ("pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel") + "<..., ROLL=1>", "launch_us": rev / reps * 1e6,
                 "note": "k env steps per launch, state in registers, on-device action sampling (pf_sample_actions keys); bit-identical to k x pf_env_step (tests/test_gpu_rollout.py)",
+            }
+        if args.env == "hover" and world == 1 and not args.no_configs and args.scaling == "weak" and args.batch == 65536 and args.flight_mode == 0 \
+                and not args.no_contact_response and not args.world:
+            # BASELINE.json configs 2-4, timed after the headline in the same process (the headline config is configs[4]'s per-GPU
+            # slice = 65 536 lanes of Hover; config 1 is the CPU plumbing case: cpu_baseline.single_env_1core)
+            out["configs"] = {
+                "hover_4096": time_config("hover", 4096, device, args),
+                "quadx_waypoints_65536": time_config("quadx_waypoints", 65536, device, args),
+                "fixedwing_waypoints_65536": time_config("fixedwing_waypoints", 65536, device, args),
             }
         if not args.no_cpu_baseline and world == 1 and args.env not in ("dogfight", "ma_hover"):
             out["cpu_baseline"] = cpu_baseline(args.env, args.noise, args.cpu_seconds)

@@ -136,7 +136,13 @@ def lib():
     return L
 
 
+ERR_ARG, ERR_UNSUPPORTED, ERR_NO_DEVICE = _ENUMS["PF_ERR_ARG"], _ENUMS["PF_ERR_UNSUPPORTED"], _ENUMS["PF_ERR_NO_DEVICE"]
+PfError = PyFlytAmdError  # (the library's status code rides on the exception: e.code)
+
+
 def check(rc: int, ctx=None):
     if rc != 0:
         msg = lib().pf_last_error(ctx)
-        raise PyFlytAmdError(f"pyflyt_amd call failed (code {rc}): {msg.decode() if msg else '?'}")
+        err = PyFlytAmdError(f"pyflyt_amd call failed (code {rc}): {msg.decode() if msg else '?'}")
+        err.code = rc
+        raise err

@@ -225,7 +225,10 @@ class BatchEngine:
             self._traj = t
         self._check_f32(actions, (k, self.n, self.action_dim), "actions")
         # (outside the specialised kernels the library runs one launch per step and needs the sampled actions to live somewhere)
-        keep = (store_actions or not self.lib.pf_ctx_is_specialised(self._ctx)) and actions is None
+        # (the library's own predicate, pf_rollout: state-resident for the QuadX and Fixedwing-Waypoints kernels only -- the
+        #  specialised dogfight kernel, which pf_ctx_is_specialised reports as well, steps once per launch)
+        resident = self.lib.pf_ctx_is_specialised(self._ctx) != 0 and self.params.task != L.TASK_DOGFIGHT
+        keep = (store_actions or not resident) and actions is None
         b = self._buffers(actions=actions, actions_out=t["actions"] if keep else None)
         b.obs, b.reward, b.terminated, b.truncated = _ptr(t["obs"]), _ptr(t["reward"]), _ptr(t["terminated"]), _ptr(t["truncated"])
         b.final_obs, b.final_info = _ptr(t["final_obs"]), _ptr(t["final_info"])

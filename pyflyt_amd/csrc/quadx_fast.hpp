@@ -1032,6 +1032,55 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     }
     lds_sync();
   };
+  // Waypoint sampling (waypoint_handler.py:53-89), cooperatively as well: a resetting lane needs 3 (4 with yaw targets) Philox calls
+  // and, per target, two sine / cosine pairs -- some 650 instructions that the 2-3 resetting lanes of a wave walked through while the
+  // other lanes idled (1.4 us of a Waypoints wave's 11.4; profiles/r04/phase_trace_waypoints65536.txt). Dealt out over all 64 lanes
+  // instead: pass 1, one (lane, call) pair per lane -> the uniforms, through the observation tile (idle here); pass 2, one (lane,
+  // target) pair per lane -> the target, same arithmetic as before; the resetting lane picks up its 4 x (x, y, z, yaw).
+  // Wave-uniform call. (Injected draws, B.u_targets, keep the per-lane path.)
+  const bool coop_targets = (TASK == PF_TASK_WAYPOINTS) && !((NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr));
+  auto prepare_targets = [&](bool reset_now) {
+    if (!coop_targets) return;
+    const unsigned long long m = __ballot(reset_now);
+    if (m == 0ull) return;
+    const int r = __popcll(m);
+    if (reset_now) {
+      spos[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+      sctr[tid] = rng_ctr;
+    }
+    lds_sync();
+    const int nt = K.num_targets, ntc = kYaw ? 4 : 3;
+    float* const U = tile;             // [lane][16]: the uniforms of calls 0 .. 3
+    float* const TG = tile + 64 * 16;  // [lane][16]: four targets x (x, y, z, yaw)
+    for (int base = 0; base < r * ntc; base += 64) {
+      const int j = base + tid;
+      if (j < r * ntc) {
+        const int which = j / ntc, call = j - which * ntc;
+        const int src = spos[which];
+        const f4 u = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, 2u));
+        float* o = U + src * 16 + call * 4;
+        o[0] = u.a; o[1] = u.b; o[2] = u.c; o[3] = u.d;
+      }
+    }
+    lds_sync();
+    for (int base = 0; base < r * nt; base += 64) {
+      const int j = base + tid;
+      if (j < r * nt) {
+        const int which = j / nt, i = j - which * nt;
+        const int src = spos[which];
+        const float* u = U + src * 16;
+        const float theta = u[i], phi = u[nt + i], dist = fmaf(K.dome09m1, u[2 * nt + i], 1.0f);  // theta, phi in turns
+        float st, ct, sph, cph;
+        sincos_turns(theta, st, ct);
+        sincos_turns(phi, sph, cph);
+        const float zz = __builtin_fabsf(dist * cph);
+        float* o = TG + src * 16 + 4 * i;
+        o[0] = dist * sph * ct; o[1] = dist * sph * st; o[2] = zz > K.min_height ? zz : K.min_height;
+        o[3] = kYaw ? fmaf(2.0f * kPi, u[3 * nt + i], -kPi) : 0.0f;
+      }
+    }
+    lds_sync();
+  };
   // env.reset() for this lane: begin_reset + waypoint sampling + set_mode(0) + the settle phase
   // (quadx_base_env.py:149-212). Level spawn at rest under the mode-0 default setpoint
   // (quadx.py:276-278): rate error 0 -> cmd 0 -> pwm 0.05 on all four motors (quadx.py:488 branch
@@ -1146,6 +1195,17 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = K.num_targets;
       n_left = nt;
+      if (coop_targets) {  // sampled by prepare_targets(): this lane's 4 x (x, y, z, yaw)
+        const float4* t4 = reinterpret_cast<const float4*>(tile + 64 * 16 + tid * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < nt) {
+            const float4 t = t4[i];
+            tgt[i][0] = t.x; tgt[i][1] = t.y; tgt[i][2] = t.z;
+            if (kYaw) ytg[i] = t.w;
+          }
+        }
+      } else {
       f4 u0, u1, u2, u3 = f4{0.f, 0.f, 0.f, 0.f};
       const bool inj = (NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr);
       if (!inj) {
@@ -1179,6 +1239,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
           float zz = __builtin_fabsf(dist * cph);
           tgt[i][0] = dist * sph * ct; tgt[i][1] = dist * sph * st; tgt[i][2] = zz > K.min_height ? zz : K.min_height;
         }
+      }
       }
       // end_reset's compute_state: distance to the first target (old distance = inf)
       float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
@@ -1271,6 +1332,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   reward = 0.0f;
   was_reset = false;
   prepare_settle_noise(do_reset);
+  prepare_targets(do_reset);
   if (do_reset) reset_lane();
   PF_STAMP(4);  // (NEXT_STEP resets done)
 
@@ -1457,6 +1519,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
         B.final_info[2 * (toff + li) + 1] = n_left - (pop_pending ? 1 : 0);
       }
       prepare_settle_noise(same);
+      prepare_targets(same);
       if (same) reset_lane();
     }
   }

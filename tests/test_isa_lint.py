@@ -65,6 +65,34 @@ _Z1kv:
         chk.fix([l.replace("off, v[80:81], off offset:28", "v5, v[80:81], off") for l in asm])
 
 
+def test_a_moved_reload_is_waited_for_before_anything_reads_it():
+    """A flagged stack reload followed by the compiler's wait and a flagged copy that reads the reloaded register: both move behind
+    the exec restore, the wait does not -- the repair must put a wait of its own right behind the moved reload."""
+    from tools import isa_exec_check as chk
+
+    asm = """
+_Z1kv:
+\ts_and_saveexec_b64 s[0:1], vcc
+\ts_cbranch_execz .LBB0_2
+\tv_add_f32_e32 v1, v2, v3
+.LBB0_2:
+\tscratch_load_dword v9, off, off offset:12
+\ts_waitcnt vmcnt(0)
+\tv_mov_b32_e32 v10, v9
+\ts_or_b64 exec, exec, s[0:1]
+\tv_mul_f32_e32 v1, v10, v9
+\ts_endpgm
+""".split("\n")
+    fixed, report = chk.fix(asm)
+    assert len(report) == 2 and not list(chk.sites(fixed))
+    ins = [chk.instruction(l) for l in fixed if chk.instruction(l)]
+    i = ins.index("s_or_b64 exec, exec, s[0:1]")
+    assert ins[i + 1] == "scratch_load_dword v9, off, off offset:12"
+    assert ins[i + 2] == "s_waitcnt vmcnt(0)"            # the reload completes before ...
+    assert ins[i + 3] == "v_mov_b32_e32 v10, v9"         # ... the copy moved along with it reads it
+    assert ins[i + 4] == "v_mul_f32_e32 v1, v10, v9"
+
+
 def test_shipped_code_object_is_clean(tmp_path):
     from tools import isa_exec_check as chk
 

@@ -137,6 +137,11 @@ def fix(lines):
         out.append(raw)
         for j in moves.get(i, ()):
             out.append(lines[j])
+            if instruction(lines[j]).startswith("scratch_load"):
+                # The wait the compiler placed for this reload stays where it was -- in front of the exec restore, now in front of the
+                # load itself -- so nothing waits for it any more: neither a copy moved along with it that reads the reloaded
+                # register, nor the block's own code. A moved reload therefore completes on the spot.
+                out.append("\ts_waitcnt vmcnt(0)")
     return out, report
 
 

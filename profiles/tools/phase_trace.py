@@ -11,7 +11,8 @@ from pyflyt_amd.engine import BatchEngine
 n = int(os.environ.get("N", "65536"))
 task = os.environ.get("TASK", "hover")
 wo = dict(contact_response=False) if os.environ.get("CR", "1") == "0" else None
-P = build_params("quadx", task, noise="philox", autoreset="next_step", seed=0, world_options=wo)
+veh = os.environ.get("VEH", "quadx")
+P = build_params(veh, task, noise="philox", autoreset="next_step", seed=0, world_options=wo)
 eng = BatchEngine(P, n, device="cuda:0")
 ring = [torch.empty(n, 4, device="cuda:0") for _ in range(100)]  # (a ring that repeats within an episode is a different action process: solver_trace.py WHAT=rates)
 for i, a in enumerate(ring):
@@ -25,6 +26,8 @@ K = 13
 waves = min(4096, (n + 63) // 64)
 names = ["entry", "int group arrived", "Philox done", "state unpacked + derive", "resets done", "Aviary steps done", "(pre obs)", "obs row in LDS",
          "obs stores issued", "state stores issued", "stores acknowledged"]
+if veh == "fixedwing":
+    assert L.pf_debug_solver_trace((C.c_ulonglong * 8)()) == 0  # (clears the tick counters)
 acc = []
 for rep in range(20):
     eng.env_step(ring[(200 + rep) % 100])
@@ -37,7 +40,7 @@ T = np.stack(acc)  # [rep][wave][stamp]
 rel = T[:, :, :11] - T[:, :, :1]
 rt0, rt1 = T[:, :, 11], T[:, :, 12]
 clk_mhz = np.median((T[:, :, 10] - T[:, :, 0]) / np.maximum(rt1 - rt0, 1)) * 100.0
-print(f"task {task} lanes {n} contact_response {bool(eng.params.contact_response)}; shader clock ~{clk_mhz:.0f} MHz (s_memtime / s_memrealtime)")
+print(f"vehicle {veh} task {task} lanes {n} contact_response {bool(eng.params.contact_response)}; shader clock ~{clk_mhz:.0f} MHz (s_memtime / s_memrealtime)")
 prev = 0.0
 for i, nm in enumerate(names):
     v = rel[:, :, i].reshape(-1) / clk_mhz  # us
@@ -55,3 +58,9 @@ print(f"  slowest wave of each launch: life median {np.median(life.max(axis=1)):
 print("   " + ", ".join(f"{names[i + 1]} +{np.median(inc[:, i]):.2f}" for i in range(10)))
 over = (life > np.median(life) + 1.0).sum(axis=1)
 print(f"  waves more than 1 us slower than the median wave, per launch: mean {over.mean():.1f}, max {over.max()}")
+if veh == "fixedwing":  # the tick's own split (diagnostic counters of the last 20 launches)
+    buf = (C.c_ulonglong * 8)()
+    assert L.pf_debug_solver_trace(buf) == 0
+    ticks = max(int(buf[0]), 1)
+    print(f"  per tick and wave: {buf[1] / ticks / clk_mhz:.3f} us in the five lifting surfaces, {buf[7] / ticks / clk_mhz:.3f} us in the motor, the floor test, "
+          f"the rigid-body tick and derive(); {ticks / (20 * waves):.2f} ticks per wave and launch")

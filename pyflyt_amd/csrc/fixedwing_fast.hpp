@@ -448,7 +448,15 @@ struct FwHot {
     tau.z = fmaf(-ry, fp, tau.z);
   }
   // one physics tick: update_physics (fixedwing.py:261-264) + stepSimulation + update_state (:266-291)
+  // FLOOR = false: the same tick for a wave none of whose aircraft can come within reach of the ground during the ticks ahead (the
+  // kernel's calm test: every velocity component is clamped to max_coord_vel, so an aircraft sinks at most that x the time ahead) --
+  // no floor test, no contact solve, neither of the two out-of-line calls in the tick loop. Bit-identical for such a wave: the
+  // floor code would have found `near` false for every lane.
+  template <bool FLOOR = true>
   PF_DEV void tick(fw_tab_cptr tab, const float xi, const pf_params* Pfull) {
+#ifdef PF_PHASE_TRACE
+    const unsigned long long pf_f0 = __builtin_readcyclecounter();
+#endif
     v3 F{0.f, 0.f, 0.f}, tau{0.f, 0.f, 0.f};
     // An opaque zero offset per tick keeps the per-surface constant loads inside the tick (16 SGPRs at
     // a time, see the file header) instead of hoisted and spilled; the scheduling barriers keep the
@@ -507,6 +515,10 @@ struct FwHot {
 #ifndef PF_FW_PREFETCH
     const FwBody K = fw_load_body(&tk->body);
 #endif
+#ifdef PF_PHASE_TRACE
+    asm volatile("" ::"v"(F.x), "v"(tau.y));
+    const unsigned long long pf_f1 = __builtin_readcyclecounter();
+#endif
     {  // motor (motors.py:110-195), at the base origin along +x
       float t = fmaf(K.m_a, cmd[5] - thr, thr);
       t = fmaf(xi * t, K.m_noise, t);
@@ -519,12 +531,14 @@ struct FwHot {
     // (within reach of the ground slab: one bounding radius (+ contact margin) of its top face, not below its bottom face,
     //  not beyond its rim -- an aircraft that has flown off the 30 m slab and keeps falling is "under the floor" for seconds,
     //  and the six 15-axis box tests per tick for such lanes were ~20 % of this kernel's instructions)
-    const bool near = ((p.z - K.bound_radius) <= 0.0f) && ((p.z + K.bound_radius) >= K.slab_bottom) &&
+    const bool near = FLOOR && ((p.z - K.bound_radius) <= 0.0f) && ((p.z + K.bound_radius) >= K.slab_bottom) &&
                       (__builtin_fabsf(p.x) - K.bound_radius <= K.slab_xy) && (__builtin_fabsf(p.y) - K.bound_radius <= K.slab_xy);
     const bool persisted = contact_now;  // contact points left by the previous tick persist up to the breaking distance
     contact_now = false;
-    if (__any(near)) {
-      if (near) contact_now = fw_floor_contact(p.x, p.y, p.z, R, Pfull, persisted);
+    if (FLOOR) {
+      if (__any(near)) {
+        if (near) contact_now = fw_floor_contact(p.x, p.y, p.z, R, Pfull, persisted);
+      }
     }
     contact_now = contact_now || peer_contact;
     // free-base multibody tick, composite of point masses: COM offset, full symmetric inertia
@@ -541,20 +555,31 @@ struct FwHot {
     v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
     float lift = 0.0f;  // contact response (see quadx_fast.hpp / uav_vehicles.hpp:contact_solve_dev)
     bool act = false;  // can a contact constraint act at all this tick? (Body::contact_may_act)
-    if (near) {
+    if (FLOOR && near) {
       const float r0 = Pfull->bound_radius, slop = Pfull->contact_slop;
       const float low = p.z - r0, vlow = v.z - fsqrt(dot(w, w)) * r0;
       act = ((fmaf(K.dt, vlow, low + slop) < 0.0f) || (low < -slop)) && (low <= (persisted ? Pfull->contact_break_distance : Pfull->contact_margin));  // (no vertex can be within reach otherwise)
     }
-    if (__any(act)) {
-      const ContactOut o = contact_solve_dev(Pfull, cws, need_cap_of(act && Pfull->contact_response, cws_floats, persisted), p, q, v, w);
-      v = o.v; w = o.w;  // (unchanged for a lane that did not ask or has no contact vertex)
-      lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
+    if (FLOOR) {
+      if (__any(act)) {
+        const ContactOut o = contact_solve_dev(Pfull, cws, need_cap_of(act && Pfull->contact_response, cws_floats, persisted), p, q, v, w);
+        v = o.v; w = o.w;  // (unchanged for a lane that did not ask or has no contact vertex)
+        lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
+      }
     }
-    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), fmaf(K.dt, v.z, p.z) + lift};
+    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), FLOOR ? fmaf(K.dt, v.z, p.z) + lift : fmaf(K.dt, v.z, p.z)};
     q = quat_integrate(q, w, K.half_dt);
     derive();
     contact_step |= contact_now;
+#ifdef PF_PHASE_TRACE
+    asm volatile("" ::"v"(wb.x), "v"(vb.z));
+    if ((threadIdx.x & 63u) == 0u) {  // (diagnostic build: per tick and wave, clocks in the five surfaces / in the rest of the tick)
+      const unsigned long long pf_f2 = __builtin_readcyclecounter();
+      atomicAdd(&g_solver_trace[0], 1ull);
+      atomicAdd(&g_solver_trace[1], pf_f1 - pf_f0);
+      atomicAdd(&g_solver_trace[7], pf_f2 - pf_f1);
+    }
+#endif
   }
 };
 
@@ -563,6 +588,12 @@ struct FwHot {
 // g3 w.yz+act0,1, g4 act2..4+throttle, g5 ints, g6..8 the 4x3 targets (Fixedwing::load/store layout).
 // ROLL: as in quadx_m0_env_kernel -- 0 one env step per launch, 1 pf_rollout with on-device action sampling (no vector-memory
 // load in the loop), 2 pf_rollout over a given action sequence.
+// (A/B switch, off: with the second tick instantiation in the kernel the 256-register budget spills another 128 B per lane inside
+//  the tick loop -- 23.9 -> 28.3 us per step at 65 536 lanes, rollout 18.9 -> 22.1 (profiles/README.md, r04). The QuadX kernel, which
+//  has the registers, gains from the same split; this one has to shrink first.)
+#ifndef PF_FW_CALM
+#define PF_FW_CALM 0
+#endif
 #ifdef PF_FW_LB1  // (A/B: one wave per SIMD -- 512 registers, the overflow into AGPRs instead of scratch)
 #define PF_FW_WAVES 1
 #else
@@ -587,8 +618,18 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   float4* Sout = reinterpret_cast<float4*>(B.state);
   fw_tab_cptr surf = (fw_tab_cptr)(uintptr_t)table_g;
 
+#ifdef PF_PHASE_TRACE
+  unsigned long long pf_ts[kPhaseStamps];
+  pf_ts[11] = __builtin_amdgcn_s_memrealtime();
+#endif
+  PF_STAMP(0);
   FwHot V;
   static_assert(64 * kMaxD >= kContactSlotFloats, "the contact solver's LDS regions alias the observation tile: at least one worst-case region");
+  // the calm test's constants (one scalar load of the table's body row): reach of the floor code, how far an aircraft can sink
+  // over an env step / over an Aviary step (max_coord_vel x ticks x dt, with a margin for the rounding of the position updates)
+  const float Kc_bound_radius = surf->body.bound_radius;
+  const float calm_sink_env = surf->body.vmax * surf->body.dt * (float)(2 * K.env_step_ratio) * 1.001f + 1e-3f;
+  const float calm_sink_av = surf->body.vmax * surf->body.dt * 2.0f * 1.001f + 1e-3f;
   V.cws = (lds_fptr)tile;
   float tgt[4][3];
   float new_dist, old_dist;
@@ -600,9 +641,11 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li];
     if (blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch((int)threadIdx.x);  // (uav_vehicles.hpp; behind the state loads: one wait for both)
     rng_ctr = (uint32_t)__float_as_int(gi.z);
+    PF_STAMP(1);
     if (NOISE == PF_NOISE_PHILOX) {
       if (op == 0) zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
     }
+    PF_STAMP(2);
     V.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
     V.q = quat{g1.x, g1.y, g1.z, g1.w};
     V.v = v3{g2.x, g2.y, g2.z};
@@ -618,6 +661,10 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   V.contact_now = (flags & PF_F_CONTACT) != 0;
   V.contact_step = false;
   V.derive();
+#ifdef PF_PHASE_TRACE
+  asm volatile("" ::"v"(V.wb.x), "v"(V.vb.z));
+#endif
+  PF_STAMP(3);
   bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
 
   bool active;
@@ -764,6 +811,7 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   reward = 0.0f;
   was_reset = false;
   if (do_reset) reset_lane();
+  PF_STAMP(4);
 
   // ---------------------------------------------------------------- the env step
   const bool stepping = active && !was_reset && op == 0;
@@ -794,16 +842,28 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
     reward = -0.1f;
   }
   bool go = stepping && !(term || trunc);  // fixedwing_base_env.py:262-263
+  // Calm waves (as in quadx_fast.hpp): no aircraft of the wave can come within reach of the ground slab during the env step -- each
+  // velocity component is clamped to max_coord_vel after every tick, so an aircraft sinks at most max_coord_vel x the time ahead
+  // -- and the wave runs ticks instantiated without the floor code (no out-of-line call in the tick loop). A wave that is not calm
+  // over the env step asks again per Aviary step, over its two ticks.
+  const float calm_reach = Kc_bound_radius;
+  const bool calm_env = PF_FW_CALM && __all(!go || (V.p.z - calm_reach > calm_sink_env));
   for (int s = 0; s < K.env_step_ratio; ++s) {
     if (!__any(go)) break;
+    const bool calm_s = calm_env || (PF_FW_CALM && __all(!go || (V.p.z - calm_reach > calm_sink_av)));
     if (go) {
       float xi0, xi1;
       if (NOISE == PF_NOISE_PHILOX) { xi0 = 1.0f + pick8(zn, (uint32_t)(2 * s)); xi1 = 1.0f + pick8(zn, (uint32_t)(2 * s + 1)); }
       else if (NOISE == PF_NOISE_INJECT) { xi0 = B.xi[(size_t)(2 * s) * N + li]; xi1 = B.xi[(size_t)(2 * s + 1) * N + li]; }
       else { xi0 = 0.f; xi1 = 0.f; }
       V.contact_step = false;
+      if (calm_s) {
 #pragma unroll 1
-      for (int t = 0; t < 2; ++t) V.tick(surf, t == 0 ? xi0 : xi1, Pfull);
+        for (int t = 0; t < 2; ++t) V.template tick<false>(surf, t == 0 ? xi0 : xi1, Pfull);
+      } else {
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) V.template tick<true>(surf, t == 0 ? xi0 : xi1, Pfull);
+      }
       // compute_state side effects + compute_term_trunc_reward
       if (pop_pending) { pop_target(); pop_pending = false; }
       float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
@@ -825,6 +885,7 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
       go = !(term || trunc);
     }
   }
+  PF_STAMP(5);
   const float out_reward = stepping ? reward : 0.0f;
   const bool out_term = stepping && term, out_trunc = stepping && trunc;
   if (stepping) {
@@ -853,8 +914,11 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   }
 
   // ---------------------------------------------------------------- outputs
+  PF_STAMP(6);
   if (active) write_obs_row();
+  PF_STAMP(7);
   flush_tile(B.obs + toff * D);
+  PF_STAMP(8);
   if (active) {
     if (pop_pending) { pop_target(); pop_pending = false; }
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
@@ -880,6 +944,16 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
     Sout[7 * N + li] = float4{tgt[1][1], tgt[1][2], tgt[2][0], tgt[2][1]};
     Sout[8 * N + li] = float4{tgt[2][2], tgt[3][0], tgt[3][1], tgt[3][2]};
   }
+#ifdef PF_PHASE_TRACE
+  PF_STAMP(9);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): every store acknowledged
+  PF_STAMP(10);
+  pf_ts[12] = __builtin_amdgcn_s_memrealtime();
+  if (ROLL == 0 && tid == 0 && blockIdx.x < 4096) {
+#pragma unroll
+    for (int i = 0; i < kPhaseStamps; ++i) g_phase_trace[blockIdx.x * kPhaseStamps + i] = pf_ts[i];
+  }
+#endif
 }
 
 }  // namespace pf

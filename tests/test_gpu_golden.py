@@ -79,8 +79,11 @@ ENVS = [
 
 # The position-controlled fixture: the outer loops differentiate fp32 velocities (lin_vel kd / T = 60 per control tick, z_vel
 # kd / T = 6; tests/tools/fp32_sensitivity.py), so the fp32 device sits further from the fp64 reference than 1e-4 from the first
-# manoeuvre on -- on both kernels alike. Bound = 4 x the measured worst (printed by the test), not a blanket allowance.
-ENV_RTOL = {"env_quadx_waypoints_mode7": 2e-2}
+# manoeuvre on -- on both kernels alike. An fp32 build of the ORACLE itself (double -> float, nothing else) replays this fixture
+# 7.9e-4 away from the fp64 one: the reference's own arithmetic does not hold 1e-4 in single precision here, whatever the kernel.
+# Bounds per kernel = about 3 x the measured worst (printed by the test: 6.8e-3 specialised, whose polynomial atan2 / asin and
+# reciprocal approximations add to it; 1.4e-3 generic), and a LOWER bound as well, so that neither can drift unnoticed.
+ENV_RTOL = {("env_quadx_waypoints_mode7", "specialised"): 2e-2, ("env_quadx_waypoints_mode7", "generic"): 5e-3}
 
 
 @pytest.mark.parametrize("kernel", ["specialised", "generic"])
@@ -128,7 +131,7 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
             assert e < RTOL_IMPACT, (name, k, e)
         else:
             worst = max(worst, e)
-            assert e < ENV_RTOL.get(name, RTOL), (name, k, e)
+            assert e < ENV_RTOL.get((name, kernel), RTOL), (name, k, e)
         r = rew.double().cpu().numpy()
         assert np.abs(r - g["reward"][k]).max() <= 1e-3 * max(1.0, abs(g["reward"][k])), (name, k, r[0], g["reward"][k])
         assert (term.cpu().numpy() == bool(g["term"][k])).all() and (trunc.cpu().numpy() == bool(g["trunc"][k])).all(), (name, k)
@@ -140,6 +143,8 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
         seen["term"] += int(g["term"][k])
         seen["trunc"] += int(g["trunc"][k])
     assert ri == len(g["reset_obs"])
+    if (name, kernel) in ENV_RTOL:  # a widened bound stays tied to what is measured: within a factor of ten of it
+        assert worst > ENV_RTOL[(name, kernel)] / 10.0, (name, kernel, worst)
     print(f"{name} [{kernel}]: worst {worst:.2e} over {len(g['action'])} steps, {ri} resets, ended {seen}")
 
 

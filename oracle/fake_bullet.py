@@ -271,6 +271,7 @@ class BulletClient:
     """Duck-type of pybullet_utils.bullet_client.BulletClient for the hot-path method set."""
 
     DEFAULT_CONTACT_RESPONSE = True  # (tests/golden/gen_goldens.py switches it off while it records the env-level fixtures)
+    DEFAULT_PAIR_RESPONSE = True     # (... and this one for the control recording of the mid-air collision)
     DIRECT = 2
     GUI = 1
     LINK_FRAME = 1
@@ -295,7 +296,7 @@ class BulletClient:
         self.contact_manifold_points = 4
         self.contact_break_distance = 0.02  # points a body held after the previous tick persist up to this gap
         self._persisted = set()  # ids of the free bodies that held contact points after the previous tick
-        self.pair_response = True  # impulses between free bodies (oracle/uav_oracle.h: orc_world.pair_response)
+        self.pair_response = BulletClient.DEFAULT_PAIR_RESPONSE  # impulses between free bodies (oracle/uav_oracle.h: orc_world.pair_response)
 
     # ------------------------------------------------------------ no-ops
     def setAdditionalSearchPath(self, path):

@@ -54,6 +54,8 @@ constexpr int kDfRestUpdates = 8;
 // instructions). pf_ctx_create picks the second whenever fw_table_from_params accepts the airframe (acrowing does).
 struct DfGenericVeh : Fixedwing {
   PF_DEV void attach(const FwTable*) {}
+  PF_DEV void tick(const pf_params& P, float xi) { Fixedwing::template tick<true>(P, xi); }  // (with the pair stage: Body::tick<SHARED>)
+  PF_DEV void share(const float* wpose, float* wvel, float*, int tid, int A) { b.wpose_ = wpose; b.wvel_ = wvel; b.wtid = tid; b.wA = A; }
 };
 struct DfFastBody : FwHot {
   v3 rpy;
@@ -109,7 +111,8 @@ struct DfFastVeh {
   PF_DEV void control(const pf_params&, const float sp[6]) {  // mode 0, fixedwing.py:143-144,246-250: ids [0,0,1,2,1,3], signs [+,-,+,-,-,+]
     b.cmd[0] = sp[0]; b.cmd[1] = -sp[0]; b.cmd[2] = sp[1]; b.cmd[3] = -sp[2]; b.cmd[4] = -sp[1]; b.cmd[5] = sp[3];
   }
-  PF_DEV void tick(const pf_params&, float xi) { b.tick(tab, xi, b.pdev); }
+  PF_DEV void tick(const pf_params&, float xi) { b.template tick<true, true>(tab, xi, b.pdev); }
+  PF_DEV void share(const float* wpose, float* wvel, float* rec, int tid, int A) { b.wpose_ = wpose; b.wvel_ = wvel; b.prec_ = rec; b.wtid = tid; b.wA = A; }
   PF_DEV void aux(float* o) const {
 #pragma unroll
     for (int k = 0; k < 5; ++k) o[k] = b.act[k];
@@ -172,6 +175,9 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
   V.b.pdev = Pdev;
   V.b.cws = (lds_fptr)tile;
   V.b.contact_regions(P, kTile);  // as many solver regions as fit the idle observation tile
+  // the pair stage's exchange arrays: the velocities in update_states()' exchange records (idle during the ticks), its contact
+  // records in the observation tile like the ground solve's (the two run one after the other)
+  V.share(wpose, rec, tile, tid, A);
   V.bind(ktab);
   float nd_unused;
   int4 ints;
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     // resting contact: the collision verdict of :667-670 stays up. A momentary `inactive` does NOT stop the integration.
     const bool wreck = (df & (DF_AT_REST | DF_FROZEN)) != 0;
     for (int t = 0; t < P.ticks_per_control; ++t) {
-      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev, wreck);
+      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev, wreck, rec);
       if (!wreck) V.tick(P, nz.get(flat_base + t));
     }
     if (wreck) V.b.contact_step = V.b.contact_now;

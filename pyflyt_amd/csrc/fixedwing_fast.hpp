@@ -33,6 +33,7 @@
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
 #include "uav_vehicles.hpp"  // contact_solve_dev
+#include "shared_world.hpp"  // pair_stage_dev (the dogfight's shared worlds)
 
 namespace pf {
 
@@ -213,7 +214,13 @@ struct FwHot {
   // shared worlds (dogfight.hpp): this tick's drone-drone verdict, ORed into the contact report; the world-global bit is only
   // exchanged (the rotational-drag gate it feeds exists on the quadrotor, quadx.py:509)
   bool peer_contact = false, world_contact = false;
-  bool world_touch = false;  // (world_exchange's verdict for the contact response between drones: implemented for the QuadX worlds)
+  bool world_touch = false;  // world_exchange's verdict: some pair of this world is within reach of the contact response between aircraft
+  // shared worlds, the pair stage (shared_world.hpp: pair_stage_dev): the wave's pose / velocity exchange arrays, the LDS for its
+  // contact records (the observation tile, as a generic pointer), this lane, aircraft per world
+  const float* wpose_ = nullptr;
+  float* wvel_ = nullptr;
+  float* prec_ = nullptr;
+  int wtid = 0, wA = 1;
 
   PF_DEV void derive() {  // unit quaternion (quat_integrate / the settled template): scale 2
     const float xs = q.x + q.x, ys = q.y + q.y, zs = q.z + q.z;
@@ -452,7 +459,9 @@ struct FwHot {
   // kernel's calm test: every velocity component is clamped to max_coord_vel, so an aircraft sinks at most that x the time ahead) --
   // no floor test, no contact solve, neither of the two out-of-line calls in the tick loop. Bit-identical for such a wave: the
   // floor code would have found `near` false for every lane.
-  template <bool FLOOR = true>
+  // SHARED (the dogfight): the contact response BETWEEN the aircraft of the world, one stage before the ground's -- publish the new
+  // velocity, the world's first lane resolves the contacts, take back velocity and position-level shift.
+  template <bool FLOOR = true, bool SHARED = false>
   PF_DEV void tick(fw_tab_cptr tab, const float xi, const pf_params* Pfull) {
 #ifdef PF_PHASE_TRACE
     const unsigned long long pf_f0 = __builtin_readcyclecounter();
@@ -553,6 +562,19 @@ struct FwHot {
     a = a - cross(wd, cw) - cross(w, cross(w, cw));
     w = v3{med3(fmaf(wd.x, K.dt, w.x), -K.vmax, K.vmax), med3(fmaf(wd.y, K.dt, w.y), -K.vmax, K.vmax), med3(fmaf(wd.z, K.dt, w.z), -K.vmax, K.vmax)};
     v = v3{med3(fmaf(a.x, K.dt, v.x), -K.vmax, K.vmax), med3(fmaf(a.y, K.dt, v.y), -K.vmax, K.vmax), med3(fmaf(a.z, K.dt, v.z), -K.vmax, K.vmax)};
+    v3 shift{0.0f, 0.0f, 0.0f};
+    if (SHARED) {
+      if (wvel_ != nullptr && Pfull->contact_response) {  // (wave-uniform)
+        float* o = wvel_ + wtid * kPairVelStride;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = w.x; o[4] = w.y; o[5] = w.z; o[6] = 0.0f; o[7] = 0.0f; o[8] = 0.0f;
+        lds_sync_wave();
+        if (__any(world_touch)) {
+          pair_stage_dev(Pfull, wpose_, wvel_, prec_, cws_floats, wtid, wA, world_touch);
+          v = v3{o[0], o[1], o[2]}; w = v3{o[3], o[4], o[5]};
+          shift = v3{o[6], o[7], o[8]};
+        }
+      }
+    }
     float lift = 0.0f;  // contact response (see quadx_fast.hpp / uav_vehicles.hpp:contact_solve_dev)
     bool act = false;  // can a contact constraint act at all this tick? (Body::contact_may_act)
     if (FLOOR && near) {
@@ -567,7 +589,8 @@ struct FwHot {
         lift = Pfull->contact_erp * o.deepest;  // (already net of the slop)
       }
     }
-    p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), FLOOR ? fmaf(K.dt, v.z, p.z) + lift : fmaf(K.dt, v.z, p.z)};
+    if (SHARED) p = v3{fmaf(K.dt, v.x, p.x) + shift.x, fmaf(K.dt, v.y, p.y) + shift.y, fmaf(K.dt, v.z, p.z) + lift + shift.z};
+    else p = v3{fmaf(K.dt, v.x, p.x), fmaf(K.dt, v.y, p.y), FLOOR ? fmaf(K.dt, v.z, p.z) + lift : fmaf(K.dt, v.z, p.z)};
     q = quat_integrate(q, w, K.half_dt);
     derive();
     contact_step |= contact_now;

@@ -68,8 +68,11 @@ __device__ __noinline__ bool peers_overlap_dev(const pf_params* __restrict__ Pd,
 //   update. rec: LDS for the contact records (kPairRecFloats per touching world; as many worlds per round as fit).
 // Drones touch rarely (a hit ends both episodes of the PettingZoo task) and then for a few ticks: ONE lane per touching world
 // -- its first -- walks that world's contacts serially, every body's twist staying in LDS where both partners of a contact find
-// it; the other lanes wait. Airframes: plain boxes, centre of mass at the base origin (the QuadX models; checked at context
-// creation). Every lane of the wave that is inside the caller's tick must call this together.
+// it; the other lanes wait. Airframes: plain boxes (checked at context creation); a centre of mass off the base origin (the
+// aeroplanes: pf_params.com) is handled -- arms from the centre of mass, the exchanged base-origin velocities converted to
+// centre-of-mass velocities for the sweeps and back. Every lane of the wave that is inside the caller's tick must call this
+// together; the lane that works for a world is the first of ITS lanes inside the call (the dogfight leaves wrecks at rest out of
+// the tick: their exchange entries hold zero velocity, world_exchange).
 constexpr int kPairVelStride = 12;   // v (3), w (3), shift (3), pad
 constexpr int kPairMaxContacts = 16; // = ORC_MAX_PAIR_CONTACTS
 constexpr int kPairRec = 44;         // floats per contact record
@@ -77,7 +80,9 @@ constexpr int kPairRecFloats = kPairMaxContacts * kPairRec;
 __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, const float* wpose, float* wvel, float* rec_all, const int rec_floats, const int tid,
                                             const int A, const bool world_touch) {
   const int wbase = (tid / A) * A;
-  bool todo = world_touch && (tid == wbase);  // the world's first lane does the work
+  const unsigned long long inside = __ballot(1);
+  const unsigned long long wmask = (A >= 64 ? ~0ull : ((1ull << A) - 1ull)) << wbase;
+  bool todo = world_touch && (tid == __ffsll((long long)(inside & wmask)) - 1);  // the world's first lane inside the call does the work
   const int slots = rec_floats / kPairRecFloats;
   unsigned long long m = __ballot(todo);
   while (m != 0ull) {
@@ -90,6 +95,17 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
       const float mu = Pd->contact_friction * Pd->contact_friction, erp = Pd->contact_erp, im = Pd->inv_mass, brad = Pd->bound_radius;
       const float Ii[6] = {Pd->I_inv[0], Pd->I_inv[1], Pd->I_inv[2], Pd->I_inv[3], Pd->I_inv[4], Pd->I_inv[5]};
       const int nb = Pd->n_boxes, iters = Pd->contact_iters;
+      const bool offc = Pd->has_com_offset != 0;
+      const v3 comb = offc ? v3{Pd->com[0], Pd->com[1], Pd->com[2]} : v3{0.0f, 0.0f, 0.0f};
+      if (offc) {  // base-origin velocities -> centre-of-mass velocities: v_c = v + w x (R com)
+        for (int i = 0; i < A; ++i) {
+          const float* pi = wpose + (wbase + i) * 8;
+          float* o = wvel + (wbase + i) * kPairVelStride;
+          const v3 cw = mul(rot_from_quat(quat{pi[3], pi[4], pi[5], pi[6]}), comb);
+          const v3 vc = v3{o[0], o[1], o[2]} + cross(v3{o[3], o[4], o[5]}, cw);
+          o[0] = vc.x; o[1] = vc.y; o[2] = vc.z;
+        }
+      }
       int n = 0;
       // ---- contacts: every box vertex of a within the margin of being inside a box of b
       for (int a = 0; a < A; ++a) {
@@ -104,6 +120,7 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
           const float rr = 2.0f * brad + 2.0f * margin;
           if (dot(d, d) > rr * rr) continue;
           const m3 Rb = rot_from_quat(quat{pb[3], pb[4], pb[5], pb[6]});
+          const v3 cwa = mul(Ra, comb), cwb = mul(Rb, comb);  // the centres of mass from the base origins
           // world-frame inverse inertias R I^-1 R^T of both bodies (symmetric xx xy xz yy yz zz)
           float Iwa[6], Iwb[6];
           {
@@ -122,8 +139,9 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
               const v3 cb = v3{pb[0], pb[1], pb[2]} + mul(Rb, v3{bb.c[0], bb.c[1], bb.c[2]});
               for (int vi = 0; vi < 8; ++vi) {
                 const v3 l{ba.c[0] + ((vi & 1) ? ba.h[0] : -ba.h[0]), ba.c[1] + ((vi & 2) ? ba.h[1] : -ba.h[1]), ba.c[2] + ((vi & 4) ? ba.h[2] : -ba.h[2])};
-                const v3 ra = mul(Ra, l);  // arm from a's centre of mass (= its base origin)
-                const v3 x = v3{pa[0], pa[1], pa[2]} + ra;
+                const v3 ro = mul(Ra, l);  // from a's base origin
+                const v3 x = v3{pa[0], pa[1], pa[2]} + ro;
+                const v3 ra = ro - cwa;    // arm from a's centre of mass
                 const v3 loc = mulT(Rb, x - cb);
                 const float pen0 = bb.h[0] - __builtin_fabsf(loc.x), pen1 = bb.h[1] - __builtin_fabsf(loc.y), pen2 = bb.h[2] - __builtin_fabsf(loc.z);
                 int ks = 0;
@@ -134,7 +152,7 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
                 const float lk = ks == 0 ? loc.x : (ks == 1 ? loc.y : loc.z);
                 const float sg = lk < 0.0f ? -1.0f : 1.0f;
                 const v3 nrm = ks == 0 ? v3{sg * Rb.m00, sg * Rb.m10, sg * Rb.m20} : (ks == 1 ? v3{sg * Rb.m01, sg * Rb.m11, sg * Rb.m21} : v3{sg * Rb.m02, sg * Rb.m12, sg * Rb.m22});
-                const v3 rb = x - v3{pb[0], pb[1], pb[2]};
+                const v3 rb = x - (v3{pb[0], pb[1], pb[2]} + cwb);
                 v3 t1, t2;  // btPlaneSpace1
                 if (__builtin_fabsf(nrm.z) > 0.70710678f) {
                   const float aa = fmaf(nrm.y, nrm.y, nrm.z * nrm.z), k = 1.0f / __builtin_sqrtf(aa);
@@ -208,6 +226,7 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
           if (!(res > res_bound)) break;
         }
         // position-level recovery: each body follows its deepest pair contact (the first on a tie)
+        // (one slot per agent of a world, in registers: pf_ctx_create admits at most 8 agents per shared world)
         float best[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < n; ++c) {
           const float* r = rec + c * kPairRec;
@@ -233,6 +252,15 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
           }
         }
       }
+      if (offc) {  // ... and back: v = v_c - w x (R com)
+        for (int i = 0; i < A; ++i) {
+          const float* pi = wpose + (wbase + i) * 8;
+          float* o = wvel + (wbase + i) * kPairVelStride;
+          const v3 cw = mul(rot_from_quat(quat{pi[3], pi[4], pi[5], pi[6]}), comb);
+          const v3 vb = v3{o[0], o[1], o[2]} - cross(v3{o[3], o[4], o[5]}, cw);
+          o[0] = vb.x; o[1] = vb.y; o[2] = vb.z;
+        }
+      }
     }
     m = __ballot(todo);
   }
@@ -248,9 +276,14 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
 // pairs x 15 axes in every tick for the rest of the episode (one such pair in 16 384 worlds made every launch 5x longer).
 template <class BODY>
 PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, const float bound_radius, const pf_params* __restrict__ Pd,
-                           const bool at_rest = false) {
+                           const bool at_rest = false, float* wvel = nullptr) {
   const int wbase = (tid / A) * A, wlocal = tid - wbase;
   float* me = wpose + tid * 8;
+  if (wvel != nullptr && at_rest) {  // (a wreck at rest sits this tick out: what the pair stage finds for it is a body standing still)
+    float* o = wvel + tid * kPairVelStride;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = 0.0f;
+  }
   me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
   me[7] = b.contact_now ? 1.0f : 0.0f;
   lds_sync_wave();

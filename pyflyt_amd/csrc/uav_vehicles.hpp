@@ -1077,6 +1077,7 @@ struct Fixedwing {
   PF_DEV v3 link_pos(const pf_params& P, int k) const {  // surface link COMs (lifting_surfaces.py:83-93)
     return b.p + mul(b.R, v3{P.surf[k].r[0], P.surf[k].r[1], P.surf[k].r[2]});
   }
+  template <bool SHARED = false>
   PF_DEV void tick(const pf_params& P, float xi, const float* wind = nullptr) {
     v3 F{0.0f, 0.0f, 0.0f}, tau{0.0f, 0.0f, 0.0f};
 #pragma unroll 1
@@ -1107,7 +1108,7 @@ struct Fixedwing {
       F = F + f;
       tau = tau + cross(r, f) + (k * P.motor_tmax[0]) * u;
     }
-    b.tick(P, F, tau);
+    b.template tick<SHARED>(P, F, tau);
   }
   PF_DEV void tick_unarmed(const pf_params& P) { b.tick(P, v3{0.f, 0.f, 0.f}, v3{0.f, 0.f, 0.f}); }
   template <int MODE_T>

@@ -198,6 +198,50 @@ def dogfight_cases():
     ]
 
 
+# what pyflyt_amd/params.py: WORLD assumes about the engine, next to the getPhysicsEngineParameters() key that settles it
+WORLD_VS_ENGINE = [("contact_iters", "numSolverIterations", 50), ("contact_residual_threshold", "solverResidualThreshold", 1e-7),
+                   ("contact_erp", "contactERP", 0.2), ("contact_slop", "contactSlop", 1e-5), ("physics_hz", "fixedTimeStep", 1.0 / 240.0),
+                   ("contact_break_distance", "contactBreakingThreshold", 0.02), ("gravity_z", "gravityAccelerationZ", -9.81)]
+
+
+def print_engine_facts(facts_json):
+    eng = json.loads(facts_json).get("engine", {})
+    print("getPhysicsEngineParameters() against pyflyt_amd.params.WORLD (DESIGN.md section 3: every entry is [BULLET-FROM-MEMORY]):")
+    for ours, key, assumed in WORLD_VS_ENGINE:
+        got = eng.get(key, "<not reported by this pybullet>")
+        flag = "" if not isinstance(got, (int, float)) or abs(float(got) - float(assumed)) <= 1e-9 * max(1.0, abs(float(assumed))) else "   <-- DIFFERS"
+        print(f"  {ours:28s} assumed {assumed!r:12}  {key} = {got!r}{flag}")
+    print("  (all of them: " + json.dumps(eng) + ")")
+
+
+def contact_probe():
+    """The contact facts no engine parameter reports: from which gap on getContactPoints lists a descending cf2x against the plane
+    (WORLD contact_report_distance, assumed 0: from touching on), how many points the manifold then holds (contact_manifold_points,
+    assumed <= 4) and at what distances, and up to which gap a RISING body keeps them (contact_break_distance, assumed 0.02)."""
+    from PyFlyt.core import Aviary
+
+    out = dict(step=[], lowest_z=[], n_points=[], distances=[])
+    for label, z0, vz in (("descending", 0.06, -0.2), ("rising", 0.0105, 0.3)):
+        env = Aviary(start_pos=np.array([[0.0, 0.0, z0]]), start_orn=np.zeros((1, 3)), drone_type="quadx", render=False, np_random=ZeroNoiseRNG(0))
+        env.set_mode(-1)
+        env.set_setpoint(0, np.zeros(4))
+        env.resetBaseVelocity(env.drones[0].Id, [0.0, 0.0, vz], [0.0, 0.0, 0.0])
+        first = None
+        for k in range(60):
+            env.step()
+            z = float(env.state(0)[3][2]) - 0.01  # the collision box is 0.02 thick, centred on the base (cf2x.urdf:30-36)
+            pts = env.getContactPoints(env.drones[0].Id)
+            out["step"].append(k); out["lowest_z"].append(z); out["n_points"].append(len(pts)); out["distances"].append([float(p[8]) for p in pts][:8] + [np.nan] * max(0, 8 - len(pts)))
+            if label == "descending" and pts and first is None:
+                first = (k, z, len(pts), [round(float(p[8]), 5) for p in pts])
+            if label == "rising" and not pts and first is None and k > 0:
+                first = (k, z)
+        print(f"contact probe, {label}: " + (f"first report at step {first[0]}, lowest vertex at z = {first[1]:+.5f}, {first[2]} points, contactDistance {first[3]}"
+                                             if label == "descending" and first else f"points kept until step {first[0] if first else None}, lowest vertex then at z = {first[1] if first else float('nan'):+.5f}"))
+        env.disconnect()
+    return {k: np.asarray(v) for k, v in out.items()}
+
+
 def main():
     try:
         import pybullet
@@ -205,10 +249,16 @@ def main():
     except ImportError as e:
         sys.exit(f"capture_pybullet.py needs the real reference stack (pip install PyFlyt pybullet): {e}")
     os.makedirs(OUT, exist_ok=True)
+    try:
+        np.savez_compressed(os.path.join(OUT, "contact_probe.npz"), **contact_probe())
+    except Exception as e:  # noqa: BLE001 (a probe: never in the way of the captures)
+        print("contact probe failed:", repr(e))
     prov = dict(pybullet_api=int(pybullet.getAPIVersion()), pyflyt_version=str(getattr(PyFlyt, "__version__", "?")),
                 numpy_version=np.__version__)
     for name, drone, mode, steps, seed, pos, orn, opts in CASES:
         d = run_aviary(drone, mode, steps, seed, pos, orn, opts)
+        if name == CASES[0][0]:
+            print_engine_facts(str(d["bullet_facts"]))
         d.update(prov)
         if drone == "rocket":
             d["starting_fuel_ratio"] = float((opts or {}).get("starting_fuel_ratio", 0.05))

@@ -689,6 +689,26 @@ def gen_dogfight():
         rec = run("env_dogfight_crash", 260, crash, seed=7, spawn=(pos, orn), flight_dome_size=400.0, max_duration_seconds=8.0)
         print("crash: steps", len(rec["action"]), "health", np.array(rec["health"])[-1], "bits", np.bitwise_or.reduce(np.array(rec["info_bits"]), axis=0),
               "others rows seen", sorted(set(int((~np.isnan(o) & (o != 0)).sum()) for o in np.array(rec["obs"]).reshape(-1, 65))))
+        # a mid-air collision (ma_fixedwing_dogfight_env.py:672-676: both aircraft are out, -1000, health 0 -- and fly on as wrecks
+        # that the other two keep observing): 0 and 2 head-on at the same height, 30 cm apart sideways, the other two far away.
+        # Recorded twice: with the contact response between the aircraft (what stepSimulation does) and, as a control, without it
+        # (`obs_nopair`): where the two recordings part is what the pair stage is worth.
+        pos = np.array([[-20.0, 0.0, 50.0], [0.0, 120.0, 60.0], [19.8, -2.52, 50.0], [0.0, -120.0, 60.0]])
+        orn = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 1.5], [0.0, 0.0, 3.0], [0.0, 0.0, -1.5]])
+
+        def level(k, i, g):
+            return np.array([0.0, 0.0, 0.0, 0.6]) + (g.uniform(-0.03, 0.03, size=4) if i in (1, 3) else 0.0)
+
+        rec = run("env_dogfight_midair", 60, level, seed=9, spawn=(pos, orn), flight_dome_size=400.0, max_duration_seconds=6.0)
+        term = np.array(rec["term"])
+        print("midair: collision steps", [int(np.argmax(term[:, i])) if term[:, i].any() else None for i in range(4)], "bits", np.bitwise_or.reduce(np.array(rec["info_bits"]), axis=0))
+        fake_bullet.BulletClient.DEFAULT_PAIR_RESPONSE = False
+        try:
+            rec0 = run("env_dogfight_midair_nopair", 60, level, seed=9, spawn=(pos, orn), flight_dome_size=400.0, max_duration_seconds=6.0)
+        finally:
+            fake_bullet.BulletClient.DEFAULT_PAIR_RESPONSE = True
+        d = np.nan_to_num(np.array(rec["obs"])[:, [1, 3]]) - np.nan_to_num(np.array(rec0["obs"])[:, [1, 3]])
+        print("midair: the survivors' observations with / without the pair stage part by", float(np.abs(d).max()))
     finally:
         np.random.default_rng = orig
         fake_bullet.BulletClient.DEFAULT_CONTACT_RESPONSE = True

@@ -123,6 +123,48 @@ def test_dogfight_golden_replay(name):
           f"row-layout mismatches per observer {layout_mismatch.tolist()}")
 
 
+def test_midair_collision_pushes_the_aircraft_apart():
+    """tests/golden/env_dogfight_midair.npz: two aircraft meet head-on (ma_fixedwing_dogfight_env.py:672-676: both are out in that
+    step) and fly on as wrecks that the two survivors keep observing. What the wrecks do afterwards is stepSimulation's contact
+    response BETWEEN the aircraft (shared_world.hpp: pair_stage_dev, in the dogfight kernel since round 4): the device follows the
+    recording made with it, and is metres away from the control recording made without it."""
+    g, g0 = np.load(os.path.join(GOLD, "env_dogfight_midair.npz")), np.load(os.path.join(GOLD, "env_dogfight_midair_nopair.npz"))
+    E = 16
+    eng, A = _engine(E, "inject", team_size=int(g["team_size"]), damage_per_hit=float(g["damage_per_hit"]), lethal_distance=float(g["lethal_distance"]),
+                     lethal_angle=float(g["lethal_angle"]), aggressiveness=float(g["aggressiveness"]), cooperativeness=float(g["cooperativeness"]),
+                     sparse_reward=bool(g["sparse_reward"]), flight_dome_size=float(g["dome"]), max_duration_seconds=int(g["max_steps"]) / 30.0)
+    S = 19 + int(g["action_dim"])
+    _set_spawn(eng, np.tile(g["start_pos"], (E, 1)), np.tile(g["start_orn"], (E, 1)))
+    tile = lambda x: torch.tensor(np.tile(x, (1, E)), dtype=torch.float32, device="cuda:0").contiguous()  # noqa: E731
+    eng.env_reset(xi_reset=tile(g["reset_xi"]))
+    k0 = int(np.argmax(g["term"][:, 0]))
+    assert g["term"][k0, 2] and not g["term"][:, [1, 3]].any()
+    worst_before = worst_after = gap_control = 0.0
+    for k in range(min(len(g["action"]), k0 + 25)):
+        act = torch.tensor(np.tile(g["action"][k], (E, 1)), dtype=torch.float32, device="cuda:0")
+        o, r, t, u = eng.env_step(act, xi=tile(g["xi"][k]))
+        o = o.cpu().numpy().astype(np.float64).reshape(E, A, -1)[0]
+        t = t.cpu().numpy().reshape(E, A)[0]
+        for i in range(A):
+            if not g["alive"][k][i]:
+                continue
+            assert bool(t[i]) == bool(g["term"][k][i]), (k, i)
+            e = _rel(o[i], g["obs"][k][i]).max()
+            if k < k0:
+                worst_before = max(worst_before, e)
+                assert e < 5e-4, (k, i, e)
+            elif i in (1, 3):  # the survivors: their own block to the flight tolerance, their rows of the wrecks to the impact tolerance
+                assert _rel(o[i][:S], g["obs"][k][i][:S]).max() < 5e-4, (k, i)
+                worst_after = max(worst_after, e)
+                gap_control = max(gap_control, _rel(g0["obs"][k][i], g["obs"][k][i]).max())
+        if k == k0:  # (-1000 for the collision, then overridden by the element-wise team-win rule: both teams lost their opponent's last ... as recorded)
+            np.testing.assert_allclose(r.cpu().numpy().reshape(E, A)[0][[0, 2]], g["reward"][k][[0, 2]], rtol=1e-5)
+    print(f"mid-air collision at step {k0}: worst before {worst_before:.2e}; the survivors' view of the wrecks over the next 24 steps: device vs recording {worst_after:.2e}, "
+          f"recording without the pair stage vs recording {gap_control:.2e}")
+    assert worst_after < 6e-2          # (measured 2.2e-2) a head-on impact at 40 m/s closing speed, tumbling wrecks: the fp32 sensitivity of such a transient
+    assert gap_control > 20 * worst_after
+
+
 def _uniforms(seed, lane_id, ctr, count, stream):
     """The device's reset-time uniforms for a world (Noise::uniform): Philox4x32-10 keyed (seed, first lane of the world, event
     counter, flat >> 2, stream), through the oracle's generator."""

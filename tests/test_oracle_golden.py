@@ -417,7 +417,7 @@ def test_ma_quadx_hover_shared_world_trajectory(golden_dir, name):
 
 
 @pytest.mark.parametrize("name", ["env_dogfight_default", "env_dogfight_engage", "env_dogfight_crash", "env_dogfight_team1_sparse", "env_dogfight_team3",
-                                  "env_dogfight_unassisted"])
+                                  "env_dogfight_unassisted", "env_dogfight_midair"])
 def test_dogfight_trajectory(golden_dir, name):
     """MAFixedwingDogfightEnv (ma_fixedwing_dogfight_env.py) recorded from the reference's env on fake_bullet, replayed through
     orc_dogfight_*: observation (self + the others in the own body frame, inactive aircraft dropped, zero padded), the
@@ -445,6 +445,14 @@ def test_dogfight_trajectory(golden_dir, name):
         assert (np.array(W.D.received_hits[:W.A]) == g["received_hits"][k]).all()
     if name == "env_dogfight_engage":
         assert g["received_hits"][-1].sum() > 50 and (bits & 1).any() and (bits & 8).any()  # hits, deaths, team wins
+    if name == "env_dogfight_midair":
+        # two aircraft met in mid-air: both out in the same step with the collision bit, and what the survivors see of the wrecks
+        # afterwards is the contact response BETWEEN the aircraft -- the control recording without it parts from this one by metres
+        assert (bits[[0, 2]] & 2).all() and not (bits[[1, 3]] & 2).any()
+        g0 = load(golden_dir, "env_dogfight_midair_nopair")
+        k0 = int(np.argmax(g["term"][:, 0]))
+        assert np.abs(np.nan_to_num(g["obs"][:k0]) - np.nan_to_num(g0["obs"][:k0])).max() < 1e-9  # the same flight until the step of the hit
+        assert np.abs(np.nan_to_num(g["obs"][k0 + 5:, [1, 3]]) - np.nan_to_num(g0["obs"][k0 + 5:, [1, 3]])).max() > 1.0
     if name == "env_dogfight_crash":
         assert (bits & 4).any() and g["trunc"].any()  # out of bounds, truncation
         assert any(W.D.inactive[:W.A])  # a dead aircraft at rest on the ground has dropped out of the observations

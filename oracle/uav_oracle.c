@@ -308,7 +308,9 @@ static int contact_points_reach(const orc_params* P, const double p[3], const do
 /* projected Gauss-Seidel on the base twist (v at the base origin, w; world frame). Returns the deepest penetration. */
 /* diagnostics (tests/tools): [contacts 0..4+][0] = solves, [1] = sweeps, [2] = solves that ran into contact_iters */
 static long long g_solve_stats[5][3];
+static int g_solve_stats_on = 0; /* off unless a tool asks: the counters are shared between the OpenMP threads of the batch entry points */
 void orc_debug_solve_stats(long long* out, int clear) {
+  g_solve_stats_on = 1;
   memcpy(out, g_solve_stats, sizeof(g_solve_stats));
   if (clear) memset(g_solve_stats, 0, sizeof(g_solve_stats));
 }
@@ -370,7 +372,7 @@ static double contact_solve(const orc_params* PP, const orc_body* B, const doubl
     sweeps_run = it + 1;
     if (res2 <= W->contact_residual_threshold) break;
   }
-  {
+  if (g_solve_stats_on) {
     const int b = n > 4 ? 4 : n;
 #pragma omp atomic
     g_solve_stats[b][0] += 1;

@@ -375,6 +375,8 @@ void orc_env_step_batch(const orc_params* P, orc_lane* L, int n, const float* ac
                         int autoreset, double* obs, double* reward, uint8_t* term, uint8_t* trunc,
                         double* final_obs);
 int orc_sizeof_lane(void);
+/* diagnostics (tests/tools/solve_stats.py): solves, sweeps and cap hits by contact count (0..4+); the first call switches the counters on */
+void orc_debug_solve_stats(long long* out, int clear);
 int orc_sizeof_params(void);
 int orc_num_threads(void);
 

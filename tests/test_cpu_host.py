@@ -129,6 +129,46 @@ def test_build_params_validation():
         build_params("rocket", "hover")
     P = build_params("quadx", "hover", agent_hz=30, max_duration_seconds=5.0)
     assert P.env_step_ratio == 4 and P.max_steps == 150
+    # the contact model's parameters (include/pyflyt_amd.h at pf_params.contact_response): world_options reach the block, and the
+    # values the device code cannot take are refused on the host
+    P = build_params("quadx", "hover", world_options=dict(contact_report_distance=0.02, contact_break_distance=0.01, contact_manifold_points=8,
+                                                          contact_iters=10, contact_residual_threshold=0.0))
+    assert (P.contact_manifold_points, P.contact_iters) == (8, 10) and P.contact_residual_threshold == 0.0
+    assert abs(P.contact_report_distance - 0.02) < 1e-8 and abs(P.contact_break_distance - 0.01) < 1e-8
+    with pytest.raises(ValueError, match="contact_manifold_points"):
+        build_params("quadx", "hover", world_options=dict(contact_manifold_points=6))
+    with pytest.raises(ValueError, match="non-negative"):
+        build_params("quadx", "hover", world_options=dict(contact_slop=-1e-3))
+
+
+def test_bench_replays_counters_only_for_the_kernels_they_were_collected_on(tmp_path, monkeypatch):
+    """bench.py: roofline.traffic / roofline.issue come from the committed PMC collection -- keyed by the source hash of the device
+    code, null with the reason when the kernels have changed since, when the env / batch is not covered, or when there is no file."""
+    import json
+
+    import bench
+
+    h = bench.source_hash()
+    assert len(h) == 16 and h == bench.source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_record("hover", 65536)[0] is None
+    rec = {"source_hash": h, "source": "x", "envs": {"hover": {"batch": 65536, "hbm_bytes_per_launch": 22e6, "valu_per_wave": 2300.0, "salu_per_wave": 360.0,
+                                                                 "clocks_per_inst": 8.0}}}
+    (prof / "pmc_latest.json").write_text(json.dumps(rec))
+    ent, why = bench.pmc_record("hover", 65536)
+    assert why is None and ent["hbm_bytes_per_launch"] == 22e6
+    r = bench.roofline_block("hover", 65536, 10.5e-6, "k")
+    assert r["traffic"] == 22e6 and abs(r["frac"] - 330 * 65536 / 10.5e-6 / 1e9 / 8000.0) < 1e-12
+    assert abs(r["issue"]["min_us"] - 2300.0 * 4 / 2400.0) < 1e-9 and abs(r["issue"]["frac"] - r["issue"]["min_us"] / 10.5) < 1e-9
+    assert bench.pmc_record("hover", 4096)[0] is None and "cover" in bench.pmc_record("quadx_waypoints", 65536)[1]
+    rec["source_hash"] = "0" * 16
+    (prof / "pmc_latest.json").write_text(json.dumps(rec))
+    ent, why = bench.pmc_record("hover", 65536)
+    assert ent is None and why.startswith("stale")
+    r = bench.roofline_block("hover", 65536, 10.5e-6, "k")
+    assert r["traffic"] is None and "issue" not in r and r["traffic_source"].startswith("stale")
 
 
 def test_quadk_hot_path_selection(built):

@@ -31,6 +31,11 @@ def test_device_params_match_oracle_params(vehicle, opts, oname):
     assert P.dt == pytest.approx(Q.world.dt, rel=1e-6) and P.ticks_per_control == Q.world.ticks_per_control
     assert P.gravity_z == pytest.approx(Q.world.gravity_z, rel=1e-6) and P.max_coord_vel == pytest.approx(Q.world.max_coord_vel)
     assert bool(P.use_gyro_term) == bool(Q.world.use_gyro_term)
+    # the contact model's named parameters: the same defaults on both sides
+    for f in ("contact_restitution", "contact_friction", "contact_erp", "contact_margin", "contact_slop", "contact_report_distance",
+              "contact_break_distance", "contact_residual_threshold"):
+        assert float(getattr(P, f)) == pytest.approx(float(getattr(Q.world, f)), rel=1e-6, abs=1e-12), f
+    assert (P.contact_response, P.contact_iters, P.contact_manifold_points) == (Q.world.contact_response, Q.world.contact_iters, Q.world.contact_manifold_points)
     assert 1.0 / P.inv_mass == pytest.approx(Q.mass, rel=2e-6)
     np.testing.assert_allclose(list(P.com), list(Q.com), **rt)
     np.testing.assert_allclose(list(P.I_own), sym6(Q.I_own), **rt)

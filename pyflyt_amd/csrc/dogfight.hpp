@@ -141,10 +141,15 @@ constexpr int kDfRec = 28;
 // A: aircraft per world (2 team_size), a template parameter so that the per-row loops and register arrays have their exact size
 // and the observation tile (the biggest LDS user: 64 x (23 + 14 (A - 1)) floats) does not limit the workgroups per CU for the
 // common 2 v 2 case.
-template <int A, class VEH>
+// ROLLOUT (pf_rollout, round 4): k_steps env steps in ONE launch with every aircraft's state resident in registers -- the PettingZoo
+// loop of tests/test_pz_envs.py:71-93 without the state's round trip through HBM and without a launch per step. Every step still
+// writes its observation / reward / flags, to trajectory buffers [k_steps][n][..]; actions: the given sequence b.actions
+// [k_steps][n][AD], or sampled on device with pf_sample_actions' keys (four-wide). Bit-identical to k_steps x (pf_sample_actions +
+// pf_env_step): the same code, instantiated with the loop.
+template <int A, class VEH, bool ROLLOUT = false>
 __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, const pf_buffers B, const int n, const uint64_t lane0,
                                                           const int op, const uint8_t* mask, const pf_params* __restrict__ Pdev,
-                                                          const FwTable* table_g) {
+                                                          const FwTable* table_g, const int k_steps = 1, const uint32_t step0 = 0u) {
   constexpr int Dmax = 25 + (A - 1) * 14;  // (six-wide actions: two more past-action entries)
   constexpr int kTile = 64 * Dmax > kContactSlotFloats ? 64 * Dmax : kContactSlotFloats;  // (at least one worst-case solver region)
   const int AD = P.df_action_dim == 6 ? 6 : 4;
@@ -378,6 +383,10 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
 
   float out_reward = 0.0f;
   bool out_term = false, out_trunc = false;
+  const int KS = ROLLOUT ? k_steps : 1;
+  for (int it = 0; it < KS; ++it) {
+  const size_t toff = ROLLOUT ? (size_t)it * N : (size_t)0;  // this step's slot in the trajectory buffers (lanes)
+  out_reward = 0.0f; out_term = false; out_trunc = false;
   if (op == 1) {
     // ---------------------------------------------------------------- reset (dogfight :215-322, base env :160-234)
     if (do_reset) {
@@ -416,11 +425,21 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     }
   } else {
     // ---------------------------------------------------------------- step (ma_fixedwing_base_env.py:272-334)
-    const float* ap = B.actions + (size_t)AD * li;
-    const float4 a = float4{ap[0], ap[1], ap[2], ap[3]};
+    float4 a;
+    float a4 = 0.0f, a5 = 0.0f;
+    if (ROLLOUT && B.actions == nullptr) {  // == sample_actions_kernel(step0 + it): same Philox key, same arithmetic (four-wide)
+      const f4 u = uniform4(philox4x32((uint32_t)P.seed, (uint32_t)(P.seed >> 32), (uint32_t)(lane0 + li), step0 + (uint32_t)it, 0u, 3u));
+      a = float4{fmaf(P.action_high[0] - P.action_low[0], u.a, P.action_low[0]), fmaf(P.action_high[1] - P.action_low[1], u.b, P.action_low[1]),
+                 fmaf(P.action_high[2] - P.action_low[2], u.c, P.action_low[2]), fmaf(P.action_high[3] - P.action_low[3], u.d, P.action_low[3])};
+      if (B.actions_out != nullptr && active) reinterpret_cast<float4*>(B.actions_out)[toff + li] = a;
+    } else {
+      const float* ap = B.actions + (size_t)AD * (toff + li);
+      a = float4{ap[0], ap[1], ap[2], ap[3]};
+      if (AD == 6) { a4 = ap[4]; a5 = ap[5]; }
+    }
     past_a4 = cur_a4;
     cur_a4 = (df & DF_ALIVE) ? a : float4{0.f, 0.f, 0.f, 0.f};  // culled agents: zero commands (:293-297)
-    if (AD == 6) a45 = float4{(df & DF_ALIVE) ? ap[4] : 0.f, (df & DF_ALIVE) ? ap[5] : 0.f, a45.x, a45.y};
+    if (AD == 6) a45 = float4{(df & DF_ALIVE) ? a4 : 0.f, (df & DF_ALIVE) ? a5 : 0.f, a45.x, a45.y};
     // :300-301 remaps the LAST action entry; mode 0 (the Aviary's mode whatever assisted_flight says, :229) reads entries 0..3
     sp[0] = cur_a4.x; sp[1] = cur_a4.y; sp[2] = cur_a4.z; sp[3] = AD == 4 ? fmaf(cur_a4.w, 0.5f, 0.5f) : cur_a4.w;
     nz.begin_event(rng_ctr, 0u, B.xi);
@@ -443,13 +462,20 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     const bool wave_all = __all(active || !valid);
     if (wave_all) {
       const int rows = min(LPW, n - wave_base);
-      stream_tile(tile, B.obs + (size_t)wave_base * D, rows * D, tid, LPW);
+      stream_tile(tile, B.obs + (toff + (size_t)wave_base) * D, rows * D, tid, LPW);
     } else if (active) {
-      float* g = B.obs + (size_t)lane * D;
+      float* g = B.obs + (toff + (size_t)lane) * D;
       const float* row = tile + tid * D;
       for (int k = 0; k < D; ++k) g[k] = row[k];
     }
   }
+  if (active && op == 0) {
+    B.reward[toff + li] = out_reward;
+    B.terminated[toff + li] = out_term ? 1 : 0;
+    B.truncated[toff + li] = out_trunc ? 1 : 0;
+  }
+  if (ROLLOUT) lds_sync_wave();  // (the tile is the next step's solver / exchange scratch)
+  }  // for it
   if (active) {
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT | PF_F_INFO_COLLISION | PF_F_INFO_OOB)) | (out_term ? PF_F_TERMINATED : 0) |
             (out_trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0) | ((df & DF_INFO_COLLISION) ? PF_F_INFO_COLLISION : 0) |
@@ -468,11 +494,6 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     Sout[13 * N + li] = sp_a;
     Sout[14 * N + li] = sp_b;
     Sout[15 * N + li] = a45;
-    if (op == 0) {
-      B.reward[li] = out_reward;
-      B.terminated[li] = out_term ? 1 : 0;
-      B.truncated[li] = out_trunc ? 1 : 0;
-    }
   }
 }
 

@@ -1080,9 +1080,24 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
   const pf_params& P = ctx->P;
   const bool fw = ctx->fast_fw && ctx->tmpl;
   if (P.noise_mode == PF_NOISE_INJECT) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: PF_NOISE_INJECT is a per-step protocol; use pf_env_step");
+  if (P.task == PF_TASK_DOGFIGHT && ctx->df_fast && (b->actions || P.df_action_dim != 6)) {
+    // the dogfight on its specialised aircraft: state-resident, dogfight_env_kernel<.., ROLLOUT = true> (four-wide actions sampled
+    // on device, or the given sequence of either width)
+    int rc = ensure_device(ctx);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int lpw = (64 / P.agents_per_world) * P.agents_per_world;  // whole worlds per wave
+    dim3 grid((ctx->n + lpw - 1) / lpw);
+#define PF_DFR(AA) hipLaunchKernelGGL((pf::dogfight_env_kernel<AA, pf::DfFastVeh, true>), grid, dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, 0, \
+                                      (const uint8_t*)nullptr, ctx->P_dev, ctx->surf_dev, k_steps, step_index0)
+    switch (P.agents_per_world) { case 2: PF_DFR(2); break; case 4: PF_DFR(4); break; case 6: PF_DFR(6); break; default: PF_DFR(8); break; }
+#undef PF_DFR
+    PF_HIP(ctx, hipGetLastError());
+    return PF_OK;
+  }
   if (!fw && !ctx->fast) {
     // Every other task (the generic env kernels: tilted multi-agent spawns, airframes outside the specialised envelopes; the
-    // dogfight): the same k_steps as k_steps x (pf_sample_actions + pf_env_step), enqueued back to back by this one call -- the
+    // dogfight on a generic airframe): the same k_steps as k_steps x (pf_sample_actions + pf_env_step), enqueued back to back by this one call -- the
     // PettingZoo loop of tests/test_pz_envs.py:71-93 without a host round trip per step. One launch (pair) per step, the state
     // goes through HBM between them: the trajectory layout and the results of the state-resident form, not its speed.
     if (P.task == PF_TASK_NONE) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: this context has no env task");

@@ -225,9 +225,10 @@ class BatchEngine:
             self._traj = t
         self._check_f32(actions, (k, self.n, self.action_dim), "actions")
         # (outside the specialised kernels the library runs one launch per step and needs the sampled actions to live somewhere)
-        # (the library's own predicate, pf_rollout: state-resident for the QuadX and Fixedwing-Waypoints kernels only -- the
-        #  specialised dogfight kernel, which pf_ctx_is_specialised reports as well, steps once per launch)
-        resident = self.lib.pf_ctx_is_specialised(self._ctx) != 0 and self.params.task != L.TASK_DOGFIGHT
+        # (the library's own predicate, pf_rollout: state-resident on every specialised kernel -- QuadX, Fixedwing-Waypoints and, since
+        #  round 4, the dogfight on its specialised aircraft with four-wide actions; everything else steps once per launch and needs
+        #  the sampled actions to live somewhere)
+        resident = self.lib.pf_ctx_is_specialised(self._ctx) != 0 and not (self.params.task == L.TASK_DOGFIGHT and self.action_dim == 6)
         keep = (store_actions or not resident) and actions is None
         b = self._buffers(actions=actions, actions_out=t["actions"] if keep else None)
         b.obs, b.reward, b.terminated, b.truncated = _ptr(t["obs"]), _ptr(t["reward"]), _ptr(t["terminated"]), _ptr(t["truncated"])

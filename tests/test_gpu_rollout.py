@@ -220,7 +220,26 @@ def test_rollout_dogfight():
     a, b = make(), make()
     k = 10
     obs, rew, term, trunc, acts = a.rollout(k, step_index0=7)
+    ref = torch.empty(4 * 50, 4, device="cuda:0")
     for s in range(k):
+        b.sample_actions(ref, 7 + s)  # the resident kernel samples with pf_sample_actions' keys
+        assert torch.equal(acts[s], ref), s
         o, r, t, u = b.env_step(acts[s].contiguous())
         assert torch.equal(obs[s], o) and torch.equal(rew[s], r) and torch.equal(term[s], t) and torch.equal(trunc[s], u), s
     assert torch.equal(a.state, b.state)
+    # ... through a longer flight (aircraft reach the ground: contact solve, wrecks, the pair stage's exchange arrays reused step
+    # after step inside one launch), over a GIVEN action sequence, and without keeping the sampled actions
+    k2 = 120
+    seq = torch.empty(k2, 4 * 50, 4, device="cuda:0")
+    for s in range(k2):
+        b.sample_actions(seq[s], 1000 + s)
+    obs2, rew2, term2, trunc2, _ = a.rollout(k2, actions=seq)
+    for s in range(k2):
+        o, r, t, u = b.env_step(seq[s].contiguous())
+        assert torch.equal(obs2[s], o) and torch.equal(rew2[s], r) and torch.equal(term2[s], t) and torch.equal(trunc2[s], u), s
+    assert torch.equal(a.state, b.state)
+    obs3, *_rest, none = a.rollout(5, step_index0=5000, store_actions=False)
+    assert none is None
+    for s in range(5):
+        b.sample_actions(ref, 5000 + s)
+        assert torch.equal(obs3[s], b.env_step(ref)[0]), s

@@ -249,16 +249,22 @@ struct ContactSet {
       // two register sets, each loaded one contact ahead of its use; contacts in pairs (for an odd count the last row of every lane
       // is the sentinel's, skipped as idle; a scalar exit between the two rows of a pair cost more than it saved: 19.8 -> 21.0 us per
       // tick for landed quadrotors)
+      // (the sixth quad of a record holds one live word, the y cone factor: read as ONE dword. Read as a quad, its three dead
+      //  registers were handed out as temporaries of the row that runs while the prefetch is in flight -- a write-after-write on
+      //  the pending load's destination, for which the compiler waits for the WHOLE prefetch: lgkmcnt(0) in front of every second
+      //  row, the LDS latency the prefetch exists to hide)
       lds_f4ptr p0 = rec(0u);
-      pf_f4v a0 = p0[0], a1 = p0[1], a2 = p0[2], a3 = p0[3], a4 = p0[4], a5 = p0[5];
+      pf_f4v a0 = p0[0], a1 = p0[1], a2 = p0[2], a3 = p0[3], a4 = p0[4];
+      float a5 = ((lds_fptr)p0)[20];
       uint32_t off = 0u;  // (wave-uniform)
       for (int c = 0; c < npair; ++c) {
         lds_f4ptr pa = rec(off), nb = rec(off + kRecBytes);
-        const pf_f4v b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3], b4 = nb[4], b5 = nb[5];
-        row3(a0, a1, a2, a3, a4, a5.x, pa + 4);
+        const pf_f4v b0 = nb[0], b1 = nb[1], b2 = nb[2], b3 = nb[3], b4 = nb[4];
+        const float b5 = ((lds_fptr)nb)[20];
+        row3(a0, a1, a2, a3, a4, a5, pa + 4);
         lds_f4ptr na = rec(off + 2u * kRecBytes);
-        a0 = na[0]; a1 = na[1]; a2 = na[2]; a3 = na[3]; a4 = na[4]; a5 = na[5];
-        row3(b0, b1, b2, b3, b4, b5.x, nb + 4);
+        a0 = na[0]; a1 = na[1]; a2 = na[2]; a3 = na[3]; a4 = na[4]; a5 = ((lds_fptr)na)[20];
+        row3(b0, b1, b2, b3, b4, b5, nb + 4);
         off += 2u * kRecBytes;
       }
 #ifdef PF_PHASE_TRACE

@@ -131,7 +131,8 @@ typedef struct pf_params {
    *    contact_friction x normal impulse. Projected Gauss-Seidel at the velocity level in collider / vertex order: at most
    *    contact_iters sweeps (50 = PyBullet's numSolverIterations), ended early once the largest squared change of a row's
    *    velocity within a sweep is <= contact_residual_threshold (1e-7 = PyBullet's solverResidualThreshold, i.e. 3.2e-4 m/s;
-   *    0: only an idle sweep ends it).
+   *    0: only an idle sweep ends it). Every solve starts from zero impulses: no warm start, as in Bullet's multibody
+   *    solver, where it is switched off (setupMultiBodyContactConstraint: `if (0)`) [BULLET-FROM-MEMORY].
    *  - After the position update a translation of contact_erp x (deepest penetration - contact_slop) along +z.
    *  - contact_response = 0: detection only (bodies fall through the floor).
    * Contact REPORT (getContactPoints, core/aviary.py:523-525): the 15-axis box-box verdict against the other box ENLARGED by

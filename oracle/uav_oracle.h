@@ -88,7 +88,8 @@ typedef struct {
    * contact_margin (above): 0 by default for the same reason -- no constraint row exists before the boxes overlap.
    * contact_manifold_points: at most this many points per collider box and slab (4: btPersistentManifold holds four, dBoxBox2
    *   is called with maxc = 4): the vertices of the box face that looks down the most (the incident face). 8: every vertex.
-   * contact_iters: 50 = PyBullet's numSolverIterations default (Bullet's own default is 10).
+   * contact_iters: 50 = PyBullet's numSolverIterations default (Bullet's own default is 10). Every solve starts from zero
+   *   impulses (btMultiBodyConstraintSolver::setupMultiBodyContactConstraint has the warm start switched off [BULLET-FROM-MEMORY]).
    * contact_residual_threshold: the sweeps stop once the largest squared change of a row's velocity in a sweep is at or below
    *   it (btMultiBodyConstraintSolver::solveSingleIteration's leastSquaredResidual against m_leastSquaresResidualThreshold,
    *   which PyBullet's server sets to 1e-7, i.e. 3.2e-4 m/s). 0: only an exactly idle sweep ends the solve early.

@@ -1,6 +1,7 @@
 """warmstart_probe.py -- evidence script (CPU only, not a test): what carrying a persisting contact's NORMAL impulse over from the
-previous tick (Bullet's warm start: factor 0.85, friction rows from zero [BULLET-FROM-MEMORY: btMultiBodyConstraintSolver::
-setupMultiBodyContactConstraint]) would do to the number of sweeps a body at rest needs. Patches a temporary copy of the oracle's source
+previous tick (the warm start of Bullet's rigid-body solver: factor 0.85, friction rows from zero; switched off -- `if (0)` -- in
+btMultiBodyConstraintSolver::setupMultiBodyContactConstraint, the solver PyFlyt's URDF bodies go through [BULLET-FROM-MEMORY], which
+is why the model starts every solve from zero) would do to the number of sweeps a body at rest needs. Patches a temporary copy of the oracle's source
 (contact ids out of the vertex scan, a one-body cache in the solve) -- the shipped oracle, the device code and the fixtures do not
 warm-start. Quoted in DESIGN.md section 3.   python tests/tools/warmstart_probe.py"""
 import ctypes as C

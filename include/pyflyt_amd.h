@@ -335,11 +335,11 @@ int pf_sample_actions(pf_ctx* ctx, float* actions, uint32_t step_index, void* st
  * step s of lane i exactly as pf_sample_actions(step_index0 + s) would (same Philox keys) and, if
  * b->actions_out != NULL, stores it there; otherwise b->actions is a given open-loop sequence
  * [k_steps][n][4]. Results are bit-identical to k_steps x (pf_sample_actions + pf_env_step).
- * State-resident where the specialised env kernels are (QuadX Hover / Waypoints / multi-agent Hover with level spawns in any
- * flight mode, Fixedwing-Waypoints, and -- since ABI 8 -- the dogfight on its specialised aircraft: ma_fixedwing_base_env.py:272-334
- * in a loop, tests/test_pz_envs.py:71-93, sampled actions four-wide or a given sequence of either width [k_steps][n][4 | 6]); every
- * other env task (the generic kernels) gets the same trajectory buffers and the same results from one launch per step enqueued back
- * to back by this call (actions there: a given sequence, or sampled into b->actions_out). PF_NOISE_OFF / PHILOX; PF_ERR_UNSUPPORTED for PF_NOISE_INJECT and for contexts without an env task. */
+ * State-resident on every env kernel: the specialised ones (QuadX Hover / Waypoints / multi-agent Hover with level spawns in any
+ * flight mode, Fixedwing-Waypoints), the dogfight on either aircraft model (ma_fixedwing_base_env.py:272-334 in a loop,
+ * tests/test_pz_envs.py:71-93; sampled actions four-wide, or a given sequence of either width [k_steps][n][4 | 6]) and the generic
+ * env kernel behind every other configuration. PF_NOISE_OFF / PHILOX; PF_ERR_UNSUPPORTED for PF_NOISE_INJECT, for contexts without
+ * an env task, for an auto-reset mode of OFF on the specialised single-agent kernels, and for sampling six-wide dogfight actions. */
 int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_index0, void* stream);
 
 /* The reference's LOWER boundary for one drone: applyExternalForce / applyExternalTorque on the base link in

@@ -81,10 +81,15 @@ __device__ __noinline__ void aviary_step_outlined(VEH* V, const pf_params* P, co
 // `tmpl`: a settled spawn state (GROUPS float4s) computed once per context when the settle phase
 // cannot depend on the lane (Fixedwing: the settle throttle command is 0, so motor noise has
 // nothing to scale; any vehicle with noise off) -- a reset is then a copy.
+// roll_steps > 0: pf_rollout -- that many env steps in this one launch, the lane's state resident in registers between them (what a
+// relaunch would re-derive from the stored groups is re-derived by VEH::relaunch, so the trajectory is the one of roll_steps x
+// (pf_sample_actions + pf_env_step), bit for bit); step k's actions are B.actions[k] or drawn here with pf_sample_actions' keys
+// (step index step0 + k), its outputs go to slot k of the trajectory buffers. 0: one step (pf_env_step / pf_env_reset).
 template <class VEH, int TASK, int MODE_T>
 __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_buffers B, const int n,
                                                     const uint64_t lane0, const int op, const uint8_t* mask,
-                                                    const float4* __restrict__ tmpl, const pf_params* __restrict__ Pdev) {
+                                                    const float4* __restrict__ tmpl, const pf_params* __restrict__ Pdev,
+                                                    const int roll_steps, const uint32_t step0) {
   __shared__ __attribute__((aligned(16))) float tile[kWave * kMaxObs];
   __shared__ __attribute__((aligned(16))) float ktab[VEH::TABLE_FLOATS];
   __shared__ float wpose[kWave * 8];  // shared worlds: each lane's pose and contact bit, exchanged once per tick
@@ -131,18 +136,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   nz.k0 = (uint32_t)P.seed; nz.k1 = (uint32_t)(P.seed >> 32);
   nz.c0 = (uint32_t)(lane0 + li); nz.nmot = (float)P.n_motors; nz.cached = -1; nz.xi = nullptr;
 
-  bool active, do_reset;
-  if (op == OP_RESET) {
-    do_reset = (mask == nullptr) || (mask[li] != 0);
-    // (shared worlds: a mask that names some agents of a world resets the world)
-    if (TASK == PF_TASK_MA_HOVER && P.agents_per_world > 1) do_reset = widen_to_world(do_reset && valid, tid, P.agents_per_world);
-    active = do_reset;
-  } else {
-    do_reset = (P.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc);
-    active = true;
-  }
-  active = active && valid;
-  do_reset = do_reset && active;
+  bool active = false, do_reset = false, wave_all = false;  // (per env step: set at the top of the step loop below)
 
   float sp[6] = {0, 0, 0, 0, 0, 0};
   float act4[4] = {0, 0, 0, 0};   // action slots of the observation
@@ -295,7 +289,6 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
       }
     }
   };
-  const bool wave_all = __all(active || !valid);
   // tile -> global with full-width stores; LDS-only sync (one wave per workgroup, see quadx_fast.hpp)
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -317,15 +310,49 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     lds_sync();
   };
 
+  const int n_env_steps = roll_steps > 0 ? roll_steps : 1;
+  for (int ks = 0; ks < n_env_steps; ++ks) {
+  const size_t toff = (size_t)ks * N;  // this env step's slot in the trajectory buffers, in lanes
+  if (ks > 0) {  // what the next launch would start from: the stored groups, re-derived
+    V.relaunch(mode, flags);
+    rpy_valid = false;
+    old_dist = new_dist;
+    yaw_err0 = 0.0f;
+    reward = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sp[k] = 0.0f;
+    act4[0] = act4[1] = act4[2] = act4[3] = 0.0f;
+  }
+  if (op == OP_RESET) {
+    do_reset = (mask == nullptr) || (mask[li] != 0);
+    // (shared worlds: a mask that names some agents of a world resets the world)
+    if (TASK == PF_TASK_MA_HOVER && P.agents_per_world > 1) do_reset = widen_to_world(do_reset && valid, tid, P.agents_per_world);
+    active = do_reset;
+  } else {
+    do_reset = (P.autoreset == PF_AUTORESET_NEXT_STEP) && (term || trunc);
+    active = true;
+  }
+  active = active && valid;
+  do_reset = do_reset && active;
+  wave_all = __all(active || !valid);
+
   // ---------------------------------------------------------------- what each lane runs
   bool settling = false;  // in the settle phase of a reset (no env logic after an Aviary step)
   int my_its = 0;         // Aviary steps this lane still has to run in the loop below
+  float4 a = float4{0.f, 0.f, 0.f, 0.f};
+  if (roll_steps > 0 && B.actions == nullptr) {  // pf_sample_actions' draw for (lane, step0 + ks): every lane's, restarting or not
+    f4 u = uniform4(philox4x32((uint32_t)P.seed, (uint32_t)(P.seed >> 32), (uint32_t)(lane0 + li), step0 + (uint32_t)ks, 0u, 3u));
+    a = float4{fmaf(P.action_high[0] - P.action_low[0], u.a, P.action_low[0]), fmaf(P.action_high[1] - P.action_low[1], u.b, P.action_low[1]),
+               fmaf(P.action_high[2] - P.action_low[2], u.c, P.action_low[2]), fmaf(P.action_high[3] - P.action_low[3], u.d, P.action_low[3])};
+    if (B.actions_out != nullptr && valid) reinterpret_cast<float4*>(B.actions_out)[toff + li] = a;
+  } else if (active && !do_reset) {
+    a = reinterpret_cast<const float4*>(B.actions)[toff + li];
+  }
   if (do_reset) {
     begin_reset();
     settling = true;
     my_its = (tmpl != nullptr) ? 0 : P.settle_steps;
   } else if (active) {
-    const float4 a = reinterpret_cast<const float4*>(B.actions)[li];
     if (TASK == PF_TASK_MA_HOVER) {  // past <- current, current <- action (ma_quadx_base_env.py:326-332)
       ma_past = float4{tg.t[2][1], tg.t[2][2], tg.t[3][0], tg.t[3][1]};
       tg.t[2][1] = a.x; tg.t[2][2] = a.y; tg.t[3][0] = a.z; tg.t[3][1] = a.w;
@@ -387,12 +414,12 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     if (__any(same)) {
       if (B.final_obs != nullptr) {  // terminal observation, before the state is re-initialised
         if (active) write_obs_row();
-        flush_tile(B.final_obs);
+        flush_tile(B.final_obs + toff * D);
       }
       if (B.final_info != nullptr && same) {  // gymnasium's final_info: the episode's flags / targets left, pre-reset
-        B.final_info[2 * li + 0] = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
-                                   (trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0);
-        B.final_info[2 * li + 1] = tg.n_left - (pop_pending ? 1 : 0);
+        B.final_info[2 * (toff + li) + 0] = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
+                                            (trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0);
+        B.final_info[2 * (toff + li) + 1] = tg.n_left - (pop_pending ? 1 : 0);
       }
       if (same) {
         begin_reset();
@@ -416,21 +443,24 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
 
   // ---------------------------------------------------------------- outputs: obs tile first, state after
   if (active) write_obs_row();
-  flush_tile(B.obs);
+  flush_tile(B.obs + toff * D);
   if (active) {
     if (pop_pending) { tg.pop(); pop_pending = false; }
     flags = (flags & ~(PF_F_TERMINATED | PF_F_TRUNCATED | PF_F_CONTACT)) | (term ? PF_F_TERMINATED : 0) |
             (trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0);
-    V.store(Sout, N, li, mode, new_dist, int4{step_count, flags, (int)rng_ctr, tg.n_left});
-    if (kSide) tg.store(Sout, N, li, VEH::G_TGT);
-    if (kYaw) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = float4{tg.yaw[0], tg.yaw[1], tg.yaw[2], tg.yaw[3]};
-    if (TASK == PF_TASK_MA_HOVER) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = ma_past;
+    if (ks == n_env_steps - 1) {  // the state goes back to HBM once per launch
+      V.store(Sout, N, li, mode, new_dist, int4{step_count, flags, (int)rng_ctr, tg.n_left});
+      if (kSide) tg.store(Sout, N, li, VEH::G_TGT);
+      if (kYaw) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = float4{tg.yaw[0], tg.yaw[1], tg.yaw[2], tg.yaw[3]};
+      if (TASK == PF_TASK_MA_HOVER) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = ma_past;
+    }
     if (op == OP_STEP) {  // a NEXT_STEP reset call reports (r=0, not done), gymnasium's convention
-      B.reward[li] = out_reward;
-      B.terminated[li] = out_term ? 1 : 0;
-      B.truncated[li] = out_trunc ? 1 : 0;
+      B.reward[toff + li] = out_reward;
+      B.terminated[toff + li] = out_term ? 1 : 0;
+      B.truncated[toff + li] = out_trunc ? 1 : 0;
     }
   }
+  }  // (env steps of this launch)
 }
 
 // Settled spawn state for contexts whose settle phase is lane-independent (see env_kernel).
@@ -809,12 +839,12 @@ static void launch_rollout_fw(pf_ctx* ctx, const pf_buffers* b, int k_steps, uin
 #undef PF_ROLL
 }
 template <class VEH, int TASK>
-static void launch_env_t(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
+static void launch_env_t(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s, int roll_steps = 0, uint32_t step0 = 0u) {
   const int grid = (ctx->n + pf::kWave - 1) / pf::kWave;
   if (ctx->P.vehicle == PF_QUADX && ctx->P.flight_mode == 0)
-    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, 0>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl, ctx->P_dev);
+    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, 0>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl, ctx->P_dev, roll_steps, step0);
   else
-    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, pf::kRuntimeMode>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl, ctx->P_dev);
+    hipLaunchKernelGGL((pf::env_kernel<VEH, TASK, pf::kRuntimeMode>), dim3(grid), dim3(pf::kWave), 0, s, ctx->P, *b, ctx->n, ctx->lane0, op, mask, ctx->tmpl, ctx->P_dev, roll_steps, step0);
 }
 extern "C" {
 
@@ -1080,47 +1110,39 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
   const pf_params& P = ctx->P;
   const bool fw = ctx->fast_fw && ctx->tmpl;
   if (P.noise_mode == PF_NOISE_INJECT) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: PF_NOISE_INJECT is a per-step protocol; use pf_env_step");
-  if (P.task == PF_TASK_DOGFIGHT && ctx->df_fast && (b->actions || P.df_action_dim != 6)) {
-    // the dogfight on its specialised aircraft: state-resident, dogfight_env_kernel<.., ROLLOUT = true> (four-wide actions sampled
-    // on device, or the given sequence of either width)
+  if (P.task == PF_TASK_NONE) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: this context has no env task");
+  if (P.task == PF_TASK_DOGFIGHT) {
+    // the dogfight, state-resident on either aircraft model: dogfight_env_kernel<.., ROLLOUT = true> (four-wide actions sampled on
+    // device, or the given sequence of either width)
+    if (!b->actions && P.df_action_dim == 6) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: on-device sampling draws four-wide actions; pass the six-wide sequence in b->actions");
     int rc = ensure_device(ctx);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int lpw = (64 / P.agents_per_world) * P.agents_per_world;  // whole worlds per wave
     dim3 grid((ctx->n + lpw - 1) / lpw);
-#define PF_DFR(AA) hipLaunchKernelGGL((pf::dogfight_env_kernel<AA, pf::DfFastVeh, true>), grid, dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, 0, \
-                                      (const uint8_t*)nullptr, ctx->P_dev, ctx->surf_dev, k_steps, step_index0)
-    switch (P.agents_per_world) { case 2: PF_DFR(2); break; case 4: PF_DFR(4); break; case 6: PF_DFR(6); break; default: PF_DFR(8); break; }
+#define PF_DFR(AA, VV) hipLaunchKernelGGL((pf::dogfight_env_kernel<AA, VV, true>), grid, dim3(64), 0, s, ctx->P, *b, ctx->n, ctx->lane0, 0, \
+                                          (const uint8_t*)nullptr, ctx->P_dev, ctx->surf_dev, k_steps, step_index0)
+#define PF_DFRA(VV) switch (P.agents_per_world) { case 2: PF_DFR(2, VV); break; case 4: PF_DFR(4, VV); break; case 6: PF_DFR(6, VV); break; default: PF_DFR(8, VV); break; }
+    if (ctx->df_fast) { PF_DFRA(pf::DfFastVeh) } else { PF_DFRA(pf::DfGenericVeh) }
+#undef PF_DFRA
 #undef PF_DFR
     PF_HIP(ctx, hipGetLastError());
     return PF_OK;
   }
   if (!fw && !ctx->fast) {
-    // Every other task (the generic env kernels: tilted multi-agent spawns, airframes outside the specialised envelopes; the
-    // dogfight on a generic airframe): the same k_steps as k_steps x (pf_sample_actions + pf_env_step), enqueued back to back by this one call -- the
-    // PettingZoo loop of tests/test_pz_envs.py:71-93 without a host round trip per step. One launch (pair) per step, the state
-    // goes through HBM between them: the trajectory layout and the results of the state-resident form, not its speed.
-    if (P.task == PF_TASK_NONE) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: this context has no env task");
-    const int AD = (P.task == PF_TASK_DOGFIGHT && P.df_action_dim == 6) ? 6 : 4;
-    if (!b->actions && AD != 4) return fail(ctx, PF_ERR_UNSUPPORTED, "pf_rollout: on-device sampling draws four-wide actions; pass the six-wide sequence in b->actions");
-    if (!b->actions && !b->actions_out) return fail(ctx, PF_ERR_ARG, "pf_rollout: outside the specialised kernels the sampled actions need b->actions_out to live in");
-    const size_t n = (size_t)ctx->n, D = (size_t)pf_obs_dim(ctx);
-    for (int st = 0; st < k_steps; ++st) {
-      pf_buffers bs = *b;
-      const size_t o = (size_t)st * n;
-      if (b->actions) bs.actions = b->actions + o * AD;
-      else {
-        int rc = pf_sample_actions(ctx, b->actions_out + o * 4, step_index0 + (uint32_t)st, stream);
-        if (rc) return rc;
-        bs.actions = b->actions_out + o * 4;
-      }
-      bs.actions_out = nullptr;
-      bs.obs = b->obs + o * D; bs.reward = b->reward + o; bs.terminated = b->terminated + o; bs.truncated = b->truncated + o;
-      if (b->final_obs) bs.final_obs = b->final_obs + o * D;
-      if (b->final_info) bs.final_info = b->final_info + 2 * o;
-      int rc = pf_env_step(ctx, &bs, stream);
-      if (rc) return rc;
+    // Every other task (the generic env kernel: tilted multi-agent spawns, airframes and flight modes outside the specialised
+    // envelopes): state-resident as well since round 4 -- env_kernel's roll_steps, one launch for the k_steps.
+    int rc = ensure_device(ctx);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (P.vehicle == PF_QUADX) {
+      if (P.task == PF_TASK_HOVER) launch_env_t<pf::QuadX, PF_TASK_HOVER>(ctx, b, pf::OP_STEP, nullptr, s, k_steps, step_index0);
+      else if (P.task == PF_TASK_MA_HOVER) launch_env_t<pf::QuadX, PF_TASK_MA_HOVER>(ctx, b, pf::OP_STEP, nullptr, s, k_steps, step_index0);
+      else launch_env_t<pf::QuadX, PF_TASK_WAYPOINTS>(ctx, b, pf::OP_STEP, nullptr, s, k_steps, step_index0);
+    } else {
+      launch_env_t<pf::Fixedwing, PF_TASK_WAYPOINTS>(ctx, b, pf::OP_STEP, nullptr, s, k_steps, step_index0);
     }
+    PF_HIP(ctx, hipGetLastError());
     return PF_OK;
   }
   // (the PettingZoo task has no auto-reset: finished agents are culled by the caller, their drones fly on in the shared world)

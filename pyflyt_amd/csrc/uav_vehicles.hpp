@@ -759,11 +759,17 @@ struct QuadX {
       E2[0] = g9.x; E2[1] = g9.y; I3[0] = g9.z; I3[1] = g9.w;
       E3[0] = g10.x; E3[1] = g10.y; zI[0] = g10.z; zI[1] = g10.w;
       zE[0] = g11.x; zE[1] = g11.y;
-    } else {
+    }
+    relaunch(mode, ints.y);
+  }
+  // What a launch starts from besides the stored words (load's tail). env_kernel's roll_steps calls it between the env steps of a
+  // launch that keeps the lane's state in registers, so that step k + 1 starts from what a relaunch would have re-derived.
+  PF_DEV void relaunch(int mode, int flags) {
+    if (!needs_cascade(mode)) {  // (groups 7-11 are not stored for the direct modes)
       zero_cascade();
       zI[0] = zI[1] = zE[0] = zE[1] = 0.0f;
     }
-    b.contact_now = (ints.y & PF_F_CONTACT) != 0;
+    b.contact_now = (flags & PF_F_CONTACT) != 0;
     b.contact_step = false;
     b.derive();
     if (needs_cascade(mode)) b.rpy = euler_from_quat_fast(b.q);
@@ -1037,7 +1043,10 @@ struct Fixedwing {
     b.w = v3{g2.w, g3.x, g3.y};
     act[0] = g3.z; act[1] = g3.w; act[2] = g4.x; act[3] = g4.y; act[4] = g4.z; thr = g4.w;
     ints = int4{__float_as_int(gi.x), __float_as_int(gi.y), __float_as_int(gi.z), __float_as_int(gi.w)};
-    b.contact_now = (ints.y & PF_F_CONTACT) != 0;
+    relaunch(mode, ints.y);
+  }
+  PF_DEV void relaunch(int, int flags) {  // (see QuadX::relaunch)
+    b.contact_now = (flags & PF_F_CONTACT) != 0;
     b.contact_step = false;
     b.derive();
     b.rpy = v3{0.0f, 0.0f, 0.0f};

@@ -207,8 +207,8 @@ class BatchEngine:
         return out
 
     def rollout(self, k_steps: int, step_index0: int = 0, actions=None, store_actions: bool = True):
-        """pf_rollout: `k_steps` env steps in one call -- one launch with the state resident in registers where a specialised
-        kernel exists, one launch per step enqueued back to back otherwise (generic kernels, dogfight). Returns the trajectory
+        """pf_rollout: `k_steps` env steps in one launch, the lanes' state resident in registers between them (every env kernel
+        since round 4: the specialised ones, the generic one, the dogfight on either aircraft model). Returns the trajectory
         tensors (obs [k, n, D], reward [k, n], terminated [k, n], truncated [k, n], actions [k, n, 4] or None);
         bit-identical to k x (sample_actions(step_index0 + s) + env_step). `actions`: an open-loop sequence
         [k, n, 4] instead of on-device sampling."""
@@ -224,12 +224,7 @@ class BatchEngine:
                      final_info=torch.zeros(k, self.n, 2, dtype=torch.int32, device=self.device) if self.final_info is not None else None)
             self._traj = t
         self._check_f32(actions, (k, self.n, self.action_dim), "actions")
-        # (outside the specialised kernels the library runs one launch per step and needs the sampled actions to live somewhere)
-        # (the library's own predicate, pf_rollout: state-resident on every specialised kernel -- QuadX, Fixedwing-Waypoints and, since
-        #  round 4, the dogfight on its specialised aircraft with four-wide actions; everything else steps once per launch and needs
-        #  the sampled actions to live somewhere)
-        resident = self.lib.pf_ctx_is_specialised(self._ctx) != 0 and not (self.params.task == L.TASK_DOGFIGHT and self.action_dim == 6)
-        keep = (store_actions or not resident) and actions is None
+        keep = store_actions and actions is None  # (the kernels sample in registers; the draws are written out only on request)
         b = self._buffers(actions=actions, actions_out=t["actions"] if keep else None)
         b.obs, b.reward, b.terminated, b.truncated = _ptr(t["obs"]), _ptr(t["reward"]), _ptr(t["terminated"]), _ptr(t["truncated"])
         b.final_obs, b.final_info = _ptr(t["final_obs"]), _ptr(t["final_info"])

@@ -180,8 +180,8 @@ def test_rollout_refusals():
 @pytest.mark.parametrize("given", [False, True])
 def test_rollout_outside_the_specialised_kernels(given):
     """pf_rollout on a configuration only the generic env kernel runs (a cascaded flight mode with the contact response opted
-    out): one launch per step enqueued by the one call, the trajectory layout and the results of k x (pf_sample_actions +
-    pf_env_step), bit for bit."""
+    out): one launch, the state resident in registers (env_kernel's roll_steps) -- the trajectory layout and the results of
+    k x (pf_sample_actions + pf_env_step), bit for bit, with or without the sampled actions written out."""
     n, k = 200, 12
     kw = dict(flight_mode=6, world_options=dict(contact_response=False), max_duration_seconds=0.2)
     a, b = (_engine("hover", n, "philox", "next_step", 3, **kw) for _ in range(2))
@@ -202,6 +202,136 @@ def test_rollout_outside_the_specialised_kernels(given):
         assert torch.equal(term[s], t) and torch.equal(trunc[s], u), s
         n_done += int((t | u).sum())
     assert torch.equal(a.state, b.state) and n_done > 0
+    if not given:  # ... and without keeping the draws
+        obs2, *_rest, none = a.rollout(4, step_index0=900, store_actions=False)
+        assert none is None
+        for s in range(4):
+            b.sample_actions(act, 900 + s)
+            assert torch.equal(obs2[s], b.env_step(act)[0]), s
+
+
+GENERIC_CASES = {
+    # every env task on the GENERIC env kernel (PF_DISABLE_FAST: the switch the fixture tests use to replay on both kernels)
+    "hover_next_step": ("hover", "philox", "next_step", dict(), 96, 200),
+    "hover_same_step": ("hover", "philox", "same_step", dict(), 96, 200),
+    "hover_noise_off_mode7": ("hover", "off", "next_step", dict(flight_mode=7, max_duration_seconds=1.0), 64, 100),
+    "waypoints_yaw_targets_same_step": ("waypoints", "philox", "same_step", dict(use_yaw_targets=True, goal_reach_distance=0.6, goal_reach_angle=3.0), 96, 100),
+    "waypoints_mode4_quaternion": ("waypoints", "philox", "next_step", dict(flight_mode=4, angle_representation="quaternion", max_duration_seconds=1.0), 64, 100),
+    "fixedwing_waypoints": ("fixedwing_waypoints", "philox", "next_step", dict(), 300, 100),
+}
+
+
+@pytest.mark.parametrize("case", sorted(GENERIC_CASES))
+def test_rollout_generic_kernel_resident(case, monkeypatch):
+    """env_kernel's roll_steps (state-resident pf_rollout on the generic kernel) against k x (pf_sample_actions + pf_env_step) on the
+    same kernel, bit for bit: through in-loop NEXT_STEP / SAME_STEP resets (final_obs / final_info slots), reached waypoints and yaw
+    targets, the cascaded modes' controller memories, crashes with the contact solve, in two launches that must continue each other,
+    with a ragged last wave."""
+    task, noise, autoreset, kw, k, min_done = GENERIC_CASES[case]
+    monkeypatch.setenv("PF_DISABLE_FAST", "1")
+    n, seed = 1000, 77
+    a = _engine(task, n, noise, autoreset, seed, lane_offset=128, **kw)
+    b = _engine(task, n, noise, autoreset, seed, lane_offset=128, **kw)
+    assert a.lib.pf_ctx_is_specialised(a._ctx) == 0
+    a.env_reset(); b.env_reset()
+    assert torch.equal(a.state, b.state)
+    chunks = []
+    for c in range(2):
+        obs, rew, term, trunc, acts = a.rollout(k // 2, step_index0=c * (k // 2))
+        chunks.append([x.clone() for x in (obs, rew, term, trunc, acts)] +
+                      [a._traj["final_obs"].clone() if a.final_obs is not None else None,
+                       a._traj["final_info"].clone() if a.final_info is not None else None])
+    act = torch.empty(n, 4, device="cuda:0")
+    n_done = 0
+    for s in range(k):
+        c, j = divmod(s, k // 2)
+        b.sample_actions(act, s)
+        o, r, t, tr = b.env_step(act)
+        assert torch.equal(act, chunks[c][4][j]), f"step {s}: sampled action"
+        assert torch.equal(o, chunks[c][0][j]), f"step {s}: obs max diff {(o - chunks[c][0][j]).abs().max().item()}"
+        assert torch.equal(r, chunks[c][1][j]), f"step {s}: reward"
+        assert torch.equal(t, chunks[c][2][j]) and torch.equal(tr, chunks[c][3][j]), f"step {s}: flags"
+        done = t | tr
+        n_done += int(done.sum())
+        if autoreset == "same_step" and done.any():
+            assert torch.equal(b.final_obs[done], chunks[c][5][j][done]), f"step {s}: final_obs"
+            assert torch.equal(b.final_info[done], chunks[c][6][j][done]), f"step {s}: final_info"
+    assert torch.equal(a.state, b.state)
+    print(f"{case}: {n_done} episode ends inside the rollouts")
+    assert n_done > min_done
+
+
+def test_rollout_generic_kernel_shared_world(monkeypatch):
+    """... and the PettingZoo task in a shared world on the generic kernel: exchange arrays, pair stage and the per-call flags, resident
+    over a given action sequence."""
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    monkeypatch.setenv("PF_DISABLE_FAST", "1")
+    n, k, A = 256, 50, 4
+    eng = []
+    for _ in range(2):
+        P = build_params("quadx", "ma_hover", noise="philox", autoreset="off", seed=3, agents_per_world=A, flight_dome_size=3.0,
+                         world_options=dict(contact_response=True))
+        e = BatchEngine(P, n, device="cuda:0")
+        assert e.lib.pf_ctx_is_specialised(e._ctx) == 0
+        pos = torch.tensor([[-0.15, 0.0, 1.0], [0.15, 0.0, 1.02], [0.0, 0.3, 1.0], [0.0, -0.3, 0.6]], device="cuda:0").repeat(n // A, 1)
+        e.state[12, :, 0:3] = pos
+        e.state[12, :, 3] = 0.0; e.state[13, :, 0] = 0.0; e.state[13, :, 1] = 0.0; e.state[13, :, 2] = 1.0
+        e.env_reset()
+        eng.append(e)
+    a, b = eng
+    assert torch.equal(a.state, b.state)
+    rng = np.random.default_rng(1)
+    seq = torch.tensor(rng.uniform([-1, -1, -1, 0.1], [1, 1, 1, 0.7], size=(k, n, 4)), dtype=torch.float32, device="cuda:0")
+    obs, rew, term, trunc, _ = a.rollout(k, actions=seq)
+    hits = 0
+    for s in range(k):
+        o, r, t, tr = b.env_step(seq[s].contiguous())
+        assert torch.equal(o, obs[s]) and torch.equal(r, rew[s]) and torch.equal(t, term[s]) and torch.equal(tr, trunc[s]), s
+        hits += int(t.sum())
+    assert torch.equal(a.state, b.state)
+    assert hits > 0
+
+
+def test_rollout_dogfight_generic_aircraft(monkeypatch):
+    """The dogfight's resident rollout on the GENERIC aircraft model (dogfight_env_kernel<A, DfGenericVeh, ROLLOUT>): equal to k x
+    pf_env_step through crashes, wrecks and the pair stage; six-wide actions as a given sequence."""
+    from pyflyt_amd import PyFlytAmdError, build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    monkeypatch.setenv("PF_DISABLE_FAST", "1")
+
+    def make(**kw):
+        P = build_params("fixedwing", "dogfight", noise="philox", autoreset="off", seed=5, angle_representation="euler",
+                         vehicle_options=dict(drone_model="acrowing"), world_options=dict(world_scale=5.0), dogfight=dict(sample_spawn=True, **kw))
+        e = BatchEngine(P, 4 * 50, device="cuda:0")
+        assert e.lib.pf_ctx_is_specialised(e._ctx) == 0
+        e.env_reset()
+        return e
+
+    a, b = make(), make()
+    k = 100
+    obs, rew, term, trunc, acts = a.rollout(k, step_index0=7)
+    ref = torch.empty(4 * 50, 4, device="cuda:0")
+    for s in range(k):
+        b.sample_actions(ref, 7 + s)
+        assert torch.equal(acts[s], ref), s
+        o, r, t, u = b.env_step(ref)
+        assert torch.equal(obs[s], o) and torch.equal(rew[s], r) and torch.equal(term[s], t) and torch.equal(trunc[s], u), s
+    assert torch.equal(a.state, b.state)
+    assert bool(term.any())  # aircraft went down inside the launch
+    # six-wide actions (assisted_flight off): not sampled on device, resident over a given sequence
+    c, d = make(assisted_flight=False), make(assisted_flight=False)
+    with pytest.raises(PyFlytAmdError):
+        c.rollout(3)
+    rng = np.random.default_rng(2)
+    seq = torch.tensor(rng.uniform(-1.0, 1.0, size=(20, 4 * 50, 6)), dtype=torch.float32, device="cuda:0")
+    obs6, rew6, term6, trunc6, _ = c.rollout(20, actions=seq)
+    for s in range(20):
+        o, r, t, u = d.env_step(seq[s].contiguous())
+        assert torch.equal(obs6[s], o) and torch.equal(rew6[s], r) and torch.equal(term6[s], t) and torch.equal(trunc6[s], u), s
+    assert torch.equal(c.state, d.state)
 
 
 def test_rollout_dogfight():

@@ -16,13 +16,14 @@ os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "*.txt")):
     shutil.copy(f, dst)
 for env in ("hover", "quadx_waypoints", "fixedwing_waypoints"):
-    for f in glob.glob(os.path.join(src, "kt_" + env, "*", "*kernel_stats.csv")):
+    # (gpurun merges a call's files into gpurun_out/: an earlier collection's files, other PIDs in their names, may sit next to them)
+    for f in sorted(glob.glob(os.path.join(src, "kt_" + env, "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1:]:
         shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_bench_{env}65536.csv"))
 
 
 def counters(tag, skip, match="env_kernel"):
     out, meta = {}, {}
-    for f in glob.glob(os.path.join(src, tag, "*", "*counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(src, tag, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1:]:  # (the newest run only)
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"] and int(r["Grid_Size"]) >= 64 * 64:

@@ -252,6 +252,9 @@ def make_params(env: str, noise_mode: int = NOISE_OFF, seed: int = 0, **override
     P.noise_mode = noise_mode
     P.seed = seed
     for k, v in overrides.items():
+        # (a ctypes Structure takes ANY attribute: a misspelt override would be dropped without a word)
+        if not (hasattr(World, k[6:]) if k.startswith("world_") else hasattr(Params, k)):
+            raise AttributeError(f"oracle.make_params: no such field: {k}")
         if k.startswith("world_"):
             setattr(P.world, k[6:], v)
         elif isinstance(v, (list, tuple, np.ndarray)):

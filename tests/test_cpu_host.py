@@ -175,3 +175,19 @@ def test_quadk_hot_path_selection(built):
     """The specialised kernel is chosen exactly for the configurations it implements."""
     src = open(os.path.join(ROOT, "pyflyt_amd", "csrc", "quadx_fast.hpp")).read()
     assert "P.flight_mode != 0" in src and "PF_TASK_HOVER" in src
+
+
+def test_integration_md_stub_matches_the_header():
+    """INTEGRATION.md section 3 shows the ctypes stub a maintainer of the reference would add: its pf_buffers mirror and the ABI version it
+    asserts must be the header's."""
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    h = open(os.path.join(root, "include", "pyflyt_amd.h")).read()
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    body = re.sub(r"/\*.*?\*/", "", re.search(r"typedef struct pf_buffers \{(.*?)\} pf_buffers;", h, re.S).group(1), flags=re.S)
+    header_fields = re.findall(r"\*\s*(\w+)\s*;", body)
+    stub = re.search(r"class PfBuffers\(C\.Structure\):.*?for n in \((.*?)\)\]", md, re.S).group(1)
+    assert re.findall(r'"(\w+)"', stub) == header_fields
+    abi = int(re.search(r"#define PF_ABI_VERSION (\d+)", h).group(1))
+    assert [int(v) for v in re.findall(r"pf_abi_version\(\)`? ==? (\d+)", md)] == [abi, abi]

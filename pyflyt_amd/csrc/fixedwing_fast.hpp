@@ -659,9 +659,13 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   int step_count, flags, n_left;
   uint32_t rng_ctr;
   f8 zn;
+  float4 a_pre = float4{0.f, 0.f, 0.f, 0.f};  // (one step per launch) this step's action, requested with the state (quadx_fast.hpp)
   {
     float4 gi = Sin[5 * N + li];
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li];
+#ifndef PF_NO_ACTION_PREFETCH
+    if (ROLL == 0 && op == 0) a_pre = reinterpret_cast<const float4*>(B.actions)[li];
+#endif
     if (blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch((int)threadIdx.x);  // (uav_vehicles.hpp; behind the state loads: one wait for both)
     rng_ctr = (uint32_t)__float_as_int(gi.z);
     PF_STAMP(1);
@@ -857,7 +861,11 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
     }
   }
   if (stepping) {
+#ifndef PF_NO_ACTION_PREFETCH
+    const float4 a = ROLLOUT ? a_roll : a_pre;
+#else
     const float4 a = ROLLOUT ? a_roll : reinterpret_cast<const float4*>(B.actions)[li];
+#endif
     act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
     const float thr_sp = K.throttle_remap ? fmaf(a.w, 0.5f, 0.5f) : a.w;  // fixedwing_base_env.py:260
     // update_control, mode 0 (fixedwing.py:143-144,246-250): constant over the env step

@@ -905,12 +905,18 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   int step_count, flags, n_left;
   uint32_t rng_ctr;
   f8 zn;  // this step's motor-noise normals (Philox call 0 of the event)
+  float4 a_pre = float4{0.f, 0.f, 0.f, 0.f};  // (one step per launch) this step's action, requested with the state
   {
     // the int group is requested first: loads complete in order, so the step's Philox call (which
     // needs only the event counter) runs while the rest of the state is still in flight
     float4 gi = Sin[6 * N + li];
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li],
            g5 = Sin[5 * N + li];
+#ifndef PF_NO_ACTION_PREFETCH
+    // the action is first needed after the resets, a microsecond from here: requested where it is used (inside the stepping
+    // lanes' branch) every wave sat out its whole memory latency there; requested behind the state groups it is long there
+    if (ROLL == 0 && op == 0) a_pre = reinterpret_cast<const float4*>(B.actions)[li];
+#endif
 #ifndef PF_NO_CODE_WARM
     if (CR && blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch(tid);  // (behind the state loads: one wait for both)
 #endif
@@ -1356,7 +1362,11 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     }
   }
   if (stepping) {
+#ifndef PF_NO_ACTION_PREFETCH
+    const float4 a = ROLLOUT ? a_roll : a_pre;
+#else
     const float4 a = ROLLOUT ? a_roll : reinterpret_cast<const float4*>(B.actions)[li];
+#endif
     act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
     sp0 = a.x; sp1 = a.y; sp2 = a.z; sp3 = a.w;
     reward = -0.1f;

@@ -1,4 +1,6 @@
-"""One-step parity of the cascaded flight modes (quadx.py:401-479, modes 4 / 6 / 7: position -> velocity -> attitude -> rate PIDs).
+"""One-step parity: every env step started from the ORACLE's state. QuadX in the cascaded flight modes (quadx.py:401-479, modes 4 / 6 / 7:
+position -> velocity -> attitude -> rate PIDs) and in mode 0 (BASELINE's configs 1-3, floor impacts included), Fixedwing-Waypoints
+(config 4), each on the specialised and on the generic kernel.
 
 The free-running comparisons (tests/test_gpu_parity.py, the fixture replays of tests/test_gpu_golden.py) let fp32 and fp64 run side
 by side for hundreds of steps; in the cascaded modes the outer loops differentiate positions and velocities (k_d / T = 60 per control
@@ -9,7 +11,9 @@ Here every env step starts from the SAME state on both sides: before each step t
 memories of all six PIDs, counters, flags, targets) is written into the device's state groups, both sides take the step, and the
 observations must agree to north_star's 1e-4 * max(1, ||vector||) after the step's eight physics ticks and four control updates of
 the whole cascade, on both kernels, with no lane dropped. What a step computes is
-the reference's arithmetic; what drifts over an episode is fp32."""
+the reference's arithmetic; what drifts over an episode is fp32. Measured worst one-step errors: mode 0 (Hover, Waypoints; 800 episode
+ends, most of them on the floor) 1.5e-6 ... 3.0e-6; Fixedwing-Waypoints 4.2e-6; modes 4 / 6 / 7 1.3e-5 ... 7.7e-5 (the angular velocity
+behind the cascade's derivative terms). No lane is ever dropped and every flag agrees."""
 import numpy as np
 import pytest
 
@@ -41,11 +45,12 @@ def pack_state(ob, eng, waypoints):
              f["info_oob"] * L.F_INFO_OOB | f["info_complete"] * L.F_INFO_COMPLETE)
     ints = np.stack([f["step_count"], flags, f["rng_ctr"].astype(np.int64), f["n_targets_left"]], axis=1).astype(np.uint32)
     g[6] = ints.view(np.float32)
-    g[7, :, 0:3] = f["pid_I"][:, 1, :]; g[7, :, 3] = f["pid_E"][:, 1, 0]
-    g[8, :, 0:2] = f["pid_E"][:, 1, 1:3]; g[8, :, 2:4] = f["pid_I"][:, 2, 0:2]
-    g[9, :, 0:2] = f["pid_E"][:, 2, 0:2]; g[9, :, 2:4] = f["pid_I"][:, 3, 0:2]
-    g[10, :, 0:2] = f["pid_E"][:, 3, 0:2]; g[10, :, 2:4] = f["zpid_I"]
-    g[11, :, 0:2] = f["zpid_E"]
+    if g.shape[0] > 11:  # (groups 7-11: the cascade's memories; the direct modes do not store them)
+        g[7, :, 0:3] = f["pid_I"][:, 1, :]; g[7, :, 3] = f["pid_E"][:, 1, 0]
+        g[8, :, 0:2] = f["pid_E"][:, 1, 1:3]; g[8, :, 2:4] = f["pid_I"][:, 2, 0:2]
+        g[9, :, 0:2] = f["pid_E"][:, 2, 0:2]; g[9, :, 2:4] = f["pid_I"][:, 3, 0:2]
+        g[10, :, 0:2] = f["pid_E"][:, 3, 0:2]; g[10, :, 2:4] = f["zpid_I"]
+        g[11, :, 0:2] = f["zpid_E"]
     if waypoints:
         t = ob.field("targets")[:, :4, :].reshape(n, 12)
         g[12] = t[:, 0:4]; g[13] = t[:, 4:8]; g[14] = t[:, 8:12]
@@ -53,8 +58,8 @@ def pack_state(ob, eng, waypoints):
 
 
 @pytest.mark.parametrize("kernel", ["specialised", "generic"])
-@pytest.mark.parametrize("task,mode", [("hover", 7), ("hover", 6), ("hover", 4), ("waypoints", 7)])
-def test_cascaded_modes_one_step_parity(task, mode, kernel, monkeypatch):
+@pytest.mark.parametrize("task,mode", [("hover", 7), ("hover", 6), ("hover", 4), ("waypoints", 7), ("hover", 0), ("waypoints", 0)])
+def test_quadx_one_step_parity(task, mode, kernel, monkeypatch):
     if kernel == "generic":
         monkeypatch.setenv("PF_DISABLE_FAST", "1")
     n, steps = 256, 150
@@ -90,3 +95,60 @@ def test_cascaded_modes_one_step_parity(task, mode, kernel, monkeypatch):
         ends += int((rt | ru).sum())
     print(f"{task} mode {mode}, {kernel} kernel: worst one-step error {worst:.2e} (step, observation columns: {worst_at}) over {steps} steps x {n} lanes, {ends} episode ends")
     assert ends > 0  # (the in-kernel resets of the mode's controller memories were part of it)
+
+
+def pack_state_fixedwing(ob, eng):
+    """the oracle's lanes -> the device's Fixedwing state groups (Fixedwing::load's layout + the Waypoints side block)"""
+    from pyflyt_amd import _lib as L
+
+    n = ob.n
+    f = {k: ob.field(k) for k in ("p", "q", "v", "w", "throttle", "actuation", "new_dist", "step_count", "terminated", "truncated", "contact_now",
+                                  "info_oob", "info_collision", "info_complete", "rng_ctr", "n_targets_left")}
+    g = np.zeros(tuple(eng.state.shape), dtype=np.float32)
+    g[0, :, :3] = f["p"]; g[0, :, 3] = np.where(np.isfinite(f["new_dist"]), f["new_dist"], np.inf)
+    g[1] = f["q"]
+    g[2, :, :3] = f["v"]; g[2, :, 3] = f["w"][:, 0]
+    g[3, :, 0:2] = f["w"][:, 1:3]; g[3, :, 2:4] = f["actuation"][:, 0:2]
+    g[4, :, 0:3] = f["actuation"][:, 2:5]; g[4, :, 3] = f["throttle"][:, 0]
+    flags = (f["terminated"] * L.F_TERMINATED | f["truncated"] * L.F_TRUNCATED | f["contact_now"] * L.F_CONTACT | f["info_collision"] * L.F_INFO_COLLISION |
+             f["info_oob"] * L.F_INFO_OOB | f["info_complete"] * L.F_INFO_COMPLETE)
+    g[5] = np.stack([f["step_count"], flags, f["rng_ctr"].astype(np.int64), f["n_targets_left"]], axis=1).astype(np.uint32).view(np.float32)
+    t = ob.field("targets")[:, :4, :].reshape(n, 12)
+    g[6] = t[:, 0:4]; g[7] = t[:, 4:8]; g[8] = t[:, 8:12]
+    eng.state.copy_(torch.tensor(g, device=eng.state.device))
+
+
+@pytest.mark.parametrize("kernel", ["specialised", "generic"])
+def test_fixedwing_waypoints_one_step_parity(kernel, monkeypatch):
+    """The same for BASELINE's config 4: every env step of Fixedwing-Waypoints from the oracle's state -- eight ticks of five lifting
+    surfaces, motor and composite-body tick -- within 1e-4 with identical flags and NO lane dropped (the free-running comparison of
+    tests/test_gpu_parity.py has to let lanes go whose threshold crossings fp32 moved over a step boundary; a single step has none to
+    move)."""
+    if kernel == "generic":
+        monkeypatch.setenv("PF_DISABLE_FAST", "1")
+    n, steps = 256, 200
+    eng = _engine("fixedwing", "waypoints", n, noise="off", autoreset="next_step", seed=5, max_duration_seconds=3.0)
+    assert (eng.lib.pf_ctx_is_specialised(eng._ctx) != 0) == (kernel == "specialised")
+    ob = O.OracleBatch(O.make_params("fixedwing_waypoints", noise_mode=O.NOISE_OFF, seed=5, max_steps=int(3.0 * 30)), n)
+    eng.env_reset()
+    ob.reset()
+    groups = obs_groups(eng.obs_dim, quat=bool(eng.params.angle_repr), aux=6, nt=4)
+    act = torch.empty(n, 4, device="cuda:0")
+    worst, worst_at, ends = 0.0, None, 0
+    for s in range(steps):
+        pack_state_fixedwing(ob, eng)
+        eng.sample_actions(act, s)
+        o, r, t, u = eng.env_step(act)
+        ro, rr, rt, ru, _ = ob.step(act.cpu().numpy(), autoreset=1)
+        assert np.array_equal(t.cpu().numpy(), rt) and np.array_equal(u.cpu().numpy(), ru), (kernel, s)
+        d = np.abs(o.cpu().numpy().astype(np.float64) - ro)
+        for a, b in groups:
+            ref = np.maximum(1.0, np.linalg.norm(ro[:, a:b], axis=1))
+            e = float((d[:, a:b].max(axis=1) / ref).max())
+            if e > worst:
+                worst, worst_at = e, (s, a, b)
+        assert worst < RTOL_ONE_STEP, (kernel, s, worst, worst_at)
+        np.testing.assert_allclose(r.cpu().numpy(), rr, rtol=1e-4, atol=1e-4)
+        ends += int((rt | ru).sum())
+    print(f"fixedwing waypoints, {kernel} kernel: worst one-step error {worst:.2e} (step, observation columns: {worst_at}) over {steps} steps x {n} lanes, {ends} episode ends")
+    assert ends > 0

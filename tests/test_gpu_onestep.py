@@ -58,20 +58,22 @@ def pack_state(ob, eng, waypoints):
 
 
 @pytest.mark.parametrize("kernel", ["specialised", "generic"])
-@pytest.mark.parametrize("task,mode", [("hover", 7), ("hover", 6), ("hover", 4), ("waypoints", 7), ("hover", 0), ("waypoints", 0)])
-def test_quadx_one_step_parity(task, mode, kernel, monkeypatch):
+@pytest.mark.parametrize("task,mode,noise", [("hover", 7, "off"), ("hover", 6, "off"), ("hover", 4, "off"), ("waypoints", 7, "off"), ("hover", 0, "off"),
+                                             ("waypoints", 0, "off"), ("hover", 0, "philox"), ("waypoints", 7, "philox")])
+def test_quadx_one_step_parity(task, mode, noise, kernel, monkeypatch):
     if kernel == "generic":
         monkeypatch.setenv("PF_DISABLE_FAST", "1")
     n, steps = 256, 150
     kw = dict(flight_mode=mode, max_duration_seconds=2.0)  # (60-step episodes: every lane restarts twice, the in-kernel reset of the controller memories included)
     if task == "waypoints":
         kw["goal_reach_distance"] = 0.4
-    eng = _engine("quadx", task, n, noise="off", autoreset="next_step", seed=11, **kw)
+    # (noise "philox": motor noise and the resets' settle noise drawn on both sides from the same keys -- seed, lane, the packed event counter)
+    eng = _engine("quadx", task, n, noise=noise, autoreset="next_step", seed=11, **kw)
     assert eng.lib.pf_ctx_is_specialised(eng._ctx) == (1 if kernel == "specialised" else 0)
     okw = dict(flight_mode=mode, max_steps=int(2.0 * (40 if task == "hover" else 30)))  # (the oracle's parameter block by its own field names)
     if task == "waypoints":
         okw["goal_reach_distance"] = 0.4
-    ob = O.OracleBatch(O.make_params("hover" if task == "hover" else "quadx_waypoints", noise_mode=O.NOISE_OFF, seed=11, **okw), n)
+    ob = O.OracleBatch(O.make_params("hover" if task == "hover" else "quadx_waypoints", noise_mode=O.NOISE_OFF if noise == "off" else O.NOISE_PHILOX, seed=11, **okw), n)
     eng.env_reset()
     ob.reset()
     D = eng.obs_dim
@@ -83,7 +85,7 @@ def test_quadx_one_step_parity(task, mode, kernel, monkeypatch):
         eng.sample_actions(act, s)
         o, r, t, u = eng.env_step(act)
         ro, rr, rt, ru, _ = ob.step(act.cpu().numpy(), autoreset=1)
-        assert np.array_equal(t.cpu().numpy(), rt) and np.array_equal(u.cpu().numpy(), ru), (task, mode, kernel, s)
+        assert np.array_equal(t.cpu().numpy(), rt) and np.array_equal(u.cpu().numpy(), ru), (task, mode, noise, kernel, s)
         d = np.abs(o.cpu().numpy().astype(np.float64) - ro)
         for a, b in groups:
             ref = np.maximum(1.0, np.linalg.norm(ro[:, a:b], axis=1))
@@ -93,7 +95,7 @@ def test_quadx_one_step_parity(task, mode, kernel, monkeypatch):
         assert worst < RTOL_ONE_STEP, (task, mode, kernel, s, worst)
         np.testing.assert_allclose(r.cpu().numpy(), rr, rtol=1e-5, atol=1e-5)
         ends += int((rt | ru).sum())
-    print(f"{task} mode {mode}, {kernel} kernel: worst one-step error {worst:.2e} (step, observation columns: {worst_at}) over {steps} steps x {n} lanes, {ends} episode ends")
+    print(f"{task} mode {mode}, noise {noise}, {kernel} kernel: worst one-step error {worst:.2e} (step, observation columns: {worst_at}) over {steps} steps x {n} lanes, {ends} episode ends")
     assert ends > 0  # (the in-kernel resets of the mode's controller memories were part of it)
 
 

@@ -793,10 +793,16 @@ PF_DEV void quad_world_exchange(QuadHot& b, float* wpose, const int tid, const i
         const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
                       Rb.m01 * Ra.m00 + Rb.m11 * Ra.m10 + Rb.m21 * Ra.m20, Rb.m01 * Ra.m01 + Rb.m11 * Ra.m11 + Rb.m21 * Ra.m21, Rb.m01 * Ra.m02 + Rb.m11 * Ra.m12 + Rb.m21 * Ra.m22,
                       Rb.m02 * Ra.m00 + Rb.m12 * Ra.m10 + Rb.m22 * Ra.m20, Rb.m02 * Ra.m01 + Rb.m12 * Ra.m11 + Rb.m22 * Ra.m21, Rb.m02 * Ra.m02 + Rb.m12 * Ra.m12 + Rb.m22 * Ra.m22};
-        // (reported from the gap rd on -- up to the breaking distance when either drone holds contact points: the peer's box enlarged)
+        // (reported from the gap rd on -- up to the breaking distance when either drone holds contact points: ONE test per pair,
+        //  the lower-indexed drone's box in the frame of the other's, enlarged -- shared_world.hpp: peers_overlap_dev)
         const float rdx = (b.contact_now || o[7] != 0.0f) ? K.brk : K.rd;
         const float hb[3] = {h[0] + rdx, h[1] + rdx, h[2] + rdx};
-        peer |= box_overlaps_aabb(mulT(Rb, d), Rrel, h, v3{0.f, 0.f, 0.f}, hb);
+        if (wlocal < jj) {
+          peer |= box_overlaps_aabb(mulT(Rb, d), Rrel, h, v3{0.f, 0.f, 0.f}, hb);
+        } else {  // the peer is a: its box in MY frame, Ra^T Rb = Rrel^T
+          const m3 RrelT{Rrel.m00, Rrel.m10, Rrel.m20, Rrel.m01, Rrel.m11, Rrel.m21, Rrel.m02, Rrel.m12, Rrel.m22};
+          peer |= box_overlaps_aabb(mulT(Ra, v3{-d.x, -d.y, -d.z}), RrelT, h, v3{0.f, 0.f, 0.f}, hb);
+        }
       }
     }
   }

@@ -39,19 +39,28 @@ __device__ __noinline__ bool peers_overlap_dev(const pf_params* __restrict__ Pd,
     const float* o = wpose + (wbase + jj) * 8;
     const v3 d{px - o[0], py - o[1], pz - o[2]};
     if (dot(d, d) <= rr2) {
-      const m3 Rb = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
-      const m3 Rrel{Rb.m00 * Ra.m00 + Rb.m10 * Ra.m10 + Rb.m20 * Ra.m20, Rb.m00 * Ra.m01 + Rb.m10 * Ra.m11 + Rb.m20 * Ra.m21, Rb.m00 * Ra.m02 + Rb.m10 * Ra.m12 + Rb.m20 * Ra.m22,
-                    Rb.m01 * Ra.m00 + Rb.m11 * Ra.m10 + Rb.m21 * Ra.m20, Rb.m01 * Ra.m01 + Rb.m11 * Ra.m11 + Rb.m21 * Ra.m21, Rb.m01 * Ra.m02 + Rb.m11 * Ra.m12 + Rb.m21 * Ra.m22,
-                    Rb.m02 * Ra.m00 + Rb.m12 * Ra.m10 + Rb.m22 * Ra.m20, Rb.m02 * Ra.m01 + Rb.m12 * Ra.m11 + Rb.m22 * Ra.m21, Rb.m02 * Ra.m02 + Rb.m12 * Ra.m12 + Rb.m22 * Ra.m22};
+      // ONE test per pair, whichever of its two lanes evaluates it: the box of the drone with the LOWER index (a) in the frame of the
+      // other's (b), b's box enlarged by the report distance (oracle: drones_overlap(i, j), i < j). With an enlargement the verdict
+      // is not symmetric -- a against b + rd is another shape than b against a + rd -- and the two lanes of a pair that separates
+      // through the breaking distance disagreed about the tick in which the report ends (tests/test_gpu_onestep.py).
+      const bool me_first = wlocal < jj;
+      const m3 Rp = rot_from_quat(quat{o[3], o[4], o[5], o[6]});
+      m3 RA, RB;
+      v3 dab;
+      if (me_first) { RA = Ra; RB = Rp; dab = d; }
+      else { RA = Rp; RB = Ra; dab = v3{-d.x, -d.y, -d.z}; }
+      const m3 Rrel{RB.m00 * RA.m00 + RB.m10 * RA.m10 + RB.m20 * RA.m20, RB.m00 * RA.m01 + RB.m10 * RA.m11 + RB.m20 * RA.m21, RB.m00 * RA.m02 + RB.m10 * RA.m12 + RB.m20 * RA.m22,
+                    RB.m01 * RA.m00 + RB.m11 * RA.m10 + RB.m21 * RA.m20, RB.m01 * RA.m01 + RB.m11 * RA.m11 + RB.m21 * RA.m21, RB.m01 * RA.m02 + RB.m11 * RA.m12 + RB.m21 * RA.m22,
+                    RB.m02 * RA.m00 + RB.m12 * RA.m10 + RB.m22 * RA.m20, RB.m02 * RA.m01 + RB.m12 * RA.m11 + RB.m22 * RA.m21, RB.m02 * RA.m02 + RB.m12 * RA.m12 + RB.m22 * RA.m22};
       const int nb = Pd->n_boxes;
       for (int k = 0; k < nb; ++k) {
         for (int l = 0; l < nb; ++l) {
           const pf_box bk = Pd->boxes[k], bl = Pd->boxes[l];
-          const v3 ca = d + mul(Ra, v3{bk.c[0], bk.c[1], bk.c[2]}) - mul(Rb, v3{bl.c[0], bl.c[1], bl.c[2]});
-          // (reported from the gap rd on -- up to the breaking distance when either drone holds contact points: the peer's box enlarged)
+          const v3 ca = dab + mul(RA, v3{bk.c[0], bk.c[1], bk.c[2]}) - mul(RB, v3{bl.c[0], bl.c[1], bl.c[2]});
+          // (reported from the gap rd on -- up to the breaking distance when either drone holds contact points: b's box enlarged)
           const float rd = (mine || o[7] != 0.0f) ? rd_kept : rd_fresh;
           const float hb[3] = {bl.h[0] + rd, bl.h[1] + rd, bl.h[2] + rd};
-          peer |= box_overlaps_aabb(mulT(Rb, ca), Rrel, bk.h, v3{0.f, 0.f, 0.f}, hb);
+          peer |= box_overlaps_aabb(mulT(RB, ca), Rrel, bk.h, v3{0.f, 0.f, 0.f}, hb);
         }
       }
     }

@@ -400,6 +400,17 @@ def gen_envs():
     save("env_fixedwing_waypoints_gentle", **run_env(lambda: FixedwingWaypointsEnv(goal_reach_distance=40.0), 400, 6, gentle_fw_action, num_targets=4, ticks=8))
 
 
+def gen_envs_options():
+    """constructor options away from their defaults (quadx_base_env.py:30-147, quadx_waypoints_env.py:28-100, fixedwing_waypoints_env.py:28-100):
+    agent_hz (env steps of 4 and of 2 Aviary steps instead of 3 / 4), flight_dome_size, max_duration_seconds, num_targets, sparse_reward,
+    Euler-angle observations, goal_reach_distance -- each of them a branch or a loop bound in the env step"""
+    save("env_hover_opts", **run_env(lambda: QuadXHoverEnv(agent_hz=30, flight_dome_size=2.0, max_duration_seconds=1.5), 200, 21, uniform_action, ticks=8))
+    save("env_quadx_waypoints_opts", **run_env(lambda: QuadXWaypointsEnv(num_targets=2, sparse_reward=True, flight_dome_size=4.0, agent_hz=60, goal_reach_distance=1.5,
+                                                                        angle_representation="euler", max_duration_seconds=4.0), 300, 22, gentle_quad_action, num_targets=2, ticks=4))
+    save("env_fixedwing_waypoints_opts", **run_env(lambda: FixedwingWaypointsEnv(num_targets=3, sparse_reward=True, angle_representation="euler", flight_dome_size=60.0, agent_hz=40,
+                                                                                goal_reach_distance=30.0, max_duration_seconds=20.0), 400, 23, gentle_fw_action, num_targets=3, ticks=6))
+
+
 def mode_action(mode):
     """Random setpoints that exercise a flight mode's outer loops without leaving its sensible range (the action box itself,
     quadx_base_env.py:80-102, is the same [-pi, pi]^3 x [0, 0.8] for every mode but -1)."""
@@ -727,6 +738,7 @@ if __name__ == "__main__":
     gen_aviary()
     gen_envs()
     gen_envs_crash()
+    gen_envs_options()
     gen_envs_yaw()
     gen_envs_modes()
     gen_landing()

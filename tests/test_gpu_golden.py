@@ -74,6 +74,13 @@ ENVS = [
     # every other flight mode (quadx.py:233-373,437-479): the cascaded-PID instantiation of the specialised kernel, and the generic one
     *[(f"env_hover_mode{'m1' if m == -1 else m}", "quadx", "hover", dict(flight_mode=m, max_duration_seconds=1.5)) for m in (-1, 1, 2, 3, 4, 5, 6, 7)],
     ("env_quadx_waypoints_mode7", "quadx", "waypoints", dict(flight_mode=7, goal_reach_distance=0.4)),
+    # constructor options away from their defaults (gen_goldens.py: gen_envs_options): env steps of four and of two Aviary steps, domes,
+    # durations, two and three targets, sparse rewards, Euler observations, reach distances
+    ("env_hover_opts", "quadx", "hover", dict(agent_hz=30, flight_dome_size=2.0, max_duration_seconds=1.5)),
+    ("env_quadx_waypoints_opts", "quadx", "waypoints", dict(num_targets=2, sparse_reward=True, flight_dome_size=4.0, agent_hz=60, goal_reach_distance=1.5,
+                                                          angle_representation="euler", max_duration_seconds=4.0)),
+    ("env_fixedwing_waypoints_opts", "fixedwing", "waypoints", dict(num_targets=3, sparse_reward=True, angle_representation="euler", flight_dome_size=60.0,
+                                                                  agent_hz=40, goal_reach_distance=30.0, max_duration_seconds=20.0)),
 ]
 
 

@@ -277,6 +277,13 @@ ENVS = [
     # every other flight mode (quadx.py:233-373,437-479), 1.5 s episodes (max_steps = 40 Hz x 1.5 s)
     *[(f"env_hover_mode{'m1' if m == -1 else m}", "hover", {"flight_mode": m, "max_steps": 60}) for m in (-1, 1, 2, 3, 4, 5, 6, 7)],
     ("env_quadx_waypoints_mode7", "quadx_waypoints", {"flight_mode": 7, "goal_reach_distance": 0.4}),
+    # constructor options away from their defaults (gen_goldens.py: gen_envs_options): agent_hz -> env_step_ratio = 120 / agent_hz and
+    # max_steps = seconds x agent_hz, flight_dome_size -> dome, num_targets, sparse_reward, Euler observations, goal_reach_distance
+    ("env_hover_opts", "hover", {"env_step_ratio": 4, "max_steps": 45, "dome": 2.0}),
+    ("env_quadx_waypoints_opts", "quadx_waypoints", {"num_targets": 2, "sparse_reward": 1, "dome": 4.0, "env_step_ratio": 2, "max_steps": 240,
+                                                     "goal_reach_distance": 1.5, "angle_repr": 0}),
+    ("env_fixedwing_waypoints_opts", "fixedwing_waypoints", {"num_targets": 3, "sparse_reward": 1, "dome": 60.0, "env_step_ratio": 3, "max_steps": 800,
+                                                             "goal_reach_distance": 30.0, "angle_repr": 0}),
 ]
 
 

@@ -206,9 +206,11 @@ def run_aviary(drone_type, mode, n_steps, seed, start_pos, start_orn, noise=True
         auxs.append(env.aux_state(0).copy())
         sps.append(np.array(env.drones[0].setpoint, dtype=np.float64).copy())
         x = rng_env.drain("normal") if noise else np.zeros(0)
-        xis.append(np.concatenate([x, np.full(2 - len(x), np.nan)]))
+        xis.append(np.concatenate([x, np.full(env.updates_per_step - len(x), np.nan)]))  # (one draw per physics tick of the step: aviary.py:510)
         contacts.append(bool(np.any(env.contact_array)))
-    return dict(states=np.array(states), aux=np.array(auxs), setpoints=np.array(sps), xi=np.array(xis),
+    hz = int(round(1.0 / env.drones[0].control_period))
+    rate = {} if hz == 120 else dict(control_hz=np.array(hz))  # (recorded where it is not the default: the older fixtures stay byte for byte)
+    return dict(**rate, states=np.array(states), aux=np.array(auxs), setpoints=np.array(sps), xi=np.array(xis),
                 contact=np.array(contacts), init_state=init_state, init_aux=init_aux, init_setpoint=init_sp,
                 mode=mode, start_pos=np.array(start_pos), start_orn=np.array(start_orn), noise=noise,
                 wind_kind=np.array({None: 0, "register": 1, "ctor": 2}[wind]), wind_coef=WIND_COEF)
@@ -227,6 +229,17 @@ def gen_aviary():
     for mode in (0, -1):
         d = run_aviary("fixedwing", mode, 200, seed=200 + mode, start_pos=[0.0, 0.0, 10.0], start_orn=[0.02, 0.05, -0.3], noise=True)
         save(f"aviary_fixedwing_mode{mode}".replace("-1", "m1"), **d)
+
+
+def gen_control_rate():
+    """drone_options=dict(control_hz=60) (base_drone.py:95-107, aviary.py:288-290,510-531): the Aviary step is FOUR physics ticks, the
+    controller runs on the first of them with T = 1/60 in its integral and derivative terms, the motor commands are held for the other
+    three. (The cascaded modes' gains are tuned for 120 Hz: at 60 Hz the rate loop swings between the motor limits and the closed loop
+    amplifies round-off by a decade every few steps -- numpy against C, 1e-11 after forty steps and 1e-3 after a hundred -- so the
+    cascaded recording is thirty steps long; mode 0, the rate loop alone, holds 1e-10 over its 120.)"""
+    save("aviary_quadx_mode6_hz60", **run_aviary("quadx", 6, 30, seed=31, start_pos=[0.0, 0.0, 1.5], start_orn=[0.0, 0.0, 0.3], drone_options=dict(control_hz=60)))
+    save("aviary_quadx_mode0_hz60", **run_aviary("quadx", 0, 120, seed=32, start_pos=[0.0, 0.0, 2.5], start_orn=[0.05, -0.05, 0.0], drone_options=dict(control_hz=60)))
+    save("aviary_fixedwing_mode0_hz60", **run_aviary("fixedwing", 0, 150, seed=33, start_pos=[0.0, 0.0, 10.0], start_orn=[0.0, 0.0, 0.0], drone_options=dict(control_hz=60)))
 
 
 def gen_primitive():
@@ -747,6 +760,7 @@ if __name__ == "__main__":
     gen_ma_hover_stack()
     gen_dogfight()
     gen_wind()
+    gen_control_rate()
     gen_primitive()
     gen_rocket()
     gen_acrowing()

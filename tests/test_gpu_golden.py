@@ -236,6 +236,10 @@ AVIARY = {
     # (the primitive drone rocks on its prop discs and the rocket on its legs for seconds: an fp32 oracle is 4e-3 / 5e-1 away
     #  from the fp64 one during that, tests/tools/fp32_contact_sensitivity.py, and both end in the same pose: prefix + loose tail)
     "aviary_quadx_land": None, "aviary_primitive_land": (22, 5e-2), "aviary_rocket_land": (31, None),
+    # drone_options=dict(control_hz=60): four ticks per Aviary step, controllers at T = 1/60 (gains tuned for 120 Hz: the loop swings
+    # between the motor limits and amplifies round-off -- gen_goldens.py: gen_control_rate; prefix strict, then the swing's fp32 drift)
+    #  measured: mode 0 1.5e-5 over its 120 steps, the aeroplane 2.4e-5 over 150, mode 6 beyond 1e-4 from step 28 of 30 on, worst 1.2e-3)
+    "aviary_quadx_mode0_hz60": None, "aviary_quadx_mode6_hz60": (25, 5e-3), "aviary_fixedwing_mode0_hz60": None,
 }
 ROCKET_FUEL = {"aviary_rocket_default_fuel": 0.05, "aviary_rocket_fuel60": 0.6, "aviary_rocket_drop": 0.0, "aviary_rocket_wind_ctor": 0.3,
                "aviary_rocket_land": 0.0}
@@ -252,6 +256,8 @@ def aviary_engine(name, g):
         vo["drone_model"] = model
     if vehicle == "rocket":
         vo["starting_fuel_ratio"] = ROCKET_FUEL[name]
+    if "control_hz" in g.files:
+        vo["control_hz"] = int(g["control_hz"])
     P = build_params(vehicle, "none", noise="inject" if bool(g["noise"]) else "off", autoreset="off", vehicle_options=vo)
     eng = BatchEngine(P, N, device=DEV)
     pose = np.concatenate([g["start_pos"], quat_from_euler(g["start_orn"])])

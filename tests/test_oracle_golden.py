@@ -91,7 +91,9 @@ AVIARY = [f"aviary_quadx_mode{m}" for m in ["m1", 0, 1, 2, 3, 4, 5, 6, 7, "7_non
          ["aviary_fixedwing_mode0", "aviary_fixedwing_modem1"] + \
          [f"aviary_primitive_mode{m}" for m in (0, 6, 7)] + \
          ["aviary_acrowing_mode0", "aviary_acrowing_modem1"] + \
-         ["aviary_quadx_land", "aviary_primitive_land"]  # motors off, from first touch to rest: the contact response
+         ["aviary_quadx_land", "aviary_primitive_land"] + \
+         ["aviary_quadx_mode6_hz60", "aviary_quadx_mode0_hz60", "aviary_fixedwing_mode0_hz60"]  # drone_options=dict(control_hz=60): four ticks per Aviary step
+# (aviary_*_land: motors off, from first touch to rest: the contact response)
 
 
 def model_of(name):
@@ -105,8 +107,12 @@ def test_aviary_trajectory(golden_dir, name):
     g = load(golden_dir, name)
     fw = "fixedwing" in name or "acrowing" in name
     noise = bool(g["noise"])
+    rate = {}
+    if "control_hz" in g.files:  # base_drone.py:95-107: physics ticks per control update, the controllers' period
+        hz = int(g["control_hz"])
+        rate = dict(world_ticks_per_control=240 // hz, control_period=1.0 / hz)
     P = O.make_params(model_of(name), noise_mode=O.NOISE_INJECT if noise else O.NOISE_OFF,
-                      start_pos=g["start_pos"], start_rpy=g["start_orn"])
+                      start_pos=g["start_pos"], start_rpy=g["start_orn"], **rate)
     L = O.Lane()
     lib = O.lib()
     lib.orc_aviary_reset(C.byref(P), C.byref(L), 0)

@@ -61,5 +61,23 @@ def main():
               f"{int((f - f0).min()):+d} .. {int((f - f0).max()):+d} steps")
 
 
+def task_level():
+    """... and at task level: QuadX-Hover under LOW-THRUST random actions (every episode ends on the floor; with the action space's
+    own uniform draws the drones leave the dome long before they could touch it and no setting changes a single flag), 4 096 lanes x
+    300 steps, auto-reset -- episode count, mean episode length and mean step reward per setting"""
+    print("\nQuadX-Hover, low-thrust random actions (every episode ends on the floor), 4 096 lanes x 300 steps:")
+    rng0 = np.random.default_rng(0)
+    acts = [rng0.uniform([-0.5] * 3 + [0.0], [0.5] * 3 + [0.25], size=(4096, 4)).astype(np.float32) for _ in range(300)]
+    for label, over in [("defaults", {})] + ALTERNATIVES:
+        ob = O.OracleBatch(O.make_params("hover", noise_mode=O.NOISE_PHILOX, seed=0, **over), 4096)
+        ob.reset()
+        ends, rew, collided = 0, 0.0, 0
+        for a in acts:
+            _, r, t, u, _ = ob.step(a, autoreset=1)
+            ends += int((t | u).sum()); rew += float(r.sum())
+        print(f"  {label:58s} {ends:6d} episode ends, {4096 * 300 / max(1, ends):6.2f} steps per episode, mean reward {rew / (4096 * 300):+.4f}")
+
+
 if __name__ == "__main__":
     main()
+    task_level()

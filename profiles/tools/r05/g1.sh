@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5, call 1: same-box A/B. Fixedwing-Waypoints on the one-wave-per-SIMD instantiation with / without the calm tick;
+# an upper bound for "resets off the hot wave" (PF_EXP_CHEAP_RESET: the reset's random state as if precomputed -- never shipped)
+cd $GRAFT_REPO_ROOT
+V=$GRAFT_REPO_ROOT/build/variants
+run() {  # name lib env
+  PF_LIB_PATH=$2 timeout 120 python bench.py --env $3 --steps 2000 --warmup 200 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1 $3', 'launch_us', round(d['roofline']['launch_us'],2), 'ms_per_step_us', round(d['ms_per_step']*1e3,2), 'rollout_us', round((d.get('rollout') or {}).get('ms_per_step',0)*1e3,2))"
+}
+for rep in 1 2; do
+  run base $GRAFT_REPO_ROOT/pyflyt_amd/libpyflyt_amd.so fixedwing_waypoints
+  run w1calm $V/libpf_fw_w1calm.so fixedwing_waypoints
+  run w1nocalm $V/libpf_fw_w1nocalm.so fixedwing_waypoints
+  run base $GRAFT_REPO_ROOT/pyflyt_amd/libpyflyt_amd.so hover
+  run cheapreset $V/libpf_cheapreset.so hover
+  run base $GRAFT_REPO_ROOT/pyflyt_amd/libpyflyt_amd.so quadx_waypoints
+  run cheapreset $V/libpf_cheapreset.so quadx_waypoints
+done

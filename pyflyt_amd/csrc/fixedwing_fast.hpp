@@ -34,6 +34,8 @@
 #include "uav_device.hpp"
 #include "uav_vehicles.hpp"  // contact_solve_dev
 #include "shared_world.hpp"  // pair_stage_dev (the dogfight's shared worlds)
+#include <cstddef>
+#include <type_traits>
 
 namespace pf {
 
@@ -200,6 +202,37 @@ PF_DEV FwSurf2 fw_load_surf2(fw_surf2_cptr p) {  // two s_load_dwordx16, every f
   S.defl_lim = p->defl_lim; S.dt_tau = p->dt_tau; S.hra = p->hra; S.chord = p->chord;
   return S;
 }
+// The whole constant table in VECTOR registers, for the one-wave-per-SIMD instantiation (512 registers): loaded once per launch
+// instead of five scalar loads -- each with its own wait, and nothing to hide it behind at one wave per SIMD -- in every tick, and a
+// uniform value in a vector register costs the instruction that reads it nothing (no constant-bus limit, no SGPR -> VGPR copy in
+// front of a packed operand; quadx_fast.hpp: QuadKV).
+#ifndef PF_FW_TABV
+#define PF_FW_TABV 2   // (A/B: 2 = the whole table in vector registers; 4 = the surface pairs only, v-tail and body rows by scalar loads in the tick)
+#endif
+struct FwTableV {
+  FwSurf2 pair[2];   // the two lift-+z surface pairs: in vector registers for the whole launch
+  FwSurf vtail;      // (PF_FW_TABV == 2) v-tail and body rows as well
+  FwBody body;
+  fw_tab_cptr rest;  // (PF_FW_TABV == 4) v-tail and body rows: scalar loads in the tick, requested a surface ahead of their first use
+};
+// Loaded with VECTOR loads from a uniform address (every lane reads the same 16-byte words: one broadcast request each), issued in
+// front of the state loads so that their latency is shared -- scalar loads would need a v_mov per value on top (the first version of
+// this: 12 s_loads, 111 v_movs and 57 AGPR writes in the prologue, 0.8 us of every launch). The opaque zero keeps the compiler from
+// recognising the address as uniform and turning the loads back into scalar ones.
+PF_DEV FwTableV fw_table_in_vgprs(const FwTable* g) {
+  uint32_t z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  const float4* q = reinterpret_cast<const float4*>(g) + z;
+  constexpr int kN = (int)((PF_FW_TABV == 2 ? sizeof(FwTable) : 2 * sizeof(FwSurf2)) / 16);
+  float4 r[kN];
+#pragma unroll
+  for (int i = 0; i < kN; ++i) r[i] = q[i];
+  FwTableV V;
+  __builtin_memcpy(&V.pair[0], r, kN * 16);
+  V.rest = (fw_tab_cptr)(uintptr_t)g;
+  return V;
+}
+static_assert(offsetof(FwTableV, vtail) == offsetof(FwTable, vtail) && offsetof(FwTableV, body) == offsetof(FwTable, body), "FwTableV starts with FwTable");
 struct FwPairOut { f2 fp, fn, ty; };  // per surface: force along +x, along the lift unit (+z), and the r x f + moment part of tau.y
 
 struct FwHot {
@@ -446,6 +479,158 @@ struct FwHot {
     o.ty = fma2(S.rz, o.fp, ty0);
     return o;
   }
+  // Both surface pairs at once: surface_pair statement by statement on the aileron pair (k = 0) and on the (h-tail, main wing) pair
+  // (k = 1) alternately. The two evaluations are independent, so every instruction has an independent neighbour: a lone wave per
+  // SIMD issues a DEPENDENT instruction every ~7.5 clocks and an independent one every ~5.5 (profiles/r05/icache_cold.txt), and the
+  // packed-result / compare-select wait states of the one-pair version are filled by the other pair instead of by hand. Per element
+  // the same operations in the same order as surface_pair: bit-identical results. Needs both pairs' constants at once (64 values):
+  // the one-wave-per-SIMD instantiation holds them in vector registers (FwTableV).
+#define PF_X2(...) { constexpr int k = 0; __VA_ARGS__ } { constexpr int k = 1; __VA_ARGS__ }
+  PF_DEV void surface_pair_x2(const FwSurf2 (&S)[2], f2 (&a)[2], const f2 (&cmd2)[2], FwPairOut (&o)[2]) const {
+    const f2 wbx = sp2(wb.x), wby = sp2(wb.y), wbz = sp2(wb.z);
+    f2 da[2], t1[2], t2[2], t3[2], vx[2], vy[2], vz[2], defl[2], fa2[2], vz2[2], h2[2], V2t[2], a0[2], V2[2], y[2];
+    PF_X2(da[k] = cmd2[k] - a[k];)
+    PF_X2(t1[k] = fma2(-wbz, S[k].ry, sp2(vb.x));)
+    PF_X2(t2[k] = fma2(-wbx, S[k].rz, sp2(vb.y));)
+    PF_X2(t3[k] = fma2(-wby, S[k].rx, sp2(vb.z));)
+    PF_X2(a[k] = fma2(S[k].dt_tau, da[k], a[k]);)  // lifting_surfaces.py:277
+    PF_X2(vx[k] = fma2(wby, S[k].rz, t1[k]);)
+    PF_X2(vy[k] = fma2(wbz, S[k].rx, t2[k]);)
+    PF_X2(vz[k] = fma2(wbx, S[k].ry, t3[k]);)
+    PF_X2(defl[k] = a[k] * S[k].defl_lim;)
+    PF_X2(fa2[k] = vx[k] * vx[k];)
+    PF_X2(vz2[k] = vz[k] * vz[k];)
+    PF_X2(h2[k] = fma2(vz[k], vz[k], fa2[k]);)
+    PF_X2(V2t[k] = fma2(vy[k], vy[k], vz2[k]);)
+    PF_X2(a0[k] = fma2(-S[k].tau_eta, defl[k], S[k].a0b);)
+    PF_X2(V2[k] = fma2(vx[k], vx[k], V2t[k]);)
+    PF_X2(y[k] = -vz[k];)
+    // fast_atan2_pair(-la, fa) with la = vz, fa = vx
+    float ax0[2], ay0[2], ax1[2], ay1[2], mx0[2], mx1[2], ih0[2], ih1[2], rc0[2], rc1[2], mn0[2], mn1[2];
+    bool zero0[2], zero1[2], still0[2], still1[2], steep0[2], steep1[2], back0[2], back1[2];
+    PF_X2(ax0[k] = __builtin_fabsf(vx[k].x); ay0[k] = __builtin_fabsf(y[k].x); ax1[k] = __builtin_fabsf(vx[k].y); ay1[k] = __builtin_fabsf(y[k].y);)
+    PF_X2(mx0[k] = __builtin_fmaxf(ax0[k], ay0[k]); mx1[k] = __builtin_fmaxf(ax1[k], ay1[k]);)
+    PF_X2(ih0[k] = frsq(h2[k].x); ih1[k] = frsq(h2[k].y);)
+    PF_X2(rc0[k] = frcp(mx0[k]); rc1[k] = frcp(mx1[k]);)
+    PF_X2(mn0[k] = __builtin_fminf(ax0[k], ay0[k]); mn1[k] = __builtin_fminf(ax1[k], ay1[k]);)
+    PF_X2(zero0[k] = mx0[k] == 0.0f; zero1[k] = mx1[k] == 0.0f;)
+    PF_X2(still0[k] = !(h2[k].x > 0.0f); still1[k] = !(h2[k].y > 0.0f);)
+    PF_X2(steep0[k] = ay0[k] > ax0[k]; steep1[k] = ay1[k] > ax1[k];)
+    PF_X2(back0[k] = vx[k].x < 0.0f; back1[k] = vx[k].y < 0.0f;)
+    f2 ih[2], t[2], cu[2], su[2], aP[2], aN[2], ss[2], QA[2], p[2], ca[2], sa[2], dd[2], c9a[2], Cd90[2], hcd[2], r[2], rq[2], rh[2], alpha[2], am[2], Cl_lin[2], ai[2];
+    PF_X2(ih[k] = f2{ih0[k], ih1[k]};)
+    PF_X2(t[k] = f2{mn0[k], mn1[k]} * f2{rc0[k], rc1[k]};)
+    PF_X2(cu[k] = vx[k] * ih[k];)
+    PF_X2(su[k] = y[k] * ih[k];)
+    PF_X2(aP[k] = fma2(S[k].c1, defl[k], S[k].aPb);)
+    PF_X2(t[k] = f2{zero0[k] ? 0.0f : t[k].x, zero1[k] ? 0.0f : t[k].y};)
+    PF_X2(aN[k] = fma2(S[k].c1, defl[k], S[k].aNb);)
+    PF_X2(ss[k] = t[k] * t[k];)
+    PF_X2(QA[k] = S[k].hra * V2[k];)
+    PF_X2(p[k] = fma2(ss[k], sp2(0.0029035410843789577f), sp2(-0.016282962635159492f));)
+    PF_X2(p[k] = fma2(ss[k], p[k], sp2(0.04303929582238197f));)
+    PF_X2(p[k] = fma2(ss[k], p[k], sp2(-0.07533670216798782f));)
+    PF_X2(ca[k] = f2{still0[k] ? 1.0f : cu[k].x, still1[k] ? 1.0f : cu[k].y};)
+    PF_X2(p[k] = fma2(ss[k], p[k], sp2(0.10654674470424652f));)
+    PF_X2(sa[k] = f2{still0[k] ? 0.0f : su[k].x, still1[k] ? 0.0f : su[k].y};)
+    PF_X2(p[k] = fma2(ss[k], p[k], sp2(-0.14207133650779724f));)
+    PF_X2(dd[k] = defl[k] * defl[k];)
+    PF_X2(p[k] = fma2(ss[k], p[k], sp2(0.19993053376674652f));)
+    PF_X2(c9a[k] = fma2(sp2(2.1e-1f), defl[k], sp2(1.98f));)
+    PF_X2(p[k] = fma2(ss[k], p[k], sp2(-0.3333309292793274f));)
+    PF_X2(Cd90[k] = fma2(sp2(-4.26e-2f), dd[k], c9a[k]);)  // (used by the post-stall branch only)
+    PF_X2(p[k] = fma2(ss[k], p[k], sp2(1.0f));)
+    PF_X2(hcd[k] = sp2(0.5f) * S[k].cd0;)
+    PF_X2(r[k] = p[k] * t[k];)
+    PF_X2(rq[k] = sp2(0.5f * kPi) - r[k];)
+    PF_X2(r[k] = f2{steep0[k] ? rq[k].x : r[k].x, steep1[k] ? rq[k].y : r[k].y};)
+    PF_X2(rh[k] = sp2(kPi) - r[k];)
+    PF_X2(r[k] = f2{back0[k] ? rh[k].x : r[k].x, back1[k] ? rh[k].y : r[k].y};)
+    PF_X2(alpha[k] = f2{__builtin_copysignf(r[k].x, y[k].x), __builtin_copysignf(r[k].y, y[k].y)};)
+    bool lin0[2], lin1[2];
+    PF_X2(lin0[k] = (aN[k].x < alpha[k].x) && (alpha[k].x < aP[k].x); lin1[k] = (aN[k].y < alpha[k].y) && (alpha[k].y < aP[k].y);)
+    PF_X2(am[k] = alpha[k] - a0[k];)
+    // (one wave-uniform test for both pairs: the post-stall code only SELECTS per element, so running it for a pair none of whose
+    //  elements is stalled changes nothing)
+    const bool any_stall = __any(!(lin0[0] && lin1[0] && lin0[1] && lin1[1]));
+    PF_X2(Cl_lin[k] = S[k].cl3d * am[k];)
+    PF_X2(ai[k] = Cl_lin[k] * S[k].ipa;)
+    if (any_stall) {  // :409-425 (see surface<>)
+      bool pos0[2], pos1[2];
+      f2 as[2], edge[2], asm0[2], den[2], num[2], aist[2], rden[2], ai_stall[2], tt[2], ais[2];
+      PF_X2(pos0[k] = alpha[k].x > 0.0f; pos1[k] = alpha[k].y > 0.0f;)
+      PF_X2(as[k] = f2{pos0[k] ? aP[k].x : aN[k].x, pos1[k] ? aP[k].y : aN[k].y};)
+      PF_X2(edge[k] = f2{pos0[k] ? 0.5f * kPi : -0.5f * kPi, pos1[k] ? 0.5f * kPi : -0.5f * kPi};)
+      PF_X2(asm0[k] = as[k] - a0[k];)
+      PF_X2(den[k] = edge[k] - as[k];)
+      PF_X2(num[k] = edge[k] - alpha[k];)
+      PF_X2(aist[k] = S[k].cl3d * asm0[k];)
+      PF_X2(rden[k] = f2{frcp(den[k].x), frcp(den[k].y)};)
+      PF_X2(ai_stall[k] = aist[k] * S[k].ipa;)
+      PF_X2(tt[k] = num[k] * rden[k];)
+      PF_X2(ais[k] = ai_stall[k] * f2{med3(tt[k].x, 0.0f, 1.0f), med3(tt[k].y, 0.0f, 1.0f)};)
+      PF_X2(ai[k] = f2{lin0[k] ? ai[k].x : ais[k].x, lin1[k] ? ai[k].y : ais[k].y};)
+    }
+    f2 x[2], tq[2], ae[2], ps[2], pc[2], cmk[2], cx[2], sx[2], cas[2], sas[2], se[2], ce[2], CT[2], CTc[2], cnn[2], CN[2], Cl[2], Cd[2], CM[2];
+    float rce0[2], rce1[2];
+    PF_X2(x[k] = a0[k] + ai[k];)
+    // sincos_small(x): the two Horner chains side by side
+    PF_X2(tq[k] = x[k] * x[k];)
+    PF_X2(ae[k] = alpha[k] - x[k];)
+    PF_X2(ps[k] = fma2(tq[k], sp2(-2.5052108e-8f), sp2(2.7557319e-6f));)
+    PF_X2(pc[k] = fma2(tq[k], sp2(2.0876757e-9f), sp2(-2.7557319e-7f));)
+    PF_X2(ps[k] = fma2(tq[k], ps[k], sp2(-1.9841270e-4f));)
+    PF_X2(pc[k] = fma2(tq[k], pc[k], sp2(2.4801587e-5f));)
+    PF_X2(ps[k] = fma2(tq[k], ps[k], sp2(8.3333333e-3f));)
+    PF_X2(pc[k] = fma2(tq[k], pc[k], sp2(-1.3888889e-3f));)
+    PF_X2(ps[k] = fma2(tq[k], ps[k], sp2(-1.6666667e-1f));)
+    PF_X2(pc[k] = fma2(tq[k], pc[k], sp2(4.1666667e-2f));)
+    PF_X2(ps[k] = fma2(tq[k], ps[k], sp2(1.0f));)
+    PF_X2(pc[k] = fma2(tq[k], pc[k], sp2(-0.5f));)
+    PF_X2(cmk[k] = fma2(sp2(0.175f * (2.0f / kPi)), ae[k], sp2(0.075f));)
+    PF_X2(cx[k] = fma2(tq[k], pc[k], sp2(1.0f));)
+    PF_X2(sx[k] = x[k] * ps[k];)
+    PF_X2(cas[k] = ca[k] * sx[k];)
+    PF_X2(sas[k] = sa[k] * sx[k];)
+    PF_X2(se[k] = fma2(sa[k], cx[k], -cas[k]); ce[k] = fma2(ca[k], cx[k], sas[k]);)
+    // :397-406
+    PF_X2(rce0[k] = frcp(ce[k].x); rce1[k] = frcp(ce[k].y);)
+    PF_X2(CT[k] = S[k].cd0 * ce[k];)
+    PF_X2(CTc[k] = CT[k] * ce[k];)
+    PF_X2(cnn[k] = fma2(CT[k], se[k], Cl_lin[k]);)
+    PF_X2(CN[k] = cnn[k] * f2{rce0[k], rce1[k]};)
+    PF_X2(Cl[k] = Cl_lin[k];)
+    PF_X2(Cd[k] = fma2(CN[k], se[k], CTc[k]);)
+    PF_X2(CM[k] = -CN[k] * cmk[k];)
+    if (any_stall) {  // :427-448
+      f2 dn[2], c9s[2], CTs[2], cms[2], rdn[2], cts[2], ctc[2], CNs[2], Cls[2], Cds[2], CMs[2];
+      PF_X2(dn[k] = fma2(sp2(0.44f), f2{__builtin_fabsf(se[k].x), __builtin_fabsf(se[k].y)}, sp2(0.56f));)
+      PF_X2(c9s[k] = Cd90[k] * se[k];)
+      PF_X2(CTs[k] = hcd[k] * ce[k];)
+      PF_X2(cms[k] = fma2(sp2(0.175f * (2.0f / kPi)), f2{__builtin_fabsf(ae[k].x), __builtin_fabsf(ae[k].y)}, sp2(0.075f));)
+      PF_X2(rdn[k] = f2{frcp(dn[k].x), frcp(dn[k].y)};)
+      PF_X2(cts[k] = CTs[k] * se[k];)
+      PF_X2(ctc[k] = CTs[k] * ce[k];)
+      PF_X2(CNs[k] = c9s[k] * (rdn[k] - S[k].exp_term);)
+      PF_X2(Cls[k] = fma2(CNs[k], ce[k], -cts[k]);)
+      PF_X2(Cds[k] = fma2(CNs[k], se[k], ctc[k]);)
+      PF_X2(CMs[k] = -CNs[k] * cms[k];)
+      PF_X2(Cl[k] = f2{lin0[k] ? Cl[k].x : Cls[k].x, lin1[k] ? Cl[k].y : Cls[k].y};)
+      PF_X2(Cd[k] = f2{lin0[k] ? Cd[k].x : Cds[k].x, lin1[k] ? Cd[k].y : Cds[k].y};)
+      PF_X2(CM[k] = f2{lin0[k] ? CM[k].x : CMs[k].x, lin1[k] ? CM[k].y : CMs[k].y};)
+    }
+    // :485-498
+    f2 L[2], D[2], qc[2], dsa[2], dca[2], tm[2], ty0[2];
+    PF_X2(L[k] = Cl[k] * QA[k]; D[k] = Cd[k] * QA[k];)
+    PF_X2(qc[k] = QA[k] * CM[k];)
+    PF_X2(dsa[k] = D[k] * sa[k]; dca[k] = D[k] * ca[k];)
+    PF_X2(tm[k] = qc[k] * S[k].chord;)
+    PF_X2(o[k].fn = fma2(L[k], ca[k], dsa[k]);)
+    PF_X2(o[k].fp = fma2(L[k], sa[k], -dca[k]);)
+    PF_X2(ty0[k] = fma2(-S[k].rx, o[k].fn, tm[k]);)
+    PF_X2(o[k].ty = fma2(S[k].rz, o[k].fp, ty0[k]);)
+  }
+#undef PF_X2
   // one lift-+z surface's force and torque into the body totals (the tail of surface<false>)
   PF_DEV static void accumulate(const float ry, const float fp, const float fn, const float ty, v3& F, v3& tau) {
     F.x += fp;
@@ -461,12 +646,54 @@ struct FwHot {
   // floor code would have found `near` false for every lane.
   // SHARED (the dogfight): the contact response BETWEEN the aircraft of the world, one stage before the ground's -- publish the new
   // velocity, the world's first lane resolves the contacts, take back velocity and position-level shift.
-  template <bool FLOOR = true, bool SHARED = false>
-  PF_DEV void tick(fw_tab_cptr tab, const float xi, const pf_params* Pfull) {
-#ifdef PF_PHASE_TRACE
+  // TAB: fw_tab_cptr -- the constant table through the scalar cache, one row at a time (16 SGPRs live); FwTableV -- the table in
+  // vector registers (the one-wave-per-SIMD instantiation): no load in the tick, both surface pairs evaluated side by side.
+  template <bool FLOOR = true, bool SHARED = false, class TAB = fw_tab_cptr>
+  PF_DEV void tick(const TAB& tab, const float xi, const pf_params* Pfull) {
+#ifdef PF_FW_TICK_TRACE  // (per-tick clocks through global atomics: inflates the timeline, its own switch since r05)
     const unsigned long long pf_f0 = __builtin_readcyclecounter();
 #endif
     v3 F{0.f, 0.f, 0.f}, tau{0.f, 0.f, 0.f};
+    if constexpr (std::is_same<TAB, FwTableV>::value) {
+#if PF_FW_TABV == 4
+      // (the opaque zero offset: the two rows are requested HERE, in every tick, not hoisted and spilled -- tick_scalar_table)
+      uint32_t zoff;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
+      const fw_tab_cptr tk = tab.rest + zoff;
+      const FwSurf Sv = fw_load_surf(&tk->vtail);
+#else
+      const FwSurf& Sv = tab.vtail;
+#endif
+      f2 a[2] = {f2{act[0], act[1]}, f2{act[2], act[4]}};
+      const f2 c2[2] = {f2{cmd[0], cmd[1]}, f2{cmd[2], cmd[4]}};
+      FwPairOut o[2];
+      surface_pair_x2(tab.pair, a, c2, o);
+      act[0] = a[0].x; act[1] = a[0].y; act[2] = a[1].x; act[4] = a[1].y;
+      // the reference's accumulation order: ailerons (0, 1), h-tail (2), v-tail (3), main wing (4)
+      accumulate(tab.pair[0].ry.x, o[0].fp.x, o[0].fn.x, o[0].ty.x, F, tau);
+      accumulate(tab.pair[0].ry.y, o[0].fp.y, o[0].fn.y, o[0].ty.y, F, tau);
+      accumulate(tab.pair[1].ry.x, o[1].fp.x, o[1].fn.x, o[1].ty.x, F, tau);
+      __builtin_amdgcn_sched_barrier(0);
+#if PF_FW_TABV == 4
+      const FwBody Kb = fw_load_body(&tk->body);  // (requested a surface ahead of its first use; both rows at the top of the tick
+                                                  //  spilled sixteen other scalars around the pairs)
+#else
+      const FwBody& Kb = tab.body;
+#endif
+      act[3] = fmaf(Sv.dt_tau, cmd[3] - act[3], act[3]);
+      surface<true>(Sv, act[3], F, tau);
+      accumulate(tab.pair[1].ry.y, o[1].fp.y, o[1].fn.y, o[1].ty.y, F, tau);
+      __builtin_amdgcn_sched_barrier(0);
+      tick_body<FLOOR, SHARED>(Kb, F, tau, xi, Pfull);
+    } else {
+      tick_scalar_table<FLOOR, SHARED>(tab, F, tau, xi, Pfull);
+    }
+  }
+  template <bool FLOOR, bool SHARED>
+  PF_DEV void tick_scalar_table(fw_tab_cptr tab, v3& F, v3& tau, const float xi, const pf_params* Pfull) {
+#ifdef PF_FW_TICK_TRACE  // (per-tick clocks through global atomics: inflates the timeline, its own switch since r05)
+    const unsigned long long pf_f0 = __builtin_readcyclecounter();
+#endif
     // An opaque zero offset per tick keeps the per-surface constant loads inside the tick (16 SGPRs at
     // a time, see the file header) instead of hoisted and spilled; the scheduling barriers keep the
     // five surface bodies from being interleaved (which cost 255 VGPRs and scratch).
@@ -524,8 +751,16 @@ struct FwHot {
 #ifndef PF_FW_PREFETCH
     const FwBody K = fw_load_body(&tk->body);
 #endif
-#ifdef PF_PHASE_TRACE
+#ifdef PF_FW_TICK_TRACE  // (per-tick clocks through global atomics: inflates the timeline, its own switch since r05)
     asm volatile("" ::"v"(F.x), "v"(tau.y));
+    if ((threadIdx.x & 63u) == 0u) { atomicAdd(&g_solver_trace[0], 1ull); atomicAdd(&g_solver_trace[1], __builtin_readcyclecounter() - pf_f0); }
+#endif
+    tick_body<FLOOR, SHARED>(K, F, tau, xi, Pfull);
+  }
+  // the rest of the tick: motor, collision detection, the free-base tick, contact response, update_state
+  template <bool FLOOR, bool SHARED>
+  PF_DEV void tick_body(const FwBody& K, v3 F, v3 tau, const float xi, const pf_params* Pfull) {
+#ifdef PF_FW_TICK_TRACE  // (per-tick clocks through global atomics: inflates the timeline, its own switch since r05)
     const unsigned long long pf_f1 = __builtin_readcyclecounter();
 #endif
     {  // motor (motors.py:110-195), at the base origin along +x
@@ -594,12 +829,10 @@ struct FwHot {
     q = quat_integrate(q, w, K.half_dt);
     derive();
     contact_step |= contact_now;
-#ifdef PF_PHASE_TRACE
+#ifdef PF_FW_TICK_TRACE  // (per-tick clocks through global atomics: inflates the timeline, its own switch since r05)
     asm volatile("" ::"v"(wb.x), "v"(vb.z));
     if ((threadIdx.x & 63u) == 0u) {  // (diagnostic build: per tick and wave, clocks in the five surfaces / in the rest of the tick)
       const unsigned long long pf_f2 = __builtin_readcyclecounter();
-      atomicAdd(&g_solver_trace[0], 1ull);
-      atomicAdd(&g_solver_trace[1], pf_f1 - pf_f0);
       atomicAdd(&g_solver_trace[7], pf_f2 - pf_f1);
     }
 #endif
@@ -611,26 +844,29 @@ struct FwHot {
 // g3 w.yz+act0,1, g4 act2..4+throttle, g5 ints, g6..8 the 4x3 targets (Fixedwing::load/store layout).
 // ROLL: as in quadx_m0_env_kernel -- 0 one env step per launch, 1 pf_rollout with on-device action sampling (no vector-memory
 // load in the loop), 2 pf_rollout over a given action sequence.
-// (A/B switch, off: with the second tick instantiation in the kernel the 256-register budget spills another 128 B per lane inside
-//  the tick loop -- 23.9 -> 28.3 us per step at 65 536 lanes, rollout 18.9 -> 22.1 (profiles/README.md, r04). The QuadX kernel, which
-//  has the registers, gains from the same split; this one has to shrink first.)
+// WPS (as in quadx_m0_env_kernel): 2 = two waves per SIMD, 256 registers, any batch; 1 = one wave per SIMD, 512 registers (the
+// overflow lives in AGPRs, not on the stack), chosen for batches of at most one wave per SIMD, where a second resident wave has
+// nothing to run. The calm-wave tick (second tick instantiation without the floor code's call sites) needs that budget: under 256
+// registers it spilled another 128 B per lane inside the tick loop (23.9 -> 28.3 us per step at 65 536 lanes, profiles/README.md, r04).
 #ifndef PF_FW_CALM
-#define PF_FW_CALM 0
+#define PF_FW_CALM 0   // (A/B: the calm tick in the two-waves-per-SIMD instantiation as well)
 #endif
-#ifdef PF_FW_LB1  // (A/B: one wave per SIMD -- 512 registers, the overflow into AGPRs instead of scratch)
-#define PF_FW_WAVES 1
-#else
-#define PF_FW_WAVES 2
+#ifndef PF_FW_CALM_W1
+#define PF_FW_CALM_W1 0   // (measured, r05: 23.9 us against 22.3 without -- the second tick instantiation's AGPR copies)
 #endif
-template <int NOISE, int ROLL>
-__global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const FwK K, const FwTable* table_g, const pf_buffers B,
+template <int NOISE, int ROLL, int WPS = 2>
+__global__ void __launch_bounds__(64, WPS) fixedwing_wp_env_kernel(const FwK K, const FwTable* table_g, const pf_buffers B,
                                                                  const pf_params* __restrict__ Pfull, const float4* __restrict__ tmpl,
                                                                  const int n, const uint64_t lane0, const int op,
                                                                  const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
+  constexpr bool CALM = WPS == 1 ? (PF_FW_CALM_W1 != 0) : (PF_FW_CALM != 0);
   constexpr bool ROLLOUT = ROLL != 0;
   constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 6 + 12;
   __shared__ __attribute__((aligned(16))) float tile[64 * kMaxD];
+  __shared__ int spos[64];        // the cooperative waypoint sampling's (lane, counter) exchange
+  __shared__ uint32_t sctr[64];
+  static_assert(64 * kMaxD >= 2 * 64 * 16, "prepare_targets stages uniforms and targets in the observation tile");
   const int tid = threadIdx.x;
   const int wave_base = blockIdx.x * 64;
   const int lane = wave_base + tid;
@@ -654,6 +890,9 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   const float calm_sink_env = surf->body.vmax * surf->body.dt * (float)(2 * K.env_step_ratio) * 1.001f + 1e-3f;
   const float calm_sink_av = surf->body.vmax * surf->body.dt * 2.0f * 1.001f + 1e-3f;
   V.cws = (lds_fptr)tile;
+  // (WPS == 1: the constant table in vector registers for the whole launch -- FwTableV)
+  FwTableV TV{};
+  if (WPS == 1) TV = fw_table_in_vgprs(table_g);
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;
@@ -717,6 +956,54 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   };
+  // Waypoint sampling (waypoint_handler.py:53-83), cooperatively (quadx_fast.hpp: prepare_targets): a resetting lane needs three
+  // Philox calls and, per target, two sine / cosine pairs -- some 700 instructions that the one or two resetting lanes of a wave walked
+  // through while the other lanes idled, in about every second wave of a launch, and a launch lasts as long as its slowest wave.
+  // Dealt out over the 64 lanes instead: pass 1, one (lane, call) pair per lane -> the uniforms, through the observation tile (idle
+  // here); pass 2, one (lane, target) pair per lane -> the target, the same arithmetic on the same numbers as the per-lane path
+  // (which injected draws, B.u_targets, keep). Wave-uniform call.
+  const bool coop_targets = !((NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr));
+  auto prepare_targets = [&](bool reset_now) {
+    if (!coop_targets) return;
+    const unsigned long long m = __ballot(reset_now);
+    if (m == 0ull) return;
+    const int r = __popcll(m);
+    if (reset_now) {
+      spos[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+      sctr[tid] = rng_ctr;
+    }
+    lds_sync();
+    const int nt = K.num_targets;
+    float* const U = tile;             // [lane][16]: the uniforms of calls 0 .. 2
+    float* const TG = tile + 64 * 16;  // [lane][16]: four targets x (x, y, z, -)
+    for (int base = 0; base < r * 3; base += 64) {
+      const int j = base + tid;
+      if (j < r * 3) {
+        const int which = j / 3, call = j - which * 3;
+        const int src = spos[which];
+        const f4 u = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, 2u));
+        float* o = U + src * 16 + call * 4;
+        o[0] = u.a; o[1] = u.b; o[2] = u.c; o[3] = u.d;
+      }
+    }
+    lds_sync();
+    for (int base = 0; base < r * nt; base += 64) {
+      const int j = base + tid;
+      if (j < r * nt) {
+        const int which = j / nt, i = j - which * nt;
+        const int src = spos[which];
+        const float* u = U + src * 16;
+        const float theta = u[i], phi = u[nt + i], dist = fmaf(K.dome09m1, u[2 * nt + i], 1.0f);  // theta, phi in turns
+        float st, ct, sph, cph;
+        sincos_turns(theta, st, ct);
+        sincos_turns(phi, sph, cph);
+        const float zz = __builtin_fabsf(dist * cph);
+        float* o = TG + src * 16 + 4 * i;
+        o[0] = dist * sph * ct; o[1] = dist * sph * st; o[2] = zz > K.min_height ? zz : K.min_height; o[3] = 0.0f;
+      }
+    }
+    lds_sync();
+  };
   // env.reset() for this lane (fixedwing_base_env.py:136-211 begin_reset/end_reset,
   // fixedwing_waypoints_env.py:101-114): settled spawn state from the template, fresh waypoints.
   auto reset_lane = [&]() {
@@ -732,6 +1019,16 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
     act0 = act1 = act2 = act3 = 0.f;
     const int nt = K.num_targets;  // waypoint_handler.py:53-83
     n_left = nt;
+    if (coop_targets) {  // sampled by prepare_targets(): this lane's 4 x (x, y, z, -)
+      const float4* t4 = reinterpret_cast<const float4*>(tile + 64 * 16 + tid * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < nt) {
+          const float4 t = t4[i];
+          tgt[i][0] = t.x; tgt[i][1] = t.y; tgt[i][2] = t.z;
+        }
+      }
+    } else {
     f4 u0, u1, u2;
     const bool inj = (NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr);
     if (!inj) {
@@ -759,6 +1056,7 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
         float zz = __builtin_fabsf(dist * cph);
         tgt[i][0] = dist * sph * ct; tgt[i][1] = dist * sph * st; tgt[i][2] = zz > K.min_height ? zz : K.min_height;
       }
+    }
     }
     float dx = tgt[0][0] - V.p.x, dy = tgt[0][1] - V.p.y, dz = tgt[0][2] - V.p.z;
     old_dist = INFINITY;
@@ -837,6 +1135,7 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   act0 = act1 = act2 = act3 = 0.f;
   reward = 0.0f;
   was_reset = false;
+  prepare_targets(do_reset);
   if (do_reset) reset_lane();
   PF_STAMP(4);
 
@@ -878,17 +1177,25 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
   // -- and the wave runs ticks instantiated without the floor code (no out-of-line call in the tick loop). A wave that is not calm
   // over the env step asks again per Aviary step, over its two ticks.
   const float calm_reach = Kc_bound_radius;
-  const bool calm_env = PF_FW_CALM && __all(!go || (V.p.z - calm_reach > calm_sink_env));
+  const bool calm_env = CALM && __all(!go || (V.p.z - calm_reach > calm_sink_env));
   for (int s = 0; s < K.env_step_ratio; ++s) {
     if (!__any(go)) break;
-    const bool calm_s = calm_env || (PF_FW_CALM && __all(!go || (V.p.z - calm_reach > calm_sink_av)));
+    const bool calm_s = calm_env || (CALM && __all(!go || (V.p.z - calm_reach > calm_sink_av)));
     if (go) {
       float xi0, xi1;
       if (NOISE == PF_NOISE_PHILOX) { xi0 = 1.0f + pick8(zn, (uint32_t)(2 * s)); xi1 = 1.0f + pick8(zn, (uint32_t)(2 * s + 1)); }
       else if (NOISE == PF_NOISE_INJECT) { xi0 = B.xi[(size_t)(2 * s) * N + li]; xi1 = B.xi[(size_t)(2 * s + 1) * N + li]; }
       else { xi0 = 0.f; xi1 = 0.f; }
       V.contact_step = false;
-      if (calm_s) {
+      if (WPS == 1) {
+        if (calm_s) {
+#pragma unroll 1
+          for (int t = 0; t < 2; ++t) V.template tick<false, false, FwTableV>(TV, t == 0 ? xi0 : xi1, Pfull);
+        } else {
+#pragma unroll 1
+          for (int t = 0; t < 2; ++t) V.template tick<true, false, FwTableV>(TV, t == 0 ? xi0 : xi1, Pfull);
+        }
+      } else if (calm_s) {
 #pragma unroll 1
         for (int t = 0; t < 2; ++t) V.template tick<false>(surf, t == 0 ? xi0 : xi1, Pfull);
       } else {
@@ -940,6 +1247,7 @@ __global__ void __launch_bounds__(64, PF_FW_WAVES) fixedwing_wp_env_kernel(const
                                             (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
         B.final_info[2 * (toff + li) + 1] = n_left - (pop_pending ? 1 : 0);
       }
+      prepare_targets(same);
       if (same) reset_lane();
     }
   }

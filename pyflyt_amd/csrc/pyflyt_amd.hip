@@ -753,6 +753,7 @@ struct pf_ctx {
   char err[256];
   // hot-path specialisation (quadx_fast.hpp)
   bool fast;
+  bool one_wave; // the batch is at most one wave per SIMD of the device (the 512-register instantiations' condition)
   bool lean;     // the batch is at most one wave per SIMD of the device: the specialised QuadX kernel's 512-register instantiation
   pf::QuadK K;
   pf_params* P_dev;  // device copy of P for the rarely-taken floor paths (contact detection and response) and the LDS constant tables
@@ -820,7 +821,9 @@ static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32
 }
 static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
-#define PF_FAST(NZ) hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ, 0>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, op, mask, 1, 0u)
+  // (the one-wave-per-SIMD instantiation -- fixedwing_fast.hpp, WPS -- where the batch is no more than that)
+#define PF_FAST(NZ) do { if (ctx->one_wave) hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ, 0, 1>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, op, mask, 1, 0u); \
+    else hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ, 0, 2>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, op, mask, 1, 0u); } while (0)
   if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_FAST(PF_NOISE_PHILOX);
   else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);
   else PF_FAST(PF_NOISE_OFF);
@@ -828,7 +831,8 @@ static void launch_fast_fw(pf_ctx* ctx, const pf_buffers* b, int op, const uint8
 }
 static void launch_rollout_fw(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 63) / 64;
-#define PF_ROLL(NZ, R) hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ, R>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0)
+#define PF_ROLL(NZ, R) do { if (ctx->one_wave) hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ, R, 1>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0); \
+    else hipLaunchKernelGGL((pf::fixedwing_wp_env_kernel<NZ, R, 2>), dim3(grid), dim3(64), 0, s, ctx->FK, ctx->surf_dev, *b, ctx->P_dev, ctx->tmpl, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0); } while (0)
   if (b->actions == nullptr) {
     if (ctx->P.noise_mode == PF_NOISE_PHILOX) PF_ROLL(PF_NOISE_PHILOX, 1);
     else PF_ROLL(PF_NOISE_OFF, 1);
@@ -912,7 +916,8 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 0;
     const long waves = ((long)n_lanes + 63) / 64;
     // (the lean instantiations solve floor contacts in registers, four slots = the incident face: quadx_fast.hpp, quad_floor_solve)
-    c->lean = cus > 0 && waves <= 4L * cus && P.contact_manifold_points < 8 && getenv("PF_NO_LEAN_KERNEL") == nullptr;  // (4 SIMDs per CU)
+    c->one_wave = cus > 0 && waves <= 4L * cus && getenv("PF_NO_LEAN_KERNEL") == nullptr;  // (4 SIMDs per CU)
+    c->lean = c->one_wave && P.contact_manifold_points < 8;
   }
   pf::FwTable fsurf;
   c->fast_fw = pf::fwk_from_params(P, c->FK, fsurf) && getenv("PF_DISABLE_FAST") == nullptr;

@@ -1022,6 +1022,9 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   // walking through its calls serially while the other lanes idle, the (lane, call) pairs are dealt
   // out over all 64 lanes, evaluated in one pass and handed back through LDS. Wave-uniform call.
   auto prepare_settle_noise = [&](bool reset_now) {
+#ifdef PF_EXP_CHEAP_RESET  // (experiment, never shipped: what would a reset cost if its random state came precomputed?)
+    return;
+#endif
     if (NOISE != PF_NOISE_PHILOX) return;
     const unsigned long long m = __ballot(reset_now);
     if (m == 0ull) return;
@@ -1052,6 +1055,9 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   // Wave-uniform call. (Injected draws, B.u_targets, keep the per-lane path.)
   const bool coop_targets = (TASK == PF_TASK_WAYPOINTS) && !((NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr));
   auto prepare_targets = [&](bool reset_now) {
+#ifdef PF_EXP_CHEAP_RESET
+    return;
+#endif
     if (!coop_targets) return;
     const unsigned long long m = __ballot(reset_now);
     if (m == 0ull) return;
@@ -1135,6 +1141,9 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       else x = float4{0.f, 0.f, 0.f, 0.f};
       return x;
     };
+#ifdef PF_EXP_CHEAP_RESET
+    if (!MODES || K.mode == 0) { z -= 0.0358f; vz = -0.8f; thr = 0.048f; } else
+#endif
     if (!MODES || K.mode == 0) {
       // Mode 0: the motor command is the constant 0.05, so the throttle recurrence does not depend on the vertical state and the
       // 20 ticks are TWO dependency chains -- throttle (3 instructions per tick) and climb rate (3-4 per tick):
@@ -1207,6 +1216,20 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = K.num_targets;
       n_left = nt;
+#ifdef PF_EXP_CHEAP_RESET
+      if (coop_targets) {
+        uint32_t h = (uint32_t)(lane0 + li) * 2654435761u + rng_ctr * 40503u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < nt) {
+            tgt[i][0] = (float)((h >> 0) & 255u) * (4.0f / 255.0f) - 2.0f; tgt[i][1] = (float)((h >> 8) & 255u) * (4.0f / 255.0f) - 2.0f;
+            tgt[i][2] = (float)((h >> 16) & 255u) * (2.0f / 255.0f) + 0.1f;
+            if (kYaw) ytg[i] = (float)((h >> 24) & 255u) * (6.0f / 255.0f) - 3.0f;
+            h = h * 1664525u + 1013904223u;
+          }
+        }
+      } else
+#endif
       if (coop_targets) {  // sampled by prepare_targets(): this lane's 4 x (x, y, z, yaw)
         const float4* t4 = reinterpret_cast<const float4*>(tile + 64 * 16 + tid * 16);
 #pragma unroll

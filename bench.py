@@ -136,24 +136,33 @@ def cpu_baseline(env, noise, seconds):
     rng = np.random.default_rng(0)
     low = np.array([-np.pi] * 3 + [0.0]) if env != "fixedwing_waypoints" else -np.ones(4)
     high = np.array([np.pi] * 3 + [0.8]) if env != "fixedwing_waypoints" else np.ones(4)
-    acts = [rng.uniform(low, high, size=(n, 4)).astype(np.float32) for _ in range(16)]
-    ob.step(acts[0], autoreset=1)
-    t0 = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t0 < seconds:
-        ob.step(acts[k % 16], autoreset=1)
-        k += 1
-    dt = time.perf_counter() - t0
+    # the same action process as the GPU leg: a ring of independent uniform draws per lane and entry, never shorter than 100 entries
+    # (a ring that repeats within an episode's length is a different workload: see --ring)
+    R = 100
+    acts = [rng.uniform(low, high, size=(n, 4)).astype(np.float32) for _ in range(R)]
+    for j in range(R):  # (the episode phases decorrelate before anything is timed, as the GPU leg's preroll does)
+        ob.step(acts[j], autoreset=1)
+    # three samples of a third of the budget each: the host is shared, and one sample swung 0.6-2.8 M with the neighbours' load
+    samples, k = [], 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        k0 = k
+        while time.perf_counter() - t0 < seconds / 3.0:
+            ob.step(acts[k % R], autoreset=1)
+            k += 1
+        samples.append(n * (k - k0) / (time.perf_counter() - t0))
+    samples.sort()
     cores = O.lib().orc_num_threads()
     # BASELINE.md B1 (config 1 plumbing): one env, 1000 random-action steps with reset on term/trunc, one core
     one = O.OracleBatch(P, 1)
     one.reset()
     t1 = time.perf_counter()
     for j in range(1000):
-        one.step(acts[j % 16][:1], autoreset=1)
+        one.step(acts[j % R][:1], autoreset=1)
     dt1 = time.perf_counter() - t1
-    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"fp64 C restatement (oracle/uav_oracle.c), {env}, batch {n}, {k} steps in {dt:.1f} s, OpenMP over lanes",
+    return {"value": samples[1], "min": samples[0], "max": samples[2], "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"fp64 C restatement (oracle/uav_oracle.c), {env}, batch {n}, action ring of {R} entries, {k} steps in three samples of {seconds / 3.0:.1f} s "
+                      "(value = their median), OpenMP over lanes",
             "single_env_1core": {"value": 1000 / dt1, "unit": "env-steps/s", "cores": 1,
                                  "sample": "1 env, 1000 steps, NEXT_STEP auto-reset, incl. ctypes call overhead per step"}}
 
@@ -269,8 +278,34 @@ def time_config(env, batch, device, args):
     per = e0.elapsed_time(e1) * 1e-3 / (reps * g)
     assert torch.isfinite(eng.obs).all(), f"non-finite observation in config {env}"
     r = roofline_block(env, batch, per, KERNEL_OF.get(env, "pf::quadx_m0_env_kernel"))
-    return {"workload": f"{env}, batch {batch}, random actions, motor noise {args.noise}, NEXT_STEP auto-reset, contact response on", "steps": reps * g,
-            "launch_us": per * 1e6, "value": batch / per, "unit": "env-steps/s", "roofline": r}
+    out = {"workload": f"{env}, batch {batch}, random actions, motor noise {args.noise}, NEXT_STEP auto-reset, contact response on", "steps": reps * g,
+           "launch_us": per * 1e6, "value": batch / per, "unit": "env-steps/s", "roofline": r}
+    if args.rollout_steps > 0:
+        # the state-resident figure (pf_rollout, K steps per launch): the only way a small batch leaves the per-launch floor --
+        # 4 096 lanes are 64 waves on 1 024 SIMDs, a launch per step costs its fixed 8 us whatever the kernel does
+        kk = args.rollout_steps
+        with torch.cuda.stream(stream):
+            eng.rollout(kk, step_index0=0)
+            stream.synchronize()
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            r0.record(stream)
+            for i in range(5):
+                eng.rollout(kk, step_index0=(i + 1) * kk)
+            r1.record(stream)
+            stream.synchronize()
+        rper = r0.elapsed_time(r1) * 1e-3 / (5 * kk)
+        assert torch.isfinite(eng._traj["obs"]).all(), f"non-finite observation in the rollout of config {env}"
+        out["rollout"] = {"k": kk, "launches": 5, "us_per_step": rper * 1e6, "value": batch / rper, "unit": "env-steps/s",
+                          "note": "pf_rollout: k env steps per launch, state in registers, on-device action sampling; bit-identical to k x pf_env_step"}
+    return out
+
+
+def time_config_guarded(env, batch, device, args):
+    """A secondary config must not take the headline line down with it: an exception is recorded in its place."""
+    try:
+        return time_config(env, batch, device, args)
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def main():
@@ -519,12 +554,15 @@ def main():
             # BASELINE.json configs 2-4, timed after the headline in the same process (the headline config is configs[4]'s per-GPU
             # slice = 65 536 lanes of Hover; config 1 is the CPU plumbing case: cpu_baseline.single_env_1core)
             out["configs"] = {
-                "hover_4096": time_config("hover", 4096, device, args),
-                "quadx_waypoints_65536": time_config("quadx_waypoints", 65536, device, args),
-                "fixedwing_waypoints_65536": time_config("fixedwing_waypoints", 65536, device, args),
+                "hover_4096": time_config_guarded("hover", 4096, device, args),
+                "quadx_waypoints_65536": time_config_guarded("quadx_waypoints", 65536, device, args),
+                "fixedwing_waypoints_65536": time_config_guarded("fixedwing_waypoints", 65536, device, args),
             }
         if not args.no_cpu_baseline and world == 1 and args.env not in ("dogfight", "ma_hover"):
-            out["cpu_baseline"] = cpu_baseline(args.env, args.noise, args.cpu_seconds)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.env, args.noise, args.cpu_seconds)
+            except Exception as e:  # noqa: BLE001  (the reported baseline must not take the measured line down)
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         line = json.dumps(out)
     if dist is not None:
         dist.destroy_process_group()

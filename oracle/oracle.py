@@ -190,6 +190,7 @@ def lib():
         L.orc_contact_plane.restype = C.c_int
         L.orc_rigid_tick.argtypes = [PP, dp, dp, dp, dp, dp, dp]
         L.orc_philox4x32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_philox4x32_r.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         L.orc_normal4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, dp]
         L.orc_uniform4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, dp]
         L.orc_update_state.argtypes = [PP, LP]

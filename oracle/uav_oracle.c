@@ -54,13 +54,14 @@ static void inv3(const double A[3][3], double B[3][3]) {
 
 /* ------------------------------------------------------------------ RNG: Philox4x32-10
  * Counter-based generator (Salmon et al., SC'11), the integer stream is bit-identical to the
- * device implementation (pyflyt_amd/csrc/uav_rng.hpp). The reference threads a numpy PCG64
+ * device implementation (pyflyt_amd/csrc/uav_device.hpp: philox4x32). The reference threads a numpy PCG64
  * Generator through its components (motors.py:134-138, waypoint_handler.py:72-83); that stream
  * cannot be matched on a GPU, so parity runs either inject the normals or share this Philox
- * stream (RNG row). */
-void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+ * stream (RNG row). orc_philox4x32_r takes the round count: tests/test_oracle_kat.py pins the round function
+ * and the key schedule to the published known-answer vectors. */
+void orc_philox4x32_r(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int rounds, uint32_t out[4]) {
   uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < rounds; ++r) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -71,6 +72,9 @@ void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+  orc_philox4x32_r(key, c0, c1, c2, c3, ORC_PHILOX_ROUNDS, out);
 }
 /* 23-bit uniform in (0,1): (k + 0.5) * 2^-23, k < 2^23 -- exactly representable in fp32 and fp64 */
 static inline double u24(uint32_t x) { return ((double)(x >> 9) + 0.5) * (1.0 / 8388608.0); }

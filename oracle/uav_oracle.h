@@ -333,7 +333,9 @@ void orc_rigid_tick(const orc_params* P, double p[3], double q[4], double v[3], 
 int orc_contact_points(const orc_params* P, const double p[3], const double q[4], double pts[][3], double depth[]);
 
 /* ---------- RNG (same integer stream as the device) ---------- */
+#define ORC_PHILOX_ROUNDS 10 /* == PF_PHILOX_ROUNDS (pyflyt_amd/csrc/uav_device.hpp) */
 void orc_philox4x32(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
+void orc_philox4x32_r(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, int rounds, uint32_t out[4]);
 void orc_normal8(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double z[8]);
 void orc_normal4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double z[4]);
 void orc_uniform4(uint64_t key, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, double u[4]);

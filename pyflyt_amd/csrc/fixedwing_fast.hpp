@@ -207,14 +207,47 @@ PF_DEV FwSurf2 fw_load_surf2(fw_surf2_cptr p) {  // two s_load_dwordx16, every f
 // uniform value in a vector register costs the instruction that reads it nothing (no constant-bus limit, no SGPR -> VGPR copy in
 // front of a packed operand; quadx_fast.hpp: QuadKV).
 #ifndef PF_FW_TABV
-#define PF_FW_TABV 2   // (A/B: 2 = the whole table in vector registers; 4 = the surface pairs only, v-tail and body rows by scalar loads in the tick)
+#define PF_FW_TABV 2   // (A/B: 2 = the whole table in vector registers; 4 = the surface pairs only, v-tail and body rows by scalar loads in
+                       //  the tick; 5 = the surface pairs in vector registers, v-tail and body rows read from LDS in the tick)
 #endif
 struct FwTableV {
   FwSurf2 pair[2];   // the two lift-+z surface pairs: in vector registers for the whole launch
   FwSurf vtail;      // (PF_FW_TABV == 2) v-tail and body rows as well
   FwBody body;
   fw_tab_cptr rest;  // (PF_FW_TABV == 4) v-tail and body rows: scalar loads in the tick, requested a surface ahead of their first use
+  lds_fptr krest;    // (PF_FW_TABV == 5) the same two rows, 48 floats, in LDS: broadcast ds_read_b128 a surface ahead of their first use
 };
+// (PF_FW_TABV == 5, measured and kept off) All 112 values in vector registers are more than the 256 a VALU instruction can address
+// leave room for: the allocator parks part of the table -- and of the aircraft's state -- in AGPRs, 55 v_accvgpr_read / _write per
+// tick. Scalar loads per tick (4) spill sixteen other scalars around the pairs instead: 22.1 us against 21.5. From LDS the two rows
+// cost eleven ds_read_b128 per tick and halve the AGPR traffic, but their latency shows: 22.2 us against 21.4 (65 536 lanes, r05).
+typedef float fw_f4v __attribute__((ext_vector_type(4)));
+typedef const fw_f4v __attribute__((address_space(3))) * fw_lds_f4ptr;
+PF_DEV FwSurf fw_lds_surf(lds_fptr base) {  // the v-tail's row (FwSurf's field order)
+  uint32_t zo;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zo));  // (per tick: keeps the reads in the tick instead of hoisted and held)
+  const fw_lds_f4ptr q = (fw_lds_f4ptr)(base + zo);
+  const fw_f4v a = q[0], b = q[1], c = q[2], d = q[3];
+  FwSurf S;
+  S.rx = a.x; S.ry = a.y; S.rz = a.z; S.cl3d = a.w; S.a0b = b.x; S.aPb = b.y; S.aNb = b.z; S.tau_eta = b.w;
+  S.c1 = c.x; S.ipa = c.y; S.exp_term = c.z; S.cd0 = c.w; S.defl_lim = d.x; S.dt_tau = d.y; S.hra = d.z; S.chord = d.w;
+  return S;
+}
+PF_DEV FwBody fw_lds_body(lds_fptr base) {  // the body's row (FwBody's field order), behind the v-tail's 16 floats
+  uint32_t zo;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zo));
+  const fw_lds_f4ptr q = (fw_lds_f4ptr)(base + 16 + zo);
+  const fw_f4v a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6];
+  FwBody K;
+  K.dt = a.x; K.half_dt = a.y; K.gravity_z = a.z; K.vmax = a.w; K.inv_mass = b.x;
+  K.H[0] = b.y; K.H[1] = b.z; K.H[2] = b.w; K.H[3] = c.x; K.H[4] = c.y; K.H[5] = c.z;
+  K.iI[0] = c.w; K.iI[1] = d.x; K.iI[2] = d.y; K.iI[3] = d.z; K.iI[4] = d.w; K.iI[5] = e.x;
+  K.com[0] = e.y; K.com[1] = e.z; K.com[2] = e.w;
+  K.bound_radius = f.x; K.m_a = f.y; K.m_noise = f.z; K.fmax = f.w; K.tmax = g.x; K.slab_xy = g.y; K.slab_bottom = g.z;
+  return K;
+}
+static_assert(offsetof(FwBody, H) == 20 && offsetof(FwBody, iI) == 44 && offsetof(FwBody, com) == 68 && offsetof(FwBody, bound_radius) == 80 &&
+              offsetof(FwBody, tmax) == 96 && offsetof(FwBody, slab_bottom) == 104, "fw_lds_body follows FwBody's layout");
 // Loaded with VECTOR loads from a uniform address (every lane reads the same 16-byte words: one broadcast request each), issued in
 // front of the state loads so that their latency is shared -- scalar loads would need a v_mov per value on top (the first version of
 // this: 12 s_loads, 111 v_movs and 57 AGPR writes in the prologue, 0.8 us of every launch). The opaque zero keeps the compiler from
@@ -230,6 +263,7 @@ PF_DEV FwTableV fw_table_in_vgprs(const FwTable* g) {
   FwTableV V;
   __builtin_memcpy(&V.pair[0], r, kN * 16);
   V.rest = (fw_tab_cptr)(uintptr_t)g;
+  V.krest = nullptr;
   return V;
 }
 static_assert(offsetof(FwTableV, vtail) == offsetof(FwTable, vtail) && offsetof(FwTableV, body) == offsetof(FwTable, body), "FwTableV starts with FwTable");
@@ -486,7 +520,8 @@ struct FwHot {
   // the same operations in the same order as surface_pair: bit-identical results. Needs both pairs' constants at once (64 values):
   // the one-wave-per-SIMD instantiation holds them in vector registers (FwTableV).
 #define PF_X2(...) { constexpr int k = 0; __VA_ARGS__ } { constexpr int k = 1; __VA_ARGS__ }
-  PF_DEV void surface_pair_x2(const FwSurf2 (&S)[2], f2 (&a)[2], const f2 (&cmd2)[2], FwPairOut (&o)[2]) const {
+  template <class PRE>
+  PF_DEV void surface_pair_x2(const FwSurf2 (&S)[2], f2 (&a)[2], const f2 (&cmd2)[2], FwPairOut (&o)[2], PRE&& request_next) const {
     const f2 wbx = sp2(wb.x), wby = sp2(wb.y), wbz = sp2(wb.z);
     f2 da[2], t1[2], t2[2], t3[2], vx[2], vy[2], vz[2], defl[2], fa2[2], vz2[2], h2[2], V2t[2], a0[2], V2[2], y[2];
     PF_X2(da[k] = cmd2[k] - a[k];)
@@ -619,6 +654,7 @@ struct FwHot {
       PF_X2(Cd[k] = f2{lin0[k] ? Cd[k].x : Cds[k].x, lin1[k] ? Cd[k].y : Cds[k].y};)
       PF_X2(CM[k] = f2{lin0[k] ? CM[k].x : CMs[k].x, lin1[k] ? CM[k].y : CMs[k].y};)
     }
+    request_next();  // (the caller's loads for what follows the pairs: their latency behind the force assembly below)
     // :485-498
     f2 L[2], D[2], qc[2], dsa[2], dca[2], tm[2], ty0[2];
     PF_X2(L[k] = Cl[k] * QA[k]; D[k] = Cd[k] * QA[k];)
@@ -661,13 +697,18 @@ struct FwHot {
       asm volatile("s_mov_b32 %0, 0" : "=s"(zoff));
       const fw_tab_cptr tk = tab.rest + zoff;
       const FwSurf Sv = fw_load_surf(&tk->vtail);
-#else
+#elif PF_FW_TABV == 2
       const FwSurf& Sv = tab.vtail;
 #endif
       f2 a[2] = {f2{act[0], act[1]}, f2{act[2], act[4]}};
       const f2 c2[2] = {f2{cmd[0], cmd[1]}, f2{cmd[2], cmd[4]}};
       FwPairOut o[2];
-      surface_pair_x2(tab.pair, a, c2, o);
+#if PF_FW_TABV == 5
+      FwSurf Sv;
+      surface_pair_x2(tab.pair, a, c2, o, [&]() { Sv = fw_lds_surf(tab.krest); });
+#else
+      surface_pair_x2(tab.pair, a, c2, o, []() {});
+#endif
       act[0] = a[0].x; act[1] = a[0].y; act[2] = a[1].x; act[4] = a[1].y;
       // the reference's accumulation order: ailerons (0, 1), h-tail (2), v-tail (3), main wing (4)
       accumulate(tab.pair[0].ry.x, o[0].fp.x, o[0].fn.x, o[0].ty.x, F, tau);
@@ -677,6 +718,8 @@ struct FwHot {
 #if PF_FW_TABV == 4
       const FwBody Kb = fw_load_body(&tk->body);  // (requested a surface ahead of its first use; both rows at the top of the tick
                                                   //  spilled sixteen other scalars around the pairs)
+#elif PF_FW_TABV == 5
+      const FwBody Kb = fw_lds_body(tab.krest);   // (requested here, first needed a surface later)
 #else
       const FwBody& Kb = tab.body;
 #endif
@@ -864,6 +907,7 @@ __global__ void __launch_bounds__(64, WPS) fixedwing_wp_env_kernel(const FwK K, 
   constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 6 + 12;
   __shared__ __attribute__((aligned(16))) float tile[64 * kMaxD];
+  __shared__ __attribute__((aligned(16))) float ktab[48];  // (WPS == 1) the constant table's v-tail and body rows: FwTableV::krest
   __shared__ int spos[64];        // the cooperative waypoint sampling's (lane, counter) exchange
   __shared__ uint32_t sctr[64];
   static_assert(64 * kMaxD >= 2 * 64 * 16, "prepare_targets stages uniforms and targets in the observation tile");
@@ -892,7 +936,6 @@ __global__ void __launch_bounds__(64, WPS) fixedwing_wp_env_kernel(const FwK K, 
   V.cws = (lds_fptr)tile;
   // (WPS == 1: the constant table in vector registers for the whole launch -- FwTableV)
   FwTableV TV{};
-  if (WPS == 1) TV = fw_table_in_vgprs(table_g);
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;
@@ -906,6 +949,19 @@ __global__ void __launch_bounds__(64, WPS) fixedwing_wp_env_kernel(const FwK K, 
     if (ROLL == 0 && op == 0) a_pre = reinterpret_cast<const float4*>(B.actions)[li];
 #endif
     if (blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch((int)threadIdx.x);  // (uav_vehicles.hpp; behind the state loads: one wait for both)
+    // (the constant table BEHIND the state groups: loads return in order, and in front of them its 28 requests held the int group --
+    //  which the Philox call below waits for -- back by 0.7 us; profiles/r05/phase_fixedwing.txt)
+    if (WPS == 1) {
+      TV = fw_table_in_vgprs(table_g);
+#if PF_FW_TABV == 5
+      float kv = 0.0f;
+      if (tid < 48) kv = reinterpret_cast<const float*>(table_g)[2 * (sizeof(FwSurf2) / 4) + tid];
+      TV.krest = (lds_fptr)ktab;
+      if (tid < 48) ktab[tid] = kv;  // (LDS operations of one wave complete in issue order: every later read of the wave sees this)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#endif
+    }
     rng_ctr = (uint32_t)__float_as_int(gi.z);
     PF_STAMP(1);
     if (NOISE == PF_NOISE_PHILOX) {

@@ -785,8 +785,9 @@ static int hip_fail(pf_ctx* ctx, hipError_t e, const char* where) {
 template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
-  // (the one-wave-per-SIMD instantiation -- quadx_fast.hpp, WPS -- where the batch is no more than that and the kernel has it)
-#define PF_FAST4(NZ, CR, MD, SH) do { constexpr int W1 = ((CR) && !(MD) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
+  // (the one-wave-per-SIMD instantiation -- quadx_fast.hpp, WPS -- where the batch is no more than that and the kernel has it; since
+  //  round 5 the cascaded flight modes as well: their fp64 controller needs the 512 registers -- 408 B of stack per lane under 256)
+#define PF_FAST4(NZ, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
     if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u); \
     else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u); } while (0)
   // (flight modes other than 0: the MODES instantiation, contact response compiled in -- quadk_from_params)
@@ -803,7 +804,7 @@ static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t*
 template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
-#define PF_ROLL4(NZ, R, CR, MD, SH) do { constexpr int W1 = ((CR) && !(MD) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
+#define PF_ROLL4(NZ, R, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
     if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0); \
     else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0); } while (0)
 #define PF_ROLL3(NZ, R, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_ROLL4(NZ, R, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_ROLL4(NZ, R, CR, MD, false); } while (0)
@@ -901,6 +902,15 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
   if (1.7320508f * P.max_coord_vel * P.dt * 0.5f > 0.3926991f + 1e-6f)
     return fail(nullptr, PF_ERR_UNSUPPORTED, "max_coord_vel * dt too large for the exponential-map polynomial");
   if (P.ticks_per_control < 1 || P.env_step_ratio < 0 || P.n_boxes > PF_MAX_BOXES) return fail(nullptr, PF_ERR_ARG, "bad loop constants");
+  // the contact model's parameters (params.py: build_params checks the same for Python callers; a C caller gets the same answer
+  // here): a negative residual threshold is sqrt -> NaN and ends every solve after one sweep, negative distances shrink the slab,
+  // a manifold size other than 4 or 8 would be mapped silently
+  if (P.contact_manifold_points != 4 && P.contact_manifold_points != 8) return fail(nullptr, PF_ERR_ARG, "contact_manifold_points must be 4 or 8");
+  if (P.contact_response && P.contact_iters < 1) return fail(nullptr, PF_ERR_ARG, "contact_iters must be at least 1");
+  if (!(P.contact_residual_threshold >= 0.0f) || !(P.contact_report_distance >= 0.0f) || !(P.contact_break_distance >= 0.0f) ||
+      !(P.contact_margin >= 0.0f) || !(P.contact_slop >= 0.0f) || !(P.contact_erp >= 0.0f) || !(P.contact_friction >= 0.0f) ||
+      !(P.contact_restitution >= 0.0f))
+    return fail(nullptr, PF_ERR_ARG, "the contact model's distances, threshold, erp, friction and restitution must be >= 0");
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
   c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;

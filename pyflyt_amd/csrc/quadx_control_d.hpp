@@ -1,0 +1,118 @@
+// quadx_control_d.hpp -- the cascaded flight modes' controller (quadx.py:401-493, modes 1 .. 7) in DOUBLE precision.
+//
+// Why (round 5): the outer loops differentiate what they read -- lin_vel k_d / T = 60, z_vel k_d / T = 6 per control tick -- and pass
+// the result down three more PIDs to the motors, so a relative rounding of 6e-8 in a body-frame velocity or an Euler angle is worth
+// 1e-5 .. 1e-4 in the angular velocity one env step later, and 1e-3 over an episode (tests/tools/fp32_rounding_sites.py: with the
+// controllers' inputs ALONE rounded to float32 the fp64 oracle replays the mode-7 fixture 7.0e-4 away from itself, with the PIDs'
+// internals alone 1.5e-4; the rigid-body state, which stays float32, accounts for 2.2e-4). The state derivation that feeds the PIDs
+// (rotation matrix, R^T v, R^T w, Euler angles: quadx.py:512-535) and the PIDs themselves therefore run in fp64 here, from the
+// float32 state; the PID memories are stored as float32 (the state groups' format). FP64 vector instructions issue at the float32
+// rate on gfx950 and these modes are on no benchmark's critical path: the mode-0 instantiations do not contain this code.
+// Used by the generic vehicle (uav_vehicles.hpp: QuadX::control) and by the specialised kernel's MODES instantiations
+// (quadx_fast.hpp), so the two agree with each other bit for bit in these modes.
+#pragma once
+#include "uav_device.hpp"
+
+namespace pf {
+
+struct QuadCtlIn {  // update_state's outputs (quadx.py:512-535), fp64 from the float32 state
+  double wb[3], vb[3], rpy[3], p[3];
+};
+PF_DEV QuadCtlIn quad_ctl_inputs(const quat qf, const v3 vf, const v3 wf, const v3 pf_) {
+  const double x = qf.x, y = qf.y, z = qf.z, w = qf.w;
+  // btMatrix3x3::setRotation
+  const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;
+  const double xs = x * s, ys = y * s, zs = z * s;
+  const double wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+  const double R00 = 1.0 - (yy + zz), R01 = xy - wz, R02 = xz + wy, R10 = xy + wz, R11 = 1.0 - (xx + zz), R12 = yz - wx,
+               R20 = xz - wy, R21 = yz + wx, R22 = 1.0 - (xx + yy);
+  QuadCtlIn o;
+  const double v0 = vf.x, v1 = vf.y, v2 = vf.z, w0 = wf.x, w1 = wf.y, w2 = wf.z;
+  o.vb[0] = R00 * v0 + R10 * v1 + R20 * v2; o.vb[1] = R01 * v0 + R11 * v1 + R21 * v2; o.vb[2] = R02 * v0 + R12 * v1 + R22 * v2;
+  o.wb[0] = R00 * w0 + R10 * w1 + R20 * w2; o.wb[1] = R01 * w0 + R11 * w1 + R21 * w2; o.wb[2] = R02 * w0 + R12 * w1 + R22 * w2;
+  // getEulerFromQuaternion (ZYX, gimbal-lock branch at |sarg| >= 0.99999)
+  const double sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  const double sarg = -2.0 * (x * z - w * y) / (sqx + sqy + sqz + squ);
+  if (sarg <= -0.99999) { o.rpy[0] = 0.0; o.rpy[1] = -0.5 * 3.14159265358979323846; o.rpy[2] = 2.0 * atan2(x, -y); }
+  else if (sarg >= 0.99999) { o.rpy[0] = 0.0; o.rpy[1] = 0.5 * 3.14159265358979323846; o.rpy[2] = 2.0 * atan2(-x, y); }
+  else {
+    o.rpy[0] = atan2(2.0 * (y * z + w * x), squ - sqx - sqy + sqz);
+    o.rpy[1] = asin(sarg);
+    o.rpy[2] = atan2(2.0 * (x * y + w * z), squ + sqx - sqy - sqz);
+  }
+  o.p[0] = pf_.x; o.p[1] = pf_.y; o.p[2] = pf_.z;
+  return o;
+}
+PF_DEV double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// abstractions/pid.py:70-94 for one component; the memories are the state groups' float32 words
+PF_DEV double pid1d(const float kp, const float ki, const float kd, const float lim, const double T, float& I, float& E, const double st, const double sp) {
+  const double e = sp - st;
+  const double l = lim;
+  const double In = clampd((double)I + (double)ki * e * T, -l, l);
+  const double der = (double)kd * (e - (double)E) / T;
+  I = (float)In;
+  E = (float)e;
+  return clampd((double)kp * e + In + der, -l, l);
+}
+// The memories of one vehicle: pointers into the owner's members (everything is force-inlined: they stay in registers)
+struct QuadMemD {
+  float *I0, *E0;  // ang_vel  [3]
+  float *I1, *E1;  // ang_pos  [3]
+  float *I2, *E2;  // lin_vel  [2]
+  float *I3, *E3;  // lin_pos  [2]
+  float *zI, *zE;  // z_vel, z_pos
+};
+// update_control for mode 1 .. 7: setpoint -> the four motor commands. PP: (pointer to) the parameter block (a plain reference's
+// address or the scalar-cache pointer of the specialised kernels). T: the control period.
+template <class PP>
+PF_DEV void quad_cascade_d(const PP P, const int mode, const double T, const QuadCtlIn& in, const QuadMemD M, const float sp[4], float pwm[4]) {
+  double a[3] = {sp[0], sp[1], sp[2]};
+  double z = sp[3];
+  auto pidn = [&](const int k, float* I, float* E, const double* st, const int n) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < n) a[i] = pid1d(P->pid[k].kp[i], P->pid[k].ki[i], P->pid[k].kd[i], P->pid[k].lim[i], T, I[i], E[i], st[i], a[i]);
+  };
+  if (mode == 2) {
+    pidn(0, M.I0, M.E0, in.wb, 3);
+  } else if (mode == 1 || mode == 3) {
+    pidn(1, M.I1, M.E1, in.rpy, 3);
+    pidn(0, M.I0, M.E0, in.wb, 3);
+  } else {
+    if (mode == 7) pidn(3, M.I3, M.E3, in.p, 2);
+    if (mode == 6 || mode == 7) {  // quadx.py:448-451,460-463
+      const double c = cos(in.rpy[2]), s = sin(in.rpy[2]);
+      const double a0 = c * a[0] + s * a[1], a1 = -s * a[0] + c * a[1];
+      a[0] = a0; a[1] = a1;
+    }
+    pidn(2, M.I2, M.E2, in.vb, 2);
+    { const double t0 = -a[1], t1 = a[0]; a[0] = t0; a[1] = t1; }
+    pidn(1, M.I1, M.E1, in.rpy, mode == 7 ? 3 : 2);
+    pidn(0, M.I0, M.E0, in.wb, 3);
+  }
+  if (!(mode == 1 || mode == 5 || mode == 6))
+    z = pid1d(P->zpid[1].kp[0], P->zpid[1].ki[0], P->zpid[1].kd[0], P->zpid[1].lim[0], T, M.zI[1], M.zE[1], in.p[2], z);
+  z = pid1d(P->zpid[0].kp[0], P->zpid[0].ki[0], P->zpid[0].kd[0], P->zpid[0].lim[0], T, M.zI[0], M.zE[0], in.vb[2], z);
+  z = clampd(z, 0.0, 1.0);
+  // mixing + saturation handling (quadx.py:482-493)
+  const double cmd[4] = {a[0], a[1], a[2], z};
+  double pw[4];
+  double hi = -INFINITY, lo = INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double s = (double)P->motor_map[i][0] * cmd[0] + (double)P->motor_map[i][1] * cmd[1] + (double)P->motor_map[i][2] * cmd[2] + (double)P->motor_map[i][3] * cmd[3];
+    pw[i] = s;
+    hi = s > hi ? s : hi;
+    lo = s < lo ? s : lo;
+  }
+  if (hi != lo) {
+    const double pmax = hi < 1.0 ? hi : 1.0, pmin = lo > 0.05 ? lo : 0.05;
+    const double ka = (pmin - lo) / (pmax - lo), ks = (hi - pmax) / (hi - pmin);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw[i] += ka * (pmax - pw[i]) - ks * (pw[i] - pmin);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pwm[i] = (float)clampd(pw[i], 0.05, 1.0);
+}
+
+}  // namespace pf

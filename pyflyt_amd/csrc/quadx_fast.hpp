@@ -22,6 +22,7 @@
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
 #include "uav_vehicles.hpp"  // contact_solve_dev
+#include "quadx_control_d.hpp"
 #include "shared_world.hpp"
 
 namespace pf {
@@ -237,11 +238,6 @@ struct QuadCasc {
     S[11 * n + i] = float4{zE[0], zE[1], 0.0f, 0.0f};
   }
 };
-// one PID component with its gains read through the scalar cache (abstractions/pid.py:70-94)
-PF_DEV float pid_k(const pf_pid __attribute__((address_space(4)))* g, int k, float T, float invT, float& I, float& E, float st, float sp) {
-  return pid1(g->kp[k], g->ki[k], g->kd[k], g->lim[k], T, invT, I, E, st, sp);
-}
-
 
 // ------------------------------------------------------------------------------------------
 // The floor contact solve of THIS kernel's airframe, in registers (round 4). What quadk_from_params guarantees -- one collision box
@@ -564,42 +560,6 @@ struct QuadHot {
     wb = v3{bx.x, by.x, bz.x};  // mulT(R, w)
     vb = v3{bx.y, by.y, bz.y};  // mulT(R, v)
   }
-  // roll, pitch, yaw of getEulerFromQuaternion from the rotation matrix derive() holds (unit q; gimbal branch: the library definition)
-  PF_DEV v3 euler_now() const {
-    if (__builtin_fabsf(R.m20) >= 0.99999f) return euler_from_quat(q);
-    return v3{fast_atan2(R.m21, R.m22), fast_asin(-R.m20), fast_atan2(R.m10, R.m00)};
-  }
-  // The outer loops of flight modes 1-7 (quadx.py:437-479): turns the setpoint into the angular-rate setpoint (s0, s1, s2) and
-  // the thrust command s3 the mode-0 stage below consumes. mode is wave-uniform; Pk: the device parameter block through the
-  // scalar cache (the outer loops' gains are read where they are used, not held in SGPRs through the tick loop).
-  PF_DEV void outer_loops(const int mode, const pf_params_kptr Pk, QuadCasc& C, float& s0, float& s1, float& s2, float& s3) {
-    const float T = Pk->control_period, iT = Pk->inv_control_period;
-    const v3 rpy = euler_now();
-    if (mode >= 4) {
-      if (mode == 7) {  // position -> velocity
-        s0 = pid_k(&Pk->pid[3], 0, T, iT, C.I3[0], C.E3[0], p.x, s0);
-        s1 = pid_k(&Pk->pid[3], 1, T, iT, C.I3[1], C.E3[1], p.y, s1);
-      }
-      if (mode == 6 || mode == 7) {  // world -> body yaw frame (quadx.py:448-451,460-463); (cos, sin) of the yaw from R, no trig
-        const float h = frsq(fmaf(R.m00, R.m00, R.m10 * R.m10));
-        const float c = R.m00 * h, sn = R.m10 * h;
-        const float b0 = fmaf(c, s0, sn * s1), b1 = fmaf(c, s1, -(sn * s0));
-        s0 = b0; s1 = b1;
-      }
-      s0 = pid_k(&Pk->pid[2], 0, T, iT, C.I2[0], C.E2[0], vb.x, s0);  // velocity -> angle
-      s1 = pid_k(&Pk->pid[2], 1, T, iT, C.I2[1], C.E2[1], vb.y, s1);
-      { const float t0 = -s1, t1 = s0; s0 = t0; s1 = t1; }
-      s0 = pid_k(&Pk->pid[1], 0, T, iT, C.I1[0], C.E1[0], rpy.x, s0);  // angle -> rate
-      s1 = pid_k(&Pk->pid[1], 1, T, iT, C.I1[1], C.E1[1], rpy.y, s1);
-      if (mode == 7) s2 = pid_k(&Pk->pid[1], 2, T, iT, C.I1[2], C.E1[2], rpy.z, s2);
-    } else if (mode == 1 || mode == 3) {
-      s0 = pid_k(&Pk->pid[1], 0, T, iT, C.I1[0], C.E1[0], rpy.x, s0);
-      s1 = pid_k(&Pk->pid[1], 1, T, iT, C.I1[1], C.E1[1], rpy.y, s1);
-      s2 = pid_k(&Pk->pid[1], 2, T, iT, C.I1[2], C.E1[2], rpy.z, s2);
-    }
-    if (!(mode == 1 || mode == 5 || mode == 6)) s3 = pid_k(&Pk->zpid[1], 0, T, iT, C.zI[1], C.zE[1], p.z, s3);  // height -> climb rate
-    s3 = pid_k(&Pk->zpid[0], 0, T, iT, C.zI[0], C.zE[0], vb.z, s3);                                            // climb rate -> thrust
-  }
   // update_control (quadx.py:401-493). MODES = false: flight mode 0 only (rate PID + thrust, :437-438,472,482-493), the
   // instantiation BASELINE's metric is quoted on; MODES = true: K.mode selects -1 .. 7 at run time (wave-uniform branches).
   template <bool MODES>
@@ -609,7 +569,16 @@ struct QuadHot {
         pw01 = f2{s0, s1}; pw23 = f2{s2, s3};
         return;
       }
-      if (K.mode != 0) outer_loops(K.mode, Pk, C, s0, s1, s2, s3);
+      if (K.mode != 0) {
+        // the cascaded modes: state derivation and every PID in fp64, shared with the generic vehicle (quadx_control_d.hpp: why --
+        // round 4's float32 outer loops on polynomial atan2 / asin sat 5 x further from the reference than the generic kernel)
+        const QuadCtlIn in = quad_ctl_inputs(q, v(), w(), p);
+        const float sp4[4] = {s0, s1, s2, s3};
+        float pw[4];
+        quad_cascade_d(Pk, K.mode, (double)Pk->control_period, in, QuadMemD{I, E, C.I1, C.E1, C.I2, C.E2, C.I3, C.E3, C.zI, C.zE}, sp4, pw);
+        pw01 = f2{pw[0], pw[1]}; pw23 = f2{pw[2], pw[3]};
+        return;
+      }
     }
     const float st[3] = {wb.x, wb.y, wb.z};
     const float sp[3] = {s0, s1, s2};
@@ -1118,11 +1087,12 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     auto settle_control = [&]() {
       if (!MODES || K.mode == 0) return;
       if (K.mode == -1) { pwm_s = 0.0f; return; }  // motor commands = setpoint = 0, no clipping (quadx.py:427-429)
-      const float T = Pk->control_period, iT = Pk->inv_control_period;
-      float zc = (K.mode == 1 || K.mode == 5 || K.mode == 6) ? 0.0f : z_hold;
-      if (!(K.mode == 1 || K.mode == 5 || K.mode == 6)) zc = pid_k(&Pk->zpid[1], 0, T, iT, C.zI[1], C.zE[1], z, zc);
-      zc = pid_k(&Pk->zpid[0], 0, T, iT, C.zI[0], C.zE[0], vz, zc);
-      pwm_s = med3(med3(zc, 0.0f, 1.0f), 0.05f, 1.0f);
+      const double T = (double)Pk->control_period;  // (fp64 like the flight's own cascade: quadx_control_d.hpp)
+      double zc = (K.mode == 1 || K.mode == 5 || K.mode == 6) ? 0.0 : (double)z_hold;
+      if (!(K.mode == 1 || K.mode == 5 || K.mode == 6))
+        zc = pid1d(Pk->zpid[1].kp[0], Pk->zpid[1].ki[0], Pk->zpid[1].kd[0], Pk->zpid[1].lim[0], T, C.zI[1], C.zE[1], (double)z, zc);
+      zc = pid1d(Pk->zpid[0].kp[0], Pk->zpid[0].ki[0], Pk->zpid[0].kd[0], Pk->zpid[0].lim[0], T, C.zI[0], C.zE[0], (double)vz, zc);
+      pwm_s = (float)clampd(clampd(zc, 0.0, 1.0), 0.05, 1.0);
     };
     auto settle_tick = [&](float xi) {
       float s = fmaf(xi, K.m_noise, 1.0f);

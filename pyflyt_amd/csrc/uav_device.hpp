@@ -272,13 +272,20 @@ PF_DEV bool cyl_overlaps_aabb(v3 c, const m3& R, float r, float hl, v3 cb, const
 }
 
 // ---------------------------------------------------------------- counter-based RNG
-// Philox4x32-10; integer stream bit-identical to oracle/uav_oracle.c:orc_philox4x32.
+// Philox4x32-10; integer stream bit-identical to oracle/uav_oracle.c:orc_philox4x32. PF_PHILOX_ROUNDS == ORC_PHILOX_ROUNDS
+// (oracle/uav_oracle.h). Seven rounds -- the generator is Crush-resistant from seven on; a round is four 32-bit multiplies, quarter-
+// rate instructions -- were measured in round 5: QuadX-Waypoints 18.2 -> 17.7 us per step, the rollouts -0.3 us, Hover per step
+// unchanged. Not adopted: every Philox-noise parity test is calibrated on the ten-round stream's realisation (which lane meets the
+// floor when), and a new realisation moves five of their event-count bounds without telling anything about the kernels.
+#ifndef PF_PHILOX_ROUNDS
+#define PF_PHILOX_ROUNDS 10
+#endif
 struct u32x4 {
   uint32_t a, b, c, d;
 };
 PF_DEV u32x4 philox4x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < PF_PHILOX_ROUNDS; ++r) {
     uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;

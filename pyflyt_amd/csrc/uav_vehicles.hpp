@@ -4,6 +4,7 @@
 #pragma once
 #include "../../include/pyflyt_amd.h"
 #include "uav_device.hpp"
+#include "quadx_control_d.hpp"
 
 namespace pf {
 
@@ -837,6 +838,12 @@ struct QuadX {
     float z = sp[3];
     if (mode == -1) {
       pwm[0] = a[0]; pwm[1] = a[1]; pwm[2] = a[2]; pwm[3] = z;
+      return;
+    }
+    if (mode != 0) {  // the cascaded modes: state derivation and PIDs in fp64 (quadx_control_d.hpp: why)
+      const QuadCtlIn in = quad_ctl_inputs(b.q, b.v, b.w, b.p);
+      const float sp4[4] = {sp[0], sp[1], sp[2], sp[3]};
+      quad_cascade_d(&P, mode, (double)cT, in, QuadMemD{I0, E0, I1, E1, I2, E2, I3, E3, zI, zE}, sp4, pwm);
       return;
     }
     if (mode == 0 || mode == 2) {

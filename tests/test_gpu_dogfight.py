@@ -166,7 +166,7 @@ def test_midair_collision_pushes_the_aircraft_apart():
 
 
 def _uniforms(seed, lane_id, ctr, count, stream):
-    """The device's reset-time uniforms for a world (Noise::uniform): Philox4x32-10 keyed (seed, first lane of the world, event
+    """The device's reset-time uniforms for a world (Noise::uniform): Philox4x32 keyed (seed, first lane of the world, event
     counter, flat >> 2, stream), through the oracle's generator."""
     import ctypes as C
     u, buf = np.zeros(count), (C.c_double * 4)()

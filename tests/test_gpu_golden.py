@@ -84,13 +84,15 @@ ENVS = [
 ]
 
 
-# The position-controlled fixture: the outer loops differentiate fp32 velocities (lin_vel kd / T = 60 per control tick, z_vel
-# kd / T = 6; tests/tools/fp32_sensitivity.py), so the fp32 device sits further from the fp64 reference than 1e-4 from the first
-# manoeuvre on -- on both kernels alike. An fp32 build of the ORACLE itself (double -> float, nothing else) replays this fixture
-# 7.9e-4 away from the fp64 one: the reference's own arithmetic does not hold 1e-4 in single precision here, whatever the kernel.
-# Bounds per kernel = about 3 x the measured worst (printed by the test: 6.8e-3 specialised, whose polynomial atan2 / asin and
-# reciprocal approximations add to it; 1.4e-3 generic), and a LOWER bound as well, so that neither can drift unnoticed.
-ENV_RTOL = {("env_quadx_waypoints_mode7", "specialised"): 2e-2, ("env_quadx_waypoints_mode7", "generic"): 5e-3}
+# The position-controlled fixture: the outer loops differentiate velocities (lin_vel kd / T = 60 per control tick, z_vel kd / T = 6;
+# tests/tools/fp32_sensitivity.py), so a float32 device sits further from the fp64 reference than 1e-4 from the first manoeuvre on.
+# An fp32 build of the ORACLE itself (double -> float, nothing else) replays this fixture 7.9e-4 away from the fp64 one. Since
+# round 5 the cascade -- the state derivation that feeds the PIDs and the PIDs -- runs in fp64 on both kernels, from the float32
+# rigid-body state (pyflyt_amd/csrc/quadx_control_d.hpp); what is left is the state's own rounding (the fp64 oracle with ONLY the
+# state rounded to float32 after every tick: 2.2e-4, tests/tools/fp32_rounding_sites.py). Measured worst (printed by the test):
+# 1.7e-3 on the specialised kernel (round 4, float32 cascade on polynomial atan2 / asin: 6.8e-3). One bound for both kernels, and
+# a LOWER bound a factor of ten below, so that neither can drift unnoticed.
+ENV_RTOL = {("env_quadx_waypoints_mode7", "specialised"): 5e-3, ("env_quadx_waypoints_mode7", "generic"): 5e-3}
 
 
 @pytest.mark.parametrize("kernel", ["specialised", "generic"])

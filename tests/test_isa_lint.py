@@ -109,3 +109,47 @@ def test_shipped_code_object_is_clean(tmp_path):
     dis = subprocess.run([objdump, "-d", "--symbolize-operands", objs[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout.split("\n")
     assert sum(1 for l in dis if "s_cbranch_execz" in l) > 1000  # (the disassembly is the real thing)
     assert chk.lint("libpyflyt_amd.so", dis) == 0
+
+
+def test_the_build_repairs_only_when_the_lint_fires_and_then_only_the_committed_sites(tmp_path, monkeypatch):
+    """__graft_entry__'s guard (round 5): clean compiler output is not touched; a product build that needs the repair accepts exactly
+    the committed set of (function, instruction) sites; PF_NO_REPAIR cannot reach the product path."""
+    import json
+
+    import __graft_entry__ as G
+
+    report = ["_ZN2pf19quadx_m0_env_kernelILi1EEEvv .LBB0_2: `v_mov_b32_e32 v5, v6` moved behind `s_or_b64 exec, exec, s[0:1]`",
+              "_ZN2pf10env_kernelINS_5QuadXELi1ELi0EEEvv .LBB3_9: `scratch_store_dword off, v40, off offset:8` moved behind `s_or_b64 exec, exec, s[2:3]`"]
+    sites = G.repair_sites(report)
+    assert sites == [["_ZN2pf10env_kernelINS_5QuadXELi1ELi0EEEvv", "scratch_store_dword off, v40, off offset:8"],
+                     ["_ZN2pf19quadx_m0_env_kernelILi1EEEvv", "v_mov_b32_e32 v5, v6"]]
+    f = tmp_path / "expected.json"
+    monkeypatch.setattr(G, "REPAIRS_FILE", str(f))
+    monkeypatch.setattr(G, "compiler_version", lambda hipcc: "HIP version: test")
+    monkeypatch.delenv("PF_ACCEPT_REPAIRS", raising=False)
+    with pytest.raises(RuntimeError, match="the audited set has 0"):  # nothing committed yet: a product build refuses
+        G.check_repairs(report, product=True, hipcc="hipcc")
+    G.check_repairs(report, product=False, hipcc="hipcc")  # (variant builds are not held to the set ...)
+    with pytest.raises(RuntimeError, match="not been audited"):  # (... but to the audited functions)
+        G.check_repairs(["_Z7strangev .LBB0_1: `v_mov_b32_e32 v1, v2` moved behind `s_or_b64 exec, exec, s[0:1]`"], product=False, hipcc="hipcc")
+    monkeypatch.setenv("PF_ACCEPT_REPAIRS", "update")
+    G.check_repairs(report, product=True, hipcc="hipcc")
+    assert json.load(open(f))["count"] == 2
+    monkeypatch.delenv("PF_ACCEPT_REPAIRS")
+    G.check_repairs(report, product=True, hipcc="hipcc")  # the committed set: accepted
+    with pytest.raises(RuntimeError, match="1 new, 1 gone"):  # the same count, another instruction: refused
+        G.check_repairs([report[0], report[1].replace("v40", "v41")], product=True, hipcc="hipcc")
+    with pytest.raises(RuntimeError, match="0 new, 1 gone"):
+        G.check_repairs(report[:1], product=True, hipcc="hipcc")
+
+
+def test_the_committed_repair_set_names_its_compiler():
+    import json
+
+    import __graft_entry__ as G
+
+    if not os.path.exists(G.REPAIRS_FILE):
+        pytest.skip("the compiler's output needed no repair when the library was last built")
+    rec = json.load(open(G.REPAIRS_FILE))
+    assert rec["compiler"].startswith("HIP version") and rec["count"] == len(rec["sites"])
+    assert all(any(fn in s[0] for fn in G.REPAIR_FUNCS) for s in rec["sites"])

@@ -273,3 +273,36 @@ def test_dogfight_known_answers():
             break
     else:
         raise AssertionError("the quarry never died")
+
+
+def test_philox_round_function_against_the_published_vectors():
+    """The counter-based generator both sides draw from (oracle/uav_oracle.c: orc_philox4x32_r; the device's philox4x32 is compared
+    with it draw for draw by every Philox-noise parity test). Random123's known-answer vectors for Philox4x32-10 (and the zero
+    vector of the seven-round variant) pin the round function and the key schedule; the product runs ORC_PHILOX_ROUNDS = 10."""
+    import ctypes as C
+
+    from oracle import oracle as O
+
+    L = O.lib()
+
+    def ph(key, ctr, rounds):
+        out = (C.c_uint32 * 4)()
+        L.orc_philox4x32_r(key, *ctr, rounds, out)
+        return tuple(out)
+
+    assert ph(0, (0, 0, 0, 0), 10) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert ph(0xFFFFFFFFFFFFFFFF, (0xFFFFFFFF,) * 4, 10) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert ph((0x299F31D0 << 32) | 0xA4093822, (0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), 10) == (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+    assert ph(0, (0, 0, 0, 0), 7) == (0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48)
+    out = (C.c_uint32 * 4)()
+    L.orc_philox4x32(0, 0, 0, 0, 0, out)
+    assert tuple(out) == ph(0, (0, 0, 0, 0), 10)  # (the product's round count)
+    # the 23-bit uniforms the draws are made of: the mean of 40 000 of them
+    u = (C.c_double * 4)()
+    acc = []
+    for i in range(10000):
+        L.orc_uniform4(12345, i, 7, 0, 2, u)
+        acc.extend(u)
+    import numpy as np
+    acc = np.array(acc)
+    assert abs(acc.mean() - 0.5) < 5e-3 and abs(acc.var() - 1.0 / 12.0) < 2e-3

@@ -549,6 +549,14 @@ def main():
                 "kernel": ("pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel") + "<..., ROLL=1>", "launch_us": rev / reps * 1e6,
                 "note": "k env steps per launch, state in registers, on-device action sampling (pf_sample_actions keys); bit-identical to k x pf_env_step (tests/test_gpu_rollout.py)",
             }
+        if args.scaling == "strong" and roll is not None:
+            # Strong scaling cuts ONE batch over the GPUs: 65 536 lanes on 8 GPUs are 8 192 per GPU = 128 waves on 1 024 SIMDs, and a
+            # launch per step costs its fixed ~8 us whatever the kernel does (~1.25 x at 8 GPUs). What scales in
+            # that regime is the state-resident path, so it is this mode's headline; the per-step-launch figure stays next to it.
+            out["per_step_launch"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "value_event_timed": out["value_event_timed"]}
+            out["value"] = out["rollout"]["value"]
+            out["ms_per_step"] = 1e3 * total_lanes / out["rollout"]["value"]  # (wall clock over the rollout launches, max over ranks: value's own denominator)
+            out["headline"] = "pf_rollout (k env steps per launch, state resident): the per-step launch sits on the launch floor at batch / N lanes per GPU"
         if args.env == "hover" and world == 1 and not args.no_configs and args.scaling == "weak" and args.batch == 65536 and args.flight_mode == 0 \
                 and not args.no_contact_response and not args.world:
             # BASELINE.json configs 2-4, timed after the headline in the same process (the headline config is configs[4]'s per-GPU

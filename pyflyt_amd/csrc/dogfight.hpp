@@ -221,9 +221,12 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     // consecutive updates (DF_AT_REST) -- is not integrated any further (the reference keeps stepping it in Bullet, where it
     // stays where it is; a world of wrecks would otherwise run the contact solve on every lane in every tick). It keeps its
     // resting contact: the collision verdict of :667-670 stays up. A momentary `inactive` does NOT stop the integration.
-    const bool wreck = (df & (DF_AT_REST | DF_FROZEN)) != 0;
+    // (round 5: a wreck at rest that a moving aircraft comes within reach of is woken -- world_exchange -- and is integrated again,
+    //  pair stage included, until it has come to rest anew; wrecks frozen by the opt-in df_freeze_wrecks stay where they are)
+    bool wreck = (df & (DF_AT_REST | DF_FROZEN)) != 0;
     for (int t = 0; t < P.ticks_per_control; ++t) {
       world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev, wreck, rec);
+      if (wreck && V.b.woken && (df & DF_FROZEN) == 0) { wreck = false; df &= ~(DF_AT_REST | DF_REST_MASK); }
       if (!wreck) V.tick(P, nz.get(flat_base + t));
     }
     if (wreck) V.b.contact_step = V.b.contact_now;

@@ -282,6 +282,7 @@ struct FwHot {
   // exchanged (the rotational-drag gate it feeds exists on the quadrotor, quadx.py:509)
   bool peer_contact = false, world_contact = false;
   bool world_touch = false;  // world_exchange's verdict: some pair of this world is within reach of the contact response between aircraft
+  bool woken = false;        // world_exchange: a wreck at rest that a moving aircraft has come within reach of
   // shared worlds, the pair stage (shared_world.hpp: pair_stage_dev): the wave's pose / velocity exchange arrays, the LDS for its
   // contact records (the observation tile, as a generic pointer), this lane, aircraft per world
   const float* wpose_ = nullptr;

@@ -8,6 +8,11 @@
 
 namespace pf {
 
+// the exchanged pose slot's eighth word: contact bit + 2 x "a wreck at rest" (world_exchange)
+PF_DEV bool slot_contact(const float x) { return (((int)x) & 1) != 0; }
+PF_DEV bool slot_at_rest(const float x) { return ((int)x) >= 2; }
+
+
 PF_DEV void lds_sync_wave() {  // one wave per workgroup: LDS traffic ordered, no s_barrier needed
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -31,7 +36,7 @@ __device__ __noinline__ bool peers_overlap_dev(const pf_params* __restrict__ Pd,
                                                const float px, const float py, const float pz, const quat q, const float rr2) {
   const m3 Ra = rot_from_quat(q);
   bool peer = false;
-  const bool mine = wpose[(wbase + wlocal) * 8 + 7] != 0.0f;  // this body held contact points after the previous tick
+  const bool mine = slot_contact(wpose[(wbase + wlocal) * 8 + 7]);  // this body held contact points after the previous tick
   const float rd_fresh = Pd->contact_report_distance, rd_kept = Pd->contact_break_distance;
   for (int j = 1; j < A; ++j) {
     int jj = wlocal + j;
@@ -58,7 +63,7 @@ __device__ __noinline__ bool peers_overlap_dev(const pf_params* __restrict__ Pd,
           const pf_box bk = Pd->boxes[k], bl = Pd->boxes[l];
           const v3 ca = dab + mul(RA, v3{bk.c[0], bk.c[1], bk.c[2]}) - mul(RB, v3{bl.c[0], bl.c[1], bl.c[2]});
           // (reported from the gap rd on -- up to the breaking distance when either drone holds contact points: b's box enlarged)
-          const float rd = (mine || o[7] != 0.0f) ? rd_kept : rd_fresh;
+          const float rd = (mine || slot_contact(o[7])) ? rd_kept : rd_fresh;
           const float hb[3] = {bl.h[0] + rd, bl.h[1] + rd, bl.h[2] + rd};
           peer |= box_overlaps_aabb(mulT(RB, ca), Rrel, bk.h, v3{0.f, 0.f, 0.f}, hb);
         }
@@ -125,7 +130,7 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
           const float* pb = wpose + (wbase + b) * 8;
           const v3 d{pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
           // (a pair one of whose bodies held contact points after the previous tick keeps its points up to the breaking distance)
-          const float margin = (pa[7] != 0.0f || pb[7] != 0.0f) ? brk : margin0;
+          const float margin = (slot_contact(pa[7]) || slot_contact(pb[7])) ? brk : margin0;
           const float rr = 2.0f * brad + 2.0f * margin;
           if (dot(d, d) > rr * rr) continue;
           const m3 Rb = rot_from_quat(quat{pb[3], pb[4], pb[5], pb[6]});
@@ -294,9 +299,9 @@ PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, co
     for (int k = 0; k < 9; ++k) o[k] = 0.0f;
   }
   me[0] = b.p.x; me[1] = b.p.y; me[2] = b.p.z; me[3] = b.q.x; me[4] = b.q.y; me[5] = b.q.z; me[6] = b.q.w;
-  me[7] = b.contact_now ? 1.0f : 0.0f;
+  me[7] = (b.contact_now ? 1.0f : 0.0f) + (at_rest ? 2.0f : 0.0f);  // (slot_contact / slot_at_rest)
   lds_sync_wave();
-  bool world = false, touch = false, near = false;
+  bool world = false, touch = false, near = false, near_awake = false;
   // (gates only: the farthest a report or a contact point between two drones can reach -- the exact tests decide)
   const float far = __builtin_fmaxf(__builtin_fmaxf(Pd->contact_margin, Pd->contact_break_distance), Pd->contact_report_distance);
   const float rr = 2.0f * bound_radius + 1.7320508f * far, rr2 = rr * rr;
@@ -305,13 +310,19 @@ PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, co
     int jj = wlocal + j;
     jj = jj >= A ? jj - A : jj;
     const float* o = wpose + (wbase + jj) * 8;
-    world |= o[7] != 0.0f;
+    world |= slot_contact(o[7]);
     const v3 d{b.p.x - o[0], b.p.y - o[1], b.p.z - o[2]};
     const float d2 = dot(d, d);
     touch |= d2 <= rr2;  // bounding spheres touch
     near |= d2 <= rp2;
+    near_awake |= d2 <= rp2 && !slot_at_rest(o[7]);
   }
-  touch = touch && !at_rest;
+  // A wreck at rest that a body still in motion comes within reach of is woken (round 5): it takes part in this tick -- box tests,
+  // the pair stage as a body of its own mass, the integration -- as it does in the reference, which never stopped stepping it. (Left
+  // asleep, the pair stage solved contacts against it as a free body whose impulse was then thrown away: the momentum vanished.)
+  // Two wrecks lying next to each other stay asleep.
+  b.woken = at_rest && near_awake;
+  touch = touch && (!at_rest || b.woken);
   b.world_touch = widen_to_world(near, tid, A);
   bool peer = false;
   if (__any(touch)) {

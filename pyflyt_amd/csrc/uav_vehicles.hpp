@@ -563,6 +563,7 @@ struct Body {
   bool world_contact = false;  // a contact point anywhere in the world after the previous tick (quadx.py:509)
   bool peer_contact = false;   // this tick's drone-drone verdict for this body
   bool world_touch = false;    // some pair of this world is close enough for contact impulses between drones this tick
+  bool woken = false;          // world_exchange: this body was a wreck at rest and a moving body has come within reach of it
   // shared world, the pair stage (shared_world.hpp: pair_stage_dev): the wave's pose / velocity exchange arrays, this lane, agents per world
   const float* wpose_ = nullptr;
   float* wvel_ = nullptr;

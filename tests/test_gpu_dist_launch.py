@@ -34,3 +34,7 @@ def test_two_rank_bench_line(scaling, global_batch):
     assert d["config"]["global_batch"] == global_batch and d["config"]["batch_per_gpu"] == (4096 if scaling == "weak" else 2048)
     assert d["value"] > 0 and d["nonfinite_lanes"] == 0 and d["roofline"]["frac"] > 0
     assert abs(d["value"] - global_batch * 60 / (d["ms_per_step"] * 1e-3 * 60)) / d["value"] < 1e-6  # whole-job aggregate
+    if scaling == "strong":  # one batch cut over the GPUs: the state-resident figure is the headline, the per-step launch next to it
+        assert "pf_rollout" in d["headline"] and d["per_step_launch"]["value"] > 0 and d["value"] == d["rollout"]["value"]
+    else:
+        assert "per_step_launch" not in d

@@ -60,6 +60,7 @@ def test_fullsize_slices_match_oracle(env_id, name, n):
     for o, orc in zip(offs, orcs):
         assert relerr(og[o:o + w].cpu().numpy().astype(np.float64), orc.reset(), G).max() < RTOL
     worst = 0.0
+    worst_impact = 0.0
     for k in range(steps):
         a = env.sample_actions(k)
         obs, rew, term, trunc, _ = env.step(a)
@@ -70,12 +71,15 @@ def test_fullsize_slices_match_oracle(env_id, name, n):
             er = np.abs(rew[o:o + w].cpu().numpy() - rr) / np.maximum(1.0, np.abs(rr))
             # an observation within reach of the floor carries the contact solve's impulses: RTOL_IMPACT there (z is entry 12
             # of the attitude block; tests/test_gpu_golden.py, tests/tools/fp32_contact_sensitivity.py), 1e-4 everywhere else
-            tol = np.where(ro[:, 12] < 0.12, 5e-3, RTOL) if "fixedwing" not in name else RTOL
+            tol = np.where(ro[:, 12] < 0.12, 1e-3, RTOL) if "fixedwing" not in name else RTOL  # (measured within reach of the floor: 2e-7; the bound 5e-3 until round 5)
             ok[j] &= (term[o:o + w].cpu().numpy() == rt) & (trunc[o:o + w].cpu().numpy() == ru) & (e < tol) & (er < 1e-3)
-            if ok[j].any():
-                worst = max(worst, e[ok[j]].max())
+            low = (ro[:, 12] < 0.12) if "fixedwing" not in name else np.zeros(len(e), dtype=bool)
+            if (ok[j] & ~low).any():
+                worst = max(worst, e[ok[j] & ~low].max())
+            if (ok[j] & low).any():
+                worst_impact = max(worst_impact, e[ok[j] & low].max())
     bad = 1.0 - np.concatenate(ok).mean()
-    print(f"{name} n={n}: worst rel err {worst:.2e}, dropped {bad:.4f}")
+    print(f"{name} n={n}: worst rel err {worst:.2e}, dropped {bad:.4f}; worst observation within reach of the floor {worst_impact:.2e}")
     # strict for the quadrotor configurations: no lane may leave the comparison; the aeroplane may lose lanes to classified
     # discrete-event flips within one step (tests/test_gpu_parity.py), at most 0.5 %
     assert bad <= (0.005 if "fixedwing" in name else 0.0), bad

@@ -9,6 +9,7 @@ vector of the observation / state, reward 1e-3 relative, flags exact. Trajectori
 fp32 rounding by itself (cascaded QuadX modes through the z-velocity PID, kd/T = 6 per control tick:
 tests/tools/fp32_sensitivity.py) are asserted over the stated prefix at 1e-4 and over the full length at the
 stated looser bound -- the bound is per fixture and in the table below, not a blanket allowance."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -16,15 +17,20 @@ import pytest
 
 torch = pytest.importorskip("torch")
 
+from oracle import oracle as O  # noqa: E402  (the checker of the one-step tails)
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 RTOL = 1e-4
-# observations / states that carry a floor impact (the contact solver's impulses): see tests/test_gpu_parity.py and
-# tests/tools/fp32_contact_sensitivity.py -- an fp32 build of the oracle itself is this far from the fp64 one there
-RTOL_IMPACT = 5e-3
-# a 9.5 m rocket dropped at a tilt topples: the fp32 sensitivity of that transient (tests/tools/fp32_contact_sensitivity.py: an fp32
-# build of the ORACLE is up to 5e-1 away from the fp64 one there); measured 9.8e-3
-IMPACT_TOL = {"aviary_rocket_drop": 3e-2}
+# observations / states that carry a floor impact (the contact solver's impulses). An fp32 build of the oracle is 4e-4 (quad) away from
+# the fp64 one through such a transient (tests/tools/fp32_contact_sensitivity.py). Round 5 measured what these fixtures need, and the
+# bound follows the measurement (each test prints its worst): env fixtures 5.0e-6 (env_hover_crash), Aviary fixtures 1.6e-5 / 2.9e-5 /
+# 4.6e-6 (fixedwing / primitive drop, quadx land) -- 1e-3 (round 4: 5e-3) -- and the two that tumble, with a LOWER bound each
+# (a factor of ten below) so that the widening stays tied to what is measured:
+RTOL_IMPACT = 1e-3
+# a cf2x dropped at a tilt bounces on an edge before it settles: measured 7.9e-4; a 9.5 m rocket dropped at a tilt topples (an fp32 build
+# of the ORACLE is up to 5e-1 away from the fp64 one there): measured 9.8e-3
+IMPACT_TOL = {"aviary_rocket_drop": 3e-2, "aviary_quadx_drop": 2.5e-3}
 N = 70
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -115,6 +121,7 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
     resets = set(int(k) for k in g["reset_before"])
     ri = 0
     worst = 0.0
+    worst_impact = 0.0
 
     def do_reset():
         nonlocal ri, worst
@@ -138,6 +145,7 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
             # an observation that carries the floor's impulses: the step that reports the collision, and the one before it,
             # in which the speculative contact constraint already stops the fall (the body is within reach of the floor)
             assert e < RTOL_IMPACT, (name, k, e)
+            worst_impact = max(worst_impact, e)
         else:
             worst = max(worst, e)
             assert e < ENV_RTOL.get((name, kernel), RTOL), (name, k, e)
@@ -154,7 +162,7 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
     assert ri == len(g["reset_obs"])
     if (name, kernel) in ENV_RTOL:  # a widened bound stays tied to what is measured: within a factor of ten of it
         assert worst > ENV_RTOL[(name, kernel)] / 10.0, (name, kernel, worst)
-    print(f"{name} [{kernel}]: worst {worst:.2e} over {len(g['action'])} steps, {ri} resets, ended {seen}")
+    print(f"{name} [{kernel}]: worst {worst:.2e} over {len(g['action'])} steps, {ri} resets, ended {seen}; worst observation with a floor impact in it {worst_impact:.2e}")
 
 
 def test_ma_hover_fixture_replay():
@@ -221,8 +229,9 @@ AVIARY = {
     #  fast, tests/tools/fp32_sensitivity.py; measured first step beyond 1e-4 on MI355X: mode1 165, mode2 87, mode4 162,
     #  mode7 164, primitive mode6 118, mode7 109 -- the prefixes below sit under those, the full-length bounds over the
     #  measured worst: 6.2e-4, 1.5e-3, 2.1e-4, 1.8e-3, 1.2e-4; primitive mode 7 is chaotic after ~110 steps (4e-2 .. 2e-1
-    #  depending on the build's rounding), so its tail is only checked for finiteness; which step crosses 1e-4 moves
-    #  with any change of rounding)
+    #  depending on the build's rounding): its tail -- bound None -- is compared one Aviary step at a time from the oracle's state
+    #  instead, at 1e-4 (measured 1.8e-6); which step crosses 1e-4 moves with any change of rounding.
+    #  Round 5, cascade in fp64: first steps beyond 1e-4 now mode1 167, mode2 87, mode4 162, mode7 172, primitive mode6 118)
     # (modem1 / mode0 / primitive mode0 fly into the floor with the motors running and tumble on it at 30 rad/s: strict up to the
     #  step before the first reported contact -- 87, 186, 73 -- then the impact regime's fp32 sensitivity, 5e-2 of the vector norm)
     "aviary_quadx_modem1": (85, 5e-2), "aviary_quadx_mode0": (184, 5e-2), "aviary_quadx_mode1": (150, 2e-3), "aviary_quadx_mode2": (80, 2e-3),
@@ -236,7 +245,9 @@ AVIARY = {
     # landings with the motors off, first touch to rest: the contact response (vertex contacts, Gauss-Seidel sweeps,
     # friction, penetration recovery) in fp32 against the reference-on-fake-Bullet recording
     # (the primitive drone rocks on its prop discs and the rocket on its legs for seconds: an fp32 oracle is 4e-3 / 5e-1 away
-    #  from the fp64 one during that, tests/tools/fp32_contact_sensitivity.py, and both end in the same pose: prefix + loose tail)
+    #  from the fp64 one during that, tests/tools/fp32_contact_sensitivity.py, and both end in the same pose: prefix + loose tail for
+    #  the drone; the rocket's tail -- bound None -- one Aviary step at a time from the oracle's state: 1.2e-4, two of 418 steps with
+    #  contact points beyond 1e-4)
     "aviary_quadx_land": None, "aviary_primitive_land": (22, 5e-2), "aviary_rocket_land": (31, None),
     # drone_options=dict(control_hz=60): four ticks per Aviary step, controllers at T = 1/60 (gains tuned for 120 Hz: the loop swings
     # between the motor limits and amplifies round-off -- gen_goldens.py: gen_control_rate; prefix strict, then the swing's fp32 drift)
@@ -277,6 +288,35 @@ def state_err(eng, ref_state, ref_aux):
     return max(e, float(np.abs(aux - ref_aux).max()) / max(1.0, float(np.abs(ref_aux).max())))
 
 
+class _OneLane:
+    """the oracle's lane replicated over the device's N lanes, as pack_state() reads it (tests/test_gpu_onestep.py)"""
+
+    def __init__(self, lane):
+        self.n = N
+        self.lanes = (O.Lane * N)()
+        for i in range(N):
+            C.memmove(C.byref(self.lanes[i]), C.byref(lane), C.sizeof(O.Lane))
+
+
+def pack_state_rocket(ob, eng):
+    """the oracle's lanes -> the device's state groups, Rocket::load's layout (pyflyt_amd/csrc/rocket.hpp)"""
+    from pyflyt_amd import _lib as L
+    from test_gpu_onestep import lanes_view
+
+    f = lanes_view(ob)
+    g = np.zeros(tuple(eng.state.shape), dtype=np.float32)
+    g[0, :, :3] = f["p"]; g[0, :, 3] = f["fuel_ratio"]
+    g[1] = f["q"]
+    g[2, :, :3] = f["v"]; g[2, :, 3] = f["w"][:, 0]
+    g[3, :, 0:2] = f["w"][:, 1:3]; g[3, :, 2:4] = f["actuation"][:, 0:2]
+    g[4, :, 0:2] = f["actuation"][:, 2:4]; g[4, :, 2] = f["throttle"][:, 0]; g[4, :, 3] = f["ignition"]
+    g[5, :, 0:2] = f["gimbal"]
+    flags = f["contact_now"] * L.F_CONTACT
+    ints = np.stack([f["step_count"].astype(np.int64), flags.astype(np.int64), f["rng_ctr"].astype(np.int64), np.zeros(ob.n, dtype=np.int64)], axis=1).astype(np.uint32)
+    g[6] = ints.view(np.float32)
+    eng.state.copy_(torch.tensor(g, device=DEV))
+
+
 @pytest.mark.parametrize("name", sorted(AVIARY))
 def test_aviary_fixture_replay(name):
     g = load(name)
@@ -288,11 +328,53 @@ def test_aviary_fixture_replay(name):
     assert state_err(eng, g["init_state"], g["init_aux"] if "init_aux" in g.files else eng.out_aux[0].double().cpu().numpy()) < RTOL
     np.testing.assert_allclose(sp[0].cpu().numpy()[: len(g["init_setpoint"])], g["init_setpoint"], atol=1e-5)
     bound = AVIARY[name]
+    # A tail without a free-running bound (an fp32 trajectory that is chaotic there: primitive_drone mode 7 from step ~110 on, the
+    # rocket rocking on its legs) is compared ONE AVIARY STEP AT A TIME instead (tests/test_gpu_onestep.py): the fp64 oracle replays
+    # the fixture alongside (tests/test_oracle_golden.py holds it to the recording at 1e-10 / 1e-7); from the prefix's end on its
+    # lane state -- pose, twist, motor / actuator states, PID memories, contact bit -- is written into the device's state groups
+    # before every step, both take the step, and the device must agree with the oracle (and through it with the recording) at
+    # 1e-4; a step in which a clamp of the contact solve switches one sweep apart is counted and held to 2e-3, as in
+    # test_landing_one_step_parity.
+    onestep = bound is not None and bound[1] is None
+    orc_lane = orc_P = None
+    if onestep:
+        from test_gpu_onestep import pack_state
+        model = model_of(name)[1]
+        okw = dict(start_pos=g["start_pos"], start_rpy=g["start_orn"], noise_mode=O.NOISE_INJECT if bool(g["noise"]) else O.NOISE_OFF)
+        if vehicle == "rocket":
+            okw["starting_fuel_ratio"] = ROCKET_FUEL[name]
+        orc_P = O.make_params(model or vehicle, **okw)
+        orc_lane = O.Lane()
+        O.lib().orc_aviary_reset(C.byref(orc_P), C.byref(orc_lane), 0)
+        O.lib().orc_set_mode(C.byref(orc_P), C.byref(orc_lane), mode)
     worst, worst_k, first_bad = 0.0, -1, None
+    worst_touch, worst_tail, tail_switches, tail_contact = 0.0, 0.0, 0, 0
     for k in range(len(g["states"])):
         sp.copy_(torch.tensor(np.repeat(g["setpoints"][k][None], N, axis=0), dtype=torch.float32))
         xi = dev_cols(g["xi"][k]) if bool(g["noise"]) else None
+        if onestep:
+            for j in range(spn):
+                orc_lane.setpoint[j] = float(g["setpoints"][k][j])
+            if k >= bound[0]:
+                ob = _OneLane(orc_lane)
+                pack_state_rocket(ob, eng) if vehicle == "rocket" else pack_state(ob, eng, False)
         eng.aviary_step(sp, 1, xi=xi)
+        if onestep:
+            xs = np.ascontiguousarray(np.nan_to_num(np.asarray(g["xi"][k], dtype=np.float64))) if bool(g["noise"]) else None
+            O.lib().orc_aviary_step(C.byref(orc_P), C.byref(orc_lane), None if xs is None else xs.ctypes.data_as(C.POINTER(C.c_double)), 0, 0)
+            ref = np.array([list(orc_lane.w_b), list(orc_lane.rpy), list(orc_lane.v_b), list(orc_lane.p)])
+            assert state_err_of(ref, g["states"][k]) < 1e-6, (name, k, "the oracle has left the recording")
+        if onestep and k >= bound[0]:
+            aux = np.array(list(orc_lane.actuation)[:4] + [orc_lane.throttle[0]]) if vehicle == "rocket" else np.array(list(orc_lane.throttle)[:4])
+            e = state_err(eng, ref, g["aux"][k] if vehicle == "rocket" else aux)
+            touching = bool(orc_lane.contact_step)
+            tail_contact += int(touching)
+            if e >= RTOL:
+                assert touching and e < 2e-3, (name, k, e)  # free flight: 1e-4, no exception
+                tail_switches += 1
+            worst_tail = max(worst_tail, e)
+            assert (eng.out_contact.cpu().numpy() == touching).all(), (name, k)
+            continue
         e = state_err(eng, g["states"][k], g["aux"][k])
         if e > worst:
             worst, worst_k = e, k
@@ -303,13 +385,27 @@ def test_aviary_fixture_replay(name):
             # from one Aviary step before the first reported contact on, the trajectory carries the contact solver's impulses
             touched = bool(g["contact"][: k + 2].any())
             assert e < (IMPACT_TOL.get(name, RTOL_IMPACT) if touched else RTOL), (name, k, e)
+            if touched:
+                worst_touch = max(worst_touch, e)
         elif k < bound[0]:
             assert e < RTOL, (name, k, e)
-        elif bound[1] is not None:
+        else:
             assert e < bound[1], (name, k, e)
-        else:  # fp32-chaotic tail (primitive_drone mode 7: z_vel kd/T = 24): finite and inside the flight envelope only
-            assert np.isfinite(eng.out_state.cpu().numpy()).all() and float(eng.out_state[:, 9:].abs().max()) < 50.0
-    print(f"{name}: worst {worst:.2e} at step {worst_k} of {len(g['states'])}, first step beyond 1e-4: {first_bad}")
+    tail = "" if not onestep else (f"; steps {bound[0]} .. {len(g['states']) - 1} one at a time from the oracle's state: worst {worst_tail:.2e}, "
+                                   f"{tail_switches} of {tail_contact} steps with contact points beyond 1e-4")
+    print(f"{name}: worst {worst:.2e} at step {worst_k} of {len(g['states'])}, first step beyond 1e-4: {first_bad}; worst after the first contact {worst_touch:.2e}{tail}")
+    if onestep:
+        assert tail_switches <= max(1, int(0.02 * tail_contact)), (name, tail_switches, tail_contact)
+    if name in IMPACT_TOL:  # a widened bound stays tied to what is measured: within a factor of ten of it
+        assert worst_touch > IMPACT_TOL[name] / 10.0, (name, worst_touch)
+
+
+def state_err_of(got, ref):
+    """the same measure on two [4, 3] state blocks (oracle against recording)"""
+    e = 0.0
+    for r in range(4):
+        e = max(e, float(np.abs(got[r] - ref[r]).max()) / max(1.0, float(np.linalg.norm(ref[r]))))
+    return e
 
 
 def wind_from_coef(c):

@@ -30,11 +30,13 @@ from oracle import oracle as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
-# The terminal observation of an episode that ends ON THE FLOOR carries the impact impulse of the contact solver (10
-# Gauss-Seidel sweeps with clamps at zero normal impulse and at the friction cone): a float32 build of the ORACLE is up to
-# 4e-4 (quad) away from the fp64 one on that one observation and back to 4e-6 a few steps later
-# (tests/tools/fp32_contact_sensitivity.py) -- a property of the non-smooth model in fp32, not of the kernels.
-RTOL_IMPACT = 2e-3
+# The terminal observation of an episode that ends ON THE FLOOR carries the impact impulse of the contact solver (Gauss-Seidel
+# sweeps with clamps at zero normal impulse and at the friction cone): a float32 build of the ORACLE is up to 4e-4 (quad) away from
+# the fp64 one on that one observation and back to 4e-6 a few steps later (tests/tools/fp32_contact_sensitivity.py) -- a property
+# of the non-smooth model in fp32, not of the kernels. Round 5 measured what each test needs (every run prints its worst such
+# observation): 1.1e-5 ... 5.1e-5 under the action space's own draws -- the bound went from 2e-3 to 1e-3 --, and 1.1e-3 in the one
+# test that flies every episode into the floor under low thrust (test_floor_endings: its own bound, with a lower bound).
+RTOL_IMPACT = 1e-3
 
 
 def _engine(vehicle, task, n, **kw):
@@ -81,7 +83,8 @@ QUAD_LOW, QUAD_HIGH = np.array([-np.pi] * 3 + [0.0]), np.array([np.pi] * 3 + [0.
 FW_LOW, FW_HIGH = -np.ones(4), np.ones(4)
 
 
-def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, high, seed=0, gentle=None, max_bad=None, **over):
+def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, high, seed=0, gentle=None, max_bad=None, rtol_impact=None, **over):
+    RTOL_IMPACT = rtol_impact if rtol_impact is not None else globals()["RTOL_IMPACT"]
     if max_bad is None:
         max_bad = 0.0 if vehicle == "quadx" else 0.005
     eng = _engine(vehicle, task, n, noise=noise, autoreset=autoreset, seed=seed,
@@ -135,6 +138,7 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
     first_bad = np.full(n, -1)   # step of the first violation
     ev_g, ev_r = [], []          # per step: (episode ended, targets left) on each side -- the discrete events
     worst = 0.0
+    worst_impact = 0.0           # the largest error among the observations held to RTOL_IMPACT (printed: the bound stays tied to it)
     n_done = 0
     lane_steps = 0
     n_final = n_final_bad = 0
@@ -157,6 +161,8 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
         if autoreset == "same_step":
             impact = np.zeros(n, dtype=bool)  # (the lane was re-initialised inside the step; its terminal observation is checked through final_obs below)
         good = (tg == tr) & (trg == trr) & (e < np.where(impact, RTOL_IMPACT, RTOL)) & (er < 1e-3)
+        if (impact & ok & good).any():
+            worst_impact = max(worst_impact, float(e[impact & ok & good].max()))
         e = np.where(impact, 0.0, e)  # (held to RTOL_IMPACT above, not part of `worst`)
         # Both sides END the episode in this env step with identical flags, but at different INNER Aviary steps
         # (quadx_base_env.py:289-290 breaks out of the inner loop once terminated): fp32 rounding moved a dome / floor /
@@ -186,6 +192,8 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
                 hit = (eng.final_info[:, 0].cpu().numpy()[d] & PL.F_INFO_COLLISION) != 0  # floor impact: RTOL_IMPACT (see the top of the file)
                 n_final += int(d.sum())
                 n_final_bad += int((ef >= np.where(hit, RTOL_IMPACT, RTOL)).sum())
+                if (hit & (ef < RTOL_IMPACT)).any():
+                    worst_impact = max(worst_impact, float(ef[hit & (ef < RTOL_IMPACT)].max()))
         if autoreset == "off":
             # finished lanes are reset together on both sides
             done = (tr | trr | tg | trg)
@@ -209,11 +217,13 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
             unexplained.append((int(i), k0))
     print(f"{vehicle}/{task} noise={noise} autoreset={autoreset}: worst rel err {worst:.2e} over {lane_steps} lane-steps, "
           f"dropped lanes {frac_bad:.4f} ({int((~ok).sum())} of {n}; unclassified: {len(unexplained)}), "
-          f"terminal observations off by an inner step {n_term_mis} of {n_done} episodes ended")
+          f"terminal observations off by an inner step {n_term_mis} of {n_done} episodes ended; worst observation with a floor impact in it {worst_impact:.2e}")
     assert not unexplained, f"lanes left the comparison without a discrete-event flip: {unexplained[:8]}"
     assert frac_bad <= max_bad, frac_bad
     assert n_term_mis <= max(2, int(2e-3 * n_done)), (n_term_mis, n_done)
     assert n_final_bad <= max(1, int(max_bad * n_final)), (n_final_bad, n_final)
+    if rtol_impact is not None:  # a bound of its own stays tied to what is measured: within a factor of ten of it
+        assert worst_impact > rtol_impact / 10.0, (worst_impact, rtol_impact)
     return worst, n_done
 
 
@@ -258,7 +268,8 @@ def test_hover_floor_contact():
     def low(rng, n):
         return np.concatenate([rng.uniform(-0.5, 0.5, size=(n, 3)), rng.uniform(0.0, 0.25, size=(n, 1))], axis=1).astype(np.float32)
 
-    eng_done = run_env_parity("quadx", "hover", "hover", 256, 60, "philox", "next_step", QUAD_LOW, QUAD_HIGH, seed=9, gentle=low)
+    # (every episode ends on the floor, 768 of them, motors running: measured worst terminal observation 1.1e-3)
+    eng_done = run_env_parity("quadx", "hover", "hover", 256, 60, "philox", "next_step", QUAD_LOW, QUAD_HIGH, seed=9, gentle=low, rtol_impact=3e-3)
     assert eng_done[1] > 200
 
 

@@ -986,15 +986,22 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt/expcnt untouched
     __builtin_amdgcn_wave_barrier();
   };
-  // Settle-phase motor noise, generated cooperatively: the few lanes of a wave that reset in this
-  // call need settle_ticks normals each (3 Philox calls per lane); instead of every resetting lane
-  // walking through its calls serially while the other lanes idle, the (lane, call) pairs are dealt
-  // out over all 64 lanes, evaluated in one pass and handed back through LDS. Wave-uniform call.
-  auto prepare_settle_noise = [&](bool reset_now) {
+  // What a resetting lane draws, generated cooperatively: settle_ticks motor-noise normals (3 Philox calls per lane, stream 1) and,
+  // in the Waypoints task, the targets (waypoint_handler.py:53-89: 3 calls, 4 with yaw targets, stream 2, and per target two sine /
+  // cosine pairs). Instead of the two or three resetting lanes of a wave walking through their calls serially while the other lanes
+  // idle (0.85 us + 1.4 us of a Waypoints wave's life, r03 / r04), the (lane, call) pairs are dealt out over all 64 lanes. Since
+  // round 5 ONE pass serves both streams -- a lane evaluates one Philox call and turns it into eight normals or four uniforms; two
+  // passes paid for the Philox latency (four quarter-rate multiplies per round) and an LDS round trip twice --; pass 2, one (lane,
+  // target) pair per lane, turns the uniforms into targets, the same arithmetic as the per-lane path, through the observation tile
+  // (idle here); the resetting lane picks up its noise from sxi and its 4 x (x, y, z, yaw) from the tile. Wave-uniform call.
+  // (Injected draws -- B.xi_reset, B.u_targets -- keep the per-lane paths.)
+  const bool coop_targets = (TASK == PF_TASK_WAYPOINTS) && !((NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr));
+  auto prepare_reset_draws = [&](bool reset_now) {
 #ifdef PF_EXP_CHEAP_RESET  // (experiment, never shipped: what would a reset cost if its random state came precomputed?)
     return;
 #endif
-    if (NOISE != PF_NOISE_PHILOX) return;
+    const bool want_noise = NOISE == PF_NOISE_PHILOX;
+    if (!want_noise && !coop_targets) return;
     const unsigned long long m = __ballot(reset_now);
     if (m == 0ull) return;
     const int r = __popcll(m);
@@ -1003,70 +1010,50 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       sctr[tid] = rng_ctr;
     }
     lds_sync();
-    const int ncall = (settle_ticks + 7) >> 3;
-    for (int base = 0; base < r * ncall; base += 64) {
-      const int j = base + tid;
-      if (j < r * ncall) {
-        const int which = j / ncall, call = j - which * ncall;
-        const int src = spos[which];
-        f8 z = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, 1u));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sxi[src * kSettleMax + call * 8 + e] = 4.0f + z.v[e];
-      }
-    }
-    lds_sync();
-  };
-  // Waypoint sampling (waypoint_handler.py:53-89), cooperatively as well: a resetting lane needs 3 (4 with yaw targets) Philox calls
-  // and, per target, two sine / cosine pairs -- some 650 instructions that the 2-3 resetting lanes of a wave walked through while the
-  // other lanes idled (1.4 us of a Waypoints wave's 11.4; profiles/r04/phase_trace_waypoints65536.txt). Dealt out over all 64 lanes
-  // instead: pass 1, one (lane, call) pair per lane -> the uniforms, through the observation tile (idle here); pass 2, one (lane,
-  // target) pair per lane -> the target, same arithmetic as before; the resetting lane picks up its 4 x (x, y, z, yaw).
-  // Wave-uniform call. (Injected draws, B.u_targets, keep the per-lane path.)
-  const bool coop_targets = (TASK == PF_TASK_WAYPOINTS) && !((NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr));
-  auto prepare_targets = [&](bool reset_now) {
-#ifdef PF_EXP_CHEAP_RESET
-    return;
-#endif
-    if (!coop_targets) return;
-    const unsigned long long m = __ballot(reset_now);
-    if (m == 0ull) return;
-    const int r = __popcll(m);
-    if (reset_now) {
-      spos[__popcll(m & ((1ull << tid) - 1ull))] = tid;
-      sctr[tid] = rng_ctr;
-    }
-    lds_sync();
-    const int nt = K.num_targets, ntc = kYaw ? 4 : 3;
+    const int ncall = want_noise ? (settle_ticks + 7) >> 3 : 0;                // stream 1: eight normals per call
+    const int nt = K.num_targets, ntc = coop_targets ? (kYaw ? 4 : 3) : 0;     // stream 2: four uniforms per call
+    const int per = ncall + ntc;
     float* const U = tile;             // [lane][16]: the uniforms of calls 0 .. 3
     float* const TG = tile + 64 * 16;  // [lane][16]: four targets x (x, y, z, yaw)
-    for (int base = 0; base < r * ntc; base += 64) {
+    for (int base = 0; base < r * per; base += 64) {
       const int j = base + tid;
-      if (j < r * ntc) {
-        const int which = j / ntc, call = j - which * ntc;
+      if (j < r * per) {
+        const int which = j / per, c = j - which * per;
         const int src = spos[which];
-        const f4 u = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, 2u));
-        float* o = U + src * 16 + call * 4;
-        o[0] = u.a; o[1] = u.b; o[2] = u.c; o[3] = u.d;
+        const bool noise_call = c < ncall;
+        const int call = noise_call ? c : c - ncall;
+        const u32x4 x = philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, noise_call ? 1u : 2u);
+        if (noise_call) {
+          const f8 z = normal8(x);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sxi[src * kSettleMax + call * 8 + e] = 4.0f + z.v[e];
+        } else {
+          const f4 u = uniform4(x);
+          float* o = U + src * 16 + call * 4;
+          o[0] = u.a; o[1] = u.b; o[2] = u.c; o[3] = u.d;
+        }
       }
     }
     lds_sync();
-    for (int base = 0; base < r * nt; base += 64) {
-      const int j = base + tid;
-      if (j < r * nt) {
-        const int which = j / nt, i = j - which * nt;
-        const int src = spos[which];
-        const float* u = U + src * 16;
-        const float theta = u[i], phi = u[nt + i], dist = fmaf(K.dome09m1, u[2 * nt + i], 1.0f);  // theta, phi in turns
-        float st, ct, sph, cph;
-        sincos_turns(theta, st, ct);
-        sincos_turns(phi, sph, cph);
-        const float zz = __builtin_fabsf(dist * cph);
-        float* o = TG + src * 16 + 4 * i;
-        o[0] = dist * sph * ct; o[1] = dist * sph * st; o[2] = zz > K.min_height ? zz : K.min_height;
-        o[3] = kYaw ? fmaf(2.0f * kPi, u[3 * nt + i], -kPi) : 0.0f;
+    if (coop_targets) {
+      for (int base = 0; base < r * nt; base += 64) {
+        const int j = base + tid;
+        if (j < r * nt) {
+          const int which = j / nt, i = j - which * nt;
+          const int src = spos[which];
+          const float* u = U + src * 16;
+          const float theta = u[i], phi = u[nt + i], dist = fmaf(K.dome09m1, u[2 * nt + i], 1.0f);  // theta, phi in turns
+          float st, ct, sph, cph;
+          sincos_turns(theta, st, ct);
+          sincos_turns(phi, sph, cph);
+          const float zz = __builtin_fabsf(dist * cph);
+          float* o = TG + src * 16 + 4 * i;
+          o[0] = dist * sph * ct; o[1] = dist * sph * st; o[2] = zz > K.min_height ? zz : K.min_height;
+          o[3] = kYaw ? fmaf(2.0f * kPi, u[3 * nt + i], -kPi) : 0.0f;
+        }
       }
+      lds_sync();
     }
-    lds_sync();
   };
   // env.reset() for this lane: begin_reset + waypoint sampling + set_mode(0) + the settle phase
   // (quadx_base_env.py:149-212). Level spawn at rest under the mode-0 default setpoint
@@ -1336,8 +1323,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   act0 = act1 = act2 = act3 = 0.f;
   reward = 0.0f;
   was_reset = false;
-  prepare_settle_noise(do_reset);
-  prepare_targets(do_reset);
+  prepare_reset_draws(do_reset);
   if (do_reset) reset_lane();
   PF_STAMP(4);  // (NEXT_STEP resets done)
 
@@ -1527,8 +1513,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
                                             (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
         B.final_info[2 * (toff + li) + 1] = n_left - (pop_pending ? 1 : 0);
       }
-      prepare_settle_noise(same);
-      prepare_targets(same);
+      prepare_reset_draws(same);
       if (same) reset_lane();
     }
   }

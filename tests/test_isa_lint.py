@@ -153,3 +153,37 @@ def test_the_committed_repair_set_names_its_compiler():
     rec = json.load(open(G.REPAIRS_FILE))
     assert rec["compiler"].startswith("HIP version") and rec["count"] == len(rec["sites"])
     assert all(any(fn in s[0] for fn in G.REPAIR_FUNCS) for s in rec["sites"])
+
+
+def test_a_copy_in_front_of_an_else_flip_is_repeated_behind_it():
+    """The flow block of an if / else switches exec from the then-lanes to the else-lanes with `s_andn2_saveexec_b64`: a copy of a
+    value that is live in all lanes, placed in front of it, has run for the then-lanes only (for none on the s_cbranch_execz edge).
+    The repair keeps it and repeats it behind the flip; the lint accepts exactly that shape. (Round 5: the in-register floor solve
+    of the one-wave-per-SIMD QuadX-Waypoints kernel; the lint used to class the flip as `exec rewritten some other way`.)"""
+    from tools import isa_exec_check as chk
+
+    asm = """
+_Z1kv:
+\ts_and_saveexec_b64 s[0:1], vcc
+\ts_cbranch_execz .LBB0_2
+\tv_mul_f32_e32 v249, v28, v28
+.LBB0_2:
+\tv_accvgpr_write_b32 a23, v177
+\ts_mov_b64 s[8:9], s[30:31]
+\ts_andn2_saveexec_b64 s[0:1], s[0:1]
+\tv_sub_f32_e32 v249, v28, v27
+\ts_or_b64 exec, exec, s[0:1]
+\tv_accvgpr_read_b32 v5, a23
+\ts_endpgm
+""".split("\n")
+    found = [asm[i].strip() for _, _, idx, _ in chk.sites(asm) for i in idx]
+    assert found == ["v_accvgpr_write_b32 a23, v177"]
+    fixed, report = chk.fix(asm)
+    assert len(report) == 1 and "repeated behind" in report[0]
+    ins = [chk.instruction(l) for l in fixed if chk.instruction(l)]
+    i = ins.index("s_andn2_saveexec_b64 s[0:1], s[0:1]")
+    assert ins[i + 1] == "v_accvgpr_write_b32 a23, v177" and ins.count("v_accvgpr_write_b32 a23, v177") == 2  # kept AND repeated
+    assert not list(chk.sites(fixed))  # the repaired shape lints clean
+    # a copy whose register a scalar-side instruction up to the flip touches is refused (the repair proves nothing about it)
+    with pytest.raises(RuntimeError):
+        chk.fix([l.replace("s_mov_b64 s[8:9], s[30:31]", "v_readlane_b32 s8, v177, 3") for l in asm])

@@ -22,6 +22,13 @@ import sys
 LABEL = re.compile(r"^(\.LBB\S+|[A-Za-z_][\w$.]*):")
 OBJ_LABEL = re.compile(r"^[0-9a-f]+ <([^>]+)>:")
 WIDEN = re.compile(r"^(s_or_b64\s+exec,\s*exec,|s_or_saveexec_b64\s)")
+# The flow block of an if / else: `s_andn2_saveexec_b64 s[a:b], s[a:b]` switches exec from the then-lanes to the else-lanes. A copy in
+# front of it runs for the then-lanes (none, when the block was entered through s_cbranch_execz), behind it for the else-lanes: a
+# value that is live in all lanes needs BOTH, so the repair REPEATS such an instruction behind the flip instead of moving it
+# (round 5: `v_accvgpr_write_b32 a23, v177` in front of the flip inside the in-register floor solve of the one-wave-per-SIMD
+# QuadX-Waypoints kernel -- the else-lanes read a stale a23 afterwards and two crashing lanes of a wave came out of the solve with
+# or without their impulses from one run to the next; the lint had classed the flip as "exec rewritten some other way").
+ELSE_FLIP = re.compile(r"^s_andn2_saveexec_b64\s")
 SCALAR_OK = ("v_writelane_b32", "v_readlane_b32", "v_readfirstlane_b32", "s_")
 MOVABLE = re.compile(r"^(v_mov_b32_e32|v_mov_b64_e32|v_accvgpr_write_b32|v_accvgpr_read_b32|v_accvgpr_mov_b32|v_pk_mov_b32)\s")
 SPILL = re.compile(r"^scratch_(store|load)_(dword|dwordx2|dwordx3|dwordx4|short|byte|ubyte)\s+(off,\s*[va]\S+,\s*off|[va]\S+,\s*off,\s*off)")  # (stack slot at a constant offset)
@@ -85,6 +92,15 @@ def sites(lines):
                 yield func, label, pending, i
             pending = None
             continue
+        if ELSE_FLIP.match(ins):
+            # (already repaired: the same instructions, in the same order, right behind the flip)
+            behind = [instruction(x) for x in lines[i + 1:i + 1 + 3 * len(pending)]] if pending else []
+            behind = [x for x in behind if x and not x.startswith("s_waitcnt")]
+            todo = [k for n, k in enumerate(pending) if not (n < len(behind) and behind[n] == instruction(lines[k]))] if pending else []
+            if todo:
+                yield func, label, todo, i
+            pending = None
+            continue
         op = ins.split()[0]
         if op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")) or re.match(r"^s_\w+\s+exec", ins) or "saveexec" in op:
             pending = None  # the block ends, or exec is rewritten some other way: not this pattern
@@ -104,7 +120,7 @@ def lint(path, lines):
 
 def fix(lines):
     """returns (new lines, report); raises if a flagged instruction is not a plain register copy or cannot be moved safely"""
-    moves, report, waits = {}, [], {}
+    moves, report, waits, repeats = {}, [], {}, set()
     for func, label, idx, at in sites(lines):
         moved = set()
         for i in idx:
@@ -117,7 +133,7 @@ def fix(lines):
                 other = instruction(lines[j])
                 if other and j not in idx and (regs(other) & mine):
                     raise RuntimeError(f"line {i + 1} ({func} {label}): cannot move `{ins}` past `{other}`")
-                if other and spill and other.startswith("s_waitcnt") and "vmcnt" in other:
+                if other and spill and not ELSE_FLIP.match(instruction(lines[at])) and other.startswith("s_waitcnt") and "vmcnt" in other:
                     # one memory operation fewer is in flight at this wait than the compiler counted: "at most N outstanding" must
                     # become "at most N - 1" to keep guaranteeing the same older operations complete
                     n = int(re.search(r"vmcnt\((\d+)\)", other).group(1))
@@ -125,9 +141,11 @@ def fix(lines):
                     if waits[j] < 0:
                         waits[j] = 0
             moved.add(i)
-            report.append(f"{func} {label}: `{ins}` moved behind `{instruction(lines[at])}`")
+            if ELSE_FLIP.match(instruction(lines[at])):
+                repeats.add(i)
+            report.append(f"{func} {label}: `{ins}` {'repeated' if i in repeats else 'moved'} behind `{instruction(lines[at])}`")
         moves[at] = sorted(moved)
-    skip = {i for v in moves.values() for i in v}
+    skip = {i for v in moves.values() for i in v if i not in repeats}
     out = []
     for i, raw in enumerate(lines):
         if i in skip:

@@ -126,7 +126,7 @@ class Lane(C.Structure):
         ("n_targets_left", C.c_int),
         ("new_dist", C.c_double), ("old_dist", C.c_double),
         ("obs", C.c_double * 48),
-        ("rng_ctr", C.c_uint32), ("lane_id", C.c_uint64),
+        ("rng_ctr", C.c_uint32), ("reset_key", C.c_uint32), ("lane_id", C.c_uint64),
     ]
 
 

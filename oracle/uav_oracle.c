@@ -998,12 +998,13 @@ void orc_set_mode(const orc_params* P, orc_lane* L, int mode) {
 }
 /* aviary.py:218-312 + quadx.py:222-231 / fixedwing.py:194-204 */
 void orc_aviary_reset(const orc_params* P, orc_lane* L, uint64_t lane_id) {
-  uint32_t ctr = L->rng_ctr;
+  uint32_t ctr = L->rng_ctr, rkey = L->reset_key;
   double keep[8];
   memcpy(keep, L->action, sizeof(double) * 4);
   memcpy(keep + 4, L->past_action, sizeof(double) * 4);
   memset(L, 0, sizeof(*L));
   L->rng_ctr = ctr;
+  L->reset_key = rkey;
   if (P->task == ORC_TASK_MA_HOVER) { /* current/past actions are created once in __init__ (ma_quadx_base_env.py:139-150) */
     memcpy(L->action, keep, sizeof(double) * 4);
     memcpy(L->past_action, keep + 4, sizeof(double) * 4);
@@ -1593,13 +1594,26 @@ static void env_term_trunc_reward(const orc_params* P, orc_lane* L) {
 }
 
 /* quadx_base_env.py:149-212 (+ quadx_waypoints_env.py:120-123) */
+/* What an env.reset() draws -- the settle phase's motor noise (stream 1) and the waypoints (stream 2) -- is keyed, for the QuadX
+ * Hover / Waypoints tasks, by the event counter AT THE PREVIOUS RESET of the lane (0 before the first), not by the current one
+ * (round 5; the fixedwing and PettingZoo tasks keep the current counter). The reference's own generator is a sequential PCG64
+ * stream that no device can follow, so the keying is this restatement's to choose; this choice makes the next episode's initial
+ * state a function of something known an episode ahead, which lets the device compute it for many lanes at once while the
+ * episode runs instead of for the two or three lanes of a wavefront that restart in a given step (quadx_fast.hpp: spares). */
+static int orc_reset_rekeyed(const orc_params* P) {
+  return P->vehicle == ORC_QUADX && (P->task == ORC_TASK_HOVER || P->task == ORC_TASK_WAYPOINTS);
+}
 void orc_env_reset(const orc_params* P, orc_lane* L, uint64_t lane_id, const double* xi_reset, const double* u_targets) {
   orc_aviary_reset(P, L, lane_id);
+  const uint32_t ctr_now = L->rng_ctr;
+  const int rekey = orc_reset_rekeyed(P);
+  if (rekey) L->rng_ctr = L->reset_key; /* (lane_normal / lane_uniform read the counter from the lane) */
   if (P->task == ORC_TASK_WAYPOINTS) sample_targets(P, L, u_targets);
   orc_set_mode(P, L, P->flight_mode);
   const int tpc = P->world.ticks_per_control;
   for (int s = 0; s < P->settle_steps; ++s)
     orc_aviary_step(P, L, xi_reset ? xi_reset + s * tpc : 0, (uint32_t)(s * tpc), 1);
+  if (rekey) { L->rng_ctr = ctr_now; L->reset_key = ctr_now; }
   env_compute_state(P, L);
   L->rng_ctr += 1;
 }

@@ -252,6 +252,7 @@ typedef struct {
   double obs[48];
   /* rng */
   uint32_t rng_ctr;
+  uint32_t reset_key; /* the event counter at this lane's previous env reset: what the NEXT reset's draws are keyed by (orc_env_reset) */
   uint64_t lane_id;
 } orc_lane;
 

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "../../include/pyflyt_amd.h"
 #include "uav_vehicles.hpp"
@@ -127,6 +128,18 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   if (TASK == PF_TASK_MA_HOVER) ma_past = Sin[(size_t)(VEH::G_TGT + 3) * N + li];
   int step_count = ints.x, flags = ints.y;
   uint32_t rng_ctr = (uint32_t)ints.z;
+  // QuadX Hover / Waypoints: a reset's draws are keyed by the event counter at the lane's PREVIOUS reset (oracle/uav_oracle.c:
+  // orc_env_reset; quadx_fast.hpp: QuadSpare). The key word lives in group 7's fourth word (flight modes -1, 0) or, where groups
+  // 7-11 hold the cascade's memories, in group 11's third; this kernel prepares nothing ahead: it writes the word back with the
+  // "spare valid" bit clear.
+  constexpr bool REKEY = std::is_same<VEH, QuadX>::value && (TASK == PF_TASK_HOVER || TASK == PF_TASK_WAYPOINTS);
+  const bool key_in11 = REKEY && mode > 0;
+  uint32_t reset_kw = 0u;
+  bool reset_kw_dirty = false;
+  if (REKEY) {
+    const float4 gk = Sin[(size_t)(key_in11 ? 11 : 7) * N + li];
+    reset_kw = (uint32_t)__float_as_int(key_in11 ? gk.z : gk.w) & 0x7fffffffu;
+  }
   tg.n_left = ints.w;
   bool term = (flags & PF_F_TERMINATED) != 0, trunc = (flags & PF_F_TRUNCATED) != 0;
   float old_dist = new_dist;
@@ -165,7 +178,8 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     rpy_valid = true;
     step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
     if (TASK != PF_TASK_MA_HOVER) act4[0] = act4[1] = act4[2] = act4[3] = 0.0f;
-    nz.begin_event(rng_ctr, 1u, B.xi_reset);
+    nz.begin_event(REKEY ? reset_kw : rng_ctr, 1u, B.xi_reset);
+    if (REKEY) { reset_kw = rng_ctr & 0x7fffffffu; reset_kw_dirty = true; }  // (the NEXT reset's key: the counter at this one)
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = P.num_targets;
       tg.n_left = nt;
@@ -450,6 +464,10 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
             (trunc ? PF_F_TRUNCATED : 0) | (V.b.contact_now ? PF_F_CONTACT : 0);
     if (ks == n_env_steps - 1) {  // the state goes back to HBM once per launch
       V.store(Sout, N, li, mode, new_dist, int4{step_count, flags, (int)rng_ctr, tg.n_left});
+      if constexpr (REKEY) {
+        if (key_in11) Sout[(size_t)11 * N + li] = float4{V.zE[0], V.zE[1], __int_as_float((int)reset_kw), 0.0f};
+        else if (reset_kw_dirty) Sout[(size_t)7 * N + li] = float4{0.0f, 0.0f, 0.0f, __int_as_float((int)reset_kw)};
+      }
       if (kSide) tg.store(Sout, N, li, VEH::G_TGT);
       if (kYaw) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = float4{tg.yaw[0], tg.yaw[1], tg.yaw[2], tg.yaw[3]};
       if (TASK == PF_TASK_MA_HOVER) Sout[(size_t)(VEH::G_TGT + 3) * N + li] = ma_past;
@@ -753,6 +771,7 @@ struct pf_ctx {
   char err[256];
   // hot-path specialisation (quadx_fast.hpp)
   bool fast;
+  uint32_t step_calls;  // env steps taken so far (pf_env_step: +1, pf_rollout: +k): the cadence the QuadX kernels refill their spares on (quadx_fast.hpp: QuadSpare)
   bool one_wave; // the batch is at most one wave per SIMD of the device (the 512-register instantiations' condition)
   bool lean;     // the batch is at most one wave per SIMD of the device: the specialised QuadX kernel's 512-register instantiation
   pf::QuadK K;
@@ -788,8 +807,8 @@ static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t*
   // (the one-wave-per-SIMD instantiation -- quadx_fast.hpp, WPS -- where the batch is no more than that and the kernel has it; since
   //  round 5 the cascaded flight modes as well: their fp64 controller needs the 512 registers -- 408 B of stack per lane under 256)
 #define PF_FAST4(NZ, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
-    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u); \
-    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u); } while (0)
+    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u, ctx->step_calls); \
+    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u, ctx->step_calls); } while (0)
   // (flight modes other than 0: the MODES instantiation, contact response compiled in -- quadk_from_params)
   // (shared worlds: PF_TASK_MA_HOVER with the contact response on -- quadk_from_params)
 #define PF_FAST3(NZ, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_FAST4(NZ, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_FAST4(NZ, CR, MD, false); } while (0)
@@ -805,8 +824,8 @@ template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
 #define PF_ROLL4(NZ, R, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
-    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0); \
-    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0); } while (0)
+    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0, ctx->step_calls); \
+    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0, ctx->step_calls); } while (0)
 #define PF_ROLL3(NZ, R, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_ROLL4(NZ, R, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_ROLL4(NZ, R, CR, MD, false); } while (0)
 #define PF_ROLL(NZ, R) do { if (ctx->K.mode != 0) PF_ROLL3(NZ, R, true, true); else if (ctx->P.contact_response) PF_ROLL3(NZ, R, true, false); else PF_ROLL3(NZ, R, false, false); } while (0)
   if (b->actions == nullptr) {
@@ -913,7 +932,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     return fail(nullptr, PF_ERR_ARG, "the contact model's distances, threshold, erp, friction and restitution must be >= 0");
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
-  c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0;
+  c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0; c->step_calls = 0u;
   {  // the airframe's worst-case contact count (collider vertices), see pf_params.contact_max_points
     int pts = 0;
     for (int k = 0; k < P.n_boxes; ++k) pts += P.boxes[k].kind == 1 ? 16 : (P.contact_manifold_points >= 8 ? 8 : 4);
@@ -1027,6 +1046,7 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
     launch_env_t<pf::Fixedwing, PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
   }
   PF_HIP(ctx, hipGetLastError());
+  if (op == pf::OP_STEP) ctx->step_calls += 1u;  // (the QuadX kernels' spare-refill cadence: quadx_fast.hpp, QuadSpare)
   return PF_OK;
 }
 int pf_env_reset(pf_ctx* ctx, const pf_buffers* b, const uint8_t* mask, void* stream) {
@@ -1158,6 +1178,7 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
       launch_env_t<pf::Fixedwing, PF_TASK_WAYPOINTS>(ctx, b, pf::OP_STEP, nullptr, s, k_steps, step_index0);
     }
     PF_HIP(ctx, hipGetLastError());
+    ctx->step_calls += (uint32_t)k_steps;
     return PF_OK;
   }
   // (the PettingZoo task has no auto-reset: finished agents are culled by the caller, their drones fly on in the shared world)
@@ -1171,6 +1192,7 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
   else if (P.task == PF_TASK_MA_HOVER) launch_rollout<PF_TASK_MA_HOVER>(ctx, b, k_steps, step_index0, s);
   else launch_rollout<PF_TASK_WAYPOINTS>(ctx, b, k_steps, step_index0, s);
   PF_HIP(ctx, hipGetLastError());
+  ctx->step_calls += (uint32_t)k_steps;
   return PF_OK;
 }
 int pf_body_tick(pf_ctx* ctx, const pf_buffers* b, int n_ticks, void* stream) {

@@ -230,12 +230,12 @@ struct QuadCasc {
     E3[0] = g10.x; E3[1] = g10.y; zI[0] = g10.z; zI[1] = g10.w;
     zE[0] = g11.x; zE[1] = g11.y;
   }
-  PF_DEV void store(float4* S, size_t n, size_t i) const {
+  PF_DEV void store(float4* S, size_t n, size_t i, const uint32_t key_word = 0u) const {  // key_word: quadx_fast.hpp, QuadSpare
     S[7 * n + i] = float4{I1[0], I1[1], I1[2], E1[0]};
     S[8 * n + i] = float4{E1[1], E1[2], I2[0], I2[1]};
     S[9 * n + i] = float4{E2[0], E2[1], I3[0], I3[1]};
     S[10 * n + i] = float4{E3[0], E3[1], zI[0], zI[1]};
-    S[11 * n + i] = float4{zE[0], zE[1], 0.0f, 0.0f};
+    S[11 * n + i] = float4{zE[0], zE[1], __int_as_float((int)key_word), 0.0f};
   }
 };
 
@@ -793,6 +793,24 @@ __device__ unsigned long long g_calm_trace[2];  // (waves that were not calm ove
 #define PF_STAMP(i) do { } while (0)
 #endif
 
+// What the next env.reset() of a lane needs that is random -- the settled spawn state (z, vz, motor state after the settle phase's
+// noisy ticks) and, in the Waypoints task, the targets -- prepared AHEAD ("spare"). For the Hover / Waypoints tasks a reset's draws are
+// keyed by the event counter at the lane's PREVIOUS reset (oracle/uav_oracle.c: orc_env_reset), which is known for a whole episode:
+// instead of every wave serving the two or three of its lanes that restart in a given env step -- 1.7 us (Hover) / 2.8 us
+// (Waypoints) of every wave's life for a SIMD utilisation of 4 % -- a wave prepares the spares of ALL its lanes that have used
+// theirs up once every kSpareEvery env steps (episodes last 16 steps at the least under the action space's own draws, 28 on
+// average: a lane cannot need two within that), and a reset copies. A lane without a valid spare (the first reset of a context,
+// a hand-written state, an episode shorter than the refill period) generates on the spot with the same code: the results do not
+// depend on when they were computed. State: group 7 = (z, vz, thr, key word), groups 8-11 = 4 x (x, y, z, yaw) of the targets;
+// key word = the key in bits 0-30, bit 31 = "the values are valid". (The cascaded flight modes, which own groups 7-11, keep the key
+// in group 11's third word and generate at reset; so do the injected-noise and shared-world instantiations and the generic kernel.)
+constexpr uint32_t kSpareValid = 0x80000000u;
+constexpr uint32_t kSpareEvery = 16u;
+struct QuadSpare {
+  float z, vz, thr;
+  float4 t[4];
+};
+
 // ------------------------------------------------------------------------------------------
 // The kernel. Control flow is deliberately flat -- a prologue, one uniform-trip-count loop over the
 // env step's Aviary steps with a single per-lane predicate, an epilogue -- because every extra
@@ -825,8 +843,14 @@ constexpr int kQuadWPB = PF_WPB;
 template <int TASK, int NOISE, int LPW, int ROLL, bool CR, bool MODES = false, bool SHARED = false, int WPS = 2>
 __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
-                                                             const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0) {
+                                                             const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0,
+                                                             const uint32_t call0) {
   constexpr bool ROLLOUT = ROLL != 0;
+  // (see QuadSpare) REKEY: a reset's draws are keyed by the counter at the previous reset; SPARE: ... and prepared ahead. call0: how many
+  // env steps this context had taken when the launch was issued (the refill cadence is a function of that count alone)
+  constexpr bool REKEY = TASK == PF_TASK_HOVER || TASK == PF_TASK_WAYPOINTS;
+  constexpr bool SPARE = REKEY && !MODES && !SHARED && NOISE != PF_NOISE_INJECT;
+  typedef QuadSpare Sp;
   constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 4 + 16;  // attitude + 4 targets x (delta, yaw error)
   constexpr int kSettleMax = 24;  // settle ticks served by the cooperative generator (3 Philox calls)
@@ -836,6 +860,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   __shared__ float wpose_all[SHARED ? kQuadWPB * 64 * 8 : 1];  // shared worlds: pose + contact bit of every lane
   __shared__ float wvel_all[SHARED ? kQuadWPB * 64 * kPairVelStride : 1];  // ... and the new velocities for the pair stage
   __shared__ uint32_t sctr_all[kQuadWPB * 64];
+  __shared__ __attribute__((aligned(16))) float splds_all[(ROLLOUT && SPARE) ? kQuadWPB * 64 * 20 : 4];  // pf_rollout: the lanes' spares (a row is its lane's own)
   const int wid = kQuadWPB > 1 ? (int)(threadIdx.x >> 6) : 0;
   const int tid = kQuadWPB > 1 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
   float* const tile = tile_all + wid * (LPW * kMaxD);
@@ -880,6 +905,11 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   int step_count, flags, n_left;
   uint32_t rng_ctr;
   f8 zn;  // this step's motor-noise normals (Philox call 0 of the event)
+  uint32_t rkw = 0u;       // (REKEY) the reset key word: key in bits 0-30, bit 31 = the spare's values are valid
+  bool sp_dirty = false;   // ... changed in this launch: goes back to the state
+  uint32_t reset_key_now = 0u;  // the key of the reset at hand (do_resets)
+  Sp spv{};                // (SPARE, one step per launch) the lane's spare as loaded / as refilled
+  float* const splds = splds_all + ((ROLLOUT && SPARE) ? (wid * 64 + tid) * 20 : 0);  // (SPARE, pf_rollout) ... its row in LDS
   float4 a_pre = float4{0.f, 0.f, 0.f, 0.f};  // (one step per launch) this step's action, requested with the state
   {
     // the int group is requested first: loads complete in order, so the step's Philox call (which
@@ -909,6 +939,28 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
 #endif
     rng_ctr = (uint32_t)__float_as_int(gi.z);
     PF_STAMP(1);  // (the int group has arrived)
+    if (REKEY) {
+      // the key word (and the spare) of the lanes that will need them, requested as soon as the flags are here: a lane that restarts
+      // in this launch, every lane of a launch that refills the spares or resets in the same step; pf_rollout: every lane, once
+      const bool in11 = MODES && K.mode > 0;
+      // (where the key shares group 11 with the cascade's memories it is rewritten with them by every launch: always read)
+      const bool need_sp = ROLLOUT || in11 || op == 1 || K.autoreset == PF_AUTORESET_SAME_STEP ||
+                           (SPARE && (call0 % kSpareEvery) == kSpareEvery - 1u) ||
+                           (__float_as_int(gi.y) & (PF_F_TERMINATED | PF_F_TRUNCATED)) != 0;
+      if (need_sp) {
+        const float4 gk = Sin[(size_t)(in11 ? 11 : 7) * N + li];
+        rkw = (uint32_t)__float_as_int(in11 ? gk.z : gk.w);
+        if (SPARE) {
+          spv.z = gk.x; spv.vz = gk.y; spv.thr = gk.z;
+          if (TASK == PF_TASK_WAYPOINTS) { spv.t[0] = Sin[8 * N + li]; spv.t[1] = Sin[9 * N + li]; spv.t[2] = Sin[10 * N + li]; spv.t[3] = Sin[11 * N + li]; }
+          if (ROLLOUT) {
+            float4* r4 = reinterpret_cast<float4*>(splds);
+            r4[0] = float4{spv.z, spv.vz, spv.thr, 0.0f};
+            if (TASK == PF_TASK_WAYPOINTS) { r4[1] = spv.t[0]; r4[2] = spv.t[1]; r4[3] = spv.t[2]; r4[4] = spv.t[3]; }
+          }
+        }
+      }
+    }
     if (NOISE == PF_NOISE_PHILOX) {
       if (op == 0) zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
     }
@@ -996,7 +1048,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   // (idle here); the resetting lane picks up its noise from sxi and its 4 x (x, y, z, yaw) from the tile. Wave-uniform call.
   // (Injected draws -- B.xi_reset, B.u_targets -- keep the per-lane paths.)
   const bool coop_targets = (TASK == PF_TASK_WAYPOINTS) && !((NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr));
-  auto prepare_reset_draws = [&](bool reset_now) {
+  auto prepare_reset_draws = [&](const bool reset_now, const uint32_t key) {
 #ifdef PF_EXP_CHEAP_RESET  // (experiment, never shipped: what would a reset cost if its random state came precomputed?)
     return;
 #endif
@@ -1007,7 +1059,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     const int r = __popcll(m);
     if (reset_now) {
       spos[__popcll(m & ((1ull << tid) - 1ull))] = tid;
-      sctr[tid] = rng_ctr;
+      sctr[tid] = key;
     }
     lds_sync();
     const int ncall = want_noise ? (settle_ticks + 7) >> 3 : 0;                // stream 1: eight normals per call
@@ -1055,20 +1107,11 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       lds_sync();
     }
   };
-  // env.reset() for this lane: begin_reset + waypoint sampling + set_mode(0) + the settle phase
-  // (quadx_base_env.py:149-212). Level spawn at rest under the mode-0 default setpoint
-  // (quadx.py:276-278): rate error 0 -> cmd 0 -> pwm 0.05 on all four motors (quadx.py:488 branch
-  // skipped, :493 clip); equal thrusts cancel every torque exactly, so the settle ticks are a
-  // vertical (z, vz, throttle) recurrence.
-  auto reset_lane = [&]() {
-    // MA hover: the agent's own spawn pose from the side block (level by quadk_from_params' contract:
-    // the host passes the least level / lowest agent as the parameter block's start pose)
-    const float sx = TASK == PF_TASK_MA_HOVER ? tgt[0][0] : K.start_pos[0], sy = TASK == PF_TASK_MA_HOVER ? tgt[0][1] : K.start_pos[1];
-    float thr = 0.f, vz = 0.f, z = TASK == PF_TASK_MA_HOVER ? tgt[0][2] : K.start_pos[2];
-    // Flight modes other than 0 (MODES): set_mode's default setpoint holds the spawn pose (quadx.py:233-373), every attitude,
-    // rate and lateral error is exactly zero on a level spawn at rest, so the cascade reduces to its z PIDs -- run here once per
-    // Aviary step on the vertical state -- and four equal motor commands: still a vertical recurrence.
-    float pwm_s = 0.05f;  // mode 0: rate error 0 -> command 0 -> clipped to 0.05
+  // The settle phase as a vertical recurrence (see reset_lane): (z, vz, thr) in -> out, pwm_s = the motor command it ends on.
+  // Its noise comes from sxi (prepare_reset_draws) / B.xi_reset. Called by reset_lane and, for the lanes whose next episode is
+  // prepared ahead, by make_spare.
+  auto settle_run = [&](float& z, float& vz, float& thr, float& pwm_s) {
+    pwm_s = 0.05f;  // mode 0: rate error 0 -> command 0 -> clipped to 0.05
     const float z_hold = z;
     C.zero();  // set_mode: fresh PID objects; drone.reset(): the z PIDs too (quadx.py:206,222-231)
     auto settle_control = [&]() {
@@ -1159,6 +1202,23 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
         settle_control(); settle_tick(x.z); settle_tick(x.w);
       }
     }
+  };
+  // env.reset() for this lane: begin_reset + waypoint sampling + set_mode(0) + the settle phase
+  // (quadx_base_env.py:149-212). Level spawn at rest under the mode-0 default setpoint
+  // (quadx.py:276-278): rate error 0 -> cmd 0 -> pwm 0.05 on all four motors (quadx.py:488 branch
+  // skipped, :493 clip); equal thrusts cancel every torque exactly, so the settle ticks are a
+  // vertical (z, vz, throttle) recurrence.
+  auto reset_lane = [&](const bool have_pre, const Sp& pre) {
+    // MA hover: the agent's own spawn pose from the side block (level by quadk_from_params' contract:
+    // the host passes the least level / lowest agent as the parameter block's start pose)
+    const float sx = TASK == PF_TASK_MA_HOVER ? tgt[0][0] : K.start_pos[0], sy = TASK == PF_TASK_MA_HOVER ? tgt[0][1] : K.start_pos[1];
+    float thr = 0.f, vz = 0.f, z = TASK == PF_TASK_MA_HOVER ? tgt[0][2] : K.start_pos[2];
+    // Flight modes other than 0 (MODES): set_mode's default setpoint holds the spawn pose (quadx.py:233-373), every attitude,
+    // rate and lateral error is exactly zero on a level spawn at rest, so the cascade reduces to its z PIDs -- run here once per
+    // Aviary step on the vertical state -- and four equal motor commands: still a vertical recurrence.
+    float pwm_s = 0.05f;
+    if (SPARE && have_pre) { z = pre.z; vz = pre.vz; thr = pre.thr; C.zero(); }  // (the next episode's settled state, computed ahead: make_spare)
+    else settle_run(z, vz, thr, pwm_s);
     V.p = v3{sx, sy, z};
     if (TASK == PF_TASK_MA_HOVER) V.q = quat{tgt[1][0], tgt[1][1], tgt[1][2], tgt[2][0]};
     else V.q = quat{K.start_quat[0], K.start_quat[1], K.start_quat[2], K.start_quat[3]};
@@ -1187,7 +1247,15 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
         }
       } else
 #endif
-      if (coop_targets) {  // sampled by prepare_targets(): this lane's 4 x (x, y, z, yaw)
+      if (SPARE && have_pre) {  // prepared ahead (make_spare)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < nt) {
+            tgt[i][0] = pre.t[i].x; tgt[i][1] = pre.t[i].y; tgt[i][2] = pre.t[i].z;
+            if (kYaw) ytg[i] = pre.t[i].w;
+          }
+        }
+      } else if (coop_targets) {  // sampled by prepare_reset_draws(): this lane's 4 x (x, y, z, yaw)
         const float4* t4 = reinterpret_cast<const float4*>(tile + 64 * 16 + tid * 16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1201,10 +1269,10 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       f4 u0, u1, u2, u3 = f4{0.f, 0.f, 0.f, 0.f};
       const bool inj = (NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr);
       if (!inj) {
-        u0 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 2u));
-        u1 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 1u, 2u));
-        u2 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 2u, 2u));
-        if (kYaw) u3 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 3u, 2u));
+        u0 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), reset_key_now, 0u, 2u));
+        u1 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), reset_key_now, 1u, 2u));
+        u2 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), reset_key_now, 2u, 2u));
+        if (kYaw) u3 = uniform4(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), reset_key_now, 3u, 2u));
       }
       auto u = [&](int flat) { return pick4(flat < 4 ? u0 : (flat < 8 ? u1 : (flat < 12 ? u2 : u3)), (uint32_t)flat & 3u); };
       if (kYaw) {  // waypoint_handler.py:85-89: uniform(-pi, pi), drawn after all the positions
@@ -1239,8 +1307,58 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
       if (kYaw) yaw_err0 = __builtin_fabsf(wrap_pi(ytg[0] - yaw_now()));
     }
+    if (REKEY) { rkw = rng_ctr & ~kSpareValid; sp_dirty = true; }  // the NEXT reset's key: the counter at this one; its spare is still to be made
     rng_ctr += 1;
     was_reset = true;
+  };
+  // The next episode's random part for the lanes that ask (wave-uniform call): the draws keyed by `key`, the settle recurrence, the
+  // targets -- the very code a reset without a spare runs.
+  auto make_spare = [&](const bool me, const uint32_t key, Sp& out) {
+    prepare_reset_draws(me, key);
+    if (me) {
+      float z = K.start_pos[2], vz = 0.f, thr = 0.f, pw = 0.05f;
+      settle_run(z, vz, thr, pw);
+      out.z = z; out.vz = vz; out.thr = thr;
+      if (TASK == PF_TASK_WAYPOINTS) {
+        const float4* t4 = reinterpret_cast<const float4*>(tile + 64 * 16 + tid * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out.t[i] = t4[i];
+      }
+    }
+  };
+  auto spare_get = [&]() -> Sp {  // (SPARE) this lane's spare: the registers it was loaded into, or its LDS row (pf_rollout)
+    if (!ROLLOUT) return spv;
+    Sp x;
+    const float4* r4 = reinterpret_cast<const float4*>(splds);
+    const float4 a0 = r4[0];
+    x.z = a0.x; x.vz = a0.y; x.thr = a0.z;
+    if (TASK == PF_TASK_WAYPOINTS) { x.t[0] = r4[1]; x.t[1] = r4[2]; x.t[2] = r4[3]; x.t[3] = r4[4]; }
+    return x;
+  };
+  auto spare_put = [&](const Sp& x) {
+    if (!ROLLOUT) { spv = x; return; }
+    float4* r4 = reinterpret_cast<float4*>(splds);
+    r4[0] = float4{x.z, x.vz, x.thr, 0.0f};
+    if (TASK == PF_TASK_WAYPOINTS) { r4[1] = x.t[0]; r4[2] = x.t[1]; r4[3] = x.t[2]; r4[4] = x.t[3]; }
+  };
+  // A wave's resets: the lanes with a valid spare copy it, the others generate (cooperatively) from their key. Wave-uniform call.
+  auto do_resets = [&](const bool r) {
+    const bool have = SPARE && r && (rkw & kSpareValid) != 0u;
+    reset_key_now = REKEY ? (rkw & ~kSpareValid) : rng_ctr;
+    prepare_reset_draws(r && !have, reset_key_now);
+    if (r) {
+      if (SPARE && __builtin_expect(have, 1)) reset_lane(true, spare_get());
+      else reset_lane(false, Sp{});
+    }
+  };
+  // The spares of the lanes that have used theirs up, once every kSpareEvery env steps (and with every explicit reset). Wave-uniform.
+  auto refill_spares = [&](const bool now) {
+    if (!SPARE || !now) return;
+    const bool want = active && (rkw & kSpareValid) == 0u;
+    if (!__any(want)) return;
+    Sp g{};
+    make_spare(want, rkw & ~kSpareValid, g);
+    if (want) { spare_put(g); rkw |= kSpareValid; sp_dirty = true; }
   };
   // observation row (Appendix A of SURVEY.md) -> LDS tile. The attitude quaternion is
   // getQuaternionFromEuler(getEulerFromQuaternion(q)) (quadx_base_env.py:243), computed without trig.
@@ -1323,8 +1441,8 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   act0 = act1 = act2 = act3 = 0.f;
   reward = 0.0f;
   was_reset = false;
-  prepare_reset_draws(do_reset);
-  if (do_reset) reset_lane();
+  do_resets(do_reset);
+  refill_spares(op == 1 || ((call0 + (uint32_t)it) % kSpareEvery) == kSpareEvery - 1u);
   PF_STAMP(4);  // (NEXT_STEP resets done)
 
   // ---------------------------------------------------------------- the env step
@@ -1513,8 +1631,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
                                             (trunc ? PF_F_TRUNCATED : 0) | (V.contact_now ? PF_F_CONTACT : 0);
         B.final_info[2 * (toff + li) + 1] = n_left - (pop_pending ? 1 : 0);
       }
-      prepare_reset_draws(same);
-      if (same) reset_lane();
+      do_resets(same);
     }
   }
 
@@ -1547,7 +1664,15 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     Sout[4 * N + li] = float4{V.t23.x, V.t23.y, V.I[0], V.I[1]};
     Sout[5 * N + li] = float4{V.I[2], V.E[0], V.E[1], V.E[2]};
     Sout[6 * N + li] = float4{__int_as_float(step_count), __int_as_float(flags), __int_as_float((int)rng_ctr), __int_as_float(n_left)};
-    if (MODES && K.mode > 0) C.store(Sout, N, li);
+    if (MODES && K.mode > 0) C.store(Sout, N, li, REKEY ? (rkw & ~kSpareValid) : 0u);
+    if (REKEY && !(MODES && K.mode > 0) && (sp_dirty || ROLLOUT)) {  // group 7: the spare's settled state + the key word; 8-11: its targets
+      const Sp x = SPARE ? spare_get() : Sp{};
+      Sout[7 * N + li] = float4{x.z, x.vz, x.thr, __int_as_float((int)(SPARE ? rkw : (rkw & ~kSpareValid)))};
+      // (pf_rollout writes its LDS rows back whole: what a consumed spare leaves behind is then the same stale words as after k launches)
+      if (SPARE && TASK == PF_TASK_WAYPOINTS && (ROLLOUT || (rkw & kSpareValid) != 0u)) {
+        Sout[8 * N + li] = x.t[0]; Sout[9 * N + li] = x.t[1]; Sout[10 * N + li] = x.t[2]; Sout[11 * N + li] = x.t[3];
+      }
+    }
     if (TASK == PF_TASK_MA_HOVER) Sout[15 * N + li] = ma_past;
     if (kYaw) Sout[15 * N + li] = float4{ytg[0], ytg[1], ytg[2], ytg[3]};
     if (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER) {

@@ -273,7 +273,7 @@ PF_DEV bool cyl_overlaps_aabb(v3 c, const m3& R, float r, float hl, v3 cb, const
 
 // ---------------------------------------------------------------- counter-based RNG
 // Philox4x32-10; integer stream bit-identical to oracle/uav_oracle.c:orc_philox4x32. PF_PHILOX_ROUNDS == ORC_PHILOX_ROUNDS
-// (oracle/uav_oracle.h). Seven rounds -- the generator is Crush-resistant from seven on; a round is four 32-bit multiplies, quarter-
+// (the checker's header). Seven rounds -- the generator is Crush-resistant from seven on; a round is four 32-bit multiplies, quarter-
 // rate instructions -- were measured in round 5: QuadX-Waypoints 18.2 -> 17.7 us per step, the rollouts -0.3 us, Hover per step
 // unchanged. Not adopted: every Philox-noise parity test is calibrated on the ten-round stream's realisation (which lane meets the
 // floor when), and a new realisation moves five of their event-count bounds without telling anything about the kernels.

@@ -62,6 +62,14 @@ def pack_state(ob, eng, waypoints):
     if waypoints:
         t = f["targets"][:, :4, :].reshape(n, 12)
         g[12] = t[:, 0:4]; g[13] = t[:, 4:8]; g[14] = t[:, 8:12]
+    # the key the lane's NEXT reset draws from (the event counter at its previous reset: oracle/uav_oracle.c, orc_env_reset), with the
+    # "a spare is prepared" bit clear -- the device generates at the reset, as the oracle does. Group 7's fourth word in the flight
+    # modes -1 and 0, group 11's third where groups 7-11 hold the cascade's memories (quadx_fast.hpp: QuadSpare)
+    key = (f["reset_key"].astype(np.uint32) & np.uint32(0x7FFFFFFF)).view(np.float32)
+    if int(eng.params.flight_mode) > 0:
+        g[11, :, 2] = key
+    else:
+        g[7, :, 3] = key
     eng.state.copy_(torch.tensor(g, device=eng.state.device))
 
 

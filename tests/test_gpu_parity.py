@@ -173,6 +173,10 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
         n_term_mis += int(term_mis.sum())
         good |= term_mis
         e = np.where(term_mis, 0.0, e)  # (counted above, not part of `worst`)
+        # (restored in round 5: these two lines had been lost with the change that introduced term_mis, and from then on no lane
+        #  could leave the comparison -- `dropped lanes` read 0 whatever happened, only the callers that assert on `worst` noticed)
+        first_bad[ok & ~good] = k
+        ok &= good
         nl_g = eng.ints()[:, 3].cpu().numpy().copy() if nt else np.zeros(n, dtype=np.int32)
         nl_r = orc.field("n_targets_left") if nt else np.zeros(n, dtype=np.int32)
         ev_g.append(np.stack([(tg | trg).astype(np.int32), nl_g], axis=1))

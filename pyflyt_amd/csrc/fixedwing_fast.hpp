@@ -797,7 +797,7 @@ struct FwHot {
 #endif
 #ifdef PF_FW_TICK_TRACE  // (per-tick clocks through global atomics: inflates the timeline, its own switch since r05)
     asm volatile("" ::"v"(F.x), "v"(tau.y));
-    if ((threadIdx.x & 63u) == 0u) { atomicAdd(&g_solver_trace[0], 1ull); atomicAdd(&g_solver_trace[1], __builtin_readcyclecounter() - pf_f0); }
+    if ((threadIdx.x & 63u) == 0u) { trace_add(&g_solver_trace[0], 1ull); trace_add(&g_solver_trace[1], __builtin_readcyclecounter() - pf_f0); }
 #endif
     tick_body<FLOOR, SHARED>(K, F, tau, xi, Pfull);
   }
@@ -877,7 +877,7 @@ struct FwHot {
     asm volatile("" ::"v"(wb.x), "v"(vb.z));
     if ((threadIdx.x & 63u) == 0u) {  // (diagnostic build: per tick and wave, clocks in the five surfaces / in the rest of the tick)
       const unsigned long long pf_f2 = __builtin_readcyclecounter();
-      atomicAdd(&g_solver_trace[7], pf_f2 - pf_f1);
+      trace_add(&g_solver_trace[7], pf_f2 - pf_f1);
     }
 #endif
   }

@@ -68,7 +68,9 @@ template <class PP>
 PF_DEV void quad_cascade_d(const PP P, const int mode, const double T, const QuadCtlIn& in, const QuadMemD M, const float sp[4], float pwm[4]) {
   double a[3] = {sp[0], sp[1], sp[2]};
   double z = sp[3];
-  auto pidn = [&](const int k, float* I, float* E, const double* st, const int n) {
+  // (always_inline: left out of line -- the diagnostic build's generic kernels did that -- the captures become flat pointers to the
+  //  caller's stack, and ROCm 7.2's instruction selection aborts on the private-aperture test that goes with them)
+  auto pidn = [&](const int k, float* I, float* E, const double* st, const int n) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       if (i < n) a[i] = pid1d(P->pid[k].kp[i], P->pid[k].ki[i], P->pid[k].kd[i], P->pid[k].lim[i], T, I[i], E[i], st[i], a[i]);

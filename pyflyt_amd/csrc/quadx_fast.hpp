@@ -471,12 +471,12 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
     const int lanes = __popcll(__ballot(any_on));
     for (int o = 32; o > 0; o >>= 1) nc = max(nc, __shfl_xor(nc, o));
     if ((int)(threadIdx.x & 63u) == first) {
-      atomicAdd(&g_solver_trace[0], 1ull);
-      atomicAdd(&g_solver_trace[6], pf_q1 - pf_q0);
-      atomicAdd(&g_solver_trace[2], pf_q2 - pf_q1);
-      atomicAdd(&g_solver_trace[3], (unsigned long long)nc);
-      atomicAdd(&g_solver_trace[4], (unsigned long long)lanes);
-      atomicAdd(&g_solver_trace[5], (unsigned long long)pf_sweeps);
+      trace_add(&g_solver_trace[0], 1ull);
+      trace_add(&g_solver_trace[6], pf_q1 - pf_q0);
+      trace_add(&g_solver_trace[2], pf_q2 - pf_q1);
+      trace_add(&g_solver_trace[3], (unsigned long long)nc);
+      trace_add(&g_solver_trace[4], (unsigned long long)lanes);
+      trace_add(&g_solver_trace[5], (unsigned long long)pf_sweeps);
     }
   }
 #endif
@@ -917,6 +917,11 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     float4 gi = Sin[6 * N + li];
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li],
            g5 = Sin[5 * N + li];
+#ifndef PF_SPARE_LAZY_LOAD
+    // (SPARE: the lane's spare with the state groups -- requested behind the int group's arrival it came 0.4 us late for the resets)
+    float4 gs7 = float4{0.f, 0.f, 0.f, 0.f};
+    if (SPARE) gs7 = Sin[7 * N + li];
+#endif
 #ifndef PF_NO_ACTION_PREFETCH
     // the action is first needed after the resets, a microsecond from here: requested where it is used (inside the stepping
     // lanes' branch) every wave sat out its whole memory latency there; requested behind the state groups it is long there
@@ -944,14 +949,28 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       // in this launch, every lane of a launch that refills the spares or resets in the same step; pf_rollout: every lane, once
       const bool in11 = MODES && K.mode > 0;
       // (where the key shares group 11 with the cascade's memories it is rewritten with them by every launch: always read)
+      // (SPARE: every lane, every launch -- 16 B a lane in Hover, 80 B in Waypoints that only the restarting lanes use. Requested
+      //  by those lanes alone, once their flags are here, the words came from HBM and not from the cache the state groups of the
+      //  previous launch still sit in: 2.8 us in front of the reset, as long as generating them had taken -- profiles/r05)
+#ifdef PF_SPARE_LAZY_LOAD
       const bool need_sp = ROLLOUT || in11 || op == 1 || K.autoreset == PF_AUTORESET_SAME_STEP ||
                            (SPARE && (call0 % kSpareEvery) == kSpareEvery - 1u) ||
                            (__float_as_int(gi.y) & (PF_F_TERMINATED | PF_F_TRUNCATED)) != 0;
+#else
+      const bool need_sp = SPARE || ROLLOUT || in11 || op == 1 || K.autoreset == PF_AUTORESET_SAME_STEP ||
+                           (__float_as_int(gi.y) & (PF_F_TERMINATED | PF_F_TRUNCATED)) != 0;
+#endif
       if (need_sp) {
+#ifndef PF_SPARE_LAZY_LOAD
+        const float4 gk = SPARE ? gs7 : Sin[(size_t)(in11 ? 11 : 7) * N + li];
+#else
         const float4 gk = Sin[(size_t)(in11 ? 11 : 7) * N + li];
+#endif
         rkw = (uint32_t)__float_as_int(in11 ? gk.z : gk.w);
         if (SPARE) {
           spv.z = gk.x; spv.vz = gk.y; spv.thr = gk.z;
+          // (the targets' four groups behind the int group: in front of it, with the state groups, they cost the Waypoints launch
+          //  0.2 us -- 16.9 against 16.7 us --, the settled state's one group gained the Hover launch 0.13)
           if (TASK == PF_TASK_WAYPOINTS) { spv.t[0] = Sin[8 * N + li]; spv.t[1] = Sin[9 * N + li]; spv.t[2] = Sin[10 * N + li]; spv.t[3] = Sin[11 * N + li]; }
           if (ROLLOUT) {
             float4* r4 = reinterpret_cast<float4*>(splds);
@@ -1502,7 +1521,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   if (CALM && K.calm_on) {
     calm = __all(!go || (V.p.z - fmaf(sink_within(K.calm_T, K.calm_TT), 1.01f, 1e-3f) > K.bound_radius));  // (wave-uniform; NaN compares false: not calm)
 #ifdef PF_PHASE_TRACE
-    if (!calm && tid == 0) atomicAdd(&g_calm_trace[0], 1ull);  // waves that keep the call site this step (rare: no contention)
+    if (!calm && tid == 0) trace_add(&g_calm_trace[0], 1ull);  // waves that keep the call site this step (rare: no contention)
 #endif
   }
   for (int s = 0; s < K.env_step_ratio; ++s) {
@@ -1513,7 +1532,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     if (CALM && K.calm_on && !calm) {
       calm_s = __all(!go || (V.p.z - fmaf(sink_within(K.calm_T2, K.calm_TT2), 1.01f, 1e-3f) > K.bound_radius));
 #ifdef PF_PHASE_TRACE
-      if (!calm_s && tid == 0) atomicAdd(&g_calm_trace[1], 1ull);  // Aviary steps that keep the call site
+      if (!calm_s && tid == 0) trace_add(&g_calm_trace[1], 1ull);  // Aviary steps that keep the call site
 #endif
     }
     if (go) {

@@ -136,7 +136,7 @@ struct ContactSet {
   float inv_mass, slop, inv_dt, rest, mu;
   v3 vc, w;             // the running twist: COM velocity, angular velocity
   float res;            // the running sweep's largest row-velocity change (magnitude)
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
   int sweeps_done = 0, rows_full = 0, rows_skipped = 0;
 #endif
   PF_DEV void begin(lds_fptr ws, const m3& R, v3 com, float im, v3 v_, v3 w_, float i0, float i1, float i2, float i3, float i4, float i5,
@@ -186,7 +186,7 @@ struct ContactSet {
     //  friction clamped to +-0; skipped when every lane of the wave agrees -- which includes the lanes that are past their
     //  last contact, or done, and sit on the sentinel record)
     const bool idle = (r4.x == 0.0f) && (un >= r0.w);
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
     if (__builtin_amdgcn_ballot_w64(!idle) == 0ull) { rows_skipped += 1; return 0u; }
     rows_full += 1;
 #else
@@ -268,7 +268,7 @@ struct ContactSet {
         row3(b0, b1, b2, b3, b4, b5, nb + 4);
         off += 2u * kRecBytes;
       }
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
       sweeps_done = it + 1;
 #endif
       done = done || !(res > res_bound);
@@ -284,6 +284,11 @@ struct ContactSet {
 // diagnostic build only (profiles/tools/solver_trace.py): calls, shader-clock cycles in setup / in the sweeps, contacts and
 // active lanes per call, summed by the first active lane of every call
 __device__ unsigned long long g_solver_trace[8];
+// (the diagnostic counters are bumped through a pointer in the GLOBAL address space: no "may this be private memory?" expansion
+//  of the 64-bit atomic)
+PF_DEV void trace_add(unsigned long long* p, const unsigned long long v) {
+  __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 #endif
 // The vertices of one collision box (centre offset cwk in the world frame, half extents bh, link yawed by (cy, sy) about the base
 // z axis) that lie within the contact margin of the slab's top face: f(off, z) in vertex order.
@@ -412,7 +417,7 @@ template <class SRC>
 PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_floats, bool need, const bool persisted, v3 p, const m3 R, v3 v, v3 w, float inv_mass, v3 com,
                                      float i0, float i1, float i2, float i3, float i4, float i5) {
   const float reach = src.reach(persisted);
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
   const unsigned long long pf_t0 = __builtin_readcyclecounter();
   unsigned long long pf_sweep = 0, pf_fill = 0;
 #endif
@@ -434,7 +439,7 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
     need = need && n > 0;
   }
   int sz = need ? (roomy ? worst_sz : (n + 1) * kContactWords) : 0;
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
   const unsigned long long pf_tc = __builtin_readcyclecounter();
 #endif
   ContactSet S;
@@ -443,13 +448,13 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
     const int incl = wave_inclusive_scan_asking(need, sz);
     // (the first lane that asks always fits: the callers' LDS holds at least one worst-case region)
     if (need && incl <= cap_floats) {
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
       const unsigned long long pf_a = __builtin_readcyclecounter();
 #endif
       S.begin(ws + (incl - sz), R, com, inv_mass, v, w, i0, i1, i2, i3, i4, i5, src.slop(), src.inv_dt(), src.rest(), src.mu());
       int seen = 0;
       src.for_each(p, R, reach, [&](v3 off, float z) { if (S.n < n) S.add(off, -z); seen += 1; });
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
       const unsigned long long pf_b = __builtin_readcyclecounter();
       pf_fill += pf_b - pf_a;
 #endif
@@ -461,12 +466,12 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
         out = S.finish(v, w);
         need = false;
       }
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
       pf_sweep += __builtin_readcyclecounter() - pf_b;
 #endif
     }
   }
-#ifdef PF_PHASE_TRACE
+#if defined(PF_PHASE_TRACE) && defined(PF_SOLVER_TRACE)  // (the general solver's own counters: a second switch since r05 -- with them in the generic env kernel ROCm 7.2 aborts)
   {
     const unsigned long long pf_t2 = __builtin_readcyclecounter();
     const unsigned long long m = __ballot(1);
@@ -480,14 +485,14 @@ PF_DEV ContactOut contact_solve_impl(const SRC src, lds_fptr ws, const int cap_f
       sw = sw > t ? sw : t; fl = fl > u ? fl : u;
     }
     if ((int)(threadIdx.x & 63u) == first) {
-      atomicAdd(&g_solver_trace[0], 1ull);
-      atomicAdd(&g_solver_trace[1], pf_tc - pf_t0);              // count pass
-      atomicAdd(&g_solver_trace[7], (pf_t2 - pf_tc) - sw - fl);   // scan / loop bookkeeping
-      atomicAdd(&g_solver_trace[6], fl);                          // records
-      atomicAdd(&g_solver_trace[2], sw);
-      atomicAdd(&g_solver_trace[3], (unsigned long long)nmax);
-      atomicAdd(&g_solver_trace[4], (unsigned long long)solved);
-      atomicAdd(&g_solver_trace[5], (unsigned long long)sd);
+      trace_add(&g_solver_trace[0], 1ull);
+      trace_add(&g_solver_trace[1], pf_tc - pf_t0);              // count pass
+      trace_add(&g_solver_trace[7], (pf_t2 - pf_tc) - sw - fl);   // scan / loop bookkeeping
+      trace_add(&g_solver_trace[6], fl);                          // records
+      trace_add(&g_solver_trace[2], sw);
+      trace_add(&g_solver_trace[3], (unsigned long long)nmax);
+      trace_add(&g_solver_trace[4], (unsigned long long)solved);
+      trace_add(&g_solver_trace[5], (unsigned long long)sd);
     }
     (void)rf;
   }

@@ -221,7 +221,11 @@ typedef struct pf_params {
   pf_rocket rocket;
 } pf_params;
 
-/* Device buffers of one call. state layout: float4 groups, [n_groups][n_lanes][4]. */
+/* Device buffers of one call. state layout: float4 groups, [n_groups][n_lanes][4]. The state belongs to the
+ * library between calls: besides the lane's physical state it holds what the kernels prepare ahead -- for the QuadX Hover /
+ * Waypoints tasks groups 7-11 carry the lane's "spare" (the random part of its NEXT episode: settled spawn state, targets) and the key
+ * its next reset draws from. A caller that writes a state by hand clears bit 31 of group 7's fourth word (group 11's third in the
+ * cascaded flight modes) and leaves the key in bits 0-30: the kernels then generate at the reset. */
 typedef struct pf_buffers {
   float* state;            /* [pf_state_groups()][n][4] fp32/int32, persistent */
   const float* actions;    /* [n][4]   gym action (quadx_base_env.py:269); PF_TASK_DOGFIGHT with df_action_dim 6: [n][6] */

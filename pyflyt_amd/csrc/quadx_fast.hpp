@@ -1076,6 +1076,10 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     const unsigned long long m = __ballot(reset_now);
     if (m == 0ull) return;
     const int r = __popcll(m);
+    // (the seed through an opaque copy made HERE: the compiler had hoisted the Philox key schedule of this rare path -- twenty
+    //  scalar additions, each spilled to a VGPR lane -- in front of the early return, into every wave's life)
+    uint32_t seed_lo = K.seed_lo, seed_hi = K.seed_hi;
+    asm volatile("" : "+s"(seed_lo), "+s"(seed_hi));
     if (reset_now) {
       spos[__popcll(m & ((1ull << tid) - 1ull))] = tid;
       sctr[tid] = key;
@@ -1093,7 +1097,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
         const int src = spos[which];
         const bool noise_call = c < ncall;
         const int call = noise_call ? c : c - ncall;
-        const u32x4 x = philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, noise_call ? 1u : 2u);
+        const u32x4 x = philox4x32(seed_lo, seed_hi, (uint32_t)(lane0 + (uint64_t)(wave_base + src)), sctr[src], (uint32_t)call, noise_call ? 1u : 2u);
         if (noise_call) {
           const f8 z = normal8(x);
 #pragma unroll

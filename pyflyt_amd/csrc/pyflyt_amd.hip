@@ -955,8 +955,14 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     int cur = -1;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
-    hipError_t e = hipMalloc((void**)&c->P_dev, sizeof(pf_params));
+    // (behind the block: what the specialised QuadX kernel's in-register floor solve reads -- quadx_fast.hpp: quad_solve_consts)
+    hipError_t e = hipMalloc((void**)&c->P_dev, pf::kQuadSolveOffset + sizeof(float) * pf::kQuadSolveWords);
     if (e == hipSuccess) e = hipMemcpy(c->P_dev, &c->P, sizeof(pf_params), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      float sw[pf::kQuadSolveWords] = {0};
+      if (c->fast) pf::quad_solve_words(c->P, sw);
+      e = hipMemcpy(reinterpret_cast<char*>(c->P_dev) + pf::kQuadSolveOffset, sw, sizeof(sw), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && (c->fast_fw || c->df_fast)) {
       e = hipMalloc((void**)&c->surf_dev, sizeof(fsurf));
       if (e == hipSuccess) e = hipMemcpy(c->surf_dev, &fsurf, sizeof(fsurf), hipMemcpyHostToDevice);

@@ -17,6 +17,7 @@
 //   (Tried and rejected, profiles/README.md: under-filled 16/32-lane waves, 128-VGPR variants.)
 #pragma once
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "../../include/pyflyt_amd.h"
@@ -36,10 +37,8 @@ struct QuadK {
   float bound_radius0, slop;   // the bare bounding radius and the allowed overlap: "can a contact constraint act this tick?"
   float margin;                // fresh contact points: no vertex above it is one (pf_params.contact_margin)
   float brk, rd;               // persisting points / reports reach up to brk (contact_break_distance); fresh reports from rd on (contact_report_distance)
-  float c_inv_dt, c_rest, c_mu, c_erp;  // the rest of the contact model (pf_params.contact_*): the solve runs inline on these
-  int32_t c_iters, c_all8;     // sweeps at most; 1: every vertex of the box is a candidate (contact_manifold_points = 8)
-  float c_res;                 // sqrt(contact_residual_threshold): the bound on a row's velocity change that ends the sweeps
-  float sqI[3], siI[3];        // sqrt of the diagonal inertia and of its inverse: quad_floor_solve works on w~ = sqrt(I) w_body
+  float c_erp;                 // contact_erp (the rest of the contact model is QuadSolveC's: only the in-register solve reads it)
+  int32_t c_all8;              // 1: every vertex of the box is a candidate (contact_manifold_points = 8)
   float box_h[3], plane_xy, plane_z;  // the collision box's half extents and the slab's: kernel-argument SGPRs, because with random
                                       // actions some lane of nearly every wave is near the floor in nearly every tick -- as scalar
                                       // loads inside that block they cost a memory round trip per tick (+0.7 us per env step)
@@ -116,10 +115,8 @@ inline bool quadk_from_params(const pf_params& P, QuadK& K) {
   K.bound_radius = P.bound_radius + fmaxf(fmaxf(P.contact_margin, P.contact_break_distance), P.contact_report_distance);
   K.bound_radius0 = P.bound_radius; K.slop = P.contact_slop; K.margin = P.contact_margin;
   K.brk = P.contact_break_distance; K.rd = P.contact_report_distance;
-  K.c_inv_dt = 1.0f / P.dt; K.c_rest = P.contact_restitution; K.c_mu = P.contact_friction; K.c_erp = P.contact_erp; K.c_iters = P.contact_iters;
+  K.c_erp = P.contact_erp;
   K.c_all8 = P.contact_manifold_points >= 8 ? 1 : 0;
-  K.c_res = sqrtf(P.contact_residual_threshold);
-  for (int k = 0; k < 3; ++k) { K.sqI[k] = sqrtf(K.I[k]); K.siI[k] = sqrtf(K.iI[k]); }
   for (int k = 0; k < 3; ++k) K.box_h[k] = P.boxes[0].h[k];
   K.plane_xy = P.plane_half_xy; K.plane_z = P.plane_half_z;
   K.m_a = P.motor_dt_over_tau[0]; K.m_noise = P.motor_noise[0]; K.fmax = P.motor_fmax[0]; K.tmax = P.motor_tmax[2];
@@ -267,6 +264,43 @@ struct QuadCasc {
 // Returns the new (v, w) and the deepest penetration net of the slop. act: this lane asks; reach: how far above the face a vertex
 // may be (margin / breaking distance); check_rim: test the vertices against the slab's rim as well (wave-uniform).
 struct QuadFloorOut { v3 v, w; float deepest; };
+// What only the solve reads of the contact model, fetched INSIDE the rare path (scalar cache): as members of the kernel-argument
+// block these fourteen words were loaded in every wave's prologue and parked in the lanes of a spill VGPR for the solve that one
+// wave in a thousand runs (round 5: 25 v_writelane and a scalar-load wait in front of every wave's resets).
+struct QuadSolveC {
+  float inv_dt, rest, mu, res, inv_mass;
+  float sqI[3], siI[3];  // sqrt of the diagonal inertia and of its inverse: quad_floor_solve works on w~ = sqrt(I) w_body
+  int iters;             // sweeps at most
+};
+// (sixteen words behind the device copy of the parameter block, written by pf_ctx_create: one scalar load; computing the derived
+//  ones in the kernel -- a division, seven square roots -- made the solving wave, the one the launch waits for, 0.3 us longer)
+constexpr size_t kQuadSolveOffset = (sizeof(pf_params) + 63) / 64 * 64;
+constexpr int kQuadSolveWords = 16;
+inline void quad_solve_words(const pf_params& P, float (&w)[kQuadSolveWords]) {  // host side
+  w[0] = 1.0f / P.dt; w[1] = P.contact_restitution; w[2] = P.contact_friction; w[3] = sqrtf(P.contact_residual_threshold); w[4] = P.inv_mass;
+  const float I[3] = {P.I_own[0], P.I_own[3], P.I_own[5]}, iI[3] = {P.I_inv[0], P.I_inv[3], P.I_inv[5]};
+  for (int k = 0; k < 3; ++k) { w[5 + k] = sqrtf(I[k]); w[8 + k] = sqrtf(iI[k]); }
+  const int32_t it = P.contact_iters;
+  memcpy(&w[11], &it, 4);
+  w[12] = w[13] = w[14] = w[15] = 0.0f;
+}
+PF_DEV QuadSolveC quad_solve_consts(const pf_params* Pg) {
+  QuadSolveC c;
+#if defined(PF_SOLVE_CONSTS_COMPUTE)  // (A/B: derive them in the kernel from the parameter block)
+  c.inv_dt = 1.0f / Pg->dt; c.rest = Pg->contact_restitution; c.mu = Pg->contact_friction; c.res = __builtin_sqrtf(Pg->contact_residual_threshold);
+  c.inv_mass = Pg->inv_mass;
+  c.sqI[0] = __builtin_sqrtf(Pg->I_own[0]); c.sqI[1] = __builtin_sqrtf(Pg->I_own[3]); c.sqI[2] = __builtin_sqrtf(Pg->I_own[5]);
+  c.siI[0] = __builtin_sqrtf(Pg->I_inv[0]); c.siI[1] = __builtin_sqrtf(Pg->I_inv[3]); c.siI[2] = __builtin_sqrtf(Pg->I_inv[5]);
+  c.iters = Pg->contact_iters;
+#else
+  typedef const float __attribute__((address_space(4)))* kfptr;
+  const kfptr q = (kfptr)(uintptr_t)(reinterpret_cast<const char*>(Pg) + kQuadSolveOffset);
+  c.inv_dt = q[0]; c.rest = q[1]; c.mu = q[2]; c.res = q[3]; c.inv_mass = q[4];
+  c.sqI[0] = q[5]; c.sqI[1] = q[6]; c.sqI[2] = q[7]; c.siI[0] = q[8]; c.siI[1] = q[9]; c.siI[2] = q[10];
+  c.iters = __float_as_int(q[11]);
+#endif
+  return c;
+}
 struct QuadFace {  // the incident face of the collision box at this pose (uav_vehicles.hpp: box_contact_vertices)
   bool use_y, use_z;
   float fs;
@@ -299,7 +333,7 @@ PF_DEV bool quad_vertex_touches(const QuadK& Kc, const v3 a, const m3& R, const 
 }
 // cand: the wave's contact vertices, 4 bits per dense slot (wave-uniform)
 template <int N>
-PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const float reach, const bool check_rim, const v3 p, const m3 R, const QuadFace F,
+PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const QuadSolveC& Sc, const bool act, const float reach, const bool check_rim, const v3 p, const m3 R, const QuadFace F,
                                        const v3 v_in, const v3 w_in, const uint32_t cand) {
 #ifdef PF_PHASE_TRACE
   const unsigned long long pf_q0 = __builtin_readcyclecounter();
@@ -317,9 +351,9 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
   const float hx = Kc.box_h[0], hy = Kc.box_h[1], hz = Kc.box_h[2];
   // (the model's constants in vector registers: as scalars they had been parked in the lanes of a spill VGPR and came back with a
   //  v_readlane in front of every use inside the sweep)
-  const float im = in_vgpr(Kc.inv_mass), mu = in_vgpr(Kc.c_mu);
+  const float im = in_vgpr(Sc.inv_mass), mu = in_vgpr(Sc.mu);
   const v3 wb = mulT(R, w_in);
-  const v3 wt0{wb.x * Kc.sqI[0], wb.y * Kc.sqI[1], wb.z * Kc.sqI[2]};
+  const v3 wt0{wb.x * Sc.sqI[0], wb.y * Sc.sqI[1], wb.z * Sc.sqI[2]};
   float deepest = 0.0f;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -332,7 +366,7 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
     // A lane that does not have this vertex gets an inert slot: zero coupling, target -FLT_MAX, zero impulse -- its rows move nothing.
 #define PF_QROW(D_, EX_, EY_, EZ_, VAX_)                                                         \
     { const v3 j_{fmaf(a.y, EZ_, -(a.z * (EY_))), fmaf(a.z, EX_, -(a.x * (EZ_))), fmaf(a.x, EY_, -(a.y * (EX_)))};  \
-      const v3 jt_{j_.x * Kc.siI[0], j_.y * Kc.siI[1], j_.z * Kc.siI[2]};                        \
+      const v3 jt_{j_.x * Sc.siI[0], j_.y * Sc.siI[1], j_.z * Sc.siI[2]};                        \
       Jt[k][D_][0] = is ? jt_.x : 0.0f; Jt[k][D_][1] = is ? jt_.y : 0.0f; Jt[k][D_][2] = is ? jt_.z : 0.0f;  \
       kk[k][D_] = frcp(im + dot(jt_, jt_));                                                      \
       u[k][D_] = fmaf(wt0.x, jt_.x, fmaf(wt0.y, jt_.y, fmaf(wt0.z, jt_.z, VAX_)));               \
@@ -343,7 +377,7 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
 #undef PF_QROW
     const float depth = -z;
     // normal row: may close the gap down to the slop, no more; otherwise towards restitution x approach speed
-    const float t = depth < Kc.slop ? (depth - Kc.slop) * Kc.c_inv_dt : (u[k][0] < 0.0f ? -Kc.c_rest * u[k][0] : 0.0f);
+    const float t = depth < Kc.slop ? (depth - Kc.slop) * Sc.inv_dt : (u[k][0] < 0.0f ? -Sc.rest * u[k][0] : 0.0f);
     tg[k] = is ? t : -3.4028235e38f;
     // friction cone in velocity units: |l'_x| <= mu (A_xx / A_zz) l'_z
     fx[k] = mu * kk[k][0] * frcp(kk[k][1]); fy[k] = mu * kk[k][0] * frcp(kk[k][2]);
@@ -432,20 +466,20 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
   };
   const bool lone = __popcll(__ballot(any_on)) <= 1;  // (wave-uniform)
   if (lone) {
-    for (int it = 0; it < Kc.c_iters; ++it) {
+    for (int it = 0; it < Sc.iters; ++it) {
 #ifdef PF_PHASE_TRACE
       pf_sweeps = it + 1;
 #endif
       sweep(std::false_type{});
-      if (__ballot(any_on && res > Kc.c_res) == 0ull) break;
+      if (__ballot(any_on && res > Sc.res) == 0ull) break;
     }
   } else {
-    for (int it = 0; it < Kc.c_iters; ++it) {
+    for (int it = 0; it < Sc.iters; ++it) {
 #ifdef PF_PHASE_TRACE
       pf_sweeps = it + 1;
 #endif
       sweep(std::true_type{});
-      done = done || !(res > Kc.c_res);
+      done = done || !(res > Sc.res);
       if (__ballot(!done) == 0ull) break;
     }
   }
@@ -460,7 +494,7 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
               fmaf(lz, Jt[c][0][2], fmaf(lx, Jt[c][1][2], fmaf(ly, Jt[c][2][2], wt.z)))};
     }
   }
-  const v3 wbn{wt.x * Kc.siI[0], wt.y * Kc.siI[1], wt.z * Kc.siI[2]};
+  const v3 wbn{wt.x * Sc.siI[0], wt.y * Sc.siI[1], wt.z * Sc.siI[2]};
 #ifdef PF_PHASE_TRACE
   {  // (diagnostic build: the same counters as the general solver's -- calls, clocks in the records / in the sweeps, contacts, lanes, sweeps)
     const unsigned long long pf_q2 = __builtin_readcyclecounter();
@@ -487,10 +521,11 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const bool act, const fl
   return o;
 }
 // (the rotation matrix entry by entry: as an m3 argument the 36-byte copy kept two rows of the caller's matrix in scratch memory)
-PF_DEV QuadFloorOut quad_floor_solve(const QuadK& Kc, const bool act, const float reach, const bool check_rim, const v3 p,
+PF_DEV QuadFloorOut quad_floor_solve(const QuadK& Kc, const pf_params* Pfull, const bool act, const float reach, const bool check_rim, const v3 p,
                                      const float r00, const float r01, const float r02, const float r10, const float r11, const float r12,
                                      const float r20, const float r21, const float r22, const v3 v_in, const v3 w_in) {
   const m3 R{r00, r01, r02, r10, r11, r12, r20, r21, r22};
+  const QuadSolveC Sc = quad_solve_consts(Pfull);
   QuadFace F;
   F.of(R);
   // which of the face's four vertices does some lane of the wave have as a contact? (wave-uniform: the dense slots)
@@ -503,10 +538,10 @@ PF_DEV QuadFloorOut quad_floor_solve(const QuadK& Kc, const bool act, const floa
     if (__any(is)) { cand |= (uint32_t)c << (4 * n); n += 1; }
   }
   switch (n) {
-    case 1: return quad_floor_solve_n<1>(Kc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
-    case 2: return quad_floor_solve_n<2>(Kc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
-    case 3: return quad_floor_solve_n<3>(Kc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
-    case 4: return quad_floor_solve_n<4>(Kc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
+    case 1: return quad_floor_solve_n<1>(Kc, Sc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
+    case 2: return quad_floor_solve_n<2>(Kc, Sc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
+    case 3: return quad_floor_solve_n<3>(Kc, Sc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
+    case 4: return quad_floor_solve_n<4>(Kc, Sc, act, reach, check_rim, p, R, F, v_in, w_in, cand);
     default: break;
   }
   return QuadFloorOut{v_in, w_in, 0.0f};
@@ -711,7 +746,7 @@ struct QuadHot {
         //  waves per SIMD the inlined solve spills. profiles/README.md, r03 / r04)
         if (INL) {  // (the launcher picks these instantiations only with the manifold reduced to the incident face: pf_ctx_create)
           const bool at_rim = !((__builtin_fabsf(p.x) + Kc.bound_radius0 < Kc.plane_xy) && (__builtin_fabsf(p.y) + Kc.bound_radius0 < Kc.plane_xy));
-          const QuadFloorOut o = quad_floor_solve(Kc, act, persisted ? Kc.brk : Kc.margin, __any(act && at_rim), p, R.m00, R.m01, R.m02, R.m10, R.m11, R.m12,
+          const QuadFloorOut o = quad_floor_solve(Kc, Pfull, act, persisted ? Kc.brk : Kc.margin, __any(act && at_rim), p, R.m00, R.m01, R.m02, R.m10, R.m11, R.m12,
                                                       R.m20, R.m21, R.m22, v(), w());
           set_wv(o.w, o.v);
           lift = Kc.c_erp * o.deepest;

@@ -484,3 +484,64 @@ def test_dead_aircraft_at_a_momentary_standstill_moves_on():
     ps = np.array(ps)
     assert np.abs(ps[0] - np.array([0.0, 0.0, 1.5])).max() > 1e-3, ps[0]          # it moved in the very first step ...
     assert (np.abs(np.diff(ps, axis=0)).max(axis=1) > 1e-4).all(), ps             # ... and in every step after it: not frozen
+
+
+def test_a_moving_aircraft_pushes_a_wreck_at_rest():
+    """A wreck the device has stopped integrating (DF_AT_REST) is still a body in Bullet's world: the reference keeps stepping it, and
+    an aircraft that slides into it pushes it along. The device wakes the wreck when a moving body comes within reach (world_exchange,
+    round 5) -- before that the pair stage solved the hit against a body that never read its impulse back, and the momentum vanished.
+    Scenario: a dead aircraft dropped from 0.4 m comes to rest; a second dead aircraft, level, 8 m/s, 3 m behind it and 0.2 m up, lands
+    and runs into it. Device against the fp64 oracle world from the same state (the oracle's wreck is put at the device's resting pose
+    when the second aircraft is placed: what is compared is the hit, not the 6 mm by which the two landings differ)."""
+    g = np.load(os.path.join(GOLD, "env_dogfight_crash.npz"))
+    eng, A = _engine(1, "inject", max_duration_seconds=30.0)
+    _set_spawn(eng, g["start_pos"], g["start_orn"])
+    eng.env_reset(xi_reset=torch.zeros(g["reset_xi"].shape, dtype=torch.float32, device="cuda:0").contiguous())
+    W = O.OracleDogfight(g["start_pos"], g["start_orn"], noise_mode=O.NOISE_OFF, max_duration_seconds=30.0)
+    W.reset()
+    n_xi = g["xi"][0].shape[0]
+
+    def place(i, p, q, v, w):
+        s = eng.state
+        s[0, i, :3] = torch.tensor(p, dtype=torch.float32, device="cuda:0"); s[1, i, :] = torch.tensor(q, dtype=torch.float32, device="cuda:0")
+        s[2, i, :3] = torch.tensor(v, dtype=torch.float32, device="cuda:0"); s[2, i, 3] = float(w[0]); s[3, i, 0] = float(w[1]); s[3, i, 1] = float(w[2])
+        s[6, i, 0] = 0.0                                         # health 0: dead ...
+        fl = s[6, :, 3].view(torch.int32); fl[i] = int(fl[i]) & ~1   # ... and culled (not DF_ALIVE)
+        L = W.Ls[i]
+        for k in range(3):
+            L.p[k], L.v[k], L.w[k] = float(np.float32(p[k])), float(np.float32(v[k])), float(np.float32(w[k]))
+        for k in range(4):
+            L.q[k] = float(np.float32(q[k]))
+        W.D.alive[i] = 0; W.D.health[i] = 0.0
+
+    def step():
+        eng.env_step(torch.zeros(A, 4, device="cuda:0"), xi=torch.zeros(n_xi, A, device="cuda:0"))
+        W.step(np.zeros((A, 4)))
+        return int(eng.state[6, 0, 3].view(torch.int32))
+
+    place(0, [10.0, 0.0, 0.4], [0, 0, 0, 1], [0, 0, 0], [0, 0, 0])
+    rest_at = next((k for k in range(40) if step() & 8192), None)
+    assert rest_at is not None, "the dropped wreck never came to rest"
+    p_rest, q_rest = eng.state[0, 0, :3].cpu().numpy().copy(), eng.state[1, 0, :].cpu().numpy().copy()
+    assert abs(float(p_rest[2]) - 0.1) < 5e-3 and np.abs(p_rest - np.array(W.Ls[0].p[:])).max() < 1e-2   # both sides: flat on the ground, where it fell
+    place(0, p_rest, q_rest, [0, 0, 0], [0, 0, 0])
+    place(1, [float(p_rest[0]) - 3.0, float(p_rest[1]), float(p_rest[2]) + 0.2], [0, 0, 0, 1], [8.0, 0, 0], [0, 0, 0])
+    woke_at, worst, moved = None, 0.0, 0.0
+    for k in range(14):
+        f0 = step()
+        pd = eng.state[0, :2, :3].cpu().numpy().astype(np.float64)
+        po = np.array([W.Ls[i].p[:] for i in range(2)])
+        if woke_at is None and not (f0 & 8192):
+            woke_at = k
+        if woke_at is None:  # nothing within reach yet: the wreck is not integrated, bit for bit where it was
+            assert np.array_equal(eng.state[0, 0, :3].cpu().numpy(), p_rest), (k, pd[0], p_rest)
+        err = float(_rel(pd, po).max())
+        worst = max(worst, err)
+        moved = float(pd[0][0] - p_rest[0])
+        assert err < RTOL_IMPACT, (k, err, pd, po)
+    vd, vo = eng.state[2, 0, :3].cpu().numpy().astype(np.float64), np.array(W.Ls[0].v[:])
+    print(f"wreck at rest after {rest_at + 1} steps, woken {woke_at} steps after the second aircraft was placed, pushed {moved:.3f} m since; worst position error "
+          f"(both bodies, 14 steps) {worst:.2e}; the wreck's velocity now: device {vd}, oracle {vo}")
+    assert woke_at is not None and woke_at <= 5, woke_at         # (the hit comes 5 steps in; the wake reaches a bounding radius ahead of it)
+    assert moved > 0.5, moved                                     # it was pushed along (the momentum used to vanish: moved == 0)
+    assert abs(vd[0] - vo[0]) < 0.05 * abs(vo[0]) and vo[0] > 2.0, (vd, vo)   # ... and it is still sliding as fast as the oracle's

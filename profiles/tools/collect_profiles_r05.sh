@@ -59,6 +59,7 @@ PY
 # micro-benchmarks of what a launch and a lone wave cost (profiles/tools/r05/ubench)
 [ -x $R/build/ubench/dispatch_ramp ] && timeout 100 $R/build/ubench/dispatch_ramp > $O/ubench_dispatch_ramp.txt 2>&1
 [ -x $R/build/ubench/icache_cold ] && timeout 100 $R/build/ubench/icache_cold > $O/ubench_icache_cold.txt 2>&1
+[ -x $R/build/ubench/sload_latency ] && timeout 60 $R/build/ubench/sload_latency > $O/ubench_sload_latency.txt 2>&1
 timeout 100 python $R/bench.py --flight-mode=4 --steps 1000 --warmup 100 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > $O/bench_mode4.json
 timeout 100 python $R/bench.py --batch 8192 --steps 2000 --warmup 200 --no-cpu-baseline --no-configs 2>/dev/null | tail -1 > $O/bench_b8192.json
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete

@@ -206,6 +206,9 @@ PF_DEV FwSurf2 fw_load_surf2(fw_surf2_cptr p) {  // two s_load_dwordx16, every f
 // instead of five scalar loads -- each with its own wait, and nothing to hide it behind at one wave per SIMD -- in every tick, and a
 // uniform value in a vector register costs the instruction that reads it nothing (no constant-bus limit, no SGPR -> VGPR copy in
 // front of a packed operand; quadx_fast.hpp: QuadKV).
+#ifndef PF_FW_TAB_VIA_LDS
+#define PF_FW_TAB_VIA_LDS 1   // (r05: 21.1 -> 20.7 us; 0 = 28 broadcast global loads)
+#endif
 #ifndef PF_FW_TABV
 #define PF_FW_TABV 2   // (A/B: 2 = the whole table in vector registers; 4 = the surface pairs only, v-tail and body rows by scalar loads in
                        //  the tick; 5 = the surface pairs in vector registers, v-tail and body rows read from LDS in the tick)
@@ -266,6 +269,22 @@ PF_DEV FwTableV fw_table_in_vgprs(const FwTable* g) {
   V.krest = nullptr;
   return V;
 }
+// The same, through LDS (PF_FW_TAB_VIA_LDS): every lane fetches two WORDS of the table with the state groups (two coalesced requests
+// instead of 28 broadcast ones, which took the wave 0.7 us to issue -- the int group, first in line, sat ready the while), the words
+// go to LDS once they are here, behind the step's Philox call, and 28 broadcast ds_read_b128 bring them to every lane.
+PF_DEV FwTableV fw_table_from_lds(lds_fptr base, const FwTable* g) {
+  const fw_lds_f4ptr q = (fw_lds_f4ptr)base;
+  constexpr int kN = (int)(sizeof(FwTable) / 16);
+  fw_f4v r[kN];
+#pragma unroll
+  for (int i = 0; i < kN; ++i) r[i] = q[i];
+  FwTableV V;
+  __builtin_memcpy(&V.pair[0], r, kN * 16);
+  V.rest = (fw_tab_cptr)(uintptr_t)g;
+  V.krest = nullptr;
+  return V;
+}
+static_assert(sizeof(FwTable) == 112 * 4, "the table's 112 words: lanes 0-63 fetch the first 64, lanes 0-47 the rest");
 static_assert(offsetof(FwTableV, vtail) == offsetof(FwTable, vtail) && offsetof(FwTableV, body) == offsetof(FwTable, body), "FwTableV starts with FwTable");
 struct FwPairOut { f2 fp, fn, ty; };  // per surface: force along +x, along the lift unit (+z), and the r x f + moment part of tau.y
 
@@ -908,7 +927,7 @@ __global__ void __launch_bounds__(64, WPS) fixedwing_wp_env_kernel(const FwK K, 
   constexpr bool GIVEN = ROLL == 2;
   constexpr int kMaxD = 13 + 4 + 6 + 12;
   __shared__ __attribute__((aligned(16))) float tile[64 * kMaxD];
-  __shared__ __attribute__((aligned(16))) float ktab[48];  // (WPS == 1) the constant table's v-tail and body rows: FwTableV::krest
+  __shared__ __attribute__((aligned(16))) float ktab[PF_FW_TAB_VIA_LDS ? 112 : 48];  // (WPS == 1) the constant table on its way to the vector registers (PF_FW_TAB_VIA_LDS) / its v-tail and body rows: FwTableV::krest
   __shared__ int spos[64];        // the cooperative waypoint sampling's (lane, counter) exchange
   __shared__ uint32_t sctr[64];
   static_assert(64 * kMaxD >= 2 * 64 * 16, "prepare_targets stages uniforms and targets in the observation tile");
@@ -949,10 +968,22 @@ __global__ void __launch_bounds__(64, WPS) fixedwing_wp_env_kernel(const FwK K, 
 #ifndef PF_NO_ACTION_PREFETCH
     if (ROLL == 0 && op == 0) a_pre = reinterpret_cast<const float4*>(B.actions)[li];
 #endif
-    if (blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch((int)threadIdx.x);  // (uav_vehicles.hpp; behind the state loads: one wait for both)
+    // (the rare code's prefetch, uav_vehicles.hpp: only where a second wave shares the SIMD -- with one wave per SIMD every wave takes
+    //  the same time and the prefetching ones were the launch's slowest: 21.1 -> 20.7 us without)
+    if (WPS != 1 && blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch((int)threadIdx.x);
     // (the constant table BEHIND the state groups: loads return in order, and in front of them its 28 requests held the int group --
     //  which the Philox call below waits for -- back by 0.7 us; profiles/r05/phase_fixedwing.txt)
+#if PF_FW_TAB_VIA_LDS
+    float tw0 = 0.0f, tw1 = 0.0f;
     if (WPS == 1) {
+      const float* tg = reinterpret_cast<const float*>(table_g);
+      tw0 = tg[tid];
+      tw1 = tg[64 + (tid < 48 ? tid : 47)];
+    }
+    if (false) {
+#else
+    if (WPS == 1) {
+#endif
       TV = fw_table_in_vgprs(table_g);
 #if PF_FW_TABV == 5
       float kv = 0.0f;
@@ -968,6 +999,13 @@ __global__ void __launch_bounds__(64, WPS) fixedwing_wp_env_kernel(const FwK K, 
     if (NOISE == PF_NOISE_PHILOX) {
       if (op == 0) zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
     }
+#if PF_FW_TAB_VIA_LDS
+    if (WPS == 1) {  // (one wave per workgroup; LDS operations of a wave complete in issue order)
+      ktab[tid] = tw0;
+      ktab[64 + (tid < 48 ? tid : 47)] = tw1;
+      TV = fw_table_from_lds((lds_fptr)ktab, table_g);
+    }
+#endif
     PF_STAMP(2);
     V.p = v3{g0.x, g0.y, g0.z}; new_dist = g0.w;
     V.q = quat{g1.x, g1.y, g1.z, g1.w};

@@ -217,6 +217,11 @@ PF_DEV void stream_tile(const float* tile, float* g, int total, int tid, int lan
   for (int i = (n4 << 2) + tid; i < total; i += lanes) __builtin_nontemporal_store(tile[i], &g[i]);
 }
 
+// (r05, measured and dropped: every LDS read of the tile issued ahead of the first store -- an unrolled, predicated copy of up to ten
+//  rounds -- instead of this loop's read / wait / store per round: Hover 9.65 -> 9.91 us, QuadX-Waypoints 16.65 -> 17.3, Fixedwing-
+//  Waypoints 20.63 -> 21.59 on one box, profiles/tools/r05/g21.sh. The phase traces' 0.36-0.6 us "obs stores issued" is the issue of
+//  the 1 KB stores themselves, not the LDS round trips in between.)
+
 // ---------------------------------------------------------------- contact reporting
 // btBoxBoxDetector verdict (15 separating axes) for an oriented box against the world-aligned
 // ground box; see oracle/uav_oracle.c:orc_box_box_overlap for the restated rule.

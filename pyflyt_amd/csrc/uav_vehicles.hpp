@@ -125,6 +125,11 @@ PF_DEV void rare_text_prefetch(const int lane) {
     asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off\n\ts_waitcnt vmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a + o0), "v"(a + o1) : "memory");
   }
 }
+// (r05, measured and dropped: the same through ONE plain, branch-free load per wave -- 136 waves requesting one 128-byte line each,
+//  consumed in front of the state stores -- made every launch slower than no prefetch at all: Hover 9.69 -> 9.89 us, Fixedwing-
+//  Waypoints 20.7 -> 21.4. The Fixedwing-Waypoints kernel, whose waves all take the same time, does without the prefetch: the
+//  sixteen prefetching waves, waiting for their rounds and with them for every state group in flight, were its slowest -- 21.1 ->
+//  20.7 us. profiles/tools/r05/g19.sh, g20.sh)
 // The per-body part of the solve that does not depend on where the contact vertices come from: records are appended with
 // add(), then sweeps() runs the projected Gauss-Seidel iteration. W4: this lane's LDS region.
 struct ContactSet {

@@ -272,6 +272,10 @@ PF_DEV FwTableV fw_table_in_vgprs(const FwTable* g) {
 // The same, through LDS (PF_FW_TAB_VIA_LDS): every lane fetches two WORDS of the table with the state groups (two coalesced requests
 // instead of 28 broadcast ones, which took the wave 0.7 us to issue -- the int group, first in line, sat ready the while), the words
 // go to LDS once they are here, behind the step's Philox call, and 28 broadcast ds_read_b128 bring them to every lane.
+// (Measured, r05: the two word loads in FRONT of the state groups and the LDS stage in front of the Philox call -- so that the LDS reads
+//  complete under it -- is slower, 20.7 -> 21.3 us: every wave of the launch asks for the same four lines at the same moment, the
+//  requests queue at one L2 channel, and behind them, in order, waits the wave's own state. Where they are, that queue drains under
+//  the state groups' latency and the Philox call. profiles/tools/r05/g22.sh)
 PF_DEV FwTableV fw_table_from_lds(lds_fptr base, const FwTable* g) {
   const fw_lds_f4ptr q = (fw_lds_f4ptr)base;
   constexpr int kN = (int)(sizeof(FwTable) / 16);

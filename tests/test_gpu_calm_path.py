@@ -61,3 +61,41 @@ def test_calm_path_is_bit_identical(monkeypatch, task, mode, lean):
         collided += int(hit.sum())
     assert collided > 20, collided  # (the floor was in play)
     assert worst < 5e-3, worst      # the two instantiations' contact solves agree to the impact tolerance in that terminal observation
+
+
+def test_fixedwing_instantiations_are_bit_identical(monkeypatch):
+    """The Fixedwing-Waypoints kernel's two instantiations -- one wave per SIMD (512 registers, the constant table in vector registers,
+    fetched through LDS, both surface pairs evaluated side by side) and two (256 registers, the table's rows by scalar loads in the
+    tick; PF_NO_LEAN_KERNEL, what batches beyond one wave per SIMD get) -- run the same arithmetic per element: bit-identical
+    observations, rewards, flags and state, through resets and out-of-bounds endings."""
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    n, steps = 4096 + 37, 120
+
+    def make(lean):
+        if lean:
+            monkeypatch.delenv("PF_NO_LEAN_KERNEL", raising=False)
+        else:
+            monkeypatch.setenv("PF_NO_LEAN_KERNEL", "1")
+        eng = BatchEngine(build_params("fixedwing", "waypoints", noise="philox", autoreset="next_step", seed=5), n, device="cuda:0")
+        assert eng.lib.pf_ctx_is_specialised(eng._ctx) != 0
+        return eng
+
+    a, b = make(True), make(False)
+    assert torch.equal(a.env_reset(), b.env_reset())
+    act = torch.empty(n, 4, device="cuda:0")
+    ended = 0
+    for k in range(steps):
+        a.sample_actions(act, k)
+        ra, rb = a.env_step(act), b.env_step(act)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), k
+        assert torch.equal(a.state, b.state), k
+        ended += int((ra[2] | ra[3]).sum())
+    assert ended > 50, ended  # (episodes ended and restarted along the way)
+    # ... and state-resident: sixty more steps in one launch on either side
+    ta, tb = a.rollout(60), b.rollout(60)
+    for x, y in zip(ta, tb):
+        assert torch.equal(x, y)
+    assert torch.equal(a.state, b.state)

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: env-steps/sec of the fused QuadX-Hover env step.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
-Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 one rank per GPU -- either launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or, when no torchrun environment is present,
+bench.py starts those N ranks ITSELF (the same torch.distributed.run command line, 127.0.0.1 rendezvous) and exits non-zero when
+fewer than N devices are visible: `--gpus 8` never reports a one-GPU number. Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json metric): PyFlyt/QuadX-Hover (flight mode 0, 40 Hz agent -> 6 physics ticks
 and 3 control ticks per env step, quaternion observation, dense reward), batch 65 536 drones PER
@@ -84,10 +85,40 @@ def parse():
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the secondary BASELINE configs (Hover 4 096, QuadX-Waypoints 65 536, Fixedwing-Waypoints 65 536) that the "
                          "default single-GPU hover run times after the headline and reports under `configs`")
+    ap.add_argument("--no-facade", action="store_true",
+                    help="skip the `facade` block: the drop-in surface itself (gym_envs.make_vec(...).step(), pz_envs.MAQuadXHoverEnv.step()) in a "
+                         "closed loop, eager and captured in a HIP graph")
     ap.add_argument("--config-steps", type=int, default=2000,
                     help="timed steps per secondary config (QuadX-Waypoints has a heavy tail -- the launches in which a lane solves a floor contact --: "
                          "500 steps were one deterministic sample 1.7 us above the 2000-step mean)")
     return ap.parse_args()
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks here (the command line the contract
+    names), pass their output through, exit with their status. Refuses when fewer than N devices are visible (PF_BENCH_SINGLE_DEVICE=1,
+    the one-GPU launcher test, puts every rank on cuda:0)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("PF_BENCH_SINGLE_DEVICE") != "1" and have < n_gpus:
+        raise SystemExit(f"bench.py --gpus {n_gpus}: {have} ROCm device(s) visible to this process; refusing to report a {have}-GPU figure under an "
+                         f"{n_gpus}-GPU label (one rank per GPU: no oversubscription, no CPU fallback)")
+    if have == 0:
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback exists for the product path)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PF_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL's intra-node transport needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def make_engine(env, batch, device, lane_offset, noise, contact_response=True, world=(), flight_mode=0, seed=0):
@@ -310,6 +341,139 @@ def time_config_guarded(env, batch, device, args):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def _loop_us(fn, steps, torch):
+    """Wall-clock microseconds per call of `fn(i)` over `steps` calls, device drained before and after (the eager closed loop)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fn(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e6 / steps
+
+
+def _graph_us(body, g, reps, stream, torch):
+    """`body(i)` for i < g captured in ONE HIP graph on `stream`, replayed once (upload), then `reps` replays timed with HIP events
+    on that stream: microseconds per captured step."""
+    with torch.cuda.stream(stream):
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            for i in range(g):
+                body(i)
+        graph.replay()
+        stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(stream)
+        stream.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * g), graph
+
+
+def facade_block(device, args, ms_per_step):
+    """The drop-in surface itself, measured: what a user of `make_vec("PyFlyt/QuadX-Hover-v4", 65536).step(actions)` and of
+    `MAQuadXHoverEnv(num_envs=16384).step(actions)` gets per step -- (a) `step_only`: env.step() over the headline's own action ring,
+    eager (wall clock, host included) and captured in a HIP graph (events): the facade's cost over the bare pf_env_step launch of the
+    headline; (b) `closed_loop`: a trivial on-device policy actions = clamp(obs @ W + b) writing into a fixed action buffer and
+    env.step() on it, eager and captured, with the policy's two torch kernels alone next to it. Nothing here reads `infos`."""
+    import torch
+
+    from pyflyt_amd.gym_envs import make_vec
+    from pyflyt_amd.pz_envs import MAQuadXHoverEnv
+
+    steps, g = 2000, 100
+    stream = torch.cuda.Stream(device=device)
+
+    def measure(step, obs, act, ring, policy_wb, lo, hi):
+        W, b = policy_wb
+        out = {}
+        for i in range(max(200, 2 * len(ring))):  # (every ring entry's buffer block prepared, clocks up)
+            step(ring[i % len(ring)])
+        eager = _loop_us(lambda i: step(ring[i % len(ring)]), steps, torch)
+        gus, gr = _graph_us(lambda i: step(ring[i % len(ring)]), g, steps // g, stream, torch)
+        out["step_only"] = {"eager_us_per_step": eager, "graph_us_per_step": gus, "graph_vs_headline_launch": gus / (ms_per_step * 1e3),
+                            "what": f"env.step(ring[i]) over a {len(ring)}-entry ring of uniform action draws, {steps} steps; infos not read"}
+        del gr
+
+        def policy():
+            torch.addmm(b, obs, W, out=act)
+            torch.clamp(act, min=lo, max=hi, out=act)
+
+        def closed(i):
+            policy()
+            step(act)
+
+        for i in range(200):
+            closed(i)
+        eager_c = _loop_us(closed, steps, torch)
+        gus_c, gr = _graph_us(closed, g, steps // g, stream, torch)
+        del gr
+        pol, gr = _graph_us(lambda i: policy(), g, steps // g, stream, torch)
+        del gr
+        out["closed_loop"] = {"eager_us_per_step": eager_c, "graph_us_per_step": gus_c, "policy_graph_us_per_step": pol,
+                              "graph_minus_policy_us": gus_c - pol,
+                              "policy": "actions = clamp(obs @ W + b) into a fixed action tensor: torch.addmm + torch.clamp (two kernels), then env.step(actions)"}
+        return out
+
+    res = {"what": "the Gymnasium-VectorEnv / PettingZoo-shaped step() of the package in a closed loop, eager (wall clock) and captured in a HIP graph "
+                   "(HIP events); per step: one foreign call, no torch kernel, no host synchronisation (tests/test_gpu_api.py)"}
+    # ---- gym_envs.make_vec("PyFlyt/QuadX-Hover-v4", 65536)
+    n = 65536
+    env = make_vec("PyFlyt/QuadX-Hover-v4", n, device=device, seed=args.seed)
+    eng = env.engine
+    ring = [torch.empty(n, 4, dtype=torch.float32, device=device) for _ in range(100)]
+    for i, a in enumerate(ring):
+        eng.sample_actions(a, i)
+    obs, _ = env.reset()
+    preroll(eng, ring, 400, 1 << 20)  # (episode phases decorrelated, as the headline's setup does)
+    lo = torch.tensor(env.single_action_space.low, device=device)
+    hi = torch.tensor(env.single_action_space.high, device=device)
+    # a hovering linear policy: rate commands against the attitude (quaternion x, y at obs[3], obs[4]) and the body rates (obs[0:3]),
+    # thrust around the hover command against height and climb rate (obs[12], obs[9]): episodes run to truncation
+    W = torch.zeros(eng.obs_dim, 4, device=device)
+    W[0, 0] = W[1, 1] = W[2, 2] = -0.2
+    W[3, 0] = W[4, 1] = -4.0
+    W[12, 3], W[9, 3] = -0.3, -0.2
+    b = torch.tensor([0.0, 0.0, 0.0, 0.3772 + 0.3], device=device)
+    act = torch.zeros(n, 4, device=device)
+    v = measure(lambda a: env.step(a), obs, act, ring, (W, b), lo, hi)
+    v["id"], v["num_envs"] = "PyFlyt/QuadX-Hover-v4", n
+    assert torch.isfinite(eng.obs).all(), "non-finite observation in the facade loop"
+    res["vector_env"] = v
+    env.close()
+    del env, eng, ring, act
+    # ---- pz_envs.MAQuadXHoverEnv, 16 384 copies of the four-agent env (65 536 lanes), every agent its own lane (the default)
+    E = 16384
+    ma = MAQuadXHoverEnv(num_envs=E, device=device, seed=args.seed, cull_agents=False)
+    ma.reset()
+    eng = ma.engine
+    bufs = ma.action_buffers()
+    flat_act = ma._act_flat  # the env's own [E * A, 4] action tensor, the storage behind action_buffers()
+    # step_only: small rate commands, thrust around the hover command, written into the env's action tensor once and held
+    eng.sample_actions(flat_act, 0)
+    flat_act[:, :3].mul_(0.01 / 3.14159265)
+    flat_act[:, 3].mul_(0.001).add_(0.3772)
+    lo = torch.tensor(ma.action_space().low, device=device)
+    hi = torch.tensor(ma.action_space().high, device=device)
+    W = torch.zeros(eng.obs_dim, 4, device=device)
+    W[0, 0] = W[1, 1] = W[2, 2] = -0.2
+    W[3, 0] = W[4, 1] = -4.0
+    W[12, 3], W[9, 3] = -0.3, -0.2
+    b = torch.tensor([0.0, 0.0, 0.0, 0.3772 + 0.3], device=device)
+
+    m = measure(lambda a: ma.step(bufs), eng.obs, flat_act, [flat_act], (W, b), lo, hi)
+    m["step_only"]["what"] = f"env.step(env.action_buffers()) with held hover commands in the env's own action tensor, {steps} steps; infos not read"
+    m["env"], m["num_envs"], m["agents"], m["lanes"] = "MAQuadXHoverEnv(cull_agents=False)", E, 4, 4 * E
+    assert torch.isfinite(eng.obs).all(), "non-finite observation in the PettingZoo facade loop"
+    res["pettingzoo"] = m
+    ma.close()
+    res["eager_us_per_step"] = res["vector_env"]["step_only"]["eager_us_per_step"]
+    res["graph_us_per_step"] = res["vector_env"]["step_only"]["graph_us_per_step"]
+    res["headline_launch_us"] = ms_per_step * 1e3
+    return res
+
+
 def main():
     args = parse()
     import torch
@@ -317,8 +481,10 @@ def main():
     from pyflyt_amd.dist import env_rank_world, strong_shard, weak_shard
 
     rank, local_rank, world = env_rank_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        if "WORLD_SIZE" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        self_launch(args.gpus)  # (does not return: the N ranks' exit status is this process's)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback exists for the product path)")
     # PF_BENCH_SINGLE_DEVICE=1 + PF_BENCH_BACKEND=gloo: every rank on cuda:0, host-side collectives -- the N > 1 launcher path
@@ -518,6 +684,9 @@ def main():
             "metric": (f"env-steps/sec (whole node), QuadX-Hover batch={args.batch} " + ("per GPU" if args.scaling == "weak" else "in total"))
             if args.env == "hover" else f"env-steps/sec (whole node), {args.env}",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "world_size": world, "launcher": ("bench.py started the ranks itself (torch.distributed.run)" if os.environ.get("PF_BENCH_SELF_LAUNCHED") == "1" else
+                                              ("torch.distributed.run environment" if "WORLD_SIZE" in os.environ else "single process")),
+            "collective_backend": (None if dist is None else ("rccl (torch 'nccl')" if backend == "nccl" else backend)),
             "ms_per_step": 1e3 * wall_max / timed_steps, "higher_is_better": True, "scaling": args.scaling,
             # the timed region: `repeats` x K steps back to back (--min-timed-ms; every figure is per step)
             "timed": {"steps": timed_steps, "repeats": repeats, "wall_ms": 1e3 * wall_max, "event_ms": 1e3 * ev_max, "min_timed_ms": args.min_timed_ms,
@@ -551,23 +720,30 @@ def main():
                 "kernel": ("pf::quadx_m0_env_kernel" if args.env != "fixedwing_waypoints" else "pf::fixedwing_wp_env_kernel") + "<..., ROLL=1>", "launch_us": rev / reps * 1e6,
                 "note": "k env steps per launch, state in registers, on-device action sampling (pf_sample_actions keys); bit-identical to k x pf_env_step (tests/test_gpu_rollout.py)",
             }
+        # `value` is the one-launch-per-step figure in EVERY mode (a policy in the loop can reach it): what the driver's scaling curve is
+        # computed from. Strong scaling cuts ONE batch over the GPUs -- 65 536 lanes on 8 GPUs are 8 192 per GPU = 128 waves on 1 024
+        # SIMDs, a launch per step costs its fixed ~8 us whatever the kernel does (~1.25 x at 8 GPUs) -- and what
+        # scales in that regime is the state-resident path: reported under `rollout`, named in `state_resident_note`, never as `value`.
+        out["value_kind"] = "one pf_env_step launch per env step (hipGraph replay)"
         if args.scaling == "strong" and roll is not None:
-            # Strong scaling cuts ONE batch over the GPUs: 65 536 lanes on 8 GPUs are 8 192 per GPU = 128 waves on 1 024 SIMDs, and a
-            # launch per step costs its fixed ~8 us whatever the kernel does (~1.25 x at 8 GPUs). What scales in
-            # that regime is the state-resident path, so it is this mode's headline; the per-step-launch figure stays next to it.
-            out["per_step_launch"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "value_event_timed": out["value_event_timed"]}
-            out["value"] = out["rollout"]["value"]
-            out["ms_per_step"] = 1e3 * total_lanes / out["rollout"]["value"]  # (wall clock over the rollout launches, max over ranks: value's own denominator)
-            out["headline"] = "pf_rollout (k env steps per launch, state resident): the per-step launch sits on the launch floor at batch / N lanes per GPU"
+            out["state_resident_note"] = ("strong scaling leaves batch / N lanes per GPU on the launch floor: `rollout` (pf_rollout, k env steps per launch, "
+                                          "open-loop or on-device actions) is the figure that scales there; `value` stays the per-step launch")
         if args.env == "hover" and world == 1 and not args.no_configs and args.scaling == "weak" and args.batch == 65536 and args.flight_mode == 0 \
                 and not args.no_contact_response and not args.world:
             # BASELINE.json configs 2-4, timed after the headline in the same process (the headline config is configs[4]'s per-GPU
             # slice = 65 536 lanes of Hover; config 1 is the CPU plumbing case: cpu_baseline.single_env_1core)
             out["configs"] = {
+                # (one GPU's best roofline point: eight waves per SIMD's worth of lanes, two resident -- 2 000 steps are 0.1 s)
+                "hover_524288": time_config_guarded("hover", 524288, device, args),
                 "hover_4096": time_config_guarded("hover", 4096, device, args),
                 "quadx_waypoints_65536": time_config_guarded("quadx_waypoints", 65536, device, args),
                 "fixedwing_waypoints_65536": time_config_guarded("fixedwing_waypoints", 65536, device, args),
             }
+            if not args.no_facade:
+                try:
+                    out["facade"] = facade_block(device, args, ms_per_step=out["ms_per_step"])
+                except Exception as e:  # noqa: BLE001  (a reported extra must not take the measured line down)
+                    out["facade"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1 and args.env not in ("dogfight", "ma_hover"):
             try:
                 out["cpu_baseline"] = cpu_baseline(args.env, args.noise, args.cpu_seconds)

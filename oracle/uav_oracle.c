@@ -1596,7 +1596,8 @@ static void env_term_trunc_reward(const orc_params* P, orc_lane* L) {
 /* quadx_base_env.py:149-212 (+ quadx_waypoints_env.py:120-123) */
 /* What an env.reset() draws -- the settle phase's motor noise (stream 1) and the waypoints (stream 2) -- is keyed, for the QuadX
  * Hover / Waypoints tasks, by the event counter AT THE PREVIOUS RESET of the lane (0 before the first), not by the current one
- * (round 5; the fixedwing and PettingZoo tasks keep the current counter). The reference's own generator is a sequential PCG64
+ * (round 5; the fixedwing and PettingZoo tasks keep the current counter). "The counter at the previous reset" is the value that reset
+ * LEFT BEHIND (its counter + 1, round 6): strictly increasing from reset to reset. The reference's own generator is a sequential PCG64
  * stream that no device can follow, so the keying is this restatement's to choose; this choice makes the next episode's initial
  * state a function of something known an episode ahead, which lets the device compute it for many lanes at once while the
  * episode runs instead of for the two or three lanes of a wavefront that restart in a given step (quadx_fast.hpp: spares). */
@@ -1613,7 +1614,10 @@ void orc_env_reset(const orc_params* P, orc_lane* L, uint64_t lane_id, const dou
   const int tpc = P->world.ticks_per_control;
   for (int s = 0; s < P->settle_steps; ++s)
     orc_aviary_step(P, L, xi_reset ? xi_reset + s * tpc : 0, (uint32_t)(s * tpc), 1);
-  if (rekey) { L->rng_ctr = ctr_now; L->reset_key = ctr_now; }
+  /* the NEXT reset's key: the counter as this reset leaves it (ctr_now + 1). Keys are strictly increasing -- a fresh lane's first reset
+   * draws with key 0 and leaves key 1; round 5 stored ctr_now, which is 0 again at the first reset, so that every lane's first and
+   * second episodes drew the same settle noise and the same waypoints. Streams 1 / 2 never meet the step stream 0. */
+  if (rekey) { L->rng_ctr = ctr_now; L->reset_key = ctr_now + 1u; }
   env_compute_state(P, L);
   L->rng_ctr += 1;
 }

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
     step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
     if (TASK != PF_TASK_MA_HOVER) act4[0] = act4[1] = act4[2] = act4[3] = 0.0f;
     nz.begin_event(REKEY ? reset_kw : rng_ctr, 1u, B.xi_reset);
-    if (REKEY) { reset_kw = rng_ctr & 0x7fffffffu; reset_kw_dirty = true; }  // (the NEXT reset's key: the counter at this one)
+    if (REKEY) { reset_kw = (rng_ctr + 1u) & 0x7fffffffu; reset_kw_dirty = true; }  // (the NEXT reset's key: the counter as this reset leaves it -- strictly increasing)
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = P.num_targets;
       tg.n_left = nt;

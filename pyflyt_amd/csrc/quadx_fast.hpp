@@ -1365,8 +1365,8 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       new_dist = fsqrt(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
       if (kYaw) yaw_err0 = __builtin_fabsf(wrap_pi(ytg[0] - yaw_now()));
     }
-    if (REKEY) { rkw = rng_ctr & ~kSpareValid; sp_dirty = true; }  // the NEXT reset's key: the counter at this one; its spare is still to be made
     rng_ctr += 1;
+    if (REKEY) { rkw = rng_ctr & ~kSpareValid; sp_dirty = true; }  // the NEXT reset's key: the counter as this reset leaves it (strictly increasing); its spare is still to be made
     was_reset = true;
   };
   // The next episode's random part for the lanes that ask (wave-uniform call): the draws keyed by `key`, the settle recurrence, the

@@ -15,6 +15,15 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+try:  # the raw handle of torch's current stream without building a torch.cuda.Stream object (0.2 us against 1.5 us per call)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+_PREPARED_MAX, _PREPARED_BYTES = 256, 256 << 20  # action tensors whose prepared buffer blocks an engine keeps alive, at most (an action ring; a policy's output buffer)
+
+
 class BatchEngine:
     """N independent drones ("lanes") on one GPU.
 
@@ -60,6 +69,10 @@ class BatchEngine:
         self.out_aux = None
         self.out_contact = None
         self._buf = L.PfBuffers()
+        self._index = index
+        # env_step's hot path: {id(action tensor): (the tensor, its filled pf_buffers block)} -- see env_step
+        self._prepared: dict[int, tuple] = {}
+        self._step_fn = self.lib.pf_env_step
 
     def close(self):
         if self._ctx:
@@ -164,6 +177,19 @@ class BatchEngine:
         return 6 if (self.params.task == L.TASK_DOGFIGHT and self.params.df_action_dim == 6) else 4
 
     def env_step(self, actions, xi=None, xi_reset=None, u_targets=None):
+        """One env step of every lane: pf_env_step on torch's current stream. Results in self.obs / reward / terminated / truncated
+        (the same tensors every call). The host cost of a call whose `actions` TENSOR OBJECT this engine has seen before -- a
+        policy writing into a fixed buffer, an action ring -- is one dictionary lookup, the raw stream handle and the foreign call:
+        the tensor checks and the ~25 pointer conversions are done once per tensor (the prepared block keeps the tensor alive, so
+        its id cannot be recycled; its address is compared on every call). Capturable in a HIP graph (no host synchronisation, no allocation)."""
+        if xi is None and xi_reset is None and u_targets is None:
+            hit = self._prepared.get(id(actions))
+            if hit is None or hit[3] != actions.data_ptr():  # (a tensor re-pointed in place -- t.data = ..., set_() -- is prepared again)
+                hit = self._prepare(actions)
+            rc = self._step_fn(self._ctx, hit[1], _raw_stream(self._index))  # (the library selects the context's device itself)
+            if rc:
+                L.check(rc, self._ctx)
+            return self.obs, self.reward, self.terminated, self.truncated
         self._check_f32(actions, (self.n, self.action_dim), "actions")
         self._check_f32(xi, (self.ticks_per_step, self.n), "xi")
         self._check_f32(xi_reset, (self.settle_ticks, self.n), "xi_reset")
@@ -172,6 +198,17 @@ class BatchEngine:
         with torch.cuda.device(self.device):
             L.check(self.lib.pf_env_step(self._ctx, C.byref(b), self._stream()), self._ctx)
         return self.obs, self.reward, self.terminated, self.truncated
+
+    def _prepare(self, actions):
+        if not torch.is_tensor(actions):
+            raise ValueError(f"actions must be a float32 tensor of shape {(self.n, self.action_dim)} on {self.device}, got {type(actions).__name__}")
+        self._check_f32(actions, (self.n, self.action_dim), "actions")
+        b = L.PfBuffers()
+        C.memmove(C.byref(b), C.byref(self._buffers(actions=actions)), C.sizeof(L.PfBuffers))
+        if len(self._prepared) >= max(8, min(_PREPARED_MAX, _PREPARED_BYTES // (16 * self.n))):
+            self._prepared.clear()
+        hit = self._prepared[id(actions)] = (actions, C.byref(b), b, actions.data_ptr())
+        return hit
 
     def prepare_step(self, actions):
         """A prepared env step: validates `actions` ([n, action_dim] float32 on the device) and fills the C buffer block ONCE,

@@ -10,6 +10,12 @@ The reference has no vector env; the batch dimension and auto-reset follow gymna
 
 Tensors are torch.float32 / torch.bool on the ROCm device and are views of buffers the kernels
 write in place: copy them if you need them after the next step().
+
+What step() costs the host (round 6): with an action tensor the env has seen before (a policy writing into a fixed buffer, an
+action ring) it is one foreign call -- no tensor check, no pointer conversion, no torch kernel, no allocation, no host
+synchronisation --, so a closed loop `policy(obs) -> env.step(actions)` can be captured whole in a HIP graph. `infos` is a
+LazyInfos: its entries are computed from the flag words of the state when they are READ (like every other value step() returns
+they describe the most recent step).
 """
 from __future__ import annotations
 
@@ -22,6 +28,65 @@ from .. import _lib as L
 from ..engine import BatchEngine
 from ..params import build_params
 from ..spaces import Box, Dict, batch_box
+
+
+class LazyInfos(dict):
+    """The `infos` of a vector env step as a read-only dict whose values are computed when they are read: each is one or two
+    element-wise torch kernels over the lanes' flag words, and a training loop reads them on a small fraction of its steps --
+    computed eagerly they were eight kernel launches per step() against the one launch of the step itself. A key maps to a
+    zero-argument function; the first read calls it and keeps the result until the env's next step() / reset(), which clears
+    the cache (the values describe the MOST RECENT step: read them, or .materialize(), before stepping on if they are to be kept)."""
+
+    __slots__ = ("_make",)
+
+    def __init__(self, makers: dict):
+        super().__init__()
+        self._make = dict(makers)
+
+    # -- the Mapping protocol over the lazy keys
+    def __missing__(self, key):
+        fn = self._make.get(key)
+        if fn is None:
+            raise KeyError(key)
+        v = fn()
+        dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self._make else default
+
+    def __contains__(self, key):
+        return key in self._make
+
+    def __iter__(self):
+        return iter(self._make)
+
+    def __len__(self):
+        return len(self._make)
+
+    def keys(self):
+        return self._make.keys()
+
+    def values(self):
+        return [self[k] for k in self._make]
+
+    def items(self):
+        return [(k, self[k]) for k in self._make]
+
+    def __repr__(self):
+        return "LazyInfos(" + ", ".join(f"{k!r}: " + (repr(dict.__getitem__(self, k)) if dict.__contains__(self, k) else "<lazy>") for k in self._make) + ")"
+
+    def __setitem__(self, key, value):  # (an eager entry: kept across invalidate() only if it is set again)
+        self._make[key] = lambda v=value: v
+        dict.__setitem__(self, key, value)
+
+    def invalidate(self):
+        """Forget the computed values (the env calls this at every step / reset)."""
+        dict.clear(self)
+
+    def materialize(self) -> dict:
+        """A plain dict of freshly computed tensors that the next step() does not touch."""
+        return {k: (v.clone() if torch.is_tensor(v) else (v.materialize() if isinstance(v, LazyInfos) else v)) for k, v in self.items()}
 
 
 class _VecEnvBase:
@@ -51,11 +116,16 @@ class _VecEnvBase:
         self.action_space = batch_box(self.single_action_space, self.num_envs)
         self._make_obs_space()
         self._needs_reset = True
+        self._coerced = None  # (what the last foreign action array was converted into: kept alive until the next one)
 
     # ------------------------------------------------------------------ construction
     def _build(self, seed):
         P = build_params(self._vehicle, self._task, noise=self._noise, autoreset=self._autoreset_mode, seed=seed, **self._kwargs)
         self.engine = BatchEngine(P, self.num_envs, device=self.device, lane_offset=self._lane_offset)
+        # what step() hands back is built ONCE per engine: views of the tensors the kernels write in place + the lazy infos
+        self._ret = None
+        self._infos_obj = None
+        self._final_infos = None
 
     def _make_obs_space(self):
         self.single_observation_space = Box(low=-np.inf, high=np.inf, shape=(self.attitude_dim,), dtype=np.float32)
@@ -80,23 +150,47 @@ class _VecEnvBase:
             mask = torch.as_tensor(np.asarray(mask), dtype=torch.bool, device=self.device)
         self.engine.env_reset(mask=mask)
         self._needs_reset = False
-        return self._obs(self.engine.obs), self._infos()
+        if self._ret is None:
+            self._make_ret()
+        self._infos_obj.invalidate()
+        return self._obs(self.engine.obs) if self._obs_copies else self._ret[0], self._infos_obj
 
-    def step(self, actions):
-        if self._needs_reset:
-            raise RuntimeError("call reset() before step()")
-        if not torch.is_tensor(actions):
-            actions = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.device)
-        actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
-        obs, rew, term, trunc = self.engine.env_step(actions)
+    def _make_ret(self):
+        eng = self.engine
         infos = self._infos()
-        if self.engine.final_obs is not None:
+        if eng.final_obs is not None:
             # SAME_STEP (gymnasium.vector AutoresetMode.SAME_STEP): lanes that finished were re-initialised inside the
             # step, so their terminal observation AND info travel in final_obs / final_info (rows of other lanes are stale)
-            infos["final_obs"] = self._obs(self.engine.final_obs)
-            infos["final_info"] = self._infos(self.engine.final_info[:, 0], self.engine.final_info[:, 1])
-            infos["_final_info"] = term | trunc
-        return self._obs(obs), rew, term, trunc, infos
+            fin = self._infos(eng.final_info[:, 0], eng.final_info[:, 1])
+            infos._make["final_obs"] = lambda: self._obs(eng.final_obs)
+            infos._make["final_info"] = lambda: fin
+            infos._make["_final_info"] = lambda: eng.terminated | eng.truncated
+            self._final_infos = fin
+        else:
+            self._final_infos = None
+        self._infos_obj = infos
+        self._ret = (self._obs(eng.obs), eng.reward, eng.terminated, eng.truncated, infos)
+
+    # (FlattenWaypointEnv with a context longer than the target list pads with zeros: that observation is a fresh tensor per step)
+    _obs_copies = False
+
+    def step(self, actions):
+        """gymnasium.vector.VectorEnv.step: (obs, reward, terminated, truncated, infos) for every env. The five values are the SAME
+        objects every call (views of the buffers the kernel writes, and the lazy infos); nothing here synchronises with the device."""
+        if self._needs_reset:
+            raise RuntimeError("call reset() before step()")
+        if not torch.is_tensor(actions):  # (numpy arrays, lists: one host-to-device copy per step)
+            actions = self._coerced = torch.as_tensor(np.asarray(actions), dtype=torch.float32, device=self.device)
+        elif actions.dtype != torch.float32 or actions.device != self.device or not actions.is_contiguous():
+            actions = self._coerced = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        self.engine.env_step(actions)
+        self._infos_obj.invalidate()
+        if self._final_infos is not None:
+            self._final_infos.invalidate()
+        if self._obs_copies:
+            r = self._ret
+            return self._obs(self.engine.obs), r[1], r[2], r[3], r[4]
+        return self._ret
 
     def close(self):
         self.engine.close()
@@ -110,14 +204,14 @@ class _VecEnvBase:
     def _obs(self, buf):
         return buf
 
-    def _infos(self, flags=None, n_left=None) -> dict[str, Any]:
-        f = self.engine.flags() if flags is None else flags
-        return {
-            "out_of_bounds": (f & L.F_INFO_OOB) != 0,      # quadx_base_env.py:266
-            "collision": (f & L.F_INFO_COLLISION) != 0,    # quadx_base_env.py:260
-            "env_complete": (f & L.F_INFO_COMPLETE) != 0,  # quadx_waypoints_env.py:203
-            "nonfinite": (f & L.F_NONFINITE) != 0,         # NaN/Inf guard (not in the reference, which carries NaNs on silently)
-        }
+    def _infos(self, flags=None, n_left=None) -> LazyInfos:
+        f = self.engine.flags() if flags is None else flags  # (a view of the state's int group: read when an entry is)
+        return LazyInfos({
+            "out_of_bounds": lambda: (f & L.F_INFO_OOB) != 0,      # quadx_base_env.py:266
+            "collision": lambda: (f & L.F_INFO_COLLISION) != 0,    # quadx_base_env.py:260
+            "env_complete": lambda: (f & L.F_INFO_COMPLETE) != 0,  # quadx_waypoints_env.py:203
+            "nonfinite": lambda: (f & L.F_NONFINITE) != 0,         # NaN/Inf guard (not in the reference, which carries NaNs on silently)
+        })
 
     @property
     def step_count(self):
@@ -172,8 +266,12 @@ class _WaypointsMixin:
         infos = super()._infos(flags)
         if n_left is None:
             n_left = self.engine.ints()[:, 3]
-        infos["num_targets_reached"] = self.num_targets - n_left  # quadx_waypoints_env.py:204
+        infos._make["num_targets_reached"] = lambda: self.num_targets - n_left  # quadx_waypoints_env.py:204
         return infos
+
+    @property
+    def _obs_copies(self):
+        return self._flatten and self._context_length > self.num_targets
 
 
 class QuadXWaypointsVecEnv(_WaypointsMixin, _VecEnvBase):

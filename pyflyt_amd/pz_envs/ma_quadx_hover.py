@@ -15,6 +15,14 @@ and the specialised kernel).
 
 `num_envs` independent copies of the whole multi-agent env are stepped at once: dict values are
 tensors of shape [num_envs, ...] (squeezed to the reference's per-agent vectors when num_envs == 1).
+
+What step() costs (round 6). The per-agent values it returns are views, built once, of the tensors the kernel writes; the
+per-agent infos are lazy (gym_envs.vector_envs.LazyInfos). Actions: `env.action_buffers()` hands out, per agent, a view of
+the env's own [num_envs, num_agents, 4] action tensor -- a policy that writes its actions THERE and passes those views back
+costs step() no copy; any other tensor / array is copied into place (one small kernel per agent). Culling (`cull_agents`,
+default True: ma_quadx_base_env.py:365-369) needs the flags on the host: ONE synchronisation per step. With
+`cull_agents=False` the agent list stays whole (the per-copy flags are in terminations / truncations anyway), step() makes
+one foreign call and nothing else, and a whole policy -> step loop can be captured in a HIP graph.
 """
 from __future__ import annotations
 
@@ -25,6 +33,7 @@ import torch
 
 from .. import _lib as L
 from ..engine import BatchEngine
+from ..gym_envs.vector_envs import LazyInfos
 from ..params import build_params, quat_from_euler
 from ..spaces import Box
 
@@ -36,7 +45,7 @@ class MAQuadXHoverEnv:
                  start_orn=np.zeros((4, 3)), sparse_reward: bool = False, flight_mode: int = 0, flight_dome_size: float = 10.0,
                  max_duration_seconds: float = 30.0, angle_representation: str = "quaternion", agent_hz: int = 40,
                  render_mode=None, num_envs: int = 1, device="cuda:0", seed: int = 0, motor_noise: bool = True,
-                 shared_world: bool = False):
+                 shared_world: bool = False, cull_agents: bool = True):
         if render_mode is not None:
             raise ValueError("rendering is out of scope for the batched GPU path")
         start_pos, start_orn = np.asarray(start_pos, dtype=np.float64), np.asarray(start_orn, dtype=np.float64)
@@ -57,6 +66,7 @@ class MAQuadXHoverEnv:
         self._noise = "philox" if motor_noise else "off"
         self._seed = int(seed)
         self.shared_world = bool(shared_world)
+        self.cull_agents = bool(cull_agents)
         if self.shared_world:
             if 64 % self.num_possible_agents != 0:
                 raise ValueError("shared_world=True needs a number of agents that divides 64 (the agents of a world share a wavefront)")
@@ -85,6 +95,19 @@ class MAQuadXHoverEnv:
         side[:, :7] = np.tile(pose, (E, 1))
         st = self.engine.state
         st[12:15] = torch.tensor(side, device=self.device).view(A * E, 3, 4).permute(1, 0, 2)
+        # what step() hands back, built once per engine: per-agent views of the kernel's output tensors, lazy per-agent infos
+        self._act = torch.zeros(E, A, 4, dtype=torch.float32, device=self.device)
+        self._act_flat = self._act.view(E * A, 4)
+        self._act_views = self._split(self._act_flat)
+        o, r = self._split(self.engine.obs), self._split(self.engine.reward)
+        t, u = self._split(self.engine.terminated), self._split(self.engine.truncated)
+        f = self._split(self.engine.flags())
+        self._out = []
+        for i in range(A):
+            infos = LazyInfos({"collision": (lambda fi=f[i]: (fi & L.F_INFO_COLLISION) != 0),
+                               "out_of_bounds": (lambda fi=f[i]: (fi & L.F_INFO_OOB) != 0)})
+            self._out.append((o[i], r[i], t[i], u[i], infos))
+        self._done_all = self.engine.terminated.view(E, A), self.engine.truncated.view(E, A)
 
     def observation_space(self, agent: Any = None):
         return self._observation_space
@@ -94,6 +117,11 @@ class MAQuadXHoverEnv:
 
     def close(self):
         self.engine.close()
+
+    def action_buffers(self) -> dict:
+        """{agent: view [num_envs, 4] (or [4]) of the env's own action tensor}: write the actions here and pass the views to step()
+        -- no copy on the way in."""
+        return {ag: self._act_views[i] for i, ag in enumerate(self.possible_agents)}
 
     def _split(self, t):
         """[E*A, ...] -> per-agent views [E, ...] (squeezed when E == 1)."""
@@ -118,20 +146,32 @@ class MAQuadXHoverEnv:
     # ------------------------------------------------------------------ ma_quadx_base_env.py:309-371
     def step(self, actions: dict):
         A, E = self.num_possible_agents, self.num_envs
-        act = torch.zeros(E, A, 4, dtype=torch.float32, device=self.device)  # current_actions *= 0 (:329)
+        act, views = self._act, self._act_views
+        # current_actions *= 0, then the live agents' actions (:329-332): an agent that is not in `actions` flies on zeros
+        missing = A - len(actions)
         for k, v in actions.items():
-            v = v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v), dtype=torch.float32)
-            act[:, self.agent_name_mapping[k]] = v.to(self.device).view(E, 4)
-        obs, rew, term, trunc = self.engine.env_step(act.view(E * A, 4))
-        o, r, t, u = self._split(obs), self._split(rew), self._split(term), self._split(trunc)
-        f = self._split(self.engine.flags())
+            i = self.agent_name_mapping[k]
+            if v is views[i]:
+                continue  # (written in place by the caller: action_buffers())
+            if not torch.is_tensor(v):
+                v = torch.as_tensor(np.asarray(v), dtype=torch.float32)
+            act[:, i] = v.to(self.device).view(E, 4)
+        if missing:
+            for ag, i in self.agent_name_mapping.items():
+                if ag not in actions:
+                    act[:, i] = 0.0
+        self.engine.env_step(self._act_flat)
+        out = self._out
         observations, rewards, terminations, truncations, infos = {}, {}, {}, {}, {}
         for ag in self.agents:
-            i = self.agent_name_mapping[ag]
-            observations[ag], rewards[ag], terminations[ag], truncations[ag] = o[i], r[i], t[i], u[i]
-            infos[ag] = {"collision": (f[i] & L.F_INFO_COLLISION) != 0, "out_of_bounds": (f[i] & L.F_INFO_OOB) != 0}
+            o = out[self.agent_name_mapping[ag]]
+            observations[ag], rewards[ag], terminations[ag], truncations[ag], infos[ag] = o
+            o[4].invalidate()
         self.step_count += 1
-        # cull finished agents (:365-369); with num_envs > 1 an agent stays listed until it has finished
-        # in every copy (its per-copy flags are in terminations/truncations)
-        self.agents = [ag for ag in self.agents if not bool((terminations[ag] | truncations[ag]).all())]
+        if self.cull_agents:
+            # cull finished agents (:365-369); with num_envs > 1 an agent stays listed until it has finished in every copy (its
+            # per-copy flags are in terminations / truncations). One reduction and one host synchronisation per step for all agents.
+            t, u = self._done_all
+            gone = (t | u).all(dim=0).tolist()
+            self.agents = [ag for ag in self.agents if not gone[self.agent_name_mapping[ag]]]
         return observations, rewards, terminations, truncations, infos

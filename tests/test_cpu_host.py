@@ -191,3 +191,20 @@ def test_integration_md_stub_matches_the_header():
     assert re.findall(r'"(\w+)"', stub) == header_fields
     abi = int(re.search(r"#define PF_ABI_VERSION (\d+)", h).group(1))
     assert [int(v) for v in re.findall(r"pf_abi_version\(\)`? ==? (\d+)", md)] == [abi, abi]
+
+
+def test_bench_gpus_n_never_runs_as_one_process():
+    """`python bench.py --gpus 8` without a torchrun environment must start eight ranks or refuse (round 5's read WORLD_SIZE,
+    found 1 and reported a one-GPU line under the eight-GPU command). Here there is no device at all: it refuses, non-zero, no line."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PF_BENCH_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "refusing" in r.stderr and "8-GPU label" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # a torchrun environment that disagrees with --gpus is an error as well, not a silent relabel
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -314,3 +314,142 @@ def test_examples_run(script, args):
     out = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip()
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 6: the facade's own cost
+def _eager_infos(env):
+    """What round 5's step() computed eagerly, from the state's flag words."""
+    from pyflyt_amd import _lib as L
+
+    f = env.engine.flags()
+    d = {"out_of_bounds": (f & L.F_INFO_OOB) != 0, "collision": (f & L.F_INFO_COLLISION) != 0,
+         "env_complete": (f & L.F_INFO_COMPLETE) != 0, "nonfinite": (f & L.F_NONFINITE) != 0}
+    if hasattr(env, "num_targets"):
+        d["num_targets_reached"] = env.num_targets - env.engine.ints()[:, 3]
+    return d
+
+
+@pytest.mark.parametrize("env_id", IDS)
+@pytest.mark.parametrize("autoreset", ["next_step", "same_step"])
+def test_lazy_infos_equal_the_eager_values(env_id, autoreset):
+    """infos is computed when it is read: every entry equals what the eager dictionary held, at every step, and the set of keys,
+    `in`, iteration and .items() behave like the dictionary's."""
+    from pyflyt_amd import _lib as L
+    from pyflyt_amd.gym_envs import make_vec
+    from pyflyt_amd.gym_envs.vector_envs import LazyInfos
+
+    n = 512
+    env = make_vec(env_id, n, seed=3, autoreset_mode=autoreset)
+    _, info0 = env.reset(seed=3)
+    assert isinstance(info0, LazyInfos) and isinstance(info0, dict)
+    flagged = 0
+    for k in range(150):
+        obs, rew, term, trunc, info = env.step(env.sample_actions(k))
+        want = _eager_infos(env)
+        assert set(info) == set(want) | ({"final_obs", "final_info", "_final_info"} if autoreset == "same_step" else set())
+        for key, v in want.items():
+            assert key in info and torch.equal(info[key], v), key
+        assert dict(info.items()).keys() == set(info.keys()) and info.get("no_such_key", 7) == 7
+        if autoreset != "same_step":
+            flagged += int(info["collision"].sum() + info["out_of_bounds"].sum() + info["env_complete"].sum())
+        if autoreset == "same_step":
+            done = term | trunc
+            assert torch.equal(info["_final_info"], done)
+            fi = info["final_info"]
+            f = env.engine.final_info[:, 0]
+            assert torch.equal(fi["collision"], (f & L.F_INFO_COLLISION) != 0) and torch.equal(fi["out_of_bounds"], (f & L.F_INFO_OOB) != 0)
+            if done.any():  # a finished lane's terminal info names the reason (its own flags were cleared by the in-step reset)
+                assert (fi["collision"] | fi["out_of_bounds"] | fi["env_complete"] | trunc)[done].all()
+                flagged += int((fi["collision"] | fi["out_of_bounds"] | fi["env_complete"])[done].sum())
+        kept = info.materialize()
+        assert all(torch.equal(kept[key], want[key]) for key in want)
+    assert flagged > 0
+    env.close()
+
+
+def test_step_returns_the_same_objects_and_launches_one_kernel():
+    """step() hands back the same five objects every call (views of what the kernel writes + the lazy infos), and with a known
+    action tensor it is ONE kernel launch: no torch kernel, nothing allocated (torch.profiler sees exactly one device kernel per
+    step, the env kernel)."""
+    from pyflyt_amd.gym_envs import make_vec
+
+    n = 4096
+    env = make_vec("PyFlyt/QuadX-Hover-v4", n, seed=1)
+    env.reset(seed=1)
+    acts = [env.sample_actions(k) for k in range(8)]
+    first = env.step(acts[0])
+    for k in range(1, 8):
+        again = env.step(acts[k])
+        assert all(a is b for a, b in zip(first, again))
+    assert len(env.engine._prepared) == 8  # one prepared buffer block per action tensor seen
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated()
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for k in range(16):
+                env.step(acts[k % 8])
+            torch.cuda.synchronize()
+        names = [e.name for e in prof.events() if e.device_type.name in ("CUDA", "PrivateUse1") or "kernel" in e.name.lower()]
+        kernels = [x for x in names if "Memcpy" not in x and "Memset" not in x]
+    except Exception as e:  # noqa: BLE001  (no roctracer on the box: the allocation check below still runs)
+        kernels = None
+        print(f"torch.profiler unavailable: {e}")
+    assert torch.cuda.memory_allocated() == mem0
+    if kernels:
+        assert len(kernels) == 16 and all("quadx_m0_env_kernel" in x for x in kernels), kernels[:4]
+    # a tensor re-pointed in place is prepared again (its id is the same, its address is not)
+    t = acts[0]
+    t.data = acts[1].clone()
+    env.step(t)
+    assert env.engine._prepared[id(t)][3] == t.data_ptr()
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", IDS)
+def test_closed_loop_captured_in_a_hip_graph(env_id):
+    """policy(obs) -> env.step(actions) captured whole in a HIP graph: replaying it gives, bit for bit, what the same loop gives eagerly
+    on a second env with the same seed -- through episode ends and the in-kernel resets (nothing in step() synchronises or allocates)."""
+    from pyflyt_amd.gym_envs import make_vec
+
+    n, g, reps = 2048, 12, 6
+    envs = [make_vec(env_id, n, seed=9) for _ in range(2)]
+    obs = [flat(e.reset(seed=9)[0]) for e in envs]
+    assert torch.equal(obs[0], obs[1])
+    D = obs[0].shape[1]
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    W = torch.randn(D, 4, device="cuda", generator=gen) * 0.3
+    lo = torch.tensor(envs[0].single_action_space.low, device="cuda")
+    hi = torch.tensor(envs[0].single_action_space.high, device="cuda")
+    acts = [torch.zeros(n, 4, device="cuda") for _ in range(2)]
+
+    def loop(e, a, k):
+        out = None
+        for _ in range(k):
+            o = e.engine.obs[:, :D]
+            torch.mm(o, W, out=a)
+            torch.clamp(a, min=lo, max=hi, out=a)
+            out = e.step(a)
+        return out
+
+    loop(envs[0], acts[0], 2); loop(envs[1], acts[1], 2)  # (both prepared and two steps in)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            loop(envs[0], acts[0], g)
+        stream.synchronize()
+    ends = 0
+    for r in range(reps):
+        graph.replay()
+        torch.cuda.synchronize()
+        o1, r1, t1, u1, i1 = loop(envs[1], acts[1], g)
+        torch.cuda.synchronize()
+        assert torch.equal(envs[0].engine.obs, envs[1].engine.obs) and torch.equal(envs[0].engine.reward, r1)
+        assert torch.equal(envs[0].engine.terminated, t1) and torch.equal(envs[0].engine.truncated, u1)
+        assert torch.equal(envs[0].engine.state[:7], envs[1].engine.state[:7])
+        ends += int((t1 | u1).sum())
+    assert ends > 0  # the random linear policy crashes drones: the graph went through resets
+    for e in envs:
+        e.close()

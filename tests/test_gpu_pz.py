@@ -249,3 +249,88 @@ def test_partial_reset_mask_is_widened_to_the_world(monkeypatch, kernel):
     assert (steps[4:8] == 0).all() and (steps[:4] == 5).all() and (steps[8:] == 5).all(), steps
     others = [i for i in range(n) if not 4 <= i < 8]
     assert torch.equal(eng.state[:12, others], before[:12, others])
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 6: the facade's own cost
+@pytest.mark.parametrize("shared", [False, True])
+def test_action_buffers_and_no_cull_path_equals_the_dict_path(shared):
+    """step() fed with the env's own action views (action_buffers(): no copy in), culling off (no host synchronisation), against
+    a second env fed with numpy arrays through the copying path and culling on: same observations, rewards, flags and lazy infos,
+    bit for bit; the culled env's agent list shrinks, the other's stays whole."""
+    from pyflyt_amd import _lib as L
+    from pyflyt_amd.pz_envs import MAQuadXHoverEnv
+
+    E = 32
+    kw = dict(num_envs=E, seed=2, flight_dome_size=2.2, max_duration_seconds=1.0, shared_world=shared)
+    fast, ref = MAQuadXHoverEnv(cull_agents=False, **kw), MAQuadXHoverEnv(**kw)
+    o1, _ = fast.reset(seed=2)
+    o2, _ = ref.reset(seed=2)
+    bufs = fast.action_buffers()
+    assert set(bufs) == set(fast.possible_agents) and all(v.shape == (E, 4) for v in bufs.values())
+    rng = np.random.default_rng(1)
+    ended = 0
+    for k in range(60):
+        acts = {a: np.concatenate([rng.uniform(-1, 1, size=(E, 3)), rng.uniform(0.2, 0.75, size=(E, 1))], 1).astype(np.float32) for a in fast.possible_agents}
+        for a in fast.possible_agents:
+            bufs[a].copy_(torch.from_numpy(acts[a]))
+        f = fast.step(bufs)
+        # the reference zeroes a culled agent's action (ma_quadx_base_env.py:329): the culling env is fed its live agents only, the
+        # other one is handed zeros for the same agents so that the two worlds stay the same
+        live = list(ref.agents)
+        for a in fast.possible_agents:
+            if a not in live:
+                bufs[a].zero_()
+        if len(live) < len(fast.possible_agents):
+            f = None  # (this step's actions differed for the culled agents: compare from the next step on)
+        r = ref.step({a: acts[a] for a in live})
+        if f is not None:
+            for a in live:
+                for x, y in zip(f[:4], r[:4]):
+                    assert torch.equal(x[a], y[a]), (k, a)
+                assert torch.equal(f[4][a]["collision"], r[4][a]["collision"]) and torch.equal(f[4][a]["out_of_bounds"], r[4][a]["out_of_bounds"])
+                fl = fast._split(fast.engine.flags())[fast.agent_name_mapping[a]]
+                assert torch.equal(f[4][a]["collision"], (fl & L.F_INFO_COLLISION) != 0)
+                ended += int((r[2][a] | r[3][a]).sum())
+        assert fast.agents == fast.possible_agents
+        if not ref.agents:
+            break
+    assert ended > 0 and len(ref.agents) < len(ref.possible_agents)  # (max_duration 1 s: every copy truncates together at step 41)
+    fast.close(); ref.close()
+
+
+def test_ma_step_captured_in_a_hip_graph():
+    """The PettingZoo step with cull_agents=False inside a HIP graph (policy -> action_buffers -> step): replays equal the eager loop."""
+    from pyflyt_amd.pz_envs import MAQuadXHoverEnv
+
+    E, g = 256, 10
+    envs = [MAQuadXHoverEnv(num_envs=E, seed=5, cull_agents=False) for _ in range(2)]
+    for e in envs:
+        e.reset(seed=5)
+    W = torch.zeros(24, 4, device="cuda")
+    W[0, 0] = W[1, 1] = W[2, 2] = -0.2
+    W[12, 3] = -0.3
+    b = torch.tensor([0.0, 0.0, 0.0, 0.68], device="cuda")
+
+    def loop(e, k):
+        bufs = e.action_buffers()
+        for _ in range(k):
+            torch.addmm(b, e.engine.obs, W, out=e._act_flat)
+            out = e.step(bufs)
+        return out
+
+    loop(envs[0], 1); loop(envs[1], 1)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            loop(envs[0], g)
+        stream.synchronize()
+    for r in range(4):
+        graph.replay()
+        o, rw, t, u, info = loop(envs[1], g)
+        torch.cuda.synchronize()
+        assert torch.equal(envs[0].engine.obs, envs[1].engine.obs) and torch.equal(envs[0].engine.reward, envs[1].engine.reward)
+        assert torch.isfinite(o["uav_0"]).all()
+    for e in envs:
+        e.close()

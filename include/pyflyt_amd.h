@@ -225,7 +225,11 @@ typedef struct pf_params {
  * library between calls: besides the lane's physical state it holds what the kernels prepare ahead -- for the QuadX Hover /
  * Waypoints tasks groups 7-11 carry the lane's "spare" (the random part of its NEXT episode: settled spawn state, targets) and the key
  * its next reset draws from. A caller that writes a state by hand clears bit 31 of group 7's fourth word (group 11's third in the
- * cascaded flight modes) and leaves the key in bits 0-30: the kernels then generate at the reset. */
+ * cascaded flight modes) and leaves the key in bits 0-30: the kernels then generate at the reset. A spare is only valid for the
+ * context that made it (seed, lane offset, spawn pose, settle length, dome, number of targets): pf_env_reset with a NULL mask -- every
+ * lane -- therefore ignores the spares it finds and prepares fresh ones, which is what a caller does first with a state buffer that
+ * another context has used; a MASKED reset trusts them. The key is the event counter as the lane's previous reset left it: strictly
+ * increasing from reset to reset (0 before the first). */
 typedef struct pf_buffers {
   float* state;            /* [pf_state_groups()][n][4] fp32/int32, persistent */
   const float* actions;    /* [n][4]   gym action (quadx_base_env.py:269); PF_TASK_DOGFIGHT with df_action_dim 6: [n][6] */

@@ -225,8 +225,8 @@ __global__ void __launch_bounds__(64) dogfight_env_kernel(const pf_params P, con
     //  pair stage included, until it has come to rest anew; wrecks frozen by the opt-in df_freeze_wrecks stay where they are)
     bool wreck = (df & (DF_AT_REST | DF_FROZEN)) != 0;
     for (int t = 0; t < P.ticks_per_control; ++t) {
-      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev, wreck, rec);
-      if (wreck && V.b.woken && (df & DF_FROZEN) == 0) { wreck = false; df &= ~(DF_AT_REST | DF_REST_MASK); }
+      world_exchange(V.b, wpose, tid, A, P.bound_radius, Pdev, wreck, rec, (df & DF_FROZEN) != 0);
+      if (wreck && V.b.woken) { wreck = false; df &= ~(DF_AT_REST | DF_REST_MASK); }  // (a frozen wreck is never woken)
       if (!wreck) V.tick(P, nz.get(flat_base + t));
     }
     if (wreck) V.b.contact_step = V.b.contact_now;

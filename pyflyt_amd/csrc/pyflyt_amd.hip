@@ -771,7 +771,7 @@ struct pf_ctx {
   char err[256];
   // hot-path specialisation (quadx_fast.hpp)
   bool fast;
-  uint32_t step_calls;  // env steps taken so far (pf_env_step: +1, pf_rollout: +k): the cadence the QuadX kernels refill their spares on (quadx_fast.hpp: QuadSpare)
+  uint32_t* launch_ctr;  // device, one word per workgroup of the specialised QuadX kernel: env steps taken so far -- the cadence its waves refill their spares on (quadx_fast.hpp: QuadSpare)
   bool one_wave; // the batch is at most one wave per SIMD of the device (the 512-register instantiations' condition)
   bool lean;     // the batch is at most one wave per SIMD of the device: the specialised QuadX kernel's 512-register instantiation
   pf::QuadK K;
@@ -807,8 +807,8 @@ static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t*
   // (the one-wave-per-SIMD instantiation -- quadx_fast.hpp, WPS -- where the batch is no more than that and the kernel has it; since
   //  round 5 the cascaded flight modes as well: their fp64 controller needs the 512 registers -- 408 B of stack per lane under 256)
 #define PF_FAST4(NZ, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
-    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u, ctx->step_calls); \
-    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u, ctx->step_calls); } while (0)
+    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u, ctx->launch_ctr); \
+    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u, ctx->launch_ctr); } while (0)
   // (flight modes other than 0: the MODES instantiation, contact response compiled in -- quadk_from_params)
   // (shared worlds: PF_TASK_MA_HOVER with the contact response on -- quadk_from_params)
 #define PF_FAST3(NZ, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_FAST4(NZ, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_FAST4(NZ, CR, MD, false); } while (0)
@@ -824,8 +824,8 @@ template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
 #define PF_ROLL4(NZ, R, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
-    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0, ctx->step_calls); \
-    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0, ctx->step_calls); } while (0)
+    if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0, ctx->launch_ctr); \
+    else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0, ctx->launch_ctr); } while (0)
 #define PF_ROLL3(NZ, R, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_ROLL4(NZ, R, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_ROLL4(NZ, R, CR, MD, false); } while (0)
 #define PF_ROLL(NZ, R) do { if (ctx->K.mode != 0) PF_ROLL3(NZ, R, true, true); else if (ctx->P.contact_response) PF_ROLL3(NZ, R, true, false); else PF_ROLL3(NZ, R, false, false); } while (0)
   if (b->actions == nullptr) {
@@ -932,7 +932,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
     return fail(nullptr, PF_ERR_ARG, "the contact model's distances, threshold, erp, friction and restitution must be >= 0");
   pf_ctx* c = new (std::nothrow) pf_ctx;
   if (!c) return fail(nullptr, PF_ERR_ARG, "out of host memory");
-  c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0; c->step_calls = 0u;
+  c->P = P; c->n = n_lanes; c->device = device; c->lane0 = lane_offset; c->err[0] = 0; c->launch_ctr = nullptr;
   {  // the airframe's worst-case contact count (collider vertices), see pf_params.contact_max_points
     int pts = 0;
     for (int k = 0; k < P.n_boxes; ++k) pts += P.boxes[k].kind == 1 ? 16 : (P.contact_manifold_points >= 8 ? 8 : 4);
@@ -963,12 +963,17 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
       if (c->fast) pf::quad_solve_words(c->P, sw);
       e = hipMemcpy(reinterpret_cast<char*>(c->P_dev) + pf::kQuadSolveOffset, sw, sizeof(sw), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && c->fast) {  // (quadx_fast.hpp: launch_ctr)
+      const size_t words = ((size_t)n_lanes + 63) / 64;
+      e = hipMalloc((void**)&c->launch_ctr, sizeof(uint32_t) * words);
+      if (e == hipSuccess) e = hipMemset(c->launch_ctr, 0, sizeof(uint32_t) * words);
+    }
     if (e == hipSuccess && (c->fast_fw || c->df_fast)) {
       e = hipMalloc((void**)&c->surf_dev, sizeof(fsurf));
       if (e == hipSuccess) e = hipMemcpy(c->surf_dev, &fsurf, sizeof(fsurf), hipMemcpyHostToDevice);
     }
     if (cur >= 0) (void)hipSetDevice(cur);
-    if (e != hipSuccess) { if (c->P_dev) hipFree(c->P_dev); delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
+    if (e != hipSuccess) { if (c->P_dev) hipFree(c->P_dev); if (c->launch_ctr) hipFree(c->launch_ctr); delete c; return hip_fail(nullptr, e, "pf_ctx_create: device parameter block"); }
   }
   if (!c->fast && (P.task == PF_TASK_HOVER || P.task == PF_TASK_WAYPOINTS) &&
       (P.vehicle == PF_FIXEDWING || P.noise_mode == PF_NOISE_OFF)) {
@@ -994,6 +999,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
 void pf_ctx_destroy(pf_ctx* ctx) {
   if (!ctx) return;
   if (ctx->P_dev) hipFree(ctx->P_dev);
+  if (ctx->launch_ctr) hipFree(ctx->launch_ctr);
   if (ctx->tmpl) hipFree(ctx->tmpl);
   if (ctx->surf_dev) hipFree(ctx->surf_dev);
   delete ctx;
@@ -1052,7 +1058,6 @@ static int launch_env(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* m
     launch_env_t<pf::Fixedwing, PF_TASK_WAYPOINTS>(ctx, b, op, mask, s);
   }
   PF_HIP(ctx, hipGetLastError());
-  if (op == pf::OP_STEP) ctx->step_calls += 1u;  // (the QuadX kernels' spare-refill cadence: quadx_fast.hpp, QuadSpare)
   return PF_OK;
 }
 int pf_env_reset(pf_ctx* ctx, const pf_buffers* b, const uint8_t* mask, void* stream) {
@@ -1184,7 +1189,6 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
       launch_env_t<pf::Fixedwing, PF_TASK_WAYPOINTS>(ctx, b, pf::OP_STEP, nullptr, s, k_steps, step_index0);
     }
     PF_HIP(ctx, hipGetLastError());
-    ctx->step_calls += (uint32_t)k_steps;
     return PF_OK;
   }
   // (the PettingZoo task has no auto-reset: finished agents are culled by the caller, their drones fly on in the shared world)
@@ -1198,7 +1202,6 @@ int pf_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step_inde
   else if (P.task == PF_TASK_MA_HOVER) launch_rollout<PF_TASK_MA_HOVER>(ctx, b, k_steps, step_index0, s);
   else launch_rollout<PF_TASK_WAYPOINTS>(ctx, b, k_steps, step_index0, s);
   PF_HIP(ctx, hipGetLastError());
-  ctx->step_calls += (uint32_t)k_steps;
   return PF_OK;
 }
 int pf_body_tick(pf_ctx* ctx, const pf_buffers* b, int n_ticks, void* stream) {

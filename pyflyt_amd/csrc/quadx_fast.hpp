@@ -286,19 +286,11 @@ inline void quad_solve_words(const pf_params& P, float (&w)[kQuadSolveWords]) { 
 }
 PF_DEV QuadSolveC quad_solve_consts(const pf_params* Pg) {
   QuadSolveC c;
-#if defined(PF_SOLVE_CONSTS_COMPUTE)  // (A/B: derive them in the kernel from the parameter block)
-  c.inv_dt = 1.0f / Pg->dt; c.rest = Pg->contact_restitution; c.mu = Pg->contact_friction; c.res = __builtin_sqrtf(Pg->contact_residual_threshold);
-  c.inv_mass = Pg->inv_mass;
-  c.sqI[0] = __builtin_sqrtf(Pg->I_own[0]); c.sqI[1] = __builtin_sqrtf(Pg->I_own[3]); c.sqI[2] = __builtin_sqrtf(Pg->I_own[5]);
-  c.siI[0] = __builtin_sqrtf(Pg->I_inv[0]); c.siI[1] = __builtin_sqrtf(Pg->I_inv[3]); c.siI[2] = __builtin_sqrtf(Pg->I_inv[5]);
-  c.iters = Pg->contact_iters;
-#else
   typedef const float __attribute__((address_space(4)))* kfptr;
   const kfptr q = (kfptr)(uintptr_t)(reinterpret_cast<const char*>(Pg) + kQuadSolveOffset);
   c.inv_dt = q[0]; c.rest = q[1]; c.mu = q[2]; c.res = q[3]; c.inv_mass = q[4];
   c.sqI[0] = q[5]; c.sqI[1] = q[6]; c.sqI[2] = q[7]; c.siI[0] = q[8]; c.siI[1] = q[9]; c.siI[2] = q[10];
   c.iters = __float_as_int(q[11]);
-#endif
   return c;
 }
 struct QuadFace {  // the incident face of the collision box at this pose (uav_vehicles.hpp: box_contact_vertices)
@@ -862,27 +854,28 @@ struct QuadSpare {
 // loop then contains NO vector-memory load, so nothing in it ever waits on vmcnt (on gfx9 stores count in vmcnt too: a
 // load in the loop would make every step wait for the previous step's observation stores to be acknowledged);
 // 2 = pf_rollout over a given action sequence (prefetched one step ahead; pays that wait).
-// PF_WPB wavefronts per workgroup (each wave works on its own 64 lanes and its own slice of the LDS arrays; there is no barrier
-// and no inter-wave traffic): the dispatcher launches workgroups, not waves, at a limited rate -- with one wave per workgroup the
-// 1 024 workgroups of a 65 536-lane launch enter over 2.5 us (profiles/r03/phase_trace_*.txt).
-#ifndef PF_WPB
-#define PF_WPB 1
-#endif
-constexpr int kQuadWPB = PF_WPB;
+// One wavefront per workgroup: no barrier, no inter-wave traffic. (Multi-wave workgroups were measured in round 3 and dropped --
+// profiles/r06/experiments/ab_switches.patch has the switch; the index arithmetic below keeps the general form.)
+constexpr int kQuadWPB = 1;
 // MODES: false = flight mode 0 only; true = the flight mode is K.mode, -1 .. 7 (cascaded PIDs; their memories in state groups
 // 7-11 and, at reset, the z PIDs inside the settle recurrence).
 // SHARED (PF_TASK_MA_HOVER only): the K.apw agents of an env share one world (pose / contact exchange before every tick).
 // WPS: the waves per SIMD the register budget is sized for. 2 (256 registers): every batch. 1 (512 registers, the contact solve
 // inlined: no stack): chosen by the launcher for batches of at most one wave per SIMD, where a second resident wave would have
 // nothing to run -- 11.6 -> 11.2 us per hover step at 65 536 lanes; at 524 288 lanes, 71 us against 57 us with two waves resident.
+// (the shared-world instantiations need more than 256 registers whatever they are asked for -- the compiler's "desired occupancy
+//  was 2, final occupancy is 1" in rounds 4 / 5 --: their budget says so)
 template <int TASK, int NOISE, int LPW, int ROLL, bool CR, bool MODES = false, bool SHARED = false, int WPS = 2>
-__global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
+__global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_kernel(const QuadK K, const pf_buffers B, const pf_params* __restrict__ Pfull,
                                                              const int n, const uint64_t lane0, const int op,
                                                              const uint8_t* __restrict__ mask, const int k_steps, const uint32_t step0,
-                                                             const uint32_t call0) {
+                                                             uint32_t* launch_ctr) {
   constexpr bool ROLLOUT = ROLL != 0;
-  // (see QuadSpare) REKEY: a reset's draws are keyed by the counter at the previous reset; SPARE: ... and prepared ahead. call0: how many
-  // env steps this context had taken when the launch was issued (the refill cadence is a function of that count alone)
+  // (see QuadSpare) REKEY: a reset's draws are keyed by the counter at the previous reset; SPARE: ... and prepared ahead. launch_ctr: one
+  // word per workgroup in device memory, the env steps this context has taken -- the refill cadence is a function of that count alone.
+  // It is DEVICE state (round 5 passed the host's count as a kernel argument, which a HIP-graph capture bakes in: a captured
+  // single step replayed for ever either never refilled or refilled in every launch -- ADVICE r05): every workgroup reads its own
+  // word with the state groups and writes it back advanced by the steps it took, so all workgroups of a launch see the same count.
   constexpr bool REKEY = TASK == PF_TASK_HOVER || TASK == PF_TASK_WAYPOINTS;
   constexpr bool SPARE = REKEY && !MODES && !SHARED && NOISE != PF_NOISE_INJECT;
   typedef QuadSpare Sp;
@@ -927,19 +920,14 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   const pf_params_kptr Pk = uniform_params(Pfull);
   // (see the calm test below)
   constexpr bool CALM = CR && !SHARED && !MODES && NOISE != PF_NOISE_INJECT;
-#ifdef PF_NO_KV  // (A/B switch: the calm ticks on the scalar constants)
-  const QuadK& KV = K;
-#define PF_KV_T QuadK
-#else
   QuadKV KV{};
   if (CALM) KV = quadkv_from(K);
-#define PF_KV_T QuadKV
-#endif
   float tgt[4][3];
   float new_dist, old_dist;
   int step_count, flags, n_left;
   uint32_t rng_ctr;
   f8 zn;  // this step's motor-noise normals (Philox call 0 of the event)
+  uint32_t call0 = 0u;     // (SPARE) env steps this context had taken before this launch (launch_ctr)
   uint32_t rkw = 0u;       // (REKEY) the reset key word: key in bits 0-30, bit 31 = the spare's values are valid
   bool sp_dirty = false;   // ... changed in this launch: goes back to the state
   uint32_t reset_key_now = 0u;  // the key of the reset at hand (do_resets)
@@ -952,31 +940,18 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     float4 gi = Sin[6 * N + li];
     float4 g0 = Sin[0 * N + li], g1 = Sin[1 * N + li], g2 = Sin[2 * N + li], g3 = Sin[3 * N + li], g4 = Sin[4 * N + li],
            g5 = Sin[5 * N + li];
-#ifndef PF_SPARE_LAZY_LOAD
     // (SPARE: the lane's spare with the state groups -- requested behind the int group's arrival it came 0.4 us late for the resets)
     float4 gs7 = float4{0.f, 0.f, 0.f, 0.f};
     if (SPARE) gs7 = Sin[7 * N + li];
-#endif
-#ifndef PF_NO_ACTION_PREFETCH
+    if (SPARE) {  // (a VECTOR load behind the state groups, in their order: as a scalar load it would sit in every lgkmcnt wait that follows)
+      const uint32_t* cp = launch_ctr + blockIdx.x;
+      asm volatile("" : "+v"(cp));
+      call0 = *cp;
+    }
     // the action is first needed after the resets, a microsecond from here: requested where it is used (inside the stepping
     // lanes' branch) every wave sat out its whole memory latency there; requested behind the state groups it is long there
     if (ROLL == 0 && op == 0) a_pre = reinterpret_cast<const float4*>(B.actions)[li];
-#endif
-#ifndef PF_NO_CODE_WARM
     if (CR && blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch(tid);  // (behind the state loads: one wait for both)
-#endif
-#ifdef PF_PARAM_WARM  // (off: with the solve inlined or rare, the wait in front of the first state word cost every wave 0.5 us -- profiles/README.md, r03)
-  if (CR) {
-    // Warm the scalar cache with the four lines of the parameter block the contact solve reads (bytes 64 .. 319: contact model,
-    // mass properties, the collision box). In the hover task a solve is rare -- a handful of single-lane calls per 65 536-lane
-    // launch -- and the launch lasts as long as its slowest wave: cold, every dependent scalar load of that call went to L2.
-    // Issued behind the state loads, they share their wait. (The wait is inside the statement: the compiler does not
-    // track loads issued by inline assembly.)
-    uint32_t w0, w1, w2, w3;
-    asm volatile("s_load_dword %0, %4, 0x40\n\ts_load_dword %1, %4, 0x80\n\ts_load_dword %2, %4, 0xc0\n\ts_load_dword %3, %4, 0x100\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(w0), "=s"(w1), "=s"(w2), "=s"(w3) : "s"(Pk) : "memory");
-  }
-#endif
     rng_ctr = (uint32_t)__float_as_int(gi.z);
     PF_STAMP(1);  // (the int group has arrived)
     if (REKEY) {
@@ -987,21 +962,15 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       // (SPARE: every lane, every launch -- 16 B a lane in Hover, 80 B in Waypoints that only the restarting lanes use. Requested
       //  by those lanes alone, once their flags are here, the words came from HBM and not from the cache the state groups of the
       //  previous launch still sit in: 2.8 us in front of the reset, as long as generating them had taken -- profiles/r05)
-#ifdef PF_SPARE_LAZY_LOAD
-      const bool need_sp = ROLLOUT || in11 || op == 1 || K.autoreset == PF_AUTORESET_SAME_STEP ||
-                           (SPARE && (call0 % kSpareEvery) == kSpareEvery - 1u) ||
-                           (__float_as_int(gi.y) & (PF_F_TERMINATED | PF_F_TRUNCATED)) != 0;
-#else
       const bool need_sp = SPARE || ROLLOUT || in11 || op == 1 || K.autoreset == PF_AUTORESET_SAME_STEP ||
                            (__float_as_int(gi.y) & (PF_F_TERMINATED | PF_F_TRUNCATED)) != 0;
-#endif
       if (need_sp) {
-#ifndef PF_SPARE_LAZY_LOAD
         const float4 gk = SPARE ? gs7 : Sin[(size_t)(in11 ? 11 : 7) * N + li];
-#else
-        const float4 gk = Sin[(size_t)(in11 ? 11 : 7) * N + li];
-#endif
         rkw = (uint32_t)__float_as_int(in11 ? gk.z : gk.w);
+        // pf_env_reset of EVERY lane (null mask): the spares in the state are not trusted -- a state buffer may come from another
+        // context (other seed, lane offset, spawn pose, settle length, dome, number of targets) with bit 31 set; this reset generates
+        // on the spot and the refill below prepares fresh ones (include/pyflyt_amd.h at pf_env_reset)
+        if (SPARE && op == 1 && mask == nullptr) rkw &= ~kSpareValid;
         if (SPARE) {
           spv.z = gk.x; spv.vz = gk.y; spv.thr = gk.z;
           // (the targets' four groups behind the int group: in front of it, with the state groups, they cost the Waypoints launch
@@ -1103,9 +1072,6 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   // (Injected draws -- B.xi_reset, B.u_targets -- keep the per-lane paths.)
   const bool coop_targets = (TASK == PF_TASK_WAYPOINTS) && !((NOISE == PF_NOISE_INJECT) && (B.u_targets != nullptr));
   auto prepare_reset_draws = [&](const bool reset_now, const uint32_t key) {
-#ifdef PF_EXP_CHEAP_RESET  // (experiment, never shipped: what would a reset cost if its random state came precomputed?)
-    return;
-#endif
     const bool want_noise = NOISE == PF_NOISE_PHILOX;
     if (!want_noise && !coop_targets) return;
     const unsigned long long m = __ballot(reset_now);
@@ -1199,9 +1165,6 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
       else x = float4{0.f, 0.f, 0.f, 0.f};
       return x;
     };
-#ifdef PF_EXP_CHEAP_RESET
-    if (!MODES || K.mode == 0) { z -= 0.0358f; vz = -0.8f; thr = 0.048f; } else
-#endif
     if (!MODES || K.mode == 0) {
       // Mode 0: the motor command is the constant 0.05, so the throttle recurrence does not depend on the vertical state and the
       // 20 ticks are TWO dependency chains -- throttle (3 instructions per tick) and climb rate (3-4 per tick):
@@ -1291,20 +1254,6 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
       const int nt = K.num_targets;
       n_left = nt;
-#ifdef PF_EXP_CHEAP_RESET
-      if (coop_targets) {
-        uint32_t h = (uint32_t)(lane0 + li) * 2654435761u + rng_ctr * 40503u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (i < nt) {
-            tgt[i][0] = (float)((h >> 0) & 255u) * (4.0f / 255.0f) - 2.0f; tgt[i][1] = (float)((h >> 8) & 255u) * (4.0f / 255.0f) - 2.0f;
-            tgt[i][2] = (float)((h >> 16) & 255u) * (2.0f / 255.0f) + 0.1f;
-            if (kYaw) ytg[i] = (float)((h >> 24) & 255u) * (6.0f / 255.0f) - 3.0f;
-            h = h * 1664525u + 1013904223u;
-          }
-        }
-      } else
-#endif
       if (SPARE && have_pre) {  // prepared ahead (make_spare)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1488,6 +1437,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   };
 
   const int KS = ROLLOUT ? k_steps : 1;
+  const uint32_t call0_u = SPARE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)call0) : 0u;  // (the same word in every lane: wave-uniform control flow below)
   float4 a_nxt = float4{0.f, 0.f, 0.f, 0.f};
   if (GIVEN) a_nxt = reinterpret_cast<const float4*>(B.actions)[li];
   for (int it = 0; it < KS; ++it) {
@@ -1500,7 +1450,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   reward = 0.0f;
   was_reset = false;
   do_resets(do_reset);
-  refill_spares(op == 1 || ((call0 + (uint32_t)it) % kSpareEvery) == kSpareEvery - 1u);
+  refill_spares(op == 1 || ((call0_u + (uint32_t)it) % kSpareEvery) == kSpareEvery - 1u);
   PF_STAMP(4);  // (NEXT_STEP resets done)
 
   // ---------------------------------------------------------------- the env step
@@ -1523,11 +1473,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
     }
   }
   if (stepping) {
-#ifndef PF_NO_ACTION_PREFETCH
     const float4 a = ROLLOUT ? a_roll : a_pre;
-#else
-    const float4 a = ROLLOUT ? a_roll : reinterpret_cast<const float4*>(B.actions)[li];
-#endif
     act0 = a.x; act1 = a.y; act2 = a.z; act3 = a.w;
     sp0 = a.x; sp1 = a.y; sp2 = a.z; sp3 = a.w;
     reward = -0.1f;
@@ -1591,13 +1537,13 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
         V.template tick<CR, true>(K, K, xi1, Pfull);
         V.peer_contact = false;
       } else if (CALM && __builtin_expect(calm_s, 1)) {
-        V.template tick<false, false, PF_KV_T>(KV, K, xi0, Pfull);
-        V.template tick<false, false, PF_KV_T>(KV, K, xi1, Pfull);
+        V.template tick<false, false, QuadKV>(KV, K, xi0, Pfull);
+        V.template tick<false, false, QuadKV>(KV, K, xi1, Pfull);
       } else if (CALM && WPS == 1) {
         // (not calm: the same ticks with the floor code in them. Their flight-path constants from the vector registers as well --
         //  the floor code's own constants stay scalar, Kc)
-        V.template tick<CR, false, PF_KV_T, true>(KV, K, xi0, Pfull);
-        V.template tick<CR, false, PF_KV_T, true>(KV, K, xi1, Pfull);
+        V.template tick<CR, false, QuadKV, true>(KV, K, xi0, Pfull);
+        V.template tick<CR, false, QuadKV, true>(KV, K, xi1, Pfull);
       } else {
         V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi0, Pfull);
         V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi1, Pfull);
@@ -1714,6 +1660,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, WPS) quadx_m0_env_kernel(const 
   if (ROLLOUT && NOISE == PF_NOISE_PHILOX && it + 1 < KS)
     zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
   }  // for it
+  if (SPARE && op == 0 && tid == 0) launch_ctr[blockIdx.x] = call0_u + (uint32_t)KS;
   if (active) {  // the persistent state goes back to HBM once per launch
     Sout[0 * N + li] = float4{V.p.x, V.p.y, V.p.z, new_dist};
     Sout[1 * N + li] = float4{V.q.x, V.q.y, V.q.z, V.q.w};

@@ -290,7 +290,7 @@ __device__ __noinline__ void pair_stage_dev(const pf_params* __restrict__ Pd, co
 // pairs x 15 axes in every tick for the rest of the episode (one such pair in 16 384 worlds made every launch 5x longer).
 template <class BODY>
 PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, const float bound_radius, const pf_params* __restrict__ Pd,
-                           const bool at_rest = false, float* wvel = nullptr) {
+                           const bool at_rest = false, float* wvel = nullptr, const bool frozen = false) {
   const int wbase = (tid / A) * A, wlocal = tid - wbase;
   float* me = wpose + tid * 8;
   if (wvel != nullptr && at_rest) {  // (a wreck at rest sits this tick out: what the pair stage finds for it is a body standing still)
@@ -321,7 +321,9 @@ PF_DEV void world_exchange(BODY& b, float* wpose, const int tid, const int A, co
   // the pair stage as a body of its own mass, the integration -- as it does in the reference, which never stopped stepping it. (Left
   // asleep, the pair stage solved contacts against it as a free body whose impulse was then thrown away: the momentum vanished.)
   // Two wrecks lying next to each other stay asleep.
-  b.woken = at_rest && near_awake;
+  // (frozen: stopped for good by the opt-in df_freeze_wrecks, which is not the reference's behaviour -- never woken, never integrated;
+  //  the pair stage still finds it standing still and the aircraft that hits it bounces off)
+  b.woken = at_rest && !frozen && near_awake;
   touch = touch && (!at_rest || b.woken);
   b.world_touch = widen_to_world(near, tid, A);
   bool peer = false;

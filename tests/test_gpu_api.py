@@ -383,19 +383,24 @@ def test_step_returns_the_same_objects_and_launches_one_kernel():
         assert all(a is b for a, b in zip(first, again))
     assert len(env.engine._prepared) == 8  # one prepared buffer block per action tensor seen
     torch.cuda.synchronize()
-    mem0 = torch.cuda.memory_allocated()
+    allocs0 = torch.cuda.memory_stats()["allocation.all.allocated"]  # (a count of allocations: only grows)
+    for k in range(16):
+        env.step(acts[k % 8])
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_stats()["allocation.all.allocated"] == allocs0
     try:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             for k in range(16):
                 env.step(acts[k % 8])
             torch.cuda.synchronize()
-        names = [e.name for e in prof.events() if e.device_type.name in ("CUDA", "PrivateUse1") or "kernel" in e.name.lower()]
-        kernels = [x for x in names if "Memcpy" not in x and "Memset" not in x]
+        names = [e.name for e in prof.events()]
+        launches = [x for x in names if x.startswith("hip") and "Launch" in x]  # (runtime API calls that start a kernel)
+        kernels = [x for x in names if not x.startswith("hip") and "Memcpy" not in x and "Memset" not in x]
+        assert len(launches) in (0, 16), launches[:4]
     except Exception as e:  # noqa: BLE001  (no roctracer on the box: the allocation check below still runs)
         kernels = None
         print(f"torch.profiler unavailable: {e}")
-    assert torch.cuda.memory_allocated() == mem0
     if kernels:
         assert len(kernels) == 16 and all("quadx_m0_env_kernel" in x for x in kernels), kernels[:4]
     # a tensor re-pointed in place is prepared again (its id is the same, its address is not)
@@ -412,7 +417,7 @@ def test_closed_loop_captured_in_a_hip_graph(env_id):
     on a second env with the same seed -- through episode ends and the in-kernel resets (nothing in step() synchronises or allocates)."""
     from pyflyt_amd.gym_envs import make_vec
 
-    n, g, reps = 2048, 12, 6
+    n, g, reps = 2048, (25 if "Fixedwing" in env_id else 12), 8
     envs = [make_vec(env_id, n, seed=9) for _ in range(2)]
     obs = [flat(e.reset(seed=9)[0]) for e in envs]
     assert torch.equal(obs[0], obs[1])
@@ -440,7 +445,6 @@ def test_closed_loop_captured_in_a_hip_graph(env_id):
         with torch.cuda.graph(graph, stream=stream):
             loop(envs[0], acts[0], g)
         stream.synchronize()
-    ends = 0
     for r in range(reps):
         graph.replay()
         torch.cuda.synchronize()
@@ -449,7 +453,7 @@ def test_closed_loop_captured_in_a_hip_graph(env_id):
         assert torch.equal(envs[0].engine.obs, envs[1].engine.obs) and torch.equal(envs[0].engine.reward, r1)
         assert torch.equal(envs[0].engine.terminated, t1) and torch.equal(envs[0].engine.truncated, u1)
         assert torch.equal(envs[0].engine.state[:7], envs[1].engine.state[:7])
-        ends += int((t1 | u1).sum())
+    ends = int((envs[0].step_count < 2 + g * reps).sum())  # lanes whose episode counter restarted on the way
     assert ends > 0  # the random linear policy crashes drones: the graph went through resets
     for e in envs:
         e.close()

@@ -74,3 +74,69 @@ def test_the_generic_kernel_keeps_the_key_and_agrees_with_the_specialised_one(mo
             ends += int(fresh.sum())
         assert torch.equal(a.state[7, ok, 3].view(torch.int32) & 0x7FFFFFFF, g.state[7, ok, 3].view(torch.int32) & 0x7FFFFFFF), k
     assert ends > n and float(ok.float().mean()) > 0.97
+
+
+@pytest.mark.parametrize("task", ["hover", "waypoints"])
+@pytest.mark.parametrize("kernel", ["specialised", "generic"])
+def test_consecutive_resets_are_different_episodes_and_equal_the_oracles(monkeypatch, task, kernel):
+    """Round 5's key (the counter AT the previous reset: 0 again at a fresh lane's first reset) gave every lane the same settle noise
+    and the same waypoints for its first and second episodes, on the device and in the oracle alike, so that no parity test could see
+    it. The key is now what the previous reset LEFT BEHIND: five consecutive explicit resets -- with 0, 1, 2 ... env steps
+    in between -- are five different episodes for every lane, the key words grow, and each reset observation equals the oracle's."""
+    from oracle import oracle as O
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    if kernel == "generic":
+        monkeypatch.setenv("PF_DISABLE_FAST", "1")
+    n = 64 * 3 + 5
+    eng = BatchEngine(build_params("quadx", task, noise="philox", autoreset="off", seed=3), n, device="cuda:0")
+    assert (eng.lib.pf_ctx_is_specialised(eng._ctx) != 0) == (kernel == "specialised")
+    orc = O.OracleBatch(O.make_params("hover" if task == "hover" else "quadx_waypoints", noise_mode=O.NOISE_PHILOX, seed=3), n)
+    act = torch.empty(n, 4, device="cuda:0")
+    seen, keys = [], []
+    for r in range(5):
+        got = eng.env_reset().cpu().numpy().astype(np.float64)
+        ref = orc.reset()
+        assert np.abs(got - ref).max() < 2e-5, (r, np.abs(got - ref).max())
+        seen.append(got)
+        keys.append((eng.state[7, :, 3].view(torch.int32) & 0x7FFFFFFF).cpu().numpy().astype(np.int64))
+        assert (keys[-1] == np.array([orc.lanes[i].reset_key for i in range(n)])).all()
+        for k in range(r):
+            eng.sample_actions(act, 10 * r + k)
+            act[:, :3] *= 0.05
+            act[:, 3] = 0.4
+            eng.env_step(act)
+            orc.step(act.cpu().numpy())
+    for a in range(5):
+        for b in range(a + 1, 5):
+            assert (np.abs(seen[a] - seen[b]).max(axis=1) > 1e-7).all(), (a, b)
+    assert all((keys[r + 1] > keys[r]).all() for r in range(4)) and (keys[0] == 1).all()
+
+
+def test_a_full_reset_does_not_trust_foreign_spares():
+    """A state buffer that another context has used carries that context's spares with bit 31 set (other seed: other settle noise,
+    other waypoints). pf_env_reset with a NULL mask ignores what it finds and prepares fresh ones: a context handed such a state
+    steps exactly like a context that started from zeros."""
+    from pyflyt_amd import build_params
+    from pyflyt_amd.engine import BatchEngine
+
+    n = 64 * 5 + 9
+    mk = lambda seed: BatchEngine(build_params("quadx", "waypoints", noise="philox", autoreset="next_step", seed=seed), n, device="cuda:0")  # noqa: E731
+    other, a, b = mk(99), mk(4), mk(4)
+    other.env_reset()
+    act = torch.empty(n, 4, device="cuda:0")
+    for k in range(20):
+        other.env_step(other.sample_actions(act, k))
+    assert bool((other.state[7, :, 3].view(torch.int32) < 0).any())
+    a.state.copy_(other.state)              # a: handed the other context's state, valid bits and all
+    a.state[6].zero_()                      # (the event counters of a fresh lane: the keys then agree with b's)
+    a.state[7, :, 3].view(torch.int32).bitwise_and_(VALID.item())  # the key 0 of a fresh lane, bit 31 still set
+    assert torch.equal(a.env_reset(), b.env_reset())
+    ends = 0
+    for k in range(100):
+        b.sample_actions(act, k)
+        ra, rb = a.env_step(act), b.env_step(act)
+        assert all(torch.equal(x, y) for x, y in zip(ra, rb)), k
+        ends += int((ra[2] | ra[3]).sum())
+    assert ends > n  # (through the next episodes' resets as well: they consumed the fresh spares)

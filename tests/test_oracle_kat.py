@@ -306,3 +306,26 @@ def test_philox_round_function_against_the_published_vectors():
     import numpy as np
     acc = np.array(acc)
     assert abs(acc.mean() - 0.5) < 5e-3 and abs(acc.var() - 1.0 / 12.0) < 2e-3
+
+
+@pytest.mark.parametrize("env", ["hover", "quadx_waypoints"])
+def test_consecutive_resets_draw_from_different_keys(env):
+    """A reset's draws (settle noise, waypoints) are keyed by what the lane's PREVIOUS reset left behind, and that key is strictly
+    increasing: round 5 stored the counter AT the reset, which is 0 again at a fresh lane's first reset, so that every lane's first and
+    second episodes started from the same settle noise and flew to the same waypoints. Every one of five consecutive
+    resets -- back to back, and with steps in between -- gives every lane a different observation, and the keys grow."""
+    from oracle import oracle as O
+
+    n = 64
+    ob = O.OracleBatch(O.make_params(env, noise_mode=O.NOISE_PHILOX, seed=3), n)
+    seen, keys = [], []
+    rng = np.random.default_rng(0)
+    for r in range(5):
+        seen.append(ob.reset().copy())
+        keys.append(np.array([ob.lanes[i].reset_key for i in range(n)], dtype=np.int64))
+        for _ in range(r):  # (0, 1, 2 ... env steps between the resets)
+            ob.step(rng.uniform(-0.2, 0.2, size=(n, 4)).astype(np.float32) + np.array([0, 0, 0, 0.4], dtype=np.float32))
+    for a in range(5):
+        for b in range(a + 1, 5):
+            assert (np.abs(seen[a] - seen[b]).max(axis=1) > 1e-9).all(), (a, b)
+    assert all((keys[r + 1] > keys[r]).all() for r in range(4)) and (keys[0] == 1).all()

@@ -213,7 +213,11 @@ struct FwTableV {
 };
 // (Measured in round 5 and dropped -- profiles/r06/experiments/ab_switches.patch has the switches: the v-tail and body rows by scalar
 //  loads in the tick, 22.1 us against 21.5, sixteen scalars spilled around the pairs; the same two rows read from LDS in the tick,
-//  22.2 against 21.4, the reads' latency shows; the whole table by 28 broadcast global loads, 21.1 against 20.7 through LDS.)
+//  22.2 against 21.4, the reads' latency shows; the whole table by 28 broadcast global loads, 21.1 against 20.7 through LDS. Round 6,
+//  profiles/r06/experiments/fixedwing_x3.patch: the v-tail as a third stream next to the two pairs -- 23.0 against 20.7, the third
+//  stream's temporaries push another 45 values per tick through AGPR copies; and the table shrunk by what a mirror-symmetric airframe
+//  makes redundant (aileron constants as splats, zero products of inertia): 21.15 against 20.65 per step, 15.63 against 16.0 per
+//  rollout step -- inside what the register allocator moves from one neutral edit to the next.)
 typedef float fw_f4v __attribute__((ext_vector_type(4)));
 typedef const fw_f4v __attribute__((address_space(3))) * fw_lds_f4ptr;
 // Into the vector registers through LDS: every lane fetches two WORDS of the table with the state groups (two coalesced requests
@@ -482,48 +486,35 @@ struct FwHot {
     o.ty = fma2(S.rz, o.fp, ty0);
     return o;
   }
-  // All five surfaces at once, as THREE streams: surface_pair statement by statement on the aileron pair (k = 0), on the (h-tail,
-  // main wing) pair (k = 1) and on the vertical tail (k = 2: the same statements on a vector whose two elements are both the
-  // v-tail -- its constants are splats, so they cost single registers, and the duplicate element's scalar steps fold away), in turn.
-  // The evaluations are independent, so every instruction has two independent neighbours: a lone wave per SIMD issues a DEPENDENT
-  // instruction every ~7.5 clocks and an independent one every ~5.5 (profiles/r05/icache_cold.txt). Round 5 ran the two pairs side by
-  // side and the v-tail's 150 instructions behind them as one dependent chain. Per element the same operations in the same order as
-  // surface_pair / surface<true> (the v-tail's lift axis is +y: its `la` is vy): bit-identical results. Needs all constants at once:
-  // the one-wave-per-SIMD instantiation holds them in vector registers (FwTableV). o[2]: .fp.x / .fn.x the v-tail's forces, tmv its
-  // pitching moment (its torque assembles differently: tick()).
-#define PF_X2(...) { constexpr int k = 0; const FwSurf2& Sk = S[0]; __VA_ARGS__ } { constexpr int k = 1; const FwSurf2& Sk = S[1]; __VA_ARGS__ } \
-                   { constexpr int k = 2; const FwSurf2& Sk = Sv; __VA_ARGS__ }
-  PF_DEV static FwSurf2 splat_surf(const FwSurf& v) {
-    FwSurf2 S;
-    S.rx = sp2(v.rx); S.ry = sp2(v.ry); S.rz = sp2(v.rz); S.cl3d = sp2(v.cl3d); S.a0b = sp2(v.a0b); S.aPb = sp2(v.aPb); S.aNb = sp2(v.aNb);
-    S.tau_eta = sp2(v.tau_eta); S.c1 = sp2(v.c1); S.ipa = sp2(v.ipa); S.exp_term = sp2(v.exp_term); S.cd0 = sp2(v.cd0);
-    S.defl_lim = sp2(v.defl_lim); S.dt_tau = sp2(v.dt_tau); S.hra = sp2(v.hra); S.chord = sp2(v.chord);
-    return S;
-  }
-  PF_DEV void surfaces_x3(const FwSurf2 (&S)[2], const FwSurf& vt, f2 (&a)[3], const f2 (&cmd2)[3], FwPairOut (&o)[3], float& tmv) const {
-    const FwSurf2 Sv = splat_surf(vt);
+  // Both surface pairs at once: surface_pair statement by statement on the aileron pair (k = 0) and on the (h-tail, main wing) pair
+  // (k = 1) alternately. The two evaluations are independent, so every instruction has an independent neighbour: a lone wave per
+  // SIMD issues a DEPENDENT instruction every ~7.5 clocks and an independent one every ~5.5 (profiles/r05/icache_cold.txt), and the
+  // packed-result / compare-select wait states of the one-pair version are filled by the other pair instead of by hand. Per element
+  // the same operations in the same order as surface_pair: bit-identical results. Needs both pairs' constants at once (64 values):
+  // the one-wave-per-SIMD instantiation holds them in vector registers (FwTableV).
+#define PF_X2(...) { constexpr int k = 0; __VA_ARGS__ } { constexpr int k = 1; __VA_ARGS__ }
+  PF_DEV void surface_pair_x2(const FwSurf2 (&S)[2], f2 (&a)[2], const f2 (&cmd2)[2], FwPairOut (&o)[2]) const {
     const f2 wbx = sp2(wb.x), wby = sp2(wb.y), wbz = sp2(wb.z);
-    f2 da[3], t1[3], t2[3], t3[3], vx[3], vy[3], vz[3], defl[3], fa2[3], la[3], vz2[3], h2[3], V2t[3], a0[3], V2[3], y[3];
+    f2 da[2], t1[2], t2[2], t3[2], vx[2], vy[2], vz[2], defl[2], fa2[2], vz2[2], h2[2], V2t[2], a0[2], V2[2], y[2];
     PF_X2(da[k] = cmd2[k] - a[k];)
-    PF_X2(t1[k] = fma2(-wbz, Sk.ry, sp2(vb.x));)
-    PF_X2(t2[k] = fma2(-wbx, Sk.rz, sp2(vb.y));)
-    PF_X2(t3[k] = fma2(-wby, Sk.rx, sp2(vb.z));)
-    PF_X2(a[k] = fma2(Sk.dt_tau, da[k], a[k]);)  // lifting_surfaces.py:277
-    PF_X2(vx[k] = fma2(wby, Sk.rz, t1[k]);)
-    PF_X2(vy[k] = fma2(wbz, Sk.rx, t2[k]);)
-    PF_X2(vz[k] = fma2(wbx, Sk.ry, t3[k]);)
-    PF_X2(defl[k] = a[k] * Sk.defl_lim;)
-    PF_X2(la[k] = k == 2 ? vy[k] : vz[k];)  // the velocity along the lift unit: +z, the v-tail's +y
+    PF_X2(t1[k] = fma2(-wbz, S[k].ry, sp2(vb.x));)
+    PF_X2(t2[k] = fma2(-wbx, S[k].rz, sp2(vb.y));)
+    PF_X2(t3[k] = fma2(-wby, S[k].rx, sp2(vb.z));)
+    PF_X2(a[k] = fma2(S[k].dt_tau, da[k], a[k]);)  // lifting_surfaces.py:277
+    PF_X2(vx[k] = fma2(wby, S[k].rz, t1[k]);)
+    PF_X2(vy[k] = fma2(wbz, S[k].rx, t2[k]);)
+    PF_X2(vz[k] = fma2(wbx, S[k].ry, t3[k]);)
+    PF_X2(defl[k] = a[k] * S[k].defl_lim;)
     PF_X2(fa2[k] = vx[k] * vx[k];)
     PF_X2(vz2[k] = vz[k] * vz[k];)
-    PF_X2(h2[k] = fma2(la[k], la[k], fa2[k]);)
+    PF_X2(h2[k] = fma2(vz[k], vz[k], fa2[k]);)
     PF_X2(V2t[k] = fma2(vy[k], vy[k], vz2[k]);)
-    PF_X2(a0[k] = fma2(-Sk.tau_eta, defl[k], Sk.a0b);)
+    PF_X2(a0[k] = fma2(-S[k].tau_eta, defl[k], S[k].a0b);)
     PF_X2(V2[k] = fma2(vx[k], vx[k], V2t[k]);)
-    PF_X2(y[k] = -la[k];)
-    // fast_atan2_pair(-la, fa) with fa = vx
-    float ax0[3], ay0[3], ax1[3], ay1[3], mx0[3], mx1[3], ih0[3], ih1[3], rc0[3], rc1[3], mn0[3], mn1[3];
-    bool zero0[3], zero1[3], still0[3], still1[3], steep0[3], steep1[3], back0[3], back1[3];
+    PF_X2(y[k] = -vz[k];)
+    // fast_atan2_pair(-la, fa) with la = vz, fa = vx
+    float ax0[2], ay0[2], ax1[2], ay1[2], mx0[2], mx1[2], ih0[2], ih1[2], rc0[2], rc1[2], mn0[2], mn1[2];
+    bool zero0[2], zero1[2], still0[2], still1[2], steep0[2], steep1[2], back0[2], back1[2];
     PF_X2(ax0[k] = __builtin_fabsf(vx[k].x); ay0[k] = __builtin_fabsf(y[k].x); ax1[k] = __builtin_fabsf(vx[k].y); ay1[k] = __builtin_fabsf(y[k].y);)
     PF_X2(mx0[k] = __builtin_fmaxf(ax0[k], ay0[k]); mx1[k] = __builtin_fmaxf(ax1[k], ay1[k]);)
     PF_X2(ih0[k] = frsq(h2[k].x); ih1[k] = frsq(h2[k].y);)
@@ -533,16 +524,16 @@ struct FwHot {
     PF_X2(still0[k] = !(h2[k].x > 0.0f); still1[k] = !(h2[k].y > 0.0f);)
     PF_X2(steep0[k] = ay0[k] > ax0[k]; steep1[k] = ay1[k] > ax1[k];)
     PF_X2(back0[k] = vx[k].x < 0.0f; back1[k] = vx[k].y < 0.0f;)
-    f2 ih[3], t[3], cu[3], su[3], aP[3], aN[3], ss[3], QA[3], p[3], ca[3], sa[3], dd[3], c9a[3], Cd90[3], hcd[3], r[3], rq[3], rh[3], alpha[3], am[3], Cl_lin[3], ai[3];
+    f2 ih[2], t[2], cu[2], su[2], aP[2], aN[2], ss[2], QA[2], p[2], ca[2], sa[2], dd[2], c9a[2], Cd90[2], hcd[2], r[2], rq[2], rh[2], alpha[2], am[2], Cl_lin[2], ai[2];
     PF_X2(ih[k] = f2{ih0[k], ih1[k]};)
     PF_X2(t[k] = f2{mn0[k], mn1[k]} * f2{rc0[k], rc1[k]};)
     PF_X2(cu[k] = vx[k] * ih[k];)
     PF_X2(su[k] = y[k] * ih[k];)
-    PF_X2(aP[k] = fma2(Sk.c1, defl[k], Sk.aPb);)
+    PF_X2(aP[k] = fma2(S[k].c1, defl[k], S[k].aPb);)
     PF_X2(t[k] = f2{zero0[k] ? 0.0f : t[k].x, zero1[k] ? 0.0f : t[k].y};)
-    PF_X2(aN[k] = fma2(Sk.c1, defl[k], Sk.aNb);)
+    PF_X2(aN[k] = fma2(S[k].c1, defl[k], S[k].aNb);)
     PF_X2(ss[k] = t[k] * t[k];)
-    PF_X2(QA[k] = Sk.hra * V2[k];)
+    PF_X2(QA[k] = S[k].hra * V2[k];)
     PF_X2(p[k] = fma2(ss[k], sp2(0.0029035410843789577f), sp2(-0.016282962635159492f));)
     PF_X2(p[k] = fma2(ss[k], p[k], sp2(0.04303929582238197f));)
     PF_X2(p[k] = fma2(ss[k], p[k], sp2(-0.07533670216798782f));)
@@ -556,39 +547,39 @@ struct FwHot {
     PF_X2(p[k] = fma2(ss[k], p[k], sp2(-0.3333309292793274f));)
     PF_X2(Cd90[k] = fma2(sp2(-4.26e-2f), dd[k], c9a[k]);)  // (used by the post-stall branch only)
     PF_X2(p[k] = fma2(ss[k], p[k], sp2(1.0f));)
-    PF_X2(hcd[k] = sp2(0.5f) * Sk.cd0;)
+    PF_X2(hcd[k] = sp2(0.5f) * S[k].cd0;)
     PF_X2(r[k] = p[k] * t[k];)
     PF_X2(rq[k] = sp2(0.5f * kPi) - r[k];)
     PF_X2(r[k] = f2{steep0[k] ? rq[k].x : r[k].x, steep1[k] ? rq[k].y : r[k].y};)
     PF_X2(rh[k] = sp2(kPi) - r[k];)
     PF_X2(r[k] = f2{back0[k] ? rh[k].x : r[k].x, back1[k] ? rh[k].y : r[k].y};)
     PF_X2(alpha[k] = f2{__builtin_copysignf(r[k].x, y[k].x), __builtin_copysignf(r[k].y, y[k].y)};)
-    bool lin0[3], lin1[3];
+    bool lin0[2], lin1[2];
     PF_X2(lin0[k] = (aN[k].x < alpha[k].x) && (alpha[k].x < aP[k].x); lin1[k] = (aN[k].y < alpha[k].y) && (alpha[k].y < aP[k].y);)
     PF_X2(am[k] = alpha[k] - a0[k];)
-    // (one wave-uniform test for all five surfaces: the post-stall code only SELECTS per element, so running it for a surface that is
-    //  not stalled changes nothing)
-    const bool any_stall = __any(!(lin0[0] && lin1[0] && lin0[1] && lin1[1] && lin0[2]));
-    PF_X2(Cl_lin[k] = Sk.cl3d * am[k];)
-    PF_X2(ai[k] = Cl_lin[k] * Sk.ipa;)
+    // (one wave-uniform test for both pairs: the post-stall code only SELECTS per element, so running it for a pair none of whose
+    //  elements is stalled changes nothing)
+    const bool any_stall = __any(!(lin0[0] && lin1[0] && lin0[1] && lin1[1]));
+    PF_X2(Cl_lin[k] = S[k].cl3d * am[k];)
+    PF_X2(ai[k] = Cl_lin[k] * S[k].ipa;)
     if (any_stall) {  // :409-425 (see surface<>)
-      bool pos0[3], pos1[3];
-      f2 as[3], edge[3], asm0[3], den[3], num[3], aist[3], rden[3], ai_stall[3], tt[3], ais[3];
+      bool pos0[2], pos1[2];
+      f2 as[2], edge[2], asm0[2], den[2], num[2], aist[2], rden[2], ai_stall[2], tt[2], ais[2];
       PF_X2(pos0[k] = alpha[k].x > 0.0f; pos1[k] = alpha[k].y > 0.0f;)
       PF_X2(as[k] = f2{pos0[k] ? aP[k].x : aN[k].x, pos1[k] ? aP[k].y : aN[k].y};)
       PF_X2(edge[k] = f2{pos0[k] ? 0.5f * kPi : -0.5f * kPi, pos1[k] ? 0.5f * kPi : -0.5f * kPi};)
       PF_X2(asm0[k] = as[k] - a0[k];)
       PF_X2(den[k] = edge[k] - as[k];)
       PF_X2(num[k] = edge[k] - alpha[k];)
-      PF_X2(aist[k] = Sk.cl3d * asm0[k];)
+      PF_X2(aist[k] = S[k].cl3d * asm0[k];)
       PF_X2(rden[k] = f2{frcp(den[k].x), frcp(den[k].y)};)
-      PF_X2(ai_stall[k] = aist[k] * Sk.ipa;)
+      PF_X2(ai_stall[k] = aist[k] * S[k].ipa;)
       PF_X2(tt[k] = num[k] * rden[k];)
       PF_X2(ais[k] = ai_stall[k] * f2{med3(tt[k].x, 0.0f, 1.0f), med3(tt[k].y, 0.0f, 1.0f)};)
       PF_X2(ai[k] = f2{lin0[k] ? ai[k].x : ais[k].x, lin1[k] ? ai[k].y : ais[k].y};)
     }
-    f2 x[3], tq[3], ae[3], ps[3], pc[3], cmk[3], cx[3], sx[3], cas[3], sas[3], se[3], ce[3], CT[3], CTc[3], cnn[3], CN[3], Cl[3], Cd[3], CM[3];
-    float rce0[3], rce1[3];
+    f2 x[2], tq[2], ae[2], ps[2], pc[2], cmk[2], cx[2], sx[2], cas[2], sas[2], se[2], ce[2], CT[2], CTc[2], cnn[2], CN[2], Cl[2], Cd[2], CM[2];
+    float rce0[2], rce1[2];
     PF_X2(x[k] = a0[k] + ai[k];)
     // sincos_small(x): the two Horner chains side by side
     PF_X2(tq[k] = x[k] * x[k];)
@@ -611,7 +602,7 @@ struct FwHot {
     PF_X2(se[k] = fma2(sa[k], cx[k], -cas[k]); ce[k] = fma2(ca[k], cx[k], sas[k]);)
     // :397-406
     PF_X2(rce0[k] = frcp(ce[k].x); rce1[k] = frcp(ce[k].y);)
-    PF_X2(CT[k] = Sk.cd0 * ce[k];)
+    PF_X2(CT[k] = S[k].cd0 * ce[k];)
     PF_X2(CTc[k] = CT[k] * ce[k];)
     PF_X2(cnn[k] = fma2(CT[k], se[k], Cl_lin[k]);)
     PF_X2(CN[k] = cnn[k] * f2{rce0[k], rce1[k]};)
@@ -619,7 +610,7 @@ struct FwHot {
     PF_X2(Cd[k] = fma2(CN[k], se[k], CTc[k]);)
     PF_X2(CM[k] = -CN[k] * cmk[k];)
     if (any_stall) {  // :427-448
-      f2 dn[3], c9s[3], CTs[3], cms[3], rdn[3], cts[3], ctc[3], CNs[3], Cls[3], Cds[3], CMs[3];
+      f2 dn[2], c9s[2], CTs[2], cms[2], rdn[2], cts[2], ctc[2], CNs[2], Cls[2], Cds[2], CMs[2];
       PF_X2(dn[k] = fma2(sp2(0.44f), f2{__builtin_fabsf(se[k].x), __builtin_fabsf(se[k].y)}, sp2(0.56f));)
       PF_X2(c9s[k] = Cd90[k] * se[k];)
       PF_X2(CTs[k] = hcd[k] * ce[k];)
@@ -627,7 +618,7 @@ struct FwHot {
       PF_X2(rdn[k] = f2{frcp(dn[k].x), frcp(dn[k].y)};)
       PF_X2(cts[k] = CTs[k] * se[k];)
       PF_X2(ctc[k] = CTs[k] * ce[k];)
-      PF_X2(CNs[k] = c9s[k] * (rdn[k] - Sk.exp_term);)
+      PF_X2(CNs[k] = c9s[k] * (rdn[k] - S[k].exp_term);)
       PF_X2(Cls[k] = fma2(CNs[k], ce[k], -cts[k]);)
       PF_X2(Cds[k] = fma2(CNs[k], se[k], ctc[k]);)
       PF_X2(CMs[k] = -CNs[k] * cms[k];)
@@ -636,16 +627,15 @@ struct FwHot {
       PF_X2(CM[k] = f2{lin0[k] ? CM[k].x : CMs[k].x, lin1[k] ? CM[k].y : CMs[k].y};)
     }
     // :485-498
-    f2 L[3], D[3], qc[3], dsa[3], dca[3], tm[3], ty0[3];
+    f2 L[2], D[2], qc[2], dsa[2], dca[2], tm[2], ty0[2];
     PF_X2(L[k] = Cl[k] * QA[k]; D[k] = Cd[k] * QA[k];)
     PF_X2(qc[k] = QA[k] * CM[k];)
     PF_X2(dsa[k] = D[k] * sa[k]; dca[k] = D[k] * ca[k];)
-    PF_X2(tm[k] = qc[k] * Sk.chord;)
+    PF_X2(tm[k] = qc[k] * S[k].chord;)
     PF_X2(o[k].fn = fma2(L[k], ca[k], dsa[k]);)
     PF_X2(o[k].fp = fma2(L[k], sa[k], -dca[k]);)
-    PF_X2(ty0[k] = fma2(-Sk.rx, o[k].fn, tm[k]);)
-    PF_X2(o[k].ty = fma2(Sk.rz, o[k].fp, ty0[k]);)  // (k = 2: unused, dead code)
-    tmv = tm[2].x;
+    PF_X2(ty0[k] = fma2(-S[k].rx, o[k].fn, tm[k]);)
+    PF_X2(o[k].ty = fma2(S[k].rz, o[k].fp, ty0[k]);)
   }
 #undef PF_X2
   // one lift-+z surface's force and torque into the body totals (the tail of surface<false>)
@@ -673,28 +663,21 @@ struct FwHot {
     v3 F{0.f, 0.f, 0.f}, tau{0.f, 0.f, 0.f};
     if constexpr (std::is_same<TAB, FwTableV>::value) {
       const FwSurf& Sv = tab.vtail;
-      f2 a[3] = {f2{act[0], act[1]}, f2{act[2], act[4]}, sp2(act[3])};
-      const f2 c2[3] = {f2{cmd[0], cmd[1]}, f2{cmd[2], cmd[4]}, sp2(cmd[3])};
-      FwPairOut o[3];
-      float tmv;
-      surfaces_x3(tab.pair, tab.vtail, a, c2, o, tmv);
-      act[0] = a[0].x; act[1] = a[0].y; act[2] = a[1].x; act[4] = a[1].y; act[3] = a[2].x;
+      f2 a[2] = {f2{act[0], act[1]}, f2{act[2], act[4]}};
+      const f2 c2[2] = {f2{cmd[0], cmd[1]}, f2{cmd[2], cmd[4]}};
+      FwPairOut o[2];
+      surface_pair_x2(tab.pair, a, c2, o);
+      act[0] = a[0].x; act[1] = a[0].y; act[2] = a[1].x; act[4] = a[1].y;
       // the reference's accumulation order: ailerons (0, 1), h-tail (2), v-tail (3), main wing (4)
       accumulate(tab.pair[0].ry.x, o[0].fp.x, o[0].fn.x, o[0].ty.x, F, tau);
       accumulate(tab.pair[0].ry.y, o[0].fp.y, o[0].fn.y, o[0].ty.y, F, tau);
       accumulate(tab.pair[1].ry.x, o[1].fp.x, o[1].fn.x, o[1].ty.x, F, tau);
-      {  // the v-tail: lift unit +y, torque unit -z (the tail of surface<true>)
-        const FwSurf& Sv = tab.vtail;
-        const float fp = o[2].fp.x, fn = o[2].fn.x;
-        F.x += fp;
-        F.y += fn;
-        tau.x = fmaf(-Sv.rz, fn, tau.x);
-        tau.y = fmaf(Sv.rz, fp, tau.y);
-        tau.z += fmaf(Sv.rx, fn, fmaf(-Sv.ry, fp, -tmv));
-      }
-      accumulate(tab.pair[1].ry.y, o[1].fp.y, o[1].fn.y, o[1].ty.y, F, tau);
       __builtin_amdgcn_sched_barrier(0);
       const FwBody& Kb = tab.body;
+      act[3] = fmaf(Sv.dt_tau, cmd[3] - act[3], act[3]);
+      surface<true>(Sv, act[3], F, tau);
+      accumulate(tab.pair[1].ry.y, o[1].fp.y, o[1].fn.y, o[1].ty.y, F, tau);
+      __builtin_amdgcn_sched_barrier(0);
       tick_body<FLOOR, SHARED>(Kb, F, tau, xi, Pfull);
     } else {
       tick_scalar_table<FLOOR, SHARED>(tab, F, tau, xi, Pfull);

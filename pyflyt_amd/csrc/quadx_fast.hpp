@@ -457,7 +457,134 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const QuadSolveC& Sc, co
     res = __builtin_fmaxf(r0, r1);
   };
   const bool lone = __popcll(__ballot(any_on)) <= 1;  // (wave-uniform)
-  if (lone) {
+  if (lone && ROWFORM && N == 1) {
+    // ONE contact on a lone lane -- four solves in five -- with the sweep loop written out. What the compiler made of the loop below
+    // was 49 instructions a sweep for a dependent chain of ten: twelve v_readlane / four v_writelane of scalars it had spilled around
+    // the loop (the trip counter among them), copies of the loop-carried impulses, a compare-select-compare for the exit test -- 325
+    // clocks a sweep on the one wave the whole launch waits for (profiles/r05/solver_trace.txt). The same instructions on the same
+    // values in the same order, 22 a sweep: bit-identical impulses, the same number of sweeps.
+    float e0 = u[0][0], e1 = u[0][1], e2 = u[0][2], l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, t_, lim_, d0_, d1_, d2_;
+    int cnt = Sc.iters;
+    const unsigned long long onm = __ballot(any_on);
+    asm volatile(
+        "1:\n\t"
+        "v_max_f32 %[t], %[e0], %[e0]\n\t"
+        "v_max_f32 %[t], 0, %[t]\n\t"
+        "v_sub_f32 %[d0], %[t], %[l0]\n\t"
+        "v_mov_b32 %[l0], %[t]\n\t"
+        "v_fma_f32 %[e1], -%[b10], %[d0], %[e1]\n\t"
+        "v_fma_f32 %[e2], -%[b20], %[d0], %[e2]\n\t"
+        "v_mul_f32 %[lim], %[fx], %[l0]\n\t"
+        "v_med3_f32 %[t], %[e1], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d1], %[t], %[l1]\n\t"
+        "v_mov_b32 %[l1], %[t]\n\t"
+        "v_fma_f32 %[e2], -%[b21], %[d1], %[e2]\n\t"
+        "v_fma_f32 %[e0], -%[b01], %[d1], %[e0]\n\t"
+        "v_mul_f32 %[lim], %[fy], %[l0]\n\t"
+        "v_med3_f32 %[t], %[e2], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d2], %[t], %[l2]\n\t"
+        "v_mov_b32 %[l2], %[t]\n\t"
+        "v_fma_f32 %[e0], -%[b02], %[d2], %[e0]\n\t"
+        "v_fma_f32 %[e1], -%[b12], %[d2], %[e1]\n\t"
+        "v_max3_f32 %[t], |%[d0]|, |%[d1]|, |%[d2]|\n\t"
+        "v_cmp_lt_f32 vcc, %[bound], %[t]\n\t"
+        "s_and_b64 vcc, vcc, %[on]\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:"
+        : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [cnt] "+s"(cnt), [t] "=&v"(t_),
+          [lim] "=&v"(lim_), [d0] "=&v"(d0_), [d1] "=&v"(d1_), [d2] "=&v"(d2_)
+        : [b10] "v"(B[ROWFORM ? 1 : 0][0]), [b20] "v"(B[ROWFORM ? 2 : 0][0]), [b01] "v"(B[0][ROWFORM ? 1 : 0]), [b21] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 1 : 0]),
+          [b02] "v"(B[0][ROWFORM ? 2 : 0]), [b12] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 2 : 0]), [fx] "v"(fx[0]), [fy] "v"(fy[0]), [bound] "s"(Sc.res), [on] "s"(onm)
+        : "vcc", "scc");
+    lam[0][0] = l0; lam[0][1] = l1; lam[0][2] = l2;
+#ifdef PF_PHASE_TRACE
+    pf_sweeps = Sc.iters - cnt;
+#endif
+  } else if (lone && ROWFORM && N == 2) {
+    // TWO contacts on a lone lane (an edge impact: one solve in six, and the ones that run into the sweep cap): the same treatment, six
+    // rows, 54 instructions a sweep for the 107 the compiler's loop took (447 clocks: profiles/r05/solver_trace.txt). Each row's five
+    // coupling updates start with the NEXT row's, the one the dependent chain waits for.
+    float e_[6] = {u[0][0], u[0][1], u[0][2], u[N > 1 ? 1 : 0][0], u[N > 1 ? 1 : 0][1], u[N > 1 ? 1 : 0][2]}, l_[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d_[6], t_, lim_;
+    int cnt = Sc.iters;
+    const unsigned long long onm = __ballot(any_on);
+    asm volatile(
+        "1:\n\t"
+        "v_max_f32 %[t], %[e0], %[e0]\n\t"
+        "v_max_f32 %[t], 0, %[t]\n\t"
+        "v_sub_f32 %[d0], %[t], %[l0]\n\t"
+        "v_mov_b32 %[l0], %[t]\n\t"
+        "v_fma_f32 %[e1], -%[b10], %[d0], %[e1]\n\t"
+        "v_fma_f32 %[e2], -%[b20], %[d0], %[e2]\n\t"
+        "v_fma_f32 %[e3], -%[b30], %[d0], %[e3]\n\t"
+        "v_fma_f32 %[e4], -%[b40], %[d0], %[e4]\n\t"
+        "v_fma_f32 %[e5], -%[b50], %[d0], %[e5]\n\t"
+        "v_mul_f32 %[lim], %[fx0], %[l0]\n\t"
+        "v_med3_f32 %[t], %[e1], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d1], %[t], %[l1]\n\t"
+        "v_mov_b32 %[l1], %[t]\n\t"
+        "v_fma_f32 %[e2], -%[b21], %[d1], %[e2]\n\t"
+        "v_fma_f32 %[e3], -%[b31], %[d1], %[e3]\n\t"
+        "v_fma_f32 %[e4], -%[b41], %[d1], %[e4]\n\t"
+        "v_fma_f32 %[e5], -%[b51], %[d1], %[e5]\n\t"
+        "v_fma_f32 %[e0], -%[b01], %[d1], %[e0]\n\t"
+        "v_mul_f32 %[lim], %[fy0], %[l0]\n\t"
+        "v_med3_f32 %[t], %[e2], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d2], %[t], %[l2]\n\t"
+        "v_mov_b32 %[l2], %[t]\n\t"
+        "v_fma_f32 %[e3], -%[b32], %[d2], %[e3]\n\t"
+        "v_fma_f32 %[e4], -%[b42], %[d2], %[e4]\n\t"
+        "v_fma_f32 %[e5], -%[b52], %[d2], %[e5]\n\t"
+        "v_fma_f32 %[e0], -%[b02], %[d2], %[e0]\n\t"
+        "v_fma_f32 %[e1], -%[b12], %[d2], %[e1]\n\t"
+        "v_max_f32 %[t], %[e3], %[e3]\n\t"
+        "v_max_f32 %[t], 0, %[t]\n\t"
+        "v_sub_f32 %[d3], %[t], %[l3]\n\t"
+        "v_mov_b32 %[l3], %[t]\n\t"
+        "v_fma_f32 %[e4], -%[b43], %[d3], %[e4]\n\t"
+        "v_fma_f32 %[e5], -%[b53], %[d3], %[e5]\n\t"
+        "v_fma_f32 %[e0], -%[b03], %[d3], %[e0]\n\t"
+        "v_fma_f32 %[e1], -%[b13], %[d3], %[e1]\n\t"
+        "v_fma_f32 %[e2], -%[b23], %[d3], %[e2]\n\t"
+        "v_mul_f32 %[lim], %[fx1], %[l3]\n\t"
+        "v_med3_f32 %[t], %[e4], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d4], %[t], %[l4]\n\t"
+        "v_mov_b32 %[l4], %[t]\n\t"
+        "v_fma_f32 %[e5], -%[b54], %[d4], %[e5]\n\t"
+        "v_fma_f32 %[e0], -%[b04], %[d4], %[e0]\n\t"
+        "v_fma_f32 %[e1], -%[b14], %[d4], %[e1]\n\t"
+        "v_fma_f32 %[e2], -%[b24], %[d4], %[e2]\n\t"
+        "v_fma_f32 %[e3], -%[b34], %[d4], %[e3]\n\t"
+        "v_mul_f32 %[lim], %[fy1], %[l3]\n\t"
+        "v_med3_f32 %[t], %[e5], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d5], %[t], %[l5]\n\t"
+        "v_mov_b32 %[l5], %[t]\n\t"
+        "v_fma_f32 %[e0], -%[b05], %[d5], %[e0]\n\t"
+        "v_fma_f32 %[e1], -%[b15], %[d5], %[e1]\n\t"
+        "v_fma_f32 %[e2], -%[b25], %[d5], %[e2]\n\t"
+        "v_fma_f32 %[e3], -%[b35], %[d5], %[e3]\n\t"
+        "v_fma_f32 %[e4], -%[b45], %[d5], %[e4]\n\t"
+        "v_max3_f32 %[t], |%[d0]|, |%[d1]|, |%[d2]|\n\t"
+        "v_max3_f32 %[lim], |%[d3]|, |%[d4]|, |%[d5]|\n\t"
+        "v_max_f32 %[t], %[t], %[lim]\n\t"
+        "v_cmp_lt_f32 vcc, %[bound], %[t]\n\t"
+        "s_and_b64 vcc, vcc, %[on]\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cbranch_vccz 2f\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "2:"
+        : [e0] "+v"(e_[0]), [e1] "+v"(e_[1]), [e2] "+v"(e_[2]), [e3] "+v"(e_[3]), [e4] "+v"(e_[4]), [e5] "+v"(e_[5]), [l0] "+v"(l_[0]), [l1] "+v"(l_[1]), [l2] "+v"(l_[2]), [l3] "+v"(l_[3]), [l4] "+v"(l_[4]), [l5] "+v"(l_[5]), [cnt] "+s"(cnt), [t] "=&v"(t_), [lim] "=&v"(lim_), [d0] "=&v"(d_[0]), [d1] "=&v"(d_[1]), [d2] "=&v"(d_[2]), [d3] "=&v"(d_[3]), [d4] "=&v"(d_[4]), [d5] "=&v"(d_[5])
+        : [b10] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 0 : 0]), [b20] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 0 : 0]), [b30] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 0 : 0]), [b40] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 0 : 0]), [b50] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 0 : 0]), [b01] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 1 : 0]), [b21] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 1 : 0]), [b31] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 1 : 0]), [b41] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 1 : 0]), [b51] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 1 : 0]), [b02] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 2 : 0]), [b12] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 2 : 0]), [b32] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 2 : 0]), [b42] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 2 : 0]), [b52] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 2 : 0]), [b03] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 3 : 0]), [b13] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 3 : 0]), [b23] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 3 : 0]), [b43] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 3 : 0]), [b53] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 3 : 0]), [b04] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 4 : 0]), [b14] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 4 : 0]), [b24] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 4 : 0]), [b34] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 4 : 0]), [b54] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 4 : 0]), [b05] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 5 : 0]), [b15] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 5 : 0]), [b25] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 5 : 0]), [b35] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 5 : 0]), [b45] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 5 : 0]), [fx0] "v"(fx[0]), [fy0] "v"(fy[0]), [fx1] "v"(fx[N > 1 ? 1 : 0]), [fy1] "v"(fy[N > 1 ? 1 : 0]), [bound] "s"(Sc.res), [on] "s"(onm)
+        : "vcc", "scc");
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lam[0][d] = l_[d]; lam[N > 1 ? 1 : 0][d] = l_[3 + d]; }
+#ifdef PF_PHASE_TRACE
+    pf_sweeps = Sc.iters - cnt;
+#endif
+  } else if (lone) {
     for (int it = 0; it < Sc.iters; ++it) {
 #ifdef PF_PHASE_TRACE
       pf_sweeps = it + 1;
@@ -943,10 +1070,15 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     // (SPARE: the lane's spare with the state groups -- requested behind the int group's arrival it came 0.4 us late for the resets)
     float4 gs7 = float4{0.f, 0.f, 0.f, 0.f};
     if (SPARE) gs7 = Sin[7 * N + li];
-    if (SPARE) {  // (a VECTOR load behind the state groups, in their order: as a scalar load it would sit in every lgkmcnt wait that follows)
-      const uint32_t* cp = launch_ctr + blockIdx.x;
-      asm volatile("" : "+v"(cp));
-      call0 = *cp;
+    if (SPARE) {
+      // (a VECTOR load behind the state groups, in their order: as a scalar load it would sit in every lgkmcnt wait that follows. The
+      //  address goes through an opaque copy so that the compiler does not recognise it as uniform, and comes back as a GLOBAL
+      //  pointer: through a generic one this was a flat_load, which may complete out of order with the global loads -- every wait
+      //  behind it became vmcnt(0), 0.35 us in front of the step's Philox call)
+      typedef const uint32_t __attribute__((address_space(1))) * gu32ptr;
+      uintptr_t ca = reinterpret_cast<uintptr_t>(launch_ctr + blockIdx.x);
+      asm volatile("" : "+v"(ca));
+      call0 = *reinterpret_cast<gu32ptr>(ca);
     }
     // the action is first needed after the resets, a microsecond from here: requested where it is used (inside the stepping
     // lanes' branch) every wave sat out its whole memory latency there; requested behind the state groups it is long there

@@ -109,6 +109,19 @@ def test_shipped_code_object_is_clean(tmp_path):
     dis = subprocess.run([objdump, "-d", "--symbolize-operands", objs[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout.split("\n")
     assert sum(1 for l in dis if "s_cbranch_execz" in l) > 1000  # (the disassembly is the real thing)
     assert chk.lint("libpyflyt_amd.so", dis) == 0
+    # no FLAT memory instruction in the specialised env kernels: a flat_load may complete out of order with the global loads, so every
+    # wait behind one becomes vmcnt(0) -- round 6 met one (a counter read through a pointer that had lost its address space) as
+    # 0.35 us in front of every wave's first Philox call
+    import re
+
+    cur, flat = None, {}
+    for l in dis:
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", l)
+        if m:
+            cur = m.group(1)
+        elif cur and ("quadx_m0_env_kernel" in cur or "fixedwing_wp_env_kernel" in cur) and re.search(r"\bflat_(load|store|atomic)", l):
+            flat[cur] = flat.get(cur, 0) + 1
+    assert not flat, flat
 
 
 def test_the_build_repairs_only_when_the_lint_fires_and_then_only_the_committed_sites(tmp_path, monkeypatch):

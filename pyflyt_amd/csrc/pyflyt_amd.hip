@@ -805,8 +805,8 @@ template <int TASK>
 static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t* mask, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
   // (the one-wave-per-SIMD instantiation -- quadx_fast.hpp, WPS -- where the batch is no more than that and the kernel has it; since
-  //  round 5 the cascaded flight modes as well: their fp64 controller needs the 512 registers -- 408 B of stack per lane under 256)
-#define PF_FAST4(NZ, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
+  //  round 6 the PettingZoo task with independent lanes as well; since round 5 the cascaded flight modes: their fp64 controller needs the 512 registers -- 408 B of stack per lane under 256)
+#define PF_FAST4(NZ, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH)) ? 1 : 2; \
     if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u, ctx->launch_ctr); \
     else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, 0, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, op, mask, 1, 0u, ctx->launch_ctr); } while (0)
   // (flight modes other than 0: the MODES instantiation, contact response compiled in -- quadk_from_params)
@@ -823,7 +823,7 @@ static void launch_fast(pf_ctx* ctx, const pf_buffers* b, int op, const uint8_t*
 template <int TASK>
 static void launch_rollout(pf_ctx* ctx, const pf_buffers* b, int k_steps, uint32_t step0, hipStream_t s) {
   const int grid = (ctx->n + 64 * pf::kQuadWPB - 1) / (64 * pf::kQuadWPB);
-#define PF_ROLL4(NZ, R, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH) && TASK != PF_TASK_MA_HOVER) ? 1 : 2; \
+#define PF_ROLL4(NZ, R, CR, MD, SH) do { constexpr int W1 = ((CR) && !(SH)) ? 1 : 2; \
     if (W1 == 1 && ctx->lean) hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, W1>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0, ctx->launch_ctr); \
     else hipLaunchKernelGGL((pf::quadx_m0_env_kernel<TASK, NZ, 64, R, CR, MD, SH, 2>), dim3(grid), dim3(64 * pf::kQuadWPB), 0, s, ctx->K, *b, ctx->P_dev, ctx->n, ctx->lane0, 0, (const uint8_t*)nullptr, k_steps, step0, ctx->launch_ctr); } while (0)
 #define PF_ROLL3(NZ, R, CR, MD) do { if (TASK == PF_TASK_MA_HOVER && CR && ctx->K.apw > 1) PF_ROLL4(NZ, R, CR, MD, (TASK == PF_TASK_MA_HOVER && CR)); else PF_ROLL4(NZ, R, CR, MD, false); } while (0)
@@ -964,7 +964,7 @@ int pf_ctx_create(const pf_params* params, int n_lanes, int device, uint64_t lan
       e = hipMemcpy(reinterpret_cast<char*>(c->P_dev) + pf::kQuadSolveOffset, sw, sizeof(sw), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && c->fast) {  // (quadx_fast.hpp: launch_ctr)
-      const size_t words = ((size_t)n_lanes + 63) / 64;
+      const size_t words = (size_t)pf::kCtrStride * (((size_t)n_lanes + 63) / 64);
       e = hipMalloc((void**)&c->launch_ctr, sizeof(uint32_t) * words);
       if (e == hipSuccess) e = hipMemset(c->launch_ctr, 0, sizeof(uint32_t) * words);
     }

@@ -960,6 +960,9 @@ __device__ unsigned long long g_calm_trace[2];  // (waves that were not calm ove
 // in group 11's third word and generate at reset; so do the injected-noise and shared-world instantiations and the generic kernel.)
 constexpr uint32_t kSpareValid = 0x80000000u;
 constexpr uint32_t kSpareEvery = 16u;
+// The refill cadence's counter words (quadx_m0_env_kernel: launch_ctr), one per workgroup, each on a 128-byte line of its own: packed
+// sixteen to a line they cost a 4 096-lane launch 0.15 us (7.60 against 7.45 us; 65 536 lanes: no difference -- profiles/r06).
+constexpr int kCtrStride = 32;
 struct QuadSpare {
   float z, vz, thr;
   float4 t[4];
@@ -999,7 +1002,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
                                                              uint32_t* launch_ctr) {
   constexpr bool ROLLOUT = ROLL != 0;
   // (see QuadSpare) REKEY: a reset's draws are keyed by the counter at the previous reset; SPARE: ... and prepared ahead. launch_ctr: one
-  // word per workgroup in device memory, the env steps this context has taken -- the refill cadence is a function of that count alone.
+  // word per workgroup (kCtrStride apart) in device memory, the env steps this context has taken -- the refill cadence is a function of that count alone.
   // It is DEVICE state (round 5 passed the host's count as a kernel argument, which a HIP-graph capture bakes in: a captured
   // single step replayed for ever either never refilled or refilled in every launch -- ADVICE r05): every workgroup reads its own
   // word with the state groups and writes it back advanced by the steps it took, so all workgroups of a launch see the same count.
@@ -1076,7 +1079,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
       //  pointer: through a generic one this was a flat_load, which may complete out of order with the global loads -- every wait
       //  behind it became vmcnt(0), 0.35 us in front of the step's Philox call)
       typedef const uint32_t __attribute__((address_space(1))) * gu32ptr;
-      uintptr_t ca = reinterpret_cast<uintptr_t>(launch_ctr + blockIdx.x);
+      uintptr_t ca = reinterpret_cast<uintptr_t>(launch_ctr + kCtrStride * blockIdx.x);
       asm volatile("" : "+v"(ca));
       call0 = *reinterpret_cast<gu32ptr>(ca);
     }
@@ -1569,7 +1572,6 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
   };
 
   const int KS = ROLLOUT ? k_steps : 1;
-  const uint32_t call0_u = SPARE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)call0) : 0u;  // (the same word in every lane: wave-uniform control flow below)
   float4 a_nxt = float4{0.f, 0.f, 0.f, 0.f};
   if (GIVEN) a_nxt = reinterpret_cast<const float4*>(B.actions)[li];
   for (int it = 0; it < KS; ++it) {
@@ -1582,6 +1584,10 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
   reward = 0.0f;
   was_reset = false;
   do_resets(do_reset);
+  // (the counter word is first needed HERE, behind the resets: read where the loop starts, its wait sat in front of them -- the load is
+  //  the last of the prologue's, and a lone wave of a 4 096-lane batch waited 0.45 us for it. The same word in every lane: made
+  //  wave-uniform for the control flow below)
+  const uint32_t call0_u = SPARE ? (uint32_t)__builtin_amdgcn_readfirstlane((int)call0) : 0u;
   refill_spares(op == 1 || ((call0_u + (uint32_t)it) % kSpareEvery) == kSpareEvery - 1u);
   PF_STAMP(4);  // (NEXT_STEP resets done)
 
@@ -1792,7 +1798,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
   if (ROLLOUT && NOISE == PF_NOISE_PHILOX && it + 1 < KS)
     zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
   }  // for it
-  if (SPARE && op == 0 && tid == 0) launch_ctr[blockIdx.x] = call0_u + (uint32_t)KS;
+  if (SPARE && op == 0 && tid == 0) launch_ctr[kCtrStride * blockIdx.x] = call0 + (uint32_t)KS;
   if (active) {  // the persistent state goes back to HBM once per launch
     Sout[0 * N + li] = float4{V.p.x, V.p.y, V.p.z, new_dist};
     Sout[1 * N + li] = float4{V.q.x, V.q.y, V.q.z, V.q.w};

@@ -104,6 +104,11 @@ ENV_RTOL = {("env_quadx_waypoints_mode7", "specialised"): 5e-3, ("env_quadx_wayp
 @pytest.mark.parametrize("kernel", ["specialised", "generic"])
 @pytest.mark.parametrize("name,vehicle,task,over", ENVS)
 def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
+    replay_env_fixture(monkeypatch, name, vehicle, task, over, kernel)
+
+
+def replay_env_fixture(monkeypatch, name, vehicle, task, over, kernel, corrupt=None):
+    """corrupt = (step, lane, group, word, delta): one word of the device state moved before that step (the harness's negative test)"""
     from pyflyt_amd import _lib as L
     from pyflyt_amd import build_params
     from pyflyt_amd.engine import BatchEngine
@@ -138,6 +143,8 @@ def test_env_fixture_replay(monkeypatch, name, vehicle, task, over, kernel):
         if k in resets:
             do_reset()
         a = torch.tensor(np.repeat(g["action"][k][None], N, axis=0), dtype=torch.float32, device=DEV).contiguous()
+        if corrupt is not None and corrupt[0] == k:
+            eng.state[corrupt[2], corrupt[1], corrupt[3]] += corrupt[4]
         obs, rew, term, trunc = eng.env_step(a, xi=dev_cols(g["xi"][k]))
         e = vec_err(obs.double().cpu().numpy(), g["obs"][k], G)
         zi = 12 if P.angle_repr else 11  # index of z in the observation
@@ -455,3 +462,14 @@ def test_aviary_wind_fixture_replay(name):
         worst = max(worst, e)
         assert e < RTOL, (name, k, e)
     print(f"{name}: worst {worst:.2e}")
+
+
+@pytest.mark.parametrize("kernel", ["specialised", "generic"])
+def test_the_fixture_replay_fails_when_one_lane_is_wrong(monkeypatch, kernel):
+    """The fixture replay's own negative test: every lane replays the same recording; with one word of ONE lane's state moved by
+    1e-3 before one step the replay fails at that step -- and passes untouched."""
+    name, vehicle, task, over = next(c for c in ENVS if c[0] == "env_hover_random")
+    with pytest.raises(AssertionError) as ei:
+        replay_env_fixture(monkeypatch, name, vehicle, task, over, kernel, corrupt=(4, N - 1, 0, 2, 1e-3))
+    assert "env_hover_random" in str(ei.value) and ", 4, " in str(ei.value)  # (the assertion names the fixture and the step)
+    replay_env_fixture(monkeypatch, name, vehicle, task, over, kernel)

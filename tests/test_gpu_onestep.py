@@ -77,9 +77,15 @@ def pack_state(ob, eng, waypoints):
 @pytest.mark.parametrize("task,mode,noise", [("hover", 7, "off"), ("hover", 6, "off"), ("hover", 4, "off"), ("waypoints", 7, "off"), ("hover", 0, "off"),
                                              ("waypoints", 0, "off"), ("hover", 0, "philox"), ("waypoints", 7, "philox")])
 def test_quadx_one_step_parity(task, mode, noise, kernel, monkeypatch):
+    quadx_one_step_parity(task, mode, noise, kernel, monkeypatch)
+
+
+def quadx_one_step_parity(task, mode, noise, kernel, monkeypatch, corrupt=None, steps=150):
+    """corrupt = (step, lane, group, word, delta): one word of the device state moved AFTER the oracle's state has been written into it
+    (the harness's negative test)"""
     if kernel == "generic":
         monkeypatch.setenv("PF_DISABLE_FAST", "1")
-    n, steps = 256, 150
+    n = 256
     kw = dict(flight_mode=mode, max_duration_seconds=2.0)  # (60-step episodes: every lane restarts twice, the in-kernel reset of the controller memories included)
     if task == "waypoints":
         kw["goal_reach_distance"] = 0.4
@@ -98,6 +104,8 @@ def test_quadx_one_step_parity(task, mode, noise, kernel, monkeypatch):
     worst, worst_at, ends = 0.0, None, 0
     for s in range(steps):
         pack_state(ob, eng, task == "waypoints")
+        if corrupt is not None and corrupt[0] == s:
+            eng.state[corrupt[2], corrupt[1], corrupt[3]] += corrupt[4]
         eng.sample_actions(act, s)
         o, r, t, u = eng.env_step(act)
         ro, rr, rt, ru, _ = ob.step(act.cpu().numpy(), autoreset=1)
@@ -360,3 +368,13 @@ def test_shared_world_one_step_parity(kernel, monkeypatch):
     print("  beyond 1e-4:", sorted(round(x, 5) for x in big))
     assert pair_hits >= E // 2 and touched_steps > 500
     assert switches <= 0.015 * touched_steps and worst_switch < 0.1 and sum(x > 1e-3 for x in big) <= 8
+
+
+@pytest.mark.parametrize("kernel", ["specialised", "generic"])
+def test_the_one_step_harness_fails_when_one_lane_is_wrong(kernel, monkeypatch):
+    """The one-step harness's own negative test: the oracle's state is written into the device before every step; with one word of
+    ONE lane moved by 1e-3 after that, the comparison fails at that step (and names it) -- untouched, the same short run passes."""
+    with pytest.raises(AssertionError) as ei:
+        quadx_one_step_parity("hover", 0, "off", kernel, monkeypatch, corrupt=(5, 200, 2, 1, 1e-3), steps=12)  # velocity y of lane 200
+    assert ", 5, " in str(ei.value), str(ei.value)[:300]
+    # (untouched, the same harness passes: test_quadx_one_step_parity[hover-0-off])

@@ -83,7 +83,9 @@ QUAD_LOW, QUAD_HIGH = np.array([-np.pi] * 3 + [0.0]), np.array([np.pi] * 3 + [0.
 FW_LOW, FW_HIGH = -np.ones(4), np.ones(4)
 
 
-def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, high, seed=0, gentle=None, max_bad=None, rtol_impact=None, **over):
+def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, high, seed=0, gentle=None, max_bad=None, rtol_impact=None, corrupt=None, diagnose=False, **over):
+    """corrupt = (step, lane, group, word, delta): add delta to one word of the DEVICE's state before that step (the harness's own negative
+    test); diagnose: return (worst, episodes ended, dropped lanes, step of each lane's first violation) instead of asserting on them."""
     RTOL_IMPACT = rtol_impact if rtol_impact is not None else globals()["RTOL_IMPACT"]
     if max_bad is None:
         max_bad = 0.0 if vehicle == "quadx" else 0.005
@@ -146,6 +148,8 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
     for k in range(steps):
         a = sample_actions(rng, n, low, high) if gentle is None else gentle(rng, n)
         xi, xr, ut, dxi, dxr, dut = draws()
+        if corrupt is not None and corrupt[0] == k:
+            eng.state[corrupt[2], corrupt[1], corrupt[3]] += corrupt[4]
         og, rg, tg, trg = eng.env_step(torch.tensor(a, device="cuda:0"), xi=dxi, xi_reset=dxr, u_targets=dut)
         og, rg = og.cpu().numpy().astype(np.float64), rg.cpu().numpy().astype(np.float64)
         tg, trg = tg.cpu().numpy(), trg.cpu().numpy()
@@ -222,6 +226,8 @@ def run_env_parity(vehicle, task, env_name, n, steps, noise, autoreset, low, hig
     print(f"{vehicle}/{task} noise={noise} autoreset={autoreset}: worst rel err {worst:.2e} over {lane_steps} lane-steps, "
           f"dropped lanes {frac_bad:.4f} ({int((~ok).sum())} of {n}; unclassified: {len(unexplained)}), "
           f"terminal observations off by an inner step {n_term_mis} of {n_done} episodes ended; worst observation with a floor impact in it {worst_impact:.2e}")
+    if diagnose:
+        return worst, n_done, np.nonzero(~ok)[0], first_bad
     assert not unexplained, f"lanes left the comparison without a discrete-event flip: {unexplained[:8]}"
     assert frac_bad <= max_bad, frac_bad
     assert n_term_mis <= max(2, int(2e-3 * n_done)), (n_term_mis, n_done)
@@ -331,3 +337,19 @@ def test_generic_kernel_parity(monkeypatch, vehicle, task, env_name, low, high):
     that path for the reference configurations so that it stays covered by the same oracle."""
     monkeypatch.setenv("PF_DISABLE_FAST", "1")
     run_env_parity(vehicle, task, env_name, 512, 100, "philox", "next_step", low, high, seed=37)
+
+
+def test_the_parity_harness_drops_exactly_the_lane_that_is_wrong():
+    """The harness's own negative test (round 5 found that `run_env_parity` had not been able to drop a lane for three rounds): one
+    word of ONE lane's device state is moved by 1e-3 before one step -- the harness reports exactly that lane as dropped, at that
+    step, keeps every other lane in the comparison, and a run with the default policy (no lane may leave) fails."""
+    lane, step = 37, 6
+    corrupt = (step, lane, 0, 0, 1e-3)  # position x, ten times the tolerance
+    worst, n_done, dropped, first_bad = run_env_parity("quadx", "hover", "hover", 256, 40, "philox", "next_step", QUAD_LOW, QUAD_HIGH, seed=3,
+                                                       corrupt=corrupt, diagnose=True)
+    assert dropped.tolist() == [lane] and first_bad[lane] == step and worst < RTOL
+    with pytest.raises(AssertionError):
+        run_env_parity("quadx", "hover", "hover", 256, 40, "philox", "next_step", QUAD_LOW, QUAD_HIGH, seed=3, corrupt=corrupt)
+    # the same run untouched: nothing dropped
+    worst, n_done, dropped, _ = run_env_parity("quadx", "hover", "hover", 256, 40, "philox", "next_step", QUAD_LOW, QUAD_HIGH, seed=3, diagnose=True)
+    assert dropped.size == 0 and worst < RTOL

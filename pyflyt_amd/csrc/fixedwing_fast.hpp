@@ -678,6 +678,10 @@ struct FwHot {
       surface<true>(Sv, act[3], F, tau);
       accumulate(tab.pair[1].ry.y, o[1].fp.y, o[1].fn.y, o[1].ty.y, F, tau);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef PF_FW_TICK_TRACE  // (the surfaces' share of the tick: this branch had no counter in round 5 -- its timeline read 0.000 us)
+      asm volatile("" ::"v"(F.x), "v"(tau.y));
+      if ((threadIdx.x & 63u) == 0u) { trace_add(&g_solver_trace[0], 1ull); trace_add(&g_solver_trace[1], __builtin_readcyclecounter() - pf_f0); }
+#endif
       tick_body<FLOOR, SHARED>(Kb, F, tau, xi, Pfull);
     } else {
       tick_scalar_table<FLOOR, SHARED>(tab, F, tau, xi, Pfull);

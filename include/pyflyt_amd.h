@@ -229,7 +229,11 @@ typedef struct pf_params {
  * context that made it (seed, lane offset, spawn pose, settle length, dome, number of targets): pf_env_reset with a NULL mask -- every
  * lane -- therefore ignores the spares it finds and prepares fresh ones, which is what a caller does first with a state buffer that
  * another context has used; a MASKED reset trusts them. The key is the event counter as the lane's previous reset left it: strictly
- * increasing from reset to reset (0 before the first). */
+ * increasing from reset to reset (0 before the first).
+ * QuadX env contexts in a cascaded flight mode (flight_mode != 0) on the specialised kernel without a shared world have 27 groups
+ * (pf_state_groups): groups 16-26 hold the float32 REMAINDERS of values the kernel carries in fp64 -- 16-19 position, quaternion,
+ * velocities, motor states; 20-21 the rate PID's memories; 22-26 the cascade's memories in the packing of groups 7-11 -- next to
+ * their float32 roundings in groups 0-5 / 7-11. A hand-written state leaves them zero (the value is then its float32 word). */
 typedef struct pf_buffers {
   float* state;            /* [pf_state_groups()][n][4] fp32/int32, persistent */
   const float* actions;    /* [n][4]   gym action (quadx_base_env.py:269); PF_TASK_DOGFIGHT with df_action_dim 6: [n][6] */

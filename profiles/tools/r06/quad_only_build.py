@@ -2,7 +2,7 @@
 """Experiment build: the library with ONLY the specialised QuadX kernels of ONE task instantiated, Philox noise, flight mode 0,
 contact response on (a temporary copy of pyflyt_amd.hip with the other launchers stubbed), straight through hipcc -- a minute
 instead of four; for A/B work on quadx_fast.hpp (PF_LIB_PATH=<out> python bench.py --env quadx_waypoints ...).
-Usage: quad_only_build.py out.so HOVER|WAYPOINTS [--save-asm] [hipcc flags]. Never the product library: no lint, no repair."""
+Usage: quad_only_build.py out.so HOVER|WAYPOINTS [--modes] [--save-asm] [hipcc flags]. Never the product library: no lint, no repair."""
 import os
 import re
 import subprocess
@@ -13,6 +13,8 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as G  # noqa: E402
 
 out, task, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
+modes = "--modes" in extra  # keep the cascaded-flight-mode instantiations (MODES = true) instead of the mode-0 ones
+extra = [e for e in extra if e != "--modes"]
 src = open(G.HIP_SRC).read()
 keep = f"PF_TASK_{task}"
 for t in ("PF_TASK_HOVER", "PF_TASK_MA_HOVER", "PF_TASK_WAYPOINTS"):
@@ -22,9 +24,9 @@ for t in ("PF_TASK_HOVER", "PF_TASK_MA_HOVER", "PF_TASK_WAYPOINTS"):
 # Philox only, mode 0 only, contact response only
 src = src.replace("  else if (ctx->P.noise_mode == PF_NOISE_INJECT) PF_FAST(PF_NOISE_INJECT);\n  else PF_FAST(PF_NOISE_OFF);\n#undef PF_FAST\n#undef PF_FAST3", "#undef PF_FAST\n#undef PF_FAST3")
 src = src.replace("#define PF_FAST(NZ) do { if (ctx->K.mode != 0) PF_FAST3(NZ, true, true); else if (ctx->P.contact_response) PF_FAST3(NZ, true, false); else PF_FAST3(NZ, false, false); } while (0)",
-                  "#define PF_FAST(NZ) do { PF_FAST3(NZ, true, false); } while (0)")
+                  "#define PF_FAST(NZ) do { PF_FAST3(NZ, true, %s); } while (0)" % ("true" if modes else "false"))
 src = src.replace("#define PF_ROLL(NZ, R) do { if (ctx->K.mode != 0) PF_ROLL3(NZ, R, true, true); else if (ctx->P.contact_response) PF_ROLL3(NZ, R, true, false); else PF_ROLL3(NZ, R, false, false); } while (0)",
-                  "#define PF_ROLL(NZ, R) do { PF_ROLL3(NZ, R, true, false); } while (0)")
+                  "#define PF_ROLL(NZ, R) do { PF_ROLL3(NZ, R, true, %s); } while (0)" % ("true" if modes else "false"))
 src = src.replace("    else PF_ROLL(PF_NOISE_OFF, 1);", "").replace("    else PF_ROLL(PF_NOISE_OFF, 2);", "")
 src = re.sub(r"(static void launch_env_t\([^{]*\{)(.*?)(\n\}\nextern \"C\")", r"\1\n  (void)ctx; (void)b; (void)op; (void)mask; (void)s; (void)roll_steps; (void)step0;\3", src, flags=re.S)
 src = src.replace("#define PF_DF(AA, VV) hipLaunchKernelGGL(", "#define PF_DF(AA, VV) if (false) hipLaunchKernelGGL(")

@@ -1006,6 +1006,9 @@ void pf_ctx_destroy(pf_ctx* ctx) {
 }
 int pf_state_groups(const pf_ctx* ctx) {
   if (ctx->P.task == PF_TASK_DOGFIGHT) return pf::kDfGroups;
+  // (the specialised QuadX kernel in a cascaded flight mode, no shared world: eleven more groups, the float32 remainders of its fp64
+  //  rigid-body state and PID memories -- quadx_fast.hpp: QuadStateD)
+  if (ctx->fast && ctx->K.mode != 0 && ctx->K.apw == 1) return pf::QuadX::GROUPS + 11;  // (16-19 state, 20-21 rate PID, 22-26 cascade)
   return ctx->P.vehicle == PF_QUADX ? pf::QuadX::GROUPS : (ctx->P.vehicle == PF_ROCKET ? pf::Rocket::GROUPS : pf::Fixedwing::GROUPS);
 }
 int pf_obs_dim(const pf_ctx* ctx) {

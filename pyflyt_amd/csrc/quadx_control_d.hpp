@@ -18,8 +18,10 @@ namespace pf {
 struct QuadCtlIn {  // update_state's outputs (quadx.py:512-535), fp64 from the float32 state
   double wb[3], vb[3], rpy[3], p[3];
 };
-PF_DEV QuadCtlIn quad_ctl_inputs(const quat qf, const v3 vf, const v3 wf, const v3 pf_) {
-  const double x = qf.x, y = qf.y, z = qf.z, w = qf.w;
+// (the double-precision core: the specialised kernel's cascaded-mode instantiations carry the rigid-body state itself in fp64 since
+//  round 6 and call this directly -- quadx_fast.hpp: QuadStateD)
+PF_DEV QuadCtlIn quad_ctl_inputs_d(const double q4[4], const double v3d[3], const double w3d[3], const double p3d[3]) {
+  const double x = q4[0], y = q4[1], z = q4[2], w = q4[3];
   // btMatrix3x3::setRotation
   const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;
   const double xs = x * s, ys = y * s, zs = z * s;
@@ -27,7 +29,7 @@ PF_DEV QuadCtlIn quad_ctl_inputs(const quat qf, const v3 vf, const v3 wf, const 
   const double R00 = 1.0 - (yy + zz), R01 = xy - wz, R02 = xz + wy, R10 = xy + wz, R11 = 1.0 - (xx + zz), R12 = yz - wx,
                R20 = xz - wy, R21 = yz + wx, R22 = 1.0 - (xx + yy);
   QuadCtlIn o;
-  const double v0 = vf.x, v1 = vf.y, v2 = vf.z, w0 = wf.x, w1 = wf.y, w2 = wf.z;
+  const double v0 = v3d[0], v1 = v3d[1], v2 = v3d[2], w0 = w3d[0], w1 = w3d[1], w2 = w3d[2];
   o.vb[0] = R00 * v0 + R10 * v1 + R20 * v2; o.vb[1] = R01 * v0 + R11 * v1 + R21 * v2; o.vb[2] = R02 * v0 + R12 * v1 + R22 * v2;
   o.wb[0] = R00 * w0 + R10 * w1 + R20 * w2; o.wb[1] = R01 * w0 + R11 * w1 + R21 * w2; o.wb[2] = R02 * w0 + R12 * w1 + R22 * w2;
   // getEulerFromQuaternion (ZYX, gimbal-lock branch at |sarg| >= 0.99999)
@@ -40,37 +42,47 @@ PF_DEV QuadCtlIn quad_ctl_inputs(const quat qf, const v3 vf, const v3 wf, const 
     o.rpy[1] = asin(sarg);
     o.rpy[2] = atan2(2.0 * (x * y + w * z), squ + sqx - sqy - sqz);
   }
-  o.p[0] = pf_.x; o.p[1] = pf_.y; o.p[2] = pf_.z;
+  o.p[0] = p3d[0]; o.p[1] = p3d[1]; o.p[2] = p3d[2];
   return o;
 }
+PF_DEV QuadCtlIn quad_ctl_inputs(const quat qf, const v3 vf, const v3 wf, const v3 pf_) {
+  const double q4[4] = {qf.x, qf.y, qf.z, qf.w}, v3d[3] = {vf.x, vf.y, vf.z}, w3d[3] = {wf.x, wf.y, wf.z}, p3d[3] = {pf_.x, pf_.y, pf_.z};
+  return quad_ctl_inputs_d(q4, v3d, w3d, p3d);
+}
 PF_DEV double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
-// abstractions/pid.py:70-94 for one component; the memories are the state groups' float32 words
-PF_DEV double pid1d(const float kp, const float ki, const float kd, const float lim, const double T, float& I, float& E, const double st, const double sp) {
+// abstractions/pid.py:70-94 for one component. MT: the memories' type -- float (the state groups' words: the generic vehicle, shared
+// worlds) or double (the specialised kernel's cascaded-mode instantiations since round 6: a stored error rounded to float32 comes back
+// through the derivative term, k_d / T = 60, in the very next control update -- with the PIDs' internals ALONE in float32 the fp64
+// oracle replays the mode-7 fixture 1.5e-4 away from itself, with everything else the device still rounds 6.6e-6)
+template <class MT>
+PF_DEV double pid1d(const float kp, const float ki, const float kd, const float lim, const double T, MT& I, MT& E, const double st, const double sp) {
   const double e = sp - st;
   const double l = lim;
   const double In = clampd((double)I + (double)ki * e * T, -l, l);
   const double der = (double)kd * (e - (double)E) / T;
-  I = (float)In;
-  E = (float)e;
+  I = (MT)In;
+  E = (MT)e;
   return clampd((double)kp * e + In + der, -l, l);
 }
 // The memories of one vehicle: pointers into the owner's members (everything is force-inlined: they stay in registers)
-struct QuadMemD {
-  float *I0, *E0;  // ang_vel  [3]
-  float *I1, *E1;  // ang_pos  [3]
-  float *I2, *E2;  // lin_vel  [2]
-  float *I3, *E3;  // lin_pos  [2]
-  float *zI, *zE;  // z_vel, z_pos
+template <class MT>
+struct QuadMemT {
+  MT *I0, *E0;  // ang_vel  [3]
+  MT *I1, *E1;  // ang_pos  [3]
+  MT *I2, *E2;  // lin_vel  [2]
+  MT *I3, *E3;  // lin_pos  [2]
+  MT *zI, *zE;  // z_vel, z_pos
 };
+typedef QuadMemT<float> QuadMemD;
 // update_control for mode 1 .. 7: setpoint -> the four motor commands. PP: (pointer to) the parameter block (a plain reference's
 // address or the scalar-cache pointer of the specialised kernels). T: the control period.
-template <class PP>
-PF_DEV void quad_cascade_d(const PP P, const int mode, const double T, const QuadCtlIn& in, const QuadMemD M, const float sp[4], float pwm[4]) {
+template <class PP, class MT, class OT = float>
+PF_DEV void quad_cascade_d(const PP P, const int mode, const double T, const QuadCtlIn& in, const QuadMemT<MT> M, const float sp[4], OT pwm[4]) {
   double a[3] = {sp[0], sp[1], sp[2]};
   double z = sp[3];
   // (always_inline: left out of line -- the diagnostic build's generic kernels did that -- the captures become flat pointers to the
   //  caller's stack, and ROCm 7.2's instruction selection aborts on the private-aperture test that goes with them)
-  auto pidn = [&](const int k, float* I, float* E, const double* st, const int n) __attribute__((always_inline)) {
+  auto pidn = [&](const int k, MT* I, MT* E, const double* st, const int n) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       if (i < n) a[i] = pid1d(P->pid[k].kp[i], P->pid[k].ki[i], P->pid[k].kd[i], P->pid[k].lim[i], T, I[i], E[i], st[i], a[i]);
@@ -114,7 +126,7 @@ PF_DEV void quad_cascade_d(const PP P, const int mode, const double T, const Qua
     for (int i = 0; i < 4; ++i) pw[i] += ka * (pmax - pw[i]) - ks * (pw[i] - pmin);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) pwm[i] = (float)clampd(pw[i], 0.05, 1.0);
+  for (int i = 0; i < 4; ++i) pwm[i] = (OT)clampd(pw[i], 0.05, 1.0);
 }
 
 }  // namespace pf

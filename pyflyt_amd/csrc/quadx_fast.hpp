@@ -209,32 +209,53 @@ PF_DEV QuadKV quadkv_from(const QuadK& K) {
   V.dt = in_vgpr(K.dt); V.vmax = in_vgpr(K.vmax); V.half_dt = in_vgpr(K.half_dt);
   return V;
 }
-struct QuadCasc {
-  float I1[3], E1[3];                // ang_pos
-  float I2[2], E2[2], I3[2], E3[2];  // lin_vel, lin_pos
-  float zI[2], zE[2];                // z_vel, z_pos
+template <class MT>
+struct QuadCascT {
+  MT I1[3], E1[3];                // ang_pos
+  MT I2[2], E2[2], I3[2], E3[2];  // lin_vel, lin_pos
+  MT zI[2], zE[2];                // z_vel, z_pos
   PF_DEV void zero() {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) I1[k] = E1[k] = 0.0f;
+    for (int k = 0; k < 3; ++k) I1[k] = E1[k] = (MT)0;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) I2[k] = E2[k] = I3[k] = E3[k] = zI[k] = zE[k] = 0.0f;
+    for (int k = 0; k < 2; ++k) I2[k] = E2[k] = I3[k] = E3[k] = zI[k] = zE[k] = (MT)0;
+  }
+  // groups g0 .. g0 + 4 of the state: the eighteen memories, packed as the generic vehicle's groups 7-11 (+ the key word)
+  PF_DEV void unpack(const float4 g7, const float4 g8, const float4 g9, const float4 g10, const float4 g11, const bool add) {
+    const MT v[18] = {(MT)g7.x, (MT)g7.y, (MT)g7.z, (MT)g7.w, (MT)g8.x, (MT)g8.y, (MT)g8.z, (MT)g8.w, (MT)g9.x, (MT)g9.y, (MT)g9.z, (MT)g9.w,
+                      (MT)g10.x, (MT)g10.y, (MT)g10.z, (MT)g10.w, (MT)g11.x, (MT)g11.y};
+    MT* const d[18] = {&I1[0], &I1[1], &I1[2], &E1[0], &E1[1], &E1[2], &I2[0], &I2[1], &E2[0], &E2[1], &I3[0], &I3[1], &E3[0], &E3[1], &zI[0], &zI[1], &zE[0], &zE[1]};
+#pragma unroll
+    for (int k = 0; k < 18; ++k) *d[k] = add ? *d[k] + v[k] : v[k];
   }
   PF_DEV void load(const float4* S, size_t n, size_t i) {
-    const float4 g7 = S[7 * n + i], g8 = S[8 * n + i], g9 = S[9 * n + i], g10 = S[10 * n + i], g11 = S[11 * n + i];
-    I1[0] = g7.x; I1[1] = g7.y; I1[2] = g7.z; E1[0] = g7.w;
-    E1[1] = g8.x; E1[2] = g8.y; I2[0] = g8.z; I2[1] = g8.w;
-    E2[0] = g9.x; E2[1] = g9.y; I3[0] = g9.z; I3[1] = g9.w;
-    E3[0] = g10.x; E3[1] = g10.y; zI[0] = g10.z; zI[1] = g10.w;
-    zE[0] = g11.x; zE[1] = g11.y;
+    unpack(S[7 * n + i], S[8 * n + i], S[9 * n + i], S[10 * n + i], S[11 * n + i], false);
   }
   PF_DEV void store(float4* S, size_t n, size_t i, const uint32_t key_word = 0u) const {  // key_word: quadx_fast.hpp, QuadSpare
-    S[7 * n + i] = float4{I1[0], I1[1], I1[2], E1[0]};
-    S[8 * n + i] = float4{E1[1], E1[2], I2[0], I2[1]};
-    S[9 * n + i] = float4{E2[0], E2[1], I3[0], I3[1]};
-    S[10 * n + i] = float4{E3[0], E3[1], zI[0], zI[1]};
-    S[11 * n + i] = float4{zE[0], zE[1], __int_as_float((int)key_word), 0.0f};
+    S[7 * n + i] = float4{(float)I1[0], (float)I1[1], (float)I1[2], (float)E1[0]};
+    S[8 * n + i] = float4{(float)E1[1], (float)E1[2], (float)I2[0], (float)I2[1]};
+    S[9 * n + i] = float4{(float)E2[0], (float)E2[1], (float)I3[0], (float)I3[1]};
+    S[10 * n + i] = float4{(float)E3[0], (float)E3[1], (float)zI[0], (float)zI[1]};
+    S[11 * n + i] = float4{(float)zE[0], (float)zE[1], __int_as_float((int)key_word), 0.0f};
+  }
+  PF_DEV void through_hilo() {  // (MT = double; see QuadStateD::hilo)
+    auto h = [](const MT x) { const float f = (float)x; return (MT)((double)f + (double)(float)((double)x - (double)f)); };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { I1[k] = h(I1[k]); E1[k] = h(E1[k]); }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { I2[k] = h(I2[k]); E2[k] = h(E2[k]); I3[k] = h(I3[k]); E3[k] = h(E3[k]); zI[k] = h(zI[k]); zE[k] = h(zE[k]); }
+  }
+  // (MT = double) the remainders: each memory minus its float32 rounding, the same packing in groups g0 .. g0 + 4
+  PF_DEV void store_lo(float4* S, size_t n, size_t i, const int g0) const {
+    auto lo = [](const MT x) { return (float)((double)x - (double)(float)x); };
+    S[(size_t)(g0 + 0) * n + i] = float4{lo(I1[0]), lo(I1[1]), lo(I1[2]), lo(E1[0])};
+    S[(size_t)(g0 + 1) * n + i] = float4{lo(E1[1]), lo(E1[2]), lo(I2[0]), lo(I2[1])};
+    S[(size_t)(g0 + 2) * n + i] = float4{lo(E2[0]), lo(E2[1]), lo(I3[0]), lo(I3[1])};
+    S[(size_t)(g0 + 3) * n + i] = float4{lo(E3[0]), lo(E3[1]), lo(zI[0]), lo(zI[1])};
+    S[(size_t)(g0 + 4) * n + i] = float4{lo(zE[0]), lo(zE[1]), 0.0f, 0.0f};
   }
 };
+typedef QuadCascT<float> QuadCasc;
 
 // ------------------------------------------------------------------------------------------
 // The floor contact solve of THIS kernel's airframe, in registers (round 4). What quadk_from_params guarantees -- one collision box
@@ -667,6 +688,48 @@ PF_DEV QuadFloorOut quad_floor_solve(const QuadK& Kc, const pf_params* Pfull, co
 }
 
 
+// The rigid-body state of the cascaded flight modes in fp64 (round 6; the MODES instantiations without a shared world). The outer
+// loops of modes 4-7 differentiate positions and velocities (k_d / T = 60 per control tick) and hand the result down three more PIDs:
+// whatever is rounded to float32 on the way -- state, derived quantities, PID internals -- comes back amplified a thousandfold over an
+// episode (tests/tools/fp32_rounding_sites.py: the fp64 oracle with ONLY the state rounded after every tick replays the mode-7 fixture
+// 2.2e-4 away from itself, with float32 parameters and fp64 arithmetic 2.5e-5, with float32 motors alone 3e-5). Round 5 moved the
+// controller to fp64 (quadx_control_d.hpp); the state it read was still float32: 1.7e-3 on that fixture. Here the master copy of
+// (p, q, v, w) is fp64 -- state groups 0-3 hold its float32 rounding as before, groups 16-19 the remainders -- and the tick's
+// arithmetic from the motor thrusts on (which stay float32) is the oracle's (oracle/uav_oracle.c: rigid_tick_vel / rigid_tick_pos)
+// for this airframe: centre of mass on the base origin, diagonal inertia. The float32 members of QuadHot are kept as the ROUNDED VIEW
+// of it: the floor tests, the contact solve, the observation and the task's tests read them as before. fp64 vector instructions issue
+// at the float32 rate on gfx950, the mode-0 instantiations do not contain this code, and no BASELINE config runs these modes.
+struct QuadStateD {
+  double p[3], q[4], v[3], w[3];
+  double R[9], wb[3], vb[3];  // update_state (quadx.py:512-535): rotation matrix of q, R^T w, R^T v
+  double rI[3], rE[3];        // the rate PID's memories (QuadHot::I / E are their float32 view)
+  double thr[4], pwm[4];      // the motors' states (QuadHot::t01 / t23 their view) and commands
+  PF_DEV void derive() {  // btMatrix3x3::setRotation
+    const double x = q[0], y = q[1], z = q[2], ww = q[3];
+    const double d = x * x + y * y + z * z + ww * ww, s = 2.0 / d;
+    const double xs = x * s, ys = y * s, zs = z * s;
+    const double wx = ww * xs, wy = ww * ys, wz = ww * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy; R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      wb[k] = R[k] * w[0] + R[3 + k] * w[1] + R[6 + k] * w[2];
+      vb[k] = R[k] * v[0] + R[3 + k] * v[1] + R[6 + k] * v[2];
+    }
+  }
+  PF_DEV QuadCtlIn ctl_inputs() const { return quad_ctl_inputs_d(q, v, w, p); }
+  // what survives a store / load through the state groups: the float32 rounding + the float32 rounding of the remainder (48 of a
+  // double's 53 bits). pf_rollout passes its resident copy through this after every env step, so that it equals k launches bit for bit.
+  PF_DEV static double hilo(const double x) { const float h = (float)x; return (double)h + (double)(float)(x - (double)h); }
+  PF_DEV void through_hilo() {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { p[k] = hilo(p[k]); v[k] = hilo(v[k]); w[k] = hilo(w[k]); rI[k] = hilo(rI[k]); rE[k] = hilo(rE[k]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { q[k] = hilo(q[k]); thr[k] = hilo(thr[k]); }
+    derive();
+  }
+};
+
 struct QuadHot {
   v3 p; quat q;
   // angular / linear velocity as (w, v) element pairs, motor throttle and pwm as (0, 1), (2, 3) pairs: the operands of the
@@ -716,20 +779,29 @@ struct QuadHot {
   }
   // update_control (quadx.py:401-493). MODES = false: flight mode 0 only (rate PID + thrust, :437-438,472,482-493), the
   // instantiation BASELINE's metric is quoted on; MODES = true: K.mode selects -1 .. 7 at run time (wave-uniform branches).
-  template <bool MODES>
-  PF_DEV void control(const QuadK& K, const pf_params_kptr Pk, QuadCasc& C, float s0, float s1, float s2, float s3) {
+  template <bool MODES, class CT = QuadCasc>
+  PF_DEV void control(const QuadK& K, const pf_params_kptr Pk, CT& C, float s0, float s1, float s2, float s3, QuadStateD* D = nullptr) {
     if (MODES) {
       if (K.mode == -1) {  // motor commands as they are (quadx.py:427-429): no clipping
         pw01 = f2{s0, s1}; pw23 = f2{s2, s3};
+        if (D != nullptr) { D->pwm[0] = s0; D->pwm[1] = s1; D->pwm[2] = s2; D->pwm[3] = s3; }
         return;
       }
       if (K.mode != 0) {
         // the cascaded modes: state derivation and every PID in fp64, shared with the generic vehicle (quadx_control_d.hpp: why --
         // round 4's float32 outer loops on polynomial atan2 / asin sat 5 x further from the reference than the generic kernel)
-        const QuadCtlIn in = quad_ctl_inputs(q, v(), w(), p);
+        const QuadCtlIn in = D != nullptr ? D->ctl_inputs() : quad_ctl_inputs(q, v(), w(), p);  // (D: the fp64 state, wave-uniformly there or not)
         const float sp4[4] = {s0, s1, s2, s3};
         float pw[4];
-        quad_cascade_d(Pk, K.mode, (double)Pk->control_period, in, QuadMemD{I, E, C.I1, C.E1, C.I2, C.E2, C.I3, C.E3, C.zI, C.zE}, sp4, pw);
+        if constexpr (std::is_same<CT, QuadCascT<double>>::value) {  // (the memories in fp64: D is there)
+          quad_cascade_d(Pk, K.mode, (double)Pk->control_period, in, QuadMemT<double>{D->rI, D->rE, C.I1, C.E1, C.I2, C.E2, C.I3, C.E3, C.zI, C.zE}, sp4, D->pwm);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { I[k] = (float)D->rI[k]; E[k] = (float)D->rE[k]; }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pw[k] = (float)D->pwm[k];
+        } else {
+          quad_cascade_d(Pk, K.mode, (double)Pk->control_period, in, QuadMemD{I, E, C.I1, C.E1, C.I2, C.E2, C.I3, C.E3, C.zI, C.zE}, sp4, pw);
+        }
         pw01 = f2{pw[0], pw[1]}; pw23 = f2{pw[2], pw[3]};
         return;
       }
@@ -880,6 +952,117 @@ struct QuadHot {
     else p = v3{fmaf(K.dt, wvx.y, p.x), fmaf(K.dt, wvy.y, p.y), CR ? fmaf(K.dt, wvz.y, p.z) + lift : fmaf(K.dt, wvz.y, p.z)};
     q = quat_integrate(q, w(), K.half_dt);
     derive();
+    contact_step |= contact_now;
+  }
+  // this struct's float32 members <- the rounding of the fp64 state (and derive() on them)
+  PF_DEV void view_of(const QuadStateD& D) {
+    p = v3{(float)D.p[0], (float)D.p[1], (float)D.p[2]};
+    q = quat{(float)D.q[0], (float)D.q[1], (float)D.q[2], (float)D.q[3]};
+    set_wv(v3{(float)D.w[0], (float)D.w[1], (float)D.w[2]}, v3{(float)D.v[0], (float)D.v[1], (float)D.v[2]});
+    derive();
+  }
+  // The same physics tick with the rigid-body state in fp64 (QuadStateD): motors in float32 as above, then the oracle's arithmetic --
+  // rigid_tick_vel / rigid_tick_pos for a body with its centre of mass on the base origin and a diagonal inertia -- on doubles;
+  // collision detection and the contact solve on the float32 view, as in tick<>; a lane whose velocities the solve changed takes them
+  // over (an impact is float32 either way: the parity tests' impact tolerance).
+  template <bool CR, bool INL>
+  PF_DEV void tick_d(QuadStateD& D, const QuadK& K, float xi, const pf_params* Pfull) {
+    double kd[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // motors.py:131-138: first-order lag, then the noise as a fraction of the state
+      D.thr[i] += (double)K.m_a * (D.pwm[i] - D.thr[i]);
+      D.thr[i] += (double)xi * D.thr[i] * (double)K.m_noise;
+      kd[i] = D.thr[i] * __builtin_fabs(D.thr[i]);
+    }
+    t01 = f2{(float)D.thr[0], (float)D.thr[1]}; t23 = f2{(float)D.thr[2], (float)D.thr[3]};
+    const double k0 = kd[0], k1 = kd[1], k2 = kd[2], k3 = kd[3];
+    const double pqf = contact_now ? 0.0 : 1.0;
+    // body-frame angular acceleration and specific force (the constants are tick<>'s: torque / inertia, force / mass)
+    double wdb[3] = {(double)K.ryfI[0] * k0 + (double)K.ryfI[1] * k1 + (double)K.ryfI[2] * k2 + (double)K.ryfI[3] * k3,
+                     (double)K.rxfI[0] * k0 + (double)K.rxfI[1] * k1 + (double)K.rxfI[2] * k2 + (double)K.rxfI[3] * k3,
+                     (double)K.tmaxI * ((k2 + k3) - (k0 + k1))};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wdb[i] -= (double)K.pqI[i] * pqf * (D.wb[i] * __builtin_fabs(D.wb[i]));
+    wdb[0] -= (double)K.gyI[0] * (D.wb[1] * D.wb[2]);
+    wdb[1] -= (double)K.gyI[1] * (D.wb[2] * D.wb[0]);
+    wdb[2] -= (double)K.gyI[2] * (D.wb[0] * D.wb[1]);
+    const double Fm[3] = {-(double)K.dragM[0] * (D.vb[0] * __builtin_fabs(D.vb[0])), -(double)K.dragM[1] * (D.vb[1] * __builtin_fabs(D.vb[1])),
+                          -(double)K.dragM[2] * (D.vb[2] * __builtin_fabs(D.vb[2])) + (double)K.fmaxM * ((k0 + k1) + (k2 + k3))};
+    // collision detection at the pre-integration pose, on the float32 view (tick<>'s code)
+    bool near = ((p.z - K.bound_radius) <= 0.0f) && ((p.z + K.bound_radius) >= -2.0f * K.plane_z);
+    const bool persisted = contact_now;
+    contact_now = false;
+    float low = INFINITY;
+    if (__any(near)) {
+      if (near) {
+        const float hx = K.box_h[0], hy = K.box_h[1], hz = K.box_h[2];
+        const float pxy = K.plane_xy, pz = K.plane_z;
+        low = p.z - fmaf(__builtin_fabsf(R.m20), hx, fmaf(__builtin_fabsf(R.m21), hy, __builtin_fabsf(R.m22) * hz));
+        const bool inside = (__builtin_fabsf(p.x) + K.bound_radius0 < pxy) && (__builtin_fabsf(p.y) + K.bound_radius0 < pxy) && (low > -pz);
+        const float rdx = persisted ? K.brk : K.rd;
+        contact_now = low <= rdx;
+        if (!inside) contact_now = quad_floor_contact(p.x, p.y, p.z, q, hx, hy, hz, pxy, pz, rdx);
+      }
+    }
+    // world-frame accelerations, semi-implicit velocity update with the per-coordinate clamp
+    const double vmax = K.vmax, dt = K.dt;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double wd = D.R[3 * i] * wdb[0] + D.R[3 * i + 1] * wdb[1] + D.R[3 * i + 2] * wdb[2];
+      const double a = D.R[3 * i] * Fm[0] + D.R[3 * i + 1] * Fm[1] + D.R[3 * i + 2] * Fm[2] + (i == 2 ? (double)K.gravity_z : 0.0);
+      const double wn = D.w[i] + wd * dt, vn = D.v[i] + a * dt;
+      D.w[i] = wn < -vmax ? -vmax : (wn > vmax ? vmax : wn);
+      D.v[i] = vn < -vmax ? -vmax : (vn > vmax ? vmax : vn);
+    }
+    float lift = 0.0f;
+    if (CR) {
+      bool act = false;
+      const v3 vf{(float)D.v[0], (float)D.v[1], (float)D.v[2]}, wf{(float)D.w[0], (float)D.w[1], (float)D.w[2]};
+      if (near) {
+        const float vlow = vf.z - fsqrt(dot(wf, wf)) * K.bound_radius0;
+        act = ((fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop)) && (low <= (persisted ? K.brk : K.margin) + 1e-6f);
+      }
+      if (__any(act)) {
+        v3 nv, nw;
+        if (INL) {
+          const bool at_rim = !((__builtin_fabsf(p.x) + K.bound_radius0 < K.plane_xy) && (__builtin_fabsf(p.y) + K.bound_radius0 < K.plane_xy));
+          const QuadFloorOut o = quad_floor_solve(K, Pfull, act, persisted ? K.brk : K.margin, __any(act && at_rim), p, R.m00, R.m01, R.m02, R.m10, R.m11, R.m12,
+                                                      R.m20, R.m21, R.m22, vf, wf);
+          nv = o.v; nw = o.w; lift = K.c_erp * o.deepest;
+        } else {
+          const ContactOut o = contact_solve_dev(Pfull, cws, need_cap_of(act, cws_floats, persisted), p, q, vf, wf);
+          nv = o.v; nw = o.w; lift = K.c_erp * o.deepest;
+        }
+        // (unchanged for a lane that did not ask or has no contact vertex: such a lane keeps its fp64 velocities)
+        if (nv.x != vf.x || nv.y != vf.y || nv.z != vf.z || nw.x != wf.x || nw.y != wf.y || nw.z != wf.z) {
+          D.v[0] = nv.x; D.v[1] = nv.y; D.v[2] = nv.z; D.w[0] = nw.x; D.w[1] = nw.y; D.w[2] = nw.z;
+        }
+      }
+    }
+    // x += v dt; q <- exp(w dt / 2) q with the world-frame w, normalised (rigid_tick_pos: Taylor branch below 1e-3 rad/s, the pi/4 cap)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) D.p[i] += dt * D.v[i];
+    D.p[2] += (double)lift;
+    {
+      double ang = __builtin_sqrt(D.w[0] * D.w[0] + D.w[1] * D.w[1] + D.w[2] * D.w[2]);
+      if (ang * dt > 0.25 * 3.14159265358979323846) ang = 0.25 * 3.14159265358979323846 / dt;
+      // sin(h) / ang = (dt / 2) sinc(h) and cos(h) for the half angle h = ang dt / 2 <= pi / 8, as series (to h^15 / h^16: 1e-18 of the
+      // leading term at the cap; the reference's own Taylor branch below 1e-3 rad/s is the first two terms of the same series) --
+      // the library's sin / cos carry an argument reduction this range never needs, 300 instructions a tick
+      const double h = 0.5 * ang * dt, h2 = h * h;
+      const double sinc = 1.0 + h2 * (-1.0 / 6.0 + h2 * (1.0 / 120.0 + h2 * (-1.0 / 5040.0 + h2 * (1.0 / 362880.0 + h2 * (-1.0 / 39916800.0 +
+                          h2 * (1.0 / 6227020800.0 + h2 * (-1.0 / 1307674368000.0)))))));
+      const double cw = 1.0 + h2 * (-0.5 + h2 * (1.0 / 24.0 + h2 * (-1.0 / 720.0 + h2 * (1.0 / 40320.0 + h2 * (-1.0 / 3628800.0 + h2 * (1.0 / 479001600.0 +
+                        h2 * (-1.0 / 87178291200.0 + h2 * (1.0 / 20922789888000.0))))))));
+      const double kq = 0.5 * dt * sinc;
+      const double ax = D.w[0] * kq, ay = D.w[1] * kq, az = D.w[2] * kq;
+      const double n0 = cw * D.q[0] + ax * D.q[3] + ay * D.q[2] - az * D.q[1], n1 = cw * D.q[1] + ay * D.q[3] + az * D.q[0] - ax * D.q[2],
+                   n2 = cw * D.q[2] + az * D.q[3] + ax * D.q[1] - ay * D.q[0], n3 = cw * D.q[3] - ax * D.q[0] - ay * D.q[1] - az * D.q[2];
+      const double inv = 1.0 / __builtin_sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+      D.q[0] = n0 * inv; D.q[1] = n1 * inv; D.q[2] = n2 * inv; D.q[3] = n3 * inv;
+    }
+    D.derive();
+    view_of(D);
     contact_step |= contact_now;
   }
 };
@@ -1042,11 +1225,15 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
   PF_STAMP(0);
 
   QuadHot V;
+  // (the cascaded flight modes without a shared world: the master copy of the rigid-body state and of every PID memory in fp64; state
+  //  groups 16-19 the state's remainders, 20-21 the rate PID's, 22-26 the cascade's)
+  constexpr bool DSTATE = MODES && !SHARED;
+  QuadStateD SD;  // (dead unless DSTATE)
   static_assert(LPW * kMaxD >= kContactSlotFloats, "the contact solver's LDS regions alias the observation tile: at least one worst-case region");
   V.cws = (lds_fptr)tile;
   V.cws_floats = LPW * kMaxD;
   if (SHARED) { V.wpose_ = wpose; V.wvel_ = wvel_all + wid * 64 * kPairVelStride; V.rec_ = tile; V.wtid = tid; V.wA = apw; }
-  QuadCasc C;  // (MODES only; dead otherwise)
+  QuadCascT<typename std::conditional<DSTATE, double, float>::type> C;  // (MODES only; dead otherwise. DSTATE: the memories in fp64, their remainders in groups 22-26)
   const pf_params_kptr Pk = uniform_params(Pfull);
   // (see the calm test below)
   constexpr bool CALM = CR && !SHARED && !MODES && NOISE != PF_NOISE_INJECT;
@@ -1086,6 +1273,9 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     // the action is first needed after the resets, a microsecond from here: requested where it is used (inside the stepping
     // lanes' branch) every wave sat out its whole memory latency there; requested behind the state groups it is long there
     if (ROLL == 0 && op == 0) a_pre = reinterpret_cast<const float4*>(B.actions)[li];
+    float4 dl0 = float4{0.f, 0.f, 0.f, 0.f}, dl1 = dl0, dl2 = dl0, dl3 = dl0;
+    float4 dl4 = dl0, dl5 = dl0;
+    if (DSTATE) { dl0 = Sin[16 * N + li]; dl1 = Sin[17 * N + li]; dl2 = Sin[18 * N + li]; dl3 = Sin[19 * N + li]; dl4 = Sin[20 * N + li]; dl5 = Sin[21 * N + li]; }
     if (CR && blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch(tid);  // (behind the state loads: one wait for both)
     rng_ctr = (uint32_t)__float_as_int(gi.z);
     PF_STAMP(1);  // (the int group has arrived)
@@ -1129,6 +1319,20 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     V.t01 = f2{g3.z, g3.w}; V.t23 = f2{g4.x, g4.y};
     V.I[0] = g4.z; V.I[1] = g4.w; V.I[2] = g5.x;
     V.E[0] = g5.y; V.E[1] = g5.z; V.E[2] = g5.w;
+    if (DSTATE) {  // master = stored float32 rounding + stored remainder (g16: p, q.x | g17: q.yzw, v.x | g18: v.yz, w.xy | g19: w.z)
+      SD.p[0] = (double)g0.x + (double)dl0.x; SD.p[1] = (double)g0.y + (double)dl0.y; SD.p[2] = (double)g0.z + (double)dl0.z;
+      SD.q[0] = (double)g1.x + (double)dl0.w; SD.q[1] = (double)g1.y + (double)dl1.x; SD.q[2] = (double)g1.z + (double)dl1.y; SD.q[3] = (double)g1.w + (double)dl1.z;
+      SD.v[0] = (double)g2.x + (double)dl1.w; SD.v[1] = (double)g2.y + (double)dl2.x; SD.v[2] = (double)g2.z + (double)dl2.y;
+      SD.w[0] = (double)g2.w + (double)dl2.z; SD.w[1] = (double)g3.x + (double)dl2.w; SD.w[2] = (double)g3.y + (double)dl3.x;
+      // (g20: the rate PID's I, E.x | g21: E.yz -- the remainders of groups 4 / 5's words)
+      SD.rI[0] = (double)g4.z + (double)dl4.x; SD.rI[1] = (double)g4.w + (double)dl4.y; SD.rI[2] = (double)g5.x + (double)dl4.z;
+      SD.rE[0] = (double)g5.y + (double)dl4.w; SD.rE[1] = (double)g5.z + (double)dl5.x; SD.rE[2] = (double)g5.w + (double)dl5.y;
+      // (the motor states' remainders in the free words: g19.yzw, g21.z)
+      SD.thr[0] = (double)g3.z + (double)dl3.y; SD.thr[1] = (double)g3.w + (double)dl3.z; SD.thr[2] = (double)g4.x + (double)dl3.w; SD.thr[3] = (double)g4.y + (double)dl5.z;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) SD.pwm[k] = 0.05;
+      SD.derive();
+    }
     step_count = __float_as_int(gi.x); flags = __float_as_int(gi.y);
     n_left = __float_as_int(gi.w);
     if (TASK == PF_TASK_WAYPOINTS || TASK == PF_TASK_MA_HOVER) {  // MA: spawn pos (3), spawn quat (4), current action (4)
@@ -1139,8 +1343,10 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     }
   }
   old_dist = new_dist;
-  if (MODES && K.mode > 0) C.load(Sin, N, li);
-  else C.zero();
+  if (MODES && K.mode > 0) {
+    C.load(Sin, N, li);
+    if constexpr (DSTATE) C.unpack(Sin[22 * N + li], Sin[23 * N + li], Sin[24 * N + li], Sin[25 * N + li], Sin[26 * N + li], true);  // (+ the remainders)
+  } else C.zero();
   // MA hover (ma_quadx_base_env.py:139-150,326-332): the action of the previous call, observed this call
   float4 ma_past = float4{0.f, 0.f, 0.f, 0.f};
   if (TASK == PF_TASK_MA_HOVER) ma_past = Sin[15 * N + li];
@@ -1359,6 +1565,41 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
       }
     }
   };
+  // (DSTATE) the same vertical recurrence in fp64, the z PIDs on fp64 memories: what the oracle's settle Aviary steps compute for a level
+  // spawn at rest. (A float32 settle leaves the episode's first state 5e-7 off the reference's, and a cascaded controller that has just
+  // been handed its setpoint turns that into 1e-4 within four env steps: profiles/tools/r06/dbg_m7.py.)
+  auto settle_run_d = [&](double& z, double& vz, double& thr, double& pwm_s) {
+    pwm_s = 0.05;
+    const double z_hold = z;
+    C.zero();
+    const double T = (double)Pk->control_period;
+    auto ctl = [&]() {
+      if (K.mode == -1) { pwm_s = 0.0; return; }
+      double zc = (K.mode == 1 || K.mode == 5 || K.mode == 6) ? 0.0 : z_hold;
+      if (!(K.mode == 1 || K.mode == 5 || K.mode == 6))
+        zc = pid1d(Pk->zpid[1].kp[0], Pk->zpid[1].ki[0], Pk->zpid[1].kd[0], Pk->zpid[1].lim[0], T, C.zI[1], C.zE[1], z, zc);
+      zc = pid1d(Pk->zpid[0].kp[0], Pk->zpid[0].ki[0], Pk->zpid[0].kd[0], Pk->zpid[0].lim[0], T, C.zI[0], C.zE[0], vz, zc);
+      pwm_s = clampd(clampd(zc, 0.0, 1.0), 0.05, 1.0);
+    };
+    auto tk = [&](const float xi) {
+      thr += (double)K.m_a * (pwm_s - thr);
+      thr += (double)xi * thr * (double)K.m_noise;
+      const double kk = thr * __builtin_fabs(thr);
+      const double az = -(double)K.dragM[2] * (vz * __builtin_fabs(vz)) + (double)K.fmaxM * (4.0 * kk) + (double)K.gravity_z;
+      const double vn = vz + az * (double)K.dt;
+      vz = vn < -(double)K.vmax ? -(double)K.vmax : (vn > (double)K.vmax ? (double)K.vmax : vn);
+      z += (double)K.dt * vz;
+    };
+    for (int t = 0; t < settle_ticks; t += 4) {
+      float4 x;
+      if (NOISE == PF_NOISE_PHILOX) x = reinterpret_cast<const float4*>(sxi + tid * kSettleMax)[t >> 2];
+      else if (NOISE == PF_NOISE_INJECT) x = float4{B.xi_reset[(size_t)(t + 0) * N + li], B.xi_reset[(size_t)(t + 1) * N + li],
+                                                    B.xi_reset[(size_t)(t + 2) * N + li], B.xi_reset[(size_t)(t + 3) * N + li]};
+      else x = float4{0.f, 0.f, 0.f, 0.f};
+      ctl(); tk(x.x); tk(x.y);
+      ctl(); tk(x.z); tk(x.w);
+    }
+  };
   // env.reset() for this lane: begin_reset + waypoint sampling + set_mode(0) + the settle phase
   // (quadx_base_env.py:149-212). Level spawn at rest under the mode-0 default setpoint
   // (quadx.py:276-278): rate error 0 -> cmd 0 -> pwm 0.05 on all four motors (quadx.py:488 branch
@@ -1373,7 +1614,9 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     // rate and lateral error is exactly zero on a level spawn at rest, so the cascade reduces to its z PIDs -- run here once per
     // Aviary step on the vertical state -- and four equal motor commands: still a vertical recurrence.
     float pwm_s = 0.05f;
+    double zd = z, vzd = 0.0, thrd = 0.0, pwmd = 0.05;  // (DSTATE)
     if (SPARE && have_pre) { z = pre.z; vz = pre.vz; thr = pre.thr; C.zero(); }  // (the next episode's settled state, computed ahead: make_spare)
+    else if (DSTATE) { settle_run_d(zd, vzd, thrd, pwmd); z = (float)zd; vz = (float)vzd; thr = (float)thrd; pwm_s = (float)pwmd; }
     else settle_run(z, vz, thr, pwm_s);
     V.p = v3{sx, sy, z};
     if (TASK == PF_TASK_MA_HOVER) V.q = quat{tgt[1][0], tgt[1][1], tgt[1][2], tgt[2][0]};
@@ -1384,6 +1627,15 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     for (int k = 0; k < 3; ++k) { V.I[k] = 0.f; V.E[k] = 0.f; }
     V.contact_now = false; V.contact_step = false;
     V.derive();
+    if (DSTATE) {  // (the settle recurrence ran in fp64: settle_run_d)
+      SD.p[0] = V.p.x; SD.p[1] = V.p.y; SD.p[2] = zd; SD.q[0] = V.q.x; SD.q[1] = V.q.y; SD.q[2] = V.q.z; SD.q[3] = V.q.w;
+      SD.v[0] = 0.0; SD.v[1] = 0.0; SD.v[2] = vzd; SD.w[0] = 0.0; SD.w[1] = 0.0; SD.w[2] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { SD.thr[k] = thrd; SD.pwm[k] = pwmd; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { SD.rI[k] = 0.0; SD.rE[k] = 0.0; }
+      SD.derive();
+    }
     step_count = 0; term = false; trunc = false; flags = 0; pop_pending = false;
     act0 = act1 = act2 = act3 = 0.f;  // (MA hover: the action memories live in the side block and survive resets)
     if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:53-83
@@ -1665,7 +1917,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
       else { xi0 = 0.f; xi1 = 0.f; }
       // one Aviary.step (aviary.py:480-531): control on the first tick, pwm held on the second
       V.contact_step = false;
-      V.template control<MODES>(K, Pk, C, sp0, sp1, sp2, sp3);
+      V.template control<MODES>(K, Pk, C, sp0, sp1, sp2, sp3, DSTATE ? &SD : nullptr);
       if (SHARED) {
         // one world for the agents of an env: pose / contact exchange before every tick. Every lane of a world is in here
         // together: the PettingZoo task has no early exit from the inner loop and resets whole worlds.
@@ -1682,6 +1934,9 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
         //  the floor code's own constants stay scalar, Kc)
         V.template tick<CR, false, QuadKV, true>(KV, K, xi0, Pfull);
         V.template tick<CR, false, QuadKV, true>(KV, K, xi1, Pfull);
+      } else if (DSTATE) {
+        V.template tick_d<CR, WPS == 1>(SD, K, xi0, Pfull);
+        V.template tick_d<CR, WPS == 1>(SD, K, xi1, Pfull);
       } else {
         V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi0, Pfull);
         V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi1, Pfull);
@@ -1794,6 +2049,10 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
       B.truncated[toff + li] = out_trunc ? 1 : 0;
     }
   }
+  if (ROLLOUT && DSTATE) {  // (the resident fp64 copies as a launch boundary would leave them)
+    SD.through_hilo();
+    if constexpr (DSTATE) C.through_hilo();
+  }
   // the next step's motor-noise normals (keyed by the event counter this step left behind)
   if (ROLLOUT && NOISE == PF_NOISE_PHILOX && it + 1 < KS)
     zn = normal8(philox4x32(K.seed_lo, K.seed_hi, (uint32_t)(lane0 + li), rng_ctr, 0u, 0u));
@@ -1808,6 +2067,20 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     Sout[5 * N + li] = float4{V.I[2], V.E[0], V.E[1], V.E[2]};
     Sout[6 * N + li] = float4{__int_as_float(step_count), __int_as_float(flags), __int_as_float((int)rng_ctr), __int_as_float(n_left)};
     if (MODES && K.mode > 0) C.store(Sout, N, li, REKEY ? (rkw & ~kSpareValid) : 0u);
+    if (DSTATE) {  // the remainders of the fp64 state: master - its float32 rounding (groups 0-3 above hold the roundings: V is the view of SD)
+      const float e0 = (float)(SD.p[0] - (double)V.p.x), e1 = (float)(SD.p[1] - (double)V.p.y), e2 = (float)(SD.p[2] - (double)V.p.z);
+      const float e3 = (float)(SD.q[0] - (double)V.q.x), e4 = (float)(SD.q[1] - (double)V.q.y), e5 = (float)(SD.q[2] - (double)V.q.z), e6 = (float)(SD.q[3] - (double)V.q.w);
+      const float e7 = (float)(SD.v[0] - (double)V.wvx.y), e8 = (float)(SD.v[1] - (double)V.wvy.y), e9 = (float)(SD.v[2] - (double)V.wvz.y);
+      const float e10 = (float)(SD.w[0] - (double)V.wvx.x), e11 = (float)(SD.w[1] - (double)V.wvy.x), e12 = (float)(SD.w[2] - (double)V.wvz.x);
+      Sout[16 * N + li] = float4{e0, e1, e2, e3};
+      Sout[17 * N + li] = float4{e4, e5, e6, e7};
+      Sout[18 * N + li] = float4{e8, e9, e10, e11};
+      Sout[19 * N + li] = float4{e12, (float)(SD.thr[0] - (double)V.t01.x), (float)(SD.thr[1] - (double)V.t01.y), (float)(SD.thr[2] - (double)V.t23.x)};
+      // (the PID memories' remainders: the rate PID's behind the state's, the cascade's in the packing of groups 7-11)
+      Sout[20 * N + li] = float4{(float)(SD.rI[0] - (double)V.I[0]), (float)(SD.rI[1] - (double)V.I[1]), (float)(SD.rI[2] - (double)V.I[2]), (float)(SD.rE[0] - (double)V.E[0])};
+      Sout[21 * N + li] = float4{(float)(SD.rE[1] - (double)V.E[1]), (float)(SD.rE[2] - (double)V.E[2]), (float)(SD.thr[3] - (double)V.t23.y), 0.0f};
+      if constexpr (DSTATE) { if (K.mode > 0) C.store_lo(Sout, N, li, 22); }
+    }
     if (REKEY && !(MODES && K.mode > 0) && (sp_dirty || ROLLOUT)) {  // group 7: the spare's settled state + the key word; 8-11: its targets
       const Sp x = SPARE ? spare_get() : Sp{};
       Sout[7 * N + li] = float4{x.z, x.vz, x.thr, __int_as_float((int)(SPARE ? rkw : (rkw & ~kSpareValid)))};

@@ -358,6 +358,8 @@ def _run_env(make, n_steps, seed, action_fn, num_targets=0, ticks=6):
             need_reset = False
             rec["reset_before"].append(k)
         a = action_fn(env, rng, k)
+        if ref_stubs.RecordingRNG.F32:  # (float32-exact inputs: see RecordingRNG)
+            a = np.asarray(a, dtype=np.float64).astype(np.float32).astype(np.float64)
         obs, r, te, tr, info = env.step(a)
         x = rng_env.drain("normal")
         rec["action"].append(a)
@@ -443,6 +445,8 @@ def mode_action(mode):
 def gen_envs_modes():
     """QuadXHoverEnv / QuadXWaypointsEnv under every flight mode other than 0 (quadx.py:233-373,437-479): the env-level fixtures of
     the cascaded-PID kernels -- set_mode's default setpoint and the z PIDs inside the reset's settle steps included."""
+    # (round 6: these fixtures' actions and draws are float32-exact -- ref_stubs.RecordingRNG.F32)
+    ref_stubs.RecordingRNG.F32 = True
     for m in (-1, 1, 2, 3, 4, 5, 6, 7):
         tag = "m1" if m == -1 else str(m)
         # (1.5 s episodes: every fixture goes through several resets, i.e. through the settle steps under its mode's controller)
@@ -453,6 +457,7 @@ def gen_envs_modes():
         return np.array([t[0], t[1], 0.0, t[2]]) + rng.uniform(-0.05, 0.05, size=4)
 
     save("env_quadx_waypoints_mode7", **run_env(lambda: QuadXWaypointsEnv(flight_mode=7, goal_reach_distance=0.4), 360, 47, chase, num_targets=4, ticks=8))
+    ref_stubs.RecordingRNG.F32 = False
 
 
 def gen_envs_yaw():

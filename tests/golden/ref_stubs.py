@@ -21,19 +21,32 @@ REFERENCE = "/root/reference"
 
 
 class RecordingRNG:
-    """Wraps a numpy Generator and logs every normal()/uniform() draw in call order."""
+    """Wraps a numpy Generator and logs every normal()/uniform() draw in call order.
+    F32 (class switch, set by the generators of the cascaded-flight-mode fixtures): every draw is handed to the reference ROUNDED to the
+    nearest float32 value -- still a float64 number, still the reference's arithmetic on it. The device's interface takes float32
+    actions and float32 injected draws; a cascaded controller turns the 6e-8 by which a float64 draw differs from its float32 rounding
+    into 1e-3 within an episode, which says nothing about the kernel. With float32-exact inputs both sides
+    start from identical numbers."""
+
+    F32 = False
 
     def __init__(self, gen):
         self._gen = gen
         self.log = []  # (kind, ndarray)
 
+    def _q(self, out):
+        if not RecordingRNG.F32:
+            return out
+        r = np.asarray(out, dtype=np.float64).astype(np.float32).astype(np.float64)
+        return float(r) if np.ndim(out) == 0 else r
+
     def normal(self, *args, **kwargs):
-        out = self._gen.normal(*args, **kwargs)
+        out = self._q(self._gen.normal(*args, **kwargs))
         self.log.append(("normal", np.atleast_1d(np.asarray(out, dtype=np.float64)).copy()))
         return out
 
     def uniform(self, *args, **kwargs):
-        out = self._gen.uniform(*args, **kwargs)
+        out = self._q(self._gen.uniform(*args, **kwargs))
         self.log.append(("uniform", np.atleast_1d(np.asarray(out, dtype=np.float64)).copy()))
         return out
 

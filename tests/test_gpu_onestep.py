@@ -33,7 +33,7 @@ def lanes_view(ob):
         return np.ctypeslib.as_array(ob.lanes)
 
 
-RTOL_ONE_STEP = 1e-4  # north_star's own bound (measured worst per case: the test's print -- 1e-5 ... 7e-5)
+RTOL_ONE_STEP = 1e-4  # north_star's own bound (measured worst per case: the test's print -- round 6: 1.9e-6 ... 4.6e-6 on the specialised kernel, whose cascaded modes carry state and PID memories in fp64; r05: 1e-5 ... 7e-5)
 
 
 def pack_state(ob, eng, waypoints):
@@ -70,6 +70,21 @@ def pack_state(ob, eng, waypoints):
         g[11, :, 2] = key
     else:
         g[7, :, 3] = key
+    if g.shape[0] > 16:  # (the cascaded modes on the specialised kernel: groups 16-19 hold the remainders of its fp64 rigid-body state)
+        lo = lambda x, hi: (x - hi.astype(np.float64)).astype(np.float32)  # noqa: E731
+        g[16, :, 0:3] = lo(f["p"], g[0, :, 0:3]); g[16, :, 3] = lo(f["q"][:, 0], g[1, :, 0])
+        g[17, :, 0:3] = lo(f["q"][:, 1:4], g[1, :, 1:4]); g[17, :, 3] = lo(f["v"][:, 0], g[2, :, 0])
+        g[18, :, 0:2] = lo(f["v"][:, 1:3], g[2, :, 1:3]); g[18, :, 2:4] = lo(f["w"][:, 0:2], np.stack([g[2, :, 3], g[3, :, 0]], axis=1))
+        g[19, :, 0] = lo(f["w"][:, 2], g[3, :, 1])
+        g[19, :, 1:3] = lo(f["throttle"][:, 0:2], g[3, :, 2:4]); g[19, :, 3] = lo(f["throttle"][:, 2], g[4, :, 0]); g[21, :, 2] = lo(f["throttle"][:, 3], g[4, :, 1])  # the motor states'
+        # ... and of its fp64 PID memories: 20-21 the rate PID's (groups 4 / 5's words), 22-26 the cascade's (the packing of groups 7-11)
+        g[20, :, 0:2] = lo(f["pid_I"][:, 0, 0:2], g[4, :, 2:4]); g[20, :, 2] = lo(f["pid_I"][:, 0, 2], g[5, :, 0]); g[20, :, 3] = lo(f["pid_E"][:, 0, 0], g[5, :, 1])
+        g[21, :, 0:2] = lo(f["pid_E"][:, 0, 1:3], g[5, :, 2:4])
+        g[22, :, 0:3] = lo(f["pid_I"][:, 1, :], g[7, :, 0:3]); g[22, :, 3] = lo(f["pid_E"][:, 1, 0], g[7, :, 3])
+        g[23, :, 0:2] = lo(f["pid_E"][:, 1, 1:3], g[8, :, 0:2]); g[23, :, 2:4] = lo(f["pid_I"][:, 2, 0:2], g[8, :, 2:4])
+        g[24, :, 0:2] = lo(f["pid_E"][:, 2, 0:2], g[9, :, 0:2]); g[24, :, 2:4] = lo(f["pid_I"][:, 3, 0:2], g[9, :, 2:4])
+        g[25, :, 0:2] = lo(f["pid_E"][:, 3, 0:2], g[10, :, 0:2]); g[25, :, 2:4] = lo(f["zpid_I"], g[10, :, 2:4])
+        g[26, :, 0:2] = lo(f["zpid_E"], g[11, :, 0:2])
     eng.state.copy_(torch.tensor(g, device=eng.state.device))
 
 

@@ -12,7 +12,7 @@ n = int(os.environ.get("N", "65536"))
 task = os.environ.get("TASK", "hover")
 wo = dict(contact_response=False) if os.environ.get("CR", "1") == "0" else None
 veh = os.environ.get("VEH", "quadx")
-P = build_params(veh, task, noise="philox", autoreset="next_step", seed=0, world_options=wo)
+P = build_params(veh, task, noise="philox", autoreset="next_step", seed=0, world_options=wo, flight_mode=int(os.environ.get("MODE", "0")))  # (MODE: a --modes variant library)
 eng = BatchEngine(P, n, device="cuda:0")
 ring = [torch.empty(n, 4, device="cuda:0") for _ in range(100)]  # (a ring that repeats within an episode is a different action process: solver_trace.py WHAT=rates)
 for i, a in enumerate(ring):

@@ -362,11 +362,17 @@ __global__ void __launch_bounds__(kWave) env_kernel(const pf_params P, const pf_
   } else if (active && !do_reset) {
     a = reinterpret_cast<const float4*>(B.actions)[toff + li];
   }
-  if (do_reset) {
-    begin_reset();
-    settling = true;
-    my_its = (tmpl != nullptr) ? 0 : P.settle_steps;
-  } else if (active) {
+  // (wave-uniform guard: most waves of most launches restart nobody. It also takes the reset's divergent region out of the path into
+  //  the Aviary-step loop: with `if (do_reset) ... else if (active) ...` the allocator's copies of the zeroed PID memories landed in
+  //  front of the join block's exec restore in the QuadX-Hover instantiations -- tools/isa_exec_check.py, 25 of round 5's 186 sites)
+  if (__builtin_expect(__any(do_reset), 0)) {
+    if (do_reset) {
+      begin_reset();
+      settling = true;
+      my_its = (tmpl != nullptr) ? 0 : P.settle_steps;
+    }
+  }
+  if (active && !do_reset) {
     if (TASK == PF_TASK_MA_HOVER) {  // past <- current, current <- action (ma_quadx_base_env.py:326-332)
       ma_past = float4{tg.t[2][1], tg.t[2][2], tg.t[3][0], tg.t[3][1]};
       tg.t[2][1] = a.x; tg.t[2][2] = a.y; tg.t[3][0] = a.z; tg.t[3][1] = a.w;

@@ -930,7 +930,10 @@ struct QuadHot {
         const float vlow = wvz.y - fsqrt(dot(w(), w())) * Kc.bound_radius0;
         act = ((fmaf(K.dt, vlow, low + Kc.slop) < 0.0f) || (low < -Kc.slop)) && (low <= (persisted ? Kc.brk : Kc.margin) + 1e-6f);
       }
-      if (__any(act)) {
+      // (unlikely: a wave solves a floor contact in a few ticks of an episode. The hint is also what keeps the register allocator's
+      //  spill burst around the out-of-line call INSIDE this cold block: without it the caller-saved registers were stored at the top of
+      //  the join block in front of it, ahead of its exec restore -- tools/isa_exec_check.py, 161 of round 5's 186 repaired sites)
+      if (__builtin_expect(__any(act), 0)) {
         // (INL: inline, in the instantiations sized for one wave per SIMD -- 512 registers: no call, so no stack, and a launch
         //  whose waves carry scratch memory dispatches 0.4 us slower; nothing pinned to callee-saved registers: the solve of this
         //  airframe in registers, quad_floor_solve. Otherwise out of line, the general solver: within the 256 registers of two
@@ -1022,7 +1025,7 @@ struct QuadHot {
         const float vlow = vf.z - fsqrt(dot(wf, wf)) * K.bound_radius0;
         act = ((fmaf(K.dt, vlow, low + K.slop) < 0.0f) || (low < -K.slop)) && (low <= (persisted ? K.brk : K.margin) + 1e-6f);
       }
-      if (__any(act)) {
+      if (__builtin_expect(__any(act), 0)) {
         v3 nv, nw;
         if (INL) {
           const bool at_rim = !((__builtin_fabsf(p.x) + K.bound_radius0 < K.plane_xy) && (__builtin_fabsf(p.y) + K.bound_radius0 < K.plane_xy));

@@ -706,7 +706,7 @@ struct QuadStateD {
   double thr[4], pwm[4];      // the motors' states (QuadHot::t01 / t23 their view) and commands
   PF_DEV void derive() {  // btMatrix3x3::setRotation
     const double x = q[0], y = q[1], z = q[2], ww = q[3];
-    const double d = x * x + y * y + z * z + ww * ww, s = 2.0 / d;
+    const double d = x * x + y * y + z * z + ww * ww, s = 2.0 * rcp_d(d);  // (quadx_control_d.hpp: rcp_d)
     const double xs = x * s, ys = y * s, zs = z * s;
     const double wx = ww * xs, wy = ww * ys, wz = ww * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
     R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy; R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
@@ -781,25 +781,30 @@ struct QuadHot {
   // instantiation BASELINE's metric is quoted on; MODES = true: K.mode selects -1 .. 7 at run time (wave-uniform branches).
   template <bool MODES, class CT = QuadCasc>
   PF_DEV void control(const QuadK& K, const pf_params_kptr Pk, CT& C, float s0, float s1, float s2, float s3, QuadStateD* D = nullptr) {
+    // (HAS_D: the fp64 state is there exactly when the memories are doubles. A compile-time fact, never a test of the pointer: a private
+    //  address compared with null is an address that has been LOOKED AT, and the whole QuadStateD then stays in scratch memory -- 352
+    //  bytes a lane, every access a memory round trip: 52 us per env step in round 6's first cascaded-mode build)
+    constexpr bool HAS_D = std::is_same<CT, QuadCascT<double>>::value;
     if (MODES) {
       if (K.mode == -1) {  // motor commands as they are (quadx.py:427-429): no clipping
         pw01 = f2{s0, s1}; pw23 = f2{s2, s3};
-        if (D != nullptr) { D->pwm[0] = s0; D->pwm[1] = s1; D->pwm[2] = s2; D->pwm[3] = s3; }
+        if constexpr (HAS_D) { D->pwm[0] = s0; D->pwm[1] = s1; D->pwm[2] = s2; D->pwm[3] = s3; }
         return;
       }
       if (K.mode != 0) {
         // the cascaded modes: state derivation and every PID in fp64, shared with the generic vehicle (quadx_control_d.hpp: why --
         // round 4's float32 outer loops on polynomial atan2 / asin sat 5 x further from the reference than the generic kernel)
-        const QuadCtlIn in = D != nullptr ? D->ctl_inputs() : quad_ctl_inputs(q, v(), w(), p);  // (D: the fp64 state, wave-uniformly there or not)
         const float sp4[4] = {s0, s1, s2, s3};
         float pw[4];
-        if constexpr (std::is_same<CT, QuadCascT<double>>::value) {  // (the memories in fp64: D is there)
+        if constexpr (HAS_D) {  // (state and memories in fp64)
+          const QuadCtlIn in = D->ctl_inputs();
           quad_cascade_d(Pk, K.mode, (double)Pk->control_period, in, QuadMemT<double>{D->rI, D->rE, C.I1, C.E1, C.I2, C.E2, C.I3, C.E3, C.zI, C.zE}, sp4, D->pwm);
 #pragma unroll
           for (int k = 0; k < 3; ++k) { I[k] = (float)D->rI[k]; E[k] = (float)D->rE[k]; }
 #pragma unroll
           for (int k = 0; k < 4; ++k) pw[k] = (float)D->pwm[k];
         } else {
+          const QuadCtlIn in = quad_ctl_inputs(q, v(), w(), p);
           quad_cascade_d(Pk, K.mode, (double)Pk->control_period, in, QuadMemD{I, E, C.I1, C.E1, C.I2, C.E2, C.I3, C.E3, C.zI, C.zE}, sp4, pw);
         }
         pw01 = f2{pw[0], pw[1]}; pw23 = f2{pw[2], pw[3]};
@@ -1047,12 +1052,14 @@ struct QuadHot {
     for (int i = 0; i < 3; ++i) D.p[i] += dt * D.v[i];
     D.p[2] += (double)lift;
     {
-      double ang = __builtin_sqrt(D.w[0] * D.w[0] + D.w[1] * D.w[1] + D.w[2] * D.w[2]);
-      if (ang * dt > 0.25 * 3.14159265358979323846) ang = 0.25 * 3.14159265358979323846 / dt;
       // sin(h) / ang = (dt / 2) sinc(h) and cos(h) for the half angle h = ang dt / 2 <= pi / 8, as series (to h^15 / h^16: 1e-18 of the
       // leading term at the cap; the reference's own Taylor branch below 1e-3 rad/s is the first two terms of the same series) --
-      // the library's sin / cos carry an argument reduction this range never needs, 300 instructions a tick
-      const double h = 0.5 * ang * dt, h2 = h * h;
+      // the library's sin / cos carry an argument reduction this range never needs, 300 instructions a tick. Both are functions of
+      // h^2 = (dt / 2)^2 |w|^2: no square root; the cap (ang dt > pi / 4, which three components clamped to vmax = 100 rad/s never reach
+      // at 240 Hz) is the same test on the squares
+      const double ww2 = D.w[0] * D.w[0] + D.w[1] * D.w[1] + D.w[2] * D.w[2];
+      const double cap = 0.25 * 3.14159265358979323846;
+      const double h2 = (ww2 * (dt * dt) > cap * cap) ? 0.25 * (cap * cap) : 0.25 * (dt * dt) * ww2;
       const double sinc = 1.0 + h2 * (-1.0 / 6.0 + h2 * (1.0 / 120.0 + h2 * (-1.0 / 5040.0 + h2 * (1.0 / 362880.0 + h2 * (-1.0 / 39916800.0 +
                           h2 * (1.0 / 6227020800.0 + h2 * (-1.0 / 1307674368000.0)))))));
       const double cw = 1.0 + h2 * (-0.5 + h2 * (1.0 / 24.0 + h2 * (-1.0 / 720.0 + h2 * (1.0 / 40320.0 + h2 * (-1.0 / 3628800.0 + h2 * (1.0 / 479001600.0 +
@@ -1061,7 +1068,11 @@ struct QuadHot {
       const double ax = D.w[0] * kq, ay = D.w[1] * kq, az = D.w[2] * kq;
       const double n0 = cw * D.q[0] + ax * D.q[3] + ay * D.q[2] - az * D.q[1], n1 = cw * D.q[1] + ay * D.q[3] + az * D.q[0] - ax * D.q[2],
                    n2 = cw * D.q[2] + az * D.q[3] + ax * D.q[1] - ay * D.q[0], n3 = cw * D.q[3] - ax * D.q[0] - ay * D.q[1] - az * D.q[2];
-      const double inv = 1.0 / __builtin_sqrt(n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3);
+      // (|n|^2 = |q|^2 (cos^2 h + sin^2 h) = 1 to a few 1e-16 below the cap: 1 / sqrt(1 + e) = 1 - e/2 + 3 e^2 / 8 is exact to 1e-30;
+      //  anything further from 1 -- the cap, a hand-written state -- through the square root)
+      const double nn = n0 * n0 + n1 * n1 + n2 * n2 + n3 * n3, en = nn - 1.0;
+      double inv = __builtin_fma(en, __builtin_fma(en, 0.375, -0.5), 1.0);
+      if (!(__builtin_fabs(en) < 1e-6)) inv = rcp_d(sqrt_pos_d(nn));
       D.q[0] = n0 * inv; D.q[1] = n1 * inv; D.q[2] = n2 * inv; D.q[3] = n3 * inv;
     }
     D.derive();
@@ -1254,6 +1265,8 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
   Sp spv{};                // (SPARE, one step per launch) the lane's spare as loaded / as refilled
   float* const splds = splds_all + ((ROLLOUT && SPARE) ? (wid * 64 + tid) * 20 : 0);  // (SPARE, pf_rollout) ... its row in LDS
   float4 a_pre = float4{0.f, 0.f, 0.f, 0.f};  // (one step per launch) this step's action, requested with the state
+  const float4 f4z = float4{0.f, 0.f, 0.f, 0.f};
+  float4 cm0 = f4z, cm1 = f4z, cm2 = f4z, cm3 = f4z, cm4 = f4z, cm5 = f4z, cm6 = f4z, cm7 = f4z, cm8 = f4z, cm9 = f4z;  // (MODES, a cascaded mode) state groups 7-11 and 22-26 as loaded
   {
     // the int group is requested first: loads complete in order, so the step's Philox call (which
     // needs only the event counter) runs while the rest of the state is still in flight
@@ -1279,6 +1292,12 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     float4 dl0 = float4{0.f, 0.f, 0.f, 0.f}, dl1 = dl0, dl2 = dl0, dl3 = dl0;
     float4 dl4 = dl0, dl5 = dl0;
     if (DSTATE) { dl0 = Sin[16 * N + li]; dl1 = Sin[17 * N + li]; dl2 = Sin[18 * N + li]; dl3 = Sin[19 * N + li]; dl4 = Sin[20 * N + li]; dl5 = Sin[21 * N + li]; }
+    // (the cascade's memories -- groups 7-11, DSTATE: their remainders in 22-26 -- requested HERE, with the state groups: asked for where
+    //  they are unpacked they were a second and a third memory round trip in front of the first Aviary step, 4.5 us by the phase trace)
+    if (MODES) {  // (whatever the mode: a wave-uniform branch around the requests costs a spill of its own; mode -1 ignores the words)
+      cm0 = Sin[7 * N + li]; cm1 = Sin[8 * N + li]; cm2 = Sin[9 * N + li]; cm3 = Sin[10 * N + li]; cm4 = Sin[11 * N + li];
+      if (DSTATE) { cm5 = Sin[22 * N + li]; cm6 = Sin[23 * N + li]; cm7 = Sin[24 * N + li]; cm8 = Sin[25 * N + li]; cm9 = Sin[26 * N + li]; }
+    }
     if (CR && blockIdx.x < kRareTextPrefetchBlocks) rare_text_prefetch(tid);  // (behind the state loads: one wait for both)
     rng_ctr = (uint32_t)__float_as_int(gi.z);
     PF_STAMP(1);  // (the int group has arrived)
@@ -1293,7 +1312,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
       const bool need_sp = SPARE || ROLLOUT || in11 || op == 1 || K.autoreset == PF_AUTORESET_SAME_STEP ||
                            (__float_as_int(gi.y) & (PF_F_TERMINATED | PF_F_TRUNCATED)) != 0;
       if (need_sp) {
-        const float4 gk = SPARE ? gs7 : Sin[(size_t)(in11 ? 11 : 7) * N + li];
+        const float4 gk = SPARE ? gs7 : (in11 ? cm4 : (MODES ? cm0 : Sin[(size_t)7 * N + li]));
         rkw = (uint32_t)__float_as_int(in11 ? gk.z : gk.w);
         // pf_env_reset of EVERY lane (null mask): the spares in the state are not trusted -- a state buffer may come from another
         // context (other seed, lane offset, spawn pose, settle length, dome, number of targets) with bit 31 set; this reset generates
@@ -1347,8 +1366,8 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
   }
   old_dist = new_dist;
   if (MODES && K.mode > 0) {
-    C.load(Sin, N, li);
-    if constexpr (DSTATE) C.unpack(Sin[22 * N + li], Sin[23 * N + li], Sin[24 * N + li], Sin[25 * N + li], Sin[26 * N + li], true);  // (+ the remainders)
+    C.unpack(cm0, cm1, cm2, cm3, cm4, false);
+    if constexpr (DSTATE) C.unpack(cm5, cm6, cm7, cm8, cm9, true);  // (+ the remainders)
   } else C.zero();
   // MA hover (ma_quadx_base_env.py:139-150,326-332): the action of the previous call, observed this call
   float4 ma_past = float4{0.f, 0.f, 0.f, 0.f};
@@ -1485,11 +1504,11 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     auto settle_control = [&]() {
       if (!MODES || K.mode == 0) return;
       if (K.mode == -1) { pwm_s = 0.0f; return; }  // motor commands = setpoint = 0, no clipping (quadx.py:427-429)
-      const double T = (double)Pk->control_period;  // (fp64 like the flight's own cascade: quadx_control_d.hpp)
+      const double T = (double)Pk->control_period, iT = rcp_d(T);  // (fp64 like the flight's own cascade: quadx_control_d.hpp)
       double zc = (K.mode == 1 || K.mode == 5 || K.mode == 6) ? 0.0 : (double)z_hold;
       if (!(K.mode == 1 || K.mode == 5 || K.mode == 6))
-        zc = pid1d(Pk->zpid[1].kp[0], Pk->zpid[1].ki[0], Pk->zpid[1].kd[0], Pk->zpid[1].lim[0], T, C.zI[1], C.zE[1], (double)z, zc);
-      zc = pid1d(Pk->zpid[0].kp[0], Pk->zpid[0].ki[0], Pk->zpid[0].kd[0], Pk->zpid[0].lim[0], T, C.zI[0], C.zE[0], (double)vz, zc);
+        zc = pid1d(Pk->zpid[1].kp[0], Pk->zpid[1].ki[0], Pk->zpid[1].kd[0], Pk->zpid[1].lim[0], T, iT, C.zI[1], C.zE[1], (double)z, zc);
+      zc = pid1d(Pk->zpid[0].kp[0], Pk->zpid[0].ki[0], Pk->zpid[0].kd[0], Pk->zpid[0].lim[0], T, iT, C.zI[0], C.zE[0], (double)vz, zc);
       pwm_s = (float)clampd(clampd(zc, 0.0, 1.0), 0.05, 1.0);
     };
     auto settle_tick = [&](float xi) {
@@ -1575,13 +1594,13 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     pwm_s = 0.05;
     const double z_hold = z;
     C.zero();
-    const double T = (double)Pk->control_period;
+    const double T = (double)Pk->control_period, iT = rcp_d(T);
     auto ctl = [&]() {
       if (K.mode == -1) { pwm_s = 0.0; return; }
       double zc = (K.mode == 1 || K.mode == 5 || K.mode == 6) ? 0.0 : z_hold;
       if (!(K.mode == 1 || K.mode == 5 || K.mode == 6))
-        zc = pid1d(Pk->zpid[1].kp[0], Pk->zpid[1].ki[0], Pk->zpid[1].kd[0], Pk->zpid[1].lim[0], T, C.zI[1], C.zE[1], z, zc);
-      zc = pid1d(Pk->zpid[0].kp[0], Pk->zpid[0].ki[0], Pk->zpid[0].kd[0], Pk->zpid[0].lim[0], T, C.zI[0], C.zE[0], vz, zc);
+        zc = pid1d(Pk->zpid[1].kp[0], Pk->zpid[1].ki[0], Pk->zpid[1].kd[0], Pk->zpid[1].lim[0], T, iT, C.zI[1], C.zE[1], z, zc);
+      zc = pid1d(Pk->zpid[0].kp[0], Pk->zpid[0].ki[0], Pk->zpid[0].kd[0], Pk->zpid[0].lim[0], T, iT, C.zI[0], C.zE[0], vz, zc);
       pwm_s = clampd(clampd(zc, 0.0, 1.0), 0.05, 1.0);
     };
     auto tk = [&](const float xi) {
@@ -1743,9 +1762,13 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     const bool have = SPARE && r && (rkw & kSpareValid) != 0u;
     reset_key_now = REKEY ? (rkw & ~kSpareValid) : rng_ctr;
     prepare_reset_draws(r && !have, reset_key_now);
-    if (r) {
-      if (SPARE && __builtin_expect(have, 1)) reset_lane(true, spare_get());
-      else reset_lane(false, Sp{});
+    // (MODES: behind a wave-uniform guard -- the fp64 state a reset writes otherwise meets the flying lanes' at this block's join, and
+    //  the allocator put those copies in front of the exec restore: tools/isa_exec_check.py. The mode-0 instantiations keep their shape)
+    if (!MODES || __any(r)) {
+      if (r) {
+        if (SPARE && __builtin_expect(have, 1)) reset_lane(true, spare_get());
+        else reset_lane(false, Sp{});
+      }
     }
   };
   // The spares of the lanes that have used theirs up, once every kSpareEvery env steps (and with every explicit reset). Wave-uniform.

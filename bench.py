@@ -77,11 +77,13 @@ def parse():
                          "distribution (aircraft reach the ground within seconds: the contact-solve regime)")
     ap.add_argument("--flight-mode", type=int, default=0, help="QuadX flight mode -1..7 (auxiliary figures; the metric is quoted on mode 0)")
     ap.add_argument("--rollout-steps", type=int, default=100, help="env steps per pf_rollout launch of the second, state-resident figure (0 = skip)")
-    ap.add_argument("--min-timed-ms", type=float, default=5.0,
+    ap.add_argument("--min-timed-ms", type=float, default=25.0,
                     help="floor on the timed region: the K steps are repeated (whole multiples of K, back to back, no host synchronisation in "
                          "between) until the region lasts at least this long, and every figure stays per step. K = 20 steps of 11 us are "
                          "0.2 ms: on one GPU that measures the launch and completion latency of the run as much as the kernels, and on eight "
-                         "the max over ranks of such a region measures launch skew. 0 = time exactly K steps")
+                         "the max over ranks of such a region measures launch skew. 0 = time exactly K steps. (25 ms since round 6: at 5 ms the one "
+                         "launch-to-first-kernel latency of the region, ~0.2 ms, was still 3 % of it -- 9.59 us per step by the wall clock against "
+                         "9.27 by the events on the same run)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the secondary BASELINE configs (Hover 4 096, QuadX-Waypoints 65 536, Fixedwing-Waypoints 65 536) that the "
                          "default single-GPU hover run times after the headline and reports under `configs`")

@@ -484,126 +484,195 @@ PF_DEV QuadFloorOut quad_floor_solve_n(const QuadK& Kc, const QuadSolveC& Sc, co
     // the loop (the trip counter among them), copies of the loop-carried impulses, a compare-select-compare for the exit test -- 325
     // clocks a sweep on the one wave the whole launch waits for (profiles/r05/solver_trace.txt). The same instructions on the same
     // values in the same order, 22 a sweep: bit-identical impulses, the same number of sweeps.
-    float e0 = u[0][0], e1 = u[0][1], e2 = u[0][2], l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, t_, lim_, d0_, d1_, d2_;
-    int cnt = Sc.iters;
+    float e0 = u[0][0], e1 = u[0][1], e2 = u[0][2], l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, n0_, n1_, n2_, lim_, d0_, d1_, d2_;
+    // (round 6, second pass: two sweeps per trip, the impulses alternating between two register sets -- no copy of the new impulse over
+    //  the old one --, the count-down's borrow as the exit test: 20 instructions a sweep; profiles/tools/r06/gen_solve.py writes the text)
+    int cnt = Sc.iters - 1;
     const unsigned long long onm = __ballot(any_on);
     asm volatile(
         "1:\n\t"
-        "v_max_f32 %[t], %[e0], %[e0]\n\t"
-        "v_max_f32 %[t], 0, %[t]\n\t"
-        "v_sub_f32 %[d0], %[t], %[l0]\n\t"
-        "v_mov_b32 %[l0], %[t]\n\t"
+        "v_max_f32 %[n0], 0, %[e0]\n\t"
+        "v_sub_f32 %[d0], %[n0], %[l0]\n\t"
+        "v_fma_f32 %[e1], -%[b10], %[d0], %[e1]\n\t"
+        "v_fma_f32 %[e2], -%[b20], %[d0], %[e2]\n\t"
+        "v_mul_f32 %[lim], %[fx], %[n0]\n\t"
+        "v_med3_f32 %[n1], %[e1], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d1], %[n1], %[l1]\n\t"
+        "v_fma_f32 %[e2], -%[b21], %[d1], %[e2]\n\t"
+        "v_fma_f32 %[e0], -%[b01], %[d1], %[e0]\n\t"
+        "v_mul_f32 %[lim], %[fy], %[n0]\n\t"
+        "v_med3_f32 %[n2], %[e2], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d2], %[n2], %[l2]\n\t"
+        "v_fma_f32 %[e0], -%[b02], %[d2], %[e0]\n\t"
+        "v_fma_f32 %[e1], -%[b12], %[d2], %[e1]\n\t"
+        "v_max3_f32 %[lim], |%[d0]|, |%[d1]|, |%[d2]|\n\t"
+        "v_cmp_lt_f32 vcc, %[bound], %[lim]\n\t"
+        "s_and_b64 vcc, vcc, %[on]\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cbranch_vccz 3f\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "v_max_f32 %[l0], 0, %[e0]\n\t"
+        "v_sub_f32 %[d0], %[l0], %[n0]\n\t"
         "v_fma_f32 %[e1], -%[b10], %[d0], %[e1]\n\t"
         "v_fma_f32 %[e2], -%[b20], %[d0], %[e2]\n\t"
         "v_mul_f32 %[lim], %[fx], %[l0]\n\t"
-        "v_med3_f32 %[t], %[e1], -%[lim], %[lim]\n\t"
-        "v_sub_f32 %[d1], %[t], %[l1]\n\t"
-        "v_mov_b32 %[l1], %[t]\n\t"
+        "v_med3_f32 %[l1], %[e1], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d1], %[l1], %[n1]\n\t"
         "v_fma_f32 %[e2], -%[b21], %[d1], %[e2]\n\t"
         "v_fma_f32 %[e0], -%[b01], %[d1], %[e0]\n\t"
         "v_mul_f32 %[lim], %[fy], %[l0]\n\t"
-        "v_med3_f32 %[t], %[e2], -%[lim], %[lim]\n\t"
-        "v_sub_f32 %[d2], %[t], %[l2]\n\t"
-        "v_mov_b32 %[l2], %[t]\n\t"
+        "v_med3_f32 %[l2], %[e2], -%[lim], %[lim]\n\t"
+        "v_sub_f32 %[d2], %[l2], %[n2]\n\t"
         "v_fma_f32 %[e0], -%[b02], %[d2], %[e0]\n\t"
         "v_fma_f32 %[e1], -%[b12], %[d2], %[e1]\n\t"
-        "v_max3_f32 %[t], |%[d0]|, |%[d1]|, |%[d2]|\n\t"
-        "v_cmp_lt_f32 vcc, %[bound], %[t]\n\t"
+        "v_max3_f32 %[lim], |%[d0]|, |%[d1]|, |%[d2]|\n\t"
+        "v_cmp_lt_f32 vcc, %[bound], %[lim]\n\t"
         "s_and_b64 vcc, vcc, %[on]\n\t"
         "s_sub_u32 %[cnt], %[cnt], 1\n\t"
         "s_cbranch_vccz 2f\n\t"
-        "s_cmp_lg_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 1b\n"
+        "s_cbranch_scc0 1b\n\t"
+        "s_branch 2f\n\t"
+        "3:\n\t"
+        "v_mov_b32 %[l0], %[n0]\n\t"
+        "v_mov_b32 %[l1], %[n1]\n\t"
+        "v_mov_b32 %[l2], %[n2]\n\t"
         "2:"
-        : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [cnt] "+s"(cnt), [t] "=&v"(t_),
+        : [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [cnt] "+s"(cnt), [n0] "=&v"(n0_), [n1] "=&v"(n1_), [n2] "=&v"(n2_),
           [lim] "=&v"(lim_), [d0] "=&v"(d0_), [d1] "=&v"(d1_), [d2] "=&v"(d2_)
         : [b10] "v"(B[ROWFORM ? 1 : 0][0]), [b20] "v"(B[ROWFORM ? 2 : 0][0]), [b01] "v"(B[0][ROWFORM ? 1 : 0]), [b21] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 1 : 0]),
           [b02] "v"(B[0][ROWFORM ? 2 : 0]), [b12] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 2 : 0]), [fx] "v"(fx[0]), [fy] "v"(fy[0]), [bound] "s"(Sc.res), [on] "s"(onm)
         : "vcc", "scc");
     lam[0][0] = l0; lam[0][1] = l1; lam[0][2] = l2;
 #ifdef PF_PHASE_TRACE
-    pf_sweeps = Sc.iters - cnt;
+    pf_sweeps = Sc.iters - 1 - cnt;
 #endif
   } else if (lone && ROWFORM && N == 2) {
     // TWO contacts on a lone lane (an edge impact: one solve in six, and the ones that run into the sweep cap): the same treatment, six
     // rows, 54 instructions a sweep for the 107 the compiler's loop took (447 clocks: profiles/r05/solver_trace.txt). Each row's five
     // coupling updates start with the NEXT row's, the one the dependent chain waits for.
-    float e_[6] = {u[0][0], u[0][1], u[0][2], u[N > 1 ? 1 : 0][0], u[N > 1 ? 1 : 0][1], u[N > 1 ? 1 : 0][2]}, l_[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d_[6], t_, lim_;
-    int cnt = Sc.iters;
+    // (round 6, second pass) The six rows' velocities as three aligned register pairs, every row's five coupling updates as three
+    // v_pk_fma_f32: two whole pairs, and the pair the row itself sits in with (-0) x 1.0 on its own half -- e + (-0) = e for every e,
+    // the zeros included, so the row passes through untouched. The step d of a row is the low half of a (d, 1.0) pair. A 32-bit
+    // instruction cannot name half of a 64-bit asm operand, hence FIXED registers for those ten (v232 .. v241: the allocator vacates
+    // them around this block, on the rare path). Two sweeps per trip as above. 42 instructions a sweep for round 6's first 63: the same
+    // operations on the same values (a packed fma is two fmas), bit-identical impulses. profiles/tools/r06/gen_solve.py writes the text.
+#define BB(s_, r_) B[ROWFORM ? (s_) : 0][ROWFORM ? (r_) : 0]
+    f2 P0 = f2{u[0][0], u[0][1]}, P1 = f2{u[0][2], u[N > 1 ? 1 : 0][0]}, P2 = f2{u[N > 1 ? 1 : 0][1], u[N > 1 ? 1 : 0][2]};
+    float l_[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, n_[6], t_, lim_;
+    int cnt = Sc.iters - 1;
     const unsigned long long onm = __ballot(any_on);
     asm volatile(
+        "v_mov_b32 v239, 1.0\n\t"
+        "v_mov_b32 v241, 1.0\n\t"
         "1:\n\t"
-        "v_max_f32 %[t], %[e0], %[e0]\n\t"
-        "v_max_f32 %[t], 0, %[t]\n\t"
-        "v_sub_f32 %[d0], %[t], %[l0]\n\t"
-        "v_mov_b32 %[l0], %[t]\n\t"
-        "v_fma_f32 %[e1], -%[b10], %[d0], %[e1]\n\t"
-        "v_fma_f32 %[e2], -%[b20], %[d0], %[e2]\n\t"
-        "v_fma_f32 %[e3], -%[b30], %[d0], %[e3]\n\t"
-        "v_fma_f32 %[e4], -%[b40], %[d0], %[e4]\n\t"
-        "v_fma_f32 %[e5], -%[b50], %[d0], %[e5]\n\t"
+        "v_max_f32 %[n0], 0, v232\n\t"
+        "v_sub_f32 v238, %[n0], %[l0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bh0], v[238:239], v[232:233] op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bw01], v[238:239], v[234:235] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bw02], v[238:239], v[236:237] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_mul_f32 %[lim], %[fx0], %[n0]\n\t"
+        "v_med3_f32 %[n1], v233, -%[lim], %[lim]\n\t"
+        "v_sub_f32 v240, %[n1], %[l1]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bw11], v[240:241], v[234:235] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bh1], v[240:241], v[232:233] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bw12], v[240:241], v[236:237] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_max_f32 %[t], |v238|, |v240|\n\t"
+        "v_mul_f32 %[lim], %[fy0], %[n0]\n\t"
+        "v_med3_f32 %[n2], v234, -%[lim], %[lim]\n\t"
+        "v_sub_f32 v238, %[n2], %[l2]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bh2], v[238:239], v[234:235] op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bw20], v[238:239], v[232:233] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bw22], v[238:239], v[236:237] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_max_f32 %[n3], 0, v235\n\t"
+        "v_sub_f32 v240, %[n3], %[l3]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bw32], v[240:241], v[236:237] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bw30], v[240:241], v[232:233] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bh3], v[240:241], v[234:235] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_max3_f32 %[t], %[t], |v238|, |v240|\n\t"
+        "v_mul_f32 %[lim], %[fx1], %[n3]\n\t"
+        "v_med3_f32 %[n4], v236, -%[lim], %[lim]\n\t"
+        "v_sub_f32 v238, %[n4], %[l4]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bh4], v[238:239], v[236:237] op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bw40], v[238:239], v[232:233] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bw41], v[238:239], v[234:235] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_mul_f32 %[lim], %[fy1], %[n3]\n\t"
+        "v_med3_f32 %[n5], v237, -%[lim], %[lim]\n\t"
+        "v_sub_f32 v240, %[n5], %[l5]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bw50], v[240:241], v[232:233] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bw51], v[240:241], v[234:235] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bh5], v[240:241], v[236:237] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_max3_f32 %[t], %[t], |v238|, |v240|\n\t"
+        "v_cmp_lt_f32 vcc, %[bound], %[t]\n\t"
+        "s_and_b64 vcc, vcc, %[on]\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cbranch_vccz 3f\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "v_max_f32 %[l0], 0, v232\n\t"
+        "v_sub_f32 v238, %[l0], %[n0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bh0], v[238:239], v[232:233] op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bw01], v[238:239], v[234:235] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bw02], v[238:239], v[236:237] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
         "v_mul_f32 %[lim], %[fx0], %[l0]\n\t"
-        "v_med3_f32 %[t], %[e1], -%[lim], %[lim]\n\t"
-        "v_sub_f32 %[d1], %[t], %[l1]\n\t"
-        "v_mov_b32 %[l1], %[t]\n\t"
-        "v_fma_f32 %[e2], -%[b21], %[d1], %[e2]\n\t"
-        "v_fma_f32 %[e3], -%[b31], %[d1], %[e3]\n\t"
-        "v_fma_f32 %[e4], -%[b41], %[d1], %[e4]\n\t"
-        "v_fma_f32 %[e5], -%[b51], %[d1], %[e5]\n\t"
-        "v_fma_f32 %[e0], -%[b01], %[d1], %[e0]\n\t"
+        "v_med3_f32 %[l1], v233, -%[lim], %[lim]\n\t"
+        "v_sub_f32 v240, %[l1], %[n1]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bw11], v[240:241], v[234:235] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bh1], v[240:241], v[232:233] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bw12], v[240:241], v[236:237] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_max_f32 %[t], |v238|, |v240|\n\t"
         "v_mul_f32 %[lim], %[fy0], %[l0]\n\t"
-        "v_med3_f32 %[t], %[e2], -%[lim], %[lim]\n\t"
-        "v_sub_f32 %[d2], %[t], %[l2]\n\t"
-        "v_mov_b32 %[l2], %[t]\n\t"
-        "v_fma_f32 %[e3], -%[b32], %[d2], %[e3]\n\t"
-        "v_fma_f32 %[e4], -%[b42], %[d2], %[e4]\n\t"
-        "v_fma_f32 %[e5], -%[b52], %[d2], %[e5]\n\t"
-        "v_fma_f32 %[e0], -%[b02], %[d2], %[e0]\n\t"
-        "v_fma_f32 %[e1], -%[b12], %[d2], %[e1]\n\t"
-        "v_max_f32 %[t], %[e3], %[e3]\n\t"
-        "v_max_f32 %[t], 0, %[t]\n\t"
-        "v_sub_f32 %[d3], %[t], %[l3]\n\t"
-        "v_mov_b32 %[l3], %[t]\n\t"
-        "v_fma_f32 %[e4], -%[b43], %[d3], %[e4]\n\t"
-        "v_fma_f32 %[e5], -%[b53], %[d3], %[e5]\n\t"
-        "v_fma_f32 %[e0], -%[b03], %[d3], %[e0]\n\t"
-        "v_fma_f32 %[e1], -%[b13], %[d3], %[e1]\n\t"
-        "v_fma_f32 %[e2], -%[b23], %[d3], %[e2]\n\t"
+        "v_med3_f32 %[l2], v234, -%[lim], %[lim]\n\t"
+        "v_sub_f32 v238, %[l2], %[n2]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bh2], v[238:239], v[234:235] op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bw20], v[238:239], v[232:233] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bw22], v[238:239], v[236:237] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_max_f32 %[l3], 0, v235\n\t"
+        "v_sub_f32 v240, %[l3], %[n3]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bw32], v[240:241], v[236:237] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bw30], v[240:241], v[232:233] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bh3], v[240:241], v[234:235] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_max3_f32 %[t], %[t], |v238|, |v240|\n\t"
         "v_mul_f32 %[lim], %[fx1], %[l3]\n\t"
-        "v_med3_f32 %[t], %[e4], -%[lim], %[lim]\n\t"
-        "v_sub_f32 %[d4], %[t], %[l4]\n\t"
-        "v_mov_b32 %[l4], %[t]\n\t"
-        "v_fma_f32 %[e5], -%[b54], %[d4], %[e5]\n\t"
-        "v_fma_f32 %[e0], -%[b04], %[d4], %[e0]\n\t"
-        "v_fma_f32 %[e1], -%[b14], %[d4], %[e1]\n\t"
-        "v_fma_f32 %[e2], -%[b24], %[d4], %[e2]\n\t"
-        "v_fma_f32 %[e3], -%[b34], %[d4], %[e3]\n\t"
+        "v_med3_f32 %[l4], v236, -%[lim], %[lim]\n\t"
+        "v_sub_f32 v238, %[l4], %[n4]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bh4], v[238:239], v[236:237] op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bw40], v[238:239], v[232:233] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bw41], v[238:239], v[234:235] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
         "v_mul_f32 %[lim], %[fy1], %[l3]\n\t"
-        "v_med3_f32 %[t], %[e5], -%[lim], %[lim]\n\t"
-        "v_sub_f32 %[d5], %[t], %[l5]\n\t"
-        "v_mov_b32 %[l5], %[t]\n\t"
-        "v_fma_f32 %[e0], -%[b05], %[d5], %[e0]\n\t"
-        "v_fma_f32 %[e1], -%[b15], %[d5], %[e1]\n\t"
-        "v_fma_f32 %[e2], -%[b25], %[d5], %[e2]\n\t"
-        "v_fma_f32 %[e3], -%[b35], %[d5], %[e3]\n\t"
-        "v_fma_f32 %[e4], -%[b45], %[d5], %[e4]\n\t"
-        "v_max3_f32 %[t], |%[d0]|, |%[d1]|, |%[d2]|\n\t"
-        "v_max3_f32 %[lim], |%[d3]|, |%[d4]|, |%[d5]|\n\t"
-        "v_max_f32 %[t], %[t], %[lim]\n\t"
+        "v_med3_f32 %[l5], v237, -%[lim], %[lim]\n\t"
+        "v_sub_f32 v240, %[l5], %[n5]\n\t"
+        "v_pk_fma_f32 v[232:233], %[bw50], v[240:241], v[232:233] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[234:235], %[bw51], v[240:241], v[234:235] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_pk_fma_f32 v[236:237], %[bh5], v[240:241], v[236:237] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+        "v_max3_f32 %[t], %[t], |v238|, |v240|\n\t"
         "v_cmp_lt_f32 vcc, %[bound], %[t]\n\t"
         "s_and_b64 vcc, vcc, %[on]\n\t"
         "s_sub_u32 %[cnt], %[cnt], 1\n\t"
         "s_cbranch_vccz 2f\n\t"
-        "s_cmp_lg_u32 %[cnt], 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
+        "s_cbranch_scc0 1b\n\t"
+        "s_branch 2f\n\t"
+        "3:\n\t"
+        "v_mov_b32 %[l0], %[n0]\n\t"
+        "v_mov_b32 %[l1], %[n1]\n\t"
+        "v_mov_b32 %[l2], %[n2]\n\t"
+        "v_mov_b32 %[l3], %[n3]\n\t"
+        "v_mov_b32 %[l4], %[n4]\n\t"
+        "v_mov_b32 %[l5], %[n5]\n\t"
         "2:"
-        : [e0] "+v"(e_[0]), [e1] "+v"(e_[1]), [e2] "+v"(e_[2]), [e3] "+v"(e_[3]), [e4] "+v"(e_[4]), [e5] "+v"(e_[5]), [l0] "+v"(l_[0]), [l1] "+v"(l_[1]), [l2] "+v"(l_[2]), [l3] "+v"(l_[3]), [l4] "+v"(l_[4]), [l5] "+v"(l_[5]), [cnt] "+s"(cnt), [t] "=&v"(t_), [lim] "=&v"(lim_), [d0] "=&v"(d_[0]), [d1] "=&v"(d_[1]), [d2] "=&v"(d_[2]), [d3] "=&v"(d_[3]), [d4] "=&v"(d_[4]), [d5] "=&v"(d_[5])
-        : [b10] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 0 : 0]), [b20] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 0 : 0]), [b30] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 0 : 0]), [b40] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 0 : 0]), [b50] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 0 : 0]), [b01] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 1 : 0]), [b21] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 1 : 0]), [b31] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 1 : 0]), [b41] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 1 : 0]), [b51] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 1 : 0]), [b02] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 2 : 0]), [b12] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 2 : 0]), [b32] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 2 : 0]), [b42] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 2 : 0]), [b52] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 2 : 0]), [b03] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 3 : 0]), [b13] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 3 : 0]), [b23] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 3 : 0]), [b43] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 3 : 0]), [b53] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 3 : 0]), [b04] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 4 : 0]), [b14] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 4 : 0]), [b24] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 4 : 0]), [b34] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 4 : 0]), [b54] "v"(B[ROWFORM ? 5 : 0][ROWFORM ? 4 : 0]), [b05] "v"(B[ROWFORM ? 0 : 0][ROWFORM ? 5 : 0]), [b15] "v"(B[ROWFORM ? 1 : 0][ROWFORM ? 5 : 0]), [b25] "v"(B[ROWFORM ? 2 : 0][ROWFORM ? 5 : 0]), [b35] "v"(B[ROWFORM ? 3 : 0][ROWFORM ? 5 : 0]), [b45] "v"(B[ROWFORM ? 4 : 0][ROWFORM ? 5 : 0]), [fx0] "v"(fx[0]), [fy0] "v"(fy[0]), [fx1] "v"(fx[N > 1 ? 1 : 0]), [fy1] "v"(fy[N > 1 ? 1 : 0]), [bound] "s"(Sc.res), [on] "s"(onm)
-        : "vcc", "scc");
+        : [p0] "+{v[232:233]}"(P0), [p1] "+{v[234:235]}"(P1), [p2] "+{v[236:237]}"(P2), [l0] "+v"(l_[0]), [l1] "+v"(l_[1]), [l2] "+v"(l_[2]), [l3] "+v"(l_[3]), [l4] "+v"(l_[4]), [l5] "+v"(l_[5]),
+          [n0] "=&v"(n_[0]), [n1] "=&v"(n_[1]), [n2] "=&v"(n_[2]), [n3] "=&v"(n_[3]), [n4] "=&v"(n_[4]), [n5] "=&v"(n_[5]), [cnt] "+s"(cnt), [t] "=&v"(t_), [lim] "=&v"(lim_)
+        : [bh0] "v"(f2{0.0f, BB(1, 0)}), [bw01] "v"(f2{BB(2, 0), BB(3, 0)}), [bw02] "v"(f2{BB(4, 0), BB(5, 0)}),
+          [bh1] "v"(f2{BB(0, 1), 0.0f}), [bw11] "v"(f2{BB(2, 1), BB(3, 1)}), [bw12] "v"(f2{BB(4, 1), BB(5, 1)}),
+          [bh2] "v"(f2{0.0f, BB(3, 2)}), [bw20] "v"(f2{BB(0, 2), BB(1, 2)}), [bw22] "v"(f2{BB(4, 2), BB(5, 2)}),
+          [bh3] "v"(f2{BB(2, 3), 0.0f}), [bw30] "v"(f2{BB(0, 3), BB(1, 3)}), [bw32] "v"(f2{BB(4, 3), BB(5, 3)}),
+          [bh4] "v"(f2{0.0f, BB(5, 4)}), [bw40] "v"(f2{BB(0, 4), BB(1, 4)}), [bw41] "v"(f2{BB(2, 4), BB(3, 4)}),
+          [bh5] "v"(f2{BB(4, 5), 0.0f}), [bw50] "v"(f2{BB(0, 5), BB(1, 5)}), [bw51] "v"(f2{BB(2, 5), BB(3, 5)}),
+          [fx0] "v"(fx[0]), [fy0] "v"(fy[0]), [fx1] "v"(fx[N > 1 ? 1 : 0]), [fy1] "v"(fy[N > 1 ? 1 : 0]), [bound] "s"(Sc.res), [on] "s"(onm)
+        : "vcc", "scc", "v238", "v239", "v240", "v241");
+#undef BB
 #pragma unroll
     for (int d = 0; d < 3; ++d) { lam[0][d] = l_[d]; lam[N > 1 ? 1 : 0][d] = l_[3 + d]; }
 #ifdef PF_PHASE_TRACE
-    pf_sweeps = Sc.iters - cnt;
+    pf_sweeps = Sc.iters - 1 - cnt;
 #endif
   } else if (lone) {
     for (int it = 0; it < Sc.iters; ++it) {
@@ -849,7 +918,7 @@ struct QuadHot {
   // and its PHI copies per tick, profiles/r02), and with random actions some lane of nearly every wave is near the floor.
   // K: the constants of the flight path (QuadK itself, in scalar registers -- or QuadKV, the same fields copied to vector
   // registers for the calm ticks); Kc: the constants of the rare floor code, always the kernel argument.
-  template <bool CR, bool SHARED = false, class KT = QuadK, bool INL = false>
+  template <bool CR, bool SHARED = false, class KT = QuadK, bool INL = false, bool COLD = true>
   PF_DEV void tick(const KT& K, const QuadK& Kc, float xi, const pf_params* Pfull) {
     const float s = fmaf(xi, K.m_noise, 1.0f);
     float k[4];
@@ -937,8 +1006,10 @@ struct QuadHot {
       }
       // (unlikely: a wave solves a floor contact in a few ticks of an episode. The hint is also what keeps the register allocator's
       //  spill burst around the out-of-line call INSIDE this cold block: without it the caller-saved registers were stored at the top of
-      //  the join block in front of it, ahead of its exec restore -- tools/isa_exec_check.py, 161 of round 5's 186 repaired sites)
-      if (__builtin_expect(__any(act), 0)) {
+      //  the join block in front of it, ahead of its exec restore -- tools/isa_exec_check.py, 161 of round 5's 186 repaired sites.
+      //  COLD = false: the Hover task's two-waves-per-SIMD instantiations, which never had such a site and lose 2-3 % at 524 288
+      //  lanes with the hint -- 75 spilled registers against 43, profiles/r06/ab_plain_build_same_box.txt)
+      if (COLD ? __builtin_expect(__any(act), 0) : (long)__any(act)) {
         // (INL: inline, in the instantiations sized for one wave per SIMD -- 512 registers: no call, so no stack, and a launch
         //  whose waves carry scratch memory dispatches 0.4 us slower; nothing pinned to callee-saved registers: the solve of this
         //  airframe in registers, quad_floor_solve. Otherwise out of line, the general solver: within the 256 registers of two
@@ -1964,8 +2035,8 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
         V.template tick_d<CR, WPS == 1>(SD, K, xi0, Pfull);
         V.template tick_d<CR, WPS == 1>(SD, K, xi1, Pfull);
       } else {
-        V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi0, Pfull);
-        V.template tick<CR, false, QuadK, WPS == 1>(K, K, xi1, Pfull);
+        V.template tick<CR, false, QuadK, WPS == 1, !(TASK == PF_TASK_HOVER && WPS == 2)>(K, K, xi0, Pfull);
+        V.template tick<CR, false, QuadK, WPS == 1, !(TASK == PF_TASK_HOVER && WPS == 2)>(K, K, xi1, Pfull);
       }
       // compute_state side effects + compute_term_trunc_reward
       if (TASK == PF_TASK_WAYPOINTS) {  // waypoint_handler.py:135-142; ||R^T d|| = ||d||

@@ -38,10 +38,15 @@ timeout 100 python $R/bench.py --env dogfight --steps 150 --warmup 20 --no-cpu-b
 PF_BENCH_SINGLE_DEVICE=1 PF_BENCH_BACKEND=gloo timeout 300 python $R/bench.py --gpus 2 --steps 200 --warmup 20 --no-cpu-baseline --rollout-steps 0 2>/dev/null | tail -1 > $O/bench_self_launched_2ranks_one_gpu.json
 # same-box A/B against round 5's library over the four BASELINE configurations
 [ -f $R/build/variants/r05.so ] && (cd $R && timeout 500 bash profiles/tools/r06/g_all.sh build/variants/r05.so pyflyt_amd/libpyflyt_amd.so > /dev/null 2>&1; cp gpurun_out/g_all.txt $O/ab_r05_vs_r06_same_box.txt)
+# ... and against this round's own first half (commit ef16607: the repaired build, before the plain build / the cascaded modes' fp64 state out of scratch / the packed sweeps)
+[ -f $R/build/variants/r06_head.so ] && (cd $R && timeout 500 bash profiles/tools/r06/g_all.sh build/variants/r06_head.so pyflyt_amd/libpyflyt_amd.so > /dev/null 2>&1; cp gpurun_out/g_all.txt $O/ab_r06_first_half_vs_final_same_box.txt)
+# the cascaded flight modes
+(cd $R && timeout 300 bash profiles/tools/r06/g_modes.sh > /dev/null 2>&1; cp gpurun_out/g_modes.txt $O/cascaded_modes.txt)
 # per-wave phase timelines and the in-register floor solve's statistics (the -DPF_PHASE_TRACE variant libraries)
 V=$R/build/variants
 [ -f $V/t_hover.so ] && TASK=hover PF_LIB_PATH=$V/t_hover.so timeout 100 python $R/profiles/tools/phase_trace.py 2>/dev/null > $O/phase_trace_hover65536.txt
 [ -f $V/t_wp.so ] && TASK=waypoints PF_LIB_PATH=$V/t_wp.so timeout 100 python $R/profiles/tools/phase_trace.py 2>/dev/null > $O/phase_trace_waypoints65536.txt
+[ -f $V/t_hover_modes.so ] && MODE=7 TASK=hover PF_LIB_PATH=$V/t_hover_modes.so timeout 100 python $R/profiles/tools/phase_trace.py 2>/dev/null > $O/phase_trace_mode7.txt
 [ -f $V/t_fw.so ] && VEH=fixedwing TASK=waypoints PF_LIB_PATH=$V/t_fw.so timeout 100 python $R/profiles/tools/phase_trace.py 2>/dev/null | grep -v "per tick and wave" > $O/phase_trace_fixedwing_waypoints65536.txt
 # (the tick's own split from the -DPF_FW_TICK_TRACE variant: its per-tick atomics inflate the wave's life tenfold, so only the RATIO of the two shares is kept)
 [ -f $V/t_fwtick.so ] && (echo "tick split (t_fwtick.so: -DPF_PHASE_TRACE -DPF_FW_TICK_TRACE; clocks inflated by the counters' own atomics -- the shares are what counts):"; VEH=fixedwing TASK=waypoints PF_LIB_PATH=$V/t_fwtick.so timeout 100 python $R/profiles/tools/phase_trace.py 2>/dev/null | grep "per tick and wave") >> $O/phase_trace_fixedwing_waypoints65536.txt

@@ -80,6 +80,21 @@ PF_DEV double atan2_d(const double y, const double x, double* cs = nullptr, doub
   phi = x < 0.0 ? 3.14159265358979323846 - phi : phi;
   return zero ? 0.0 : __builtin_copysign(phi, y);
 }
+// getEulerFromQuaternion (ZYX, gimbal-lock branch at |sarg| >= 0.99999) with cos / sin of the yaw; rd = 1 / |q|^2
+PF_DEV void quad_ctl_euler_d(const double q4[4], const double rd, QuadCtlIn& o) {
+  const double x = q4[0], y = q4[1], z = q4[2], w = q4[3];
+  const double sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
+  const double sarg = -2.0 * (x * z - w * y) * rd;
+  if (sarg <= -0.99999 || sarg >= 0.99999) {  // gimbal lock, rare: the library's functions
+    o.rpy[0] = 0.0; o.rpy[1] = sarg < 0.0 ? -0.5 * 3.14159265358979323846 : 0.5 * 3.14159265358979323846;
+    o.rpy[2] = sarg < 0.0 ? 2.0 * atan2(x, -y) : 2.0 * atan2(-x, y);
+    o.cyaw = cos(o.rpy[2]); o.syaw = sin(o.rpy[2]);
+  } else {
+    o.rpy[0] = atan2_d(2.0 * (y * z + w * x), squ - sqx - sqy + sqz);
+    o.rpy[1] = atan2_d(sarg, sqrt_pos_d((1.0 - sarg) * (1.0 + sarg)));  // asin(sarg), |sarg| < 0.99999
+    o.rpy[2] = atan2_d(2.0 * (x * y + w * z), squ + sqx - sqy - sqz, &o.cyaw, &o.syaw);
+  }
+}
 // (the double-precision core: the specialised kernel's cascaded-mode instantiations carry the rigid-body state itself in fp64 since
 //  round 6 and call this directly -- quadx_fast.hpp: QuadStateD)
 PF_DEV QuadCtlIn quad_ctl_inputs_d(const double q4[4], const double v3d[3], const double w3d[3], const double p3d[3]) {
@@ -94,18 +109,7 @@ PF_DEV QuadCtlIn quad_ctl_inputs_d(const double q4[4], const double v3d[3], cons
   const double v0 = v3d[0], v1 = v3d[1], v2 = v3d[2], w0 = w3d[0], w1 = w3d[1], w2 = w3d[2];
   o.vb[0] = R00 * v0 + R10 * v1 + R20 * v2; o.vb[1] = R01 * v0 + R11 * v1 + R21 * v2; o.vb[2] = R02 * v0 + R12 * v1 + R22 * v2;
   o.wb[0] = R00 * w0 + R10 * w1 + R20 * w2; o.wb[1] = R01 * w0 + R11 * w1 + R21 * w2; o.wb[2] = R02 * w0 + R12 * w1 + R22 * w2;
-  // getEulerFromQuaternion (ZYX, gimbal-lock branch at |sarg| >= 0.99999)
-  const double sqx = x * x, sqy = y * y, sqz = z * z, squ = w * w;
-  const double sarg = -2.0 * (x * z - w * y) * rd;
-  if (sarg <= -0.99999 || sarg >= 0.99999) {  // gimbal lock, rare: the library's functions
-    o.rpy[0] = 0.0; o.rpy[1] = sarg < 0.0 ? -0.5 * 3.14159265358979323846 : 0.5 * 3.14159265358979323846;
-    o.rpy[2] = sarg < 0.0 ? 2.0 * atan2(x, -y) : 2.0 * atan2(-x, y);
-    o.cyaw = cos(o.rpy[2]); o.syaw = sin(o.rpy[2]);
-  } else {
-    o.rpy[0] = atan2_d(2.0 * (y * z + w * x), squ - sqx - sqy + sqz);
-    o.rpy[1] = atan2_d(sarg, sqrt_pos_d((1.0 - sarg) * (1.0 + sarg)));  // asin(sarg), |sarg| < 0.99999
-    o.rpy[2] = atan2_d(2.0 * (x * y + w * z), squ + sqx - sqy - sqz, &o.cyaw, &o.syaw);
-  }
+  quad_ctl_euler_d(q4, rd, o);
   o.p[0] = p3d[0]; o.p[1] = p3d[1]; o.p[2] = p3d[2];
   return o;
 }

@@ -786,7 +786,15 @@ struct QuadStateD {
       vb[k] = R[k] * v[0] + R[3 + k] * v[1] + R[6 + k] * v[2];
     }
   }
-  PF_DEV QuadCtlIn ctl_inputs() const { return quad_ctl_inputs_d(q, v, w, p); }
+  // (the controller's inputs: wb / vb are what derive() left -- the same formula on the same q, v, w as quad_ctl_inputs_d's, which the
+  //  first build evaluated a second time, 60 fp64 instructions a control update --, the Euler angles from q)
+  PF_DEV QuadCtlIn ctl_inputs() const {
+    QuadCtlIn o;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.wb[k] = wb[k]; o.vb[k] = vb[k]; o.p[k] = p[k]; }
+    quad_ctl_euler_d(q, rcp_d(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), o);
+    return o;
+  }
   // what survives a store / load through the state groups: the float32 rounding + the float32 rounding of the remainder (48 of a
   // double's 53 bits). pf_rollout passes its resident copy through this after every env step, so that it equals k launches bit for bit.
   PF_DEV static double hilo(const double x) { const float h = (float)x; return (double)h + (double)(float)(x - (double)h); }

@@ -100,7 +100,7 @@ ENVS = [
 # 1.7e-3), env_hover_mode7 2.2e-5, modes 1-6 8e-7 ... 4e-6 -- all inside north_star's 1e-4 over the episode, no bound of their own.
 # The generic kernel keeps its float32 state (fp64 controller from float32 memories, round 5): 3.9e-4 / 1.7e-4 on the two mode-7
 # fixtures, with bounds of its own and a LOWER bound a factor of ten below each, so that neither can drift unnoticed.
-ENV_RTOL = {("env_quadx_waypoints_mode7", "generic"): 2e-3, ("env_hover_mode7", "generic"): 1e-3}
+ENV_RTOL = {("env_quadx_waypoints_mode7", "generic"): 1e-3, ("env_hover_mode7", "generic"): 1e-3}
 
 
 @pytest.mark.parametrize("kernel", ["specialised", "generic"])

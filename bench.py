@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 SHADER_CLOCK_GHZ = 2.4   # MI355X peak engine clock (same guide); the phase traces read 2.2-2.25 GHz under this load
+LAUNCH_FLOOR_US = 1.42    # a graph launch of 1 024 one-wave workgroups beyond its waves' life (profiles/r05/ubench_dispatch_ramp.txt)
 # algorithmic HBM bytes per env step per lane:
 #   reads  128 B = 7 state float4 groups (112) + action float4 (16)
 #   writes 202 B = 7 state groups (112) + obs 21 f32 (84) + reward (4) + terminated (1) + truncated (1)
@@ -273,6 +274,14 @@ def roofline_block(env, n, per_launch_s, kernel):
                         "clocks_per_inst": ent.get("clocks_per_inst"), "clock_ghz": clk, "min_us": min_us, "frac": min_us / (per_launch_s * 1e6),
                         "note": "one wave per SIMD: a wave64 VALU instruction holds its SIMD for 4 clocks; clocks_per_inst = measured wave "
                                 "cycles / (VALU + SALU) of the same collection"}
+        if ent.get("issue_slots_per_wave"):
+            # the tighter floor of a LONE wave (profiles/r06/lone_wave_issue.txt, measured on MI355X): it issues ONE instruction of any
+            # kind -- vector, scalar, LDS, memory, wait, branch -- per 4 clocks (5 in a run of 8-byte encodings: 1.6 B of code per clock),
+            # dependent or not, nothing co-issues, a transcendental takes two slots; and a launch of 1 024 one-wave workgroups costs
+            # 1.42 us beyond its slowest wave's life (profiles/r05/ubench_dispatch_ramp.txt)
+            slots_us = ent["issue_slots_per_wave"] * 4.0 / (clk * 1e3)
+            out["issue"]["lone_wave"] = {"issue_slots_per_wave": ent["issue_slots_per_wave"], "issue_us": slots_us, "launch_floor_us": LAUNCH_FLOOR_US,
+                                         "min_us": slots_us + LAUNCH_FLOOR_US, "frac": (slots_us + LAUNCH_FLOOR_US) / (per_launch_s * 1e6)}
     return out
 
 

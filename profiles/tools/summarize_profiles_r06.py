@@ -60,6 +60,9 @@ for env, (v, t) in {"hover": ("quadx", "hover"), "quadx_waypoints": ("quadx", "w
     insts = per_wave.get("INSTS_VALU", 0.0) + per_wave.get("INSTS_SALU", 0.0)
     latest[env] = {"batch": 65536, "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "valu_per_wave": per_wave.get("INSTS_VALU"),
                    "salu_per_wave": per_wave.get("INSTS_SALU"),
+                   # (quad-cycles in which the wave issued anything: VALU + SALU + LDS + VMEM + SMEM + branches / waits, a transcendental
+                   #  counted twice -- what a LONE wave pays four clocks each for, profiles/r06/lone_wave_issue.txt)
+                   "issue_slots_per_wave": per_wave.get("ACTIVE_INST_ANY"),
                    # (SQ_WAVE_CYCLES under counter collection is not the product's wave life: 46 k clocks per Hover wave in this
                    #  collection against 16 k by the phase trace -- the counters' own run time; not replayed)
                    "clocks_per_inst": None}

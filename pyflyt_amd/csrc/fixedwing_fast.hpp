@@ -487,9 +487,11 @@ struct FwHot {
     return o;
   }
   // Both surface pairs at once: surface_pair statement by statement on the aileron pair (k = 0) and on the (h-tail, main wing) pair
-  // (k = 1) alternately. The two evaluations are independent, so every instruction has an independent neighbour: a lone wave per
-  // SIMD issues a DEPENDENT instruction every ~7.5 clocks and an independent one every ~5.5 (profiles/r05/icache_cold.txt), and the
-  // packed-result / compare-select wait states of the one-pair version are filled by the other pair instead of by hand. Per element
+  // (k = 1) alternately. The two evaluations are independent, so every instruction has an independent neighbour: the
+  // packed-result / compare-select wait states of the one-pair version are filled by the other pair instead of by hand or by s_nop
+  // (that is the whole gain: a lone wave issues one instruction per 4-5 clocks dependent or not, profiles/r06/lone_wave_issue.txt --
+  // round 5's "7.5 clocks per dependent instruction" was an fma plus the s_nop the compiler puts between inline-asm statements; the two
+  // pairs one after the other on the same table are 0.63 us per step slower, profiles/r06/ab_fixedwing_x1_vs_x2_same_box.txt). Per element
   // the same operations in the same order as surface_pair: bit-identical results. Needs both pairs' constants at once (64 values):
   // the one-wave-per-SIMD instantiation holds them in vector registers (FwTableV).
 #define PF_X2(...) { constexpr int k = 0; __VA_ARGS__ } { constexpr int k = 1; __VA_ARGS__ }

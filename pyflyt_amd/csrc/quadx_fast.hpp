@@ -264,7 +264,8 @@ typedef QuadCascT<float> QuadCasc;
 // wave prefix sum, a count pass, sentinel records) unnecessary: with the manifold reduced to the incident face there are at most
 // four contact points. In the env tasks a solve is a LONE lane on a lone wave and the launch waits for it (1.1 calls per 65 536-lane
 // Waypoints launch; 19 k clocks each through the general solver: such a launch took twice as long as its other 1023 waves), and a
-// lone wave issues a DEPENDENT instruction every ~6.5 clocks: what counts is the length of the dependent chain per row.
+// lone wave issues ONE instruction of any kind per 4-5 clocks, dependent or not (profiles/r06/lone_wave_issue.txt; round 5's
+// "~6.5 clocks per dependent instruction" was the instruction plus an s_nop): what counts is the NUMBER of instructions per row.
 //   * rows r = (slot, direction); directions normal (+z), +x, +y. With the twist as (v, w~ = sqrt(I) w_body) and
 //     J~_r = sqrt(I^-1) (a_body x e_r,body): row velocity u_r = v . e_r + w~ . J~_r, and the rows couple through
 //     A_rs = J~_r . J~_s + [e_r = e_s] / m (the Delassus matrix; A_rr = the inverse effective mass);
@@ -1612,8 +1613,9 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
       // 20 ticks are TWO dependency chains -- throttle (3 instructions per tick) and climb rate (3-4 per tick):
       //   vz' = clamp(vz + dt (F/m + g)) with F/m + g = 4 fmax/m t|t| + g - drag/m vz|vz|
       //       = clamp(fma(-dt drag/m, vz|vz|, vz + e)),  e = fma(4 dt fmax/m, t|t|, dt g).
-      // A lone wave issues a dependent instruction every ~6.5 clocks and an independent one every 4: the chains are interleaved
-      // statement by statement (the build runs with the machine scheduler off: statement order is the schedule), the throttle
+      // The chains are interleaved statement by statement (the build runs with the machine scheduler off: statement order is the
+      // schedule; a lone wave pays per INSTRUCTION, 4-5 clocks each whether dependent or not -- profiles/r06/lone_wave_issue.txt --, so
+      // what the interleaving buys is the wait states behind a compare / a packed result filled with work instead of s_nop), the throttle
       // chain running one chunk of four ticks ahead of the climb-rate chain. (The few lanes of a wave that reset are what the
       // whole wave waits for: the serial 10-instructions-per-tick version was 0.85 us of every env step.)
       const float A4 = 4.0f * (K.fmaxM * K.dt), G = K.gravity_z * K.dt, Dd = K.dragM[2] * K.dt;

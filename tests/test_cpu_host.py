@@ -162,6 +162,13 @@ def test_bench_replays_counters_only_for_the_kernels_they_were_collected_on(tmp_
     r = bench.roofline_block("hover", 65536, 10.5e-6, "k")
     assert r["traffic"] == 22e6 and abs(r["frac"] - 330 * 65536 / 10.5e-6 / 1e9 / 8000.0) < 1e-12
     assert abs(r["issue"]["min_us"] - 2300.0 * 4 / 2400.0) < 1e-9 and abs(r["issue"]["frac"] - r["issue"]["min_us"] / 10.5) < 1e-9
+    assert "lone_wave" not in r["issue"]  # (a collection without the issue-slot count: no lone-wave floor is invented)
+    rec["envs"]["hover"]["issue_slots_per_wave"] = 2600.0
+    (prof / "pmc_latest.json").write_text(json.dumps(rec))
+    lw = bench.roofline_block("hover", 65536, 10.5e-6, "k")["issue"]["lone_wave"]
+    # every instruction of a lone wave takes four clocks (profiles/r06/lone_wave_issue.txt) + the launch floor of 1 024 one-wave workgroups
+    assert abs(lw["issue_us"] - 2600.0 * 4 / 2400.0) < 1e-9 and abs(lw["min_us"] - (lw["issue_us"] + bench.LAUNCH_FLOOR_US)) < 1e-12
+    assert abs(lw["frac"] - lw["min_us"] / 10.5) < 1e-9 and lw["min_us"] < 10.5
     assert bench.pmc_record("hover", 4096)[0] is None and "cover" in bench.pmc_record("quadx_waypoints", 65536)[1]
     rec["source_hash"] = "0" * 16
     (prof / "pmc_latest.json").write_text(json.dumps(rec))

@@ -28,7 +28,7 @@ for head in ("static void launch_fast(pf_ctx* ctx", "static void launch_rollout(
     src = stub(src, head, "\n}\n")
 src = re.sub(r"(static void launch_env_t\([^{]*\{)(.*?)(\n\}\nextern \"C\")", r"\1\n  (void)ctx; (void)b; (void)op; (void)mask; (void)s; (void)roll_steps; (void)step0;\3", src, flags=re.S)
 src = src.replace("#define PF_DF(AA, VV) hipLaunchKernelGGL(", "#define PF_DF(AA, VV) if (false) hipLaunchKernelGGL(")
-tmp = os.path.join(os.path.dirname(G.HIP_SRC), "_fw_only_tmp.hip")
+tmp = os.path.join(os.path.dirname(G.HIP_SRC), f"_fw_only_tmp_{os.getpid()}.hip")  # (one per process: variants build side by side)
 open(tmp, "w").write(src)
 try:
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *G.HIPCC_FLAGS, *extra, "-shared", "-fPIC", tmp, "-o", out]

@@ -35,7 +35,7 @@ for head in ("static void launch_fast_fw(pf_ctx* ctx", "static void launch_rollo
     j = src.index("{", src.index(")", i)) + 1
     k = src.index("\n}\n", j)
     src = src[:j] + "\n  (void)ctx; (void)b; (void)s;\n" + src[k:]
-tmp = os.path.join(os.path.dirname(G.HIP_SRC), "_quad_only_tmp.hip")
+tmp = os.path.join(os.path.dirname(G.HIP_SRC), f"_quad_only_tmp_{os.getpid()}.hip")  # (one per process: variants build side by side)
 open(tmp, "w").write(src)
 try:
     save = "--save-asm" in extra

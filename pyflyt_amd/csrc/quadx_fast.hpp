@@ -927,8 +927,12 @@ struct QuadHot {
   // and its PHI copies per tick, profiles/r02), and with random actions some lane of nearly every wave is near the floor.
   // K: the constants of the flight path (QuadK itself, in scalar registers -- or QuadKV, the same fields copied to vector
   // registers for the calm ticks); Kc: the constants of the rare floor code, always the kernel argument.
-  template <bool CR, bool SHARED = false, class KT = QuadK, bool INL = false, bool COLD = true>
+  // NOFLOOR: the ticks of a calm wave (quadx_m0_env_kernel: no lane can come within a bounding radius of the floor during this env
+  // step, and none holds a contact point): `near` is false in every lane and contact_now stays false, so the detection, the gate's
+  // select and its three multiplications by 1.0 are left out -- x * 1.0f is x: the same bits, a dozen issue slots a tick fewer.
+  template <bool CR, bool SHARED = false, class KT = QuadK, bool INL = false, bool COLD = true, bool NOFLOOR = false>
   PF_DEV void tick(const KT& K, const QuadK& Kc, float xi, const pf_params* Pfull) {
+    static_assert(!NOFLOOR || (!CR && !SHARED), "NOFLOOR is the calm tick: no contact response, no shared world");
     const float s = fmaf(xi, K.m_noise, 1.0f);
     float k[4];
     {  // motors.py:110-195, t = fma(a, pwm - thr, thr) * noise; motors (0, 1) and (2, 3) as packed pairs
@@ -944,9 +948,15 @@ struct QuadHot {
     v3 wdb{fmaf(K.ryfI[0], k[0], fmaf(K.ryfI[1], k[1], fmaf(K.ryfI[2], k[2], K.ryfI[3] * k[3]))),
            fmaf(K.rxfI[0], k[0], fmaf(K.rxfI[1], k[1], fmaf(K.rxfI[2], k[2], K.rxfI[3] * k[3]))),
            K.tmaxI * ((k[2] + k[3]) - (k[0] + k[1]))};
+    if (NOFLOOR) {
+      wdb.x = fmaf(-K.pqI[0], wb.x * __builtin_fabsf(wb.x), wdb.x);
+      wdb.y = fmaf(-K.pqI[1], wb.y * __builtin_fabsf(wb.y), wdb.y);
+      wdb.z = fmaf(-K.pqI[2], wb.z * __builtin_fabsf(wb.z), wdb.z);
+    } else {
     wdb.x = fmaf(-K.pqI[0], pqf * (wb.x * __builtin_fabsf(wb.x)), wdb.x);
     wdb.y = fmaf(-K.pqI[1], pqf * (wb.y * __builtin_fabsf(wb.y)), wdb.y);
     wdb.z = fmaf(-K.pqI[2], pqf * (wb.z * __builtin_fabsf(wb.z)), wdb.z);
+    }
     wdb.x = fmaf(-K.gyI[0], wb.y * wb.z, wdb.x);
     wdb.y = fmaf(-K.gyI[1], wb.z * wb.x, wdb.y);
     wdb.z = fmaf(-K.gyI[2], wb.x * wb.y, wdb.z);
@@ -958,11 +968,11 @@ struct QuadHot {
     // "penetration >= 0" IS low <= 0 (the slab's top-face normal is the only axis that can separate a box from what is
     // locally a half-space; the direct form also avoids the cancellation of (p.z + 5) - (5 + ext) in fp32). The out-of-line
     // 15-axis test runs only within one bounding radius of the rim.
-    bool near = ((p.z - K.bound_radius) <= 0.0f) && ((p.z + K.bound_radius) >= -2.0f * K.plane_z);  // (not once it has fallen through, contact_response off)
+    bool near = !NOFLOOR && ((p.z - K.bound_radius) <= 0.0f) && ((p.z + K.bound_radius) >= -2.0f * K.plane_z);  // (not once it has fallen through, contact_response off)
     const bool persisted = contact_now;  // contact points left by the previous tick persist up to the breaking distance
     contact_now = false;
     float low = INFINITY;
-    if (__any(near)) {
+    if (!NOFLOOR && __any(near)) {
       if (near) {
         const float hx = Kc.box_h[0], hy = Kc.box_h[1], hz = Kc.box_h[2];
         const float pxy = Kc.plane_xy, pz = K.plane_z;
@@ -1040,7 +1050,7 @@ struct QuadHot {
     else p = v3{fmaf(K.dt, wvx.y, p.x), fmaf(K.dt, wvy.y, p.y), CR ? fmaf(K.dt, wvz.y, p.z) + lift : fmaf(K.dt, wvz.y, p.z)};
     q = quat_integrate(q, w(), K.half_dt);
     derive();
-    contact_step |= contact_now;
+    if (!NOFLOOR) contact_step |= contact_now;
   }
   // this struct's float32 members <- the rounding of the fp64 state (and derive() on them)
   PF_DEV void view_of(const QuadStateD& D) {
@@ -1992,6 +2002,11 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
   // dissipates); the body sinks by at most |vz0| T + A T (T + dt) / 2 (semi-implicit Euler, the velocity clamp only shrinks).
   // (instantiated where the env benchmarks live -- flight mode 0, noise drawn on device or off; in the cascaded-mode and
   //  injected-noise instantiations the second copy of the ticks cost registers they do not have: stack spills)
+  // NF: this instantiation's calm ticks without the floor detection and the rotational-drag gate (tick<.., NOFLOOR>, see there)
+  // (the one-wave-per-SIMD instantiations only: with two waves' 256 registers the Hover rollout without the detection came out of the
+  //  compiler with 31 vector copies in front of an exec restore -- tools/isa_exec_check.py stopped the build; at 524 288 lanes the one-step
+  //  launch had gained 0.7 %)
+  constexpr bool NF = WPS == 1 && (TASK == PF_TASK_HOVER || (TASK == PF_TASK_WAYPOINTS && ROLLOUT));
   bool calm = false;
   // the same bound over any horizon T (TT = T (T + dt) / 2): how far a lane can sink within it
   auto sink_within = [&](const float T, const float TT) {
@@ -2001,7 +2016,8 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     return fmaf(__builtin_fabsf(V.wvz.y), T, fmaf(K.calm_c, u * u, a_nd) * TT);
   };
   if (CALM && K.calm_on) {
-    calm = __all(!go || (V.p.z - fmaf(sink_within(K.calm_T, K.calm_TT), 1.01f, 1e-3f) > K.bound_radius));  // (wave-uniform; NaN compares false: not calm)
+    // (... and holds no contact point: the calm ticks leave the rotational-drag gate out as well -- tick<.., NOFLOOR>)
+    calm = __all(!go || ((!NF || !V.contact_now) && V.p.z - fmaf(sink_within(K.calm_T, K.calm_TT), 1.01f, 1e-3f) > K.bound_radius));  // (wave-uniform; NaN compares false: not calm)
 #ifdef PF_PHASE_TRACE
     if (!calm && tid == 0) trace_add(&g_calm_trace[0], 1ull);  // waves that keep the call site this step (rare: no contention)
 #endif
@@ -2012,7 +2028,7 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
     // over the two ticks ahead (a lane sinks a few millimetres in them) -- evaluated in those waves only
     bool calm_s = calm;
     if (CALM && K.calm_on && !calm) {
-      calm_s = __all(!go || (V.p.z - fmaf(sink_within(K.calm_T2, K.calm_TT2), 1.01f, 1e-3f) > K.bound_radius));
+      calm_s = __all(!go || ((!NF || !V.contact_now) && V.p.z - fmaf(sink_within(K.calm_T2, K.calm_TT2), 1.01f, 1e-3f) > K.bound_radius));
 #ifdef PF_PHASE_TRACE
       if (!calm_s && tid == 0) trace_add(&g_calm_trace[1], 1ull);  // Aviary steps that keep the call site
 #endif
@@ -2034,8 +2050,11 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
         V.template tick<CR, true>(K, K, xi1, Pfull);
         V.peer_contact = false;
       } else if (CALM && __builtin_expect(calm_s, 1)) {
-        V.template tick<false, false, QuadKV>(KV, K, xi0, Pfull);
-        V.template tick<false, false, QuadKV>(KV, K, xi1, Pfull);
+        // (NOFLOOR where it measured faster, same box, bit-identical over 400 steps x 65 536 lanes: Hover 9.60 -> 9.25 us per step, 7.71 ->
+        //  7.26 at 4 096 lanes, pf_rollout 5.80 -> 5.35; QuadX-Waypoints' pf_rollout 7.50 -> 7.02 -- but its one-step launch 15.72 -> 16.19:
+        //  without the detection its allocation spills 169 scalar registers for 145; profiles/r06/ab_calm_tick_nofloor_same_box.txt)
+        V.template tick<false, false, QuadKV, false, true, NF>(KV, K, xi0, Pfull);
+        V.template tick<false, false, QuadKV, false, true, NF>(KV, K, xi1, Pfull);
       } else if (CALM && WPS == 1) {
         // (not calm: the same ticks with the floor code in them. Their flight-path constants from the vector registers as well --
         //  the floor code's own constants stay scalar, Kc)

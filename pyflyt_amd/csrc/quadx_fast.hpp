@@ -2006,7 +2006,9 @@ __global__ void __launch_bounds__(64 * kQuadWPB, SHARED ? 1 : WPS) quadx_m0_env_
   // (the one-wave-per-SIMD instantiations only: with two waves' 256 registers the Hover rollout without the detection came out of the
   //  compiler with 31 vector copies in front of an exec restore -- tools/isa_exec_check.py stopped the build; at 524 288 lanes the one-step
   //  launch had gained 0.7 %)
-  constexpr bool NF = WPS == 1 && (TASK == PF_TASK_HOVER || (TASK == PF_TASK_WAYPOINTS && ROLLOUT));
+  // (the PettingZoo task with independent lanes as well: its facade's env.step() 10.93 -> 10.32 us captured, 10.68 -> 9.99 eager -- same box,
+  //  profiles/r06/ab_calm_tick_nofloor_same_box.txt)
+  constexpr bool NF = WPS == 1 && (TASK == PF_TASK_HOVER || TASK == PF_TASK_MA_HOVER || (TASK == PF_TASK_WAYPOINTS && ROLLOUT));
   bool calm = false;
   // the same bound over any horizon T (TT = T (T + dt) / 2): how far a lane can sink within it
   auto sink_within = [&](const float T, const float TT) {

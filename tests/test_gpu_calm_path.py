@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("lean", [True, False])
-@pytest.mark.parametrize("task,mode", [("hover", 0), ("waypoints", 0), ("hover", 6), ("hover", 7)])
+@pytest.mark.parametrize("task,mode", [("hover", 0), ("waypoints", 0), ("ma_hover", 0), ("hover", 6), ("hover", 7)])
 def test_calm_path_is_bit_identical(monkeypatch, task, mode, lean):
     from pyflyt_amd import _lib as L
     from pyflyt_amd import build_params
@@ -28,8 +28,13 @@ def test_calm_path_is_bit_identical(monkeypatch, task, mode, lean):
                 monkeypatch.delenv(var, raising=False)
             else:
                 monkeypatch.setenv(var, "1")
-        eng = BatchEngine(build_params("quadx", task, noise="philox", autoreset="next_step", seed=11, **kw), n, device="cuda:0")
+        # (the PettingZoo task has no auto-reset: its crashed drones stay on the floor, their waves leave the calm path and come back)
+        eng = BatchEngine(build_params("quadx", task, noise="philox", autoreset="off" if task == "ma_hover" else "next_step", seed=11, **kw), n, device="cuda:0")
         assert eng.lib.pf_ctx_is_specialised(eng._ctx) != 0
+        if task == "ma_hover":  # the agents' spawn poses live in the state's side block (pz_envs/ma_quadx_hover.py writes them; bench.py: make_engine)
+            side = torch.zeros(n, 12, device="cuda:0")
+            side[:, 2], side[:, 6] = 1.0, 1.0  # (0, 0, 1), level: quaternion (0, 0, 0, 1)
+            eng.state[12:15] = side.view(n, 3, 4).permute(1, 0, 2)
         return eng
 
     a, b, c = make(True, lean), make(False, lean), make(False, not lean)
@@ -51,6 +56,9 @@ def test_calm_path_is_bit_identical(monkeypatch, task, mode, lean):
             assert torch.equal(x, y), (task, mode, k)
         assert torch.equal(a.state, b.state), (task, mode, k)
         hit = (a.flags() & L.F_INFO_COLLISION) != 0
+        if task == "ma_hover":  # (no reset: after its first floor contact a lane's state differs between the two instantiations' solves for good --
+            collided += int(hit.sum())  # the calm path against no calm path, above, is this task's whole statement)
+            continue
         assert torch.equal(hit, (c.flags() & L.F_INFO_COLLISION) != 0)
         for x, y in zip(ra[2:], rc[2:]):   # terminated, truncated: identical
             assert torch.equal(x, y), (task, mode, k)
@@ -60,7 +68,7 @@ def test_calm_path_is_bit_identical(monkeypatch, task, mode, lean):
             worst = max(worst, float((ra[0][hit] - rc[0][hit]).abs().max()), float((ra[1][hit] - rc[1][hit]).abs().max()))
         collided += int(hit.sum())
     assert collided > 20, collided  # (the floor was in play)
-    assert worst < 5e-3, worst      # the two instantiations' contact solves agree to the impact tolerance in that terminal observation
+    assert task == "ma_hover" or worst < 5e-3, worst      # the two instantiations' contact solves agree to the impact tolerance in that terminal observation
 
 
 def test_fixedwing_instantiations_are_bit_identical(monkeypatch):
